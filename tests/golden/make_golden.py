@@ -1,0 +1,172 @@
+#!/usr/bin/env python3 -B
+"""Mint golden vectors for the truncated-EM hot path from the REFERENCE itself.
+
+Runs only in the build container: imports ml-uol/prosper from /root/reference through the
+single-rank mpi4py / tables shims in ./_shims and the NumPy-2 alias patch (SURVEY appendix
+A), feeds it seeded inputs and stores inputs + outputs as small .npz files next to this
+script.  The fixtures (data) are committed; the reference (code) is not and never travels.
+
+    python -B tests/golden/make_golden.py            # regenerates every *.npz here
+
+Fixtures (all float64, bit-for-bit what the reference returned):
+  bsc_step_<case>.npz   one select_Hprimes -> E_step -> M_step of BSC_ET on seeded data,
+                        incl. L / N / N_use captured from the reference's dlog
+  bsc_traj_c1.npz       BASELINE config 1: bars data D=25 H=10 H'=5 gamma=3 N=2000,
+                        20 EM.run steps, parameters after every step
+  bsc_init_c1.npz       generate_data + standard_init for fixed seeds (RNG stream order)
+  anneal_tracks.npz     LinearAnnealing values per step for the bars-learning schedule
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(1, "/root/reference")
+
+import numpy as np
+
+for _n, _t in (("int", int), ("bool", bool), ("str", str), ("object", object), ("float", float)):
+    if _n not in np.__dict__:
+        setattr(np, _n, _t)
+
+from prosper.utils.datalog import dlog, DataHandler          # noqa: E402
+from prosper.em import EM                                    # noqa: E402
+from prosper.em.annealing import LinearAnnealing             # noqa: E402
+from prosper.em.camodels.bsc_et import BSC_ET                # noqa: E402
+from prosper.utils.barstest import generate_bars_dict        # noqa: E402
+
+
+class Capture(DataHandler):
+    rows = {}
+
+    def append(self, tblname, value):
+        Capture.rows.setdefault(tblname, []).append(np.array(value, copy=True))
+
+
+dlog.set_handler(("L", "N", "N_use"), Capture)
+
+
+class FixedAnneal(dict):
+    """One annealing position; unknown keys -> 0.0 like LinearAnnealing.__getitem__."""
+    crit_params = []
+
+    def __missing__(self, k):
+        return 0.0
+
+
+def bsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior, bars=False,
+                  mu=False, to_learn=("W", "pi", "sigma"), sigma_gt=1.0, amp=1.0):
+    rng = np.random.RandomState(seed)
+    if bars:
+        W_gt = 10 * generate_bars_dict(H)
+        pi_gt, sigma_gt = 2. / H, 2.0
+    else:
+        W_gt = amp * rng.normal(size=(D, H))
+        pi_gt = min(0.45, 2.0 / H)
+    model = BSC_ET(D, H, Hp, gamma, to_learn=list(to_learn))
+    s = rng.random_sample((N, H)) < pi_gt
+    y = s.astype(float) @ W_gt.T + rng.normal(scale=sigma_gt, size=(N, D))
+    mu_vec = rng.normal(scale=0.3, size=D) if mu else None
+    if mu:
+        y = y + mu_vec
+    params = {"W": W_gt + 0.3 * amp * rng.normal(size=(D, H)), "pi": pi_gt * 1.3, "sigma": sigma_gt * 1.2}
+    if mu:
+        params["mu"] = mu_vec + 0.05 * rng.normal(size=D)
+    anneal = FixedAnneal(T=T, Ncut_factor=Ncut, anneal_prior=anneal_prior)
+    inp = {k: np.array(v, copy=True) for k, v in params.items()}
+    data = {"y": y.copy()}
+    Capture.rows.clear()
+    data = model.select_Hprimes(params, data)
+    ss = model.E_step(anneal, params, data)
+    new = model.M_step(anneal, params, ss, data)
+    assert np.isfinite(new["W"]).all() and np.isfinite(Capture.rows["L"][0]), name
+    out = dict(D=D, H=H, Hprime=Hp, gamma=gamma, T=T, Ncut_factor=Ncut, anneal_prior=bool(anneal_prior),
+               to_learn=np.array(list(to_learn)), y=y, W=inp["W"], pi=inp["pi"], sigma=inp["sigma"],
+               mu=inp.get("mu", np.zeros(D)), has_mu=bool(mu),
+               candidates=data["candidates"].astype(np.int64), logpj=ss["logpj"],
+               W_new=new["W"], pi_new=new["pi"], sigma_new=new["sigma"], mu_new=new["mu"],
+               L=Capture.rows["L"][0], N=Capture.rows["N"][0], N_use=Capture.rows["N_use"][0],
+               state_matrix=model.state_matrix, state_abs=model.state_abs)
+    np.savez_compressed(os.path.join(HERE, "bsc_step_%s.npz" % name), **out)
+    print("bsc_step_%s: N=%d K=%d L=%.6f N_use=%d" % (name, N, ss["logpj"].shape[1], out["L"], out["N_use"]))
+
+
+def bsc_trajectory():
+    D, H, Hp, gamma, N, steps = 25, 10, 5, 3, 2000, 20
+    np.random.seed(7)
+    model = BSC_ET(D, H, Hp, gamma)
+    params_gt = {"W": 10 * generate_bars_dict(H), "pi": 2. / H, "sigma": 1.0}
+    data = model.generate_data(params_gt, N)
+    np.random.seed(11)
+    init = model.standard_init(data)
+    anneal = LinearAnnealing(steps)
+    anneal["T"] = [(0, 2.), (.7, 1.)]
+    anneal["Ncut_factor"] = [(0, 0.), (2. / 3, 1.)]
+    anneal["anneal_prior"] = False
+    Capture.rows.clear()
+    em = EM(model=model, anneal=anneal)
+    em.data = {"y": data["y"].copy()}
+    em.lparams = {k: np.array(v, copy=True) for k, v in init.items()}
+    Ws, pis, sigmas = [], [], []
+    while not anneal.finished:                      # EM.run body (em/__init__.py:163-178), recording each step
+        new = model.step(anneal, em.lparams, em.data)
+        anneal.next(model.gain(em.lparams, new))
+        em.lparams = new
+        Ws.append(new["W"].copy()); pis.append(new["pi"]); sigmas.append(new["sigma"])
+    np.savez_compressed(os.path.join(HERE, "bsc_traj_c1.npz"),
+                        D=D, H=H, Hprime=Hp, gamma=gamma, steps=steps, y=data["y"], s=data["s"],
+                        W_gt=params_gt["W"], W0=init["W"], pi0=init["pi"], sigma0=init["sigma"],
+                        W=np.stack(Ws), pi=np.array(pis), sigma=np.array(sigmas),
+                        L=np.array(Capture.rows["L"]), N_use=np.array(Capture.rows["N_use"]))
+    print("bsc_traj_c1: L[0]=%.6f L[-1]=%.6f pi=%.5f sigma=%.5f N_use[-1]=%d" % (
+        Capture.rows["L"][0], Capture.rows["L"][-1], pis[-1], sigmas[-1], Capture.rows["N_use"][-1]))
+
+
+def bsc_init():
+    D, H, Hp, gamma, N = 25, 10, 5, 3, 64
+    model = BSC_ET(D, H, Hp, gamma)
+    params_gt = {"W": 10 * generate_bars_dict(H), "pi": 2. / H, "sigma": 1.0}
+    np.random.seed(3)
+    data = model.generate_data(params_gt, N)
+    np.random.seed(5)
+    init = model.standard_init(data)
+    np.savez_compressed(os.path.join(HERE, "bsc_init_c1.npz"), D=D, H=H, N=N, seed_data=3, seed_init=5,
+                        W_gt=params_gt["W"], pi_gt=params_gt["pi"], sigma_gt=params_gt["sigma"],
+                        y=data["y"], s=data["s"], W0=init["W"], pi0=init["pi"], sigma0=init["sigma"])
+    print("bsc_init_c1 ok")
+
+
+def anneal_tracks():
+    steps = 50
+    a = LinearAnnealing(steps)
+    a["T"] = [(0, 2.), (.7, 1.)]
+    a["Ncut_factor"] = [(0, 0.), (2. / 3, 1.)]
+    a["anneal_prior"] = False
+    a["W_noise"] = [(0, 0.5), (-10, 0.0)]
+    names = sorted(a.as_dict().keys())
+    rows = []
+    while not a.finished:
+        d = a.as_dict()
+        rows.append([float(d[k]) for k in names] + [float(a["not_a_param"])])
+        a.next()
+    np.savez_compressed(os.path.join(HERE, "anneal_tracks.npz"), steps=steps, names=np.array(names + ["not_a_param"]),
+                        values=np.array(rows))
+    print("anneal_tracks ok", names)
+
+
+if __name__ == "__main__":
+    # BASELINE config-1 dims (D=25 H=10 H'=5 gamma=3)
+    bsc_step_case("c1_plain", 25, 10, 5, 3, 400, seed=1, T=1.0, Ncut=0.0, anneal_prior=False, bars=True)
+    bsc_step_case("c1_anneal_cut", 25, 10, 5, 3, 333, seed=2, T=1.7, Ncut=0.6, anneal_prior=True, bars=True)
+    bsc_step_case("c1_fullcut", 25, 10, 5, 3, 257, seed=3, T=1.25, Ncut=1.0, anneal_prior=False, bars=True)
+    # other shapes: H not a multiple of 64, H' = gamma (2^H' - H' - 1 multi states), learned mu
+    bsc_step_case("h32", 64, 32, 6, 3, 200, seed=4, T=1.0, Ncut=0.0, anneal_prior=False)
+    bsc_step_case("h100_cut", 48, 100, 7, 4, 150, seed=5, T=1.4, Ncut=0.8, anneal_prior=False)
+    bsc_step_case("gamma_eq_hp", 30, 12, 4, 4, 120, seed=6, T=1.0, Ncut=0.0, anneal_prior=True)
+    bsc_step_case("mu", 40, 16, 5, 3, 180, seed=8, T=1.1, Ncut=0.5, anneal_prior=False, mu=True,
+                  to_learn=("W", "pi", "sigma", "mu"))
+    bsc_step_case("h256", 96, 256, 8, 4, 96, seed=9, T=1.0, Ncut=0.0, anneal_prior=False, amp=0.5)
+    bsc_trajectory()
+    bsc_init()
+    anneal_tracks()

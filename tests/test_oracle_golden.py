@@ -1,0 +1,93 @@
+"""Pin the oracle (oracle/bsc_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, minted by tests/golden/make_golden.py from /root/reference)."""
+import numpy as np
+import pytest
+
+from conftest import golden, bsc_step_cases
+from oracle import bsc_oracle as O
+
+RTOL = 1e-10   # CPU restatement vs reference
+
+
+def _model(g):
+    m = O.make_model(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    assert np.array_equal(m["SM"], g["state_matrix"])
+    assert np.array_equal(m["state_abs"], g["state_abs"])
+    return m
+
+
+def _anneal(g):
+    return O.Anneal(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
+
+
+@pytest.mark.parametrize("case", bsc_step_cases())
+@pytest.mark.parametrize("flavour", ["loop", "vec"])
+def test_bsc_step_matches_reference(case, flavour):
+    g = golden(case)
+    m, an = _model(g), _anneal(g)
+    mu = g["mu"]
+    select = O.select_hprimes_loop if flavour == "loop" else O.select_hprimes_vec
+    estep = O.e_step_loop if flavour == "loop" else O.e_step_vec
+    stats = O.m_step_stats_loop if flavour == "loop" else O.m_step_stats_vec
+    cand = select(g["W"], g["y"], m["Hprime"])
+    assert np.array_equal(cand, g["candidates"])
+    logpj = estep(an, g["W"], float(g["pi"]), float(g["sigma"]), mu, g["y"], cand, m["SM"], m["state_abs"])
+    np.testing.assert_allclose(logpj, g["logpj"], rtol=1e-11, atol=1e-10)
+    new, log = O.m_step(an, m, g["W"], float(g["pi"]), float(g["sigma"]), mu, g["y"], cand, g["logpj"],
+                        to_learn=tuple(str(s) for s in g["to_learn"]), stats_fn=stats)
+    assert log["N_use"] == int(g["N_use"]) == int(g["N"])
+    np.testing.assert_allclose(log["L"], g["L"], rtol=1e-12)
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=RTOL, atol=1e-9 * np.abs(g["W_new"]).max())
+    np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=RTOL)
+    np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=RTOL)
+    np.testing.assert_allclose(new["mu"], g["mu_new"], rtol=1e-9, atol=1e-10)
+
+
+def test_state_matrix_counts():
+    # config 2 has S = 28+56+70 = 154, config 1 has S = 20
+    assert O.generate_state_matrix(8, 4)[1] == 154
+    assert O.generate_state_matrix(5, 3)[1] == 20
+    assert O.generate_state_matrix(4, 4)[1] == 2 ** 4 - 4 - 1
+
+
+def test_sharded_statistics_equal_single_shard():
+    g = golden("bsc_step_c1_anneal_cut.npz")
+    m, an = _model(g), _anneal(g)
+    N = g["y"].shape[0]
+    shards = [np.arange(0, N // 3), np.arange(N // 3, N)]
+    args = (an, m, g["W"], float(g["pi"]), float(g["sigma"]), g["mu"], g["y"], g["candidates"], g["logpj"])
+    a, _ = O.m_step(*args, stats_fn=O.m_step_stats_vec)
+    b, _ = O.m_step(*args, stats_fn=O.m_step_stats_vec, shards=shards)
+    np.testing.assert_allclose(a["W"], b["W"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(a["sigma"], b["sigma"], rtol=1e-13)
+
+
+def test_trajectory_c1_matches_reference():
+    """BASELINE config 1: 20 EM steps on bars data, parameters after every step."""
+    g = golden("bsc_traj_c1.npz")
+    m = O.make_model(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    steps = int(g["steps"])
+    params = {"W": g["W0"].copy(), "pi": float(g["pi0"]), "sigma": float(g["sigma0"])}
+    for t in range(steps):
+        # LinearAnnealing(20): T [(0,2),(.7,1)], Ncut_factor [(0,0),(2/3,1)]
+        T = 2.0 + (1.0 - 2.0) * min(t, 14) / 14.0
+        nc = min(t, 13) / 13.0
+        an = O.Anneal(T=T, Ncut_factor=nc, anneal_prior=False)
+        params, log = O.em_step(an, m, params, g["y"], stats_fn=O.m_step_stats_vec, vec=True)
+        np.testing.assert_allclose(log["L"], g["L"][t], rtol=1e-9, err_msg="step %d" % t)
+        assert log["N_use"] == int(g["N_use"][t])
+        np.testing.assert_allclose(params["W"], g["W"][t], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(params["pi"], g["pi"][t], rtol=1e-8)
+        np.testing.assert_allclose(params["sigma"], g["sigma"][t], rtol=1e-8)
+
+
+def test_init_and_generate_match_reference_rng_stream():
+    g = golden("bsc_init_c1.npz")
+    rng = np.random.RandomState(int(g["seed_data"]))
+    y, s = O.generate_bsc_data(g["W_gt"], float(g["pi_gt"]), float(g["sigma_gt"]), int(g["N"]), rng)
+    assert np.array_equal(s, g["s"])
+    np.testing.assert_allclose(y, g["y"], rtol=1e-13, atol=1e-13)
+    init = O.standard_init(g["y"], int(g["H"]), np.random.RandomState(int(g["seed_init"])))
+    np.testing.assert_allclose(init["W"], g["W0"], rtol=1e-13)
+    np.testing.assert_allclose(init["sigma"], g["sigma0"], rtol=1e-13)
+    assert init["pi"] == float(g["pi0"])
