@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: truncated-EM E-step throughput of Binary Sparse Coding on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path -- select_Hprimes + E_step (prosper/em/camodels/
+bsc_et.py:98-192) -- over one resident data shard of BASELINE config 2 per GPU:
+D=1024, H=256, H'=8, gamma=4 (K = 411 truncated states), N = 200 000 datapoints per GPU,
+synthetic BSC data generated on the device, float64 throughout.  Datapoints shard over ranks
+with no data-path collective, so scaling is weak (config 3 = 8 x 200k = 1.6 M).  The full
+EM iteration (CAModel.step incl. the one RCCL all-reduce and the H x H solve) is timed in a
+second region and reported as `em_iter_ms`.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the f64 MFMA scores
+GEMM) by algorithmic flops / its average launch duration measured with HIP events inside the
+timed region; `cpu_baseline` is the oracle's faithful per-datapoint restatement of the
+reference timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, H, HP, GAMMA, N_PER_GPU = 1024, 256, 8, 4, 200_000
+MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X dense f64 matrix peak (datasheet; = 32 flop/clk/SIMD)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--em-steps", type=int, default=5, help="full EM iterations timed for em_iter_ms")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=8.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle leg, run as a child process BEFORE this process touches the GPU."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--D", str(D), "--H", str(H),
+           "--Hprime", str(HP), "--gamma", str(GAMMA), "--budget", str(args.cpu_budget),
+           "--full-budget", str(min(6.0, args.cpu_budget))]
+    try:
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()
+        return json.loads(out[-1])
+    except Exception as e:  # the GPU numbers are still worth printing
+        return {"value": None, "unit": "datapoints/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # convenience: self-launch one rank per GPU (child process; nothing here touched the GPU yet)
+        port = os.environ.get("MASTER_PORT", "29531")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from prosper_amd.em.camodels.bsc_et import BSC_ET, KernelTimer
+    from prosper_amd.utils import parallel
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    comm = parallel.Comm()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- synthetic workload: same W_gt everywhere, rank-seeded rows
+    N = args.n_per_gpu
+    g0 = torch.Generator(device=dev).manual_seed(0)
+    W_gt = torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)
+    W0 = (W_gt + 0.1 * torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)).cpu().numpy()
+    gr = torch.Generator(device=dev).manual_seed(100 + rank)
+    Y = torch.empty(N, D, dtype=torch.float64, device=dev)
+    for lo in range(0, N, 25_000):      # chunked so the generator temporaries stay small
+        hi = min(N, lo + 25_000)
+        S = (torch.rand(hi - lo, H, generator=gr, device=dev) < 4.0 / H).to(torch.float64)
+        Y[lo:hi] = S @ W_gt.t() + torch.randn(hi - lo, D, generator=gr, device=dev, dtype=torch.float64)
+    del S
+    params = {"W": W0, "pi": 4.0 / H, "sigma": 1.0, "mu": np.zeros(D)}
+
+    class Anneal(dict):
+        crit_params = []
+
+        def __missing__(self, k):
+            return 0.0
+
+        def as_dict(self):
+            return dict(self)
+
+    anneal = Anneal(T=1.0, Ncut_factor=0.0, anneal_prior=False)
+    model = BSC_ET(D, H, HP, GAMMA, comm=comm)
+    data = {"y": Y}
+
+    def estep_pass():
+        model._par = {}                       # new parameters every EM step: scores are recomputed
+        d = model.select_Hprimes(params, data)
+        return model.E_step(anneal, params, d)
+
+    for _ in range(args.warmup):
+        estep_pass()
+    timer = KernelTimer()
+    model.timer = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        estep_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    model.timer = None
+    kern = timer.summary()
+
+    # ---- full EM iterations (select + E + M incl. all-reduce and solve)
+    p = dict(params)
+    for _ in range(2):
+        model.step(anneal, dict(p), data)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.em_steps):
+        p = model.step(anneal, p, data)
+    barrier()
+    em_elapsed = time.perf_counter() - t1
+
+    t = torch.tensor([elapsed, em_elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, em_elapsed = float(t[0]), float(t[1])
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * N * args.steps / elapsed
+        gemm_ms = kern["scores_gemm"][1]
+        flops = 2.0 * N * D * H                            # algorithmic flops of one scores-GEMM launch
+        achieved = flops / (gemm_ms * 1e-3) / 1e12
+        estep_bytes = N * (D * 8 + HP * 4 + (1 + H + 154) * 8)   # 11 512 B/datapoint
+        out = {
+            "metric": "E-step datapoints/sec (+ EM-iter wall-clock) BSC D=1024 H=256 H'=8",
+            "value": value, "unit": "datapoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BSC_ET synthetic Gaussian D=1024 H=256 H'=8 gamma=4 (K=411 states), "
+                                   "N=%d datapoints per GPU, select_Hprimes+E_step per step" % N,
+                       "global_datapoints": world * N, "parallelism": "dp%d" % world},
+            "em_iter_ms": em_elapsed / args.em_steps * 1e3,
+            "em_iter_datapoints_per_s": world * N * args.em_steps / em_elapsed,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f64_kernel (scores A = Y.W^T)",
+                         "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": gemm_ms,
+                         "estep_hbm_frac": (estep_bytes / (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS},
+            "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * prosper_hip.h -- C ABI of libprosper_hip.so: the MI355X (gfx950) implementation of
+ * prosper's truncated-EM hot path (select_Hprimes -> E_step -> M_step of the
+ * component-analysis models in prosper/em/camodels/).
+ *
+ * The reference is pure Python/NumPy and has no FFI; each entry point below names the
+ * reference code it replaces (file:line relative to the reference root).  A maintainer
+ * binds these with ctypes from the model's select_Hprimes / E_step / M_step methods
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()) unless its name ends
+ *     in _host; the caller owns the memory and keeps it alive until the stream has drained
+ *   - matrices are dense row-major; "ld" arguments are row strides in elements
+ *   - dims are int64_t; `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - calls only enqueue work: results are valid after the stream is synchronised
+ *   - return value: 0 = ok, <0 = PM_E* bad argument, >0 = hipError_t of a failed launch
+ *   - no hidden allocation, no global mutable state, no host<->device copies
+ *   - float64 throughout: the reference computes in IEEE double
+ */
+#ifndef PROSPER_HIP_H
+#define PROSPER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK 0
+#define PM_EINVAL (-1)      /* null pointer / non-positive dimension            */
+#define PM_ERANGE (-2)      /* dimension outside the supported range (see below) */
+
+#define PM_MAX_H 1024       /* latents per datapoint row handled by one wavefront */
+#define PM_MAX_HPRIME 16    /* candidates; state masks are 16-bit                 */
+
+/* ABI version (major*1000 + minor); bumped when a signature changes. */
+int pm_version(void);
+const char *pm_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense building blocks (hand-written f64 MFMA kernels, v_mfma_f64_16x16x4_f64)
+ * ------------------------------------------------------------------------------------- */
+
+/* C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous).
+ * Scores a = W.y for every datapoint (replaces np.inner(W, y) per datapoint,
+ * bsc_et.py:111, and the (W-y)**2 sums of bsc_et.py:177 via the Gram identity) with
+ * A = Y, B = W^T-as-rows (H,D); also G = W.W^T (replaces np.inner(W,W), bsc_et.py:111). */
+int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int64_t ldb,
+                   double *C, int64_t ldc, int64_t M, int64_t N, int64_t K, void *stream);
+
+/* C[M,N] += A[K,M]^T . B[K,N]   (reduction over the leading/row index, split over
+ * workgroups, f64 atomics into C; C must be initialised by the caller).
+ * Wp = E[s]^T . Y  -- replaces the per-datapoint np.outer accumulation of
+ * bsc_et.py:339-363 (my_Wp). */
+int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B, int64_t ldb,
+                       double *C, int64_t ldc, int64_t M, int64_t N, int64_t K, void *stream);
+
+/* out[n] = sum_d Y[n,d]^2 -- np.inner(y, y) of bsc_et.py:111 and (y**2).sum() of :172;
+ * computed once per resident data shard. */
+int pm_row_sqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Binary Sparse Coding (prosper/em/camodels/bsc_et.py)
+ * ------------------------------------------------------------------------------------- */
+
+/* select_Hprimes, bsc_et.py:98-115.
+ *   scores  (N,H)  a[n,h] = <W_h, y_n>            (from pm_gemm_nt_f64)
+ *   wnorm2  (H)    |W_h|^2  (diag of G; element stride `wnorm2_stride`, pass H+1 to read diag(G) in place)
+ *   ynorm2  (N)    |y_n|^2
+ *   cand    (N,Hprime) int32 out: indices of the Hprime largest a/|W_h|/|y|, ascending
+ *           (last = best), i.e. np.argsort(sim)[-Hprime:]; ties broken towards the larger index. */
+int pm_bsc_select_f64(const double *scores, int64_t lds, const double *wnorm2, int64_t wnorm2_stride,
+                      const double *ynorm2, int64_t N, int64_t H, int64_t Hprime,
+                      int32_t *cand, void *stream);
+
+/* Scalars of one E-step (bsc_et.py:151-154,187-190). */
+typedef struct pm_bsc_estep_params {
+    double pil_bar;      /* log(pi / (1 - pi))                                   */
+    double ecoef;        /* beta * pre1 = -(1/T) / (2 sigma^2): multiplies energies */
+    double prior_scale;  /* 1 (anneal_prior false) or beta (anneal_prior true)    */
+    double mu_sqnorm;    /* |mu|^2 (0 when mu == 0)                              */
+} pm_bsc_estep_params;
+
+/* E_step, bsc_et.py:119-192: log-pseudo-joints of the truncated state set
+ *   [null ; singletons h = 0..H-1 ; multi-cause states in generate_state_matrix order].
+ *   gram    (H,H)  G = W.W^T
+ *   wmu     (H)    W.mu, or NULL when mu == 0
+ *   ymu     (N)    Y.mu, or NULL when mu == 0
+ *   cand    (N,Hprime) int32
+ *   state_masks (S) uint16: bit j set <=> state uses candidate position j
+ *                  (rows of camodels/__init__.py:21-47's state_matrix)
+ *   logpj   (N, 1+H+S) out;  lse (N) out = log sum_k exp(logpj[n,k]) (stable), or NULL. */
+int pm_bsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
+                     const double *wmu, const double *ymu, const int32_t *cand,
+                     const uint16_t *state_masks, int64_t S,
+                     const pm_bsc_estep_params *params_host,
+                     int64_t N, int64_t H, int64_t Hprime,
+                     double *logpj, int64_t ldl, double *lse, void *stream);
+
+/* Layout of the packed M-step statistics buffer (float64, one RCCL all-reduce per EM step):
+ *   [ Wp (H*D) | Wq (H*H) | qdiag (H) | mus (H) | scalars (PM_BSC_NSCALARS) ]
+ * scalars: [0] sum_n sum_k q_nk e_nk (sigma statistic, bsc_et.py:395-415)
+ *          [1] sum over kept n of log sum_k exp(logpj) (Fs, bsc_et.py:265)
+ *          [2] number of kept datapoints (my_N after truncation, bsc_et.py:257)
+ *          [3] reserved                                                              */
+#define PM_BSC_NSCALARS 4
+int64_t pm_bsc_stats_len(int64_t H, int64_t D);
+int64_t pm_bsc_stats_offset_wq(int64_t H, int64_t D);
+int64_t pm_bsc_stats_offset_qdiag(int64_t H, int64_t D);
+int64_t pm_bsc_stats_offset_mus(int64_t H, int64_t D);
+int64_t pm_bsc_stats_offset_scalars(int64_t H, int64_t D);
+
+/* Per-datapoint part of M_step, bsc_et.py:271-272,334-366,395-415: posterior weights
+ * q = exp(logpj - lse) of every kept datapoint (lse[n] >= lse_cut; pass -inf to keep all),
+ * expectations E[s] (N,H) out (zero rows for cut datapoints), Wq block scatter, and the
+ * scalar statistics.  `pair_ptr` (Hprime*Hprime+1) / `pair_states` are the CSR lists of
+ * multi-cause states containing candidate positions (i,j) (derived from state_masks on
+ * the host; pair_len = pair_ptr[Hprime*Hprime] entries).  Only the upper triangle of Wq is
+ * accumulated (row <= col); the caller mirrors it and adds diag(qdiag).  Accumulates into `stats` (caller zeroes it once per EM step). */
+int pm_bsc_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                          const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                          const int32_t *pair_ptr, const uint16_t *pair_states, int64_t pair_len,
+                          const pm_bsc_estep_params *params_host,
+                          int64_t N, int64_t H, int64_t D, int64_t Hprime,
+                          double *expect, int64_t lde, double *stats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROSPER_HIP_H */

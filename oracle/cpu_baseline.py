@@ -1,0 +1,96 @@
+"""ORACLE leg of bench.py: time the per-datapoint reference algorithm on the host cores.
+
+Test/measurement infrastructure, not product code.  Runs the faithful restatement
+(oracle/bsc_oracle.py *_loop functions == prosper/em/camodels/bsc_et.py:98-115, 119-192,
+195-438 including their redundant per-datapoint work) on a BOUNDED sample of the bench
+workload: every worker process (one per host core, OPENBLAS_NUM_THREADS=1 -- the stand-in
+for `mpirun -np P`) draws its own rows of the config-2 generator and processes rows until its
+time budget is spent.  Prints one JSON object.
+
+    python oracle/cpu_baseline.py --D 1024 --H 256 --Hprime 8 --gamma 4 --budget 8
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("MKL_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import bsc_oracle as O  # noqa: E402
+
+
+def _worker(args):
+    rank, D, H, Hp, gamma, budget, full_budget, chunk = args
+    rng = np.random.RandomState(0)
+    W_gt = rng.normal(size=(D, H))                       # same ground truth on every worker
+    rng = np.random.RandomState(1000 + rank)
+    pi_gt = 4.0 / H
+    model = O.make_model(D, H, Hp, gamma)
+    params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": pi_gt, "sigma": 1.0}
+    an = O.Anneal(T=1.0)
+    mu = np.zeros(D)
+    done, t_e = 0, 0.0
+    last = None
+    while t_e < budget:
+        y, _ = O.generate_bsc_data(W_gt, pi_gt, 1.0, chunk, rng)
+        t0 = time.perf_counter()
+        cand = O.select_hprimes_loop(params["W"], y, Hp)
+        logpj = O.e_step_loop(an, params["W"], params["pi"], params["sigma"], mu, y, cand,
+                              model["SM"], model["state_abs"])
+        t_e += time.perf_counter() - t0
+        done += chunk
+        last = (y, cand, logpj)
+    # M-step statistics loops on the last chunk(s), separately budgeted
+    m_done, t_m = 0, 0.0
+    while t_m < full_budget and last is not None:
+        y, cand, logpj = last
+        t0 = time.perf_counter()
+        O.m_step_stats_loop(params["W"], mu, y, cand, logpj, model["SM"])
+        t_m += time.perf_counter() - t0
+        m_done += chunk
+    return done, t_e, m_done, t_m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--D", type=int, default=1024)
+    ap.add_argument("--H", type=int, default=256)
+    ap.add_argument("--Hprime", type=int, default=8)
+    ap.add_argument("--gamma", type=int, default=4)
+    ap.add_argument("--budget", type=float, default=8.0, help="seconds of E-step work per core")
+    ap.add_argument("--full-budget", type=float, default=6.0, help="seconds of M-step work per core")
+    ap.add_argument("--chunk", type=int, default=32)
+    ap.add_argument("--cores", type=int, default=0)
+    a = ap.parse_args()
+    cores = a.cores or len(os.sched_getaffinity(0))
+    ctx = mp.get_context("spawn")
+    jobs = [(r, a.D, a.H, a.Hprime, a.gamma, a.budget, a.full_budget, a.chunk) for r in range(cores)]
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_worker, jobs)
+    wall = time.perf_counter() - t0
+    rows = sum(r[0] for r in res)
+    t_e = max(r[1] for r in res)
+    e_rate = rows / t_e                                    # all cores together, slowest worker's clock
+    per_core_e = np.mean([r[0] / r[1] for r in res])
+    per_core_m = np.mean([r[2] / r[3] for r in res if r[3] > 0]) if any(r[3] > 0 for r in res) else float("nan")
+    full = 1.0 / (1.0 / per_core_e + 1.0 / per_core_m) * cores if per_core_m == per_core_m else None
+    print(json.dumps({
+        "value": e_rate, "unit": "datapoints/s", "cores": cores, "kind": "port",
+        "sample": "%d rows of the config-2 generator (D=%d H=%d H'=%d gamma=%d), %d rows/chunk, %.0f s E-step budget "
+                  "per core; faithful per-datapoint NumPy loops, 1 BLAS thread per process" % (
+                      rows, a.D, a.H, a.Hprime, a.gamma, a.chunk, a.budget),
+        "per_core_estep": per_core_e, "per_core_mstep": per_core_m, "full_step_value": full,
+        "wall_s": wall,
+    }))
+
+
+if __name__ == "__main__":
+    main()

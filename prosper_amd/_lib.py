@@ -1,0 +1,78 @@
+"""ctypes binding of libprosper_hip.so (C ABI: include/prosper_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this raises, so a
+GPU box can never silently run something else than the HIP kernels.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprosper_hip.so")
+
+c_dp = C.c_void_p      # device pointers travel as integers (torch.Tensor.data_ptr())
+i64 = C.c_int64
+
+
+class EStepParams(C.Structure):
+    """struct pm_bsc_estep_params"""
+    _fields_ = [("pil_bar", C.c_double), ("ecoef", C.c_double),
+                ("prior_scale", C.c_double), ("mu_sqnorm", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/prosper_hip.h declares
+SIGNATURES = {
+    "pm_version": (C.c_int, []),
+    "pm_error_string": (C.c_char_p, [C.c_int]),
+    "pm_gemm_nt_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
+    "pm_gemm_tn_acc_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
+    "pm_row_sqnorm_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp]),
+    "pm_bsc_select_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp, c_dp]),
+    "pm_bsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64,
+                                   C.POINTER(EStepParams), i64, i64, i64, c_dp, i64, c_dp, c_dp]),
+    "pm_bsc_stats_len": (i64, [i64, i64]),
+    "pm_bsc_stats_offset_wq": (i64, [i64, i64]),
+    "pm_bsc_stats_offset_qdiag": (i64, [i64, i64]),
+    "pm_bsc_stats_offset_mus": (i64, [i64, i64]),
+    "pm_bsc_stats_offset_scalars": (i64, [i64, i64]),
+    "pm_bsc_mstep_rows_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64, c_dp, c_dp, i64,
+                                        C.POINTER(EStepParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
+}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library once and attach prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the ONE HIP runtime in the process
+    # (pointers and streams handed to the C ABI come from it).  Loading ours first would pull
+    # /opt/rocm's copy of the same soname and leave torch and the kernels on different runtimes.
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise HipError("libprosper_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or prosper_amd/csrc/build.sh (looked in %s)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().pm_error_string(code).decode()
+        raise HipError("%s failed: %s (code %d)" % (what or "libprosper_hip call", msg, code))
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,14 @@
+// ABI bookkeeping for libprosper_hip.so (see include/prosper_hip.h).
+#include <hip/hip_runtime.h>
+
+#include "prosper_hip.h"
+
+extern "C" int pm_version(void) { return 1000; }
+
+extern "C" const char *pm_error_string(int code) {
+    if (code == PM_OK) return "ok";
+    if (code == PM_EINVAL) return "invalid argument (null pointer, non-positive dimension or short leading dimension)";
+    if (code == PM_ERANGE) return "dimension outside the supported range";
+    if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+    return "unknown error";
+}

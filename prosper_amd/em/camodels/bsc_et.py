@@ -1,0 +1,485 @@
+"""Binary Sparse Coding on the MI355X: drop-in for prosper/em/camodels/bsc_et.py.
+
+Same class name, constructor, ``select_Hprimes / E_step / M_step`` signatures, dict keys,
+``dlog`` side effects and return layouts as the reference (``BSC_ET``, bsc_et.py:24-438);
+the three hot methods enqueue hand-written HIP kernels through the C ABI of
+libprosper_hip.so (include/prosper_hip.h) instead of looping over datapoints in NumPy:
+
+  select_Hprimes  scores A = Y.W^T and Gram G = W.W^T (f64 MFMA GEMM), wavefront top-H'
+  E_step          energies of all 1+H+S truncated states from A and G, log-sum-exp
+  M_step          posterior weights, E[s], Wq scatter, sigma/pi/L statistics, then
+                  Wp = E[s]^T.Y (f64 MFMA GEMM), ONE all-reduce of the packed statistics
+                  (RCCL over xGMI; replaces the MPI calls at bsc_et.py:225-417), and the
+                  H x H solve on the device.
+
+Data stays resident in HBM between EM steps; ``candidates`` and ``logpj`` are returned as
+``DeviceArray`` handles (NumPy-convertible, downloaded only when a caller looks at them).
+There is no CPU fallback for the kernels: without the HIP library / a GPU this raises.
+"""
+import ctypes
+from math import pi as _PI
+
+import numpy as np
+from scipy.special import comb
+
+from . import CAModel
+from ... import _lib
+from ...utils import parallel
+from ...utils import tracing
+from ...utils.datalog import dlog
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class DeviceArray(object):
+    """NumPy-compatible handle of a tensor living in HBM.
+
+    ``np.asarray(handle)`` (or any NumPy function) downloads it once; row selection with an
+    index array stays on the device (``CAModel.select_partial_data``)."""
+
+    def __init__(self, tensor, np_dtype=None):
+        self.tensor = tensor
+        self._np_dtype = np.dtype(np_dtype) if np_dtype is not None else None
+        self._host = None
+        self.lse = None          # log-evidence per row, attached to 'logpj' handles
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+    @property
+    def ndim(self):
+        return self.tensor.dim()
+
+    @property
+    def dtype(self):
+        if self._np_dtype is not None:
+            return self._np_dtype
+        return np.dtype(str(self.tensor.dtype).replace("torch.", ""))
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def numpy(self):
+        if self._host is None:
+            host = self.tensor.detach().cpu().numpy()
+            if self._np_dtype is not None and host.dtype != self._np_dtype:
+                host = host.astype(self._np_dtype)
+            self._host = host
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None and np.dtype(dtype) != a.dtype else a
+
+    def __getitem__(self, idx):
+        if isinstance(idx, np.ndarray) and idx.ndim == 1 and idx.dtype.kind in "iub":
+            t = torch.from_numpy(np.ascontiguousarray(idx)).to(self.tensor.device)
+            out = DeviceArray(self.tensor[t], self._np_dtype)
+            if self.lse is not None:
+                out.lse = self.lse[t]
+            return out
+        return self.numpy()[idx]
+
+    def __repr__(self):
+        return "DeviceArray(shape=%s, dtype=%s, device=%s)" % (self.shape, self.dtype, self.tensor.device)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class KernelTimer(object):
+    """HIP-event timing of individual kernel launches on the stream they are enqueued on
+    (torch's current stream, which is the one handed to the C ABI).  bench.py attaches one
+    to a model to obtain per-kernel average durations inside the timed region."""
+
+    def __init__(self):
+        self.events = {}
+
+    def launch(self, label, fn):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        fn()
+        end.record()
+        self.events.setdefault(label, []).append((start, end))
+
+    def summary(self):
+        """label -> (launches, average milliseconds); synchronises."""
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+class BSC_ET(CAModel):
+    """Binary Sparse Coding with Expectation Truncation; HIP kernels behind the
+    reference's plugin surface.  ``device`` defaults to the current CUDA/HIP device."""
+
+    def __init__(self, D, H, Hprime, gamma, to_learn=['W', 'pi', 'sigma'], comm=parallel.COMM_WORLD,
+                 device=None):
+        CAModel.__init__(self, D, H, Hprime, gamma, to_learn, comm)
+        self._device = device
+        self._tables = None      # device copies of the state table
+        self._data = {}          # resident data shard: key, Y, ynorm2
+        self._par = {}           # per-step parameter products: W host copy, Wt, G, scores
+        self._ws = {}            # workspaces keyed by name
+        self.timer = None        # optional KernelTimer (bench.py)
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        if self._device is None:
+            if torch is None or not torch.cuda.is_available():
+                raise _lib.HipError("BSC_ET needs a HIP device: the hot path has no CPU fallback")
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        return torch.device(self._device)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _call(self, label, entry, *args):
+        """Enqueue one C-ABI entry point on the current stream (raises on a bad status)."""
+        if self.timer is None:
+            _lib.call(entry, *args)
+        else:
+            self.timer.launch(label, lambda: _lib.call(entry, *args))
+
+    def _buf(self, name, shape, dtype=None):
+        """Reusable device workspace (no allocation inside the EM loop once warm)."""
+        dtype = dtype or torch.float64
+        t = self._ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._ws[name] = t
+        return t
+
+    def _state_tables(self):
+        """Upload the truncated state table: 16-bit masks + CSR lists of the multi-cause
+        states containing each pair of candidate positions (for E[s s^T])."""
+        key = (self.Hprime, self.gamma, self.no_states)
+        if self._tables is not None and self._tables["key"] == key:
+            return self._tables
+        _lib.load()
+        Hp = self.Hprime
+        SM = self.state_matrix.astype(np.int64)                      # (S, Hp)
+        masks = (SM << np.arange(Hp)[None, :]).sum(axis=1).astype(np.uint16) if SM.size else np.zeros(0, np.uint16)
+        ptr = [0]
+        lst = []
+        for i in range(Hp):
+            for j in range(Hp):
+                if SM.size:
+                    lst.extend(np.where((SM[:, i] == 1) & (SM[:, j] == 1))[0].tolist())
+                ptr.append(len(lst))
+        dev = self.device
+        self._tables = {
+            "key": key,
+            # uint16 payloads travel as int16 tensors (same bytes)
+            "masks": torch.from_numpy(np.ascontiguousarray(masks).view(np.int16).copy()).to(dev)
+            if masks.size else torch.zeros(1, dtype=torch.int16, device=dev),
+            "pair_ptr": torch.tensor(ptr, dtype=torch.int32, device=dev),
+            "pair_states": torch.tensor(lst if lst else [0], dtype=torch.int16, device=dev),
+            "pair_len": len(lst),
+        }
+        return self._tables
+
+    def _resident(self, y):
+        """Device copy of the data shard + |y_n|^2, uploaded once and kept in HBM."""
+        if isinstance(y, DeviceArray):
+            y = y.tensor
+        if torch.is_tensor(y):
+            key = ("t", y.data_ptr(), tuple(y.shape), y._version)
+        else:
+            y = np.asarray(y)
+            probe = float(y[0].sum() + y[-1].sum()) if y.shape[0] else 0.0
+            key = ("n", y.__array_interface__["data"][0], y.shape, probe)
+        if self._data.get("key") == key:
+            return self._data
+        if torch.is_tensor(y):
+            Y = y.to(device=self.device, dtype=torch.float64).contiguous()
+        else:
+            Y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(self.device)
+        N, D = Y.shape
+        assert D == self.D
+        yn = torch.empty(N, dtype=torch.float64, device=self.device)
+        self._call("row_sqnorm", "pm_row_sqnorm_f64", _ptr(Y), D, N, D, _ptr(yn), self._stream())
+        self._data = {"key": key, "Y": Y, "ynorm2": yn}
+        self._par = {}
+        return self._data
+
+    def invalidate_data(self):
+        """Forget the resident shard (call after modifying ``my_data['y']`` in place)."""
+        self._data = {}
+        self._par = {}
+
+    def _gemm_nt(self, A, B, out, label="gemm_nt"):
+        M, K = A.shape
+        N = B.shape[0]
+        self._call(label, "pm_gemm_nt_f64", _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0),
+                  M, N, K, self._stream())
+        return out
+
+    def _scores(self, model_params, res):
+        """A = Y.W^T (N,H) and G = W.W^T for the current W; reused by E_step when
+        select_Hprimes just computed them for the same W and data."""
+        W = np.asarray(model_params['W'])
+        par = self._par
+        if par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape \
+                and np.array_equal(par["W"], W):
+            return par
+        Y = res["Y"]
+        N = Y.shape[0]
+        Wt = torch.from_numpy(np.ascontiguousarray(W.T, dtype=np.float64)).to(self.device)   # (H, D)
+        G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
+        A = self._buf("scores", (N, self.H))
+        if N:
+            self._gemm_nt(Y, Wt, A, "scores_gemm")
+        self._par = {"ykey": res["key"], "W": W.copy(), "Wt": Wt, "G": G, "A": A}
+        return self._par
+
+    # ------------------------------------------------------------------ data generation
+    @tracing.traced
+    def generate_from_hidden(self, model_params, my_hdata):
+        """y = s.W^T + N(0, sigma^2) (bsc_et.py:67-95; one normal((my_N, D)) draw).
+        Does not obey gamma."""
+        W = model_params['W'].T
+        s = my_hdata['s']
+        my_N = s.shape[0]
+        y = np.asarray(s, dtype=np.float64) @ W
+        y += np.random.normal(scale=model_params['sigma'], size=(my_N, W.shape[1]))
+        return {'y': y, 's': s}
+
+    # ------------------------------------------------------------------ hot path
+    @tracing.traced
+    def select_Hprimes(self, model_params, data):
+        """Annotate ``data`` with ``data['candidates']`` (N, Hprime): per datapoint the
+        Hprime latents with the largest <W_h,y>/|W_h|/|y|, ascending (bsc_et.py:98-115)."""
+        res = self._resident(data['y'])
+        par = self._scores(model_params, res)
+        N = res["Y"].shape[0]
+        cand = self._buf("cand", (N, self.Hprime), torch.int32)
+        if N:
+            G = par["G"]
+            self._call("select", "pm_bsc_select_f64", _ptr(par["A"]), self.H, _ptr(G), self.H + 1, _ptr(res["ynorm2"]),
+                      N, self.H, self.Hprime, _ptr(cand), self._stream())
+        data['candidates'] = DeviceArray(cand, np.int64)
+        return data
+
+    def _estep_params(self, anneal, pies, sigma, mu):
+        beta = 1. / anneal['T']
+        pre1 = -1. / 2. / sigma / sigma
+        return _lib.EStepParams(pil_bar=float(np.log(pies / (1. - pies))), ecoef=float(beta * pre1),
+                                prior_scale=float(beta if anneal['anneal_prior'] else 1.0),
+                                mu_sqnorm=float(np.dot(mu, mu)))
+
+    def _mu_terms(self, par, res, mu):
+        """W.mu and Y.mu when the data offset is non-zero (bsc_et.py:169 uses y - mu)."""
+        if not np.any(mu):
+            return None, None
+        mu_d = torch.from_numpy(np.ascontiguousarray(mu, dtype=np.float64)).to(self.device).reshape(1, -1)
+        wmu = self._gemm_nt(par["Wt"], mu_d, self._buf("wmu", (self.H, 1)))
+        N = res["Y"].shape[0]
+        ymu = self._buf("ymu", (N, 1))
+        if N:
+            self._gemm_nt(res["Y"], mu_d, ymu)
+        return wmu, ymu
+
+    def _device_candidates(self, cand, N):
+        if isinstance(cand, DeviceArray):
+            t = cand.tensor
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(cand, dtype=np.int32)).to(self.device)
+        if t.dtype != torch.int32:
+            t = t.to(torch.int32)
+        assert tuple(t.shape) == (N, self.Hprime)
+        return t.contiguous()
+
+    @tracing.traced
+    def E_step(self, anneal, model_params, my_data):
+        """Log-pseudo-joints of the truncated state set -> ``{'logpj': (N, 1+H+S)}``
+        (bsc_et.py:119-192).  Inserts ``model_params['mu']`` when absent, as upstream."""
+        res = self._resident(my_data['y'])
+        N, D = res["Y"].shape
+        H, Hp, S = self.H, self.Hprime, self.no_states
+        try:
+            mu = model_params['mu']
+        except KeyError:
+            mu = np.zeros(D)
+            model_params['mu'] = mu
+        par = self._scores(model_params, res)
+        tab = self._state_tables()
+        cand = self._device_candidates(my_data['candidates'], N)
+        P = self._estep_params(anneal, model_params['pi'], model_params['sigma'], np.asarray(mu, dtype=np.float64))
+        wmu, ymu = self._mu_terms(par, res, np.asarray(mu, dtype=np.float64))
+        K = 1 + H + S
+        logpj = self._buf("logpj", (N, K))
+        lse = self._buf("lse", (N,))
+        tracing.tracepoint("E_step:iterating")
+        if N:
+            self._call("estep", "pm_bsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]),
+                      _ptr(wmu), _ptr(ymu), _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P),
+                      N, H, Hp, _ptr(logpj), K, _ptr(lse), self._stream())
+        out = DeviceArray(logpj)
+        out.lse = lse
+        return {'logpj': out}
+
+    def _kth_largest_global(self, lse, N_use):
+        """sort(all log-evidences)[-N_use] across ranks (bsc_et.py:252 via
+        parallel.allsort).  Shards are padded to equal length for the all-gather."""
+        comm = self.comm
+        if comm.size > 1:
+            import torch.distributed as dist
+            sizes = comm.allgather(int(lse.shape[0]))
+            n_max = max(sizes)
+            pad = torch.full((n_max,), float("-inf"), dtype=torch.float64, device=lse.device)
+            pad[:lse.shape[0]] = lse
+            parts = [torch.empty_like(pad) for _ in range(comm.size)]
+            dist.all_gather(parts, pad, group=comm._group)
+            pool = torch.cat(parts)
+        else:
+            pool = lse
+        vals = torch.topk(pool, N_use, largest=True, sorted=True).values
+        return float(vals[-1])
+
+    @tracing.traced
+    def M_step(self, anneal, model_params, my_suff_stat, my_data):
+        """New W, pi, sigma (, mu) from the posterior over the truncated states
+        (bsc_et.py:195-438).  Logs ``N``, ``L`` (free energy) and ``N_use`` to dlog."""
+        comm = self.comm
+        H, Hp, D, gamma, S = self.H, self.Hprime, self.D, self.gamma, self.no_states
+        W_DH = np.asarray(model_params['W'])
+        pies = model_params['pi']
+        sigma = model_params['sigma']
+        mu = np.asarray(model_params['mu'], dtype=np.float64)
+
+        res = self._resident(my_data['y'])
+        Y = res["Y"]
+        my_N = Y.shape[0]
+        tab = self._state_tables()
+        cand = self._device_candidates(my_data['candidates'], my_N)
+        K = 1 + H + S
+
+        logpj = my_suff_stat['logpj']
+        if isinstance(logpj, DeviceArray) and logpj.lse is not None:
+            lp, lse = logpj.tensor, logpj.lse
+        else:   # log-joints handed in from outside: upload, recompute the log-evidence
+            lp = torch.from_numpy(np.ascontiguousarray(np.asarray(logpj), dtype=np.float64)).to(self.device)
+            lse = torch.logsumexp(lp, dim=1)
+        lp = lp.contiguous()
+        lse = lse.contiguous()
+        assert tuple(lp.shape) == (my_N, K)
+
+        N = comm.allreduce(my_N)
+
+        # factors of the pi update (bsc_et.py:237-244)
+        A_pi_gamma = 0
+        B_pi_gamma = 0
+        for gamma_p in range(gamma + 1):
+            t = comb(H, gamma_p) * (pies ** gamma_p) * ((1 - pies) ** (H - gamma_p))
+            A_pi_gamma += t
+            B_pi_gamma += gamma_p * t
+        E_pi_gamma = pies * H * A_pi_gamma / B_pi_gamma
+
+        # data truncation (bsc_et.py:247-258): keep the N_use datapoints with the largest evidence
+        lse_cut = float("-inf")
+        if anneal['Ncut_factor'] > 0.0:
+            tracing.tracepoint("M_step:truncating")
+            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
+            lse_cut = self._kth_largest_global(lse, N_use)
+
+        # per-datapoint statistics + Wp GEMM into the packed buffer
+        tracing.tracepoint("M_step:iterating")
+        _lib.load()
+        n_stats = _lib.load().pm_bsc_stats_len(H, D)
+        stats = self._buf("stats", (n_stats,))
+        stats.zero_()
+        expect = self._buf("expect", (my_N, H))
+        P = self._estep_params(anneal, pies, sigma, mu)
+        if my_N:
+            self._call("mstep_rows", "pm_bsc_mstep_rows_f64", _ptr(lp), K, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand),
+                      _ptr(tab["masks"]), S, _ptr(tab["pair_ptr"]), _ptr(tab["pair_states"]), tab["pair_len"],
+                      ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats), self._stream())
+            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, self._stream())
+        need_mu = 'mu' in self.to_learn
+        if need_mu:
+            keep = (lse >= lse_cut).to(torch.float64)
+            data_sum = torch.mv(Y.t(), keep) if my_N else torch.zeros(D, dtype=torch.float64, device=self.device)
+            packed = torch.cat([stats, data_sum])
+        else:
+            packed = stats
+
+        # the ONE exchange of the step (replaces bsc_et.py:225,258,266,373,374,387,417,426,427)
+        comm.allreduce_device(packed)
+        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma)
+
+    def _finalize(self, packed, model_params, A_pi_gamma, E_pi_gamma):
+        """Parameter updates from the all-reduced statistics (bsc_et.py:264-267, 369-438).
+        Device-agnostic: ``packed`` may live in HBM (product path) or on the host (the
+        world_size-2 gloo tests feed it CPU tensors)."""
+        comm = self.comm
+        H, D = self.H, self.D
+        W_DH = np.asarray(model_params['W'])
+        pies, sigma = model_params['pi'], model_params['sigma']
+        mu = np.asarray(model_params['mu'], dtype=np.float64)
+        lib = _lib.load()
+        n_stats = lib.pm_bsc_stats_len(H, D)
+        o_wq, o_qd = lib.pm_bsc_stats_offset_wq(H, D), lib.pm_bsc_stats_offset_qdiag(H, D)
+        o_mus, o_sc = lib.pm_bsc_stats_offset_mus(H, D), lib.pm_bsc_stats_offset_scalars(H, D)
+        Wp = packed[:o_wq].view(H, D)
+        Wq_u = packed[o_wq:o_qd].view(H, H)
+        qdiag = packed[o_qd:o_mus]
+        mus = packed[o_mus:o_sc]
+        scal = packed[o_sc:o_sc + 4].cpu().numpy()
+        my_sigma, Fs, N_use = float(scal[0]), float(scal[1]), int(round(scal[2]))
+        dlog.append('N', N_use)
+
+        L = H * np.log(1 - pies) - 0.5 * D * np.log(2 * _PI * sigma ** 2) - np.log(A_pi_gamma)
+        L += Fs / N_use
+        dlog.append('L', L)
+
+        if 'W' in self.to_learn:
+            tracing.tracepoint("M_step:update W")
+            Wq = Wq_u + Wq_u.t() - torch.diag(torch.diagonal(Wq_u)) + torch.diag(qdiag)
+            rhs = Wp
+            if np.any(mu):   # Wp was accumulated against y, the reference uses y - mu
+                rhs = Wp - torch.outer(mus, torch.from_numpy(mu).to(packed.device))
+            W_new = self._solve(Wq, rhs)
+        else:
+            W_new = W_DH.T
+
+        if 'pi' in self.to_learn:
+            tracing.tracepoint("M_step:update pi")
+            pi_new = E_pi_gamma * float(mus.sum()) / H / N_use
+        else:
+            pi_new = pies
+
+        if 'sigma' in self.to_learn:
+            tracing.tracepoint("M_step:update sigma")
+            sigma_new = np.sqrt(my_sigma / D / N_use)
+        else:
+            sigma_new = sigma
+
+        if 'mu' in self.to_learn:
+            tracing.tracepoint("M_step:update mu")
+            # the reference divides by the rank-local kept count (bsc_et.py:428), which is only
+            # meaningful on one rank; with several ranks the global count is used
+            mu_new = packed[n_stats:].cpu().numpy() / N_use - np.inner(W_new.T / N_use, mus.cpu().numpy())
+        else:
+            mu_new = mu
+
+        dlog.append('N_use', N_use)
+        return {'W': W_new.T, 'pi': pi_new, 'sigma': sigma_new, 'mu': mu_new}
+
+    def _solve(self, Wq, Wp):
+        """W_new = argmin |Wq X - Wp| (np.linalg.lstsq at bsc_et.py:380).  Wq is a sum of
+        second moments (symmetric PSD): Cholesky on the device; when it is numerically
+        singular fall back to the reference's own LAPACK lstsq on the host."""
+        Lc, info = torch.linalg.cholesky_ex(Wq)
+        ok = int(info) == 0
+        if ok:
+            d = torch.diagonal(Lc)
+            ok = bool((d.min() / d.max()) ** 2 > 1e-11)
+        if ok:
+            return torch.cholesky_solve(Wp, Lc).cpu().numpy()
+        return np.linalg.lstsq(Wq.cpu().numpy(), Wp.cpu().numpy(), rcond=None)[0]

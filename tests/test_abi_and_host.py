@@ -1,0 +1,156 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/prosper_hip.h
+declares (no compute without a GPU), and the host-side mirror of the reference's driver
+(LinearAnnealing, EM loop, state table, dlog, comm helpers) behaves like the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+
+def test_library_exports_every_declared_symbol():
+    from prosper_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "prosper_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libprosper_hip.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), "ctypes table and header disagree: %s" % (
+        declared ^ set(_lib.SIGNATURES))
+    assert lib.pm_version() >= 1000
+    assert lib.pm_error_string(0) == b"ok"
+    assert b"invalid" in lib.pm_error_string(-1)
+
+
+def test_stats_layout_helpers():
+    from prosper_amd import _lib
+    lib = _lib.load()
+    H, D = 256, 1024
+    assert lib.pm_bsc_stats_offset_wq(H, D) == H * D
+    assert lib.pm_bsc_stats_offset_qdiag(H, D) == H * D + H * H
+    assert lib.pm_bsc_stats_offset_mus(H, D) == H * D + H * H + H
+    assert lib.pm_bsc_stats_len(H, D) == H * D + H * H + 2 * H + 4
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from prosper_amd import _lib
+    lib = _lib.load()
+    assert lib.pm_gemm_nt_f64(None, 1, None, 1, None, 1, 1, 1, 1, None) == -1
+    assert lib.pm_bsc_select_f64(None, 1, None, 1, None, 1, 1, 1, None, None) == -1
+    with pytest.raises(_lib.HipError):
+        _lib.call("pm_row_sqnorm_f64", None, 1, 1, 1, None, None)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    m = BSC_ET(25, 10, 5, 3)
+    with pytest.raises(_lib.HipError):
+        m.select_Hprimes({"W": np.ones((25, 10))}, {"y": np.ones((4, 25))})
+
+
+def test_annealing_tracks_match_reference():
+    from prosper_amd.em.annealing import LinearAnnealing
+    g = golden("anneal_tracks.npz")
+    a = LinearAnnealing(int(g["steps"]))
+    a["T"] = [(0, 2.), (.7, 1.)]
+    a["Ncut_factor"] = [(0, 0.), (2. / 3, 1.)]
+    a["anneal_prior"] = False
+    a["W_noise"] = [(0, 0.5), (-10, 0.0)]
+    names = [str(n) for n in g["names"]]
+    rows = []
+    while not a.finished:
+        rows.append([float(a[n]) for n in names])
+        a.next()
+    np.testing.assert_allclose(np.array(rows), g["values"], rtol=0, atol=0)
+    with pytest.raises(RuntimeError):
+        a.next()
+    with pytest.raises(TypeError):
+        a["bad"] = [1.0, 2.0]
+
+
+def test_state_matrix_matches_reference_fixture():
+    from prosper_amd.em.camodels import generate_state_matrix
+    g = golden("bsc_step_h256.npz")
+    sl, S, SM, sabs = generate_state_matrix(int(g["Hprime"]), int(g["gamma"]))
+    assert S == 154 and np.array_equal(SM, g["state_matrix"]) and np.array_equal(sabs, g["state_abs"])
+    assert SM.dtype == np.uint8 and all(len(s) == a for s, a in zip(sl, sabs))
+
+
+class _CountingModel(object):
+    """Minimal Model: records the annealing values every step sees."""
+
+    def __init__(self):
+        self.seen = []
+
+    def step(self, anneal, params, data):
+        self.seen.append((anneal["T"], anneal["step"]))
+        return {"x": params["x"] + 1}
+
+    def gain(self, old, new):
+        return 0.
+
+
+def test_em_run_loop_contract():
+    from prosper_amd.em import EM
+    from prosper_amd.em.annealing import LinearAnnealing
+    a = LinearAnnealing(7)
+    a["T"] = [(0, 3.), (-1, 1.)]
+    em = EM(model=_CountingModel(), anneal=a, data={}, lparams={"x": 0})
+    em.run()
+    assert em.lparams == {"x": 7}
+    assert len(em.model.seen) == 7 and em.model.seen[0] == (3.0, 0.0)
+    assert a.finished
+
+
+def test_dlog_policy_and_wildcard():
+    from prosper_amd.utils.datalog import DataLog, StoreInMemory
+    d = DataLog()
+    h1 = d.set_handler(("L", "N"), StoreInMemory)
+    h2 = d.set_handler("*", StoreInMemory)
+    d.append("L", 1.5)
+    d.append_all({"W": np.ones(3), "N": 7})
+    assert [float(v) for v in h1.tables["L"]] == [1.5] and int(h1.tables["N"][0]) == 7
+    assert set(h2.tables) == {"L", "W", "N"} and "W" not in h1.tables
+    assert not d.ignored("anything") and DataLog().ignored("L")
+    d.remove_handler(h2)
+    d.append("W", np.zeros(3))
+    assert len(h2.tables["W"]) == 1
+
+
+def test_single_rank_comm_and_helpers():
+    from prosper_amd.utils import parallel
+    c = parallel.Comm()
+    assert (c.rank, c.size) == (0, 1)
+    assert c.allreduce(5) == 5
+    a, b = np.arange(6.).reshape(2, 3), np.empty((2, 3))
+    c.Allreduce([a, parallel.DOUBLE], [b, parallel.DOUBLE])
+    assert np.array_equal(a, b)
+    x = np.array([3., 1., 2.])
+    assert np.array_equal(parallel.allsort(x), np.array([1., 2., 3.]))
+    assert parallel.allmean(np.ones((4, 3)), axis=0).tolist() == [1., 1., 1.]
+    assert parallel.allsum(np.ones((4, 3))) == 12
+    assert parallel.stride_data(10) == (0, 10)
+
+
+def test_standard_init_and_generate_data_rng_stream():
+    """Host-side CAModel mirror reproduces the reference's RNG stream (golden from reference)."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    g = golden("bsc_init_c1.npz")
+    m = BSC_ET(int(g["D"]), int(g["H"]), 5, 3)
+    np.random.seed(int(g["seed_data"]))
+    data = m.generate_data({"W": g["W_gt"], "pi": float(g["pi_gt"]), "sigma": float(g["sigma_gt"])}, int(g["N"]))
+    assert np.array_equal(data["s"], g["s"])
+    np.testing.assert_allclose(data["y"], g["y"], rtol=1e-13, atol=1e-13)
+    np.random.seed(int(g["seed_init"]))
+    init = m.standard_init({"y": g["y"]})
+    np.testing.assert_allclose(init["W"], g["W0"], rtol=1e-13)
+    np.testing.assert_allclose(init["sigma"], g["sigma0"], rtol=1e-13)
+    assert init["pi"] == float(g["pi0"])
