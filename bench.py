@@ -139,12 +139,16 @@ def main():
     p = dict(params)
     for _ in range(2):
         model.step(anneal, dict(p), data)
+    em_timer = KernelTimer()
+    model.timer = em_timer
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.em_steps):
         p = model.step(anneal, p, data)
     barrier()
     em_elapsed = time.perf_counter() - t1
+    model.timer = None
+    em_kern = em_timer.summary()
 
     t = torch.tensor([elapsed, em_elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -174,6 +178,7 @@ def main():
                          "avg_launch_ms": gemm_ms,
                          "estep_hbm_frac": (estep_bytes / (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
+            "em_kernels_ms": {k: round(v[1], 4) for k, v in sorted(em_kern.items())},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -305,9 +305,9 @@ extern "C" int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B,
 }
 
 extern "C" int pm_row_sqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, double *out, void *stream) {
+    if (N == 0) return PM_OK;
     if (!Y || !out || N < 0 || D <= 0 || ldy < D) return PM_EINVAL;
     if (D > INT32_MAX) return PM_ERANGE;
-    if (N == 0) return PM_OK;
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(row_sqnorm_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), Y,

@@ -203,7 +203,8 @@ class BSC_ET(CAModel):
         N, D = Y.shape
         assert D == self.D
         yn = torch.empty(N, dtype=torch.float64, device=self.device)
-        self._call("row_sqnorm", "pm_row_sqnorm_f64", _ptr(Y), D, N, D, _ptr(yn), self._stream())
+        if N:
+            self._call("row_sqnorm", "pm_row_sqnorm_f64", _ptr(Y), D, N, D, _ptr(yn), self._stream())
         self._data = {"key": key, "Y": Y, "ynorm2": yn}
         self._par = {}
         return self._data

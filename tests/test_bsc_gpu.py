@@ -211,7 +211,11 @@ def test_bsc_step_matches_oracle(dev, D, H, Hp, gamma, N, T, ncut, ap):
         dlog.remove_handler(h)
     assert int(h.tables["N_use"][0]) == rlog["N_use"]
     np.testing.assert_allclose(float(h.tables["L"][0]), rlog["L"], rtol=1e-10)
-    np.testing.assert_allclose(new["W"], ref["W"], rtol=1e-7, atol=1e-8 * np.abs(ref["W"]).max())
+    # W_new solves Wq X = Wp; the reference's SVD lstsq and the device Cholesky each carry an
+    # error ~ cond(Wq) * eps, so the comparison is scaled by the conditioning of this case
+    tol = max(1e-8, 20 * np.linalg.cond(rlog["stats"]["Wq"]) * np.finfo(float).eps)
+    assert tol < BASELINE_RTOL
+    np.testing.assert_allclose(new["W"], ref["W"], rtol=10 * tol, atol=tol * np.abs(ref["W"]).max())
     np.testing.assert_allclose(new["pi"], ref["pi"], rtol=1e-9)
     np.testing.assert_allclose(new["sigma"], ref["sigma"], rtol=1e-9)
 
