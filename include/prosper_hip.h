@@ -125,6 +125,34 @@ int pm_bsc_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse, d
                           int64_t N, int64_t H, int64_t D, int64_t Hprime,
                           double *expect, int64_t lde, double *stats, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * BSC fast path: 16 lanes per datapoint (four datapoints per wavefront, DPP row reductions),
+ * incremental multi-cause energies, negligible posterior terms skipped.  Same results as the
+ * entry points above; available when pm_bsc_rows16_supported(H, Hprime, S) != 0 (H <= 512 and
+ * the per-datapoint state areas fit LDS).
+ * ------------------------------------------------------------------------------------- */
+int pm_bsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S);
+
+/* select_Hprimes (bsc_et.py:98-115) and/or E_step (bsc_et.py:119-192) in one pass over the
+ * scores: mode bit 0 = select (write `cand`; otherwise `cand` is an input), bit 1 = E-step
+ * (write `logpj`, `lse`).  `state_parents[s]` = index of the state obtained from state s by
+ * dropping its highest candidate position (0xFFFF when that leaves a singleton);
+ * `size_offsets_host[g-2]` = index of the first state with g causes, g = 2..gamma, and
+ * size_offsets_host[gamma-1] = S (states are ordered by size, camodels/__init__.py:32-35).
+ * Selection ties: similarities equal in their leading 42 mantissa bits rank by latent index. */
+int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
+                            const double *wmu, const double *ymu, const uint16_t *state_masks,
+                            const uint16_t *state_parents, const int32_t *size_offsets_host, int64_t S,
+                            int64_t gamma, const pm_bsc_estep_params *params_host, int64_t N, int64_t H,
+                            int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl,
+                            double *lse, void *stream);
+
+/* Fast-path twin of pm_bsc_mstep_rows_f64 (same outputs, same `stats` layout). */
+int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                            const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                            const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D,
+                            int64_t Hprime, double *expect, int64_t lde, double *stats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

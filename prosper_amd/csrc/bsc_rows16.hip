@@ -1,0 +1,524 @@
+// Binary Sparse Coding row kernels, fast path: 16 lanes per datapoint.
+//
+// A 64-lane wavefront is four DPP rows of 16 lanes; each row owns one datapoint, so a wavefront
+// works on four datapoints at once and every reduction over a datapoint's latents / states (top-H',
+// max, sum) is a 4-step DPP butterfly inside the row -- no LDS crossbar (ds_bpermute), no
+// cross-row traffic.  Lane j of a row holds latents h = j + 16 i (i < VPL), i.e. each row reads and
+// writes whole 128-byte segments of its datapoint's rows of `scores` / `logpj` / `expect`.
+//
+//   bsc_select_estep16_kernel   select_Hprimes (bsc_et.py:98-115) and/or E_step (bsc_et.py:119-192)
+//                               in ONE pass over the scores: the scores stay in registers between
+//                               the two, candidates never round-trip through HBM
+//   bsc_mstep_rows16_kernel     per-datapoint part of M_step (bsc_et.py:271-272,334-366,395-415)
+//
+// Multi-cause state energies are built incrementally by state size (pairs, triples, ...):
+//   e'(s) = e'(s minus its highest candidate k) + d_k + 2 sum_{i in s, i<k} G[c_i, c_k],
+//   d_k = G[c_k,c_k] - 2 a_{c_k},   e(s) = |y|^2 + e'(s)
+// with the parent's index precomputed on the host; a state costs |s|+1 LDS reads instead of
+// |s|(|s|+3)/2.  Posterior terms below exp(-37) (< 1e-16 of the largest) are skipped wave-wide.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "prosper_hip.h"
+#include "pm_common.h"
+
+namespace {
+
+constexpr int ROWS = 16;          // datapoints per 256-thread workgroup (4 wavefronts x 4 DPP rows)
+constexpr double NEGLIGIBLE = -37.0;
+
+// ---- DPP helpers (all-reduce butterflies inside a 16-lane row) -------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+    const unsigned lo = dpp32<CTRL>((unsigned)v), hi = dpp32<CTRL>((unsigned)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int CTRL>
+__device__ __forceinline__ double dppf64(double v) {
+    return __longlong_as_double((long long)dpp64<CTRL>((uint64_t)__double_as_longlong(v)));
+}
+// xor 1, xor 2 (quad_perm), reverse within 8 (row_half_mirror), reverse within 16 (row_mirror)
+#define PM_ROW_BUTTERFLY(OP, T, F)          \
+    v = OP(v, F<0xB1>(v));                  \
+    v = OP(v, F<0x4E>(v));                  \
+    v = OP(v, F<0x141>(v));                 \
+    v = OP(v, F<0x140>(v));
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ double fadd(double a, double b) { return a + b; }
+__device__ __forceinline__ uint64_t row_max_u64(uint64_t v) {
+    PM_ROW_BUTTERFLY(umax64, uint64_t, dpp64)
+    return v;
+}
+__device__ __forceinline__ double row_max_f64(double v) {
+    PM_ROW_BUTTERFLY(fmax, double, dppf64)
+    return v;
+}
+__device__ __forceinline__ double row_sum_f64(double v) {
+    PM_ROW_BUTTERFLY(fadd, double, dppf64)
+    return v;
+}
+
+__device__ __forceinline__ void wave_lds_sync16() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// total order on doubles as unsigned integers (NaN handled by the caller)
+__device__ __forceinline__ uint64_t order_key(double x) {
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+struct SizeOffsets {  // multi-cause states of size g occupy [off[g-2], off[g-1]) ; g = 2..gamma
+    int off[PM_MAX_HPRIME];
+};
+
+// ---------------------------------------------------------------------------------------------
+// select_Hprimes + E_step
+//   mode bit 0: select (compute + write candidates); else candidates are read from `cand`
+//   mode bit 1: E-step (write logpj / lse)
+// ---------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
+    const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
+    const double *__restrict__ ynorm2, const double *__restrict__ wmu, const double *__restrict__ ymu,
+    const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents, SizeOffsets so, int S, int gamma,
+    pm_bsc_estep_params P, int64_t N, int H, int Hp, int mode, int32_t *__restrict__ cand,
+    double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [ w2 (H) | sw (H) | per datapoint: d (16) G (Hp*Hp) e (S) | tab (S x u32) ]
+    double *s_w2 = reinterpret_cast<double *>(smem);
+    double *s_sw = s_w2 + H;
+    double *s_dp = s_sw + H;
+    const int dp_stride = 16 + Hp * Hp + S;
+    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_dp + ROWS * dp_stride);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, row = lane >> 4;
+    for (int h = tid; h < H; h += 256) {
+        const double g = gram[(int64_t)h * H + h];
+        s_w2[h] = g + (wmu ? 2.0 * wmu[h] : 0.0);
+        s_sw[h] = sqrt(g);
+    }
+    for (int s = tid; s < S; s += 256) s_tab[s] = (uint32_t)masks[s] | ((uint32_t)parents[s] << 16);
+    __syncthreads();
+
+    double *s_d = s_dp + (wave * 4 + row) * dp_stride;
+    double *s_G = s_d + 16;
+    double *s_e = s_G + Hp * Hp;
+    const double ppil = P.prior_scale * P.pil_bar;
+    const bool do_select = mode & 1, do_estep = mode & 2;
+
+    const int64_t groups = (N + ROWS - 1) / ROWS;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int64_t n = grp * ROWS + wave * 4 + row;
+        const bool live = n < N;               // uniform per DPP row
+        const int64_t nn = live ? n : N - 1;   // dead rows shadow the last datapoint, write nothing
+        const double *arow = scores + nn * lds;
+
+        double a[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            a[i] = (h < H) ? arow[h] : 0.0;
+        }
+        double yn = ynorm2[nn];
+
+        // ---------------- top-H' of a / |W_h| / |y| (ascending, best last) -------------------
+        int myc = 0;  // lane j < Hp ends up with candidate position j
+        if (do_select) {
+            const double sy = sqrt(yn);
+            uint64_t key[VPL];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int h = j + 16 * i;
+                uint64_t k = 0;
+                if (h < H) {
+                    const double x = a[i] / s_sw[h] / sy;  // the reference's operation order
+                    k = (x == x) ? order_key(x) : 0x0000000000000400ull;  // NaN ranks below every number
+                    k = (k & ~0x3FFull) | (uint64_t)h;     // low 10 bits carry the latent index
+                    if (k < 0x400ull) k |= 0x400ull;       // keep valid keys above the "taken" value 0
+                }
+                key[i] = k;
+            }
+            for (int r = 0; r < Hp; ++r) {
+                uint64_t m = key[0];
+#pragma unroll
+                for (int i = 1; i < VPL; ++i) m = umax64(m, key[i]);
+                m = row_max_u64(m);
+#pragma unroll
+                for (int i = 0; i < VPL; ++i)
+                    if (key[i] == m) key[i] = 0;
+                if (j == Hp - 1 - r) myc = (int)(m & 0x3FFull);
+            }
+            if (live && j < Hp) cand[n * Hp + j] = myc;
+        } else {
+            if (j < Hp) myc = cand[nn * Hp + j];
+        }
+        if (!do_estep) continue;
+
+        // ---------------- candidate block: d_k and G[c_i,c_k] -> LDS ------------------------
+        if (ymu) yn = yn - 2.0 * ymu[nn] + P.mu_sqnorm;
+        int cpos[PM_MAX_HPRIME];  // every lane learns all candidates of its datapoint (row broadcast)
+#pragma unroll
+        for (int k = 0; k < PM_MAX_HPRIME; ++k)
+            cpos[k] = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc);
+        if (j < Hp) {
+            const int c = myc;
+            const double ac = arow[c] - (wmu ? wmu[c] : 0.0);
+            s_d[j] = gram[(int64_t)c * H + c] - 2.0 * ac;
+        }
+        for (int p = j; p < Hp * Hp; p += 16) {
+            const int i = p / Hp, k = p - i * Hp;
+            int ci = 0, ck = 0;
+#pragma unroll
+            for (int q = 0; q < PM_MAX_HPRIME; ++q) {
+                ci = (q == i) ? cpos[q] : ci;
+                ck = (q == k) ? cpos[q] : ck;
+            }
+            s_G[p] = gram[(int64_t)ci * H + ck];
+        }
+        wave_lds_sync16();
+
+        // ---------------- multi-cause energies by size --------------------------------------
+        for (int g = 2; g <= gamma; ++g) {
+            for (int s = so.off[g - 2] + j; s < so.off[g - 1]; s += 16) {
+                const uint32_t t = s_tab[s];
+                const unsigned mask = t & 0xFFFFu;
+                const int k = 31 - __builtin_clz(mask);  // highest candidate position of the state
+                unsigned rest = mask & ~(1u << k);
+                double e = s_d[k];
+                if (g == 2) {
+                    const int i = __builtin_ctz(rest);
+                    e += s_d[i] + 2.0 * s_G[i * Hp + k];
+                } else {
+                    e += s_e[t >> 16];
+                    double off = 0.0;
+                    while (rest) {
+                        const int i = __builtin_ctz(rest);
+                        rest &= rest - 1;
+                        off += s_G[i * Hp + k];
+                    }
+                    e += 2.0 * off;
+                }
+                s_e[s] = e;
+            }
+            wave_lds_sync16();
+        }
+
+        // ---------------- log-pseudo-joints ---------------------------------------------------
+        double *out = logpj + nn * ldl;
+        double f1[VPL];
+        double mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            double f = -INFINITY;
+            if (h < H) {
+                const double e = s_w2[h] - 2.0 * a[i] + yn;
+                f = ppil + P.ecoef * e;
+                if (live) out[1 + h] = f;
+            }
+            f1[i] = f;
+            mx = fmax(mx, f);
+        }
+        const double f0 = P.ecoef * yn;
+        if (j == 0) {
+            if (live) out[0] = f0;
+            mx = fmax(mx, f0);
+        }
+        for (int s = j; s < S; s += 16) {
+            const unsigned mask = s_tab[s] & 0xFFFFu;
+            const double f = ppil * (double)__builtin_popcount(mask) + P.ecoef * (yn + s_e[s]);
+            if (live) out[1 + H + s] = f;
+            s_e[s] = f;  // kept for the log-sum-exp pass (same lane re-reads it)
+            mx = fmax(mx, f);
+        }
+        if (!lse) {
+            wave_lds_sync16();
+            continue;
+        }
+        mx = row_max_f64(mx);
+        double sum = (j == 0) ? exp(f0 - mx) : 0.0;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const double dlt = f1[i] - mx;
+            const bool need = dlt > NEGLIGIBLE;
+            if (__any(need)) sum += need ? exp(dlt) : 0.0;
+        }
+        for (int s0 = 0; s0 < S; s0 += 16) {  // uniform trip count
+            const int s = s0 + j;
+            const double dlt = (s < S) ? s_e[s] - mx : -INFINITY;
+            const bool need = dlt > NEGLIGIBLE;
+            if (__any(need)) sum += need ? exp(dlt) : 0.0;
+        }
+        sum = row_sum_f64(sum);
+        if (live && j == 0) lse[n] = mx + log(sum);
+        wave_lds_sync16();  // per-datapoint LDS areas are reused by the next group
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// M_step, per-datapoint part
+// ---------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void bsc_mstep_rows16_kernel(
+    const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
+    const int32_t *__restrict__ cand, const uint16_t *__restrict__ masks, int S, pm_bsc_estep_params P, int64_t N,
+    int H, int D, int Hp, double *__restrict__ expect, int64_t lde, double *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [ qdiag (H) | mus (H) | per datapoint: m2 (Hp*Hp) | red (3*4) | masks (S) ]
+    double *s_qdiag = reinterpret_cast<double *>(smem);
+    double *s_mus = s_qdiag + H;
+    double *s_m2all = s_mus + H;
+    double *s_red = s_m2all + ROWS * Hp * Hp;
+    uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_red + 12);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, row = lane >> 4;
+    for (int h = tid; h < H; h += 256) {
+        s_qdiag[h] = 0.0;
+        s_mus[h] = 0.0;
+    }
+    for (int s = tid; s < S; s += 256) s_masks[s] = masks[s];
+    double *s_m2 = s_m2all + (wave * 4 + row) * Hp * Hp;
+    for (int p = j; p < Hp * Hp; p += 16) s_m2[p] = 0.0;
+    __syncthreads();
+
+    double *Wq = stats + pm_bsc_stats_offset_wq_dev(H, D);
+    const double ppil = P.prior_scale * P.pil_bar;
+    const double inv_ecoef = 1.0 / P.ecoef;
+    const double qcut = -50.0;  // exp(-50) ~ 2e-22: below every statistic's rounding
+
+    double qd[VPL], mu_acc[VPL];  // column sums of q1 and of E[s] over this lane's datapoints
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) qd[i] = mu_acc[i] = 0.0;
+    double sig = 0.0, fs = 0.0, cnt = 0.0;
+
+    const int64_t groups = (N + ROWS - 1) / ROWS;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int64_t n = grp * ROWS + wave * 4 + row;
+        const bool live = n < N;
+        const int64_t nn = live ? n : N - 1;
+        const double l = lse[nn];
+        const bool keep = live && (l >= lse_cut);  // uniform per DPP row
+        double *erow = expect + nn * lde;
+        const double *f = logpj + nn * ldl;
+
+        int myc = (j < Hp) ? cand[nn * Hp + j] : 0;
+        int cpos[PM_MAX_HPRIME];
+#pragma unroll
+        for (int k = 0; k < PM_MAX_HPRIME; ++k)
+            cpos[k] = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc);
+
+        double es[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            double q = 0.0;
+            if (keep && h < H) {
+                const double fh = f[1 + h];
+                const double dlt = fh - l;
+                if (dlt > qcut) {
+                    q = exp(dlt);
+                    sig += q * ((fh - ppil) * inv_ecoef);
+                }
+            }
+            es[i] = q;
+            qd[i] += q;
+        }
+        if (keep && j == 0) {
+            const double f0 = f[0];
+            const double dlt = f0 - l;
+            if (dlt > qcut) sig += exp(dlt) * (f0 * inv_ecoef);
+            fs += l;
+            cnt += 1.0;
+        }
+        // multi-cause states: only the few with a non-negligible posterior touch the moments
+        if (keep) {
+            for (int s = j; s < S; s += 16) {
+                const double fv = f[1 + H + s];
+                const double dlt = fv - l;
+                if (dlt > qcut) {
+                    const unsigned mask = s_masks[s];
+                    const double q = exp(dlt);
+                    sig += q * ((fv - ppil * (double)__builtin_popcount(mask)) * inv_ecoef);
+                    unsigned mi = mask;
+                    while (mi) {
+                        const int i = __builtin_ctz(mi);
+                        mi &= mi - 1;
+                        atomicAdd(&s_m2[i * Hp + i], q);
+                        unsigned mk = mi;
+                        while (mk) {
+                            const int k = __builtin_ctz(mk);
+                            mk &= mk - 1;
+                            atomicAdd(&s_m2[i * Hp + k], q);  // i < k: upper triangle
+                        }
+                    }
+                }
+            }
+        }
+        wave_lds_sync16();
+        // scatter E[s_i s_k] of the candidate block into Wq (upper triangle), add E[s_c] to the row
+        for (int p = j; p < Hp * Hp; p += 16) {
+            const int i = p / Hp, k = p - i * Hp;
+            const double m2 = s_m2[p];
+            if (k >= i && m2 != 0.0) {
+                int ci = 0, ck = 0;
+#pragma unroll
+                for (int q = 0; q < PM_MAX_HPRIME; ++q) {
+                    ci = (q == i) ? cpos[q] : ci;
+                    ck = (q == k) ? cpos[q] : ck;
+                }
+                const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
+                pm_atomic_add(Wq + (int64_t)lo * H + hi, m2);
+            }
+        }
+        // E[s_c] = q1_c + sum_{s containing c} q_s: the owner lane of latent c adds the diagonal term
+#pragma unroll
+        for (int k = 0; k < PM_MAX_HPRIME; ++k) {
+            if (k < Hp) {
+                const int c = cpos[k];
+                const double m1 = s_m2[k * Hp + k];
+                if ((c & 15) == j) {
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i)
+                        if ((c >> 4) == i) es[i] += m1;
+                }
+            }
+        }
+        wave_lds_sync16();
+        for (int p = j; p < Hp * Hp; p += 16) s_m2[p] = 0.0;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            if (live && h < H) erow[h] = es[i];
+            mu_acc[i] += es[i];
+        }
+        wave_lds_sync16();
+    }
+
+    // column sums: rows of a wavefront, then wavefronts of the workgroup, then one atomic per latent
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int h = j + 16 * i;
+        if (h < H) {
+            atomicAdd(&s_qdiag[h], qd[i]);
+            atomicAdd(&s_mus[h], mu_acc[i]);
+        }
+    }
+    sig = pm_wave_sum(sig);
+    fs = pm_wave_sum(fs);
+    cnt = pm_wave_sum(cnt);
+    if (lane == 0) {
+        s_red[wave * 3 + 0] = sig;
+        s_red[wave * 3 + 1] = fs;
+        s_red[wave * 3 + 2] = cnt;
+    }
+    __syncthreads();
+    double *sc = stats + pm_bsc_stats_offset_scalars_dev(H, D);
+    if (tid < 3) {
+        double v = 0.0;
+        for (int w = 0; w < 4; ++w) v += s_red[w * 3 + tid];
+        if (v != 0.0) pm_atomic_add(sc + tid, v);
+    }
+    double *g_qdiag = stats + pm_bsc_stats_offset_qdiag_dev(H, D);
+    double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, D);
+    for (int h = tid; h < H; h += 256) {
+        const double a = s_qdiag[h], b = s_mus[h];
+        if (a != 0.0) pm_atomic_add(g_qdiag + h, a);
+        if (b != 0.0) pm_atomic_add(g_mus + h, b);
+    }
+}
+
+inline int64_t grid_groups(int64_t N) {
+    const int64_t groups = (N + ROWS - 1) / ROWS;
+    const int64_t cap = 256 * 8;
+    return groups < cap ? (groups < 1 ? 1 : groups) : cap;
+}
+
+static int allow_lds16(const void *kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    return (int)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+// The fast path covers H <= 512 (VPL <= 32 scores per lane) and states that fit the LDS areas.
+extern "C" int pm_bsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S) {
+    if (H <= 0 || H > 512 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || Hprime > H || S < 0) return 0;
+    const size_t shmem = sizeof(double) * (2 * H + ROWS * (16 + Hprime * Hprime + S)) + sizeof(uint32_t) * S;
+    return shmem <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
+                                       const double *wmu, const double *ymu, const uint16_t *state_masks,
+                                       const uint16_t *state_parents, const int32_t *size_offsets_host, int64_t S,
+                                       int64_t gamma, const pm_bsc_estep_params *params_host, int64_t N, int64_t H,
+                                       int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl,
+                                       double *lse, void *stream) {
+    if (!scores || !gram || !ynorm2 || !cand || N < 0 || H <= 0 || Hprime <= 0 || S < 0 || lds < H ||
+        !(mode & 3) || ((wmu == nullptr) != (ymu == nullptr)))
+        return PM_EINVAL;
+    if ((mode & 2) && (!params_host || !logpj || ldl < 1 + H + S || gamma < 1 || gamma > Hprime ||
+                       (S > 0 && (!state_masks || !state_parents || !size_offsets_host))))
+        return PM_EINVAL;
+    if (!pm_bsc_rows16_supported(H, Hprime, S)) return PM_ERANGE;
+    if (N == 0) return PM_OK;
+    SizeOffsets so;
+    for (int g = 0; g < PM_MAX_HPRIME; ++g) so.off[g] = (int)S;
+    if ((mode & 2) && S > 0)
+        for (int g = 0; g < gamma; ++g) so.off[g] = size_offsets_host[g];  // off[g-2] = first state of size g
+    pm_bsc_estep_params P = params_host ? *params_host : pm_bsc_estep_params{0, 0, 0, 0};
+    const size_t shmem = sizeof(double) * (2 * H + ROWS * (16 + Hprime * Hprime + S)) + sizeof(uint32_t) * S;
+    dim3 grid((unsigned)grid_groups(N)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PM_LAUNCH(V)                                                                                                 \
+    do {                                                                                                             \
+        if (int e = allow_lds16(reinterpret_cast<const void *>(bsc_select_estep16_kernel<V>), shmem)) return e;      \
+        hipLaunchKernelGGL(bsc_select_estep16_kernel<V>, grid, block, shmem, s, scores, lds, gram, ynorm2, wmu, ymu, \
+                           state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H, (int)Hprime, mode,     \
+                           cand, logpj, ldl, lse);                                                                  \
+    } while (0)
+    if (H <= 16) PM_LAUNCH(1);
+    else if (H <= 32) PM_LAUNCH(2);
+    else if (H <= 64) PM_LAUNCH(4);
+    else if (H <= 128) PM_LAUNCH(8);
+    else if (H <= 256) PM_LAUNCH(16);
+    else PM_LAUNCH(32);
+#undef PM_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                                       const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                                       const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D,
+                                       int64_t Hprime, double *expect, int64_t lde, double *stats, void *stream) {
+    if (!logpj || !lse || !cand || !params_host || !expect || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 ||
+        S < 0 || ldl < 1 + H + S || lde < H || (S > 0 && !state_masks))
+        return PM_EINVAL;
+    if (!pm_bsc_rows16_supported(H, Hprime, S)) return PM_ERANGE;
+    if (N == 0) return PM_OK;
+    const size_t shmem = sizeof(double) * (2 * H + ROWS * Hprime * Hprime + 12) + sizeof(uint16_t) * S;
+    dim3 grid((unsigned)grid_groups(N)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PM_LAUNCH(V)                                                                                               \
+    do {                                                                                                           \
+        if (int e = allow_lds16(reinterpret_cast<const void *>(bsc_mstep_rows16_kernel<V>), shmem)) return e;      \
+        hipLaunchKernelGGL(bsc_mstep_rows16_kernel<V>, grid, block, shmem, s, logpj, ldl, lse, lse_cut, cand,      \
+                           state_masks, (int)S, *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats); \
+    } while (0)
+    if (H <= 16) PM_LAUNCH(1);
+    else if (H <= 32) PM_LAUNCH(2);
+    else if (H <= 64) PM_LAUNCH(4);
+    else if (H <= 128) PM_LAUNCH(8);
+    else if (H <= 256) PM_LAUNCH(16);
+    else PM_LAUNCH(32);
+#undef PM_LAUNCH
+    return (int)hipGetLastError();
+}

@@ -3,13 +3,24 @@
 //   gemm_nt : C[M,N]  = A[M,K] . B[N,K]^T   scores a = Y.W^T and Gram G = W.W^T
 //   gemm_tn : C[M,N] += A[K,M]^T . B[K,N]   Wp = E[s]^T . Y, split over the datapoint index
 //
-// Tiling (both): 128x128 output tile per 256-thread workgroup = 4 wavefronts in a 2x2 grid,
-// each wavefront owns 64x64 = 4x4 MFMA tiles of 16x16 (accumulators: 16 x 4 f64 = 128 VGPRs),
-// K advanced in steps of 16 through two LDS buffers: the global loads of tile t+1 are issued
-// before the MFMAs of tile t and written to the other buffer after them, one barrier per step.
-// An f64 MFMA occupies the matrix pipe for 64 cycles, so one wavefront issues 64 MFMAs
-// (4096 cycles) per K-step against 8 16-byte global loads, 8 LDS writes and 32 ds_read_b64:
-// the loop is matrix-pipe bound by construction.
+// Hardware facts these kernels are built on (measured on MI355X, scratch/mfma_peak*.hip):
+//   * v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD with its accumulator in ARCH VGPRs
+//     (77.2 TF/s chip-wide = 98 % of the 78.6 TF/s datasheet peak, clock holds ~2.39 GHz); with
+//     the accumulator in AGPRs the same stream runs 2.1x slower (138 cycles).  Accumulators are
+//     therefore kept in arch VGPRs (__launch_bounds__(256, 2) => <= 256 VGPRs, no AGPR spill).
+//   * between two MFMAs of one wavefront ~56 issue cycles are free: global loads, LDS traffic and
+//     address arithmetic placed there cost nothing; only what sits outside the MFMA stream
+//     (barrier skew, un-overlapped LDS latency, a partially filled last round of workgroups) does.
+//
+// Tiling: 128x128 output tile per 256-thread workgroup = 4 wavefronts in a 2x2 grid, each
+// wavefront owns (16 MT)x64 = MT x 4 MFMA tiles (MT = 4 for the main grid; MT = 2 / 1 give 64- and
+// 32-row tiles for the ragged last round, see launch_nt), K advanced 16 at a time through two LDS
+// buffers, two workgroups per CU.  Software pipeline per K-step (4 MFMA k-groups of 4):
+//   k-groups 0..2: ds_read the next k-group's fragments, then MT*4 MFMAs on the current ones
+//   k-group 3    : write the staged registers of K-step t+1 to the other LDS buffer, barrier,
+//                  ds_read K-step t+1's first fragments, issue the global loads of K-step t+2,
+//                  THEN the MFMAs of k-group 3 -- so LDS latency after the barrier and the whole
+//                  global-load issue run in the shadow of 16 MFMAs (1024 pipe cycles).
 //
 // Fragment maps of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md section 3):
 //   A: lane l holds A[i = l & 15][k = l >> 4]      B: lane l holds B[k = l >> 4][j = l & 15]
@@ -25,68 +36,237 @@ namespace {
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int NT_LD = BK + 2;    // LDS row stride (doubles) for K-contiguous tiles: 144 B rows ->
-                                 // the 16 rows x 2 k of one ds_read_b64 half-wave hit 32 distinct bank pairs
-constexpr int TN_LD = BM + 16;   // LDS row stride for K-strided tiles: consecutive k land 32 banks apart
+constexpr int BN = 128, BK = 16;
+constexpr int NT_LD = BK + 2;     // LDS row stride (doubles) of K-contiguous tiles: 144-B rows, so the
+                                  // 16 rows x 2 k of one ds_read_b64 half-wave hit distinct bank pairs
+constexpr int TN_BM = 128;
+constexpr int TN_LD = TN_BM + 16; // LDS row stride of K-strided tiles: consecutive k land 32 banks apart
 
 __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
-// C = A . B^T, A (M,K) and B (N,K) row-major.
+// C = A . B^T, A (M,K) and B (N,K) row-major.  One (32 MT) x 128 tile.
 // ---------------------------------------------------------------------------------------------
-template <bool ALIGNED>
+template <int MT, bool ALIGNED, bool EDGE>
+__device__ __forceinline__ void nt_tile(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
+                                        int64_t ldb, double *__restrict__ C, int64_t ldc, int M, int N, int K,
+                                        int m0, int n0, double *sm) {
+    constexpr int BM = 32 * MT;
+    constexpr int STAGE = (BM + BN) * NT_LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // staging map: thread -> (row = tid/8 + 32 c, k pair = 2 (tid % 8))
+    const int srow = tid >> 3, skc = (tid & 7) * 2;
+    d2 ra[MT], rb[4];
+    const double *pa = A + (int64_t)(m0 + srow) * lda + skc;
+    const double *pb = B + (int64_t)(n0 + srow) * ldb + skc;
+
+    auto gload = [&](int k0) {
+        const int k = k0 + skc;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+            const double *p = pa + (int64_t)(32 * c) * lda + k0;
+            if (!EDGE) {
+                ra[c] = *reinterpret_cast<const d2 *>(p);
+            } else {
+                d2 v = {0.0, 0.0};
+                if (m0 + srow + 32 * c < M) {
+                    if (ALIGNED) {
+                        if (k < K) v = *reinterpret_cast<const d2 *>(p);
+                    } else {
+                        if (k < K) v.x = p[0];
+                        if (k + 1 < K) v.y = p[1];
+                    }
+                }
+                ra[c] = v;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double *p = pb + (int64_t)(32 * c) * ldb + k0;
+            if (!EDGE) {
+                rb[c] = *reinterpret_cast<const d2 *>(p);
+            } else {
+                d2 v = {0.0, 0.0};
+                if (n0 + srow + 32 * c < N) {
+                    if (ALIGNED) {
+                        if (k < K) v = *reinterpret_cast<const d2 *>(p);
+                    } else {
+                        if (k < K) v.x = p[0];
+                        if (k + 1 < K) v.y = p[1];
+                    }
+                }
+                rb[c] = v;
+            }
+        }
+    };
+    auto swrite = [&](int buf) {
+        double *sa = sm + buf * STAGE + srow * NT_LD + skc;
+        double *sb = sa + BM * NT_LD;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) *reinterpret_cast<d2 *>(sa + 32 * c * NT_LD) = ra[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<d2 *>(sb + 32 * c * NT_LD) = rb[c];
+    };
+
+    const int frow = lane & 15, fk = lane >> 4;
+    const int a_off = (wm * 16 * MT + frow) * NT_LD + fk;
+    const int b_off = BM * NT_LD + (wn * 64 + frow) * NT_LD + fk;
+    double fa[2][MT], fb[2][4];
+    auto fread = [&](int buf, int kk, int slot) {
+        const double *sa = sm + buf * STAGE + a_off + kk * 4;
+        const double *sb = sm + buf * STAGE + b_off + kk * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[slot][i] = sa[i * 16 * NT_LD];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[slot][j] = sb[j * 16 * NT_LD];
+    };
+
+    d4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    if (nk > 1) gload(BK);
+    fread(0, 0, 0);
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                fread(buf, kk + 1, (kk + 1) & 1);
+            } else if (t + 1 < nk) {
+                swrite(buf ^ 1);
+                __syncthreads();  // everyone: fragments of K-step t are in registers, K-step t+1 is in LDS
+                fread(buf ^ 1, 0, 0);
+                if (t + 2 < nk) gload((t + 2) * BK);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+        }
+    }
+
+    // epilogue: lane holds C[row = fk + 4 r][col = frow] of each 16x16 tile
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * 16 * MT + i * 16 + fk + 4 * r;
+            if (EDGE && row >= M) continue;
+            double *crow = C + (int64_t)row * ldc + n0 + wn * 64 + frow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!EDGE || n0 + wn * 64 + j * 16 + frow < N) crow[j * 16] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+template <int MT, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *__restrict__ A, int64_t lda,
                                                               const double *__restrict__ B, int64_t ldb,
                                                               double *__restrict__ C, int64_t ldc, int M, int N,
                                                               int K, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) double sm[2][(BM + BN) * NT_LD];
+    constexpr int BM = 32 * MT;
+    __shared__ __attribute__((aligned(16))) double sm[2 * (BM + BN) * NT_LD];
+    const int bn = blockIdx.x % tiles_n, bm = blockIdx.x / tiles_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const bool edge = !ALIGNED || (m0 + BM > M) || (n0 + BN > N) || (K % BK != 0);
+    if (edge)
+        nt_tile<MT, ALIGNED, true>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, sm);
+    else
+        nt_tile<MT, ALIGNED, false>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, sm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C = A . B^T through an LDS-DMA ring (global_load_lds_dwordx4): the fast path of gemm_nt.
+//
+// The register-staged kernel above has ONE K-step of lead time between issuing a tile's global
+// loads and needing them in LDS; measured on MI355X that is not enough (waiting on loads costs
+// 56 -> 72 TF/s).  Here tiles travel HBM/L2 -> LDS directly, no VGPR staging, into a ring of 4
+// stages of 8 K-columns, three K-steps ahead of the MFMAs.  128x128 tile, 4 wavefronts (2x2), two
+// workgroups per CU (64 KB LDS each).
+//
+// Stage image: [A rows 0..127 | B rows 0..127] x 8 doubles (64 B per row), 16 chunks of 1 KB; one
+// wave-instruction moves one chunk (16 rows x 64 B): lane l writes LDS slot l (16 B) = row l/4,
+// position l%4, and fetches k-pair (l%4) ^ ((l/16)%4) of that row -- an XOR swizzle applied on the
+// SOURCE address (the LDS side of an LDS-DMA is linear), undone by the fragment reads, which makes
+// the 16 rows of a ds_read_b64 half-wave hit 16 distinct bank pairs.
+// Per K-step and wavefront: 4 DMA instructions, 16 ds_read_b64, 32 MFMAs, one raw s_barrier placed
+// before the last 16 MFMAs (their operands are already in registers), counted s_waitcnt vmcnt.
+// Rows/columns past M/N are clamped on load (garbage accumulators that are never stored).
+// ---------------------------------------------------------------------------------------------
+constexpr int DK = 8, DSTAGES = 4, DSTAGE = (128 + 128) * DK;  // doubles per stage (16 KB)
+
+#define PM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *__restrict__ A, int64_t lda,
+                                                                  const double *__restrict__ B, int64_t ldb,
+                                                                  double *__restrict__ C, int64_t ldc, int M, int N,
+                                                                  int K, int tiles_n, int kps) {
+    // gridDim.y > 1: split-K -- this workgroup covers K-steps [blockIdx.y*kps, +kps) and ADDS its
+    // partial tile to C with f64 atomics (C zeroed by the launcher)
+    __shared__ __attribute__((aligned(1024))) double sm[DSTAGES * DSTAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bn = blockIdx.x % tiles_n, bm = blockIdx.x / tiles_n;
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int m0 = bm * 128, n0 = bn * 128;
 
-    // staging map: thread -> (row = tid/8 + 32 c, k pair = 2 (tid % 8)), c = 0..3
-    const int srow = tid >> 3, skc = (tid & 7) * 2;
-    d2 ra[4], rb[4];
-
-    auto gload = [&](int k0) {
+    // DMA sources: this wavefront moves chunks {wave, wave+4} of A and of B
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((lane >> 4) & 3);
+    const double *src[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int r = srow + 32 * c;
-            const int k = k0 + skc;
-            d2 va = {0.0, 0.0}, vb = {0.0, 0.0};
-            if (ALIGNED) {
-                if (m0 + r < M && k < K) va = *reinterpret_cast<const d2 *>(A + (int64_t)(m0 + r) * lda + k);
-                if (n0 + r < N && k < K) vb = *reinterpret_cast<const d2 *>(B + (int64_t)(n0 + r) * ldb + k);
-            } else {
-                if (m0 + r < M) {
-                    const double *p = A + (int64_t)(m0 + r) * lda + k;
-                    if (k < K) va.x = p[0];
-                    if (k + 1 < K) va.y = p[1];
-                }
-                if (n0 + r < N) {
-                    const double *p = B + (int64_t)(n0 + r) * ldb + k;
-                    if (k < K) vb.x = p[0];
-                    if (k + 1 < K) vb.y = p[1];
-                }
-            }
-            ra[c] = va;
-            rb[c] = vb;
-        }
+    for (int q = 0; q < 2; ++q) {
+        int ra = m0 + 16 * (wave + 4 * q) + dr, rb = n0 + 16 * (wave + 4 * q) + dr;
+        ra = ra < M ? ra : M - 1;
+        rb = rb < N ? rb : N - 1;
+        src[q] = A + (int64_t)ra * lda + 2 * dj;
+        src[2 + q] = B + (int64_t)rb * ldb + 2 * dj;
+    }
+    const int kt0 = blockIdx.y * kps;
+    auto dma = [&](int kt, int stage) {
+        double *dst = sm + stage * DSTAGE + wave * 128;  // chunk = 128 doubles
+        const int k0 = (kt0 + kt) * DK;
+        __builtin_amdgcn_global_load_lds(src[0] + k0, dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src[1] + k0, dst + 4 * 128, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src[2] + k0, dst + 8 * 128, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src[3] + k0, dst + 12 * 128, 16, 0, 0);
     };
-    auto swrite = [&](int buf) {
-        double *sa = sm[buf], *sb = sm[buf] + BM * NT_LD;
+
+    // fragment reads: element q = kk*4 + fk of row R sits at R*8 + (((q>>1) ^ ((R>>2)&3)) << 1) + (q&1)
+    const int frow = lane & 15, fk = lane >> 4;
+    const int sw = (frow >> 2) & 3;
+    int a_off[2], b_off[2];  // per kk
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int r = srow + 32 * c;
-            *reinterpret_cast<d2 *>(sa + r * NT_LD + skc) = ra[c];
-            *reinterpret_cast<d2 *>(sb + r * NT_LD + skc) = rb[c];
-        }
+    for (int kk = 0; kk < 2; ++kk) {
+        const int q = kk * 4 + fk;
+        const int col = (((q >> 1) ^ sw) << 1) + (q & 1);
+        a_off[kk] = (wm * 64 + frow) * DK + col;
+        b_off[kk] = 128 * DK + (wn * 64 + frow) * DK + col;
+    }
+    double fa[2][4], fb[2][4];
+    auto fread = [&](int stage, int kk, int slot) {
+        const double *sa = sm + stage * DSTAGE + a_off[kk];
+        const double *sb = sm + stage * DSTAGE + b_off[kk];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[slot][i] = sa[i * 16 * DK];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[slot][j] = sb[j * 16 * DK];
     };
 
     d4 acc[4][4];
@@ -95,43 +275,58 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *__res
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
-    const int nk = (K + BK - 1) / BK;
-    gload(0);
-    swrite(0);
-    __syncthreads();
+    int nk = K / DK - kt0;  // host guarantees K % DK == 0
+    nk = nk < kps ? nk : kps;
+    if (nk <= 0) return;
+#pragma unroll
+    for (int t = 0; t < DSTAGES; ++t)
+        if (t < nk) dma(t, t);
+    // this wavefront's part of K-step 0 has landed
+    if (nk >= 4) PM_WAIT_VMCNT(12);
+    else if (nk == 3) PM_WAIT_VMCNT(8);
+    else if (nk == 2) PM_WAIT_VMCNT(4);
+    else PM_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    fread(0, 0, 0);
 
-    const int frow = lane & 15, fk = lane >> 4;
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) gload((t + 1) * BK);
-        const double *sa = sm[t & 1] + (wm * 64 + frow) * NT_LD + fk;
-        const double *sb = sm[t & 1] + BM * NT_LD + (wn * 64 + frow) * NT_LD + fk;
+        const int stage = t & (DSTAGES - 1);
+        fread(stage, 1, 1);
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double a[4], b[4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = sa[i * 16 * NT_LD + kk * 4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = sb[j * 16 * NT_LD + kk * 4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[0][i], fb[0][j], acc[i][j]);
+        if (t + 1 < nk) {
+            // my reads of this stage are done (lgkmcnt) and my share of K-step t+1 has landed (vmcnt);
+            // after the barrier that holds for every wavefront: stage t may be refilled, t+1 may be read
+            const int ahead = nk - t - 2;  // K-steps issued beyond t+1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ahead >= 2) PM_WAIT_VMCNT(8);
+            else if (ahead == 1) PM_WAIT_VMCNT(4);
+            else PM_WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            fread((t + 1) & (DSTAGES - 1), 0, 0);
+            if (t + DSTAGES < nk) dma(t + DSTAGES, stage);
         }
-        if (t + 1 < nk) swrite((t + 1) & 1);
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[1][i], fb[1][j], acc[i][j]);
     }
 
-    // epilogue: lane holds C[row = fk + 4 r][col = frow] of each 16x16 tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * 64 + i * 16 + fk + 4 * r;
             if (row >= M) continue;
+            double *crow = C + (int64_t)row * ldc + n0 + wn * 64 + frow;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wn * 64 + j * 16 + frow;
-                if (col < N) C[(int64_t)row * ldc + col] = acc[i][j][r];
+                if (n0 + wn * 64 + j * 16 + frow < N) {
+                    if (gridDim.y > 1) pm_atomic_add(crow + j * 16, acc[i][j][r]);
+                    else crow[j * 16] = acc[i][j][r];
+                }
             }
         }
     }
@@ -139,58 +334,70 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *__res
 
 // ---------------------------------------------------------------------------------------------
 // C += A^T . B, A (K,M) and B (K,N) row-major; the K range is split over blockIdx.y and the
-// partial tiles are added with f64 atomics (global_atomic_add_f64).
+// partial tiles are added with f64 atomics (global_atomic_add_f64).  Same pipeline as above.
 // ---------------------------------------------------------------------------------------------
-template <bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(const double *__restrict__ A, int64_t lda,
-                                                              const double *__restrict__ B, int64_t ldb,
-                                                              double *__restrict__ C, int64_t ldc, int M, int N,
-                                                              int64_t K, int tiles_n, int64_t k_per_split) {
-    __shared__ __attribute__((aligned(16))) double sm[2][2 * BK * TN_LD];
-
+template <bool ALIGNED, bool EDGE>
+__device__ __forceinline__ void tn_tile(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
+                                        int64_t ldb, double *__restrict__ C, int64_t ldc, int M, int N, int64_t kbeg,
+                                        int64_t kend, int m0, int n0, double *sm) {
+    constexpr int STAGE = 2 * BK * TN_LD;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bn = blockIdx.x % tiles_n, bm = blockIdx.x / tiles_n;
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
-    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
-    if (kbeg >= kend) return;
 
     // staging map: thread -> (k = tid/64 + 4 c, column pair = 2 (tid % 64)), c = 0..3
     const int sk = tid >> 6, scol = (tid & 63) * 2;
     d2 ra[4], rb[4];
+    const double *pa = A + m0 + scol;
+    const double *pb = B + n0 + scol;
 
     auto gload = [&](int64_t k0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int64_t k = k0 + sk + 4 * c;
-            d2 va = {0.0, 0.0}, vb = {0.0, 0.0};
-            if (k < kend) {
-                const double *pa = A + k * lda + m0 + scol;
-                const double *pb = B + k * ldb + n0 + scol;
-                if (ALIGNED) {
-                    if (m0 + scol < M) va = *reinterpret_cast<const d2 *>(pa);
-                    if (n0 + scol < N) vb = *reinterpret_cast<const d2 *>(pb);
-                } else {
-                    if (m0 + scol < M) va.x = pa[0];
-                    if (m0 + scol + 1 < M) va.y = pa[1];
-                    if (n0 + scol < N) vb.x = pb[0];
-                    if (n0 + scol + 1 < N) vb.y = pb[1];
+            if (!EDGE) {
+                ra[c] = *reinterpret_cast<const d2 *>(pa + k * lda);
+                rb[c] = *reinterpret_cast<const d2 *>(pb + k * ldb);
+            } else {
+                d2 va = {0.0, 0.0}, vb = {0.0, 0.0};
+                if (k < kend) {
+                    const double *qa = pa + k * lda, *qb = pb + k * ldb;
+                    if (ALIGNED) {
+                        if (m0 + scol < M) va = *reinterpret_cast<const d2 *>(qa);
+                        if (n0 + scol < N) vb = *reinterpret_cast<const d2 *>(qb);
+                    } else {
+                        if (m0 + scol < M) va.x = qa[0];
+                        if (m0 + scol + 1 < M) va.y = qa[1];
+                        if (n0 + scol < N) vb.x = qb[0];
+                        if (n0 + scol + 1 < N) vb.y = qb[1];
+                    }
                 }
+                ra[c] = va;
+                rb[c] = vb;
             }
-            ra[c] = va;
-            rb[c] = vb;
         }
     };
     auto swrite = [&](int buf) {
-        double *sa = sm[buf], *sb = sm[buf] + BK * TN_LD;
+        double *sa = sm + buf * STAGE + sk * TN_LD + scol;
+        double *sb = sa + BK * TN_LD;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int k = sk + 4 * c;
-            *reinterpret_cast<d2 *>(sa + k * TN_LD + scol) = ra[c];
-            *reinterpret_cast<d2 *>(sb + k * TN_LD + scol) = rb[c];
+            *reinterpret_cast<d2 *>(sa + 4 * c * TN_LD) = ra[c];
+            *reinterpret_cast<d2 *>(sb + 4 * c * TN_LD) = rb[c];
         }
+    };
+
+    const int fcol = lane & 15, fk = lane >> 4;
+    const int a_off = fk * TN_LD + wm * 64 + fcol;
+    const int b_off = BK * TN_LD + fk * TN_LD + wn * 64 + fcol;
+    double fa[2][4], fb[2][4];
+    auto fread = [&](int buf, int kk, int slot) {
+        const double *sa = sm + buf * STAGE + a_off + kk * 4 * TN_LD;
+        const double *sb = sm + buf * STAGE + b_off + kk * 4 * TN_LD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[slot][i] = sa[i * 16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[slot][j] = sb[j * 16];
     };
 
     d4 acc[4][4];
@@ -203,26 +410,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(const double *__res
     gload(kbeg);
     swrite(0);
     __syncthreads();
+    if (nk > 1) gload(kbeg + BK);
+    fread(0, 0, 0);
 
-    const int fcol = lane & 15, fk = lane >> 4;
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) gload(kbeg + (int64_t)(t + 1) * BK);
-        const double *sa = sm[t & 1] + fk * TN_LD + wm * 64 + fcol;
-        const double *sb = sm[t & 1] + BK * TN_LD + fk * TN_LD + wn * 64 + fcol;
+        const int buf = t & 1;
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = sa[kk * 4 * TN_LD + i * 16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = sb[kk * 4 * TN_LD + j * 16];
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) {
+                fread(buf, kk + 1, (kk + 1) & 1);
+            } else if (t + 1 < nk) {
+                swrite(buf ^ 1);
+                __syncthreads();
+                fread(buf ^ 1, 0, 0);
+                if (t + 2 < nk) gload(kbeg + (int64_t)(t + 2) * BK);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
         }
-        if (t + 1 < nk) swrite((t + 1) & 1);
-        __syncthreads();
     }
 
 #pragma unroll
@@ -230,14 +437,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(const double *__res
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * 64 + i * 16 + fk + 4 * r;
-            if (row >= M) continue;
+            if (EDGE && row >= M) continue;
+            double *crow = C + (int64_t)row * ldc + n0 + wn * 64 + fcol;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wn * 64 + j * 16 + fcol;
-                if (col < N) pm_atomic_add(C + (int64_t)row * ldc + col, acc[i][j][r]);
+                if (!EDGE || n0 + wn * 64 + j * 16 + fcol < N) pm_atomic_add(crow + j * 16, acc[i][j][r]);
             }
         }
     }
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(const double *__restrict__ A, int64_t lda,
+                                                              const double *__restrict__ B, int64_t ldb,
+                                                              double *__restrict__ C, int64_t ldc, int M, int N,
+                                                              int64_t K, int tiles_n, int64_t k_per_split) {
+    __shared__ __attribute__((aligned(16))) double sm[2 * 2 * BK * TN_LD];
+    const int bn = blockIdx.x % tiles_n, bm = blockIdx.x / tiles_n;
+    const int m0 = bm * TN_BM, n0 = bn * BN;
+    const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    if (kbeg >= kend) return;
+    const bool edge = !ALIGNED || (m0 + TN_BM > M) || (n0 + BN > N) || ((kend - kbeg) % BK != 0);
+    if (edge)
+        tn_tile<ALIGNED, true>(A, lda, B, ldb, C, ldc, M, N, kbeg, kend, m0, n0, sm);
+    else
+        tn_tile<ALIGNED, false>(A, lda, B, ldb, C, ldc, M, N, kbeg, kend, m0, n0, sm);
 }
 
 // out[n] = sum_d Y[n,d]^2; one wavefront per row, lanes stride the row.
@@ -257,22 +482,81 @@ __global__ __launch_bounds__(256) void row_sqnorm_f64_kernel(const double *__res
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int resident_slots() {  // workgroups of these kernels resident at once: 2 per CU
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        slots = 2 * cus;
+    }
+    return slots;
+}
+
+template <int MT>
+void launch_nt_mt(bool al, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int M,
+                  int N, int K, hipStream_t s) {
+    const int tiles_m = (M + 32 * MT - 1) / (32 * MT), tiles_n = (N + BN - 1) / BN;
+    dim3 grid((unsigned)((int64_t)tiles_m * tiles_n)), block(256);
+    if (al)
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<MT, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<MT, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K,
+                           tiles_n);
+}
+
+// LDS-DMA kernel over M rows; nsplit > 1 zeroes C and splits K over grid.y
+void launch_nt_dma(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int M, int N,
+                   int K, int nsplit, hipStream_t s) {
+    const int tiles_m = (M + 127) / 128, tiles_n = (N + BN - 1) / BN;
+    const int nk = K / DK;
+    int kps = (nk + nsplit - 1) / nsplit;
+    nsplit = (nk + kps - 1) / kps;
+    if (nsplit > 1) (void)hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)N * sizeof(double), (size_t)M, s);
+    dim3 grid((unsigned)((int64_t)tiles_m * tiles_n), (unsigned)nsplit), block(256);
+    hipLaunchKernelGGL(gemm_nt_f64_dma_kernel, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, kps);
+}
+
 }  // namespace
 
 extern "C" int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                               int64_t M, int64_t N, int64_t K, void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldb < K || ldc < N) return PM_EINVAL;
     if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return PM_ERANGE;
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     const bool al = aligned16(A) && aligned16(B) && (lda % 2 == 0) && (ldb % 2 == 0) && (K % 2 == 0);
-    dim3 grid((unsigned)(tiles_m * (int64_t)tiles_n)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (al)
-        hipLaunchKernelGGL(gemm_nt_f64_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
-                           tiles_n);
+
+    // Workgroups resident at once ("slots", 2 per CU) process the grid in rounds.  Whole rounds of
+    // 128x128 tiles run un-split; the ragged remainder (and any problem smaller than one round, e.g.
+    // the H x H Gram matrix) is split over K so that it still covers the chip for a fraction of a
+    // round instead of leaving most CUs idle for a whole one.
+    const int slots = resident_slots();
+    const int64_t tiles_n = (N + BN - 1) / BN;
+    if (al && K % DK == 0) {
+        const int64_t panels = (M + 127) / 128;
+        const int64_t per_round = slots / tiles_n > 0 ? slots / tiles_n : 1;
+        const int64_t main_panels = (M / 128) / per_round * per_round;
+        const int64_t rest_rows = M - main_panels * 128;
+        if (main_panels > 0) launch_nt_dma(A, lda, B, ldb, C, ldc, (int)(main_panels * 128), (int)N, (int)K, 1, s);
+        if (rest_rows > 0) {
+            const int64_t rest_tiles = (panels - main_panels) * tiles_n;
+            int64_t nsplit = slots / rest_tiles;           // fill the slots once
+            const int64_t max_split = (K / DK) / 8;        // at least 8 K-steps per workgroup
+            if (nsplit > max_split) nsplit = max_split;
+            if (nsplit < 1 || rest_tiles * 10 >= (int64_t)slots * 7) nsplit = 1;
+            launch_nt_dma(A + main_panels * 128 * lda, lda, B, ldb, C + main_panels * 128 * ldc, ldc, (int)rest_rows,
+                          (int)N, (int)K, (int)nsplit, s);
+        }
+        return (int)hipGetLastError();
+    }
+    // register-staged kernels: any alignment, any K; small tiles for small problems
+    const int64_t t128 = (M + 127) / 128 * tiles_n;
+    if (t128 * 2 <= slots && M > 32)
+        (M + 31) / 32 * tiles_n <= slots ? launch_nt_mt<1>(al, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, s)
+                                         : launch_nt_mt<2>(al, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, s);
     else
-        hipLaunchKernelGGL(gemm_nt_f64_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K,
-                           tiles_n);
+        launch_nt_mt<4>(al, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, s);
     return (int)hipGetLastError();
 }
 
@@ -281,10 +565,12 @@ extern "C" int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B,
     if (!A || !B || !C || M <= 0 || N <= 0 || K < 0 || lda < M || ldb < N || ldc < N) return PM_EINVAL;
     if (M > INT32_MAX || N > INT32_MAX) return PM_ERANGE;
     if (K == 0) return PM_OK;
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+    const int tiles_m = (int)((M + TN_BM - 1) / TN_BM), tiles_n = (int)((N + BN - 1) / BN);
     const int64_t tiles = (int64_t)tiles_m * tiles_n;
-    // enough K-splits to put ~4 workgroups on every CU, at least 8 K-steps each
-    int64_t nsplit = (1024 + tiles - 1) / tiles;
+    // K-splits: whole rounds of resident workgroups (2 per CU), at least 8 K-steps each
+    const int slots = resident_slots();
+    int64_t nsplit = (2 * slots + tiles - 1) / tiles;
+    if (nsplit * tiles > 2 * slots && nsplit > 1) nsplit = 2 * slots / tiles > 0 ? 2 * slots / tiles : 1;
     const int64_t max_split = (K + 8 * BK - 1) / (8 * BK);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;

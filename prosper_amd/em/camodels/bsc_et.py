@@ -126,6 +126,7 @@ class BSC_ET(CAModel):
         self._par = {}           # per-step parameter products: W host copy, Wt, G, scores
         self._ws = {}            # workspaces keyed by name
         self.timer = None        # optional KernelTimer (bench.py)
+        self.use_rows16 = True   # 16-lanes-per-datapoint kernels when the shape allows (tests flip this)
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -158,7 +159,7 @@ class BSC_ET(CAModel):
     def _state_tables(self):
         """Upload the truncated state table: 16-bit masks + CSR lists of the multi-cause
         states containing each pair of candidate positions (for E[s s^T])."""
-        key = (self.Hprime, self.gamma, self.no_states)
+        key = (self.Hprime, self.gamma, self.no_states, self.use_rows16)
         if self._tables is not None and self._tables["key"] == key:
             return self._tables
         _lib.load()
@@ -172,9 +173,25 @@ class BSC_ET(CAModel):
                 if SM.size:
                     lst.extend(np.where((SM[:, i] == 1) & (SM[:, j] == 1))[0].tolist())
                 ptr.append(len(lst))
+        # fast path tables: parent state (state minus its highest candidate position) and the
+        # first state index of every size 2..gamma (states are ordered by size)
+        mlist = masks.tolist()
+        index_of = {m: i for i, m in enumerate(mlist)}
+        parents = np.full(len(mlist), 0xFFFF, dtype=np.uint16)
+        for i, m in enumerate(mlist):
+            rest = m & ~(1 << (m.bit_length() - 1))
+            if bin(rest).count("1") >= 2:
+                parents[i] = index_of[rest]
+        sizes = np.array([bin(m).count("1") for m in mlist], dtype=np.int64)
+        size_off = [int(np.searchsorted(sizes, g, side="left")) for g in range(2, self.gamma + 1)] + [len(mlist)]
+        size_off = (size_off + [len(mlist)])[:max(self.gamma, 1)]
         dev = self.device
         self._tables = {
             "key": key,
+            "parents": torch.from_numpy(parents.view(np.int16).copy()).to(dev)
+            if parents.size else torch.zeros(1, dtype=torch.int16, device=dev),
+            "size_off": (ctypes.c_int32 * len(size_off))(*size_off),
+            "fast": bool(_lib.load().pm_bsc_rows16_supported(self.H, Hp, len(mlist))) and self.use_rows16,
             # uint16 payloads travel as int16 tensors (same bytes)
             "masks": torch.from_numpy(np.ascontiguousarray(masks).view(np.int16).copy()).to(dev)
             if masks.size else torch.zeros(1, dtype=torch.int16, device=dev),
@@ -260,7 +277,11 @@ class BSC_ET(CAModel):
         par = self._scores(model_params, res)
         N = res["Y"].shape[0]
         cand = self._buf("cand", (N, self.Hprime), torch.int32)
-        if N:
+        if N and self._state_tables()["fast"]:
+            self._call("select", "pm_bsc_select_estep_f64", _ptr(par["A"]), self.H, _ptr(par["G"]),
+                       _ptr(res["ynorm2"]), None, None, None, None, None, 0, self.gamma, None,
+                       N, self.H, self.Hprime, 1, _ptr(cand), None, 0, None, self._stream())
+        elif N:
             G = par["G"]
             self._call("select", "pm_bsc_select_f64", _ptr(par["A"]), self.H, _ptr(G), self.H + 1, _ptr(res["ynorm2"]),
                       N, self.H, self.Hprime, _ptr(cand), self._stream())
@@ -317,7 +338,12 @@ class BSC_ET(CAModel):
         logpj = self._buf("logpj", (N, K))
         lse = self._buf("lse", (N,))
         tracing.tracepoint("E_step:iterating")
-        if N:
+        if N and tab["fast"]:
+            self._call("estep", "pm_bsc_select_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]),
+                       _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S,
+                       self.gamma, ctypes.byref(P), N, H, Hp, 2, _ptr(cand), _ptr(logpj), K, _ptr(lse),
+                       self._stream())
+        elif N:
             self._call("estep", "pm_bsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]),
                       _ptr(wmu), _ptr(ymu), _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P),
                       N, H, Hp, _ptr(logpj), K, _ptr(lse), self._stream())
@@ -397,7 +423,12 @@ class BSC_ET(CAModel):
         stats.zero_()
         expect = self._buf("expect", (my_N, H))
         P = self._estep_params(anneal, pies, sigma, mu)
-        if my_N:
+        if my_N and tab["fast"]:
+            self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", _ptr(lp), K, _ptr(lse), ctypes.c_double(lse_cut),
+                       _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,
+                       _ptr(stats), self._stream())
+            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, self._stream())
+        elif my_N:
             self._call("mstep_rows", "pm_bsc_mstep_rows_f64", _ptr(lp), K, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand),
                       _ptr(tab["masks"]), S, _ptr(tab["pair_ptr"]), _ptr(tab["pair_states"]), tab["pair_len"],
                       ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats), self._stream())

@@ -90,11 +90,12 @@ class _An(dict):
         return dict(self)
 
 
-def _run_step(g, to_learn=None):
+def _run_step(g, to_learn=None, rows16=True):
     from prosper_amd.em.camodels.bsc_et import BSC_ET
     from prosper_amd.utils.datalog import dlog, StoreInMemory
     to_learn = to_learn or [str(s) for s in g["to_learn"]]
     m = BSC_ET(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]), to_learn=to_learn)
+    m.use_rows16 = rows16    # False: the generic one-wavefront-per-datapoint kernels
     an = _An(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
     params = {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])}
     if bool(g["has_mu"]):
@@ -110,9 +111,11 @@ def _run_step(g, to_learn=None):
 
 
 @pytest.mark.parametrize("case", bsc_step_cases())
-def test_bsc_step_matches_reference_golden(dev, case):
+@pytest.mark.parametrize("rows16", [True, False], ids=["rows16", "wave64"])
+def test_bsc_step_matches_reference_golden(dev, case, rows16):
     g = golden(case)
-    m, params, data, ss, new, log = _run_step(g)
+    m, params, data, ss, new, log = _run_step(g, rows16=rows16)
+    assert m._state_tables()["fast"] == rows16
     cand = np.asarray(data["candidates"])
     assert cand.dtype == np.int64 and np.array_equal(cand, g["candidates"])
     logpj = np.asarray(ss["logpj"])
