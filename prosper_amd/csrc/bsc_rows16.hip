@@ -84,7 +84,7 @@ struct SizeOffsets {  // multi-cause states of size g occupy [off[g-2], off[g-1]
 //   mode bit 1: E-step (write logpj / lse)
 // ---------------------------------------------------------------------------------------------
 template <int VPL>
-__global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
+__global__ __launch_bounds__(256, VPL <= 16 ? 4 : 2) void bsc_select_estep16_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
     const double *__restrict__ ynorm2, const double *__restrict__ wmu, const double *__restrict__ ymu,
     const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents, SizeOffsets so, int S, int gamma,
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
     for (int h = tid; h < H; h += 256) {
         const double g = gram[(int64_t)h * H + h];
         s_w2[h] = g + (wmu ? 2.0 * wmu[h] : 0.0);
-        s_sw[h] = sqrt(g);
+        s_sw[h] = 1.0 / sqrt(g);   // ranking uses a * (1/|W_h|) * (1/|y|): keys keep 42 mantissa bits anyway
     }
     for (int s = tid; s < S; s += 256) s_tab[s] = (uint32_t)masks[s] | ((uint32_t)parents[s] << 16);
     __syncthreads();
@@ -132,14 +132,14 @@ __global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
         // ---------------- top-H' of a / |W_h| / |y| (ascending, best last) -------------------
         int myc = 0;  // lane j < Hp ends up with candidate position j
         if (do_select) {
-            const double sy = sqrt(yn);
+            const double sy = 1.0 / sqrt(yn);
             uint64_t key[VPL];
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 const int h = j + 16 * i;
                 uint64_t k = 0;
                 if (h < H) {
-                    const double x = a[i] / s_sw[h] / sy;  // the reference's operation order
+                    const double x = a[i] * s_sw[h] * sy;
                     k = (x == x) ? order_key(x) : 0x0000000000000400ull;  // NaN ranks below every number
                     k = (k & ~0x3FFull) | (uint64_t)h;     // low 10 bits carry the latent index
                     if (k < 0x400ull) k |= 0x400ull;       // keep valid keys above the "taken" value 0
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
         int cpos[PM_MAX_HPRIME];  // every lane learns all candidates of its datapoint (row broadcast)
 #pragma unroll
         for (int k = 0; k < PM_MAX_HPRIME; ++k)
-            cpos[k] = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc);
+            cpos[k] = (k < Hp) ? __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc) : 0;
         if (j < Hp) {
             const int c = myc;
             const double ac = arow[c] - (wmu ? wmu[c] : 0.0);
@@ -213,10 +213,9 @@ __global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
 
         // ---------------- log-pseudo-joints ---------------------------------------------------
         double *out = logpj + nn * ldl;
-        double f1[VPL];
         double mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
+        for (int i = 0; i < VPL; ++i) {  // a[i] becomes the singleton log-joint of latent h
             const int h = j + 16 * i;
             double f = -INFINITY;
             if (h < H) {
@@ -224,7 +223,7 @@ __global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
                 f = ppil + P.ecoef * e;
                 if (live) out[1 + h] = f;
             }
-            f1[i] = f;
+            a[i] = f;
             mx = fmax(mx, f);
         }
         const double f0 = P.ecoef * yn;
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
         double sum = (j == 0) ? exp(f0 - mx) : 0.0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const double dlt = f1[i] - mx;
+            const double dlt = a[i] - mx;
             const bool need = dlt > NEGLIGIBLE;
             if (__any(need)) sum += need ? exp(dlt) : 0.0;
         }
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(256) void bsc_select_estep16_kernel(
 // M_step, per-datapoint part
 // ---------------------------------------------------------------------------------------------
 template <int VPL>
-__global__ __launch_bounds__(256) void bsc_mstep_rows16_kernel(
+__global__ __launch_bounds__(256, VPL <= 16 ? 3 : 1) void bsc_mstep_rows16_kernel(
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint16_t *__restrict__ masks, int S, pm_bsc_estep_params P, int64_t N,
     int H, int D, int Hp, double *__restrict__ expect, int64_t lde, double *__restrict__ stats) {
@@ -295,9 +294,9 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows16_kernel(
     const double inv_ecoef = 1.0 / P.ecoef;
     const double qcut = -50.0;  // exp(-50) ~ 2e-22: below every statistic's rounding
 
-    double qd[VPL], mu_acc[VPL];  // column sums of q1 and of E[s] over this lane's datapoints
+    double qd[VPL];  // column sums of q1 over this lane's datapoints (mus = these + the candidate terms)
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) qd[i] = mu_acc[i] = 0.0;
+    for (int i = 0; i < VPL; ++i) qd[i] = 0.0;
     double sig = 0.0, fs = 0.0, cnt = 0.0;
 
     const int64_t groups = (N + ROWS - 1) / ROWS;
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows16_kernel(
         int cpos[PM_MAX_HPRIME];
 #pragma unroll
         for (int k = 0; k < PM_MAX_HPRIME; ++k)
-            cpos[k] = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc);
+            cpos[k] = (k < Hp) ? __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc) : 0;
 
         double es[VPL];
 #pragma unroll
@@ -380,6 +379,10 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows16_kernel(
             }
         }
         // E[s_c] = q1_c + sum_{s containing c} q_s: the owner lane of latent c adds the diagonal term
+        if (j < Hp) {
+            const double m1 = s_m2[j * Hp + j];
+            if (m1 != 0.0) atomicAdd(&s_mus[myc], m1);
+        }
 #pragma unroll
         for (int k = 0; k < PM_MAX_HPRIME; ++k) {
             if (k < Hp) {
@@ -398,7 +401,6 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows16_kernel(
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
             if (live && h < H) erow[h] = es[i];
-            mu_acc[i] += es[i];
         }
         wave_lds_sync16();
     }
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows16_kernel(
         const int h = j + 16 * i;
         if (h < H) {
             atomicAdd(&s_qdiag[h], qd[i]);
-            atomicAdd(&s_mus[h], mu_acc[i]);
+            atomicAdd(&s_mus[h], qd[i]);
         }
     }
     sig = pm_wave_sum(sig);

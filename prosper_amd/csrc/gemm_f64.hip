@@ -314,17 +314,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[1][i], fb[1][j], acc[i][j]);
     }
 
+    const bool split = gridDim.y > 1;
+    const bool interior = (m0 + 128 <= M) && (n0 + 128 <= N);
+    double *cbase = C + (int64_t)(m0 + wm * 64 + fk) * ldc + n0 + wn * 64 + frow;
+    if (!split && interior) {  // the common case: plain stores, no guards
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cbase[(int64_t)(i * 16 + 4 * r) * ldc + j * 16] = acc[i][j][r];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * 64 + i * 16 + fk + 4 * r;
             if (row >= M) continue;
-            double *crow = C + (int64_t)row * ldc + n0 + wn * 64 + frow;
+            double *crow = cbase + (int64_t)(i * 16 + 4 * r) * ldc;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (n0 + wn * 64 + j * 16 + frow < N) {
-                    if (gridDim.y > 1) pm_atomic_add(crow + j * 16, acc[i][j][r]);
+                    if (split) pm_atomic_add(crow + j * 16, acc[i][j][r]);
                     else crow[j * 16] = acc[i][j][r];
                 }
             }

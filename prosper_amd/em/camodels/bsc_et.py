@@ -17,6 +17,7 @@ Data stays resident in HBM between EM steps; ``candidates`` and ``logpj`` are re
 There is no CPU fallback for the kernels: without the HIP library / a GPU this raises.
 """
 import ctypes
+import os
 from math import pi as _PI
 
 import numpy as np
@@ -88,6 +89,47 @@ class DeviceArray(object):
         return "DeviceArray(shape=%s, dtype=%s, device=%s)" % (self.shape, self.dtype, self.tensor.device)
 
 
+class LazyCandidates(DeviceArray):
+    """``data['candidates']`` as handed out by the fast path of ``select_Hprimes``: the
+    selection is deferred.  If ``E_step`` is called next with the same parameters (what
+    ``CAModel.step`` / ``compute_lpj`` do) both stages run as ONE fused pass that overlaps with
+    the scores GEMM; if anything looks at the handle first (``np.asarray``, indexing, ``M_step``
+    with foreign log-joints) the candidates are computed on the spot.  Either way the values
+    are those of bsc_et.py:98-115."""
+
+    def __init__(self, model, ticket, shape):
+        self._model = model
+        self._ticket = ticket
+        self._shape = tuple(shape)
+        self._np_dtype = np.dtype(np.int64)
+        self._host = None
+        self.lse = None
+
+    @property
+    def tensor(self):
+        if self._ticket["cand"] is None:
+            self._model._materialize_candidates(self._ticket)
+        return self._ticket["cand"]
+
+    @property
+    def pending(self):
+        return self._ticket["cand"] is None
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return 2
+
+    def __len__(self):
+        return self._shape[0]
+
+    def __repr__(self):
+        return "LazyCandidates(shape=%s, pending=%s)" % (self._shape, self.pending)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -97,10 +139,17 @@ class KernelTimer(object):
     (torch's current stream, which is the one handed to the C ABI).  bench.py attaches one
     to a model to obtain per-kernel average durations inside the timed region."""
 
-    def __init__(self):
+    def __init__(self, only=None, stride=1):
         self.events = {}
+        self.only = set(only) if only else None    # labels to time (None = all)
+        self.stride = max(1, int(stride))          # time every stride-th launch of a label
+        self._count = {}
 
     def launch(self, label, fn):
+        n = self._count[label] = self._count.get(label, 0) + 1
+        if (self.only is not None and label not in self.only) or (n - 1) % self.stride:
+            fn()
+            return
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         fn()
@@ -127,6 +176,10 @@ class BSC_ET(CAModel):
         self._ws = {}            # workspaces keyed by name
         self.timer = None        # optional KernelTimer (bench.py)
         self.use_rows16 = True   # 16-lanes-per-datapoint kernels when the shape allows (tests flip this)
+        self._side = None        # side stream of the chunked GEMM / row-kernel pipeline
+        self._pin = {}           # pinned staging buffers for asynchronous parameter uploads
+        self.overlap_streams = False   # run GEMM(c+1) beside the row kernel of chunk c (measured: no gain)
+        self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "1"))   # GEMM rounds per pipeline chunk
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -238,23 +291,110 @@ class BSC_ET(CAModel):
                   M, N, K, self._stream())
         return out
 
-    def _scores(self, model_params, res):
-        """A = Y.W^T (N,H) and G = W.W^T for the current W; reused by E_step when
-        select_Hprimes just computed them for the same W and data."""
-        W = np.asarray(model_params['W'])
+    def _upload(self, name, host):
+        """Asynchronous host -> device copy through a rotating pair of pinned staging buffers
+        (a pageable ``.to(device)`` would block the host until the stream drains and stall the
+        EM loop at every step boundary)."""
+        slot = self._pin.setdefault(name, {"i": 0, "bufs": [None, None], "evs": [None, None]})
+        i = slot["i"] = slot["i"] ^ 1
+        buf = slot["bufs"][i]
+        if buf is None or buf.shape != host.shape:
+            buf = slot["bufs"][i] = torch.empty(host.shape, dtype=torch.float64).pin_memory()
+        elif slot["evs"][i] is not None:
+            slot["evs"][i].synchronize()          # the copy that last used this buffer has completed
+        buf.numpy()[...] = host
+        dev = torch.empty(host.shape, dtype=torch.float64, device=self.device)
+        dev.copy_(buf, non_blocking=True)
+        ev = slot["evs"][i] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return dev
+
+    def _params_dev(self, W, res):
+        """Device copy of W^T (H,D) and the Gram matrix G = W.W^T for the current W."""
         par = self._par
         if par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape \
                 and np.array_equal(par["W"], W):
             return par
-        Y = res["Y"]
-        N = Y.shape[0]
-        Wt = torch.from_numpy(np.ascontiguousarray(W.T, dtype=np.float64)).to(self.device)   # (H, D)
+        Wt = self._upload("W", np.asarray(W, dtype=np.float64)).t().contiguous()   # (H, D), transposed on device
         G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
-        A = self._buf("scores", (N, self.H))
-        if N:
-            self._gemm_nt(Y, Wt, A, "scores_gemm")
-        self._par = {"ykey": res["key"], "W": W.copy(), "Wt": Wt, "G": G, "A": A}
+        self._par = {"ykey": res["key"], "W": np.array(W, dtype=np.float64, copy=True), "Wt": Wt, "G": G, "A": None}
         return self._par
+
+    def _scores(self, model_params, res):
+        """A = Y.W^T (N,H) and G = W.W^T for the current W; reused by E_step when
+        select_Hprimes just computed them for the same W and data."""
+        par = self._params_dev(np.asarray(model_params['W']), res)
+        if par["A"] is None:
+            Y = res["Y"]
+            N = Y.shape[0]
+            A = self._buf("scores", (N, self.H))
+            if N:
+                self._gemm_nt(Y, par["Wt"], A, "scores_gemm")
+            par["A"] = A
+        return par
+
+    # ---- fused, chunked select + E-step (fast path) -------------------------------------------
+    def _chunk_rows(self):
+        """Rows per pipeline chunk: one round of resident 128x128 GEMM tiles (2 per CU)."""
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        tiles_n = (self.H + 127) // 128
+        return max(1, (2 * cus) // tiles_n) * 128 * self.chunk_rounds
+
+    def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None):
+        """Chunked scores GEMM + fused select/E-step kernel.  A chunk is one round of resident GEMM
+        tiles; its (chunk, H) score block is consumed by the row kernel straight away, so the
+        scores never make a round trip through HBM (two alternating buffers, cache resident).
+        ``overlap``: GEMM of chunk c+1 on a side stream while the row kernel of chunk c runs."""
+        Y = res["Y"]
+        N, H, Hp, S = Y.shape[0], self.H, self.Hprime, self.no_states
+        tab = self._state_tables()
+        K = 1 + H + S
+        rows = self._chunk_rows()
+        nchunks = (N + rows - 1) // rows
+        main = torch.cuda.current_stream(self.device)
+        bufs = [self._buf("scores_c0", (rows, H)), self._buf("scores_c1", (rows, H))]
+        overlap = self.overlap_streams and nchunks > 1
+        if overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            side = self._side
+            side.wait_stream(main)
+        else:
+            side = main
+        done = [None, None]
+        for c in range(nchunks):
+            r0, r1 = c * rows, min(N, (c + 1) * rows)
+            A = bufs[c & 1]
+            with torch.cuda.stream(side):
+                if overlap and done[c & 1] is not None:
+                    side.wait_event(done[c & 1])         # the row kernel that read this buffer is finished
+                Yc = Y[r0:r1]
+                self._call("scores_gemm" if r1 - r0 == rows else "scores_gemm_tail", "pm_gemm_nt_f64", _ptr(Yc),
+                           Y.stride(0), _ptr(par["Wt"]), par["Wt"].stride(0), _ptr(A), H, r1 - r0, H, Y.shape[1],
+                           ctypes.c_void_p(side.cuda_stream))
+                if overlap:
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+            if overlap:
+                main.wait_event(ready)
+            off = lambda t, w=1: ctypes.c_void_p(t.data_ptr() + r0 * w * t.element_size()) if t is not None else None
+            self._call("select_estep", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
+                       _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S,
+                       self.gamma, ctypes.byref(P) if P is not None else None, r1 - r0, H, Hp, mode,
+                       off(cand, Hp), off(logpj, K), K, off(lse), ctypes.c_void_p(main.cuda_stream))
+            if overlap:
+                done[c & 1] = torch.cuda.Event()
+                done[c & 1].record(main)
+
+    def _materialize_candidates(self, ticket):
+        """Selection on its own (someone looked at the lazy candidates before E_step ran)."""
+        res = ticket["res"]
+        par = self._params_dev(ticket["W"], res)
+        N = res["Y"].shape[0]
+        cand = torch.empty((N, self.Hprime), dtype=torch.int32, device=self.device)
+        if N:
+            self._run_select_estep(res, par, 1, cand)
+        ticket["cand"] = cand
 
     # ------------------------------------------------------------------ data generation
     @tracing.traced
@@ -274,14 +414,15 @@ class BSC_ET(CAModel):
         """Annotate ``data`` with ``data['candidates']`` (N, Hprime): per datapoint the
         Hprime latents with the largest <W_h,y>/|W_h|/|y|, ascending (bsc_et.py:98-115)."""
         res = self._resident(data['y'])
-        par = self._scores(model_params, res)
         N = res["Y"].shape[0]
-        cand = self._buf("cand", (N, self.Hprime), torch.int32)
-        if N and self._state_tables()["fast"]:
-            self._call("select", "pm_bsc_select_estep_f64", _ptr(par["A"]), self.H, _ptr(par["G"]),
-                       _ptr(res["ynorm2"]), None, None, None, None, None, 0, self.gamma, None,
-                       N, self.H, self.Hprime, 1, _ptr(cand), None, 0, None, self._stream())
-        elif N:
+        if self._state_tables()["fast"]:
+            # deferred: E_step fuses selection with the log-joints in one pass (LazyCandidates)
+            ticket = {"res": res, "W": np.array(model_params['W'], dtype=np.float64, copy=True), "cand": None}
+            data['candidates'] = LazyCandidates(self, ticket, (N, self.Hprime))
+            return data
+        par = self._scores(model_params, res)
+        cand = torch.empty((N, self.Hprime), dtype=torch.int32, device=self.device)
+        if N:
             G = par["G"]
             self._call("select", "pm_bsc_select_f64", _ptr(par["A"]), self.H, _ptr(G), self.H + 1, _ptr(res["ynorm2"]),
                       N, self.H, self.Hprime, _ptr(cand), self._stream())
@@ -329,21 +470,38 @@ class BSC_ET(CAModel):
         except KeyError:
             mu = np.zeros(D)
             model_params['mu'] = mu
-        par = self._scores(model_params, res)
         tab = self._state_tables()
-        cand = self._device_candidates(my_data['candidates'], N)
-        P = self._estep_params(anneal, model_params['pi'], model_params['sigma'], np.asarray(mu, dtype=np.float64))
-        wmu, ymu = self._mu_terms(par, res, np.asarray(mu, dtype=np.float64))
+        W = np.asarray(model_params['W'])
+        mu64 = np.asarray(mu, dtype=np.float64)
+        P = self._estep_params(anneal, model_params['pi'], model_params['sigma'], mu64)
         K = 1 + H + S
-        logpj = self._buf("logpj", (N, K))
-        lse = self._buf("lse", (N,))
+        # results are handed to the caller: fresh tensors (the caching allocator recycles last step's)
+        logpj = torch.empty((N, K), dtype=torch.float64, device=self.device)
+        lse = torch.empty((N,), dtype=torch.float64, device=self.device)
         tracing.tracepoint("E_step:iterating")
-        if N and tab["fast"]:
-            self._call("estep", "pm_bsc_select_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]),
-                       _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S,
-                       self.gamma, ctypes.byref(P), N, H, Hp, 2, _ptr(cand), _ptr(logpj), K, _ptr(lse),
-                       self._stream())
-        elif N:
+        cobj = my_data['candidates']
+        if tab["fast"]:
+            par = self._params_dev(W, res)
+            wmu, ymu = self._mu_terms(par, res, mu64)
+            fuse = (isinstance(cobj, LazyCandidates) and cobj.pending and cobj._model is self
+                    and cobj._ticket["res"] is res and np.array_equal(cobj._ticket["W"], W))
+            if fuse:      # selection + log-joints in one pass
+                cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
+                mode = 3
+            else:
+                cand = self._device_candidates(cobj, N)
+                mode = 2
+            if N:
+                self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse)
+            if fuse:
+                cobj._ticket["cand"] = cand
+            out = DeviceArray(logpj)
+            out.lse = lse
+            return {'logpj': out}
+        par = self._scores(model_params, res)
+        cand = self._device_candidates(cobj, N)
+        wmu, ymu = self._mu_terms(par, res, mu64)
+        if N:
             self._call("estep", "pm_bsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]),
                       _ptr(wmu), _ptr(ymu), _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P),
                       N, H, Hp, _ptr(logpj), K, _ptr(lse), self._stream())
