@@ -178,6 +178,7 @@ class BSC_ET(CAModel):
         self.use_rows16 = True   # 16-lanes-per-datapoint kernels when the shape allows (tests flip this)
         self._side = None        # side stream of the chunked GEMM / row-kernel pipeline
         self._pin = {}           # pinned staging buffers for asynchronous parameter uploads
+        self._pin_out = None     # pinned buffer of the one device->host copy per M-step
         self.overlap_streams = False   # run GEMM(c+1) beside the row kernel of chunk c (measured: no gain)
         self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "1"))   # GEMM rounds per pipeline chunk
 
@@ -605,9 +606,10 @@ class BSC_ET(CAModel):
 
     def _finalize(self, packed, model_params, A_pi_gamma, E_pi_gamma):
         """Parameter updates from the all-reduced statistics (bsc_et.py:264-267, 369-438).
+        Everything is enqueued on the device first (Wq assembly, Cholesky solve, reductions) and
+        fetched with ONE device->host copy, so an EM step synchronises with the GPU exactly once.
         Device-agnostic: ``packed`` may live in HBM (product path) or on the host (the
         world_size-2 gloo tests feed it CPU tensors)."""
-        comm = self.comm
         H, D = self.H, self.D
         W_DH = np.asarray(model_params['W'])
         pies, sigma = model_params['pi'], model_params['sigma']
@@ -620,27 +622,50 @@ class BSC_ET(CAModel):
         Wq_u = packed[o_wq:o_qd].view(H, H)
         qdiag = packed[o_qd:o_mus]
         mus = packed[o_mus:o_sc]
-        scal = packed[o_sc:o_sc + 4].cpu().numpy()
-        my_sigma, Fs, N_use = float(scal[0]), float(scal[1]), int(round(scal[2]))
-        dlog.append('N', N_use)
+        learn_W, learn_mu = 'W' in self.to_learn, 'mu' in self.to_learn
 
+        parts = [packed[o_sc:o_sc + 4], mus.sum().reshape(1)]
+        Wq = rhs = None
+        if learn_W:
+            tracing.tracepoint("M_step:update W")
+            Wq = torch.triu(Wq_u, 1)
+            Wq = Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)
+            rhs = Wp
+            if np.any(mu):   # Wp was accumulated against y, the reference uses y - mu
+                rhs = Wp - torch.outer(mus, torch.from_numpy(mu).to(packed.device))
+            Lc, info = torch.linalg.cholesky_ex(Wq)
+            d = torch.diagonal(Lc)
+            X = torch.cholesky_solve(rhs, Lc)                 # (H, D); garbage if the factorisation failed
+            parts += [info.to(torch.float64).reshape(1), ((d.min() / d.max()) ** 2).reshape(1), X.reshape(-1)]
+        if learn_mu:
+            parts += [mus, packed[n_stats:]]
+        flat = torch.cat(parts)
+        if flat.is_cuda:                                        # the one synchronisation of the EM step
+            host = self._download(flat)
+        else:
+            host = flat.numpy()
+
+        my_sigma, Fs, N_use = float(host[0]), float(host[1]), int(round(host[2]))
+        mus_sum = float(host[4])
+        dlog.append('N', N_use)
         L = H * np.log(1 - pies) - 0.5 * D * np.log(2 * _PI * sigma ** 2) - np.log(A_pi_gamma)
         L += Fs / N_use
         dlog.append('L', L)
 
-        if 'W' in self.to_learn:
-            tracing.tracepoint("M_step:update W")
-            Wq = Wq_u + Wq_u.t() - torch.diag(torch.diagonal(Wq_u)) + torch.diag(qdiag)
-            rhs = Wp
-            if np.any(mu):   # Wp was accumulated against y, the reference uses y - mu
-                rhs = Wp - torch.outer(mus, torch.from_numpy(mu).to(packed.device))
-            W_new = self._solve(Wq, rhs)
+        pos = 5
+        if learn_W:
+            ok = host[pos] == 0 and host[pos + 1] > 1e-11 and np.isfinite(host[pos + 1])
+            if ok:
+                W_new = host[pos + 2:pos + 2 + H * D].reshape(H, D).copy()
+            else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host
+                W_new = np.linalg.lstsq(Wq.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0]
+            pos += 2 + H * D
         else:
             W_new = W_DH.T
 
         if 'pi' in self.to_learn:
             tracing.tracepoint("M_step:update pi")
-            pi_new = E_pi_gamma * float(mus.sum()) / H / N_use
+            pi_new = E_pi_gamma * mus_sum / H / N_use
         else:
             pi_new = pies
 
@@ -650,26 +675,26 @@ class BSC_ET(CAModel):
         else:
             sigma_new = sigma
 
-        if 'mu' in self.to_learn:
+        if learn_mu:
             tracing.tracepoint("M_step:update mu")
             # the reference divides by the rank-local kept count (bsc_et.py:428), which is only
             # meaningful on one rank; with several ranks the global count is used
-            mu_new = packed[n_stats:].cpu().numpy() / N_use - np.inner(W_new.T / N_use, mus.cpu().numpy())
+            mus_h, dsum = host[pos:pos + H], host[pos + H:pos + H + D]
+            mu_new = dsum / N_use - np.inner(W_new.T / N_use, mus_h)
         else:
             mu_new = mu
 
         dlog.append('N_use', N_use)
         return {'W': W_new.T, 'pi': pi_new, 'sigma': sigma_new, 'mu': mu_new}
 
-    def _solve(self, Wq, Wp):
-        """W_new = argmin |Wq X - Wp| (np.linalg.lstsq at bsc_et.py:380).  Wq is a sum of
-        second moments (symmetric PSD): Cholesky on the device; when it is numerically
-        singular fall back to the reference's own LAPACK lstsq on the host."""
-        Lc, info = torch.linalg.cholesky_ex(Wq)
-        ok = int(info) == 0
-        if ok:
-            d = torch.diagonal(Lc)
-            ok = bool((d.min() / d.max()) ** 2 > 1e-11)
-        if ok:
-            return torch.cholesky_solve(Wp, Lc).cpu().numpy()
-        return np.linalg.lstsq(Wq.cpu().numpy(), Wp.cpu().numpy(), rcond=None)[0]
+    def _download(self, flat):
+        """Device -> pinned host copy + wait; returns a NumPy view valid until the next call."""
+        n = flat.numel()
+        if self._pin_out is None or self._pin_out.numel() < n:
+            self._pin_out = torch.empty(n, dtype=torch.float64).pin_memory()
+        dst = self._pin_out[:n]
+        dst.copy_(flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ev.synchronize()
+        return dst.numpy()
