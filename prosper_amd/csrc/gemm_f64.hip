@@ -213,6 +213,7 @@ constexpr int DK = 8, DSTAGES = 4, DSTAGE = (128 + 128) * DK;  // doubles per st
 
 #define PM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+template <bool SPLITK>  // SPLITK: grid.y K-slices added to a zeroed C with atomics (own kernel name in profiles)
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *__restrict__ A, int64_t lda,
                                                                   const double *__restrict__ B, int64_t ldb,
                                                                   double *__restrict__ C, int64_t ldc, int M, int N,
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[1][i], fb[1][j], acc[i][j]);
     }
 
-    const bool split = gridDim.y > 1;
+    constexpr bool split = SPLITK;
     const bool interior = (m0 + 128 <= M) && (n0 + 128 <= N);
     double *cbase = C + (int64_t)(m0 + wm * 64 + fk) * ldc + n0 + wn * 64 + frow;
     if (!split && interior) {  // the common case: plain stores, no guards
@@ -527,7 +528,10 @@ void launch_nt_dma(const double *A, int64_t lda, const double *B, int64_t ldb, d
     nsplit = (nk + kps - 1) / kps;
     if (nsplit > 1) (void)hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)N * sizeof(double), (size_t)M, s);
     dim3 grid((unsigned)((int64_t)tiles_m * tiles_n), (unsigned)nsplit), block(256);
-    hipLaunchKernelGGL(gemm_nt_f64_dma_kernel, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, kps);
+    if (nsplit > 1)
+        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, kps);
+    else
+        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, kps);
 }
 
 }  // namespace
