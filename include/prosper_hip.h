@@ -153,6 +153,51 @@ int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse,
                             const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D,
                             int64_t Hprime, double *expect, int64_t lde, double *stats, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Maximal Causes Analysis (prosper/em/camodels/mca_et.py)
+ * ------------------------------------------------------------------------------------- */
+
+/* R[n,h] = sum_d max(W[h,d] - Y[n,d], 0) = sum_d |max(W_hd, y_d) - y_d|: the candidate-selection
+ * score of mca_et.py:104-106 (W (H,D) row-major).  Candidates = the Hprime SMALLEST per row,
+ * ascending: pm_bsc_select_estep_f64 with mode = 1|4|8 (select, smallest-first, raw scores). */
+int pm_mca_select_scores_f64(const double *Y, int64_t ldy, const double *W, int64_t ldw, double *R,
+                             int64_t ldr, int64_t N, int64_t H, int64_t D, void *stream);
+
+/* Scalars of one MCA step (mca_et.py:142-149, 213-221). */
+typedef struct pm_mca_params {
+    double pil_bar;   /* log(pi / (1 - pi))                                 */
+    double pre1;      /* -1 / (2 sigma^2)                                   */
+    double beta;      /* 1 / T (applied to the log-joints in the M-step)    */
+    double inv_rho;   /* 1 / rho, rho = 1 / (1 - 1 / max(T, 1.05))          */
+} pm_mca_params;
+
+/* E_step, mca_et.py:114-179.  scores = Y.W^T (pm_gemm_nt_f64), wnorm2 = |W_h|^2 (contiguous),
+ * Wrho = W^rho (H,D).  Multi-cause states use Wbar_sd = (sum_{j in s} Wrho[c_j,d])^(1/rho).
+ * Outputs logpj (N,1+H+S), lse1 = log sum_k exp(logpj), lseb = log sum_k exp(beta*logpj). */
+int pm_mca_estep_f64(const double *scores, int64_t lds, const double *wnorm2, const double *ynorm2,
+                     const double *Y, int64_t ldy, const double *Wrho, const int32_t *cand,
+                     const uint16_t *state_masks, int64_t S, const pm_mca_params *params_host, int64_t N,
+                     int64_t H, int64_t D, int64_t Hprime, double *logpj, int64_t ldl, double *lse1,
+                     double *lseb, void *stream);
+
+/* Packed MCA statistics (float64): [ G1 = Q1^T.Y (H*D) | Wp_multi (H*D) | Wq_multi (H*D) |
+ * q1sum (H) | scalars: sum E|s| (pi), sum_nk q e (sigma), sum lse1 (Q), kept count ].
+ * Wp = G1 * W^2 + Wp_multi, Wq = q1sum (x) 1 * W^2 + Wq_multi (mca_et.py:293-321). */
+#define PM_MCA_NSCALARS 4
+int64_t pm_mca_stats_len(int64_t H, int64_t D);
+
+/* Per-datapoint part of M_step, mca_et.py:236-327: q = exp(beta*logpj - lseb) for datapoints
+ * with lseb[n] >= lse_cut; writes the singleton weights q1 (N,H) (zero rows for cut datapoints;
+ * G1 = q1^T.Y is then one pm_gemm_tn_acc_f64 into stats[0..H*D)), scatters the multi-cause
+ * terms Aid (mca_et.py:309) into Wp_multi / Wq_multi, accumulates the scalars.  W_new = Wp/Wq is
+ * an element-wise ratio, so only weights that underflow to 0 (as in the reference) are dropped.
+ * Wrm1 = W^(rho-1) (H,D).  `stats` is zeroed by the caller once per EM step. */
+int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse1, const double *lseb,
+                          double lse_cut, const double *Y, int64_t ldy, const double *Wrho,
+                          const double *Wrm1, const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                          const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
+                          int64_t Hprime, double *q1, int64_t ldq, double *stats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

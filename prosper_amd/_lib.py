@@ -13,6 +13,11 @@ c_dp = C.c_void_p      # device pointers travel as integers (torch.Tensor.data_p
 i64 = C.c_int64
 
 
+class McaParams(C.Structure):
+    """struct pm_mca_params"""
+    _fields_ = [("pil_bar", C.c_double), ("pre1", C.c_double), ("beta", C.c_double), ("inv_rho", C.c_double)]
+
+
 class EStepParams(C.Structure):
     """struct pm_bsc_estep_params"""
     _fields_ = [("pil_bar", C.c_double), ("ecoef", C.c_double),
@@ -42,6 +47,12 @@ SIGNATURES = {
                                           C.c_int, c_dp, c_dp, i64, c_dp, c_dp]),
     "pm_bsc_mstep_rows16_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64,
                                           C.POINTER(EStepParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
+    "pm_mca_select_scores_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
+    "pm_mca_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, i64,
+                                   C.POINTER(McaParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp, c_dp]),
+    "pm_mca_stats_len": (i64, [i64, i64]),
+    "pm_mca_mstep_rows_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64,
+                                        C.POINTER(McaParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
 }
 
 

@@ -133,15 +133,19 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 2) void bsc_select_estep16_ker
         int myc = 0;  // lane j < Hp ends up with candidate position j
         if (do_select) {
             const double sy = 1.0 / sqrt(yn);
+            const bool smallest = mode & 4, raw = mode & 8;
             uint64_t key[VPL];
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 const int h = j + 16 * i;
                 uint64_t k = 0;
                 if (h < H) {
-                    const double x = a[i] * s_sw[h] * sy;
+                    double x = raw ? a[i] : a[i] * s_sw[h] * sy;
+                    if (smallest) x = -x;
                     k = (x == x) ? order_key(x) : 0x0000000000000400ull;  // NaN ranks below every number
-                    k = (k & ~0x3FFull) | (uint64_t)h;     // low 10 bits carry the latent index
+                    // low 10 bits carry the latent index; ties resolve as a stable argsort would:
+                    // largest-first keeps the larger index last-best, smallest-first the smaller index first
+                    k = (k & ~0x3FFull) | (uint64_t)(smallest ? 0x3FF - h : h);
                     if (k < 0x400ull) k |= 0x400ull;       // keep valid keys above the "taken" value 0
                 }
                 key[i] = k;
@@ -154,7 +158,8 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 2) void bsc_select_estep16_ker
 #pragma unroll
                 for (int i = 0; i < VPL; ++i)
                     if (key[i] == m) key[i] = 0;
-                if (j == Hp - 1 - r) myc = (int)(m & 0x3FFull);
+                const int win = (int)(m & 0x3FFull);
+                if (j == (smallest ? r : Hp - 1 - r)) myc = smallest ? 0x3FF - win : win;
             }
             if (live && j < Hp) cand[n * Hp + j] = myc;
         } else {

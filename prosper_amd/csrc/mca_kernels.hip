@@ -1,0 +1,488 @@
+// Maximal Causes Analysis (prosper/em/camodels/mca_et.py) on gfx950.
+//
+//   mca_select_scores_kernel   sim[n,h] = sum_d max(W_hd - y_d, 0)        (mca_et.py:104-106)
+//                              a register-tiled N x H x D max-plus contraction: no MFMA form exists,
+//                              the bound is the f64 VALU (3 ops per (n,h,d))
+//   mca_estep_kernel           log-pseudo-joints (mca_et.py:142-175): singletons from the scores GEMM
+//                              (Gram identity), multi-cause states from
+//                              Wbar_sd = (sum_{j in s} W_{c_j d}^rho)^(1/rho) -- one f64 log+exp per
+//                              (state, d): the kernel is transcendental-bound, not HBM-bound
+//   mca_mstep_rows_kernel      posterior weights q ~ exp(beta logpj), sufficient statistics
+//                              (mca_et.py:236-327) with
+//                              (W_j / Wbar_s)^(rho-1) = W_j^(rho-1) * Wbar_s / T_s   (T_s = Wbar_s^rho)
+//                              so the M-step needs no transcendental beyond Wbar, and only for the few
+//                              states whose posterior is not negligible
+//
+// One 64-lane wavefront per datapoint; lane l owns observed dimensions d = l + 64 i (i < DPL): the
+// H' x D block W^rho[cand] sits in LDS (row reads are contiguous across lanes), the state loop is
+// wave-uniform (every lane walks the same state), the sum over d of each state is a wave reduction.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "prosper_hip.h"
+#include "pm_common.h"
+
+namespace {
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// sim[n,h] = sum_d max(W[h,d] - Y[n,d], 0): 64 x 64 output tile per 256-thread workgroup, 4 x 4 per
+// thread, D walked in 16-column slabs through LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST = 64, SK = 16, SLD = SK + 1;
+
+__global__ __launch_bounds__(256) void mca_select_scores_kernel(const double *__restrict__ Y, int64_t ldy,
+                                                                 const double *__restrict__ W, int64_t ldw,
+                                                                 double *__restrict__ R, int64_t ldr, int64_t N,
+                                                                 int H, int D, int tiles_h) {
+    __shared__ double sy[ST * SLD], sw[ST * SLD];
+    const int tid = threadIdx.x;
+    const int64_t n0 = (int64_t)(blockIdx.x / tiles_h) * ST;
+    const int h0 = (blockIdx.x % tiles_h) * ST;
+    const int tr = tid >> 4, tc = tid & 15;  // thread tile: rows tr + 16 a, cols tc + 16 b
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+
+    for (int k0 = 0; k0 < D; k0 += SK) {
+        // stage: 64 rows x 16 columns of Y and of W, 4 elements per thread each
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, r = idx >> 4, c = idx & 15;
+            const int64_t n = n0 + r;
+            sy[r * SLD + c] = (n < N && k0 + c < D) ? Y[n * ldy + k0 + c] : 0.0;
+            // padding columns: W = -inf side (contributes max(.,0) = 0) -> use y = 0, w = 0
+            sw[r * SLD + c] = (h0 + r < H && k0 + c < D) ? W[(int64_t)(h0 + r) * ldw + k0 + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SK; ++k) {
+            double yv[4], wv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) yv[a] = sy[(tr + 16 * a) * SLD + k];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wv[b] = sw[(tc + 16 * b) * SLD + k];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += fmax(wv[b] - yv[a], 0.0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int64_t n = n0 + tr + 16 * a;
+        if (n >= N) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int h = h0 + tc + 16 * b;
+            if (h < H) R[n * ldr + h] = acc[a][b];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// E-step
+// ---------------------------------------------------------------------------------------------
+template <int DPL>  // observed dimensions per lane: D <= 64 * DPL
+__global__ void mca_estep_kernel(const double *__restrict__ scores, int64_t lds, const double *__restrict__ wnorm2,
+                                 const double *__restrict__ ynorm2, const double *__restrict__ Y, int64_t ldy,
+                                 const double *__restrict__ Wrho, const int32_t *__restrict__ cand,
+                                 const uint16_t *__restrict__ masks, int S, pm_mca_params P, int64_t N, int H, int D,
+                                 int Hp, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse1,
+                                 double *__restrict__ lseb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [ per wave: wr (Hp * DS) | e (S) ] ; DS = 64 * DPL
+    constexpr int DS = 64 * DPL;
+    const int waves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *s_wr = reinterpret_cast<double *>(smem) + (size_t)wave * (Hp * DS + S);
+    double *s_e = s_wr + Hp * DS;
+
+    const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * waves;
+    for (int64_t n = wave0; n < N; n += nwaves) {
+        const int32_t *cn = cand + n * Hp;
+        double y[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            y[i] = (d < D) ? Y[n * ldy + d] : 0.0;
+        }
+        for (int j = 0; j < Hp; ++j) {
+            const double *src = Wrho + (int64_t)cn[j] * D;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                s_wr[j * DS + d] = (d < D) ? src[d] : 0.0;
+            }
+        }
+        wave_sync_lds();
+
+        // multi-cause states: e_s = sum_d (Wbar_sd - y_d)^2
+        for (int s = 0; s < S; ++s) {
+            const unsigned mask = masks[s];  // wave-uniform
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                double T = 0.0;
+                unsigned m = mask;
+                while (m) {
+                    const int j = __builtin_ctz(m);
+                    m &= m - 1;
+                    T += s_wr[j * DS + d];
+                }
+                if (d < D) {
+                    const double wbar = exp(log(T) * P.inv_rho);
+                    const double df = wbar - y[i];
+                    part += df * df;
+                }
+            }
+            part = pm_wave_sum(part);
+            if (lane == 0) s_e[s] = part;
+        }
+        wave_sync_lds();
+
+        // log-pseudo-joints and the two log-evidences (beta = 1 for Q, beta = 1/T for the weights)
+        const double yn = ynorm2[n];
+        const double *arow = scores + n * lds;
+        double *out = logpj + n * ldl;
+        double m1 = -INFINITY;
+        if (lane == 0) {
+            const double f0 = P.pre1 * yn;
+            out[0] = f0;
+            m1 = f0;
+        }
+        for (int h = lane; h < H; h += 64) {
+            const double f = P.pil_bar + P.pre1 * (wnorm2[h] - 2.0 * arow[h] + yn);
+            out[1 + h] = f;
+            m1 = fmax(m1, f);
+        }
+        for (int s = lane; s < S; s += 64) {
+            const double f = P.pil_bar * (double)__builtin_popcount((unsigned)masks[s]) + P.pre1 * s_e[s];
+            out[1 + H + s] = f;
+            s_e[s] = f;
+            m1 = fmax(m1, f);
+        }
+        m1 = pm_wave_max(m1);
+        double s1 = 0.0, sb = 0.0;
+        if (lane == 0) {
+            const double dlt = out[0] - m1;  // own store, same lane
+            s1 += exp(dlt);
+            sb += exp(P.beta * dlt);
+        }
+        for (int h = lane; h < H; h += 64) {
+            const double dlt = (P.pil_bar + P.pre1 * (wnorm2[h] - 2.0 * arow[h] + yn)) - m1;
+            if (dlt > -745.0) {
+                s1 += exp(dlt);
+                sb += exp(P.beta * dlt);
+            }
+        }
+        for (int s = lane; s < S; s += 64) {
+            const double dlt = s_e[s] - m1;
+            if (dlt > -745.0) {
+                s1 += exp(dlt);
+                sb += exp(P.beta * dlt);
+            }
+        }
+        s1 = pm_wave_sum(s1);
+        sb = pm_wave_sum(sb);
+        if (lane == 0) {
+            lse1[n] = m1 + log(s1);
+            lseb[n] = P.beta * m1 + log(sb);
+        }
+        wave_sync_lds();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// M-step, per-datapoint part
+// ---------------------------------------------------------------------------------------------
+template <int DPL, int HP>
+__global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse1,
+                                      const double *__restrict__ lseb, double lse_cut,
+                                      const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
+                                      const double *__restrict__ Wrm1, const int32_t *__restrict__ cand,
+                                      const uint16_t *__restrict__ masks, int S, pm_mca_params P, int64_t N, int H,
+                                      int D, int Hp, double *__restrict__ q1, int64_t ldq,
+                                      double *__restrict__ stats) {
+    // HP = register-tile height (Hp rounded up to 4 / 8 / 12); state masks only use bits < Hp
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [ q1sum (H) | red (4 * waves) | per wave: wr (HP * DS) ]
+    constexpr int DS = 64 * DPL;
+    const int waves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *s_q1sum = reinterpret_cast<double *>(smem);
+    double *s_red = s_q1sum + H;
+    double *s_wr = s_red + 4 * waves + (size_t)wave * (HP * DS);
+    for (int h = tid; h < H; h += blockDim.x) s_q1sum[h] = 0.0;
+    __syncthreads();
+
+    double *Wp = stats + (int64_t)H * D;       // multi-cause numerator   (stats[0 .. H*D) = Q1^T Y by the GEMM)
+    double *Wq = stats + 2 * (int64_t)H * D;   // multi-cause denominator
+    // W_new = Wp / Wq is an ELEMENT-wise ratio (mca_et.py:348): an element (h,d) can be dominated by a
+    // state of vanishing posterior whose factor (W_hd / Wbar_sd)^(rho-1) is ~1 while the likely states'
+    // factors are ~1e-100 there.  Only weights that underflow to exactly 0 -- as they do in the
+    // reference -- may be dropped.
+    const double qcut = -745.2;
+    double st_pi = 0.0, st_sigma = 0.0, st_ld = 0.0, st_cnt = 0.0;
+
+    const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * waves;
+    for (int64_t n = wave0; n < N; n += nwaves) {
+        double *qrow = q1 + n * ldq;
+        const double lb = lseb[n];
+        if (!(lb >= lse_cut)) {  // truncated (mca_et.py:243-253)
+            for (int h = lane; h < H; h += 64) qrow[h] = 0.0;
+            continue;
+        }
+        const double *f = logpj + n * ldl;
+        const int32_t *cn = cand + n * Hp;
+        if (lane == 0) {
+            const double f0 = f[0];
+            const double dlt = P.beta * f0 - lb;
+            st_sigma += exp(dlt) * (f0 / P.pre1);
+            st_ld += lse1[n];
+            st_cnt += 1.0;
+        }
+        for (int h = lane; h < H; h += 64) {
+            const double fh = f[1 + h];
+            const double dlt = P.beta * fh - lb;
+            const double q = exp(dlt);       // singletons are never dropped (underflow aside)
+            if (q != 0.0) {
+                st_sigma += q * ((fh - P.pil_bar) / P.pre1);
+                st_pi += q;
+                atomicAdd(&s_q1sum[h], q);
+            }
+            qrow[h] = q;
+        }
+
+        // significant multi-cause states (wave-uniform walk; most are skipped)
+        bool staged = false;
+        double V[HP][DPL], y[DPL];
+#pragma unroll
+        for (int j = 0; j < HP; ++j)
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) V[j][i] = 0.0;
+        unsigned touched = 0;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int sl = s0 + lane;
+            double dl = -INFINITY;
+            if (sl < S) dl = P.beta * f[1 + H + sl] - lb;
+            unsigned long long live = __ballot(dl > qcut);
+            while (live) {
+                const int src = __builtin_ctzll(live);
+                live &= live - 1;
+                const int s = s0 + src;
+                const unsigned mask = masks[s];
+                const double fs = f[1 + H + s];
+                const double q = exp(P.beta * fs - lb);
+                if (lane == 0) {
+                    const double ns = (double)__builtin_popcount(mask);
+                    st_pi += q * ns;
+                    st_sigma += q * ((fs - P.pil_bar * ns) / P.pre1);
+                }
+                if (!staged) {  // first significant state: stage y and W^rho[cand] once
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) {
+                        const int d = lane + 64 * i;
+                        y[i] = (d < D) ? Y[n * ldy + d] : 0.0;
+                    }
+                    for (int j = 0; j < Hp; ++j) {
+                        const double *srcw = Wrho + (int64_t)cn[j] * D;
+#pragma unroll
+                        for (int i = 0; i < DPL; ++i) {
+                            const int d = lane + 64 * i;
+                            s_wr[j * DS + d] = (d < D) ? srcw[d] : 1.0;
+                        }
+                    }
+                    wave_sync_lds();
+                    staged = true;
+                }
+                touched |= mask;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    const int d = lane + 64 * i;
+                    double T = 0.0;
+#pragma unroll
+                    for (int j = 0; j < HP; ++j)
+                        if ((mask >> j) & 1u) T += s_wr[j * DS + d];
+                    const double wbar = exp(log(T) * P.inv_rho);
+                    const double v = q * wbar / T;  // q_s * Wbar_sd / T_sd
+#pragma unroll
+                    for (int j = 0; j < HP; ++j)
+                        if ((mask >> j) & 1u) V[j][i] += v;
+                }
+            }
+        }
+        if (staged) {
+#pragma unroll
+            for (int j = 0; j < HP; ++j) {
+                if ((touched >> j) & 1u) {
+                    const int64_t base = (int64_t)cn[j] * D;
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) {
+                        const int d = lane + 64 * i;
+                        if (d < D) {
+                            const double aid = V[j][i] * Wrm1[base + d];  // Aid[j,d] (mca_et.py:309)
+                            pm_atomic_add(Wp + base + d, aid * y[i]);
+                            pm_atomic_add(Wq + base + d, aid);
+                        }
+                    }
+                }
+            }
+            wave_sync_lds();
+        }
+    }
+
+    st_pi = pm_wave_sum(st_pi);
+    st_sigma = pm_wave_sum(st_sigma);
+    st_ld = pm_wave_sum(st_ld);
+    st_cnt = pm_wave_sum(st_cnt);
+    if (lane == 0) {
+        s_red[wave * 4 + 0] = st_pi;
+        s_red[wave * 4 + 1] = st_sigma;
+        s_red[wave * 4 + 2] = st_ld;
+        s_red[wave * 4 + 3] = st_cnt;
+    }
+    __syncthreads();
+    double *g_q1sum = stats + 3 * (int64_t)H * D;
+    double *sc = g_q1sum + H;
+    if (tid < 4) {
+        double v = 0.0;
+        for (int w = 0; w < waves; ++w) v += s_red[w * 4 + tid];
+        if (v != 0.0) pm_atomic_add(sc + tid, v);
+    }
+    for (int h = tid; h < H; h += blockDim.x) {
+        const double v = s_q1sum[h];
+        if (v != 0.0) pm_atomic_add(g_q1sum + h, v);
+    }
+}
+
+static int allow_lds_mca(const void *kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    return (int)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// wavefronts per workgroup so that the per-wave LDS areas fit ~64 KB
+inline int pick_waves(size_t per_wave_bytes, size_t shared_bytes) {
+    int w = 4;
+    while (w > 1 && shared_bytes + w * per_wave_bytes > 64 * 1024) w >>= 1;
+    return w;
+}
+
+inline int64_t grid_waves(int64_t N, int waves) {
+    int64_t blocks = (N + waves - 1) / waves;
+    const int64_t cap = 256 * 8;
+    return blocks < cap ? (blocks < 1 ? 1 : blocks) : cap;
+}
+
+}  // namespace
+
+extern "C" int64_t pm_mca_stats_len(int64_t H, int64_t D) { return 3 * H * D + H + PM_MCA_NSCALARS; }
+
+extern "C" int pm_mca_select_scores_f64(const double *Y, int64_t ldy, const double *W, int64_t ldw, double *R,
+                                        int64_t ldr, int64_t N, int64_t H, int64_t D, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!Y || !W || !R || N < 0 || H <= 0 || D <= 0 || ldy < D || ldw < D || ldr < H) return PM_EINVAL;
+    if (H > INT32_MAX || D > INT32_MAX) return PM_ERANGE;
+    const int tiles_h = (int)((H + ST - 1) / ST);
+    const int64_t blocks = (N + ST - 1) / ST * tiles_h;
+    if (blocks > INT32_MAX) return PM_ERANGE;
+    hipLaunchKernelGGL(mca_select_scores_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), Y, ldy, W, ldw, R, ldr, N, (int)H, (int)D, tiles_h);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_mca_estep_f64(const double *scores, int64_t lds, const double *wnorm2, const double *ynorm2,
+                                const double *Y, int64_t ldy, const double *Wrho, const int32_t *cand,
+                                const uint16_t *state_masks, int64_t S, const pm_mca_params *params_host, int64_t N,
+                                int64_t H, int64_t D, int64_t Hprime, double *logpj, int64_t ldl, double *lse1,
+                                double *lseb, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!scores || !wnorm2 || !ynorm2 || !Y || !Wrho || !cand || !params_host || !logpj || !lse1 || !lseb || N < 0 ||
+        H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || lds < H || ldy < D || ldl < 1 + H + S || (S > 0 && !state_masks))
+        return PM_EINVAL;
+    if (D > 1024 || Hprime > PM_MAX_HPRIME || Hprime > H || S > 65535) return PM_ERANGE;
+    const int dpl = D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : D <= 512 ? 8 : 16;
+    const size_t per_wave = sizeof(double) * ((size_t)Hprime * 64 * dpl + S);
+    if (per_wave > 150 * 1024) return PM_ERANGE;
+    const int waves = pick_waves(per_wave, 0);
+    const size_t shmem = per_wave * waves;
+    dim3 grid((unsigned)grid_waves(N, waves)), block(64 * waves);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PM_LAUNCH(V)                                                                                            \
+    do {                                                                                                        \
+        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_kernel<V>), shmem)) return e;        \
+        hipLaunchKernelGGL(mca_estep_kernel<V>, grid, block, shmem, s, scores, lds, wnorm2, ynorm2, Y, ldy, Wrho, \
+                           cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, (int)Hprime, logpj, ldl, \
+                           lse1, lseb);                                                                         \
+    } while (0)
+    switch (dpl) {
+        case 1: PM_LAUNCH(1); break;
+        case 2: PM_LAUNCH(2); break;
+        case 4: PM_LAUNCH(4); break;
+        case 8: PM_LAUNCH(8); break;
+        default: PM_LAUNCH(16); break;
+    }
+#undef PM_LAUNCH
+    return (int)hipGetLastError();
+}
+
+namespace {
+template <int DPL>
+int launch_mstep_hp(int hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, const double *logpj, int64_t ldl,
+                    const double *lse1, const double *lseb, double lse_cut, const double *Y, int64_t ldy,
+                    const double *Wrho, const double *Wrm1, const int32_t *cand, const uint16_t *masks, int S,
+                    pm_mca_params P, int64_t N, int H, int D, double *q1, int64_t ldq, double *stats) {
+    const int Hp = hp;
+    hp = hp <= 4 ? 4 : hp <= 8 ? 8 : 12;
+#define PM_CASE(HPV)                                                                                              \
+    case HPV: {                                                                                                   \
+        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_mstep_rows_kernel<DPL, HPV>), shmem)) return e; \
+        hipLaunchKernelGGL((mca_mstep_rows_kernel<DPL, HPV>), grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, \
+                           ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, q1, ldq, stats);                      \
+        return (int)hipGetLastError();                                                                            \
+    }
+    switch (hp) {
+        PM_CASE(4) PM_CASE(8) PM_CASE(12)
+        default: return PM_ERANGE;
+    }
+#undef PM_CASE
+}
+}  // namespace
+
+extern "C" int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse1, const double *lseb,
+                                     double lse_cut, const double *Y, int64_t ldy, const double *Wrho,
+                                     const double *Wrm1, const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                                     const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
+                                     int64_t Hprime, double *q1, int64_t ldq, double *stats, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!logpj || !lse1 || !lseb || !Y || !Wrho || !Wrm1 || !cand || !params_host || !q1 || !stats || N < 0 ||
+        H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || ldl < 1 + H + S || ldy < D || ldq < H || (S > 0 && !state_masks))
+        return PM_EINVAL;
+    if (D > 512 || Hprime > 12 || Hprime > H || S > 65535) return PM_ERANGE;
+    const int dpl = D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : 8;
+    const int hp_tile = Hprime <= 4 ? 4 : Hprime <= 8 ? 8 : 12;
+    if ((int64_t)dpl * hp_tile > 48) return PM_ERANGE;  // V[HP][DPL] register tile
+    const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl);
+    const size_t shared = sizeof(double) * (H + 16);
+    const int waves = pick_waves(per_wave, shared);
+    const size_t shmem = shared + per_wave * waves;
+    dim3 grid((unsigned)grid_waves(N, waves)), block(64 * waves);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dpl) {
+        case 1: return launch_mstep_hp<1>((int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats);
+        case 2: return launch_mstep_hp<2>((int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats);
+        case 4: return launch_mstep_hp<4>((int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats);
+        default: return launch_mstep_hp<8>((int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats);
+    }
+}

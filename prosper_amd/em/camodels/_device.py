@@ -1,0 +1,297 @@
+"""Device plumbing shared by the HIP-backed component-analysis models: resident data shards,
+workspace reuse, asynchronous parameter upload, the one device->host copy per M-step, kernel
+launch bookkeeping and the NumPy-compatible handles (``DeviceArray``) results are returned in.
+PyTorch supplies memory, streams and process groups; every computation on the hot path is a call
+into libprosper_hip.so (include/prosper_hip.h)."""
+import ctypes
+
+import numpy as np
+
+from . import CAModel
+from ... import _lib
+from ...utils import parallel
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class DeviceArray(object):
+    """NumPy-compatible handle of a tensor living in HBM.
+
+    ``np.asarray(handle)`` (or any NumPy function) downloads it once; row selection with an
+    index array stays on the device (``CAModel.select_partial_data``)."""
+
+    def __init__(self, tensor, np_dtype=None):
+        self.tensor = tensor
+        self._np_dtype = np.dtype(np_dtype) if np_dtype is not None else None
+        self._host = None
+        self.lse = None          # log-evidence per row, attached to 'logpj' handles
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+    @property
+    def ndim(self):
+        return self.tensor.dim()
+
+    @property
+    def dtype(self):
+        if self._np_dtype is not None:
+            return self._np_dtype
+        return np.dtype(str(self.tensor.dtype).replace("torch.", ""))
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def numpy(self):
+        if self._host is None:
+            host = self.tensor.detach().cpu().numpy()
+            if self._np_dtype is not None and host.dtype != self._np_dtype:
+                host = host.astype(self._np_dtype)
+            self._host = host
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None and np.dtype(dtype) != a.dtype else a
+
+    def __getitem__(self, idx):
+        if isinstance(idx, np.ndarray) and idx.ndim == 1 and idx.dtype.kind in "iub":
+            t = torch.from_numpy(np.ascontiguousarray(idx)).to(self.tensor.device)
+            out = DeviceArray(self.tensor[t], self._np_dtype)
+            if self.lse is not None:
+                out.lse = self.lse[t]
+            return out
+        return self.numpy()[idx]
+
+    def __repr__(self):
+        return "DeviceArray(shape=%s, dtype=%s, device=%s)" % (self.shape, self.dtype, self.tensor.device)
+
+
+class LazyCandidates(DeviceArray):
+    """``data['candidates']`` as handed out by the fast path of ``select_Hprimes``: the
+    selection is deferred.  If ``E_step`` is called next with the same parameters (what
+    ``CAModel.step`` / ``compute_lpj`` do) both stages run as ONE fused pass that overlaps with
+    the scores GEMM; if anything looks at the handle first (``np.asarray``, indexing, ``M_step``
+    with foreign log-joints) the candidates are computed on the spot.  Either way the values
+    are those of bsc_et.py:98-115."""
+
+    def __init__(self, model, ticket, shape):
+        self._model = model
+        self._ticket = ticket
+        self._shape = tuple(shape)
+        self._np_dtype = np.dtype(np.int64)
+        self._host = None
+        self.lse = None
+
+    @property
+    def tensor(self):
+        if self._ticket["cand"] is None:
+            self._model._materialize_candidates(self._ticket)
+        return self._ticket["cand"]
+
+    @property
+    def pending(self):
+        return self._ticket["cand"] is None
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return 2
+
+    def __len__(self):
+        return self._shape[0]
+
+    def __repr__(self):
+        return "LazyCandidates(shape=%s, pending=%s)" % (self._shape, self.pending)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class KernelTimer(object):
+    """HIP-event timing of individual kernel launches on the stream they are enqueued on
+    (torch's current stream, which is the one handed to the C ABI).  bench.py attaches one
+    to a model to obtain per-kernel average durations inside the timed region."""
+
+    def __init__(self, only=None, stride=1):
+        self.events = {}
+        self.only = set(only) if only else None    # labels to time (None = all)
+        self.stride = max(1, int(stride))          # time every stride-th launch of a label
+        self._count = {}
+
+    def launch(self, label, fn):
+        n = self._count[label] = self._count.get(label, 0) + 1
+        if (self.only is not None and label not in self.only) or (n - 1) % self.stride:
+            fn()
+            return
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        fn()
+        end.record()
+        self.events.setdefault(label, []).append((start, end))
+
+    def summary(self):
+        """label -> (launches, average milliseconds); synchronises."""
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+
+class DeviceCAModel(CAModel):
+    """CAModel whose select_Hprimes / E_step / M_step run on one MI355X."""
+
+    def __init__(self, D, H, Hprime, gamma, to_learn=['W', 'pi', 'sigma'], comm=parallel.COMM_WORLD,
+                 device=None):
+        CAModel.__init__(self, D, H, Hprime, gamma, to_learn, comm)
+        self._device = device
+        self._data = {}          # resident data shard: key, Y, ynorm2
+        self._par = {}           # per-step parameter products
+        self._ws = {}            # workspaces keyed by name
+        self.timer = None        # optional KernelTimer (bench.py)
+        self._pin = {}           # pinned staging buffers for asynchronous parameter uploads
+        self._pin_out = None     # pinned buffer of the one device->host copy per M-step
+
+    def _state_masks(self):
+        """uint16 mask per multi-cause state: bit j <=> candidate position j is on."""
+        SM = self.state_matrix.astype(np.int64)
+        if not SM.size:
+            return np.zeros(0, np.uint16)
+        return (SM << np.arange(self.Hprime)[None, :]).sum(axis=1).astype(np.uint16)
+
+    def _u16_dev(self, arr):
+        """uint16 payloads travel as int16 tensors (same bytes)."""
+        arr = np.ascontiguousarray(arr, dtype=np.uint16)
+        if not arr.size:
+            return torch.zeros(1, dtype=torch.int16, device=self.device)
+        return torch.from_numpy(arr.view(np.int16).copy()).to(self.device)
+
+    @property
+    def device(self):
+        if self._device is None:
+            if torch is None or not torch.cuda.is_available():
+                raise _lib.HipError("BSC_ET needs a HIP device: the hot path has no CPU fallback")
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        return torch.device(self._device)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _call(self, label, entry, *args):
+        """Enqueue one C-ABI entry point on the current stream (raises on a bad status)."""
+        if self.timer is None:
+            _lib.call(entry, *args)
+        else:
+            self.timer.launch(label, lambda: _lib.call(entry, *args))
+
+    def _buf(self, name, shape, dtype=None):
+        """Reusable device workspace (no allocation inside the EM loop once warm)."""
+        dtype = dtype or torch.float64
+        t = self._ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._ws[name] = t
+        return t
+
+    def _resident(self, y):
+        """Device copy of the data shard + |y_n|^2, uploaded once and kept in HBM."""
+        if isinstance(y, DeviceArray):
+            y = y.tensor
+        if torch.is_tensor(y):
+            key = ("t", y.data_ptr(), tuple(y.shape), y._version)
+        else:
+            y = np.asarray(y)
+            probe = float(y[0].sum() + y[-1].sum()) if y.shape[0] else 0.0
+            key = ("n", y.__array_interface__["data"][0], y.shape, probe)
+        if self._data.get("key") == key:
+            return self._data
+        if torch.is_tensor(y):
+            Y = y.to(device=self.device, dtype=torch.float64).contiguous()
+        else:
+            Y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(self.device)
+        N, D = Y.shape
+        assert D == self.D
+        yn = torch.empty(N, dtype=torch.float64, device=self.device)
+        if N:
+            self._call("row_sqnorm", "pm_row_sqnorm_f64", _ptr(Y), D, N, D, _ptr(yn), self._stream())
+        self._data = {"key": key, "Y": Y, "ynorm2": yn}
+        self._par = {}
+        return self._data
+
+    def invalidate_data(self):
+        """Forget the resident shard (call after modifying ``my_data['y']`` in place)."""
+        self._data = {}
+        self._par = {}
+
+    def _gemm_nt(self, A, B, out, label="gemm_nt"):
+        M, K = A.shape
+        N = B.shape[0]
+        self._call(label, "pm_gemm_nt_f64", _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0),
+                  M, N, K, self._stream())
+        return out
+
+    def _upload(self, name, host):
+        """Asynchronous host -> device copy through a rotating pair of pinned staging buffers
+        (a pageable ``.to(device)`` would block the host until the stream drains and stall the
+        EM loop at every step boundary)."""
+        slot = self._pin.setdefault(name, {"i": 0, "bufs": [None, None], "evs": [None, None]})
+        i = slot["i"] = slot["i"] ^ 1
+        buf = slot["bufs"][i]
+        if buf is None or buf.shape != host.shape:
+            buf = slot["bufs"][i] = torch.empty(host.shape, dtype=torch.float64).pin_memory()
+        elif slot["evs"][i] is not None:
+            slot["evs"][i].synchronize()          # the copy that last used this buffer has completed
+        buf.numpy()[...] = host
+        dev = torch.empty(host.shape, dtype=torch.float64, device=self.device)
+        dev.copy_(buf, non_blocking=True)
+        ev = slot["evs"][i] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return dev
+
+    def _download(self, flat):
+        """Device -> pinned host copy + wait; returns a NumPy view valid until the next call."""
+        n = flat.numel()
+        if self._pin_out is None or self._pin_out.numel() < n:
+            self._pin_out = torch.empty(n, dtype=torch.float64).pin_memory()
+        dst = self._pin_out[:n]
+        dst.copy_(flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ev.synchronize()
+        return dst.numpy()
+
+    def _device_candidates(self, cand, N):
+        if isinstance(cand, DeviceArray):
+            t = cand.tensor
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(cand, dtype=np.int32)).to(self.device)
+        if t.dtype != torch.int32:
+            t = t.to(torch.int32)
+        assert tuple(t.shape) == (N, self.Hprime)
+        return t.contiguous()
+
+    def _kth_largest_global(self, lse, N_use):
+        """sort(all log-evidences)[-N_use] across ranks (bsc_et.py:252 via
+        parallel.allsort).  Shards are padded to equal length for the all-gather."""
+        comm = self.comm
+        if comm.size > 1:
+            import torch.distributed as dist
+            sizes = comm.allgather(int(lse.shape[0]))
+            n_max = max(sizes)
+            pad = torch.full((n_max,), float("-inf"), dtype=torch.float64, device=lse.device)
+            pad[:lse.shape[0]] = lse
+            parts = [torch.empty_like(pad) for _ in range(comm.size)]
+            dist.all_gather(parts, pad, group=comm._group)
+            pool = torch.cat(parts)
+        else:
+            pool = lse
+        vals = torch.topk(pool, N_use, largest=True, sorted=True).values
+        return float(vals[-1])
+

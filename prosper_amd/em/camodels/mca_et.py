@@ -1,0 +1,258 @@
+"""Maximal Causes Analysis on the MI355X: drop-in for prosper/em/camodels/mca_et.py.
+
+Same constructor, ``check_params`` (W >= 1e-4), ``select_Hprimes / E_step / M_step``
+signatures, return keys (``W, pi, sigma, Q``) and ``dlog`` side effect (``N_use``) as the
+reference's ``MCA_ET`` (mca_et.py:22-389).  Kernels (prosper_amd/csrc/mca_kernels.hip):
+
+  select_Hprimes  sim[n,h] = sum_d |max(W_hd, y_d) - y_d| (register-tiled max-plus contraction),
+                  the H' smallest per datapoint by the 16-lane DPP selection kernel
+  E_step          singleton energies from the f64 MFMA scores GEMM, multi-cause states from
+                  Wbar = (sum W^rho)^(1/rho) (one f64 log+exp per state and dimension)
+  M_step          posterior q ~ exp(beta*logpj); Q1^T.Y as an f64 MFMA GEMM, the multi-cause
+                  terms Aid scattered with f64 atomics, ONE all-reduce of the packed statistics
+"""
+import ctypes
+from math import pi as _PI
+
+import numpy as np
+from scipy.special import comb
+
+from ._device import DeviceCAModel, DeviceArray, _ptr
+from ... import _lib
+from ...utils import parallel
+from ...utils import tracing
+from ...utils.datalog import dlog
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class MCA_ET(DeviceCAModel):
+    """Maximal Causes Analysis (max-superposition) with Expectation Truncation."""
+
+    def __init__(self, D, H, Hprime, gamma, to_learn=['W', 'pi', 'sigma'], comm=parallel.COMM_WORLD,
+                 device=None):
+        DeviceCAModel.__init__(self, D, H, Hprime, gamma, to_learn, comm, device)
+        self.rho_temp_bound = 1.05    # for rho: never use a T smaller than this (mca_et.py:31)
+        self.W_tol = 1e-4             # for W: ensure W[W<W_tol] = W_tol       (mca_et.py:32)
+        W_tol = self.W_tol
+        self.noise_policy = {
+            'W':     (W_tol, +np.inf, True),
+            'pi':    (W_tol, 1 - W_tol, False),
+            'sigma': (W_tol, +np.inf, False),
+        }
+        self._masks_dev = None
+
+    @tracing.traced
+    def check_params(self, model_params):
+        """Clamp W to >= W_tol (mca_et.py:44-55)."""
+        model_params['W'] = np.maximum(model_params['W'], self.W_tol)
+        return model_params
+
+    @tracing.traced
+    def generate_data(self, model_params, my_N):
+        """Max-rule superposition + Gaussian noise; RNG stream as upstream (mca_et.py:58-85):
+        one ``random(H)`` per datapoint, then one ``normal((my_N, D))``.  Does not obey gamma."""
+        H, D = self.H, self.D
+        W = model_params['W'].T
+        y = np.zeros((my_N, D))
+        s = np.zeros((my_N, H), dtype=bool)
+        for n in range(my_N):
+            s[n] = np.random.random(H) < model_params['pi']
+            if s[n].any():
+                y[n] = np.maximum(0.0, W[s[n]].max(axis=0))
+        y += np.random.normal(scale=model_params['sigma'], size=(my_N, D))
+        return {'y': y, 's': s}
+
+    # ------------------------------------------------------------------ plumbing
+    def _masks(self):
+        if self._masks_dev is None or self._masks_dev[0] != (self.Hprime, self.gamma):
+            lib = _lib.load()
+            if not lib.pm_bsc_rows16_supported(self.H, self.Hprime, 0):
+                raise _lib.HipError("MCA_ET: H = %d is outside the selection kernel's range (H <= 512)" % self.H)
+            self._masks_dev = ((self.Hprime, self.gamma), self._u16_dev(self._state_masks()))
+        return self._masks_dev[1]
+
+    def _tables_for(self, W_DH, T, res):
+        """Device copies of the per-step tables: W (H,D), |W_h|^2, W^rho, W^(rho-1)."""
+        W = np.asarray(W_DH, dtype=np.float64)
+        par = self._par
+        if par.get("ykey") == res["key"] and par.get("T") == T and par.get("W") is not None \
+                and par["W"].shape == W.shape and np.array_equal(par["W"], W):
+            return par
+        T_rho = np.maximum(T, self.rho_temp_bound)
+        rho = 1. / (1. - 1. / T_rho)
+        Wt = np.ascontiguousarray(W.T)                     # (H, D)
+        Wl = np.log(Wt)
+        host = np.stack([Wt, np.exp(rho * Wl), np.exp((rho - 1.) * Wl)])
+        assert np.isfinite(Wl).all() and np.isfinite(host[1]).all() and (host[1] > 1e-86).all()   # mca_et.py:224-227
+        dev = self._upload("mca_tabs", host)
+        wnorm2 = self._upload("mca_wn", (Wt * Wt).sum(axis=1))
+        self._par = {"ykey": res["key"], "T": T, "W": W.copy(), "Wt": dev[0], "Wrho": dev[1], "Wrm1": dev[2],
+                     "wnorm2": wnorm2, "rho": float(rho), "A": None}
+        return self._par
+
+    def _params(self, anneal, pies, sigma, rho):
+        return _lib.McaParams(pil_bar=float(np.log(pies / (1. - pies))), pre1=float(-1. / 2. / sigma / sigma),
+                              beta=float(1. / anneal['T']), inv_rho=float(1. / rho))
+
+    # ------------------------------------------------------------------ hot path
+    @tracing.traced
+    def select_Hprimes(self, model_params, data):
+        """``data['candidates']`` (N, Hprime): the latents with the smallest
+        sum_d |max(W_hd, y_d) - y_d|, ascending (mca_et.py:88-111)."""
+        res = self._resident(data['y'])
+        Y = res["Y"]
+        N, D = Y.shape
+        H, Hp = self.H, self.Hprime
+        self._masks()
+        Wt = self._upload("mca_W", np.ascontiguousarray(np.asarray(model_params['W'], dtype=np.float64).T))
+        cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
+        if N:
+            R = self._buf("mca_sim", (N, H))
+            self._call("select_scores", "pm_mca_select_scores_f64", _ptr(Y), D, _ptr(Wt), D, _ptr(R), H, N, H, D,
+                       self._stream())
+            # raw mode ranks R itself: the Gram / norm arguments only need to be valid memory
+            gdummy = self._buf("mca_gdummy", (H, H))
+            self._call("select", "pm_bsc_select_estep_f64", _ptr(R), H, _ptr(gdummy), _ptr(res["ynorm2"]), None, None,
+                       None, None, None, 0, self.gamma, None, N, H, Hp, 1 | 4 | 8, _ptr(cand), None, 0, None,
+                       self._stream())
+        data['candidates'] = DeviceArray(cand, np.int64)
+        return data
+
+    @tracing.traced
+    def E_step(self, anneal, model_params, my_data):
+        """Log-pseudo-joints ``{'logpj': (N, 1+H+S)}`` (mca_et.py:114-179; no beta here)."""
+        res = self._resident(my_data['y'])
+        Y = res["Y"]
+        N, D = Y.shape
+        H, Hp, S = self.H, self.Hprime, self.no_states
+        T = anneal['T']
+        par = self._tables_for(model_params['W'], T, res)
+        masks = self._masks()
+        cand = self._device_candidates(my_data['candidates'], N)
+        P = self._params(anneal, model_params['pi'], model_params['sigma'], par["rho"])
+        K = 1 + H + S
+        logpj = torch.empty((N, K), dtype=torch.float64, device=self.device)
+        lse1 = torch.empty((N,), dtype=torch.float64, device=self.device)
+        lseb = torch.empty((N,), dtype=torch.float64, device=self.device)
+        tracing.tracepoint("E_step:iterating")
+        if N:
+            A = self._gemm_nt(Y, par["Wt"], self._buf("scores", (N, H)), "scores_gemm")
+            self._call("estep", "pm_mca_estep_f64", _ptr(A), H, _ptr(par["wnorm2"]), _ptr(res["ynorm2"]), _ptr(Y), D,
+                       _ptr(par["Wrho"]), _ptr(cand), _ptr(masks), S, ctypes.byref(P), N, H, D, Hp,
+                       _ptr(logpj), K, _ptr(lse1), _ptr(lseb), self._stream())
+        out = DeviceArray(logpj)
+        out.lse = lseb          # log sum exp(beta * logpj): weights and truncation
+        out.lse1 = lse1         # log sum exp(logpj): the likelihood term Q
+        out.T = T
+        return {'logpj': out}
+
+    @tracing.traced
+    def M_step(self, anneal, model_params, my_suff_stat, my_data):
+        """New W, pi, sigma and the ET log-likelihood Q (mca_et.py:182-377)."""
+        comm = self.comm
+        H, Hp, D, gamma, S = self.H, self.Hprime, self.D, self.gamma, self.no_states
+        pies, sigma = model_params['pi'], model_params['sigma']
+        res = self._resident(my_data['y'])
+        Y = res["Y"]
+        my_N = Y.shape[0]
+        T = anneal['T']
+        beta = 1. / T
+        par = self._tables_for(model_params['W'], T, res)
+        masks = self._masks()
+        cand = self._device_candidates(my_data['candidates'], my_N)
+        K = 1 + H + S
+
+        logpj = my_suff_stat['logpj']
+        if isinstance(logpj, DeviceArray) and getattr(logpj, "lse1", None) is not None and logpj.T == T:
+            lp, lseb, lse1 = logpj.tensor, logpj.lse, logpj.lse1
+        else:   # foreign log-joints (or another temperature): recompute the log-evidences
+            lp = logpj.tensor if isinstance(logpj, DeviceArray) else \
+                torch.from_numpy(np.ascontiguousarray(np.asarray(logpj), dtype=np.float64)).to(self.device)
+            lse1 = torch.logsumexp(lp, dim=1)
+            lseb = torch.logsumexp(beta * lp, dim=1)
+        lp, lseb, lse1 = lp.contiguous(), lseb.contiguous(), lse1.contiguous()
+        assert tuple(lp.shape) == (my_N, K)
+        N = comm.allreduce(my_N)
+
+        A_pi_gamma = 0.
+        B_pi_gamma = 0.
+        for gp in range(0, gamma + 1):
+            a = comb(H, gp, exact=1) * pies ** gp * (1. - pies) ** (H - gp)
+            A_pi_gamma += a
+            B_pi_gamma += gp * a
+
+        lse_cut = float("-inf")
+        if anneal['Ncut_factor'] > 0.0:
+            tracing.tracepoint("M_step:truncating")
+            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
+            lse_cut = self._kth_largest_global(lseb, N_use)
+
+        tracing.tracepoint("M_step:iterating")
+        lib = _lib.load()
+        n_stats = lib.pm_mca_stats_len(H, D)
+        stats = self._buf("mca_stats", (n_stats,))
+        stats.zero_()
+        q1 = self._buf("mca_q1", (my_N, H))
+        P = self._params(anneal, pies, sigma, par["rho"])
+        if my_N:
+            self._call("mstep_rows", "pm_mca_mstep_rows_f64", _ptr(lp), K, _ptr(lse1), _ptr(lseb),
+                       ctypes.c_double(lse_cut), _ptr(Y), D, _ptr(par["Wrho"]), _ptr(par["Wrm1"]), _ptr(cand),
+                       _ptr(masks), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(q1), H, _ptr(stats), self._stream())
+            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(q1), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N,
+                       self._stream())
+        comm.allreduce_device(stats)      # replaces mca_et.py:208,253,340,341,357,366,371
+        return self._finalize(stats, model_params, par, A_pi_gamma, B_pi_gamma)
+
+    def _finalize(self, stats, model_params, par, A_pi_gamma, B_pi_gamma):
+        """Element-wise W update and the scalars (mca_et.py:333-377), one device->host copy."""
+        H, D = self.H, self.D
+        pies, sigma = model_params['pi'], model_params['sigma']
+        HD = H * D
+        G1 = stats[:HD].view(H, D)
+        Wp_m = stats[HD:2 * HD].view(H, D)
+        Wq_m = stats[2 * HD:3 * HD].view(H, D)
+        q1sum = stats[3 * HD:3 * HD + H]
+        scal = stats[3 * HD + H:3 * HD + H + 4]
+        parts = [scal]
+        learn_W = 'W' in self.to_learn
+        if learn_W:
+            tracing.tracepoint("M_step:update W")
+            Wsq = par["Wt"] * par["Wt"]
+            Wp = G1 * Wsq + Wp_m
+            Wq = q1sum[:, None] * Wsq + Wq_m
+            tiny = float(np.finfo(np.float64).tiny)
+            small = Wq < tiny                       # make sure we do not divide by zero (mca_et.py:343-346)
+            Wp = torch.where(small, torch.zeros_like(Wp), Wp)
+            Wq = torch.where(small, torch.full_like(Wq, tiny), Wq)
+            parts.append((Wp / Wq).reshape(-1))
+        flat = torch.cat(parts)
+        host = self._download(flat) if flat.is_cuda else flat.numpy()
+        my_pi, my_sigma, ldenom_sum, N_use = float(host[0]), float(host[1]), float(host[2]), int(round(host[3]))
+        dlog.append('N_use', N_use)
+
+        W_new = host[4:4 + HD].reshape(H, D).T.copy() if learn_W else np.asarray(model_params['W'])
+        if 'pi' in self.to_learn:
+            tracing.tracepoint("M_step:update pi")
+            pi_new = A_pi_gamma / B_pi_gamma * pies * my_pi / N_use
+        else:
+            pi_new = pies
+        if 'sigma' in self.to_learn:
+            tracing.tracepoint("M_step:update sigma")
+            sigma_new = np.sqrt(my_sigma / D / N_use)
+        else:
+            sigma_new = sigma
+        lAi = (H * np.log(1. - pi_new)) - ((D / 2) * np.log(2 * _PI)) - (D * np.log(sigma_new))
+        loglike_et = (lAi * N_use) + ldenom_sum
+        return {'W': W_new, 'pi': pi_new, 'sigma': sigma_new, 'Q': loglike_et}
+
+    def calculate_respons(self, anneal, model_params, data):
+        """Posterior over the truncated states (mca_et.py:380-389)."""
+        cand = np.sort(np.asarray(data['candidates']), axis=1)
+        data['candidates'] = cand
+        F = np.asarray(self.E_step(anneal, model_params, data)['logpj'])
+        e = np.exp(F - F.max(axis=1)[:, None])
+        return e / e.sum(axis=1).reshape(-1, 1)

@@ -34,6 +34,7 @@ from prosper.utils.datalog import dlog, DataHandler          # noqa: E402
 from prosper.em import EM                                    # noqa: E402
 from prosper.em.annealing import LinearAnnealing             # noqa: E402
 from prosper.em.camodels.bsc_et import BSC_ET                # noqa: E402
+from prosper.em.camodels.mca_et import MCA_ET                # noqa: E402
 from prosper.utils.barstest import generate_bars_dict        # noqa: E402
 
 
@@ -45,6 +46,41 @@ class Capture(DataHandler):
 
 
 dlog.set_handler(("L", "N", "N_use"), Capture)
+
+
+def mca_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, bars=False):
+    """One check_params -> select_Hprimes -> E_step -> M_step of MCA_ET on seeded data."""
+    rng = np.random.RandomState(seed)
+    if bars:
+        W_gt = 10 * generate_bars_dict(H)
+        pi_gt, sigma_gt = 2. / H, 2.0
+        W0 = W_gt + 0.5 * np.abs(rng.normal(size=(D, H)))
+    else:
+        W_gt = np.abs(rng.normal(size=(D, H))) * 2.0 + 0.1
+        pi_gt, sigma_gt = min(0.45, 2.0 / H), 1.0
+        W0 = W_gt * (1.0 + 0.2 * rng.uniform(-1, 1, size=(D, H)))
+    model = MCA_ET(D, H, Hp, gamma)
+    s = rng.random_sample((N, H)) < pi_gt
+    y = np.zeros((N, D))
+    for n in range(N):
+        if s[n].any():
+            y[n] = np.maximum(0.0, W_gt.T[s[n]].max(axis=0))
+    y += rng.normal(scale=sigma_gt, size=(N, D))
+    params = {"W": W0, "pi": pi_gt * 1.3, "sigma": sigma_gt * 1.2}
+    inp = {k: np.array(v, copy=True) for k, v in params.items()}
+    anneal = FixedAnneal(T=T, Ncut_factor=Ncut)
+    Capture.rows.clear()
+    params = model.check_params(params)
+    data = model.select_Hprimes(params, {"y": y.copy()})
+    ss = model.E_step(anneal, params, data)
+    new = model.M_step(anneal, params, ss, data)
+    assert np.isfinite(new["W"]).all() and np.isfinite(new["Q"]), name
+    np.savez_compressed(os.path.join(HERE, "mca_step_%s.npz" % name), D=D, H=H, Hprime=Hp, gamma=gamma, T=T,
+                        Ncut_factor=Ncut, y=y, W=inp["W"], pi=inp["pi"], sigma=inp["sigma"],
+                        candidates=data["candidates"].astype(np.int64), logpj=ss["logpj"],
+                        W_new=new["W"], pi_new=new["pi"], sigma_new=new["sigma"], Q=new["Q"],
+                        N_use=Capture.rows["N_use"][0], state_matrix=model.state_matrix)
+    print("mca_step_%s: N=%d K=%d Q=%.6f N_use=%d" % (name, N, ss["logpj"].shape[1], new["Q"], Capture.rows["N_use"][0]))
 
 
 class FixedAnneal(dict):
@@ -167,6 +203,11 @@ if __name__ == "__main__":
     bsc_step_case("mu", 40, 16, 5, 3, 180, seed=8, T=1.1, Ncut=0.5, anneal_prior=False, mu=True,
                   to_learn=("W", "pi", "sigma", "mu"))
     bsc_step_case("h256", 96, 256, 8, 4, 96, seed=9, T=1.0, Ncut=0.0, anneal_prior=False, amp=0.5)
+    mca_step_case("small", 16, 8, 4, 3, 300, seed=21, T=1.0, Ncut=0.0)
+    mca_step_case("small_cut", 16, 8, 4, 3, 257, seed=22, T=1.4, Ncut=0.5)
+    mca_step_case("bars", 25, 10, 5, 3, 300, seed=23, T=1.0, Ncut=1.0, bars=True)
+    mca_step_case("h40", 48, 40, 6, 3, 150, seed=24, T=2.0, Ncut=0.7)
+    mca_step_case("h128", 64, 128, 8, 3, 96, seed=25, T=1.0, Ncut=0.0)
     bsc_trajectory()
     bsc_init()
     anneal_tracks()

@@ -1,0 +1,92 @@
+"""MCA parity on the GPU: HIP path (through the C ABI) vs golden vectors minted from the reference
+(tests/golden/mca_step_*.npz) and vs the oracle at sizes it finishes in seconds.  float64 kernels:
+held to 1e-8 on W/pi/sigma/Q (BASELINE asks 1e-4)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden, GOLDEN
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class _An(dict):
+    crit_params = []
+
+    def __missing__(self, k):
+        return 0.0
+
+    def as_dict(self):
+        return dict(self)
+
+
+def _cases():
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "mca_step_*.npz")))
+
+
+@pytest.mark.parametrize("case", _cases())
+def test_mca_step_matches_reference_golden(case):
+    assert torch.cuda.is_available()
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    g = golden(case)
+    m = MCA_ET(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    an = _An(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]))
+    params = {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])}
+    h = dlog.set_handler(("N_use",), StoreInMemory)
+    try:
+        params = m.check_params(params)
+        data = m.select_Hprimes(params, {"y": g["y"]})
+        ss = m.E_step(an, params, data)
+        new = m.M_step(an, params, ss, data)
+    finally:
+        dlog.remove_handler(h)
+    assert np.array_equal(np.asarray(data["candidates"]), g["candidates"])
+    np.testing.assert_allclose(np.asarray(ss["logpj"]), g["logpj"], rtol=1e-10, atol=1e-9)
+    assert int(h.tables["N_use"][0]) == int(g["N_use"])
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=1e-9)
+    np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=1e-9)
+    np.testing.assert_allclose(new["Q"], g["Q"], rtol=1e-10)
+    assert new["W"].shape == (int(g["D"]), int(g["H"]))
+    # foreign NumPy inputs take the same kernels
+    new2 = m.M_step(an, params, {"logpj": g["logpj"]}, {"y": g["y"], "candidates": g["candidates"]})
+    np.testing.assert_allclose(new2["W"], g["W_new"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(new2["Q"], g["Q"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("D,H,Hp,gamma,N,T,ncut", [(256, 128, 8, 3, 1500, 1.0, 0.0), (100, 70, 5, 4, 333, 1.6, 0.6),
+                                                    (40, 20, 3, 2, 65, 1.0, 1.0)])
+def test_mca_step_matches_oracle(D, H, Hp, gamma, N, T, ncut):
+    from oracle import mca_oracle as M
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    rng = np.random.RandomState(D + H + N)
+    W_gt = np.abs(rng.normal(size=(D, H))) * 2.0 + 0.1
+    y, _ = M.generate_mca_data(W_gt, 2.0 / H, 1.0, N, rng)
+    params = {"W": W_gt * (1 + 0.2 * rng.uniform(-1, 1, size=(D, H))), "pi": 2.4 / H, "sigma": 1.1}
+    model = M.make_model(D, H, Hp, gamma)
+    an = M.Anneal(T=T, Ncut_factor=ncut)
+    ref, log = M.em_step(an, model, dict(params), y, vec=True)
+    m = MCA_ET(D, H, Hp, gamma)
+    new = m.step(_An(T=T, Ncut_factor=ncut), dict(params), {"y": y})
+    np.testing.assert_allclose(new["W"], ref["W"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(new["pi"], ref["pi"], rtol=1e-9)
+    np.testing.assert_allclose(new["sigma"], ref["sigma"], rtol=1e-9)
+    np.testing.assert_allclose(new["Q"], ref["Q"], rtol=1e-10)
+
+
+def test_mca_generate_data_rng_stream():
+    """Host-side generate_data keeps the reference's RNG order (one random(H) per datapoint)."""
+    from oracle import mca_oracle as M
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    rng = np.random.RandomState(4)
+    W = np.abs(rng.normal(size=(12, 6))) + 0.1
+    m = MCA_ET(12, 6, 3, 2)
+    np.random.seed(9)
+    d = m.generate_data({"W": W, "pi": 0.3, "sigma": 0.5}, 20)
+    y, s = M.generate_mca_data(W, 0.3, 0.5, 20, np.random.RandomState(9))
+    assert np.array_equal(d["s"], s)
+    np.testing.assert_allclose(d["y"], y, rtol=1e-13, atol=1e-13)

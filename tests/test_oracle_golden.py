@@ -91,3 +91,33 @@ def test_init_and_generate_match_reference_rng_stream():
     np.testing.assert_allclose(init["W"], g["W0"], rtol=1e-13)
     np.testing.assert_allclose(init["sigma"], g["sigma0"], rtol=1e-13)
     assert init["pi"] == float(g["pi0"])
+
+
+# ----------------------------------------------------------------------------- MCA (mca_et.py)
+def _mca_cases():
+    import glob, os
+    from conftest import GOLDEN
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "mca_step_*.npz")))
+
+
+@pytest.mark.parametrize("case", _mca_cases())
+@pytest.mark.parametrize("flavour", ["loop", "vec"])
+def test_mca_step_matches_reference(case, flavour):
+    from oracle import mca_oracle as M
+    g = golden(case)
+    model = M.make_model(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    assert np.array_equal(model["SM"], g["state_matrix"])
+    an = M.Anneal(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]))
+    params = M.check_params({"W": g["W"], "pi": float(g["pi"]), "sigma": float(g["sigma"])})
+    vec = flavour == "vec"
+    cand = (M.select_hprimes_vec if vec else M.select_hprimes_loop)(params["W"], g["y"], model["Hprime"])
+    assert np.array_equal(cand, g["candidates"])
+    logpj = (M.e_step_vec if vec else M.e_step_loop)(an, params["W"], params["pi"], params["sigma"], g["y"], cand,
+                                                     model["SM"], model["state_abs"])
+    np.testing.assert_allclose(logpj, g["logpj"], rtol=1e-10, atol=1e-9)
+    new, log = M.m_step(an, model, params["W"], params["pi"], params["sigma"], g["y"], cand, g["logpj"], vec=vec)
+    assert log["N_use"] == int(g["N_use"])
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=1e-10)
+    np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=1e-10)
+    np.testing.assert_allclose(new["Q"], g["Q"], rtol=1e-11)
