@@ -1,0 +1,29 @@
+import sys, time, numpy as np, torch
+sys.path.insert(0,'.')
+from prosper_amd.em.camodels.mca_et import MCA_ET
+from prosper_amd.em.camodels._device import KernelTimer
+D,H,HP,GAMMA,N=256,128,8,3,100000
+dev=torch.device('cuda',0)
+g=torch.Generator(device=dev).manual_seed(0)
+W_gt=(torch.randn(D,H,generator=g,device=dev,dtype=torch.float64).abs()*2+0.1)
+Y=torch.empty(N,D,dtype=torch.float64,device=dev)
+for lo in range(0,N,25000):
+    S=(torch.rand(25000,H,generator=g,device=dev)<2.0/H)
+    Wm=torch.where(S[:,None,:], W_gt[None,:,:].expand(25000,D,H), torch.zeros((),dtype=torch.float64,device=dev)).max(dim=2).values
+    Y[lo:lo+25000]=Wm+torch.randn(25000,D,generator=g,device=dev,dtype=torch.float64)
+W0=(W_gt*(1+0.1*(2*torch.rand(D,H,generator=g,device=dev,dtype=torch.float64)-1))).cpu().numpy()
+class An(dict):
+    crit_params=[]
+    def __missing__(s,k): return 0.0
+    def as_dict(s): return dict(s)
+an=An(T=1.0)
+m=MCA_ET(D,H,HP,GAMMA)
+p={"W":W0,"pi":2.0/H,"sigma":1.0}
+data={"y":Y}
+for _ in range(2): q=m.step(an,dict(p),data)
+m.timer=KernelTimer()
+torch.cuda.synchronize(); t=time.perf_counter()
+q=dict(p)
+for _ in range(3): q=m.step(an,q,data)
+torch.cuda.synchronize(); print("EM iter ms", (time.perf_counter()-t)/3*1e3)
+print({k:round(v[1],3) for k,v in m.timer.summary().items()})

@@ -35,6 +35,7 @@ from prosper.em import EM                                    # noqa: E402
 from prosper.em.annealing import LinearAnnealing             # noqa: E402
 from prosper.em.camodels.bsc_et import BSC_ET                # noqa: E402
 from prosper.em.camodels.mca_et import MCA_ET                # noqa: E402
+from prosper.em.camodels.gsc_et import GSC                   # noqa: E402
 from prosper.utils.barstest import generate_bars_dict        # noqa: E402
 
 
@@ -46,6 +47,47 @@ class Capture(DataHandler):
 
 
 dlog.set_handler(("L", "N", "N_use"), Capture)
+
+
+def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False):
+    """select_Hprimes -> E_step -> M_step (+ compute_lpj) of GSC with scalar sigma_sq.  The reference
+    returns its statistics in candidate-bucket order; they are mapped back to datapoint order here."""
+    rng = np.random.RandomState(seed)
+    W_gt = rng.normal(size=(D, H))
+    pi_gt = np.full(H, min(0.4, 2.0 / H))
+    psi_gt = np.eye(H)
+    mu_gt = np.ones(H) * 1.5
+    s = rng.random_sample((N, H)) <= pi_gt
+    z = np.where(s, mu_gt[None, :] + rng.normal(size=(N, H)), 0.0)
+    y = z @ W_gt.T + rng.normal(size=(N, D))
+    psi0 = np.diag(rng.uniform(0.6, 1.6, size=H))
+    if full_psi:
+        Q = 0.08 * rng.normal(size=(H, H))
+        psi0 = psi0 + Q @ Q.T
+    params = {"W": W_gt + 0.2 * rng.normal(size=(D, H)), "pi": np.clip(pi_gt * rng.uniform(0.7, 1.4, size=H), 0.02, 0.9),
+              "mu": mu_gt + 0.2 * rng.normal(size=H), "psi_sq": psi0, "sigma_sq": 1.3}
+    inp = {k: np.array(v, copy=True) for k, v in params.items()}
+    model = GSC(D, H, Hp, gamma, "scalar")
+    anneal = FixedAnneal(T=T)
+    logpj, cands = model.compute_lpj(anneal, {k: np.array(v, copy=True) for k, v in inp.items()}, {"y": y.copy()})
+    data = model.select_Hprimes(params, {"y": y.copy()})
+    order = np.concatenate([np.array(c["ind"]) for c in data["data_clusters"].values()])
+    suff = model.E_step(anneal, params, data)
+    assert np.array_equal(data["y"], y[order])
+    inv = np.argsort(order)
+    new = model.M_step(anneal, params, suff, data)
+    out = dict(D=D, H=H, Hprime=model.Hprime, gamma=model.gamma, T=T, y=y, candidates=cands.astype(np.int64),
+               logpj=logpj, xpt_s=suff["xpt_s"][inv], xpt_sz=suff["xpt_sz"][inv],
+               sum_xpt_ss=suff["xpt_ss"].sum(axis=0), sum_xpt_szsz=suff["xpt_szsz"].sum(axis=0),
+               state_matrix=model.state_matrix)
+    for k, v in inp.items():
+        out[k] = v
+    for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
+        out[k + "_new"] = np.asarray(new[k])
+    assert all(np.isfinite(out[k + "_new"]).all() for k in ("W", "pi", "mu", "psi_sq", "sigma_sq")), name
+    np.savez_compressed(os.path.join(HERE, "gsc_step_%s.npz" % name), **out)
+    print("gsc_step_%s: N=%d K=%d clusters=%d sigma_sq_new=%.6f" % (name, N, logpj.shape[1], len(data["data_clusters"]),
+                                                                   float(new["sigma_sq"])))
 
 
 def mca_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, bars=False):
@@ -203,6 +245,11 @@ if __name__ == "__main__":
     bsc_step_case("mu", 40, 16, 5, 3, 180, seed=8, T=1.1, Ncut=0.5, anneal_prior=False, mu=True,
                   to_learn=("W", "pi", "sigma", "mu"))
     bsc_step_case("h256", 96, 256, 8, 4, 96, seed=9, T=1.0, Ncut=0.0, anneal_prior=False, amp=0.5)
+    gsc_step_case("small", 16, 8, 4, 3, 200, seed=31, T=1.0)
+    gsc_step_case("small_T", 16, 8, 4, 3, 151, seed=32, T=1.5, full_psi=True)
+    gsc_step_case("h24", 40, 24, 5, 3, 120, seed=33, T=1.0, full_psi=True)
+    gsc_step_case("g4", 30, 12, 5, 4, 100, seed=34, T=1.2)
+    gsc_step_case("h128", 64, 128, 6, 3, 64, seed=35, T=1.0)
     mca_step_case("small", 16, 8, 4, 3, 300, seed=21, T=1.0, Ncut=0.0)
     mca_step_case("small_cut", 16, 8, 4, 3, 257, seed=22, T=1.4, Ncut=0.5)
     mca_step_case("bars", 25, 10, 5, 3, 300, seed=23, T=1.0, Ncut=1.0, bars=True)

@@ -121,3 +121,36 @@ def test_mca_step_matches_reference(case, flavour):
     np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=1e-10)
     np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=1e-10)
     np.testing.assert_allclose(new["Q"], g["Q"], rtol=1e-11)
+
+
+# ----------------------------------------------------------------------------- GSC (gsc_et.py)
+def _gsc_cases():
+    import glob, os
+    from conftest import GOLDEN
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "gsc_step_*.npz")))
+
+
+def _gsc_params(g):
+    return {"W": g["W"], "pi": g["pi"], "mu": g["mu"], "psi_sq": g["psi_sq"], "sigma_sq": float(g["sigma_sq"])}
+
+
+@pytest.mark.parametrize("case", _gsc_cases())
+def test_gsc_step_matches_reference(case):
+    from oracle import gsc_oracle as G
+    g = golden(case)
+    model = G.make_model(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    assert np.array_equal(model["SM"], g["state_matrix"])
+    params = _gsc_params(g)
+    an = G.Anneal(T=float(g["T"]))
+    cand = G.select_hprimes(params, g["y"], model["Hprime"])
+    assert np.array_equal(cand, g["candidates"])
+    np.testing.assert_allclose(G.compute_lpj(model, params, g["y"], cand), g["logpj"], rtol=1e-9, atol=1e-8)
+    suff = G.e_step(an, model, params, g["y"], cand)
+    np.testing.assert_allclose(suff["xpt_s"], g["xpt_s"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(suff["xpt_sz"], g["xpt_sz"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(suff["xpt_ss"].sum(0), g["sum_xpt_ss"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(suff["xpt_szsz"].sum(0), g["sum_xpt_szsz"], rtol=1e-9, atol=1e-10)
+    new = G.m_step(model, params, suff, g["y"])
+    for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
+        ref = g[k + "_new"]
+        np.testing.assert_allclose(new[k], ref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(ref).max()), err_msg=k)
