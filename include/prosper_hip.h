@@ -198,6 +198,34 @@ int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse1, 
                           const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
                           int64_t Hprime, double *q1, int64_t ldq, double *stats, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Gaussian (spike-and-slab) Sparse Coding, scalar noise (prosper/em/camodels/gsc_et.py, GSC)
+ * ------------------------------------------------------------------------------------- */
+
+/* Shapes the GSC kernel covers: H <= 512, gamma <= 4 (g x g systems solved in registers). */
+int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma);
+
+/* stats (float64): [ sum_n xpt_ss, upper triangle, multi-cause part (H*H) |
+ *                    sum_n xpt_szsz, upper triangle, multi-cause part (H*H) |
+ *                    sum_n xpt_s (H) | sum_n xpt_sz (H) | singleton diagonal of sum_n xpt_szsz (H) ]
+ * diag(sum xpt_ss) = sum_n xpt_s (s_h^2 = s_h). */
+int64_t pm_gsc_stats_len(int64_t H);
+
+/* select_Hprimes + E_step of GSC in one pass (gsc_et.py:721-809, 401-580, 260-398):
+ *   scores (N,H) = Y.W;  gram = W^T.W (H,H);  psi_sq (H,H);
+ *   tables (8*H): per-latent constants [c0 | c1 | gm | il | kl | ilam | mu | lpi] with
+ *     lam = G_hh/s2 + 1/psi_hh, c0 = -(log psi_hh + log lam) - mu^2 G_hh/s2, c1 = 2 mu/s2,
+ *     gm = G_hh mu, il = 1/(lam s2^2), kl = 1/(lam s2), ilam = 1/lam, lpi = log(pi/(1-pi))
+ *   do_select != 0: candidates = the Hprime best component scores, sorted by latent index,
+ *     written to `cand`; otherwise `cand` (sorted) is an input.
+ * Outputs: xpt_s, xpt_sz (N,H) and the sums over datapoints accumulated into `stats`
+ * (zeroed by the caller).  The (N,H,H) moments of the reference are never materialised. */
+int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                     const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                     int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                     int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
+                     double *stats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,336 @@
+"""Gaussian (spike-and-slab) Sparse Coding on the MI355X: drop-in for
+prosper/em/camodels/gsc_et.py (class ``GSC``), scalar observation noise.
+
+Same constructor (incl. the silent gamma / Hprime reset, gsc_et.py:45-50), ``standard_init``,
+``check_params``, ``generate_data``, ``select_Hprimes / E_step / M_step`` and parameter keys
+(``W, pi, mu, psi_sq, sigma_sq``).  One HIP kernel per E-step (prosper_amd/csrc/gsc_kernels.hip)
+computes the component scores, the candidates and every truncated state's posterior moments from
+the f64 MFMA scores GEMM ``Y.W`` and ``G = W^T.W``; the M-step's contractions
+(``Y^T.xpt_sz``, ``xpt_s^T.xpt_sz``, ``xpt_sz^T.xpt_sz``) are f64 MFMA GEMMs, its H x H algebra runs on
+the host exactly as upstream (gsc_et.py:584-718).
+
+Differences a caller can observe: datapoints keep their order (the reference returns
+its statistics in candidate-bucket order and rewrites ``my_data['y']``, gsc_et.py:572-573; every
+consumer only sums over datapoints), and the per-datapoint (N,H,H) moments ``xpt_ss`` / ``xpt_szsz``
+are handed over as ``SummedMoments`` (their sum over datapoints), never materialised.
+``sigma_sq_type`` 'diagonal' / 'full' are not on the GPU path yet and raise.
+"""
+import ctypes
+
+import numpy as np
+
+from ._device import DeviceCAModel, DeviceArray, _ptr
+from . import CAModel
+from ... import _lib
+from ...utils import parallel
+from ...utils import tracing
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class SummedMoments(object):
+    """sum over datapoints of a per-datapoint (H,H) moment (what the M-step consumes of
+    ``xpt_ss`` / ``xpt_szsz``).  ``.sum(axis=0)`` returns the (H,H) ndarray."""
+
+    def __init__(self, total, N):
+        self._total = total
+        self.shape = (N,) + tuple(total.shape)
+
+    def sum(self, axis=0):
+        assert axis == 0, "only the sum over datapoints exists"
+        return self._total
+
+
+class GSC(DeviceCAModel):
+    def __init__(self, D, H, Hprime=0, gamma=0, sigma_sq_type='scalar',
+                 to_learn=['W', 'pi', 'mu', 'sigma_sq', 'psi_sq'], comm=parallel.COMM_WORLD, device=None):
+        # CAModel asserts Hprime <= H, gamma <= Hprime on the raw arguments (camodels/__init__.py:90-91)
+        DeviceCAModel.__init__(self, D, H, Hprime, gamma, to_learn, comm, device)
+        tol = 1e-5
+        self.noise_policy = {
+            'W':        (-np.inf, +np.inf, False),
+            'pi':       (tol, 1. - tol, False),
+            'sigma_sq': (0., +np.inf, False),
+            'mu':       (-np.inf, +np.inf, False),
+            'psi_sq':   (0., +np.inf, False),
+        }
+        # gsc_et.py:45-50 -- note: the state table built by CAModel.__init__ is NOT regenerated upstream
+        if gamma <= 0 or gamma > H:
+            self.gamma = self.H
+        if Hprime <= 0 or Hprime > H:
+            self.Hprime = self.H
+        elif Hprime < gamma:
+            self.gamma = self.Hprime
+        self.sigma_sq_type = sigma_sq_type
+        self.dtype_precision = np.float64
+        self._masks_dev = None
+
+    # ------------------------------------------------------------------ host-side mirror
+    @tracing.traced
+    def standard_init(self, my_data):
+        """gsc_et.py:59-114 (same RNG draw order: W noise, pi, [mu], [psi_sq])."""
+        comm = self.comm
+        temp = CAModel.standard_init(self, my_data)
+        model_params = {'W': temp['W'].copy()}
+        pi = comm.bcast(np.random.rand(self.H)) * 0.95
+        pi[pi < 0.05] = 0.05
+        model_params['pi'] = pi
+        my_y = np.asarray(my_data['y'])
+        W_mean = parallel.allmean(my_y, axis=0, comm=comm)
+        sigma_sq_sq = parallel.allmean((my_y - W_mean) ** 2, axis=0, comm=comm)
+        if self.sigma_sq_type == 'full':
+            model_params['sigma_sq'] = np.diag(np.diag(sigma_sq_sq)) + (0.001 * np.eye(self.D))
+        elif self.sigma_sq_type == 'diagonal':
+            model_params['sigma_sq'] = sigma_sq_sq + 0.001
+        else:
+            model_params['sigma_sq'] = np.mean(sigma_sq_sq) + 0.001
+        if 'mu' in self.to_learn:
+            mu = comm.bcast(np.random.normal(0, 1, [self.H]))
+        else:
+            mu = np.zeros(self.H)
+        model_params['mu'] = mu
+        if 'psi_sq' in self.to_learn:
+            psi_sq_diag = comm.bcast(np.random.rand(self.H)) * 2
+            psi_sq_diag[psi_sq_diag < 0.05] = 0.05
+            psi_sq = np.diag(psi_sq_diag)
+        else:
+            psi_sq = np.eye(self.H)
+        model_params['psi_sq'] = psi_sq
+        return comm.bcast(model_params)
+
+    @tracing.traced
+    def check_params(self, model_params):
+        """gsc_et.py:164-184: finiteness / positivity asserts on rank 0."""
+        if self.comm.rank == 0:
+            for k in ('W', 'mu', 'pi', 'psi_sq'):
+                assert np.isfinite(model_params[k]).all()
+            assert np.isfinite(model_params['sigma_sq']).all()
+            assert np.all(np.asarray(model_params['sigma_sq']) > 0) or self.sigma_sq_type == 'full'
+        return model_params
+
+    @tracing.traced
+    def generate_data(self, model_params, my_N):
+        """gsc_et.py:186-202: one ``random(H)`` draw per datapoint, ``p <= pi``."""
+        s = np.zeros((my_N, self.H), dtype=bool)
+        for n in range(my_N):
+            s[n] = np.random.random(self.H) <= model_params['pi']
+        return self.generate_from_hidden(model_params, {'s': s})
+
+    @tracing.traced
+    def generate_from_hidden(self, model_params, my_hdata):
+        """gsc_et.py:204-257 incl. its quirk of skipping a datapoint whose active INDICES sum to 0."""
+        D, H = self.D, self.H
+        s = my_hdata['s']
+        my_N = s.shape[0]
+        y = np.zeros((my_N, D))
+        z = np.zeros((my_N, H))
+        if self.sigma_sq_type == 'full':
+            sd = np.sqrt(model_params['sigma_sq'].diagonal())
+        elif self.sigma_sq_type == 'diagonal':
+            sd = np.sqrt(model_params['sigma_sq'])
+        else:
+            sd = np.sqrt(model_params['sigma_sq']) * np.ones(D)
+        for n in range(my_N):
+            act = np.nonzero(s[n])[0]
+            if np.sum(act) == 0:
+                continue
+            Ws = model_params['W'][:, act]
+            z_n = np.random.multivariate_normal(model_params['mu'][act], (model_params['psi_sq'][act, :])[:, act],
+                                                1).flatten()
+            z[n, act] = z_n
+            y[n] = Ws @ z_n + sd * np.random.randn(D)
+        return {'y': y, 's': s, 'z': z}
+
+    # ------------------------------------------------------------------ device tables
+    def _require_scalar(self):
+        if self.sigma_sq_type != 'scalar':
+            raise _lib.HipError("GSC on the GPU covers sigma_sq_type='scalar'; %r is not built yet" % self.sigma_sq_type)
+        if not _lib.load().pm_gsc_supported(self.H, self.Hprime, self.gamma):
+            raise _lib.HipError("GSC kernel range: H <= 512, gamma <= 4 (got H=%d Hprime=%d gamma=%d)"
+                                % (self.H, self.Hprime, self.gamma))
+
+    def _masks(self):
+        key = (self.Hprime, self.gamma, self.no_states)
+        if self._masks_dev is None or self._masks_dev[0] != key:
+            SM = self.state_matrix.astype(np.int64)
+            m = (SM << np.arange(SM.shape[1])[None, :]).sum(axis=1).astype(np.uint16) if SM.size else np.zeros(0, np.uint16)
+            self._masks_dev = (key, self._u16_dev(m))
+        return self._masks_dev[1]
+
+    def _tables_for(self, model_params, res):
+        W = np.asarray(model_params['W'], dtype=np.float64)
+        mu = np.asarray(model_params['mu'], dtype=np.float64)
+        psi = np.asarray(model_params['psi_sq'], dtype=np.float64)
+        pi = np.asarray(model_params['pi'], dtype=np.float64)
+        s2 = float(model_params['sigma_sq'])
+        par = self._par
+        same = (par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape
+                and np.array_equal(par["W"], W) and np.array_equal(par["mu"], mu) and np.array_equal(par["psi"], psi)
+                and np.array_equal(par["pi"], pi) and par["s2"] == s2)
+        if same:
+            return par
+        Gd = (W * W).sum(axis=0)
+        psid = np.diag(psi)
+        lam = Gd / s2 + 1. / psid
+        with np.errstate(divide='ignore', invalid='ignore'):
+            c0 = -(np.log(psid) + np.log(lam)) - mu * mu * Gd / s2
+            lpi = np.log(pi) - np.log(1 - pi)
+        tables = np.stack([c0, 2. * mu / s2, Gd * mu, 1. / (lam * s2 * s2), 1. / (lam * s2), 1. / lam, mu, lpi])
+        Wt = self._upload("gsc_W", W).t().contiguous()          # (H, D): rows = latents
+        G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
+        self._par = {"ykey": res["key"], "W": W.copy(), "mu": mu.copy(), "psi": psi.copy(), "pi": pi.copy(), "s2": s2,
+                     "Wt": Wt, "G": G, "psi_d": self._upload("gsc_psi", psi), "tables": self._upload("gsc_tab", tables)}
+        return self._par
+
+    # ------------------------------------------------------------------ hot path
+    def _run(self, anneal_T, model_params, res, cand_in):
+        """Scores GEMM + the fused select / E-step kernel; returns (cand, xpt_s, xpt_sz, stats)."""
+        self._require_scalar()
+        Y = res["Y"]
+        N, D = Y.shape
+        H, Hp, S = self.H, self.Hprime, self.no_states
+        par = self._tables_for(model_params, res)
+        masks = self._masks()
+        n_stats = _lib.load().pm_gsc_stats_len(H)
+        stats = torch.zeros(n_stats, dtype=torch.float64, device=self.device)
+        xs = torch.empty((N, H), dtype=torch.float64, device=self.device)
+        xsz = torch.empty((N, H), dtype=torch.float64, device=self.device)
+        if cand_in is None:
+            cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
+            do_select = 1
+        else:
+            cand, do_select = cand_in, 0
+        if N:
+            A = self._gemm_nt(Y, par["Wt"], self._buf("scores", (N, H)), "scores_gemm")
+            self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(par["G"]), _ptr(par["psi_d"]), _ptr(res["ynorm2"]),
+                       _ptr(par["tables"]), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
+                       ctypes.c_double(par["s2"]), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), H,
+                       _ptr(stats), self._stream())
+        return cand, xs, xsz, stats
+
+    @tracing.traced
+    def select_Hprimes(self, model_params, my_data):
+        """Candidates = the Hprime latents with the best singleton log-posterior, sorted by index
+        (gsc_et.py:721-728).  The selection itself is fused into the E-step kernel; this records the
+        request (the reference's ``data_clusters`` bucketing has no counterpart: datapoints keep
+        their order)."""
+        self._require_scalar()
+        res = self._resident(my_data['y'])
+        my_data['data_clusters'] = {'deferred': True}
+        my_data.pop('candidates', None)
+        return my_data
+
+    def candidates(self, model_params, my_data):
+        """Sorted candidates (N, Hprime) on their own (np.asarray-able)."""
+        res = self._resident(my_data['y'])
+        cand, _, _, _ = self._run(1.0, model_params, res, None)
+        return DeviceArray(cand, np.int64)
+
+    @tracing.traced
+    def E_step(self, anneal, model_params, my_data):
+        """Posterior moments over the truncated state set (gsc_et.py:401-580): ``xpt_s``, ``xpt_sz``
+        (N,H) device handles, ``xpt_ss`` / ``xpt_szsz`` as sums over datapoints."""
+        res = self._resident(my_data['y'])
+        N = res["Y"].shape[0]
+        cand_in = None
+        if 'candidates' in my_data and 'data_clusters' not in my_data:   # candidates handed in (sorted, as upstream)
+            cand_in = self._device_candidates(np.sort(np.asarray(my_data['candidates']).astype(np.int64), axis=1), N)
+        tracing.tracepoint("E_step:iterating")
+        cand, xs, xsz, stats = self._run(anneal['T'], model_params, res, cand_in)
+        my_data['candidates'] = DeviceArray(cand, np.float64)             # float array upstream (gsc_et.py:431)
+        H = self.H
+        st = stats
+        U_ss = st[:H * H].view(H, H)
+        U_zz = st[H * H:2 * H * H].view(H, H)
+        cs, csz, dzz = st[2 * H * H:2 * H * H + H], st[2 * H * H + H:2 * H * H + 2 * H], st[2 * H * H + 2 * H:]
+        off = torch.triu(U_ss, 1)
+        sum_ss = off + off.t() + torch.diag(cs)                            # diag(sum xpt_ss) = sum xpt_s
+        offz = torch.triu(U_zz, 1)
+        sum_zz = offz + offz.t() + torch.diag(torch.diagonal(U_zz) + dzz)
+        out = {'xpt_s': DeviceArray(xs), 'xpt_sz': DeviceArray(xsz),
+               'xpt_ss': SummedMoments(sum_ss, N), 'xpt_szsz': SummedMoments(sum_zz, N)}
+        out['_sums'] = (cs, csz)
+        return out
+
+    @tracing.traced
+    def M_step(self, anneal, model_params, suff_stats, my_data):
+        """gsc_et.py:584-718 for scalar sigma_sq: the three contractions over datapoints are f64 MFMA
+        GEMMs into one packed buffer (ONE all-reduce), the H x H algebra follows upstream on the host."""
+        comm = self.comm
+        H, D = self.H, self.D
+        res = self._resident(my_data['y'])
+        Y = res["Y"]
+        my_N = Y.shape[0]
+        N = comm.allreduce(my_N)
+        eps = 1e-5
+
+        def dev(x):
+            if isinstance(x, DeviceArray):
+                return x.tensor
+            if torch.is_tensor(x):
+                return x.to(self.device)
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float64)).to(self.device)
+
+        xs, xsz = dev(suff_stats['xpt_s']).contiguous(), dev(suff_stats['xpt_sz']).contiguous()
+        sum_ss = dev(suff_stats['xpt_ss'].sum(axis=0))
+        sum_zz = dev(suff_stats['xpt_szsz'].sum(axis=0))
+        # packed: [Wp (D,H) | xs^T xsz (H,H) | xsz^T xsz (H,H) | sum_ss | sum_zz | sum_s | sum_sz | sum |y|^2]
+        nWp, nHH = D * H, H * H
+        packed = torch.zeros(nWp + 4 * nHH + 2 * H + 1, dtype=torch.float64, device=self.device)
+        if my_N:
+            s = self._stream()
+            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(Y), D, _ptr(xsz), H, _ptr(packed), H, D, H, my_N, s)
+            self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xs), H, _ptr(xsz), H,
+                       ctypes.c_void_p(packed.data_ptr() + 8 * nWp), H, H, H, my_N, s)
+            self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xsz), H, _ptr(xsz), H,
+                       ctypes.c_void_p(packed.data_ptr() + 8 * (nWp + nHH)), H, H, H, my_N, s)
+        o = nWp + 2 * nHH
+        packed[o:o + nHH] = sum_ss.reshape(-1)
+        packed[o + nHH:o + 2 * nHH] = sum_zz.reshape(-1)
+        o2 = o + 2 * nHH
+        packed[o2:o2 + H] = xs.sum(dim=0)
+        packed[o2 + H:o2 + 2 * H] = xsz.sum(dim=0)
+        packed[o2 + 2 * H] = res["ynorm2"].sum()
+        comm.allreduce_device(packed)      # replaces gsc_et.py:608-610,620,668,671,713
+        host = self._download(packed) if packed.is_cuda else packed.numpy()
+        Wp = host[:nWp].reshape(D, H)
+        xs_xsz = host[nWp:nWp + nHH].reshape(H, H)
+        xsz_xsz = host[nWp + nHH:nWp + 2 * nHH].reshape(H, H)
+        sum_xpt_ss = host[o:o + nHH].reshape(H, H).copy()
+        sum_xpt_szsz = host[o + nHH:o + 2 * nHH].reshape(H, H).copy()
+        sum_xpt_s, sum_xpt_sz = host[o2:o2 + H].copy(), host[o2 + H:o2 + 2 * H].copy()
+        sum_yy = float(host[o2 + 2 * H])
+
+        try:
+            W_n = np.dot(Wp, np.linalg.inv(sum_xpt_szsz))
+        except np.linalg.LinAlgError:
+            try:
+                noise = np.random.normal(0, eps, self.H)
+                W_n = np.dot(Wp, np.linalg.pinv(sum_xpt_szsz + np.outer(noise, noise)))
+            except np.linalg.LinAlgError:
+                W_n = model_params['W'] + (eps * np.random.normal(0, 1, [self.D, self.H]))
+
+        if 'pi' in self.to_learn:
+            pi_eps = 5e-5
+            pi_new = sum_xpt_s / N
+            pi_new[pi_new <= pi_eps] = pi_eps
+            pi_new[pi_new >= (1 - pi_eps)] = 1 - pi_eps
+            model_params['pi'] = pi_new
+        if 'W' in self.to_learn:
+            model_params['W'] = W_n
+        if 'mu' in self.to_learn:
+            model_params['mu'] = sum_xpt_sz * 1. / (sum_xpt_s + np.finfo(np.float64).eps)
+        if 'psi_sq' in self.to_learn:
+            mu = model_params['mu']
+            psi_sq = np.outer(mu, mu) * sum_xpt_ss + sum_xpt_szsz - 2 * (mu[:, None] * xs_xsz)
+            model_params['psi_sq'] = (psi_sq * np.linalg.inv(sum_xpt_ss + eps * np.eye(self.H))) + (eps * np.eye(self.H))
+        if 'sigma_sq' in self.to_learn:
+            if self.sigma_sq_type != 'scalar':
+                raise _lib.HipError("sigma_sq_type %r is not built yet" % self.sigma_sq_type)
+            WT_outer = np.dot(W_n.T, W_n)
+            my_sigma_sq = sum_yy - np.trace(np.dot(xsz_xsz, WT_outer))
+            model_params['sigma_sq'] = (my_sigma_sq / N / D) + eps
+        return model_params
