@@ -16,6 +16,29 @@ try:
 except Exception:  # pragma: no cover
     torch = None
 
+try:
+    from threadpoolctl import threadpool_limits as _threadpool_limits
+except Exception:  # pragma: no cover
+    _threadpool_limits = None
+
+
+class small_blas(object):
+    """Host LAPACK on the H x H matrices of an M-step with a handful of threads: on a 256-core GPU
+    host OpenBLAS otherwise wakes every core for a 128 x 128 inverse (measured 16 ms instead of 0.2)."""
+
+    def __init__(self, threads=4):
+        self._ctx = _threadpool_limits(limits=threads, user_api="blas") if _threadpool_limits else None
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
 
 class DeviceArray(object):
     """NumPy-compatible handle of a tensor living in HBM.

@@ -23,7 +23,7 @@ from math import pi as _PI
 import numpy as np
 from scipy.special import comb
 
-from ._device import (DeviceCAModel, DeviceArray, LazyCandidates, KernelTimer, _ptr)  # noqa: F401
+from ._device import (DeviceCAModel, DeviceArray, LazyCandidates, KernelTimer, _ptr, small_blas)  # noqa: F401
 from ... import _lib
 from ...utils import parallel
 from ...utils import tracing
@@ -414,7 +414,8 @@ class BSC_ET(DeviceCAModel):
             if ok:
                 W_new = host[pos + 2:pos + 2 + H * D].reshape(H, D).copy()
             else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host
-                W_new = np.linalg.lstsq(Wq.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0]
+                with small_blas():
+                    W_new = np.linalg.lstsq(Wq.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0]
             pos += 2 + H * D
         else:
             W_new = W_DH.T

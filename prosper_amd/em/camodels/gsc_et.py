@@ -19,7 +19,7 @@ import ctypes
 
 import numpy as np
 
-from ._device import DeviceCAModel, DeviceArray, _ptr
+from ._device import DeviceCAModel, DeviceArray, _ptr, small_blas
 from . import CAModel
 from ... import _lib
 from ...utils import parallel
@@ -304,6 +304,13 @@ class GSC(DeviceCAModel):
         sum_xpt_s, sum_xpt_sz = host[o2:o2 + H].copy(), host[o2 + H:o2 + 2 * H].copy()
         sum_yy = float(host[o2 + 2 * H])
 
+        with small_blas():
+            return self._update(model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss,
+                                sum_xpt_szsz, sum_yy)
+
+    def _update(self, model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss, sum_xpt_szsz, sum_yy):
+        """The H x H parameter algebra of gsc_et.py:624-716 on the host."""
+        D, eps = self.D, 1e-5
         try:
             W_n = np.dot(Wp, np.linalg.inv(sum_xpt_szsz))
         except np.linalg.LinAlgError:
