@@ -225,7 +225,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bn = blockIdx.x % tiles_n, bm = blockIdx.x / tiles_n;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its L2).  With two
+    // column tiles per row panel, remap so that both tiles of a panel run back-to-back on ONE XCD: the
+    // A panel is then fetched from the fabric once and the second tile hits it in that XCD's L2
+    // (speed / traffic only; any placement is correct).
+    int tile = blockIdx.x;
+    if (tiles_n == 2 && ((tile >> 4) + 1) * 16 <= (int)gridDim.x)
+        tile = (tile & ~15) + ((tile & 7) << 1) + ((tile >> 3) & 1);
+    const int bn = tile % tiles_n, bm = tile / tiles_n;
     const int m0 = bm * 128, n0 = bn * 128;
 
     // DMA sources: this wavefront moves chunks {wave, wave+4} of A and of B
@@ -466,9 +473,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(const double *__res
                                                               double *__restrict__ C, int64_t ldc, int M, int N,
                                                               int64_t K, int tiles_n, int64_t k_per_split) {
     __shared__ __attribute__((aligned(16))) double sm[2 * 2 * BK * TN_LD];
-    const int bn = blockIdx.x % tiles_n, bm = blockIdx.x / tiles_n;
+    // All output tiles of one K-split read the same rows of A and B.  Workgroups are dealt round-robin
+    // over the 8 XCDs (linear ids L and L+8 share an XCD), so hand XCD r the splits r, r+8, ... with all
+    // their tiles back-to-back: each operand slab then crosses the fabric once per split instead of once
+    // per XCD that happens to hold one of its tiles (speed / traffic only).
+    int tile = blockIdx.x, split = blockIdx.y;
+    if (gridDim.y % 8 == 0) {
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned r = L & 7u, q = L >> 3;
+        tile = (int)(q % gridDim.x);
+        split = (int)(r + 8u * (q / gridDim.x));
+    }
+    const int bn = tile % tiles_n, bm = tile / tiles_n;
     const int m0 = bm * TN_BM, n0 = bn * BN;
-    const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+    const int64_t kbeg = (int64_t)split * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
     if (kbeg >= kend) return;
     const bool edge = !ALIGNED || (m0 + TN_BM > M) || (n0 + BN > N) || ((kend - kbeg) % BK != 0);
