@@ -164,6 +164,15 @@ def main():
     elapsed, em_elapsed = float(t[0]), float(t[1])
 
     if rank == 0:
+        # HBM-side bytes of the dominant kernel from the committed rocprofv3 --pmc passes
+        # (profiles/summarize_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), per launch
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            key = "scores_gemm@grid%d" % (min(N, model._chunk_rows()) // 128 * ((H + 127) // 128) * 256)
+            traffic = pmc[key]["hbm_bytes"] if N == N_PER_GPU else None
+        except Exception:
+            traffic = None
         ms_step = elapsed / args.steps * 1e3
         value = world * N * args.steps / elapsed
         # dominant kernel: the scores GEMM, launched once per pipeline chunk of `chunk` datapoints
@@ -184,7 +193,8 @@ def main():
             "em_iter_datapoints_per_s": world * N * args.em_steps / em_elapsed,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_f64_dma_kernel (scores A = Y.W^T)",
                          "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (algorithmic: %d)" % (chunk * (D + H) * 8 + H * D * 8),
                          "avg_launch_ms": gemm_ms, "datapoints_per_launch": chunk,
                          "launches_per_step": chunks_per_step, "launches_timed": kern["scores_gemm"][0],
                          "estep_hbm_frac": (estep_bytes / (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS},
