@@ -133,7 +133,7 @@ class BSC_ET(DeviceCAModel):
         Y = res["Y"]
         N, H, Hp, S = Y.shape[0], self.H, self.Hprime, self.no_states
         tab = self._state_tables()
-        K = 1 + H + S
+        ldl = logpj.stride(0) if logpj is not None else 0
         rows = self._chunk_rows()
         nchunks = (N + rows - 1) // rows
         main = torch.cuda.current_stream(self.device)
@@ -166,7 +166,7 @@ class BSC_ET(DeviceCAModel):
             self._call("select_estep", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
                        _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S,
                        self.gamma, ctypes.byref(P) if P is not None else None, r1 - r0, H, Hp, mode,
-                       off(cand, Hp), off(logpj, K), K, off(lse), ctypes.c_void_p(main.cuda_stream))
+                       off(cand, Hp), off(logpj, ldl), ldl, off(lse), ctypes.c_void_p(main.cuda_stream))
             if overlap:
                 done[c & 1] = torch.cuda.Event()
                 done[c & 1].record(main)
@@ -251,7 +251,10 @@ class BSC_ET(DeviceCAModel):
         P = self._estep_params(anneal, model_params['pi'], model_params['sigma'], mu64)
         K = 1 + H + S
         # results are handed to the caller: fresh tensors (the caching allocator recycles last step's)
-        logpj = torch.empty((N, K), dtype=torch.float64, device=self.device)
+        # rows padded to whole 128-byte lines: unaligned rows made every row store straddle two lines
+        # (WRITE_SIZE 1.8x the bytes); the caller sees the (N, K) view
+        Kpad = (K + 15) // 16 * 16 if os.environ.get('PM_PAD', '1') == '1' else K
+        logpj = torch.empty((N, Kpad), dtype=torch.float64, device=self.device)[:, :K]
         lse = torch.empty((N,), dtype=torch.float64, device=self.device)
         tracing.tracepoint("E_step:iterating")
         cobj = my_data['candidates']
@@ -279,7 +282,7 @@ class BSC_ET(DeviceCAModel):
         if N:
             self._call("estep", "pm_bsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]),
                       _ptr(wmu), _ptr(ymu), _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P),
-                      N, H, Hp, _ptr(logpj), K, _ptr(lse), self._stream())
+                      N, H, Hp, _ptr(logpj), logpj.stride(0), _ptr(lse), self._stream())
         out = DeviceArray(logpj)
         out.lse = lse
         return {'logpj': out}
@@ -308,7 +311,9 @@ class BSC_ET(DeviceCAModel):
         else:   # log-joints handed in from outside: upload, recompute the log-evidence
             lp = torch.from_numpy(np.ascontiguousarray(np.asarray(logpj), dtype=np.float64)).to(self.device)
             lse = torch.logsumexp(lp, dim=1)
-        lp = lp.contiguous()
+        if lp.dim() != 2 or lp.stride(1) != 1:
+            lp = lp.contiguous()
+        ldl = lp.stride(0) if my_N else K
         lse = lse.contiguous()
         assert tuple(lp.shape) == (my_N, K)
 
@@ -339,12 +344,12 @@ class BSC_ET(DeviceCAModel):
         expect = self._buf("expect", (my_N, H))
         P = self._estep_params(anneal, pies, sigma, mu)
         if my_N and tab["fast"]:
-            self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", _ptr(lp), K, _ptr(lse), ctypes.c_double(lse_cut),
+            self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut),
                        _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,
                        _ptr(stats), self._stream())
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, self._stream())
         elif my_N:
-            self._call("mstep_rows", "pm_bsc_mstep_rows_f64", _ptr(lp), K, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand),
+            self._call("mstep_rows", "pm_bsc_mstep_rows_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand),
                       _ptr(tab["masks"]), S, _ptr(tab["pair_ptr"]), _ptr(tab["pair_states"]), tab["pair_len"],
                       ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats), self._stream())
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, self._stream())
