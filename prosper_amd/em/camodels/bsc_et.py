@@ -45,8 +45,9 @@ class BSC_ET(DeviceCAModel):
         self._tables = None      # device copies of the state table
         self.use_rows16 = True   # 16-lanes-per-datapoint kernels when the shape allows (tests flip this)
         self._side = None        # side stream of the chunked GEMM / row-kernel pipeline
-        self.overlap_streams = False   # run GEMM(c+1) beside the row kernel of chunk c (measured: no gain)
-        self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "1"))   # GEMM rounds per pipeline chunk
+        self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
+        self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
+        self.max_chunk_rows = 1 << 20
 
     # ------------------------------------------------------------------ plumbing
     def _state_tables(self):
@@ -119,22 +120,33 @@ class BSC_ET(DeviceCAModel):
         return par
 
     # ---- fused, chunked select + E-step (fast path) -------------------------------------------
-    def _chunk_rows(self):
-        """Rows per pipeline chunk: one round of resident 128x128 GEMM tiles (2 per CU)."""
+    def _round_rows(self):
+        """Rows of one round of resident 128x128 GEMM tiles (2 workgroups per CU)."""
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         tiles_n = (self.H + 127) // 128
-        return max(1, (2 * cus) // tiles_n) * 128 * self.chunk_rounds
+        return max(1, (2 * cus) // tiles_n) * 128
+
+    def _chunk_rows(self, N=None):
+        """Rows per pipeline chunk: the largest whole number of GEMM rounds that fits the shard (so
+        the main GEMM launch has no ragged last round; the remainder is a second, split-K launch),
+        capped at ``max_chunk_rows`` to bound the score buffer."""
+        rr = self._round_rows()
+        if self.chunk_rounds > 0:
+            return rr * self.chunk_rounds
+        N = self.max_chunk_rows if N is None else min(N, self.max_chunk_rows)
+        return max(rr, N // rr * rr)
 
     def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None):
         """Chunked scores GEMM + fused select/E-step kernel.  A chunk is one round of resident GEMM
         tiles; its (chunk, H) score block is consumed by the row kernel straight away, so the
-        scores never make a round trip through HBM (two alternating buffers, cache resident).
+        scores buffer is bounded (two alternating buffers).  Measured: chunk size barely matters
+        (one round per chunk 2.27 ms, whole shard 2.18 ms per pass at config 2).
         ``overlap``: GEMM of chunk c+1 on a side stream while the row kernel of chunk c runs."""
         Y = res["Y"]
         N, H, Hp, S = Y.shape[0], self.H, self.Hprime, self.no_states
         tab = self._state_tables()
         ldl = logpj.stride(0) if logpj is not None else 0
-        rows = self._chunk_rows()
+        rows = self._chunk_rows(N)
         nchunks = (N + rows - 1) // rows
         main = torch.cuda.current_stream(self.device)
         bufs = [self._buf("scores_c0", (rows, H)), self._buf("scores_c1", (rows, H))]
@@ -154,7 +166,7 @@ class BSC_ET(DeviceCAModel):
                 if overlap and done[c & 1] is not None:
                     side.wait_event(done[c & 1])         # the row kernel that read this buffer is finished
                 Yc = Y[r0:r1]
-                self._call("scores_gemm" if r1 - r0 == rows else "scores_gemm_tail", "pm_gemm_nt_f64", _ptr(Yc),
+                self._call("scores_gemm" if (r1 - r0 == rows or nchunks == 1) else "scores_gemm_tail", "pm_gemm_nt_f64", _ptr(Yc),
                            Y.stride(0), _ptr(par["Wt"]), par["Wt"].stride(0), _ptr(A), H, r1 - r0, H, Y.shape[1],
                            ctypes.c_void_p(side.cuda_stream))
                 if overlap:
