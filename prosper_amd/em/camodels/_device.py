@@ -318,3 +318,107 @@ class DeviceCAModel(CAModel):
         vals = torch.topk(pool, N_use, largest=True, sorted=True).values
         return float(vals[-1])
 
+    # ------------------------------------------------------------------ inference ("next" row)
+    def inference(self, anneal, model_params, test_data, topK=10, logprob=False, adaptive=True,
+                  Hprime_max=None, gamma_max=None):
+        """Top-K posterior states and marginals per datapoint (camodels/__init__.py:256-375).
+
+        Same return dict as the reference: ``s`` (N,topK,H) int8, ``m`` (N,H), ``p`` (N,topK),
+        ``gamma`` / ``Hprime`` (N,).  With ``adaptive`` the datapoints whose MAP state has exactly
+        gamma active units are re-run with Hprime+1 / gamma+1 (the state table is regenerated) until
+        none remain or the caps are reached.  The log-joints come from the HIP E-step; the
+        normalisation, top-K and marginals run on the device too."""
+        from . import generate_state_matrix
+        assert 'y' in test_data, "Key 'y' in test_data dict not defined."
+        model_params = self.check_params(model_params)
+        comm = self.comm
+        my_y = test_data['y']
+        if isinstance(my_y, DeviceArray):
+            my_y = my_y.tensor
+        my_N, D = my_y.shape
+        H = self.H
+        Hprime_start, gamma_start = self.Hprime, self.gamma
+        if topK == -1:
+            topK = self.state_matrix.shape[0]
+        dev = self.device
+        res_s = torch.zeros((my_N, topK, H), dtype=torch.int8, device=dev)
+        res_m = torch.zeros((my_N, H), dtype=torch.float64, device=dev)
+        res_p = torch.zeros((my_N, topK), dtype=torch.float64, device=dev)
+        res_gamma = torch.zeros((my_N,), dtype=torch.float64, device=dev)
+        res_Hprime = torch.zeros((my_N,), dtype=torch.float64, device=dev)
+
+        cur_y = my_y
+        which = torch.ones(my_N, dtype=torch.bool, device=dev)
+        try:
+            while bool(which.any()):
+                ind_n = torch.nonzero(which).flatten()
+                logpj, cand = self.compute_lpj(anneal, model_params, {'y': cur_y})
+                lp = logpj.tensor if isinstance(logpj, DeviceArray) else torch.as_tensor(np.asarray(logpj)).to(dev)
+                cd = cand.tensor if isinstance(cand, DeviceArray) else torch.as_tensor(np.asarray(cand)).to(dev)
+                cd = cd.long()
+                n_cur, K = lp.shape
+                Hp = self.Hprime
+                lpc = lp - torch.logsumexp(lp, dim=1, keepdim=True)          # normalised log posterior
+                k_eff = min(topK, K)
+                top_val, top_idx = torch.topk(lpc, k_eff, dim=1, largest=True, sorted=True)
+                # upstream quirk (:309-312): logprob=False reports exp(logpj - max), NOT the normalised value
+                top_rel = torch.gather(lp, 1, top_idx) - lp.max(dim=1, keepdim=True).values
+                res_Hprime[ind_n] = float(self.Hprime)
+                res_gamma[ind_n] = float(self.gamma)
+                # top-K states as H-dimensional binary vectors
+                SM = torch.from_numpy(self.state_matrix.astype(np.int8)).to(dev) if self.no_states else \
+                    torch.zeros((1, Hp), dtype=torch.int8, device=dev)
+                # upstream quirk (:313-319): a re-run datapoint's earlier entries are never cleared -- one-cause
+                # states only SET their bit, the null state writes nothing, multi-cause states overwrite the
+                # candidate positions; start from what is there
+                s_blk = res_s[ind_n, :k_eff].clone()
+                single = (top_idx >= 1) & (top_idx <= H)
+                if bool(single.any()):
+                    nn_, mm_ = torch.nonzero(single, as_tuple=True)
+                    s_blk[nn_, mm_, top_idx[nn_, mm_] - 1] = 1
+                multi = top_idx > H
+                if bool(multi.any()):
+                    nn_, mm_ = torch.nonzero(multi, as_tuple=True)
+                    rows = SM[top_idx[nn_, mm_] - H - 1]                           # (M, Hp)
+                    s_blk[nn_[:, None].expand(-1, Hp), mm_[:, None].expand(-1, Hp), cd[nn_]] = rows
+                res_s[ind_n, :k_eff] = s_blk
+                res_p[ind_n, :k_eff] = top_val if logprob else torch.exp(top_rel)
+                # marginals: log p(s_h = 1 | y) = logsumexp over the states containing h
+                m_blk = lpc[:, 1:H + 1].clone()
+                if self.no_states:
+                    multi_lp = lpc[:, H + 1:]                                       # (n, S)
+                    SMb = SM.bool()
+                    for j in range(Hp):
+                        lj = torch.logsumexp(torch.where(SMb[:, j][None, :], multi_lp,
+                                                         torch.full_like(multi_lp, float("-inf"))), dim=1)
+                        hj = cd[:, j]
+                        rows_n = torch.arange(n_cur, device=dev)
+                        m_blk[rows_n, hj] = torch.logaddexp(lpc[rows_n, 1 + hj], lj)
+                res_m[ind_n] = m_blk
+                if not adaptive:
+                    break
+                which = ((res_s[:, 0, :] != 0).sum(-1) == self.gamma)
+                if not bool(which.any()):
+                    break
+                if (Hprime_max is not None and self.Hprime == Hprime_max) and \
+                        (gamma_max is not None and self.gamma == gamma_max):
+                    break
+                cur_y = my_y[which.cpu().numpy()] if not torch.is_tensor(my_y) else my_y[which]
+                n_left = int(which.sum())
+                print("Rank %i: For %i data points MAP state has activity equal to gamma." % (comm.rank, n_left))
+                if not ((self.Hprime == self.H) or (Hprime_max is not None and self.Hprime == Hprime_max)):
+                    self.Hprime += 1
+                if (self.gamma == self.H) or (gamma_max is not None and self.gamma == gamma_max):
+                    continue
+                self.gamma += 1
+                print("Rank %i: Updating state matrix and running again." % comm.rank)
+                (self.state_list, self.no_states, self.state_matrix,
+                 self.state_abs) = generate_state_matrix(self.Hprime, self.gamma)
+        finally:
+            comm.Barrier()
+            self.Hprime, self.gamma = Hprime_start, gamma_start
+            (self.state_list, self.no_states, self.state_matrix,
+             self.state_abs) = generate_state_matrix(self.Hprime, self.gamma)
+        m_out = res_m if logprob else torch.exp(res_m)
+        return {'s': res_s.cpu().numpy(), 'm': m_out.cpu().numpy(), 'p': res_p.cpu().numpy(),
+                'gamma': res_gamma.cpu().numpy(), 'Hprime': res_Hprime.cpu().numpy()}

@@ -90,6 +90,32 @@ def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False):
                                                                    float(new["sigma_sq"])))
 
 
+def bsc_inference_case():
+    """CAModel.inference (camodels/__init__.py:256-375) of BSC_ET: top-K states, marginals, adaptive H'/gamma."""
+    D, H, Hp, gamma, N = 25, 10, 4, 2, 60
+    rng = np.random.RandomState(41)
+    W = 10 * generate_bars_dict(H) + 0.3 * rng.normal(size=(D, H))
+    params = {"W": W, "pi": 0.25, "sigma": 1.5}
+    s = rng.random_sample((N, H)) < 0.25
+    y = s.astype(float) @ (10 * generate_bars_dict(H)).T + rng.normal(scale=1.5, size=(N, D))
+    model = BSC_ET(D, H, Hp, gamma)
+    anneal = LinearAnnealing(1)
+    anneal["T"] = [(0, 1.)]
+    anneal["anneal_prior"] = False
+    out = {}
+    for tag, kw in (("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
+                    ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True))):
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = model.inference(anneal, {k: np.array(v, copy=True) for k, v in params.items()}, {"y": y.copy()}, **kw)
+        for k, v in res.items():
+            out["%s_%s" % (tag, k)] = v
+    assert (model.Hprime, model.gamma) == (Hp, gamma)
+    np.savez_compressed(os.path.join(HERE, "bsc_inference.npz"), D=D, H=H, Hprime=Hp, gamma=gamma, y=y, W=W,
+                        pi=params["pi"], sigma=params["sigma"], **out)
+    print("bsc_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
+
+
 def mca_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, bars=False):
     """One check_params -> select_Hprimes -> E_step -> M_step of MCA_ET on seeded data."""
     rng = np.random.RandomState(seed)
@@ -255,6 +281,7 @@ if __name__ == "__main__":
     mca_step_case("bars", 25, 10, 5, 3, 300, seed=23, T=1.0, Ncut=1.0, bars=True)
     mca_step_case("h40", 48, 40, 6, 3, 150, seed=24, T=2.0, Ncut=0.7)
     mca_step_case("h128", 64, 128, 8, 3, 96, seed=25, T=1.0, Ncut=0.0)
+    bsc_inference_case()
     bsc_trajectory()
     bsc_init()
     anneal_tracks()
