@@ -60,6 +60,15 @@ int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B, int64_t ld
  * computed once per resident data shard. */
 int pm_row_sqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, double *out, void *stream);
 
+/* inv = (U + U^T - diag(U) + diag(diag_add))^-1 for a symmetric positive definite n x n matrix given
+ * by its upper triangle `upper` (n <= 256, one workgroup, Gauss-Jordan in registers, no pivoting).
+ * `full` (optional) receives the assembled matrix, `pivots` (optional, 2 doubles) the smallest and
+ * largest pivot: a non-positive or vanishing smallest pivot means "numerically singular".
+ * Solves the H x H system of the M-step, np.linalg.lstsq(Wq, Wp) at bsc_et.py:380, as
+ * W_new = inv . Wp (one pm_gemm_tn_acc_f64). */
+int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, double *full,
+                       double *inv, int64_t ldo, double *pivots, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Binary Sparse Coding (prosper/em/camodels/bsc_et.py)
  * ------------------------------------------------------------------------------------- */

@@ -79,6 +79,39 @@ def test_row_sqnorm(dev):
     np.testing.assert_allclose(out.cpu().numpy(), (Y * Y).sum(1), rtol=1e-13)
 
 
+@pytest.mark.parametrize("n", [1, 7, 32, 33, 100, 256])
+def test_spd_inverse(dev, n):
+    """pm_spd_inverse_f64 (the M-step's W solve, bsc_et.py:380) against LAPACK."""
+    from prosper_amd import _lib
+    rs = np.random.RandomState(n)
+    B = rs.normal(size=(n, 3 * n + 5))
+    A = B @ B.T
+    dadd = rs.uniform(0.1, 1.0, size=n)
+    U = np.triu(A) + np.tril(rs.normal(size=(n, n)), -1)         # the strict lower triangle must be ignored
+    u = torch.from_numpy(U).to(dev)
+    da = torch.from_numpy(dadd).to(dev)
+    full = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    inv = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    piv = torch.zeros(2, dtype=torch.float64, device=dev)
+    _lib.call("pm_spd_inverse_f64", _p(u), n, _p(da), n, _p(full), _p(inv), n, _p(piv), _stream())
+    Af = A + np.diag(dadd)
+    np.testing.assert_array_equal(full.cpu().numpy(), Af)
+    ref = np.linalg.inv(Af)
+    got = inv.cpu().numpy()
+    np.testing.assert_array_equal(got, got.T)
+    cond = np.linalg.cond(Af)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-14 * cond * np.abs(ref).max())
+    d2 = np.diag(np.linalg.cholesky(Af)) ** 2                      # sweep pivots = squared Cholesky diagonal
+    np.testing.assert_allclose(piv.cpu().numpy(), [d2.min(), d2.max()], rtol=1e-9)
+
+
+def test_spd_inverse_rejects_large(dev):
+    from prosper_amd import _lib
+    t = torch.zeros((300, 300), dtype=torch.float64, device=dev)
+    with pytest.raises(_lib.HipError):
+        _lib.call("pm_spd_inverse_f64", _p(t), 300, None, 300, None, _p(t), 300, None, _stream())
+
+
 # ------------------------------------------------------------------------- BSC vs golden
 class _An(dict):
     crit_params = []
