@@ -180,7 +180,7 @@ class DeviceCAModel(CAModel):
         self._ws = {}            # workspaces keyed by name
         self.timer = None        # optional KernelTimer (bench.py)
         self._pin = {}           # pinned staging buffers for asynchronous parameter uploads
-        self._pin_out = None     # pinned buffer of the one device->host copy per M-step
+        self._pin_out = {}       # pinned buffers of the device->host copies (one per M-step), by slot
 
     def _state_masks(self):
         """uint16 mask per multi-cause state: bit j <=> candidate position j is on."""
@@ -260,10 +260,11 @@ class DeviceCAModel(CAModel):
                   M, N, K, self._stream())
         return out
 
-    def _upload(self, name, host):
+    def _upload(self, name, host, keep=False):
         """Asynchronous host -> device copy through a rotating pair of pinned staging buffers
         (a pageable ``.to(device)`` would block the host until the stream drains and stall the
-        EM loop at every step boundary)."""
+        EM loop at every step boundary).  ``keep``: also return the staging buffer's NumPy view,
+        which stays intact until the second-next upload under the same name."""
         slot = self._pin.setdefault(name, {"i": 0, "bufs": [None, None], "evs": [None, None]})
         i = slot["i"] = slot["i"] ^ 1
         buf = slot["bufs"][i]
@@ -271,19 +272,22 @@ class DeviceCAModel(CAModel):
             buf = slot["bufs"][i] = torch.empty(host.shape, dtype=torch.float64).pin_memory()
         elif slot["evs"][i] is not None:
             slot["evs"][i].synchronize()          # the copy that last used this buffer has completed
-        buf.numpy()[...] = host
+        view = buf.numpy()
+        view[...] = host
         dev = torch.empty(host.shape, dtype=torch.float64, device=self.device)
         dev.copy_(buf, non_blocking=True)
         ev = slot["evs"][i] = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return dev
+        return (dev, view) if keep else dev
 
-    def _download(self, flat):
-        """Device -> pinned host copy + wait; returns a NumPy view valid until the next call."""
+    def _download(self, flat, slot="default"):
+        """Device -> pinned host copy + wait; returns a NumPy view valid until the next call
+        with the same ``slot``."""
         n = flat.numel()
-        if self._pin_out is None or self._pin_out.numel() < n:
-            self._pin_out = torch.empty(n, dtype=torch.float64).pin_memory()
-        dst = self._pin_out[:n]
+        buf = self._pin_out.get(slot)
+        if buf is None or buf.numel() < n:
+            buf = self._pin_out[slot] = torch.empty(n, dtype=torch.float64).pin_memory()
+        dst = buf[:n]
         dst.copy_(flat, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))

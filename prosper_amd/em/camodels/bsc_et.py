@@ -45,6 +45,7 @@ class BSC_ET(DeviceCAModel):
         self._tables = None      # device copies of the state table
         self.use_rows16 = True   # 16-lanes-per-datapoint kernels when the shape allows (tests flip this)
         self._side = None        # side stream of the chunked GEMM / row-kernel pipeline
+        self._a0 = None          # (par, data key, rows): whose first-chunk scores the scores_c0 buffer holds
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
         self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
         self.max_chunk_rows = 1 << 20
@@ -95,16 +96,34 @@ class BSC_ET(DeviceCAModel):
         }
         return self._tables
 
+    def _same_W(self, par, W):
+        """Is ``W`` (D,H) the matrix ``par`` was built from?  Compared against a private host snapshot
+        (a pinned staging / download buffer), so in-place edits by the caller are seen."""
+        Wh = par.get("Whost")
+        if Wh is None or W.shape != (self.D, self.H):
+            return False
+        return np.array_equal(Wh, W.T if par["Whost_T"] else W)
+
     def _params_dev(self, W, res):
-        """Device copy of W^T (H,D) and the Gram matrix G = W.W^T for the current W."""
+        """Device copy of W^T (H,D) and the Gram matrix G = W.W^T for the current W.  The M-step leaves
+        its solution on the device (``_seed_params``), so inside an EM loop nothing is uploaded."""
         par = self._par
-        if par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape \
-                and np.array_equal(par["W"], W):
+        if par.get("ykey") == res["key"] and self._same_W(par, W):
             return par
-        Wt = self._upload("W", np.asarray(W, dtype=np.float64)).t().contiguous()   # (H, D), transposed on device
+        W = np.asarray(W, dtype=np.float64)
+        if W.T.flags.c_contiguous:           # (D,H) view of an (H,D) array, e.g. what M_step returns
+            Wt, Whost, flag = self._upload("W", W.T, keep=True) + (True,)
+        else:
+            Wd, Whost = self._upload("W", W, keep=True)
+            Wt, flag = Wd.t().contiguous(), False                                  # transposed on device
         G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
-        self._par = {"ykey": res["key"], "W": np.array(W, dtype=np.float64, copy=True), "Wt": Wt, "G": G, "A": None}
+        self._par = {"ykey": res["key"], "Whost": Whost, "Whost_T": flag, "Wt": Wt, "G": G, "A": None}
         return self._par
+
+    def _seed_params(self, res, Wt_dev, Wt_host, G):
+        """After an M-step: the next step's W^T and Gram matrix are already on the device; ``Wt_host`` is
+        our private host snapshot of W^T, against which the W handed to the next call is checked."""
+        self._par = {"ykey": res["key"], "Whost": Wt_host, "Whost_T": True, "Wt": Wt_dev, "G": G, "A": None}
 
     def _scores(self, model_params, res):
         """A = Y.W^T (N,H) and G = W.W^T for the current W; reused by E_step when
@@ -159,21 +178,22 @@ class BSC_ET(DeviceCAModel):
         else:
             side = main
         done = [None, None]
+        tag = (par, res["key"], rows)
+        have0 = self._a0 is not None and self._a0[0] is par and self._a0[1:] == tag[1:]   # prefetched
+        self._a0 = tag if nchunks <= 2 else None          # whose chunk-0 scores bufs[0] holds afterwards
         for c in range(nchunks):
             r0, r1 = c * rows, min(N, (c + 1) * rows)
             A = bufs[c & 1]
-            with torch.cuda.stream(side):
-                if overlap and done[c & 1] is not None:
-                    side.wait_event(done[c & 1])         # the row kernel that read this buffer is finished
-                Yc = Y[r0:r1]
-                self._call("scores_gemm" if (r1 - r0 == rows or nchunks == 1) else "scores_gemm_tail", "pm_gemm_nt_f64", _ptr(Yc),
-                           Y.stride(0), _ptr(par["Wt"]), par["Wt"].stride(0), _ptr(A), H, r1 - r0, H, Y.shape[1],
-                           ctypes.c_void_p(side.cuda_stream))
+            if not (c == 0 and have0):
+                with torch.cuda.stream(side):
+                    if overlap and done[c & 1] is not None:
+                        side.wait_event(done[c & 1])     # the row kernel that read this buffer is finished
+                    self._scores_chunk(res, par, A, r0, r1, rows, nchunks, side)
+                    if overlap:
+                        ready = torch.cuda.Event()
+                        ready.record(side)
                 if overlap:
-                    ready = torch.cuda.Event()
-                    ready.record(side)
-            if overlap:
-                main.wait_event(ready)
+                    main.wait_event(ready)
             off = lambda t, w=1: ctypes.c_void_p(t.data_ptr() + r0 * w * t.element_size()) if t is not None else None
             self._call("select_estep", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
                        _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S,
@@ -183,10 +203,30 @@ class BSC_ET(DeviceCAModel):
                 done[c & 1] = torch.cuda.Event()
                 done[c & 1].record(main)
 
+    def _scores_chunk(self, res, par, A, r0, r1, rows, nchunks, stream):
+        Y = res["Y"]
+        self._call("scores_gemm" if (r1 - r0 == rows or nchunks == 1) else "scores_gemm_tail", "pm_gemm_nt_f64",
+                   _ptr(Y[r0:r1]), Y.stride(0), _ptr(par["Wt"]), par["Wt"].stride(0), _ptr(A), self.H, r1 - r0, self.H,
+                   Y.shape[1], ctypes.c_void_p(stream.cuda_stream))
+
+    def _prefetch_scores(self, res, par):
+        """Enqueue the scores GEMM of the first chunk as soon as W is known (select_Hprimes), so the
+        device is busy while the host walks on to E_step."""
+        N = res["Y"].shape[0]
+        if not N or self.overlap_streams:
+            return
+        rows = self._chunk_rows(N)
+        tag = (par, res["key"], rows)
+        if self._a0 is not None and self._a0[0] is par and self._a0[1:] == tag[1:]:
+            return
+        nchunks = (N + rows - 1) // rows
+        A = self._buf("scores_c0", (rows, self.H))
+        self._scores_chunk(res, par, A, 0, min(N, rows), rows, nchunks, torch.cuda.current_stream(self.device))
+        self._a0 = tag
+
     def _materialize_candidates(self, ticket):
         """Selection on its own (someone looked at the lazy candidates before E_step ran)."""
-        res = ticket["res"]
-        par = self._params_dev(ticket["W"], res)
+        res, par = ticket["res"], ticket["par"]
         N = res["Y"].shape[0]
         cand = torch.empty((N, self.Hprime), dtype=torch.int32, device=self.device)
         if N:
@@ -214,7 +254,9 @@ class BSC_ET(DeviceCAModel):
         N = res["Y"].shape[0]
         if self._state_tables()["fast"]:
             # deferred: E_step fuses selection with the log-joints in one pass (LazyCandidates)
-            ticket = {"res": res, "W": np.array(model_params['W'], dtype=np.float64, copy=True), "cand": None}
+            par = self._params_dev(np.asarray(model_params['W']), res)
+            self._prefetch_scores(res, par)
+            ticket = {"res": res, "par": par, "cand": None}
             data['candidates'] = LazyCandidates(self, ticket, (N, self.Hprime))
             return data
         par = self._scores(model_params, res)
@@ -274,7 +316,7 @@ class BSC_ET(DeviceCAModel):
             par = self._params_dev(W, res)
             wmu, ymu = self._mu_terms(par, res, mu64)
             fuse = (isinstance(cobj, LazyCandidates) and cobj.pending and cobj._model is self
-                    and cobj._ticket["res"] is res and np.array_equal(cobj._ticket["W"], W))
+                    and cobj._ticket["res"] is res and cobj._ticket["par"] is par)
             if fuse:      # selection + log-joints in one pass
                 cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
                 mode = 3
@@ -375,9 +417,9 @@ class BSC_ET(DeviceCAModel):
 
         # the ONE exchange of the step (replaces bsc_et.py:225,258,266,373,374,387,417,426,427)
         comm.allreduce_device(packed)
-        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma)
+        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res)
 
-    def _finalize(self, packed, model_params, A_pi_gamma, E_pi_gamma):
+    def _finalize(self, packed, model_params, A_pi_gamma, E_pi_gamma, res=None):
         """Parameter updates from the all-reduced statistics (bsc_et.py:264-267, 369-438).
         Everything is enqueued on the device first (Wq assembly, Cholesky solve, reductions) and
         fetched with ONE device->host copy, so an EM step synchronises with the GPU exactly once.
@@ -398,7 +440,7 @@ class BSC_ET(DeviceCAModel):
         learn_W, learn_mu = 'W' in self.to_learn, 'mu' in self.to_learn
 
         parts = [packed[o_sc:o_sc + 4], mus.sum().reshape(1)]
-        Wq = rhs = None
+        Wq = rhs = seed = None
         if learn_W:
             tracing.tracepoint("M_step:update W")
             rhs = Wp
@@ -422,6 +464,8 @@ class BSC_ET(DeviceCAModel):
                 self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(R), D, _ptr(X), D, H, D, H, st)
                 ok_flag = (piv[0] <= 0).to(torch.float64).reshape(1)          # 0 = fine, like cholesky's info
                 parts += [ok_flag, (piv[0] / piv[1]).reshape(1), X.reshape(-1)]
+                if res is not None:      # next step's W^T and Gram matrix are already here: no upload then
+                    seed = (X, self._gemm_nt(X, X, self._buf("gram", (H, H)), "gram_gemm"))
             else:
                 Wq = torch.triu(Wq_u, 1)
                 Wq = Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)
@@ -433,7 +477,9 @@ class BSC_ET(DeviceCAModel):
             parts += [mus, packed[n_stats:]]
         flat = torch.cat(parts)
         if flat.is_cuda:                                        # the one synchronisation of the EM step
-            host = self._download(flat)
+            if learn_W:
+                self._par = {}                                  # its host snapshot may live in the buffer reused now
+            host = self._download(flat, slot="mstep")
         else:
             host = flat.numpy()
 
@@ -448,7 +494,10 @@ class BSC_ET(DeviceCAModel):
         if learn_W:
             ok = host[pos] == 0 and host[pos + 1] > 1e-11 and np.isfinite(host[pos + 1])
             if ok:
-                W_new = host[pos + 2:pos + 2 + H * D].reshape(H, D).copy()
+                Wt_host = host[pos + 2:pos + 2 + H * D].reshape(H, D)
+                W_new = Wt_host.copy()
+                if seed is not None:
+                    self._seed_params(res, seed[0], Wt_host, seed[1])
             else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host
                 with small_blas():
                     W_new = np.linalg.lstsq(Wq.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0]

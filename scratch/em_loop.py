@@ -1,0 +1,29 @@
+"""8 EM iterations of BSC config 2 (for rocprofv3 --kernel-trace --memory-copy-trace timelines)."""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from prosper_amd.em.camodels.bsc_et import BSC_ET
+D,H,HP,GAMMA,N = 1024,256,8,4,200000
+dev=torch.device('cuda',0)
+g0=torch.Generator(device=dev).manual_seed(0)
+W_gt=torch.randn(D,H,generator=g0,device=dev,dtype=torch.float64)
+W0=(W_gt+0.1*torch.randn(D,H,generator=g0,device=dev,dtype=torch.float64)).cpu().numpy()
+Y=torch.empty(N,D,dtype=torch.float64,device=dev)
+for lo in range(0,N,25000):
+    S=(torch.rand(25000,H,generator=g0,device=dev)<4.0/H).to(torch.float64)
+    Y[lo:lo+25000]=S@W_gt.t()+torch.randn(25000,D,generator=g0,device=dev,dtype=torch.float64)
+class An(dict):
+    crit_params=[]
+    def __missing__(s,k): return 0.0
+    def as_dict(s): return dict(s)
+an=An(T=1.0)
+m=BSC_ET(D,H,HP,GAMMA)
+p={"W":W0,"pi":4.0/H,"sigma":1.0,"mu":np.zeros(D)}
+data={"y":Y}
+for _ in range(3): m.step(an,dict(p),data)
+torch.cuda.synchronize()
+q=dict(p)
+t=time.perf_counter()
+for _ in range(8):
+    q=m.step(an,q,data)
+torch.cuda.synchronize()
+print("ms/iter", (time.perf_counter()-t)/8*1e3)
