@@ -12,6 +12,10 @@
 
 #include "prosper_hip.h"
 
+#ifndef PM_SPD_ABL
+#define PM_SPD_ABL 0   // timing ablations for scratch/spd_bench.hip; 0 = the real kernel
+#endif
+
 namespace {
 
 constexpr int TS = 32, EL = 8, NMAX = TS * EL;  // 256
@@ -47,62 +51,47 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const double *__restr
             a[x][y] = v;
         }
     double pmin = INFINITY, pmax = 0.0;
-    for (int k = 0; k < n; ++k) {
-        const int buf = k & 1;
-        const int kx = k >> 5, km = k & 31;
-        // publish column k: c[i] = A[min(i,k)][max(i,k)].  For i in block-row x <= kx the element sits at block
-        // (x, kx) of the threads with tj == km; for x > kx at block (kx, x) of the threads with ti == km.
-        if (tj == km) {
+    // k = 32 kx + km; the outer loop is unrolled so that every register-array index below is static
 #pragma unroll
-            for (int x = 0; x < EL; ++x)
+    for (int kx = 0; kx < EL; ++kx) {
+        const int kend = min(TS, n - TS * kx);             // <= 0 once past the matrix
+        for (int km = 0; km < kend; ++km) {
+            const int k = TS * kx + km;
+            double *cb = s_c[k & 1];
+            // publish column k: c[i] = A[min(i,k)][max(i,k)].  For i in block-row x <= kx the element sits at
+            // block (x, kx) of the threads with tj == km; for x > kx at block (kx, x) of the threads with ti == km.
+            if (PM_SPD_ABL != 3 && tj == km) {
 #pragma unroll
-                for (int y = 0; y < EL; ++y)
-                    if (y >= x && y == kx) s_c[buf][ti + TS * x] = a[x][y];   // rows i = ti + 32 x, x <= kx
-        }
-        if (ti == km) {
-#pragma unroll
-            for (int x = 0; x < EL; ++x)
-#pragma unroll
-                for (int y = 0; y < EL; ++y)
-                    if (y > x && x == kx) s_c[buf][tj + TS * y] = a[x][y];    // columns j = tj + 32 y, y > kx
-        }
-        __syncthreads();
-        const double p = s_c[buf][k];
-        const double ip = 1.0 / p;
-        pmin = fmin(pmin, p);
-        pmax = fmax(pmax, p);
-        const double *cb = s_c[buf];
-        double ci[EL];
-#pragma unroll
-        for (int x = 0; x < EL; ++x) ci[x] = cb[ti + TS * x];
-        // rank-1 update of everything, then the few threads holding row / column k overwrite those entries
-#pragma unroll
-        for (int y = 0; y < EL; ++y) {
-            const double cjy = cb[tj + TS * y] * ip;
-#pragma unroll
-            for (int x = 0; x < EL; ++x) {
-                if (y < x) continue;
-                a[x][y] = fma(-ci[x], cjy, a[x][y]);
+                for (int x = 0; x <= kx; ++x) cb[ti + TS * x] = a[x][kx];
             }
-            asm volatile("" ::: "memory");         // keep the LDS reads of later columns from being hoisted
-        }
-        if (tj == km) {                            // column k: B_ik = A_ik / p
+            if (PM_SPD_ABL != 3 && ti == km) {
 #pragma unroll
-            for (int y = 0; y < EL; ++y)
-                if (y == kx) {
+                for (int y = kx + 1; y < EL; ++y) cb[tj + TS * y] = a[kx][y];
+            }
+            if (PM_SPD_ABL != 4) __syncthreads();
+            const double p = cb[k];
+            const double ip = (PM_SPD_ABL == 1) ? p * 0.5 : 1.0 / p;
+            pmin = fmin(pmin, p);
+            pmax = fmax(pmax, p);
+            double ci[EL];
 #pragma unroll
-                    for (int x = 0; x < EL; ++x)
-                        if (x <= y) a[x][y] = ci[x] * ip;
-                }
-        }
-        if (ti == km) {                            // row k: B_kj = A_kj / p, and B_kk = -1/p
+            for (int x = 0; x < EL; ++x) ci[x] = (PM_SPD_ABL == 2) ? p + x : cb[ti + TS * x];
+            // rank-1 update of everything, then the few threads holding row / column k overwrite those entries
 #pragma unroll
-            for (int x = 0; x < EL; ++x)
-                if (x == kx) {
+            for (int y = 0; y < EL; ++y) {
+                const double cjy = ((PM_SPD_ABL == 2) ? p - y : cb[tj + TS * y]) * ip;
 #pragma unroll
-                    for (int y = 0; y < EL; ++y)
-                        if (y >= x) a[x][y] = (tj == km && y == x) ? -ip : cb[tj + TS * y] * ip;
-                }
+                for (int x = 0; x <= y; ++x) a[x][y] = fma(-ci[x], cjy, a[x][y]);
+                asm volatile("" ::: "memory");             // keep the LDS reads of later columns from being hoisted
+            }
+            if (tj == km) {                                // column k: B_ik = A_ik / p
+#pragma unroll
+                for (int x = 0; x <= kx; ++x) a[x][kx] = ci[x] * ip;
+            }
+            if (ti == km) {                                // row k: B_kj = A_kj / p, and B_kk = -1/p
+#pragma unroll
+                for (int y = kx; y < EL; ++y) a[kx][y] = (tj == km && y == kx) ? -ip : cb[tj + TS * y] * ip;
+            }
         }
     }
 #pragma unroll
