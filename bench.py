@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
-    ap.add_argument("--em-steps", type=int, default=5, help="full EM iterations timed for em_iter_ms")
+    ap.add_argument("--em-steps", type=int, default=20, help="full EM iterations timed for em_iter_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
     return ap.parse_args()

@@ -280,9 +280,10 @@ class DeviceCAModel(CAModel):
         ev.record(torch.cuda.current_stream(self.device))
         return (dev, view) if keep else dev
 
-    def _download(self, flat, slot="default"):
+    def _download(self, flat, slot="default", then=None):
         """Device -> pinned host copy + wait; returns a NumPy view valid until the next call
-        with the same ``slot``."""
+        with the same ``slot``.  ``then()`` runs after the copy is enqueued and before the wait:
+        work it launches keeps the device busy while the host digests the result."""
         n = flat.numel()
         buf = self._pin_out.get(slot)
         if buf is None or buf.numel() < n:
@@ -291,6 +292,8 @@ class DeviceCAModel(CAModel):
         dst.copy_(flat, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
+        if then is not None:
+            then()
         ev.synchronize()
         return dst.numpy()
 

@@ -46,6 +46,8 @@ class BSC_ET(DeviceCAModel):
         self.use_rows16 = True   # 16-lanes-per-datapoint kernels when the shape allows (tests flip this)
         self._side = None        # side stream of the chunked GEMM / row-kernel pipeline
         self._a0 = None          # (par, data key, rows): whose first-chunk scores the scores_c0 buffer holds
+        self._spec_ok = False    # the last M-step's seeded parameters were used as they were
+        self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
         self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
         self.max_chunk_rows = 1 << 20
@@ -109,7 +111,10 @@ class BSC_ET(DeviceCAModel):
         its solution on the device (``_seed_params``), so inside an EM loop nothing is uploaded."""
         par = self._par
         if par.get("ykey") == res["key"] and self._same_W(par, W):
+            if par.pop("seeded", False):
+                self._spec_ok = True         # the EM loop fed the M-step's W straight back: keep speculating
             return par
+        self._spec_ok = False
         W = np.asarray(W, dtype=np.float64)
         if W.T.flags.c_contiguous:           # (D,H) view of an (H,D) array, e.g. what M_step returns
             Wt, Whost, flag = self._upload("W", W.T, keep=True) + (True,)
@@ -120,10 +125,15 @@ class BSC_ET(DeviceCAModel):
         self._par = {"ykey": res["key"], "Whost": Whost, "Whost_T": flag, "Wt": Wt, "G": G, "A": None}
         return self._par
 
-    def _seed_params(self, res, Wt_dev, Wt_host, G):
-        """After an M-step: the next step's W^T and Gram matrix are already on the device; ``Wt_host`` is
-        our private host snapshot of W^T, against which the W handed to the next call is checked."""
-        self._par = {"ykey": res["key"], "Whost": Wt_host, "Whost_T": True, "Wt": Wt_dev, "G": G, "A": None}
+    def _seed_params(self, res, Wt_dev, G, speculate):
+        """After an M-step the next step's W^T and Gram matrix are already on the device.  Returns the
+        parameter record to install once the host snapshot ``Whost`` has arrived.  ``speculate``: the
+        previous seed was consumed unchanged (plain EM loop, no parameter noise), so the next step's
+        scores GEMM is enqueued right away and runs while the host finishes this step."""
+        par = {"ykey": res["key"], "Whost": None, "Whost_T": True, "Wt": Wt_dev, "G": G, "A": None, "seeded": True}
+        if speculate:
+            self._prefetch_scores(res, par)
+        return par
 
     def _scores(self, model_params, res):
         """A = Y.W^T (N,H) and G = W.W^T for the current W; reused by E_step when
@@ -477,9 +487,12 @@ class BSC_ET(DeviceCAModel):
             parts += [mus, packed[n_stats:]]
         flat = torch.cat(parts)
         if flat.is_cuda:                                        # the one synchronisation of the EM step
+            spec = []
             if learn_W:
                 self._par = {}                                  # its host snapshot may live in the buffer reused now
-            host = self._download(flat, slot="mstep")
+                self._a0 = None
+            then = (lambda: spec.append(self._seed_params(res, seed[0], seed[1], self._spec_ok and self.speculate))) if seed else None
+            host = self._download(flat, slot="mstep", then=then)
         else:
             host = flat.numpy()
 
@@ -497,8 +510,10 @@ class BSC_ET(DeviceCAModel):
                 Wt_host = host[pos + 2:pos + 2 + H * D].reshape(H, D)
                 W_new = Wt_host.copy()
                 if seed is not None:
-                    self._seed_params(res, seed[0], Wt_host, seed[1])
+                    spec[0]["Whost"] = Wt_host
+                    self._par = spec[0]
             else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host
+                self._a0 = None
                 with small_blas():
                     W_new = np.linalg.lstsq(Wq.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0]
             pos += 2 + H * D
