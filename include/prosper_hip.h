@@ -148,7 +148,10 @@ int pm_bsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S);
  * dropping its highest candidate position (0xFFFF when that leaves a singleton);
  * `size_offsets_host[g-2]` = index of the first state with g causes, g = 2..gamma, and
  * size_offsets_host[gamma-1] = S (states are ordered by size, camodels/__init__.py:32-35).
- * Selection ties: similarities equal in their leading 42 mantissa bits rank by latent index. */
+ * Selection ties: similarities equal in their leading 42 mantissa bits rank by latent index.
+ * Further selection modes (other models reuse the selection pass): bit 2 = the Hprime SMALLEST
+ * first (mca_et.py:107), bit 3 = rank `scores` as they are (no normalisation), bit 4 = rank the
+ * squared distance |W_h|^2 - 2 scores[n,h] with |W_h|^2 from the Gram diagonal (mmca_et.py:119-120). */
 int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
                             const double *wmu, const double *ymu, const uint16_t *state_masks,
                             const uint16_t *state_parents, const int32_t *size_offsets_host, int64_t S,
@@ -172,12 +175,15 @@ int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse,
 int pm_mca_select_scores_f64(const double *Y, int64_t ldy, const double *W, int64_t ldw, double *R,
                              int64_t ldr, int64_t N, int64_t H, int64_t D, void *stream);
 
-/* Scalars of one MCA step (mca_et.py:142-149, 213-221). */
+/* Scalars of one MCA step (mca_et.py:142-149, 213-221) or MMCA step (mmca_et.py:156-168, 251-262). */
 typedef struct pm_mca_params {
     double pil_bar;   /* log(pi / (1 - pi))                                 */
     double pre1;      /* -1 / (2 sigma^2)                                   */
     double beta;      /* 1 / T (applied to the log-joints in the M-step)    */
-    double inv_rho;   /* 1 / rho, rho = 1 / (1 - 1 / max(T, 1.05))          */
+    double inv_rho;   /* 1 / rho, rho = 1 / (1 - 1 / max(T, 1.05)) (MMCA: T bound 1.2, rho in [1, 35]) */
+    double signed_w;  /* 0: MCA (W > 0).  1: MMCA, signed W (prosper/em/camodels/mmca_et.py): Wrho holds
+                         sign(W)|W|^rho, Wrm1 holds |W|^(rho-1); Wbar_sd = sign(t)|t|^(1/rho), t = sum Wrho;
+                         the M-step factor is min(1, (|W_jd| / |Wbar_sd|)^(rho-1)) (mmca_et.py:321-324) */
 } pm_mca_params;
 
 /* E_step, mca_et.py:114-179.  scores = Y.W^T (pm_gemm_nt_f64), wnorm2 = |W_h|^2 (contiguous),

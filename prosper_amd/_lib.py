@@ -15,7 +15,8 @@ i64 = C.c_int64
 
 class McaParams(C.Structure):
     """struct pm_mca_params"""
-    _fields_ = [("pil_bar", C.c_double), ("pre1", C.c_double), ("beta", C.c_double), ("inv_rho", C.c_double)]
+    _fields_ = [("pil_bar", C.c_double), ("pre1", C.c_double), ("beta", C.c_double), ("inv_rho", C.c_double),
+                ("signed_w", C.c_double)]
 
 
 class EStepParams(C.Structure):

@@ -83,6 +83,8 @@ struct SizeOffsets {  // multi-cause states of size g occupy [off[g-2], off[g-1]
 // select_Hprimes + E_step
 //   mode bit 0: select (compute + write candidates); else candidates are read from `cand`
 //   mode bit 1: E-step (write logpj / lse)
+//   mode bit 2: rank smallest first; bit 3: rank the scores as they are; bit 4: rank the squared
+//               distance |W_h|^2 - 2 a_h (MMCA, mmca_et.py:119-120)
 // ---------------------------------------------------------------------------------------------
 template <int VPL>
 __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 2) void bsc_select_estep16_kernel(
@@ -134,14 +136,14 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 2) void bsc_select_estep16_ker
         int myc = 0;  // lane j < Hp ends up with candidate position j
         if (do_select) {
             const double sy = 1.0 / sqrt(yn);
-            const bool smallest = mode & 4, raw = mode & 8;
+            const bool smallest = mode & 4, raw = mode & 8, dist = mode & 16;
             uint64_t key[VPL];
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 const int h = j + 16 * i;
                 uint64_t k = 0;
                 if (h < H) {
-                    double x = raw ? a[i] : a[i] * s_sw[h] * sy;
+                    double x = raw ? a[i] : dist ? s_w2[h] - 2.0 * a[i] : a[i] * s_sw[h] * sy;
                     if (smallest) x = -x;
                     k = (x == x) ? order_key(x) : 0x0000000000000400ull;  // NaN ranks below every number
                     // low 10 bits carry the latent index; ties resolve as a stable argsort would:

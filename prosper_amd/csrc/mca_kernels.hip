@@ -141,7 +141,8 @@ __global__ void mca_estep_kernel(const double *__restrict__ scores, int64_t lds,
                     T += s_wr[j * DS + d];
                 }
                 if (d < D) {
-                    const double wbar = exp(log(T) * P.inv_rho);
+                    // MMCA: T may be negative or 0 (mmca_et.py:191: sign(t) exp(log|t| / rho)); for MCA T > 0
+                    const double wbar = copysign(exp(log(fabs(T)) * P.inv_rho), T);
                     const double df = wbar - y[i];
                     part += df * df;
                 }
@@ -206,7 +207,7 @@ __global__ void mca_estep_kernel(const double *__restrict__ scores, int64_t lds,
 // ---------------------------------------------------------------------------------------------
 // M-step, per-datapoint part
 // ---------------------------------------------------------------------------------------------
-template <int DPL, int HP>
+template <int DPL, int HP, bool SIGNED>
 __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse1,
                                       const double *__restrict__ lseb, double lse_cut,
                                       const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
@@ -222,7 +223,8 @@ __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *s_q1sum = reinterpret_cast<double *>(smem);
     double *s_red = s_q1sum + H;
-    double *s_wr = s_red + 4 * waves + (size_t)wave * (HP * DS);
+    double *s_wr = s_red + 4 * waves + (size_t)wave * ((SIGNED ? 2 : 1) * HP * DS);
+    double *s_wm = s_wr + HP * DS;   // SIGNED only: |W|^(rho-1)[cand]
     for (int h = tid; h < H; h += blockDim.x) s_q1sum[h] = 0.0;
     __syncthreads();
 
@@ -302,6 +304,7 @@ __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t 
                         for (int i = 0; i < DPL; ++i) {
                             const int d = lane + 64 * i;
                             s_wr[j * DS + d] = (d < D) ? srcw[d] : 1.0;
+                            if (SIGNED) s_wm[j * DS + d] = (d < D) ? Wrm1[(int64_t)cn[j] * D + d] : 1.0;
                         }
                     }
                     wave_sync_lds();
@@ -315,11 +318,21 @@ __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t 
 #pragma unroll
                     for (int j = 0; j < HP; ++j)
                         if ((mask >> j) & 1u) T += s_wr[j * DS + d];
-                    const double wbar = exp(log(T) * P.inv_rho);
-                    const double v = q * wbar / T;  // q_s * Wbar_sd / T_sd
+                    if (!SIGNED) {
+                        const double wbar = exp(log(T) * P.inv_rho);
+                        const double v = q * wbar / T;  // q_s * Wbar_sd / T_sd
 #pragma unroll
-                    for (int j = 0; j < HP; ++j)
-                        if ((mask >> j) & 1u) V[j][i] += v;
+                        for (int j = 0; j < HP; ++j)
+                            if ((mask >> j) & 1u) V[j][i] += v;
+                    } else {
+                        // q_s min(1, (|W_jd| / |Wbar_sd|)^(rho-1)), (.)^(rho-1) = |W_jd|^(rho-1) |Wbar_sd| / |t_sd|;
+                        // t = 0 gives Wbar = 0 and the factor 1 (mmca_et.py:316-324: max(-inf - Wl, 0) = 0)
+                        const double aT = fabs(T);
+                        const double r = (aT > 0.0) ? q * exp(log(aT) * P.inv_rho) / aT : INFINITY;
+#pragma unroll
+                        for (int j = 0; j < HP; ++j)
+                            if ((mask >> j) & 1u) V[j][i] += fmin(q, r * s_wm[j * DS + d]);
+                    }
                 }
             }
         }
@@ -332,7 +345,7 @@ __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t 
                     for (int i = 0; i < DPL; ++i) {
                         const int d = lane + 64 * i;
                         if (d < D) {
-                            const double aid = V[j][i] * Wrm1[base + d];  // Aid[j,d] (mca_et.py:309)
+                            const double aid = SIGNED ? V[j][i] : V[j][i] * Wrm1[base + d];  // Aid[j,d] (mca_et.py:309)
                             pm_atomic_add(Wp + base + d, aid * y[i]);
                             pm_atomic_add(Wq + base + d, aid);
                         }
@@ -438,7 +451,7 @@ extern "C" int pm_mca_estep_f64(const double *scores, int64_t lds, const double 
 }
 
 namespace {
-template <int DPL>
+template <int DPL, bool SIGNED>
 int launch_mstep_hp(int hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, const double *logpj, int64_t ldl,
                     const double *lse1, const double *lseb, double lse_cut, const double *Y, int64_t ldy,
                     const double *Wrho, const double *Wrm1, const int32_t *cand, const uint16_t *masks, int S,
@@ -447,8 +460,8 @@ int launch_mstep_hp(int hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, 
     hp = hp <= 4 ? 4 : hp <= 8 ? 8 : 12;
 #define PM_CASE(HPV)                                                                                              \
     case HPV: {                                                                                                   \
-        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_mstep_rows_kernel<DPL, HPV>), shmem)) return e; \
-        hipLaunchKernelGGL((mca_mstep_rows_kernel<DPL, HPV>), grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, \
+        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_mstep_rows_kernel<DPL, HPV, SIGNED>), shmem)) return e; \
+        hipLaunchKernelGGL((mca_mstep_rows_kernel<DPL, HPV, SIGNED>), grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, \
                            ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, q1, ldq, stats);                      \
         return (int)hipGetLastError();                                                                            \
     }
@@ -473,16 +486,21 @@ extern "C" int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
     const int dpl = D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : 8;
     const int hp_tile = Hprime <= 4 ? 4 : Hprime <= 8 ? 8 : 12;
     if ((int64_t)dpl * hp_tile > 48) return PM_ERANGE;  // V[HP][DPL] register tile
-    const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl);
+    const bool sgn = params_host->signed_w != 0.0;
+    const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl) * (sgn ? 2 : 1);
     const size_t shared = sizeof(double) * (H + 16);
     const int waves = pick_waves(per_wave, shared);
     const size_t shmem = shared + per_wave * waves;
+    if (shmem > 150 * 1024) return PM_ERANGE;
     dim3 grid((unsigned)grid_waves(N, waves)), block(64 * waves);
     hipStream_t s = static_cast<hipStream_t>(stream);
+#define PM_ARGS (int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, \
+                (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats
     switch (dpl) {
-        case 1: return launch_mstep_hp<1>((int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats);
-        case 2: return launch_mstep_hp<2>((int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats);
-        case 4: return launch_mstep_hp<4>((int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats);
-        default: return launch_mstep_hp<8>((int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats);
+        case 1: return sgn ? launch_mstep_hp<1, true>(PM_ARGS) : launch_mstep_hp<1, false>(PM_ARGS);
+        case 2: return sgn ? launch_mstep_hp<2, true>(PM_ARGS) : launch_mstep_hp<2, false>(PM_ARGS);
+        case 4: return sgn ? launch_mstep_hp<4, true>(PM_ARGS) : launch_mstep_hp<4, false>(PM_ARGS);
+        default: return sgn ? launch_mstep_hp<8, true>(PM_ARGS) : launch_mstep_hp<8, false>(PM_ARGS);
     }
+#undef PM_ARGS
 }

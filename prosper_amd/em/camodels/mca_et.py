@@ -44,6 +44,7 @@ class MCA_ET(DeviceCAModel):
             'sigma': (W_tol, +np.inf, False),
         }
         self._masks_dev = None
+        self.signed_w = 0.0           # 1.0 in MMCA_ET: signed W, see pm_mca_params
 
     @tracing.traced
     def check_params(self, model_params):
@@ -96,7 +97,7 @@ class MCA_ET(DeviceCAModel):
 
     def _params(self, anneal, pies, sigma, rho):
         return _lib.McaParams(pil_bar=float(np.log(pies / (1. - pies))), pre1=float(-1. / 2. / sigma / sigma),
-                              beta=float(1. / anneal['T']), inv_rho=float(1. / rho))
+                              beta=float(1. / anneal['T']), inv_rho=float(1. / rho), signed_w=self.signed_w)
 
     # ------------------------------------------------------------------ hot path
     @tracing.traced

@@ -36,6 +36,7 @@ from prosper.em.annealing import LinearAnnealing             # noqa: E402
 from prosper.em.camodels.bsc_et import BSC_ET                # noqa: E402
 from prosper.em.camodels.mca_et import MCA_ET                # noqa: E402
 from prosper.em.camodels.gsc_et import GSC                   # noqa: E402
+from prosper.em.camodels.mmca_et import MMCA_ET              # noqa: E402
 from prosper.utils.barstest import generate_bars_dict        # noqa: E402
 
 
@@ -151,6 +152,35 @@ def mca_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, bars=False):
     print("mca_step_%s: N=%d K=%d Q=%.6f N_use=%d" % (name, N, ss["logpj"].shape[1], new["Q"], Capture.rows["N_use"][0]))
 
 
+def mmca_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut):
+    """One check_params -> select_Hprimes -> E_step -> M_step of MMCA_ET (signed max-magnitude causes)."""
+    rng = np.random.RandomState(seed)
+    W_gt = rng.normal(size=(D, H)) * 3.0
+    pi_gt, sigma_gt = min(0.45, 2.0 / H), 1.0
+    W0 = W_gt * (1.0 + 0.2 * rng.uniform(-1, 1, size=(D, H)))
+    W0[rng.random_sample((D, H)) < 0.03] = 1e-6        # some entries below tol: check_params must lift them
+    model = MMCA_ET(D, H, Hp, gamma)
+    s = rng.random_sample((N, H)) < pi_gt
+    gen = model.generate_from_hidden({"W": W_gt, "pi": pi_gt, "sigma": 0.0}, {"s": s})
+    y_clean = gen["y"]
+    y = y_clean + rng.normal(scale=sigma_gt, size=(N, D))
+    params = {"W": W0, "pi": pi_gt * 1.3, "sigma": sigma_gt * 1.2}
+    inp = {k: np.array(v, copy=True) for k, v in params.items()}
+    anneal = FixedAnneal(T=T, Ncut_factor=Ncut)
+    Capture.rows.clear()
+    params = model.check_params(params)
+    data = model.select_Hprimes(params, {"y": y.copy()})
+    ss = model.E_step(anneal, params, data)
+    new = model.M_step(anneal, params, ss, data)
+    assert np.isfinite(new["W"]).all() and np.isfinite(new["Q"]), name
+    np.savez_compressed(os.path.join(HERE, "mmca_step_%s.npz" % name), D=D, H=H, Hprime=Hp, gamma=gamma, T=T,
+                        Ncut_factor=Ncut, y=y, s=s, y_clean=y_clean, W_gt=W_gt, W=inp["W"], pi=inp["pi"],
+                        sigma=inp["sigma"], candidates=data["candidates"].astype(np.int64), logpj=ss["logpj"],
+                        W_new=new["W"], pi_new=new["pi"], sigma_new=new["sigma"], Q=new["Q"],
+                        N_use=Capture.rows["N_use"][0], state_matrix=model.state_matrix)
+    print("mmca_step_%s: N=%d K=%d Q=%.6f N_use=%d" % (name, N, ss["logpj"].shape[1], new["Q"], Capture.rows["N_use"][0]))
+
+
 class FixedAnneal(dict):
     """One annealing position; unknown keys -> 0.0 like LinearAnnealing.__getitem__."""
     crit_params = []
@@ -259,7 +289,14 @@ def anneal_tracks():
     print("anneal_tracks ok", names)
 
 
-if __name__ == "__main__":
+def main(only=None):
+    """``only``: regenerate just the fixtures whose name starts with this prefix (e.g. ``mmca``)."""
+    want = lambda fn: only is None or fn.__name__.startswith(only)
+    g = globals()
+    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "bsc_inference_case",
+               "bsc_trajectory", "bsc_init", "anneal_tracks"):
+        if not want(g[_n]):
+            g[_n] = (lambda *a, **k: None)
     # BASELINE config-1 dims (D=25 H=10 H'=5 gamma=3)
     bsc_step_case("c1_plain", 25, 10, 5, 3, 400, seed=1, T=1.0, Ncut=0.0, anneal_prior=False, bars=True)
     bsc_step_case("c1_anneal_cut", 25, 10, 5, 3, 333, seed=2, T=1.7, Ncut=0.6, anneal_prior=True, bars=True)
@@ -285,3 +322,11 @@ if __name__ == "__main__":
     bsc_trajectory()
     bsc_init()
     anneal_tracks()
+    mmca_step_case("small", 16, 8, 4, 3, 300, seed=51, T=1.0, Ncut=0.0)
+    mmca_step_case("small_cut", 16, 8, 4, 3, 257, seed=52, T=1.5, Ncut=0.5)
+    mmca_step_case("h40", 48, 40, 6, 3, 150, seed=53, T=2.5, Ncut=0.7)
+    mmca_step_case("h128", 64, 128, 8, 3, 96, seed=54, T=1.0, Ncut=0.0)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

@@ -123,6 +123,44 @@ def test_mca_step_matches_reference(case, flavour):
     np.testing.assert_allclose(new["Q"], g["Q"], rtol=1e-11)
 
 
+# ----------------------------------------------------------------------------- MMCA (mmca_et.py)
+def _mmca_cases():
+    import glob, os
+    from conftest import GOLDEN
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "mmca_step_*.npz")))
+
+
+@pytest.mark.parametrize("case", _mmca_cases())
+@pytest.mark.parametrize("flavour", ["loop", "vec"])
+def test_mmca_step_matches_reference(case, flavour):
+    from oracle import mmca_oracle as M
+    g = golden(case)
+    model = M.make_model(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    assert np.array_equal(model["SM"], g["state_matrix"])
+    an = M.Anneal(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]))
+    np.testing.assert_array_equal(M.generate_from_hidden(g["W_gt"], g["s"]), g["y_clean"])
+    params = M.check_params({"W": g["W"], "pi": float(g["pi"]), "sigma": float(g["sigma"])})
+    assert np.abs(params["W"]).min() >= M.TOL and (np.abs(g["W"]) < M.TOL).any()
+    vec = flavour == "vec"
+    cand = (M.select_hprimes_vec if vec else M.select_hprimes_loop)(params["W"], g["y"], model["Hprime"])
+    if vec:     # Gram form: rounding may swap near-ties; the sets must agree wherever the distances are distinct
+        d = ((params["W"].T[None] - g["y"][:, None, :]) ** 2).sum(axis=2)
+        for n in np.where((cand != g["candidates"]).any(axis=1))[0]:
+            np.testing.assert_allclose(d[n, cand[n]], d[n, g["candidates"][n]], rtol=1e-10)
+        cand = g["candidates"]
+    else:
+        assert np.array_equal(cand, g["candidates"])
+    logpj = (M.e_step_vec if vec else M.e_step_loop)(an, params["W"], params["pi"], params["sigma"], g["y"], cand,
+                                                     model["SM"], model["state_abs"])
+    np.testing.assert_allclose(logpj, g["logpj"], rtol=1e-10, atol=1e-9)
+    new, log = M.m_step(an, model, params["W"], params["pi"], params["sigma"], g["y"], cand, g["logpj"], vec=vec)
+    assert log["N_use"] == int(g["N_use"])
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=1e-10)
+    np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=1e-10)
+    np.testing.assert_allclose(new["Q"], g["Q"], rtol=1e-11)
+
+
 # ----------------------------------------------------------------------------- GSC (gsc_et.py)
 def _gsc_cases():
     import glob, os
