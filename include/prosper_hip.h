@@ -214,6 +214,52 @@ int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse1, 
                           int64_t Hprime, double *q1, int64_t ldq, double *stats, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Discrete Sparse Coding (prosper/em/camodels/dsc_et.py, DSC_ET): K-ary latents
+ * ------------------------------------------------------------------------------------- */
+#define PM_DSC_MAX_K 8      /* latent values incl. the zero value */
+
+/* Scalars of one DSC step (dsc_et.py:376-388, 533-558). */
+typedef struct pm_dsc_params {
+    int32_t K;                       /* number of latent values                                   */
+    int32_t K0;                      /* index of the value 0 (dsc_et.py:153)                      */
+    double values[PM_DSC_MAX_K];     /* the latent values `states`                                */
+    double logpi[PM_DSC_MAX_K];      /* log pi_k (selection only)                                 */
+    double pre1;                     /* -1 / (2 sigma^2) (selection only)                         */
+    double ecoef;                    /* beta * pre1: logpj = ecoef * e + pscale * prior           */
+    double pscale;                   /* beta if anneal['anneal_prior'] else 1 (dsc_et.py:579-584)  */
+} pm_dsc_params;
+
+/* select_Hprimes, dsc_et.py:347-410: R[n,h] = -max_{k != K0} (pre1 (v_k^2 G_hh - 2 v_k scores[n,h]) + log pi_k),
+ * the negated best singleton log-joint of latent h up to per-datapoint constants.  The candidates are
+ * the Hprime smallest R, best first: pm_bsc_select_estep_f64(mode = 1|4|8) on R. */
+int pm_dsc_select_scores_f64(const double *scores, int64_t lds, const double *gram,
+                             const pm_dsc_params *params_host, int64_t N, int64_t H, double *R, int64_t ldr,
+                             void *stream);
+
+/* E_step, dsc_et.py:492-585.  state_idx (S,Hprime) uint8: index into `values` of every entry of the
+ * multi-cause state matrix (itertools.product order, dsc_et.py:56-63); prior = pre_F (1 + (K-1)H + S)
+ * (dsc_et.py:539-558).  Columns of logpj: [null | singletons by non-zero value then latent | states].
+ * Also writes lse = log sum_k exp(logpj). */
+int pm_dsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
+                     const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
+                     const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t Hprime, double *logpj,
+                     int64_t ldl, double *lse, void *stream);
+
+/* Packed DSC statistics (float64): [ Wp = E[s]^T.Y (H*D, filled by pm_gemm_tn_acc_f64) |
+ * Wq upper triangle, multi-cause part (H*H) | Wq diagonal, singleton part (H) |
+ * expected counts of every non-zero value (PM_DSC_MAX_K, entry K0 unused) |
+ * sum_nk q e, sum lse, kept datapoints, unused ]. */
+int64_t pm_dsc_stats_len(int64_t H, int64_t D);
+
+/* Per-datapoint part of M_step, dsc_et.py:660-735, for datapoints with lse[n] > lse_cut (strict,
+ * dsc_et.py:832): writes E[s] rows into expect (N,H) (zero rows for cut datapoints) and accumulates
+ * the statistics above into `stats` (caller zeroes it once per EM step). */
+int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                          const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
+                          const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
+                          double *expect, int64_t lde, double *stats, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Gaussian (spike-and-slab) Sparse Coding, scalar noise (prosper/em/camodels/gsc_et.py, GSC)
  * ------------------------------------------------------------------------------------- */
 

@@ -19,6 +19,12 @@ class McaParams(C.Structure):
                 ("signed_w", C.c_double)]
 
 
+class DscParams(C.Structure):
+    """struct pm_dsc_params"""
+    _fields_ = [("K", C.c_int32), ("K0", C.c_int32), ("values", C.c_double * 8), ("logpi", C.c_double * 8),
+                ("pre1", C.c_double), ("ecoef", C.c_double), ("pscale", C.c_double)]
+
+
 class EStepParams(C.Structure):
     """struct pm_bsc_estep_params"""
     _fields_ = [("pil_bar", C.c_double), ("ecoef", C.c_double),
@@ -55,6 +61,12 @@ SIGNATURES = {
     "pm_mca_stats_len": (i64, [i64, i64]),
     "pm_mca_mstep_rows_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64,
                                         C.POINTER(McaParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
+    "pm_dsc_select_scores_f64": (C.c_int, [c_dp, i64, c_dp, C.POINTER(DscParams), i64, i64, c_dp, i64, c_dp]),
+    "pm_dsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp, C.POINTER(DscParams), i64, i64, i64,
+                                   c_dp, i64, c_dp, c_dp]),
+    "pm_dsc_stats_len": (i64, [i64, i64]),
+    "pm_dsc_mstep_rows_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64, c_dp, C.POINTER(DscParams),
+                                        i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
     "pm_gsc_supported": (C.c_int, [i64, i64, i64]),
     "pm_gsc_stats_len": (i64, [i64]),
     "pm_gsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,

@@ -1,0 +1,332 @@
+// Discrete Sparse Coding (prosper/em/camodels/dsc_et.py) on gfx950: K-ary latents with values
+// v_k (one of them 0), linear superposition.  All energies come from the f64 MFMA scores GEMM
+// a = Y.W^T and the Gram matrix G = W.W^T:
+//
+//   singleton (k,h):   e = v_k^2 G_hh - 2 v_k a_h + |y|^2
+//   multi-cause state: e = |y|^2 + sum_j v_j (v_j G_jj - 2 a_j) + 2 sum_{j<k} v_j v_k G_jk   (candidate block)
+//
+//   dsc_select_scores_kernel   R[n,h] = -max_k (pre1 (v_k^2 G_hh - 2 v_k a_h) + log pi_k): the per-latent
+//                              best singleton log-joint up to datapoint constants (dsc_et.py:389-400);
+//                              ranked by the 16-lane selection kernel (smallest R first = best first)
+//   dsc_estep_kernel           log-pseudo-joints + stabilised log-evidence (dsc_et.py:492-585)
+//   dsc_mstep_rows_kernel      q = exp(logpj - lse); E[s] rows (for Wp = E[s]^T.Y), E[s s^T] scatter,
+//                              expected value counts (pi), sum q e (sigma), sum lse (L) (dsc_et.py:660-735)
+//
+// One 64-lane wavefront per datapoint, four per workgroup; the state table (S x H' value indices,
+// one byte each) and |W_h|^2 sit in LDS.  These kernels are bandwidth/latency-bound row passes; the
+// flops of the model are in the two GEMMs.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "prosper_hip.h"
+#include "pm_common.h"
+
+namespace {
+
+constexpr int WAVES = 4;
+
+__device__ __forceinline__ void wave_sync_lds_dsc() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void dsc_select_scores_kernel(const double *__restrict__ scores, int64_t lds,
+                                                                 const double *__restrict__ gram, pm_dsc_params P,
+                                                                 int64_t N, int H, double *__restrict__ R,
+                                                                 int64_t ldr) {
+    const int64_t total = N * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / H;
+        const int h = (int)(i - n * H);
+        const double a = scores[n * lds + h];
+        const double w2 = gram[(int64_t)h * H + h];
+        double best = -INFINITY;
+        for (int k = 0; k < P.K; ++k) {
+            if (k == P.K0) continue;
+            const double v = P.values[k];
+            best = fmax(best, P.pre1 * (v * v * w2 - 2.0 * v * a) + P.logpi[k]);
+        }
+        R[n * ldr + h] = -best;
+    }
+}
+
+// energy of multi-cause state `row` (H' value indices) from the candidate block in LDS
+__device__ __forceinline__ double state_energy(const uint8_t *row, int Hp, const pm_dsc_params &P,
+                                               const double *s_a, const double *s_G, double yn) {
+    double e = yn;
+    for (int j = 0; j < Hp; ++j) {
+        const double vj = P.values[row[j]];
+        if (vj == 0.0) continue;
+        double t = vj * s_G[j * Hp + j] - 2.0 * s_a[j];
+        for (int k = 0; k < j; ++k) {
+            const double vk = P.values[row[k]];
+            if (vk != 0.0) t += 2.0 * vk * s_G[j * Hp + k];
+        }
+        e += vj * t;
+    }
+    return e;
+}
+
+__global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
+    const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
+    const double *__restrict__ ynorm2, const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S,
+    const double *__restrict__ prior, pm_dsc_params P, int64_t N, int H, int Hp, double *__restrict__ logpj,
+    int64_t ldl, double *__restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [ w2 (H) | per wave: a (Hp) G (Hp*Hp) | state table (S*Hp bytes) ]
+    double *s_w2 = reinterpret_cast<double *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *s_a = s_w2 + H + wave * (Hp + Hp * Hp);
+    double *s_G = s_a + Hp;
+    uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_w2 + H + WAVES * (Hp + Hp * Hp));
+    for (int h = tid; h < H; h += blockDim.x) s_w2[h] = gram[(int64_t)h * H + h];
+    for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
+    __syncthreads();
+
+    const int nss = (P.K - 1) * H;
+    for (int64_t n = (int64_t)blockIdx.x * WAVES + wave; n < N; n += (int64_t)gridDim.x * WAVES) {
+        const double *arow = scores + n * lds;
+        const int32_t *cn = cand + n * Hp;
+        const double yn = ynorm2[n];
+        if (lane < Hp) s_a[lane] = arow[cn[lane]];
+        for (int p = lane; p < Hp * Hp; p += 64) s_G[p] = gram[(int64_t)cn[p / Hp] * H + cn[p % Hp]];
+        wave_sync_lds_dsc();
+
+        double *out = logpj + n * ldl;
+        double m = -INFINITY;
+        if (lane == 0) {
+            const double f0 = P.ecoef * yn + P.pscale * prior[0];
+            out[0] = f0;
+            m = f0;
+        }
+        // singletons: column 1 + c*H + h for the c-th non-zero value (dsc_et.py:566-568)
+        int c = 0;
+        for (int k = 0; k < P.K; ++k) {
+            if (k == P.K0) continue;
+            const double v = P.values[k];
+            for (int h = lane; h < H; h += 64) {
+                const double e = v * v * s_w2[h] - 2.0 * v * arow[h] + yn;
+                const double f = P.ecoef * e + P.pscale * prior[1 + c * H + h];
+                out[1 + c * H + h] = f;
+                m = fmax(m, f);
+            }
+            ++c;
+        }
+        for (int s = lane; s < S; s += 64) {
+            const double e = state_energy(s_tab + s * Hp, Hp, P, s_a, s_G, yn);
+            const double f = P.ecoef * e + P.pscale * prior[1 + nss + s];
+            out[1 + nss + s] = f;
+            m = fmax(m, f);
+        }
+        m = pm_wave_max(m);
+        // second pass over this lane's own stores
+        double sum = 0.0;
+        if (lane == 0) sum += exp(out[0] - m);
+        c = 0;
+        for (int k = 0; k < P.K; ++k) {
+            if (k == P.K0) continue;
+            for (int h = lane; h < H; h += 64) sum += exp(out[1 + c * H + h] - m);
+            ++c;
+        }
+        for (int s = lane; s < S; s += 64) sum += exp(out[1 + nss + s] - m);
+        sum = pm_wave_sum(sum);
+        if (lane == 0) lse[n] = m + log(sum);
+        wave_sync_lds_dsc();
+    }
+}
+
+__global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
+    const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
+    const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior,
+    pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ expect, int64_t lde,
+    double *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [ qdiag (H) | cnt (8) | scal (4) | per wave: row (H) m (Hp) B (Hp*Hp) | state table ]
+    double *s_qdiag = reinterpret_cast<double *>(smem);
+    double *s_cnt = s_qdiag + H;
+    double *s_scal = s_cnt + PM_DSC_MAX_K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_wave = H + Hp + Hp * Hp;
+    double *s_row = s_scal + 4 + wave * per_wave;
+    double *s_m = s_row + H;
+    double *s_B = s_m + Hp;
+    uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_scal + 4 + WAVES * per_wave);
+    for (int h = tid; h < H + PM_DSC_MAX_K + 4; h += blockDim.x) s_qdiag[h] = 0.0;
+    for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
+    __syncthreads();
+
+    const int nss = (P.K - 1) * H;
+    const double inv_ecoef = 1.0 / P.ecoef;
+    const double qcut = -60.0;     // multi-cause weights below e^-60 of the evidence add nothing in f64
+    double sig = 0.0, fs = 0.0, kept = 0.0;
+    double cnt[PM_DSC_MAX_K];
+#pragma unroll
+    for (int k = 0; k < PM_DSC_MAX_K; ++k) cnt[k] = 0.0;
+
+    for (int64_t n = (int64_t)blockIdx.x * WAVES + wave; n < N; n += (int64_t)gridDim.x * WAVES) {
+        double *erow = expect + n * lde;
+        const double l = lse[n];
+        if (!(l > lse_cut)) {   // truncated: strictly-greater rule of dsc_et.py:832
+            for (int h = lane; h < H; h += 64) erow[h] = 0.0;
+            continue;
+        }
+        const double *f = logpj + n * ldl;
+        const int32_t *cn = cand + n * Hp;
+        if (lane < Hp) s_m[lane] = 0.0;
+        for (int p = lane; p < Hp * Hp; p += 64) s_B[p] = 0.0;
+        if (lane == 0) {
+            const double f0 = f[0];
+            sig += exp(f0 - l) * ((f0 - P.pscale * prior[0]) * inv_ecoef);
+            fs += l;
+            kept += 1.0;
+        }
+        for (int h = lane; h < H; h += 64) {
+            double row = 0.0, qd = 0.0;
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < PM_DSC_MAX_K; ++k) {
+                if (k >= P.K || k == P.K0) continue;
+                const double fh = f[1 + c * H + h];
+                const double q = exp(fh - l);
+                const double v = P.values[k];
+                row += q * v;
+                qd += q * v * v;
+                cnt[k] += q;
+                sig += q * ((fh - P.pscale * prior[1 + c * H + h]) * inv_ecoef);
+                ++c;
+            }
+            s_row[h] = row;
+            if (qd != 0.0) atomicAdd(&s_qdiag[h], qd);
+        }
+        wave_sync_lds_dsc();
+        for (int s = lane; s < S; s += 64) {
+            const double fsv = f[1 + nss + s];
+            const double dl = fsv - l;
+            if (!(dl > qcut)) continue;
+            const double q = exp(dl);
+            sig += q * ((fsv - P.pscale * prior[1 + nss + s]) * inv_ecoef);
+            const uint8_t *row = s_tab + s * Hp;
+            for (int j = 0; j < Hp; ++j) {
+                const int kj = row[j];
+                if (kj == P.K0) continue;
+                const double vj = P.values[kj];
+#pragma unroll
+                for (int k = 0; k < PM_DSC_MAX_K; ++k)
+                    if (k == kj) cnt[k] += q;
+                atomicAdd(&s_m[j], q * vj);
+                for (int k2 = j; k2 < Hp; ++k2) {
+                    const int kk = row[k2];
+                    if (kk != P.K0) atomicAdd(&s_B[j * Hp + k2], q * vj * P.values[kk]);
+                }
+            }
+        }
+        wave_sync_lds_dsc();
+        if (lane < Hp) s_row[cn[lane]] += s_m[lane];     // candidates of one datapoint are distinct
+        wave_sync_lds_dsc();
+        for (int h = lane; h < H; h += 64) erow[h] = s_row[h];
+        double *Wq = stats + (int64_t)H * D;
+        for (int p = lane; p < Hp * Hp; p += 64) {
+            const int j = p / Hp, k2 = p - j * Hp;
+            if (k2 < j) continue;
+            const double v = s_B[p];
+            if (v == 0.0) continue;
+            const int cj = cn[j], ck = cn[k2];
+            const int r = cj < ck ? cj : ck, cc = cj < ck ? ck : cj;
+            pm_atomic_add(Wq + (int64_t)r * H + cc, v);      // upper triangle (pm_spd_inverse_f64 layout)
+        }
+        wave_sync_lds_dsc();
+    }
+
+    sig = pm_wave_sum(sig);
+    fs = pm_wave_sum(fs);
+    kept = pm_wave_sum(kept);
+#pragma unroll
+    for (int k = 0; k < PM_DSC_MAX_K; ++k) cnt[k] = pm_wave_sum(cnt[k]);
+    if (lane == 0) {
+        atomicAdd(&s_scal[0], sig);
+        atomicAdd(&s_scal[1], fs);
+        atomicAdd(&s_scal[2], kept);
+#pragma unroll
+        for (int k = 0; k < PM_DSC_MAX_K; ++k)
+            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], cnt[k]);
+    }
+    __syncthreads();
+    double *g_qdiag = stats + (int64_t)H * D + (int64_t)H * H;
+    for (int h = tid; h < H + PM_DSC_MAX_K + 4; h += blockDim.x) {
+        const double v = s_qdiag[h];
+        if (v != 0.0) pm_atomic_add(g_qdiag + h, v);
+    }
+}
+
+inline size_t align8(size_t x) { return (x + 7) & ~size_t(7); }
+
+inline int allow_lds_dsc(const void *kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    return (int)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+inline bool bad_params(const pm_dsc_params *P) {
+    return !P || P->K < 2 || P->K > PM_DSC_MAX_K || P->K0 < 0 || P->K0 >= P->K || P->values[P->K0] != 0.0;
+}
+
+inline unsigned row_grid(int64_t N) {
+    const int64_t blocks = (N + WAVES - 1) / WAVES;
+    return (unsigned)(blocks < 1 ? 1 : blocks > 256 * 8 ? 256 * 8 : blocks);
+}
+
+}  // namespace
+
+extern "C" int64_t pm_dsc_stats_len(int64_t H, int64_t D) { return H * D + H * H + H + PM_DSC_MAX_K + 4; }
+
+extern "C" int pm_dsc_select_scores_f64(const double *scores, int64_t lds, const double *gram,
+                                        const pm_dsc_params *params_host, int64_t N, int64_t H, double *R,
+                                        int64_t ldr, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!scores || !gram || !R || N < 0 || H <= 0 || lds < H || ldr < H || bad_params(params_host)) return PM_EINVAL;
+    if (H > INT32_MAX) return PM_ERANGE;
+    const int64_t total = N * H;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(dsc_select_scores_kernel, dim3((unsigned)(blocks > 256 * 16 ? 256 * 16 : blocks)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), scores, lds, gram, *params_host, N, (int)H, R, ldr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
+                                const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
+                                const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t Hprime, double *logpj,
+                                int64_t ldl, double *lse, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!scores || !gram || !ynorm2 || !cand || !prior || !logpj || !lse || N < 0 || H <= 0 || Hprime <= 0 || S < 0 ||
+        lds < H || bad_params(params_host) || (S > 0 && !state_idx))
+        return PM_EINVAL;
+    if (ldl < 1 + (params_host->K - 1) * H + S) return PM_EINVAL;
+    if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
+    const size_t shmem = sizeof(double) * (H + WAVES * (Hprime + Hprime * Hprime)) + align8((size_t)S * Hprime);
+    if (shmem > 150 * 1024) return PM_ERANGE;
+    if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_estep_kernel), shmem)) return e;
+    hipLaunchKernelGGL(dsc_estep_kernel, dim3(row_grid(N)), dim3(64 * WAVES), shmem, static_cast<hipStream_t>(stream),
+                       scores, lds, gram, ynorm2, cand, state_idx, (int)S, prior, *params_host, N, (int)H, (int)Hprime,
+                       logpj, ldl, lse);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                                     const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
+                                     const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
+                                     double *expect, int64_t lde, double *stats, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!logpj || !lse || !cand || !prior || !expect || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 ||
+        lde < H || bad_params(params_host) || (S > 0 && !state_idx))
+        return PM_EINVAL;
+    if (ldl < 1 + (params_host->K - 1) * H + S || params_host->ecoef == 0.0) return PM_EINVAL;
+    if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
+    const size_t shmem = sizeof(double) * (H + PM_DSC_MAX_K + 4 + WAVES * (H + Hprime + Hprime * Hprime)) +
+                         align8((size_t)S * Hprime);
+    if (shmem > 150 * 1024) return PM_ERANGE;
+    if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows_kernel), shmem)) return e;
+    hipLaunchKernelGGL(dsc_mstep_rows_kernel, dim3(row_grid(N)), dim3(64 * WAVES), shmem,
+                       static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior,
+                       *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats);
+    return (int)hipGetLastError();
+}

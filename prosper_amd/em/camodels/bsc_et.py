@@ -398,6 +398,8 @@ class BSC_ET(DeviceCAModel):
             tracing.tracepoint("M_step:truncating")
             N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
             lse_cut = self._kth_largest_global(lse, N_use)
+            if lse_cut < -745.1332191019412:     # log(2^-1075): the reference's un-stabilised evidence sums are exactly
+                lse_cut = float("-inf")          # 0 there, and `all_denoms >= 0` keeps every datapoint (bsc_et.py:253)
 
         # per-datapoint statistics + Wp GEMM into the packed buffer
         tracing.tracepoint("M_step:iterating")
@@ -456,33 +458,11 @@ class BSC_ET(DeviceCAModel):
             rhs = Wp
             if np.any(mu):   # Wp was accumulated against y, the reference uses y - mu
                 rhs = Wp - torch.outer(mus, torch.from_numpy(mu).to(packed.device))
-            if packed.is_cuda and H <= 256:
-                # one-workgroup SPD inverse + GEMMs (csrc/spd_inverse.hip) instead of ~40 rocSOLVER launches
-                Wq = torch.empty((H, H), dtype=torch.float64, device=packed.device)
-                Winv = torch.empty((H, H), dtype=torch.float64, device=packed.device)
-                piv = torch.empty(2, dtype=torch.float64, device=packed.device)
-                st = self._stream()
-                self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
-                           H, _ptr(piv), st)
-                rhs = rhs.contiguous()
-                X = torch.zeros((H, D), dtype=torch.float64, device=packed.device)
-                self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(rhs), D, _ptr(X), D, H, D, H, st)
-                # one step of iterative refinement: X += Winv (rhs - Wq X)
-                T = torch.zeros((H, D), dtype=torch.float64, device=packed.device)
-                self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Wq), H, _ptr(X), D, _ptr(T), D, H, D, H, st)
-                R = rhs - T
-                self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(R), D, _ptr(X), D, H, D, H, st)
-                ok_flag = (piv[0] <= 0).to(torch.float64).reshape(1)          # 0 = fine, like cholesky's info
-                parts += [ok_flag, (piv[0] / piv[1]).reshape(1), X.reshape(-1)]
-                if res is not None:      # next step's W^T and Gram matrix are already here: no upload then
-                    seed = (X, self._gemm_nt(X, X, self._buf("gram", (H, H)), "gram_gemm"))
-            else:
-                Wq = torch.triu(Wq_u, 1)
-                Wq = Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)
-                Lc, info = torch.linalg.cholesky_ex(Wq)
-                d = torch.diagonal(Lc)
-                X = torch.cholesky_solve(rhs, Lc)                 # (H, D); garbage if the factorisation failed
-                parts += [info.to(torch.float64).reshape(1), ((d.min() / d.max()) ** 2).reshape(1), X.reshape(-1)]
+            rhs = rhs.contiguous()
+            X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, rhs)
+            parts += [status, X.reshape(-1)]
+            if packed.is_cuda and res is not None:   # next step's W^T and Gram matrix are already here: no upload then
+                seed = (X, self._gemm_nt(X, X, self._buf("gram", (H, H)), "gram_gemm"))
         if learn_mu:
             parts += [mus, packed[n_stats:]]
         flat = torch.cat(parts)

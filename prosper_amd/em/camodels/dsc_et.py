@@ -1,0 +1,441 @@
+"""Discrete Sparse Coding on the MI355X: drop-in for prosper/em/camodels/dsc_et.py.
+
+Same constructor (``states`` array incl. 0), ``select_Hprimes / E_step / M_step`` signatures, return
+keys (``W, pi, sigma, Q``), state tables (``state_matrix`` in itertools.product order,
+``single_state_matrix``, ``state_abs``) and ``dlog`` side effects (``prior_mass``, ``L``, ``N_use``) as the
+reference's ``DSC_ET`` (dsc_et.py:96-925).  Kernels (prosper_amd/csrc/dsc_kernels.hip):
+
+  select_Hprimes  scores GEMM a = Y.W^T (f64 MFMA) -> per-latent best singleton log-joint ->
+                  16-lane selection kernel, best first
+  E_step          all energies from a and the Gram matrix (no D-length work per state)
+  M_step          E[s] rows + Wp = E[s]^T.Y (f64 MFMA), E[s s^T] scatter, value counts; ONE all-reduce of
+                  the packed statistics; the H x H solve on the device (pm_spd_inverse_f64)
+"""
+import ctypes
+import itertools as itls
+
+import numpy as np
+from scipy.special import gammaln
+
+from ._device import DeviceCAModel, DeviceArray, _ptr, small_blas
+from ... import _lib
+from ...utils import parallel
+from ...utils import tracing
+from ...utils.datalog import dlog
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+_LOG_UNDERFLOW = -745.1332191019412      # log(2^-1075): exp() of anything below rounds to 0.0
+
+
+def multinom2(n, k):
+    """Multinomial coefficient n! / prod k_i! (dsc_et.py:23-39)."""
+    return np.exp(gammaln(n + 1) - gammaln(k + 1).sum())
+
+
+def get_states(states, Hprime, gamma):
+    """All Hprime-vectors over ``states`` with 2..gamma non-zeros, itertools.product order (dsc_et.py:56-63)."""
+    assert len(states.shape) == 1
+    sl = [np.array(c) for c in itls.product(states, repeat=Hprime)
+          if (np.sum(np.array(c) != 0) <= gamma and np.sum(np.array(c) != 0) > 1)]
+    return np.array(sl) if sl else np.zeros((0, Hprime))
+
+
+def generate_state_matrix(Hprime, gamma, states=np.array([0, 1])):
+    """(no_states, state_matrix, state_abs) as dsc_et.py:66-93."""
+    state_matrix = get_states(np.asarray(states), Hprime, gamma)
+    return state_matrix.shape[0], state_matrix, (state_matrix != 0).sum(axis=1)
+
+
+class DSC_ET(DeviceCAModel):
+    """Discrete Sparse Coding (K-ary latents, linear superposition) with Expectation Truncation."""
+
+    def __init__(self, D, H, Hprime, gamma, states=np.array([-1., 0., 1.]), to_learn=['W', 'pi', 'sigma'],
+                 comm=parallel.COMM_WORLD, device=None):
+        DeviceCAModel.__init__(self, D, H, Hprime, gamma, to_learn, comm, device)
+        if not type(states) == np.ndarray:
+            raise TypeError("DSC: states must be of type numpy.ndarray")
+        if Hprime > H:
+            raise Exception("Hprime must be less or equal to H")
+        if gamma > Hprime:
+            raise Exception("gamma must be less or equal to Hprime")
+        self.states = states
+        self.K = self.states.shape[0]
+        self._K_0 = int(np.argwhere(states == 0.)[0, 0])
+        if self.K > 8:
+            raise _lib.HipError("DSC_ET: at most 8 latent values (PM_DSC_MAX_K)")
+        tol = 1e-5
+        self._noise_policy = {
+            'W': (-np.inf, +np.inf, False),
+            'pi': (tol, 1. - tol, False),
+            'sigma': (0., +np.inf, False),
+        }
+        # state tables (dsc_et.py:167-191)
+        ss = np.empty((0, self.H), dtype=np.int8)
+        for i in range(self.K):
+            if i == self._K_0:
+                continue
+            ss = np.concatenate((ss, np.eye(self.H, dtype=np.int8) * states[i]))
+        self.single_state_matrix = ss[np.sum(np.abs(np.sign(ss)), 1) == 1]
+        self.state_matrix = get_states(self.states, self.Hprime, self.gamma)
+        self.no_states = self.state_matrix.shape[0]
+        self.state_abs = np.empty((self.K, self.no_states))
+        for i in range(self.K):
+            self.state_abs[i, :] = (self.state_matrix == self.states[i]).sum(axis=1)
+        self.state_abs[self._K_0, :] = self.H - self.state_abs.sum(0) + self.state_abs[self._K_0, :]
+        self._tab = None
+
+    # ------------------------------------------------------------------ reference-shaped helpers
+    def check_params(self, model_params):
+        """Finite parameters, sigma >= 0 (dsc_et.py:194-236)."""
+        assert np.isfinite(model_params['W']).all()
+        assert np.isfinite(model_params['pi']).all()
+        assert np.isfinite(model_params['sigma']).all()
+        assert model_params['sigma'] >= 0.
+        return model_params
+
+    def generate_data(self, model_params, my_N, noise_on=True, gs=None, gp=None):
+        """Latents drawn per datapoint with ``np.random.choice(states, H, p=pi)``, y = s.W^T (+ noise);
+        RNG stream as upstream (dsc_et.py:238-299)."""
+        D, H, states = self.D, self.H, self.states
+        pi = model_params['pi']
+        W = model_params['W'].T
+        y = np.zeros((my_N, D))
+        s = np.zeros((my_N, H), dtype=np.int8)
+        for n in range(my_N):
+            if gs is None:
+                s[n] = np.random.choice(states, size=H, replace=True, p=pi)
+            else:
+                assert gs.shape[0] == my_N
+                if gp is None:
+                    assert len(gs.shape) == 2
+                    s[n] = gs[n]
+                else:
+                    assert gp.shape[0] == my_N
+                    assert gp.shape[1] == gs.shape[1]
+                    s[n] = (gs[n] * gp[n]).sum(0)
+        y = s.astype(np.float64) @ W
+        if noise_on:
+            y += np.random.normal(scale=model_params['sigma'], size=(my_N, D))
+        return {'y': y, 's': s}
+
+    def noisify_params(self, model_params, anneal):
+        """Parameter noise under ``_noise_policy``; pi gets uniform noise and is renormalised
+        (dsc_et.py:412-490)."""
+        comm = self.comm
+        for param, policy in self._noise_policy.items():
+            pvalue = model_params[param]
+            if (not param + '_noise' == 'pi_noise') and anneal[param + "_noise"] != 0.0:
+                if np.isscalar(pvalue):
+                    new_pvalue = 0
+                    if comm.rank == 0:
+                        new_pvalue = pvalue + np.random.normal(scale=anneal[param + "_noise"])
+                        if new_pvalue < policy[0]:
+                            new_pvalue = policy[0]
+                        if new_pvalue >= policy[1]:
+                            new_pvalue = policy[1]
+                        if policy[2]:
+                            new_pvalue = np.abs(new_pvalue)
+                    pvalue = comm.bcast(new_pvalue)
+                else:
+                    if comm.rank == 0:
+                        new_pvalue = pvalue + np.random.normal(scale=anneal[param + "_noise"], size=pvalue.shape)
+                        low_bound, up_bound, absify = policy
+                        new_pvalue = np.minimum(up_bound, np.maximum(low_bound, new_pvalue))
+                        if absify:
+                            new_pvalue = np.abs(new_pvalue)
+                        pvalue = new_pvalue
+                    comm.Bcast(pvalue)
+            elif param + '_noise' == 'pi_noise' and anneal["pi_noise"] != 0.0:
+                if comm.rank == 0:
+                    new_pvalue = pvalue + np.random.rand(*pvalue.shape) * anneal["pi_noise"]
+                    pvalue = new_pvalue / new_pvalue.sum()
+                comm.Bcast(pvalue)
+            model_params[param] = pvalue
+        return model_params
+
+    def get_scaling_factors(self, pi):
+        """Prior mass of the states with at most gamma non-zero latents (dsc_et.py:798-823)."""
+        A_pi_gamma = 0.0
+        for gp in itls.product(np.arange(self.gamma + 1), repeat=len(self.states) - 1):
+            ngp = np.array(gp)
+            if ngp.sum() > self.gamma:
+                continue
+            abs_array = np.insert(ngp, self._K_0, self.H - ngp.sum())
+            if not abs_array.sum() == self.H:
+                raise Exception("wrong number of elements counted")
+            A_pi_gamma += multinom2(abs_array.sum(), abs_array) * np.prod(pi ** abs_array)
+        return A_pi_gamma
+
+    def standard_init(self, data):
+        """W = data mean + N(0, (sigma_init/4)^2), pi = (1 - 1/H) on the zero value and a random split of
+        1/H over the others (dsc_et.py:872-925; RNG order: normal((D,H)) then rand(K-1))."""
+        comm = self.comm
+        my_y = np.asarray(data['y'])
+        my_N, D = my_y.shape
+        assert D == self.D
+        W_mean = parallel.allmean(my_y, axis=0, comm=comm)
+        sigma_sq = parallel.allmean((my_y - W_mean) ** 2, axis=0, comm=comm)
+        sigma_init = np.sqrt(sigma_sq).sum() / D
+        W_init = W_mean[:, None] + np.random.normal(scale=sigma_init / 4., size=[D, self.H])
+        sparsity = 1. - (1. / self.H)
+        pi_init = np.random.rand(self.K - 1)
+        pi_init = (1 - sparsity) * pi_init / pi_init.sum()
+        pi_init = np.insert(pi_init, self._K_0, sparsity)
+        return {'W': W_init, 'pi': pi_init, 'sigma': sigma_init}
+
+    def free_energy(self, model_params, my_data):
+        return 0.0
+
+    def gain(self, old_parameters, new_parameters):
+        return 0.0
+
+    # ------------------------------------------------------------------ plumbing
+    def _tables(self):
+        """Device state table: (S, Hprime) uint8 indices into ``states``."""
+        key = (self.Hprime, self.gamma, self.no_states)
+        if self._tab is None or self._tab[0] != key:
+            lib = _lib.load()
+            if not lib.pm_bsc_rows16_supported(self.H, self.Hprime, 0):
+                raise _lib.HipError("DSC_ET: H = %d is outside the selection kernel's range (H <= 512)" % self.H)
+            idx = np.zeros((max(self.no_states, 1), self.Hprime), dtype=np.uint8)
+            for k in range(self.K):
+                idx[:self.no_states][self.state_matrix == self.states[k]] = k
+            self._tab = (key, torch.from_numpy(idx).to(self.device))
+        return self._tab[1]
+
+    def _prior(self, pi):
+        """pre_F (dsc_et.py:539-558)."""
+        H, K, K0 = self.H, self.K, self._K_0
+        pre_F = np.empty(1 + (K - 1) * H + self.no_states)
+        l_pis = np.zeros(self.no_states)
+        for i in range(K):
+            l_pis += self.state_abs[i] * np.log(pi[i])
+        pre_F[0] = H * np.log(pi[K0])
+        c = 0
+        for state in range(K):
+            if state == K0:
+                continue
+            pre_F[c * H + 1:(c + 1) * H + 1] = np.log(pi[state]) + ((H - 1) * np.log(pi[K0]))
+            c += 1
+        pre_F[(K - 1) * H + 1:] = l_pis
+        return pre_F
+
+    def _params(self, anneal, pi, sigma):
+        beta = 1. / anneal['T']
+        pre1 = -1. / 2. / sigma / sigma
+        P = _lib.DscParams(K=self.K, K0=self._K_0, pre1=float(pre1), ecoef=float(beta * pre1),
+                           pscale=float(beta if anneal['anneal_prior'] else 1.0))
+        with np.errstate(divide='ignore'):
+            lp = np.log(np.asarray(pi, dtype=np.float64))
+        for k in range(self.K):
+            P.values[k] = float(self.states[k])
+            P.logpi[k] = float(lp[k])
+        return P
+
+    def _params_dev(self, W, res):
+        """Device copy of W^T (H,D), the Gram matrix and the scores for the current W and data."""
+        W = np.asarray(W, dtype=np.float64)
+        par = self._par
+        if par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape \
+                and np.array_equal(par["W"], W):
+            return par
+        Wt = self._upload("W", W).t().contiguous()
+        G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
+        Y = res["Y"]
+        A = self._buf("scores", (Y.shape[0], self.H))
+        if Y.shape[0]:
+            self._gemm_nt(Y, Wt, A, "scores_gemm")
+        self._par = {"ykey": res["key"], "W": W.copy(), "Wt": Wt, "G": G, "A": A}
+        return self._par
+
+    # ------------------------------------------------------------------ hot path
+    @tracing.traced
+    def select_Hprimes(self, model_params, data):
+        """``data['candidates']`` (N, Hprime): latents ranked by their best singleton log-joint, best
+        first (dsc_et.py:347-410)."""
+        res = self._resident(data['y'])
+        N = res["Y"].shape[0]
+        H, Hp = self.H, self.Hprime
+        self._tables()
+        par = self._params_dev(model_params['W'], res)
+        P = self._params(FixedT(), model_params['pi'], model_params['sigma'])
+        cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
+        if N:
+            R = self._buf("dsc_sel", (N, H))
+            self._call("select_scores", "pm_dsc_select_scores_f64", _ptr(par["A"]), H, _ptr(par["G"]),
+                       ctypes.byref(P), N, H, _ptr(R), H, self._stream())
+            self._call("select", "pm_bsc_select_estep_f64", _ptr(R), H, _ptr(par["G"]), _ptr(res["ynorm2"]), None,
+                       None, None, None, None, 0, self.gamma, None, N, H, Hp, 1 | 4 | 8, _ptr(cand), None, 0, None,
+                       self._stream())
+        data['candidates'] = DeviceArray(cand, np.int64)
+        return data
+
+    @tracing.traced
+    def E_step(self, anneal, model_params, my_data):
+        """Log-pseudo-joints ``{'logpj': (N, 1 + (K-1)H + S)}`` (dsc_et.py:492-585)."""
+        res = self._resident(my_data['y'])
+        N = res["Y"].shape[0]
+        H, Hp, S = self.H, self.Hprime, self.no_states
+        tab = self._tables()
+        par = self._params_dev(model_params['W'], res)
+        cand = self._device_candidates(my_data['candidates'], N)
+        P = self._params(anneal, model_params['pi'], model_params['sigma'])
+        prior = self._upload("dsc_prior", self._prior(np.asarray(model_params['pi'], dtype=np.float64)))
+        Kt = 1 + (self.K - 1) * H + S
+        logpj = torch.empty((N, Kt), dtype=torch.float64, device=self.device)
+        lse = torch.empty((N,), dtype=torch.float64, device=self.device)
+        tracing.tracepoint("E_step:iterating")
+        if N:
+            self._call("estep", "pm_dsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]), _ptr(cand),
+                       _ptr(tab), S, _ptr(prior), ctypes.byref(P), N, H, Hp, _ptr(logpj), Kt, _ptr(lse),
+                       self._stream())
+        out = DeviceArray(logpj)
+        out.lse = lse
+        return {'logpj': out}
+
+    @tracing.traced
+    def M_step(self, anneal, model_params, my_suff_stat, my_data):
+        """New W, pi, sigma (dsc_et.py:587-774).  Logs ``prior_mass``, ``L`` and ``N_use``."""
+        comm = self.comm
+        H, Hp, D, S, K = self.H, self.Hprime, self.D, self.no_states, self.K
+        pi = np.asarray(model_params['pi'], dtype=np.float64)
+        sigma = model_params['sigma']
+        res = self._resident(my_data['y'])
+        Y = res["Y"]
+        my_N = Y.shape[0]
+        tab = self._tables()
+        cand = self._device_candidates(my_data['candidates'], my_N)
+        Kt = 1 + (K - 1) * H + S
+
+        logpj = my_suff_stat['logpj']
+        if isinstance(logpj, DeviceArray) and getattr(logpj, "lse", None) is not None:
+            lp, lse = logpj.tensor, logpj.lse
+        else:
+            lp = torch.from_numpy(np.ascontiguousarray(np.asarray(logpj), dtype=np.float64)).to(self.device)
+            lse = torch.logsumexp(lp, dim=1)
+        lp, lse = lp.contiguous(), lse.contiguous()
+        assert tuple(lp.shape) == (my_N, Kt)
+        N = comm.allreduce(my_N)
+
+        A_pi_gamma = self.get_scaling_factors(pi)
+        dlog.append("prior_mass", A_pi_gamma)
+
+        # data truncation (dsc_et.py:825-843): keep the datapoints STRICTLY above the N_use-th largest evidence
+        lse_cut = float("-inf")
+        if anneal['Ncut_factor'] > 0.0:
+            tracing.tracepoint("M_step:truncating")
+            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
+            # the reference cuts on un-stabilised sums of exp(logpj), which are exactly 0 below the
+            # underflow boundary: with the cut among those only strictly positive sums survive
+            lse_cut = max(self._kth_largest_global(lse, N_use), _LOG_UNDERFLOW)
+
+        tracing.tracepoint("M_step:iterating")
+        lib = _lib.load()
+        n_stats = lib.pm_dsc_stats_len(H, D)
+        stats = self._buf("dsc_stats", (n_stats,))
+        stats.zero_()
+        expect = self._buf("expect", (my_N, H))
+        P = self._params(anneal, pi, sigma)
+        prior = self._upload("dsc_prior", self._prior(pi))
+        if my_N:
+            self._call("mstep_rows", "pm_dsc_mstep_rows_f64", _ptr(lp), Kt, _ptr(lse), ctypes.c_double(lse_cut),
+                       _ptr(cand), _ptr(tab), S, _ptr(prior), ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,
+                       _ptr(stats), self._stream())
+            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N,
+                       self._stream())
+        comm.allreduce_device(stats)      # replaces dsc_et.py:648,738,739,747,769 and the allreduce in get_likelihood
+        return self._finalize(stats, model_params)
+
+    def _finalize(self, stats, model_params):
+        """Parameter updates from the all-reduced statistics (dsc_et.py:736-774), one device->host copy."""
+        H, D, K, K0 = self.H, self.D, self.K, self._K_0
+        pi = np.asarray(model_params['pi'], dtype=np.float64)
+        sigma = model_params['sigma']
+        o_wq, o_qd = H * D, H * D + H * H
+        o_cnt = o_qd + H
+        Wp = stats[:o_wq].view(H, D)
+        Wq_u = stats[o_wq:o_qd].view(H, H)
+        qdiag = stats[o_qd:o_cnt]
+        parts = [stats[o_cnt:o_cnt + 8 + 4]]
+        learn_W = 'W' in self.to_learn
+        Wq = None
+        if learn_W:
+            tracing.tracepoint("M_step:update W")
+            X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, Wp.contiguous())
+            parts += [status, X.reshape(-1)]
+        flat = torch.cat(parts)
+        host = self._download(flat) if flat.is_cuda else flat.numpy()
+        cnt = host[:8]
+        my_sigma, Fs, N_use = float(host[8]) / D, float(host[9]), int(round(host[10]))
+
+        L = -0.5 * D * np.log(2 * np.pi * sigma ** 2) + Fs / N_use          # dsc_et.py:845-870
+        dlog.append('L', L)
+
+        W = np.asarray(model_params['W'])
+        if learn_W:
+            ok = host[12] == 0 and host[13] > 1e-11 and np.isfinite(host[13])
+            if ok:
+                W_new = host[14:14 + H * D].reshape(H, D).copy()
+            else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host
+                with small_blas():
+                    W_new = np.linalg.lstsq(Wq.cpu().numpy(), Wp.cpu().numpy(), rcond=None)[0]
+            W_out = W_new.transpose()
+        else:
+            W_out = W
+
+        if 'pi' in self.to_learn:
+            tracing.tracepoint("M_step:update pi")
+            my_pi = np.zeros(K)
+            for k in range(K):
+                if k != K0:
+                    my_pi[k] = cnt[k]
+            my_pi[K0] = H * N_use - my_pi.sum()       # every kept datapoint distributes H latents over the values
+            pi_new = my_pi / my_pi.sum()
+            eps = 1e-6
+            if np.any(pi_new < eps):
+                which_lo = pi_new < eps
+                which_hi = pi_new >= eps
+                pi_new[which_lo] += eps - pi_new[which_lo]
+                pi_new[which_hi] -= (eps * np.sum(which_lo)) / np.sum(which_hi)
+            if 'penalty' in list(self.__dict__.keys()):
+                if self.penalty > pi_new[K0]:
+                    r = (1 - self.penalty) / (1 - pi_new[K0])
+                    pi_new[pi_new != 0] = pi_new[pi_new != 0] * r
+                    pi_new[K0] = self.penalty
+                    pi_new /= pi_new.sum()
+        else:
+            pi_new = pi
+
+        if 'sigma' in self.to_learn:
+            tracing.tracepoint("M_step:update sigma")
+            sigma_new = np.sqrt(my_sigma / N_use)
+        else:
+            sigma_new = sigma
+
+        dlog.append('N_use', N_use)
+        return {'W': W_out, 'pi': pi_new, 'sigma': sigma_new, 'Q': 0.}
+
+    def inference(self, *args, **kwargs):
+        """DSC's own top-K inference (dsc_et.py:927-1059) is not built yet; the base-class version assumes
+        binary states and would be wrong here."""
+        raise NotImplementedError("DSC_ET.inference is not available in this build")
+
+    def calculate_respons(self, anneal, model_params, data):
+        """Posterior over the truncated states (dsc_et.py:776-784)."""
+        cand = np.sort(np.asarray(data['candidates']), axis=1)
+        data['candidates'] = cand
+        F = np.asarray(self.E_step(anneal, model_params, data)['logpj'])
+        e = np.exp(F - F.max(axis=1)[:, None])
+        return e / e.sum(axis=1).reshape(-1, 1)
+
+
+class FixedT(dict):
+    """Annealing stand-in for calls that need no temperature (selection)."""
+
+    def __missing__(self, k):
+        return 1.0 if k == 'T' else 0.0

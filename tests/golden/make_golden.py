@@ -37,6 +37,7 @@ from prosper.em.camodels.bsc_et import BSC_ET                # noqa: E402
 from prosper.em.camodels.mca_et import MCA_ET                # noqa: E402
 from prosper.em.camodels.gsc_et import GSC                   # noqa: E402
 from prosper.em.camodels.mmca_et import MMCA_ET              # noqa: E402
+from prosper.em.camodels.dsc_et import DSC_ET                # noqa: E402
 from prosper.utils.barstest import generate_bars_dict        # noqa: E402
 
 
@@ -47,7 +48,7 @@ class Capture(DataHandler):
         Capture.rows.setdefault(tblname, []).append(np.array(value, copy=True))
 
 
-dlog.set_handler(("L", "N", "N_use"), Capture)
+dlog.set_handler(("L", "N", "N_use", "prior_mass"), Capture)
 
 
 def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False):
@@ -181,6 +182,38 @@ def mmca_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut):
     print("mmca_step_%s: N=%d K=%d Q=%.6f N_use=%d" % (name, N, ss["logpj"].shape[1], new["Q"], Capture.rows["N_use"][0]))
 
 
+def dsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior, states, pi_gt):
+    """One select_Hprimes -> E_step -> M_step of DSC_ET (K-ary latents) on seeded data."""
+    import warnings
+    warnings.simplefilter("ignore")
+    rng = np.random.RandomState(seed)
+    states = np.asarray(states, dtype=np.float64)
+    pi_gt = np.asarray(pi_gt, dtype=np.float64)
+    W_gt = rng.normal(size=(D, H)) * 2.0
+    sigma_gt = 1.0
+    s = rng.choice(states, size=(N, H), replace=True, p=pi_gt)
+    y = s @ W_gt.T + rng.normal(scale=sigma_gt, size=(N, D))
+    model = DSC_ET(D, H, Hp, gamma, states=states)
+    pi0 = pi_gt * rng.uniform(0.8, 1.25, size=pi_gt.shape)
+    params = {"W": W_gt + 0.3 * rng.normal(size=(D, H)), "pi": pi0 / pi0.sum(), "sigma": sigma_gt * 1.2}
+    inp = {k: np.array(v, copy=True) for k, v in params.items()}
+    anneal = FixedAnneal(T=T, Ncut_factor=Ncut, anneal_prior=anneal_prior)
+    Capture.rows.clear()
+    data = model.select_Hprimes(params, {"y": y.copy()})
+    ss = model.E_step(anneal, params, data)
+    new = model.M_step(anneal, params, ss, data)
+    assert np.isfinite(new["W"]).all(), name
+    np.savez_compressed(os.path.join(HERE, "dsc_step_%s.npz" % name), D=D, H=H, Hprime=Hp, gamma=gamma, T=T,
+                        Ncut_factor=Ncut, anneal_prior=anneal_prior, states=states, y=y, W=inp["W"], pi=inp["pi"],
+                        sigma=inp["sigma"], candidates=data["candidates"].astype(np.int64), logpj=ss["logpj"],
+                        W_new=new["W"], pi_new=new["pi"], sigma_new=new["sigma"], Q=new["Q"],
+                        L=Capture.rows["L"][0], N_use=Capture.rows["N_use"][0], prior_mass=Capture.rows["prior_mass"][0],
+                        state_matrix=model.state_matrix, single_state_matrix=model.single_state_matrix,
+                        state_abs=model.state_abs)
+    print("dsc_step_%s: N=%d K=%d L=%.6f N_use=%d" % (name, N, ss["logpj"].shape[1], Capture.rows["L"][0],
+                                                      Capture.rows["N_use"][0]))
+
+
 class FixedAnneal(dict):
     """One annealing position; unknown keys -> 0.0 like LinearAnnealing.__getitem__."""
     crit_params = []
@@ -293,7 +326,7 @@ def main(only=None):
     """``only``: regenerate just the fixtures whose name starts with this prefix (e.g. ``mmca``)."""
     want = lambda fn: only is None or fn.__name__.startswith(only)
     g = globals()
-    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "bsc_inference_case",
+    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "bsc_inference_case",
                "bsc_trajectory", "bsc_init", "anneal_tracks"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
@@ -326,6 +359,16 @@ def main(only=None):
     mmca_step_case("small_cut", 16, 8, 4, 3, 257, seed=52, T=1.5, Ncut=0.5)
     mmca_step_case("h40", 48, 40, 6, 3, 150, seed=53, T=2.5, Ncut=0.7)
     mmca_step_case("h128", 64, 128, 8, 3, 96, seed=54, T=1.0, Ncut=0.0)
+    dsc_step_case("ternary", 16, 8, 4, 3, 300, seed=61, T=1.0, Ncut=0.0, anneal_prior=False,
+                  states=[-1., 0., 1.], pi_gt=[0.1, 0.8, 0.1])
+    dsc_step_case("ternary_cut", 20, 10, 5, 3, 257, seed=62, T=1.5, Ncut=0.6, anneal_prior=True,
+                  states=[-1., 0., 1.], pi_gt=[0.08, 0.8, 0.12])
+    dsc_step_case("k4", 24, 12, 4, 2, 200, seed=63, T=1.2, Ncut=0.0, anneal_prior=False,
+                  states=[0., 1., 2., 3.], pi_gt=[0.82, 0.1, 0.05, 0.03])
+    dsc_step_case("binary", 25, 10, 5, 3, 200, seed=64, T=1.0, Ncut=1.0, anneal_prior=False,
+                  states=[0., 1.], pi_gt=[0.8, 0.2])
+    dsc_step_case("h64", 48, 64, 6, 3, 120, seed=65, T=1.0, Ncut=0.0, anneal_prior=False,
+                  states=[-2., -1., 0., 1., 2.], pi_gt=[0.02, 0.03, 0.9, 0.03, 0.02])
 
 
 if __name__ == "__main__":

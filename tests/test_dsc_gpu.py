@@ -1,0 +1,146 @@
+"""DSC parity on the GPU: HIP path (through the C ABI) vs golden vectors minted from the reference
+(tests/golden/dsc_step_*.npz) and vs the oracle at sizes it finishes in seconds.  float64 kernels:
+held to 1e-8 on W/pi/sigma/L (BASELINE asks 1e-4)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden, GOLDEN
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class _An(dict):
+    crit_params = []
+
+    def __missing__(self, k):
+        return 0.0
+
+    def as_dict(self):
+        return dict(self)
+
+
+def _cases():
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "dsc_step_*.npz")))
+
+
+def _check_candidates(cand, ref, best):
+    """Best-first ranking of the per-latent best singleton log-joint; rows may differ from the reference's
+    only where those scores tie to rounding (the device ranks the Gram form)."""
+    cand = np.asarray(cand)
+    bad = np.where((cand != ref).any(axis=1))[0]
+    if bad.size:
+        np.testing.assert_allclose(np.take_along_axis(best[bad], cand[bad], 1),
+                                   np.take_along_axis(best[bad], ref[bad], 1), rtol=1e-9)
+    return bad.size
+
+
+@pytest.mark.parametrize("case", _cases())
+def test_dsc_step_matches_reference_golden(case):
+    assert torch.cuda.is_available()
+    from oracle import dsc_oracle as M
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    g = golden(case)
+    D, H, Hp, gamma = int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"])
+    m = DSC_ET(D, H, Hp, gamma, states=g["states"])
+    assert np.array_equal(m.state_matrix, g["state_matrix"])
+    assert np.array_equal(m.single_state_matrix, g["single_state_matrix"])
+    assert np.array_equal(m.state_abs, g["state_abs"])
+    an = _An(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
+    params = {"W": g["W"].copy(), "pi": g["pi"].copy(), "sigma": float(g["sigma"])}
+    h = dlog.set_handler(("N_use", "L", "prior_mass"), StoreInMemory)
+    try:
+        params = m.check_params(params)
+        data = m.select_Hprimes(params, {"y": g["y"]})
+        model = M.make_model(D, H, Hp, gamma, g["states"])
+        best = M.select_scores_vec(model, params["W"], params["pi"], params["sigma"], g["y"])
+        assert _check_candidates(data["candidates"], g["candidates"], best) == 0
+        ss = m.E_step(an, params, data)
+        new = m.M_step(an, params, ss, data)
+    finally:
+        dlog.remove_handler(h)
+    np.testing.assert_allclose(np.asarray(ss["logpj"]), g["logpj"], rtol=1e-10, atol=1e-9)
+    assert int(h.tables["N_use"][0]) == int(g["N_use"])
+    np.testing.assert_allclose(h.tables["L"][0], float(g["L"]), rtol=1e-10)
+    np.testing.assert_allclose(h.tables["prior_mass"][0], float(g["prior_mass"]), rtol=1e-12)
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=0, atol=1e-8 * np.abs(g["W_new"]).max())
+    np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=1e-9)
+    np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=1e-9)
+    assert new["Q"] == 0.0 and new["W"].shape == (D, H)
+    # foreign NumPy inputs take the same kernels
+    new2 = m.M_step(an, params, {"logpj": g["logpj"]}, {"y": g["y"], "candidates": g["candidates"]})
+    np.testing.assert_allclose(new2["W"], g["W_new"], rtol=0, atol=1e-8 * np.abs(g["W_new"]).max())
+    np.testing.assert_allclose(new2["pi"], g["pi_new"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("D,H,Hp,gamma,N,T,ncut,states", [
+    (256, 128, 6, 3, 1500, 1.0, 0.0, [-1., 0., 1.]),
+    (100, 70, 5, 4, 333, 1.6, 0.6, [0., 1., 2.]),
+    (40, 20, 3, 2, 65, 1.0, 1.0, [-2., -1., 0., 1., 2.]),
+    (64, 256, 8, 3, 3000, 1.0, 0.0, [-1., 0., 1.])])
+def test_dsc_step_matches_oracle(D, H, Hp, gamma, N, T, ncut, states):
+    from oracle import dsc_oracle as M
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    rng = np.random.RandomState(D + H + N)
+    states = np.array(states)
+    K = len(states)
+    pi_gt = np.where(states == 0, 1 - 2.0 / H, (2.0 / H) / (K - 1))      # ~2 active latents per datapoint
+    W_gt = rng.normal(size=(D, H)) * 2.0
+    s = rng.choice(states, size=(N, H), p=pi_gt)
+    y = s @ W_gt.T + rng.normal(size=(N, D))
+    pi0 = pi_gt * rng.uniform(0.8, 1.25, size=K)
+    params = {"W": W_gt + 0.2 * rng.normal(size=(D, H)), "pi": pi0 / pi0.sum(), "sigma": 1.1}
+    model = M.make_model(D, H, Hp, gamma, states)
+    an = M.Anneal(T=T, Ncut_factor=ncut, anneal_prior=(T != 1.0))
+    m = DSC_ET(D, H, Hp, gamma, states=states)
+    dan = _An(T=T, Ncut_factor=ncut, anneal_prior=(T != 1.0))
+    data = m.select_Hprimes(params, {"y": y})
+    best = M.select_scores_vec(model, params["W"], params["pi"], params["sigma"], y)
+    ref_cand = M.select_hprimes_vec(model, params["W"], params["pi"], params["sigma"], y)
+    _check_candidates(data["candidates"], ref_cand, best)
+    cand = np.asarray(data["candidates"])
+    logpj = M.e_step_vec(an, model, params["W"], params["pi"], params["sigma"], y, cand)
+    ss = m.E_step(dan, params, data)
+    np.testing.assert_allclose(np.asarray(ss["logpj"]), logpj, rtol=1e-10, atol=1e-9)
+    ref, log = M.m_step(an, model, params["W"], params["pi"], params["sigma"], y, cand, logpj, vec=True)
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    h = dlog.set_handler(("N_use", "L"), StoreInMemory)
+    try:
+        new = m.M_step(dan, params, ss, data)
+    finally:
+        dlog.remove_handler(h)
+    assert int(h.tables["N_use"][0]) == log["N_use"]
+    np.testing.assert_allclose(h.tables["L"][0], log["L"], rtol=1e-10)
+    cond = np.linalg.cond(log["stats"]["Wq"])
+    np.testing.assert_allclose(new["W"], ref["W"], rtol=0, atol=max(1e-8, 1e-13 * cond) * np.abs(ref["W"]).max())
+    np.testing.assert_allclose(new["pi"], ref["pi"], rtol=1e-9)
+    np.testing.assert_allclose(new["sigma"], ref["sigma"], rtol=1e-9)
+
+
+def test_dsc_em_recovers_parameters():
+    """EM through the reference-shaped step loop on ternary data: the free energy rises and sigma approaches
+    the generating value."""
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    D, H, Hp, gamma, N = 48, 12, 5, 3, 6000
+    rng = np.random.RandomState(3)
+    states = np.array([-1., 0., 1.])
+    W_gt = rng.normal(size=(D, H)) * 3.0
+    s = rng.choice(states, size=(N, H), p=[0.1, 0.8, 0.1])
+    y = s @ W_gt.T + rng.normal(size=(N, D))
+    m = DSC_ET(D, H, Hp, gamma, states=states)
+    p = {"W": W_gt + 0.5 * rng.normal(size=(D, H)), "pi": np.array([0.15, 0.7, 0.15]), "sigma": 2.0}
+    h = dlog.set_handler(("L",), StoreInMemory)
+    try:
+        for _ in range(25):
+            p = m.step(_An(T=1.0), p, {"y": y})
+    finally:
+        dlog.remove_handler(h)
+    L = [float(v) for v in h.tables["L"]]
+    assert L[-1] > L[0] and all(b > a - 1e-9 for a, b in zip(L[5:], L[6:]))
+    assert p["sigma"] < 1.9 and np.isfinite(p["W"]).all()
+    np.testing.assert_allclose(p["pi"], [0.1, 0.8, 0.1], atol=0.05)

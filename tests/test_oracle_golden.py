@@ -161,6 +161,46 @@ def test_mmca_step_matches_reference(case, flavour):
     np.testing.assert_allclose(new["Q"], g["Q"], rtol=1e-11)
 
 
+# ----------------------------------------------------------------------------- DSC (dsc_et.py)
+def _dsc_cases():
+    import glob, os
+    from conftest import GOLDEN
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "dsc_step_*.npz")))
+
+
+@pytest.mark.parametrize("case", _dsc_cases())
+@pytest.mark.parametrize("flavour", ["loop", "vec"])
+def test_dsc_step_matches_reference(case, flavour):
+    from oracle import dsc_oracle as M
+    g = golden(case)
+    model = M.make_model(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]), g["states"])
+    assert np.array_equal(model["SM"], g["state_matrix"])
+    assert np.array_equal(model["SSM"], g["single_state_matrix"])
+    assert np.array_equal(model["state_abs"], g["state_abs"])
+    an = M.Anneal(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
+    W, pi, sigma = g["W"], g["pi"], float(g["sigma"])
+    vec = flavour == "vec"
+    cand = (M.select_hprimes_vec if vec else M.select_hprimes_loop)(model, W, pi, sigma, g["y"])
+    if vec:   # Gram form: rounding may swap near-ties only
+        best = M.select_scores_vec(model, W, pi, sigma, g["y"])
+        for n in np.where((cand != g["candidates"]).any(axis=1))[0]:
+            np.testing.assert_allclose(best[n, cand[n]], best[n, g["candidates"][n]], rtol=1e-10)
+        cand = g["candidates"]
+    else:
+        assert np.array_equal(cand, g["candidates"])
+    logpj = (M.e_step_vec if vec else M.e_step_loop)(an, model, W, pi, sigma, g["y"], cand)
+    np.testing.assert_allclose(logpj, g["logpj"], rtol=1e-10, atol=1e-9)
+    new, log = M.m_step(an, model, W, pi, sigma, g["y"], cand, g["logpj"], vec=vec)
+    assert log["N_use"] == int(g["N_use"])
+    np.testing.assert_allclose(log["L"], float(g["L"]), rtol=1e-12)
+    np.testing.assert_allclose(log["prior_mass"], float(g["prior_mass"]), rtol=1e-12)
+    cond = np.linalg.cond(log["stats"]["Wq"])
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=0, atol=max(1e-9, 1e-14 * cond) * np.abs(g["W_new"]).max())
+    np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=1e-10)
+    np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=1e-10)
+    assert new["Q"] == float(g["Q"]) == 0.0
+
+
 # ----------------------------------------------------------------------------- GSC (gsc_et.py)
 def _gsc_cases():
     import glob, os
