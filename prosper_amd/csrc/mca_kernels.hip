@@ -126,28 +126,31 @@ __global__ void mca_estep_kernel(const double *__restrict__ scores, int64_t lds,
         }
         wave_sync_lds();
 
-        // multi-cause states: e_s = sum_d (Wbar_sd - y_d)^2
+        // multi-cause states: e_s = sum_d (Wbar_sd - y_d)^2.  Padding dimensions hold W^rho = 0 and y = 0:
+        // Wbar = 0 there and they add nothing, so the loop body is branch-free and the DPL powers of a
+        // lane are independent instruction streams.
         for (int s = 0; s < S; ++s) {
             const unsigned mask = masks[s];  // wave-uniform
+            double T[DPL];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+            unsigned m = mask;
+            while (m) {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                const double *wr = s_wr + j * DS + lane;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) T[i] += wr[64 * i];
+            }
             double part = 0.0;
 #pragma unroll
             for (int i = 0; i < DPL; ++i) {
-                const int d = lane + 64 * i;
-                double T = 0.0;
-                unsigned m = mask;
-                while (m) {
-                    const int j = __builtin_ctz(m);
-                    m &= m - 1;
-                    T += s_wr[j * DS + d];
-                }
-                if (d < D) {
-                    // MMCA: T may be negative or 0 (mmca_et.py:191: sign(t) exp(log|t| / rho)); for MCA T > 0
-                    const double wbar = copysign(exp(log(fabs(T)) * P.inv_rho), T);
-                    const double df = wbar - y[i];
-                    part += df * df;
-                }
+                // MMCA: T may be negative or 0 (mmca_et.py:191: sign(t) exp(log|t| / rho)); for MCA T > 0
+                const double wbar = copysign(pm_pow_pos(fabs(T[i]), P.inv_rho), T[i]);
+                const double df = wbar - y[i];
+                part = fma(df, df, part);
             }
-            part = pm_wave_sum(part);
+            part = pm_wave_sum_dpp(part);
             if (lane == 0) s_e[s] = part;
         }
         wave_sync_lds();
@@ -319,8 +322,7 @@ __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t 
                     for (int j = 0; j < HP; ++j)
                         if ((mask >> j) & 1u) T += s_wr[j * DS + d];
                     if (!SIGNED) {
-                        const double wbar = exp(log(T) * P.inv_rho);
-                        const double v = q * wbar / T;  // q_s * Wbar_sd / T_sd
+                        const double v = q * pm_pow_pos(T, P.inv_rho - 1.0);  // q_s * Wbar_sd / T_sd = q_s T^(1/rho - 1)
 #pragma unroll
                         for (int j = 0; j < HP; ++j)
                             if ((mask >> j) & 1u) V[j][i] += v;
@@ -328,7 +330,7 @@ __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t 
                         // q_s min(1, (|W_jd| / |Wbar_sd|)^(rho-1)), (.)^(rho-1) = |W_jd|^(rho-1) |Wbar_sd| / |t_sd|;
                         // t = 0 gives Wbar = 0 and the factor 1 (mmca_et.py:316-324: max(-inf - Wl, 0) = 0)
                         const double aT = fabs(T);
-                        const double r = (aT > 0.0) ? q * exp(log(aT) * P.inv_rho) / aT : INFINITY;
+                        const double r = (aT > 0.0) ? q * pm_pow_pos(aT, P.inv_rho - 1.0) : INFINITY;
 #pragma unroll
                         for (int j = 0; j < HP; ++j)
                             if ((mask >> j) & 1u) V[j][i] += fmin(q, r * s_wm[j * DS + d]);

@@ -25,6 +25,29 @@ __device__ __forceinline__ double pm_wave_max(double v) {
     return v;
 }
 
+// Wave-wide sum without the LDS crossbar: DPP butterflies inside each 16-lane row (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror), then the four row totals through v_readlane.  Result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double pm_dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double pm_readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double pm_wave_sum_dpp(double v) {
+    v += pm_dpp_f64<0xB1>(v);
+    v += pm_dpp_f64<0x4E>(v);
+    v += pm_dpp_f64<0x141>(v);
+    v += pm_dpp_f64<0x140>(v);
+    return (pm_readlane_f64(v, 0) + pm_readlane_f64(v, 16)) + (pm_readlane_f64(v, 32) + pm_readlane_f64(v, 48));
+}
+
 // Wave-wide argmax of (value, index): larger value wins, ties go to the larger index.
 __device__ __forceinline__ void pm_wave_argmax(double &v, int &idx) {
 #pragma unroll
@@ -35,6 +58,62 @@ __device__ __forceinline__ void pm_wave_argmax(double &v, int &idx) {
         v = take ? ov : v;
         idx = take ? oi : idx;
     }
+}
+
+// x^c for finite x >= 0 and modest |c log x| (MCA: Wbar = T^(1/rho), mca_et.py:170): exp(c log x) without
+// libm's double-double log and special-case handling (144 VALU instructions there, ~50 here).
+//   log:  x = m 2^e, m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), log m = 2 s sum_k s^(2k)/(2k+1) (k <= 10)
+//   exp:  y = n ln2 + r, |r| <= ln2/2, degree-13 Taylor polynomial, ldexp
+// Relative error <= ~3e-16 for results within [1e-100, 1e100]; x == 0 gives 0 (c > 0).
+__device__ __forceinline__ double pm_pow_pos(double x, double c) {
+    double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double s = num * r;
+    s = fma(fma(-den, s, num), r, s);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = p * z;                                            // log m = 2s (1 + p)
+    const double ed = (double)e;
+    const double two_s = s + s;
+    // log x = e ln2_hi + (2s + (2s p + e ln2_lo))
+    const double lg_lo = fma(two_s, p, ed * 1.9082149292705877e-10);
+    const double lg = fma(ed, 6.9314718036912382e-01, two_s + lg_lo);
+    const double y = c * lg;
+    const double n = rint(y * 1.4426950408889634);
+    double t = fma(-n, 6.9314718036912382e-01, y);
+    t = fma(-n, 1.9082149292705877e-10, t);
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, t, 1.0 / 479001600.0);
+    q = fma(q, t, 1.0 / 39916800.0);
+    q = fma(q, t, 1.0 / 3628800.0);
+    q = fma(q, t, 1.0 / 362880.0);
+    q = fma(q, t, 1.0 / 40320.0);
+    q = fma(q, t, 1.0 / 5040.0);
+    q = fma(q, t, 1.0 / 720.0);
+    q = fma(q, t, 1.0 / 120.0);
+    q = fma(q, t, 1.0 / 24.0);
+    q = fma(q, t, 1.0 / 6.0);
+    q = fma(q, t, 0.5);
+    q = fma(q, t, 1.0);
+    q = fma(q, t, 1.0);
+    const double res = ldexp(q, (int)n);
+    return x == 0.0 ? 0.0 : res;
 }
 
 // Packed BSC statistics buffer: [ Wp (H*D) | Wq (H*H) | qdiag (H) | mus (H) | scalars ]
