@@ -280,16 +280,20 @@ __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t 
         unsigned touched = 0;
         for (int s0 = 0; s0 < S; s0 += 64) {
             const int sl = s0 + lane;
-            double dl = -INFINITY;
-            if (sl < S) dl = P.beta * f[1 + H + sl] - lb;
+            double dl = -INFINITY, fl = 0.0;
+            if (sl < S) {
+                fl = f[1 + H + sl];
+                dl = P.beta * fl - lb;
+            }
+            const double ql = exp(dl);        // this lane's state; broadcast below (one exp per 64 states)
             unsigned long long live = __ballot(dl > qcut);
             while (live) {
                 const int src = __builtin_ctzll(live);
                 live &= live - 1;
                 const int s = s0 + src;
                 const unsigned mask = masks[s];
-                const double fs = f[1 + H + s];
-                const double q = exp(P.beta * fs - lb);
+                const double fs = pm_readlane_f64(fl, src);
+                const double q = pm_readlane_f64(ql, src);
                 if (lane == 0) {
                     const double ns = (double)__builtin_popcount(mask);
                     st_pi += q * ns;
@@ -314,28 +318,34 @@ __global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t 
                     staged = true;
                 }
                 touched |= mask;
+                // T for all of the lane's dimensions, then DPL independent powers, then the scatter into V
+                double T[DPL], v[DPL];
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < HP; ++j)
+                    if ((mask >> j) & 1u) {
+#pragma unroll
+                        for (int i = 0; i < DPL; ++i) T[i] += s_wr[j * DS + lane + 64 * i];
+                    }
 #pragma unroll
                 for (int i = 0; i < DPL; ++i) {
-                    const int d = lane + 64 * i;
-                    double T = 0.0;
-#pragma unroll
-                    for (int j = 0; j < HP; ++j)
-                        if ((mask >> j) & 1u) T += s_wr[j * DS + d];
                     if (!SIGNED) {
-                        const double v = q * pm_pow_pos(T, P.inv_rho - 1.0);  // q_s * Wbar_sd / T_sd = q_s T^(1/rho - 1)
-#pragma unroll
-                        for (int j = 0; j < HP; ++j)
-                            if ((mask >> j) & 1u) V[j][i] += v;
+                        v[i] = q * pm_pow_pos(T[i], P.inv_rho - 1.0);  // q_s * Wbar_sd / T_sd = q_s T^(1/rho - 1)
                     } else {
                         // q_s min(1, (|W_jd| / |Wbar_sd|)^(rho-1)), (.)^(rho-1) = |W_jd|^(rho-1) |Wbar_sd| / |t_sd|;
                         // t = 0 gives Wbar = 0 and the factor 1 (mmca_et.py:316-324: max(-inf - Wl, 0) = 0)
-                        const double aT = fabs(T);
-                        const double r = (aT > 0.0) ? q * pm_pow_pos(aT, P.inv_rho - 1.0) : INFINITY;
-#pragma unroll
-                        for (int j = 0; j < HP; ++j)
-                            if ((mask >> j) & 1u) V[j][i] += fmin(q, r * s_wm[j * DS + d]);
+                        const double aT = fabs(T[i]);
+                        v[i] = (aT > 0.0) ? q * pm_pow_pos(aT, P.inv_rho - 1.0) : INFINITY;
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < HP; ++j)
+                    if ((mask >> j) & 1u) {
+#pragma unroll
+                        for (int i = 0; i < DPL; ++i)
+                            V[j][i] += SIGNED ? fmin(q, v[i] * s_wm[j * DS + lane + 64 * i]) : v[i];
+                    }
             }
         }
         if (staged) {

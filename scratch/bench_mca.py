@@ -24,6 +24,6 @@ for _ in range(2): q=m.step(an,dict(p),data)
 m.timer=KernelTimer()
 torch.cuda.synchronize(); t=time.perf_counter()
 q=dict(p)
-for _ in range(3): q=m.step(an,q,data)
-torch.cuda.synchronize(); print("EM iter ms", (time.perf_counter()-t)/3*1e3)
+for _ in range(10): q=m.step(an,q,data)
+torch.cuda.synchronize(); print("EM iter ms", (time.perf_counter()-t)/10*1e3)
 print({k:round(v[1],3) for k,v in m.timer.summary().items()})
