@@ -60,6 +60,12 @@ int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B, int64_t ld
  * computed once per resident data shard. */
 int pm_row_sqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, double *out, void *stream);
 
+/* sums[d] += sum_n Y[n,d] (center == NULL) or sum_n (Y[n,d] - center[d])^2: the two collective means of
+ * CAModel.standard_init (camodels/__init__.py:209-217, dsc_et.py:892-899) over a resident shard.
+ * `sums` (D) is accumulated into (caller zeroes it). */
+int pm_col_moments_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *center,
+                       double *sums, void *stream);
+
 /* inv = (U + U^T - diag(U) + diag(diag_add))^-1 for a symmetric positive definite n x n matrix given
  * by its upper triangle `upper` (n <= 256, one workgroup, Gauss-Jordan in registers, no pivoting).
  * `full` (optional) receives the assembled matrix, `pivots` (optional, 2 doubles) the smallest and

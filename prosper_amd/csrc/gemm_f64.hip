@@ -511,6 +511,31 @@ __global__ __launch_bounds__(256) void row_sqnorm_f64_kernel(const double *__res
     }
 }
 
+// sums[d] += sum_n (Y[n,d] - center[d])^2 (center given) or sum_n Y[n,d] (center null): the two passes of
+// CAModel.standard_init (camodels/__init__.py:209-217).  A workgroup walks a slab of rows with 256
+// consecutive columns per pass (coalesced 2 KB row segments) and adds its partial column sums atomically.
+__global__ __launch_bounds__(256) void col_moments_f64_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N,
+                                                               int D, const double *__restrict__ center,
+                                                               double *__restrict__ sums, int64_t rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < D; d += gridDim.x * 256) {
+        const double c = center ? center[d] : 0.0;
+        double a0 = 0.0, a1 = 0.0;
+        int64_t n = r0;
+        for (; n + 1 < r1; n += 2) {
+            const double u = Y[n * ldy + d] - c, v = Y[(n + 1) * ldy + d] - c;
+            a0 += center ? u * u : u;
+            a1 += center ? v * v : v;
+        }
+        if (n < r1) {
+            const double u = Y[n * ldy + d] - c;
+            a0 += center ? u * u : u;
+        }
+        pm_atomic_add(sums + d, a0 + a1);
+    }
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int resident_slots() {  // workgroups of these kernels resident at once: 2 per CU
@@ -632,5 +657,20 @@ extern "C" int pm_row_sqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(row_sqnorm_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), Y,
                        ldy, N, (int)D, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_col_moments_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *center,
+                                  double *sums, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!Y || !sums || N < 0 || D <= 0 || ldy < D) return PM_EINVAL;
+    if (D > INT32_MAX) return PM_ERANGE;
+    const unsigned gx = (unsigned)((D + 255) / 256 > 64 ? 64 : (D + 255) / 256);
+    int64_t gy = (2 * (int64_t)resident_slots() + gx - 1) / gx;       // ~4 workgroups per CU in flight
+    if (gy > N) gy = N;
+    const int64_t rows_per_block = (N + gy - 1) / gy;
+    gy = (N + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(col_moments_f64_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), Y,
+                       ldy, N, (int)D, center, sums, rows_per_block);
     return (int)hipGetLastError();
 }

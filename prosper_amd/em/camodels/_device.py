@@ -248,6 +248,43 @@ class DeviceCAModel(CAModel):
         self._par = {}
         return self._data
 
+    def _global_count(self, res, my_N):
+        """N = sum of the shard sizes (``comm.allreduce(my_N)``, bsc_et.py:225): fetched once per resident
+        data set -- on an nccl-only group every host-side allreduce is a blocking device round trip."""
+        if res.get("N_global") is None:
+            res["N_global"] = self.comm.allreduce(my_N)
+        return res["N_global"]
+
+    def _data_moments(self, data):
+        """Per-dimension mean and variance of the (sharded) data on the device: two passes over the
+        resident shard (pm_col_moments_f64) and two tiny all-reduces, instead of the reference's two
+        host passes over N x D (``parallel.allmean``, camodels/__init__.py:209-213)."""
+        res = self._resident(data['y'])
+        Y = res["Y"]
+        my_N, D = Y.shape
+        N = self._global_count(res, my_N)
+        s1 = torch.zeros(D, dtype=torch.float64, device=self.device)
+        if my_N:
+            self._call("col_moments", "pm_col_moments_f64", _ptr(Y), Y.stride(0), my_N, D, None, _ptr(s1), self._stream())
+        self.comm.allreduce_device(s1)
+        mean = s1 / N
+        s2 = torch.zeros(D, dtype=torch.float64, device=self.device)
+        if my_N:
+            self._call("col_moments", "pm_col_moments_f64", _ptr(Y), Y.stride(0), my_N, D, _ptr(mean), _ptr(s2), self._stream())
+        self.comm.allreduce_device(s2)
+        host = self._download(torch.cat([mean, s2 / N]), slot="moments").copy()
+        return host[:D], host[D:]
+
+    def standard_init(self, data):
+        """W = data mean + N(0, (sigma_init/4)^2) per column, sigma = mean per-dimension std, pi = 1/H
+        (camodels/__init__.py:196-235); the two passes over the data run on the device."""
+        W_mean, sigma_sq = self._data_moments(data)
+        D = W_mean.shape[0]
+        assert D == self.D
+        sigma_init = np.sqrt(sigma_sq).sum() / D
+        W_init = W_mean[:, None] + np.random.normal(scale=sigma_init / 4., size=[D, self.H])
+        return {'W': W_init, 'pi': 1. / self.H, 'sigma': sigma_init}
+
     def invalidate_data(self):
         """Forget the resident shard (call after modifying ``my_data['y']`` in place)."""
         self._data = {}

@@ -381,7 +381,7 @@ class BSC_ET(DeviceCAModel):
         lse = lse.contiguous()
         assert tuple(lp.shape) == (my_N, K)
 
-        N = comm.allreduce(my_N)
+        N = self._global_count(res, my_N)
 
         # factors of the pi update (bsc_et.py:237-244)
         A_pi_gamma = 0

@@ -174,12 +174,9 @@ class DSC_ET(DeviceCAModel):
     def standard_init(self, data):
         """W = data mean + N(0, (sigma_init/4)^2), pi = (1 - 1/H) on the zero value and a random split of
         1/H over the others (dsc_et.py:872-925; RNG order: normal((D,H)) then rand(K-1))."""
-        comm = self.comm
-        my_y = np.asarray(data['y'])
-        my_N, D = my_y.shape
+        W_mean, sigma_sq = self._data_moments(data)
+        D = W_mean.shape[0]
         assert D == self.D
-        W_mean = parallel.allmean(my_y, axis=0, comm=comm)
-        sigma_sq = parallel.allmean((my_y - W_mean) ** 2, axis=0, comm=comm)
         sigma_init = np.sqrt(sigma_sq).sum() / D
         W_init = W_mean[:, None] + np.random.normal(scale=sigma_init / 4., size=[D, self.H])
         sparsity = 1. - (1. / self.H)
@@ -320,7 +317,7 @@ class DSC_ET(DeviceCAModel):
             lse = torch.logsumexp(lp, dim=1)
         lp, lse = lp.contiguous(), lse.contiguous()
         assert tuple(lp.shape) == (my_N, Kt)
-        N = comm.allreduce(my_N)
+        N = self._global_count(res, my_N)
 
         A_pi_gamma = self.get_scaling_factors(pi)
         dlog.append("prior_mass", A_pi_gamma)

@@ -264,7 +264,7 @@ class GSC(DeviceCAModel):
         res = self._resident(my_data['y'])
         Y = res["Y"]
         my_N = Y.shape[0]
-        N = comm.allreduce(my_N)
+        N = self._global_count(res, my_N)
         eps = 1e-5
 
         def dev(x):

@@ -177,7 +177,7 @@ class MCA_ET(DeviceCAModel):
             lseb = torch.logsumexp(beta * lp, dim=1)
         lp, lseb, lse1 = lp.contiguous(), lseb.contiguous(), lse1.contiguous()
         assert tuple(lp.shape) == (my_N, K)
-        N = comm.allreduce(my_N)
+        N = self._global_count(res, my_N)
 
         A_pi_gamma = 0.
         B_pi_gamma = 0.

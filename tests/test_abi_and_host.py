@@ -150,7 +150,8 @@ def test_standard_init_and_generate_data_rng_stream():
     assert np.array_equal(data["s"], g["s"])
     np.testing.assert_allclose(data["y"], g["y"], rtol=1e-13, atol=1e-13)
     np.random.seed(int(g["seed_init"]))
-    init = m.standard_init({"y": g["y"]})
+    from prosper_amd.em.camodels import CAModel
+    init = CAModel.standard_init(m, {"y": g["y"]})          # host mirror; the device version is a GPU test
     np.testing.assert_allclose(init["W"], g["W0"], rtol=1e-13)
     np.testing.assert_allclose(init["sigma"], g["sigma0"], rtol=1e-13)
     assert init["pi"] == float(g["pi0"])

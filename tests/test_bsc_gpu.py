@@ -112,6 +112,30 @@ def test_spd_inverse_rejects_large(dev):
         _lib.call("pm_spd_inverse_f64", _p(t), 300, None, 300, None, _p(t), 300, None, _stream())
 
 
+def test_col_moments_and_standard_init(dev):
+    """pm_col_moments_f64 and the device standard_init (camodels/__init__.py:196-235) against the
+    reference's golden init (same RNG stream, data passes on the device)."""
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    rs = np.random.RandomState(3)
+    Y = rs.normal(size=(1237, 300)) * 3 + rs.normal(size=300)
+    y = torch.from_numpy(Y).to(dev)
+    s1 = torch.zeros(300, dtype=torch.float64, device=dev)
+    _lib.call("pm_col_moments_f64", _p(y), 300, 1237, 300, None, _p(s1), _stream())
+    np.testing.assert_allclose(s1.cpu().numpy(), Y.sum(0), rtol=1e-12, atol=1e-10)
+    c = torch.from_numpy(Y.mean(0)).to(dev)
+    s2 = torch.zeros(300, dtype=torch.float64, device=dev)
+    _lib.call("pm_col_moments_f64", _p(y), 300, 1237, 300, _p(c), _p(s2), _stream())
+    np.testing.assert_allclose(s2.cpu().numpy(), ((Y - Y.mean(0)) ** 2).sum(0), rtol=1e-12)
+    g = golden("bsc_init_c1.npz")
+    m = BSC_ET(int(g["D"]), int(g["H"]), 5, 3)
+    np.random.seed(int(g["seed_init"]))
+    init = m.standard_init({"y": g["y"]})
+    np.testing.assert_allclose(init["W"], g["W0"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(init["sigma"], g["sigma0"], rtol=1e-12)
+    assert init["pi"] == float(g["pi0"])
+
+
 # ------------------------------------------------------------------------- BSC vs golden
 class _An(dict):
     crit_params = []
