@@ -1,0 +1,32 @@
+"""EM-iteration timing of DSC_ET (ternary) at D=256, H=128, H'=6, gamma=3, N=100k."""
+import sys, time, numpy as np, torch
+sys.path.insert(0,'.')
+from prosper_amd.em.camodels.dsc_et import DSC_ET
+from prosper_amd.em.camodels._device import KernelTimer
+D,H,HP,GAMMA,N=256,128,6,3,100000
+dev=torch.device('cuda',0)
+g=torch.Generator(device=dev).manual_seed(0)
+W_gt=torch.randn(D,H,generator=g,device=dev,dtype=torch.float64)*2
+Y=torch.empty(N,D,dtype=torch.float64,device=dev)
+for lo in range(0,N,25000):
+    u=torch.rand(25000,H,generator=g,device=dev)
+    S=(u<1.0/H).to(torch.float64)-(u>1-1.0/H).to(torch.float64)
+    Y[lo:lo+25000]=S@W_gt.t()+torch.randn(25000,D,generator=g,device=dev,dtype=torch.float64)
+W0=(W_gt+0.1*torch.randn(D,H,generator=g,device=dev,dtype=torch.float64)).cpu().numpy()
+class An(dict):
+    crit_params=[]
+    def __missing__(s,k): return 0.0
+    def as_dict(s): return dict(s)
+an=An(T=1.0)
+m=DSC_ET(D,H,HP,GAMMA,states=np.array([-1.,0.,1.]))
+print("states", m.no_states, "columns", 1+2*H+m.no_states)
+p={"W":W0,"pi":np.array([1.0/H,1-2.0/H,1.0/H]),"sigma":1.0}
+data={"y":Y}
+for _ in range(2): q=m.step(an,dict(p),data)
+m.timer=KernelTimer()
+torch.cuda.synchronize(); t=time.perf_counter()
+q=dict(p)
+for _ in range(10): q=m.step(an,q,data)
+torch.cuda.synchronize(); print("EM iter ms", (time.perf_counter()-t)/10*1e3)
+print({k:round(v[1],3) for k,v in m.timer.summary().items()})
+print("pi", q["pi"], "sigma", q["sigma"])
