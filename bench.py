@@ -48,8 +48,13 @@ def cpu_baseline(args):
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--D", str(D), "--H", str(H),
            "--Hprime", str(HP), "--gamma", str(GAMMA), "--budget", str(args.cpu_budget),
            "--full-budget", str(min(6.0, args.cpu_budget))]
+    # the child is plain NumPy: keep profiler / tool injection (rocprofv3 preloads its library into every
+    # descendant) out of its 100+ worker processes
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER", "ROCTX"))}
     try:
-        out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=240,
+                             env=env).stdout.strip().splitlines()
         return json.loads(out[-1])
     except Exception as e:  # the GPU numbers are still worth printing
         return {"value": None, "unit": "datapoints/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
