@@ -14,13 +14,16 @@ second region and reported as `em_iter_ms`.
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the f64 MFMA scores
 GEMM) by algorithmic flops / its average launch duration measured with HIP events inside the
 timed region; `cpu_baseline` is the oracle's faithful per-datapoint restatement of the
-reference timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+reference timed on this box's host cores on a bounded sample (rank 0, N=1 only); `parity` compares
+the HIP path with the oracle's answer (minted by that same leg) after 3 EM steps on a seeded sample at
+the bench's dimensions -- outside every timed region.
 """
 import argparse
 import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -43,11 +46,47 @@ def parse():
     return ap.parse_args()
 
 
+PARITY_FILE = os.path.join(tempfile.gettempdir(), "prosper_amd_parity_%d.npz" % os.getpid())
+
+
+def parity_report(model_cls, anneal_cls):
+    """SURVEY 8d "parity check reported with the numbers": the oracle's answer (written by the cpu_baseline
+    leg as plain arrays) against the HIP path on the same seeded sample at the bench's dimensions."""
+    import numpy as np
+    if not os.path.exists(PARITY_FILE):
+        return None
+    try:
+        ref = np.load(PARITY_FILE)
+        m = model_cls(D, H, HP, GAMMA)
+        p = {"W": ref["W0"].copy(), "pi": float(ref["pi0"]), "sigma": float(ref["sigma0"]), "mu": np.zeros(D)}
+        data = {"y": ref["y"]}
+        steps = int(ref["steps"])
+        cand_same = None
+        for k in range(steps):
+            if k == 0:
+                cand = np.asarray(m.select_Hprimes(p, dict(data))["candidates"])
+                cand_same = float((np.sort(cand, 1) == np.sort(ref["candidates1"], 1)).all(axis=1).mean())
+            p = m.step(anneal_cls(T=1.0), p, data)
+        rel = lambda a, b: float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))
+        return {"sample": "%d datapoints at the bench's dimensions, %d EM steps, oracle (vectorised NumPy restatement, "
+                          "golden-pinned) vs HIP path" % (ref["y"].shape[0], steps),
+                "W_rel_frobenius": rel(p["W"], ref["W"]), "pi_rel": abs(p["pi"] / float(ref["pi"]) - 1.0),
+                "sigma_rel": abs(p["sigma"] / float(ref["sigma"]) - 1.0),
+                "candidate_sets_identical_frac": cand_same, "tolerance": 1e-4}
+    except Exception as e:   # never lose the measurement over the report
+        return {"error": repr(e)}
+    finally:
+        try:
+            os.remove(PARITY_FILE)
+        except OSError:
+            pass
+
+
 def cpu_baseline(args):
     """Oracle leg, run as a child process BEFORE this process touches the GPU."""
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--D", str(D), "--H", str(H),
            "--Hprime", str(HP), "--gamma", str(GAMMA), "--budget", str(args.cpu_budget),
-           "--full-budget", str(min(6.0, args.cpu_budget))]
+           "--full-budget", str(min(6.0, args.cpu_budget)), "--parity-out", PARITY_FILE]
     # the child is plain NumPy: keep profiler / tool injection (rocprofv3 preloads its library into every
     # descendant) out of its 100+ worker processes
     env = {k: v for k, v in os.environ.items()
@@ -163,6 +202,8 @@ def main():
     model.timer = None
     em_kern = em_timer.summary()
 
+    parity = parity_report(BSC_ET, Anneal) if (rank == 0 and cpu is not None) else None
+
     t = torch.tensor([elapsed, em_elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,6 +248,7 @@ def main():
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(all_kern.items())},
             "em_kernels_ms": {k: round(v[1], 4) for k, v in sorted(em_kern.items())},
             "cpu_baseline": cpu,
+            "parity": parity,
         }
         print(json.dumps(out))
     if world > 1:

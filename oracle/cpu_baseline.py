@@ -58,6 +58,28 @@ def _worker(args):
     return done, t_e, m_done, t_m
 
 
+def parity_case(path, D, H, Hp, gamma, N=1536, steps=3):
+    """Reference answer for bench.py's parity report: `steps` EM steps of the (vectorised, golden-pinned)
+    oracle on a seeded sample at the bench's dimensions.  Written as plain arrays to `path`; bench.py runs
+    the same inputs through the HIP path and reports the differences."""
+    rng = np.random.RandomState(7)
+    W_gt = rng.normal(size=(D, H))
+    y, _ = O.generate_bsc_data(W_gt, 4.0 / H, 1.0, N, rng)
+    params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 4.0 / H, "sigma": 1.0, "mu": np.zeros(D)}
+    model = O.make_model(D, H, Hp, gamma)
+    an = O.Anneal(T=1.0)
+    out = {"y": y, "W0": params["W"], "pi0": params["pi"], "sigma0": params["sigma"], "steps": steps}
+    p = dict(params)
+    for k in range(steps):
+        p, log = O.em_step(an, model, p, y, stats_fn=O.m_step_stats_vec, vec=True)
+        p["mu"] = np.zeros(D)
+        if k == 0:
+            out["candidates1"] = log["candidates"]
+        out["L%d" % (k + 1)] = log["L"]
+    out.update(W=p["W"], pi=p["pi"], sigma=p["sigma"])
+    np.savez(path, **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--D", type=int, default=1024)
@@ -68,7 +90,10 @@ def main():
     ap.add_argument("--full-budget", type=float, default=6.0, help="seconds of M-step work per core")
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--cores", type=int, default=0)
+    ap.add_argument("--parity-out", default="", help="also write the oracle's answer for bench.py's parity report")
     a = ap.parse_args()
+    if a.parity_out:
+        parity_case(a.parity_out, a.D, a.H, a.Hprime, a.gamma)
     cores = a.cores or len(os.sched_getaffinity(0))
     ctx = mp.get_context("spawn")
     jobs = [(r, a.D, a.H, a.Hprime, a.gamma, a.budget, a.full_budget, a.chunk) for r in range(cores)]
