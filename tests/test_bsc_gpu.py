@@ -243,6 +243,82 @@ def test_trajectory_c1_matches_reference(dev):
     assert mae < 0.5
 
 
+def _bsc_problem(seed, D=96, H=32, N=3000):
+    rng = np.random.RandomState(seed)
+    W_gt = rng.normal(size=(D, H)) * 2
+    s = rng.random_sample((N, H)) < 3.0 / H
+    y = s @ W_gt.T + rng.normal(size=(N, D))
+    return W_gt, y, {"W": W_gt + 0.3 * rng.normal(size=(D, H)), "pi": 3.0 / H, "sigma": 1.2}
+
+
+def test_em_loop_pipelining_is_transparent(dev, monkeypatch):
+    """The EM-loop shortcuts (W kept on the device between steps, prefetched / speculative scores GEMM) never
+    change results (up to the run-to-run rounding of the f64 atomics in the split-K GEMMs and statistics): same
+    parameters with and without them, also when the caller edits W in place or feeds other parameters in between."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    _, y, p0 = _bsc_problem(11)
+    an = _An(T=1.0)
+
+    def run(speculate, edit):
+        m = BSC_ET(96, 32, 6, 3)
+        m.speculate = speculate
+        p = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in p0.items()}
+        out = []
+        for it in range(6):
+            if edit and it == 3:
+                p["W"][:, 0] *= 1.5            # in place, on the array M_step handed out
+            if edit and it == 4:
+                p = dict(p, W=np.ascontiguousarray(p["W"]) + 0.01)      # a different array, C order
+            p = m.step(an, p, {"y": y})
+            out.append((p["W"].copy(), p["pi"], p["sigma"]))
+        return out, m
+
+    for edit in (False, True):
+        a, ma = run(True, edit)
+        b, _ = run(False, edit)
+        for (Wa, pa, sa), (Wb, pb, sb) in zip(a, b):
+            np.testing.assert_allclose(Wa, Wb, rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose([pa, sa], [pb, sb], rtol=1e-10)
+    # a fresh model fed the edited parameters gives the same next step as the pipelined one
+    a, _ = run(True, True)
+    b, _ = run(True, False)
+    m2 = BSC_ET(96, 32, 6, 3)
+    p = {"W": a[2][0].copy(), "pi": a[2][1], "sigma": a[2][2]}
+    p["W"][:, 0] *= 1.5
+    q = m2.step(an, p, {"y": y})
+    np.testing.assert_allclose(q["W"], a[3][0], rtol=1e-9, atol=1e-10)
+    assert not np.allclose(q["W"], b[3][0], rtol=1e-3)          # ... and the edit did change the outcome
+
+
+def test_em_run_with_partial_data_and_parameter_noise(dev):
+    """EM.run with anneal['partial'] < 1 and W_noise > 0 (select_partial_data / noisify_params,
+    camodels/__init__.py:124-161, em/__init__.py:97-150): device-resident rows are sub-sampled, the noisy W
+    misses the seeded parameters, the loop still converges on the data."""
+    from prosper_amd.em import EM
+    from prosper_amd.em.annealing import LinearAnnealing
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    W_gt, y, p0 = _bsc_problem(12)
+    model = BSC_ET(96, 32, 6, 3)
+    anneal = LinearAnnealing(12)
+    anneal["T"] = [(0, 1.5), (.6, 1.)]
+    anneal["partial"] = [(0, .5), (.5, 1.)]
+    anneal["W_noise"] = [(0, 0.05), (.5, 0.)]
+    anneal["anneal_prior"] = False
+    np.random.seed(5)
+    h = dlog.set_handler(("L", "N"), StoreInMemory)
+    try:
+        em = EM(model=model, anneal=anneal, data={"y": y}, lparams=dict(p0))
+        em.run()
+    finally:
+        dlog.remove_handler(h)
+    N_seen = np.array(h.tables["N"], dtype=int)
+    assert N_seen[0] == 1500 and N_seen[-1] == 3000
+    assert np.isfinite(em.lparams["W"]).all() and np.isfinite(em.lparams["sigma"])
+    L = np.array(h.tables["L"], dtype=float)
+    assert np.isfinite(L).all() and (np.diff(L[-4:]) > -1e-9).all()      # plain EM once T = 1, all data, no noise
+
+
 # ------------------------------------------------------------------------- BSC vs oracle
 @pytest.mark.parametrize("D,H,Hp,gamma,N,T,ncut,ap", [
     (256, 128, 6, 3, 3000, 1.0, 0.0, False),
