@@ -219,6 +219,17 @@ int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse1, 
                           const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
                           int64_t Hprime, double *q1, int64_t ldq, double *stats, void *stream);
 
+/* E_step and the per-datapoint part of M_step in one pass (no data truncation: every datapoint is
+ * kept): outputs of pm_mca_estep_f64 plus q1 / stats of pm_mca_mstep_rows_f64, with every multi-cause
+ * power evaluated once instead of twice (mca_et.py:114-179 + 236-327, mmca_et.py:126-199 + 274-347).
+ * D <= 512, Hprime <= 12.  `stats` is accumulated into (caller zeroes it). */
+int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const double *wnorm2, const double *ynorm2,
+                            const double *Y, int64_t ldy, const double *Wrho, const double *Wrm1,
+                            const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                            const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
+                            int64_t Hprime, double *logpj, int64_t ldl, double *lse1, double *lseb,
+                            double *q1, int64_t ldq, double *stats, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Discrete Sparse Coding (prosper/em/camodels/dsc_et.py, DSC_ET): K-ary latents
  * ------------------------------------------------------------------------------------- */

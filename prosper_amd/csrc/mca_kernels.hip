@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void mca_select_scores_kernel(const double *__
 // E-step
 // ---------------------------------------------------------------------------------------------
 template <int DPL>  // observed dimensions per lane: D <= 64 * DPL
-__global__ void mca_estep_kernel(const double *__restrict__ scores, int64_t lds, const double *__restrict__ wnorm2,
+__global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict__ scores, int64_t lds, const double *__restrict__ wnorm2,
                                  const double *__restrict__ ynorm2, const double *__restrict__ Y, int64_t ldy,
                                  const double *__restrict__ Wrho, const int32_t *__restrict__ cand,
                                  const uint16_t *__restrict__ masks, int S, pm_mca_params P, int64_t N, int H, int D,
@@ -208,10 +208,251 @@ __global__ void mca_estep_kernel(const double *__restrict__ scores, int64_t lds,
 }
 
 // ---------------------------------------------------------------------------------------------
+// E-step + per-datapoint M-step statistics in ONE pass (no data truncation): the multi-cause powers are the
+// cost of both mca_estep_kernel and mca_mstep_rows_kernel, here they are evaluated once.  The posterior
+// weights of the states are not known until every state has been seen, so the Aid accumulators
+// V[j][d] = sum_s w_s T_sd^(1/rho-1) are kept relative to a running maximum M of beta*f_s (rescaled when it
+// moves, like an online softmax) and normalised by exp(M - lse_beta) at the end.  A stored term is never
+// smaller than its final value, so nothing underflows that would survive in the two-pass form.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pm_div_pos(double a, double b) {   // a / b for normal positive b
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+template <int DPL, int HP, bool SIGNED>
+__global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
+                                       const double *__restrict__ wnorm2, const double *__restrict__ ynorm2,
+                                       const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
+                                       const double *__restrict__ Wrm1, const int32_t *__restrict__ cand,
+                                       const uint16_t *__restrict__ masks, int S, pm_mca_params P, int64_t N, int H,
+                                       int D, int Hp, double *__restrict__ logpj, int64_t ldl,
+                                       double *__restrict__ lse1, double *__restrict__ lseb,
+                                       double *__restrict__ q1, int64_t ldq, double *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [ q1sum (H) | red (4 * waves) | per wave: wr (HP*DS) [wm (HP*DS)] e (S) ]
+    constexpr int DS = 64 * DPL;
+    const int waves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *s_q1sum = reinterpret_cast<double *>(smem);
+    double *s_red = s_q1sum + H;
+    const size_t per_wave = (size_t)(SIGNED ? 2 : 1) * HP * DS + S;
+    double *s_wr = s_red + 4 * waves + (size_t)wave * per_wave;
+    double *s_wm = s_wr + HP * DS;                       // SIGNED only
+    double *s_e = s_wr + (SIGNED ? 2 : 1) * HP * DS;
+    for (int h = tid; h < H; h += blockDim.x) s_q1sum[h] = 0.0;
+    __syncthreads();
+
+    double *Wp = stats + (int64_t)H * D;
+    double *Wq = stats + 2 * (int64_t)H * D;
+    double st_pi = 0.0, st_sigma = 0.0, st_ld = 0.0, st_cnt = 0.0;
+
+    const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * waves;
+    for (int64_t n = wave0; n < N; n += nwaves) {
+        const int32_t *cn = cand + n * Hp;
+        double y[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            y[i] = (d < D) ? Y[n * ldy + d] : 0.0;
+        }
+        for (int j = 0; j < HP; ++j) {
+            const bool have = j < Hp;
+            const int64_t base = have ? (int64_t)cn[j] * D : 0;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                s_wr[j * DS + d] = (have && d < D) ? Wrho[base + d] : 0.0;
+                if (SIGNED) s_wm[j * DS + d] = (have && d < D) ? Wrm1[base + d] : 1.0;
+            }
+        }
+        wave_sync_lds();
+
+        double V[HP][DPL];
+#pragma unroll
+        for (int j = 0; j < HP; ++j)
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) V[j][i] = 0.0;
+        double M = -INFINITY;   // running maximum of beta * f_s over the multi-cause states seen so far
+
+        for (int s = 0; s < S; ++s) {
+            const unsigned mask = masks[s];  // wave-uniform
+            double T[DPL], wbar[DPL];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < HP; ++j)
+                if ((mask >> j) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) T[i] += s_wr[j * DS + lane + 64 * i];
+                }
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                wbar[i] = pm_pow_pos(fabs(T[i]), P.inv_rho);          // |Wbar|
+                const double df = copysign(wbar[i], T[i]) - y[i];
+                part = fma(df, df, part);
+            }
+            part = pm_wave_sum_dpp(part);                               // wave-uniform
+            if (lane == 0) s_e[s] = part;
+            const double bf = P.beta * (P.pil_bar * (double)__builtin_popcount(mask) + P.pre1 * part);
+            if (bf > M) {                                               // uniform branch; rare after the first states
+                const double sc = exp(M - bf);
+#pragma unroll
+                for (int j = 0; j < HP; ++j)
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) V[j][i] *= sc;
+                M = bf;
+            }
+            const double w = exp(bf - M);
+            double v[DPL];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const double aT = fabs(T[i]);
+                // padding dimensions have T = 0: contribute nothing (never scattered)
+                if (!SIGNED) v[i] = (aT > 0.0) ? w * pm_div_pos(wbar[i], aT) : 0.0;
+                else v[i] = (aT > 0.0) ? w * pm_div_pos(wbar[i], aT) : INFINITY;
+            }
+#pragma unroll
+            for (int j = 0; j < HP; ++j)
+                if ((mask >> j) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i)
+                        V[j][i] += SIGNED ? fmin(w, v[i] * s_wm[j * DS + lane + 64 * i]) : v[i];
+                }
+        }
+        wave_sync_lds();
+
+        // log-pseudo-joints and the two log-evidences (as mca_estep_kernel)
+        const double yn = ynorm2[n];
+        const double *arow = scores + n * lds;
+        double *out = logpj + n * ldl;
+        double m1 = -INFINITY;
+        const double f0 = P.pre1 * yn;
+        if (lane == 0) {
+            out[0] = f0;
+            m1 = f0;
+        }
+        for (int h = lane; h < H; h += 64) {
+            const double f = P.pil_bar + P.pre1 * (wnorm2[h] - 2.0 * arow[h] + yn);
+            out[1 + h] = f;
+            m1 = fmax(m1, f);
+        }
+        for (int s = lane; s < S; s += 64) {
+            const double f = P.pil_bar * (double)__builtin_popcount((unsigned)masks[s]) + P.pre1 * s_e[s];
+            out[1 + H + s] = f;
+            s_e[s] = f;
+            m1 = fmax(m1, f);
+        }
+        m1 = pm_wave_max(m1);
+        double s1 = 0.0, sb = 0.0;
+        if (lane == 0) {
+            const double dlt = f0 - m1;
+            s1 += exp(dlt);
+            sb += exp(P.beta * dlt);
+        }
+        for (int h = lane; h < H; h += 64) {
+            const double dlt = (P.pil_bar + P.pre1 * (wnorm2[h] - 2.0 * arow[h] + yn)) - m1;
+            if (dlt > -745.0) {
+                s1 += exp(dlt);
+                sb += exp(P.beta * dlt);
+            }
+        }
+        for (int s = lane; s < S; s += 64) {
+            const double dlt = s_e[s] - m1;
+            if (dlt > -745.0) {
+                s1 += exp(dlt);
+                sb += exp(P.beta * dlt);
+            }
+        }
+        s1 = pm_wave_sum(s1);
+        sb = pm_wave_sum(sb);
+        const double l1 = m1 + log(s1), lb = P.beta * m1 + log(sb);
+        if (lane == 0) {
+            lse1[n] = l1;
+            lseb[n] = lb;
+        }
+
+        // ---- M-step statistics of this datapoint (mca_et.py:274-327) ----
+        double *qrow = q1 + n * ldq;
+        if (lane == 0) {
+            st_sigma += exp(P.beta * f0 - lb) * yn;
+            st_ld += l1;
+            st_cnt += 1.0;
+        }
+        for (int h = lane; h < H; h += 64) {
+            const double e = wnorm2[h] - 2.0 * arow[h] + yn;
+            const double q = exp(P.beta * (P.pil_bar + P.pre1 * e) - lb);
+            if (q != 0.0) {
+                st_sigma += q * e;
+                st_pi += q;
+                atomicAdd(&s_q1sum[h], q);
+            }
+            qrow[h] = q;
+        }
+        for (int s = lane; s < S; s += 64) {
+            const double fs = s_e[s];
+            const double q = exp(P.beta * fs - lb);
+            const double ns = (double)__builtin_popcount((unsigned)masks[s]);
+            st_pi += q * ns;
+            st_sigma += q * ((fs - P.pil_bar * ns) / P.pre1);
+        }
+        const double g = exp(M - lb);                   // <= 1: every multi-cause beta*f_s is <= lb
+        if (S > 0 && g != 0.0) {
+#pragma unroll
+            for (int j = 0; j < HP; ++j) {
+                if (j < Hp) {
+                    const int64_t base = (int64_t)cn[j] * D;
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) {
+                        const int d = lane + 64 * i;
+                        if (d < D) {
+                            const double aid = SIGNED ? V[j][i] * g : V[j][i] * g * Wrm1[base + d];
+                            if (aid != 0.0) {
+                                pm_atomic_add(Wp + base + d, aid * y[i]);
+                                pm_atomic_add(Wq + base + d, aid);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync_lds();
+    }
+
+    st_pi = pm_wave_sum(st_pi);
+    st_sigma = pm_wave_sum(st_sigma);
+    st_ld = pm_wave_sum(st_ld);
+    st_cnt = pm_wave_sum(st_cnt);
+    if (lane == 0) {
+        s_red[wave * 4 + 0] = st_pi;
+        s_red[wave * 4 + 1] = st_sigma;
+        s_red[wave * 4 + 2] = st_ld;
+        s_red[wave * 4 + 3] = st_cnt;
+    }
+    __syncthreads();
+    double *g_q1sum = stats + 3 * (int64_t)H * D;
+    double *sc = g_q1sum + H;
+    if (tid < 4) {
+        double v = 0.0;
+        for (int w = 0; w < waves; ++w) v += s_red[w * 4 + tid];
+        if (v != 0.0) pm_atomic_add(sc + tid, v);
+    }
+    for (int h = tid; h < H; h += blockDim.x) {
+        const double v = s_q1sum[h];
+        if (v != 0.0) pm_atomic_add(g_q1sum + h, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // M-step, per-datapoint part
 // ---------------------------------------------------------------------------------------------
 template <int DPL, int HP, bool SIGNED>
-__global__ void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse1,
+__global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse1,
                                       const double *__restrict__ lseb, double lse_cut,
                                       const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
                                       const double *__restrict__ Wrm1, const int32_t *__restrict__ cand,
@@ -513,6 +754,65 @@ extern "C" int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
         case 2: return sgn ? launch_mstep_hp<2, true>(PM_ARGS) : launch_mstep_hp<2, false>(PM_ARGS);
         case 4: return sgn ? launch_mstep_hp<4, true>(PM_ARGS) : launch_mstep_hp<4, false>(PM_ARGS);
         default: return sgn ? launch_mstep_hp<8, true>(PM_ARGS) : launch_mstep_hp<8, false>(PM_ARGS);
+    }
+#undef PM_ARGS
+}
+
+namespace {
+template <int DPL, bool SIGNED>
+int launch_fused_hp(int Hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, const double *scores, int64_t lds,
+                    const double *wnorm2, const double *ynorm2, const double *Y, int64_t ldy, const double *Wrho,
+                    const double *Wrm1, const int32_t *cand, const uint16_t *masks, int S, pm_mca_params P, int64_t N,
+                    int H, int D, double *logpj, int64_t ldl, double *lse1, double *lseb, double *q1, int64_t ldq,
+                    double *stats) {
+    const int hp = Hp <= 4 ? 4 : Hp <= 8 ? 8 : 12;
+#define PM_CASE(HPV)                                                                                                  \
+    case HPV: {                                                                                                       \
+        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, SIGNED>), shmem))   \
+            return e;                                                                                                 \
+        hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, SIGNED>), grid, block, shmem, s, scores, lds, wnorm2,    \
+                           ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, ldq, \
+                           stats);                                                                                    \
+        return (int)hipGetLastError();                                                                                \
+    }
+    switch (hp) {
+        PM_CASE(4) PM_CASE(8) PM_CASE(12)
+        default: return PM_ERANGE;
+    }
+#undef PM_CASE
+}
+}  // namespace
+
+extern "C" int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const double *wnorm2, const double *ynorm2,
+                                       const double *Y, int64_t ldy, const double *Wrho, const double *Wrm1,
+                                       const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                                       const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
+                                       int64_t Hprime, double *logpj, int64_t ldl, double *lse1, double *lseb,
+                                       double *q1, int64_t ldq, double *stats, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!scores || !wnorm2 || !ynorm2 || !Y || !Wrho || !Wrm1 || !cand || !params_host || !logpj || !lse1 || !lseb ||
+        !q1 || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || lds < H || ldy < D ||
+        ldl < 1 + H + S || ldq < H || (S > 0 && !state_masks))
+        return PM_EINVAL;
+    if (D > 512 || Hprime > 12 || Hprime > H || S > 65535) return PM_ERANGE;
+    const int dpl = D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : 8;
+    const int hp_tile = Hprime <= 4 ? 4 : Hprime <= 8 ? 8 : 12;
+    if ((int64_t)dpl * hp_tile > 48) return PM_ERANGE;  // V[HP][DPL] register tile
+    const bool sgn = params_host->signed_w != 0.0;
+    const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl * (sgn ? 2 : 1) + S);
+    const size_t shared = sizeof(double) * (H + 16);
+    const int waves = pick_waves(per_wave, shared);
+    const size_t shmem = shared + per_wave * waves;
+    if (shmem > 150 * 1024) return PM_ERANGE;
+    dim3 grid((unsigned)grid_waves(N, waves)), block(64 * waves);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PM_ARGS (int)Hprime, grid, block, shmem, s, scores, lds, wnorm2, ynorm2, Y, ldy, Wrho, Wrm1, cand, state_masks, \
+                (int)S, *params_host, N, (int)H, (int)D, logpj, ldl, lse1, lseb, q1, ldq, stats
+    switch (dpl) {
+        case 1: return sgn ? launch_fused_hp<1, true>(PM_ARGS) : launch_fused_hp<1, false>(PM_ARGS);
+        case 2: return sgn ? launch_fused_hp<2, true>(PM_ARGS) : launch_fused_hp<2, false>(PM_ARGS);
+        case 4: return sgn ? launch_fused_hp<4, true>(PM_ARGS) : launch_fused_hp<4, false>(PM_ARGS);
+        default: return sgn ? launch_fused_hp<8, true>(PM_ARGS) : launch_fused_hp<8, false>(PM_ARGS);
     }
 #undef PM_ARGS
 }

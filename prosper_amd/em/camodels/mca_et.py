@@ -45,6 +45,7 @@ class MCA_ET(DeviceCAModel):
         }
         self._masks_dev = None
         self.signed_w = 0.0           # 1.0 in MMCA_ET: signed W, see pm_mca_params
+        self.fuse_em = True           # E_step also produces the M-step's per-datapoint statistics when it can
 
     @tracing.traced
     def check_params(self, model_params):
@@ -140,12 +141,28 @@ class MCA_ET(DeviceCAModel):
         lse1 = torch.empty((N,), dtype=torch.float64, device=self.device)
         lseb = torch.empty((N,), dtype=torch.float64, device=self.device)
         tracing.tracepoint("E_step:iterating")
+        fused = None
         if N:
             A = self._gemm_nt(Y, par["Wt"], self._buf("scores", (N, H)), "scores_gemm")
-            self._call("estep", "pm_mca_estep_f64", _ptr(A), H, _ptr(par["wnorm2"]), _ptr(res["ynorm2"]), _ptr(Y), D,
-                       _ptr(par["Wrho"]), _ptr(cand), _ptr(masks), S, ctypes.byref(P), N, H, D, Hp,
-                       _ptr(logpj), K, _ptr(lse1), _ptr(lseb), self._stream())
+            hp_tile = 4 if Hp <= 4 else 8 if Hp <= 8 else 12
+            dpl = 1 if D <= 64 else 2 if D <= 128 else 4 if D <= 256 else 8
+            if self.fuse_em and anneal['Ncut_factor'] == 0.0 and D <= 512 and Hp <= 12 and dpl * hp_tile <= 48:
+                # no data truncation ahead: the M-step's per-datapoint statistics come out of the same pass
+                # (every multi-cause power is evaluated once instead of twice)
+                stats = torch.zeros(_lib.load().pm_mca_stats_len(H, D), dtype=torch.float64, device=self.device)
+                q1 = torch.empty((N, H), dtype=torch.float64, device=self.device)
+                self._call("estep_mstats", "pm_mca_estep_mstats_f64", _ptr(A), H, _ptr(par["wnorm2"]),
+                           _ptr(res["ynorm2"]), _ptr(Y), D, _ptr(par["Wrho"]), _ptr(par["Wrm1"]), _ptr(cand),
+                           _ptr(masks), S, ctypes.byref(P), N, H, D, Hp, _ptr(logpj), K, _ptr(lse1), _ptr(lseb),
+                           _ptr(q1), H, _ptr(stats), self._stream())
+                fused = {"stats": stats, "q1": q1, "par": par, "res": res, "cand": my_data['candidates'],
+                         "pi": model_params['pi'], "sigma": model_params['sigma']}
+            else:
+                self._call("estep", "pm_mca_estep_f64", _ptr(A), H, _ptr(par["wnorm2"]), _ptr(res["ynorm2"]), _ptr(Y),
+                           D, _ptr(par["Wrho"]), _ptr(cand), _ptr(masks), S, ctypes.byref(P), N, H, D, Hp,
+                           _ptr(logpj), K, _ptr(lse1), _ptr(lseb), self._stream())
         out = DeviceArray(logpj)
+        out.fused = fused
         out.lse = lseb          # log sum exp(beta * logpj): weights and truncation
         out.lse1 = lse1         # log sum exp(logpj): the likelihood term Q
         out.T = T
@@ -195,14 +212,23 @@ class MCA_ET(DeviceCAModel):
         tracing.tracepoint("M_step:iterating")
         lib = _lib.load()
         n_stats = lib.pm_mca_stats_len(H, D)
-        stats = self._buf("mca_stats", (n_stats,))
-        stats.zero_()
-        q1 = self._buf("mca_q1", (my_N, H))
-        P = self._params(anneal, pies, sigma, par["rho"])
+        fz = getattr(logpj, "fused", None) if isinstance(logpj, DeviceArray) else None
+        if fz is not None and lse_cut == float("-inf") and fz["par"] is par and fz["res"] is res \
+                and fz["cand"] is my_data['candidates'] and fz["pi"] == pies and fz["sigma"] == sigma \
+                and logpj.T == T:
+            # E_step already accumulated the per-datapoint statistics for exactly these inputs
+            stats, q1 = fz["stats"], fz["q1"]
+            logpj.fused = None            # consumed: the buffer is all-reduced in place below
+        else:
+            stats = self._buf("mca_stats", (n_stats,))
+            stats.zero_()
+            q1 = self._buf("mca_q1", (my_N, H))
+            P = self._params(anneal, pies, sigma, par["rho"])
+            if my_N:
+                self._call("mstep_rows", "pm_mca_mstep_rows_f64", _ptr(lp), K, _ptr(lse1), _ptr(lseb),
+                           ctypes.c_double(lse_cut), _ptr(Y), D, _ptr(par["Wrho"]), _ptr(par["Wrm1"]), _ptr(cand),
+                           _ptr(masks), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(q1), H, _ptr(stats), self._stream())
         if my_N:
-            self._call("mstep_rows", "pm_mca_mstep_rows_f64", _ptr(lp), K, _ptr(lse1), _ptr(lseb),
-                       ctypes.c_double(lse_cut), _ptr(Y), D, _ptr(par["Wrho"]), _ptr(par["Wrm1"]), _ptr(cand),
-                       _ptr(masks), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(q1), H, _ptr(stats), self._stream())
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(q1), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N,
                        self._stream())
         comm.allreduce_device(stats)      # replaces mca_et.py:208,253,340,341,357,366,371

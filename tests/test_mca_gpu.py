@@ -90,3 +90,37 @@ def test_mca_generate_data_rng_stream():
     y, s = M.generate_mca_data(W, 0.3, 0.5, 20, np.random.RandomState(9))
     assert np.array_equal(d["s"], s)
     np.testing.assert_allclose(d["y"], y, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("cls_name", ["MCA_ET", "MMCA_ET"])
+@pytest.mark.parametrize("D,H,Hp,gamma,N", [(256, 128, 8, 3, 700), (60, 33, 5, 4, 301), (512, 40, 4, 2, 130)])
+def test_fused_estep_statistics_match_two_pass(cls_name, D, H, Hp, gamma, N):
+    """pm_mca_estep_mstats_f64 (E-step + M-step statistics in one pass, running-maximum accumulation)
+    against pm_mca_estep_f64 + pm_mca_mstep_rows_f64."""
+    import importlib
+    mod = importlib.import_module("prosper_amd.em.camodels." + ("mca_et" if cls_name == "MCA_ET" else "mmca_et"))
+    cls = getattr(mod, cls_name)
+    rng = np.random.RandomState(D + N)
+    signed = cls_name == "MMCA_ET"
+    W_gt = rng.normal(size=(D, H)) * 3.0 if signed else np.abs(rng.normal(size=(D, H))) * 2.0 + 0.1
+    s = rng.random_sample((N, H)) < 2.0 / H
+    y = np.zeros((N, D))
+    for n in range(N):
+        if s[n].any():
+            t0 = W_gt.T[s[n]]
+            y[n] = t0[np.argmax(np.abs(t0), axis=0), np.arange(D)] if signed else t0.max(axis=0)
+    y += rng.normal(size=(N, D))
+    p0 = {"W": W_gt * (1 + 0.1 * rng.uniform(-1, 1, size=(D, H))), "pi": 2.4 / H, "sigma": 1.1}
+    outs = []
+    for fuse in (True, False):
+        m = cls(D, H, Hp, gamma)
+        m.fuse_em = fuse
+        p = m.check_params({k: (v.copy() if hasattr(v, "copy") else v) for k, v in p0.items()})
+        data = m.select_Hprimes(p, {"y": y})
+        ss = m.E_step(_An(T=1.3), p, data)
+        assert (ss["logpj"].fused is not None) == fuse
+        new = m.M_step(_An(T=1.3), p, ss, data)
+        outs.append((np.asarray(ss["logpj"]), new))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-12, atol=1e-10)
+    for k in ("W", "pi", "sigma", "Q"):
+        np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=1e-9, atol=1e-12)
