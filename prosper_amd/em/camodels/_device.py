@@ -17,17 +17,26 @@ except Exception:  # pragma: no cover
     torch = None
 
 try:
-    from threadpoolctl import threadpool_limits as _threadpool_limits
+    from threadpoolctl import ThreadpoolController as _ThreadpoolController
 except Exception:  # pragma: no cover
-    _threadpool_limits = None
+    _ThreadpoolController = None
+
+_blas_controller = None
 
 
 class small_blas(object):
     """Host LAPACK on the H x H matrices of an M-step with a handful of threads: on a 256-core GPU
-    host OpenBLAS otherwise wakes every core for a 128 x 128 inverse (measured 16 ms instead of 0.2)."""
+    host OpenBLAS otherwise wakes every core for a 128 x 128 inverse (measured 16 ms instead of 0.2).
+    The library scan of threadpoolctl (0.6 ms) is done once per process."""
 
     def __init__(self, threads=4):
-        self._ctx = _threadpool_limits(limits=threads, user_api="blas") if _threadpool_limits else None
+        global _blas_controller
+        if _blas_controller is None and _ThreadpoolController is not None:
+            w = np.ones((256, 256))
+            np.dot(w, w)                             # OpenBLAS builds its thread pool on the first threaded call:
+            np.linalg.inv(w + 256 * np.eye(256))     # do that before any limit is in force (else every call rebuilds it)
+            _blas_controller = _ThreadpoolController()
+        self._ctx = _blas_controller.limit(limits=threads, user_api="blas") if _blas_controller is not None else None
 
     def __enter__(self):
         if self._ctx is not None:
