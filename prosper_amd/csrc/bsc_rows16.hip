@@ -19,7 +19,6 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "prosper_hip.h"
 #include "pm_common.h"
@@ -448,8 +447,7 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 3 : 1) void bsc_mstep_rows16_kerne
 
 inline int64_t grid_groups(int64_t N) {
     const int64_t groups = (N + ROWS - 1) / ROWS;
-    static const int64_t env_cap = getenv("PM_ROWS16_MAX_BLOCKS") ? atoll(getenv("PM_ROWS16_MAX_BLOCKS")) : 0;
-    const int64_t cap = env_cap > 0 ? env_cap : 256 * 8;
+    const int64_t cap = 256 * 8;      // persistent grid: two rounds of resident workgroups walk the groups
     return groups < cap ? (groups < 1 ? 1 : groups) : cap;
 }
 

@@ -165,19 +165,53 @@ class BSC_ET(DeviceCAModel):
         N = self.max_chunk_rows if N is None else min(N, self.max_chunk_rows)
         return max(rr, N // rr * rr)
 
+    def _whole_shard(self, N):
+        """One scores buffer and one row-kernel launch for the shard (the default up to ``max_chunk_rows``)."""
+        return self.chunk_rounds <= 0 and not self.overlap_streams and N <= self.max_chunk_rows + self._round_rows()
+
+    def _ensure_scores(self, res, par):
+        """Whole-shard mode: A = Y.W^T for every row of the shard in one (N, H) buffer.  The rows that fill whole
+        rounds of resident GEMM tiles go out as one launch, the ragged remainder as a split-K launch."""
+        Y = res["Y"]
+        N, H = Y.shape[0], self.H
+        A = self._buf("scores_all", (N, H))
+        tag = (par, res["key"], "all", N)
+        if self._a0 is not None and self._a0[0] is par and self._a0[1:] == tag[1:]:
+            return A
+        rows = min(N, self._chunk_rows(N))
+        stream = torch.cuda.current_stream(self.device)
+        if rows < N:
+            self._scores_chunk(res, par, A[rows:], rows, N, rows, 2, stream)
+        self._scores_chunk(res, par, A[:rows], 0, rows, rows, 2 if rows < N else 1, stream)
+        self._a0 = tag
+        return A
+
     def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None):
-        """Chunked scores GEMM + fused select/E-step kernel.  A chunk is one round of resident GEMM
-        tiles; its (chunk, H) score block is consumed by the row kernel straight away, so the
-        scores buffer is bounded (two alternating buffers).  Measured: chunk size barely matters
-        (one round per chunk 2.27 ms, whole shard 2.18 ms per pass at config 2).
+        """Scores GEMM + fused select/E-step kernel.  Whole-shard mode: the scores of all rows, then ONE pass of
+        the row kernel.  Chunked mode (``chunk_rounds`` / shards beyond ``max_chunk_rows``): a chunk is a whole
+        number of rounds of resident GEMM tiles; its (chunk, H) score block is consumed by the row kernel
+        straight away, so the scores buffer is bounded (two alternating buffers).  Measured: chunk size barely
+        matters (one round per chunk 2.27 ms, whole shard 2.15 ms per pass at config 2).
         ``overlap``: GEMM of chunk c+1 on a side stream while the row kernel of chunk c runs."""
         Y = res["Y"]
         N, H, Hp, S = Y.shape[0], self.H, self.Hprime, self.no_states
         tab = self._state_tables()
         ldl = logpj.stride(0) if logpj is not None else 0
+        main = torch.cuda.current_stream(self.device)
+
+        def rows_kernel(A, r0, r1):
+            off = lambda t, w=1: ctypes.c_void_p(t.data_ptr() + r0 * w * t.element_size()) if t is not None else None
+            self._call("select_estep", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
+                       _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S,
+                       self.gamma, ctypes.byref(P) if P is not None else None, r1 - r0, H, Hp, mode,
+                       off(cand, Hp), off(logpj, ldl), ldl, off(lse), ctypes.c_void_p(main.cuda_stream))
+
+        if self._whole_shard(N):
+            rows_kernel(self._ensure_scores(res, par), 0, N)
+            return
+
         rows = self._chunk_rows(N)
         nchunks = (N + rows - 1) // rows
-        main = torch.cuda.current_stream(self.device)
         bufs = [self._buf("scores_c0", (rows, H)), self._buf("scores_c1", (rows, H))]
         overlap = self.overlap_streams and nchunks > 1
         if overlap:
@@ -188,27 +222,20 @@ class BSC_ET(DeviceCAModel):
         else:
             side = main
         done = [None, None]
-        tag = (par, res["key"], rows)
-        have0 = self._a0 is not None and self._a0[0] is par and self._a0[1:] == tag[1:]   # prefetched
-        self._a0 = tag if nchunks <= 2 else None          # whose chunk-0 scores bufs[0] holds afterwards
+        self._a0 = None
         for c in range(nchunks):
             r0, r1 = c * rows, min(N, (c + 1) * rows)
             A = bufs[c & 1]
-            if not (c == 0 and have0):
-                with torch.cuda.stream(side):
-                    if overlap and done[c & 1] is not None:
-                        side.wait_event(done[c & 1])     # the row kernel that read this buffer is finished
-                    self._scores_chunk(res, par, A, r0, r1, rows, nchunks, side)
-                    if overlap:
-                        ready = torch.cuda.Event()
-                        ready.record(side)
+            with torch.cuda.stream(side):
+                if overlap and done[c & 1] is not None:
+                    side.wait_event(done[c & 1])     # the row kernel that read this buffer is finished
+                self._scores_chunk(res, par, A, r0, r1, rows, nchunks, side)
                 if overlap:
-                    main.wait_event(ready)
-            off = lambda t, w=1: ctypes.c_void_p(t.data_ptr() + r0 * w * t.element_size()) if t is not None else None
-            self._call("select_estep", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
-                       _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S,
-                       self.gamma, ctypes.byref(P) if P is not None else None, r1 - r0, H, Hp, mode,
-                       off(cand, Hp), off(logpj, ldl), ldl, off(lse), ctypes.c_void_p(main.cuda_stream))
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+            if overlap:
+                main.wait_event(ready)
+            rows_kernel(A, r0, r1)
             if overlap:
                 done[c & 1] = torch.cuda.Event()
                 done[c & 1].record(main)
@@ -220,19 +247,11 @@ class BSC_ET(DeviceCAModel):
                    Y.shape[1], ctypes.c_void_p(stream.cuda_stream))
 
     def _prefetch_scores(self, res, par):
-        """Enqueue the scores GEMM of the first chunk as soon as W is known (select_Hprimes), so the
-        device is busy while the host walks on to E_step."""
+        """Enqueue the scores GEMMs as soon as W is known (select_Hprimes, or speculatively at the end of an
+        M-step), so the device is busy while the host walks on to E_step."""
         N = res["Y"].shape[0]
-        if not N or self.overlap_streams:
-            return
-        rows = self._chunk_rows(N)
-        tag = (par, res["key"], rows)
-        if self._a0 is not None and self._a0[0] is par and self._a0[1:] == tag[1:]:
-            return
-        nchunks = (N + rows - 1) // rows
-        A = self._buf("scores_c0", (rows, self.H))
-        self._scores_chunk(res, par, A, 0, min(N, rows), rows, nchunks, torch.cuda.current_stream(self.device))
-        self._a0 = tag
+        if N and self._whole_shard(N):
+            self._ensure_scores(res, par)
 
     def _materialize_candidates(self, ticket):
         """Selection on its own (someone looked at the lazy candidates before E_step ran)."""
@@ -317,7 +336,7 @@ class BSC_ET(DeviceCAModel):
         # results are handed to the caller: fresh tensors (the caching allocator recycles last step's)
         # rows padded to whole 128-byte lines: unaligned rows made every row store straddle two lines
         # (WRITE_SIZE 1.8x the bytes); the caller sees the (N, K) view
-        Kpad = (K + 15) // 16 * 16 if os.environ.get('PM_PAD', '1') == '1' else K
+        Kpad = (K + 15) // 16 * 16
         logpj = torch.empty((N, Kpad), dtype=torch.float64, device=self.device)[:, :K]
         lse = torch.empty((N,), dtype=torch.float64, device=self.device)
         tracing.tracepoint("E_step:iterating")
