@@ -135,6 +135,17 @@ class BSC_ET(DeviceCAModel):
             self._prefetch_scores(res, par)
         return par
 
+    def install_parameters(self, data, Wt_dev, Wt_host):
+        """Install a W^T (H,D) that already lives on the device -- the state an M-step leaves behind --
+        for the shard ``data['y']``: the Gram matrix is recomputed and scores of earlier parameters are
+        dropped.  ``Wt_host`` is the caller's host copy of the same matrix (checked against the W of later calls)."""
+        res = self._resident(data['y'])
+        G = self._gemm_nt(Wt_dev, Wt_dev, self._buf("gram", (self.H, self.H)), "gram_gemm")
+        par = self._seed_params(res, Wt_dev, G, False)
+        par["Whost"] = Wt_host
+        par["seeded"] = False
+        self._par, self._a0 = par, None
+
     def _scores(self, model_params, res):
         """A = Y.W^T (N,H) and G = W.W^T for the current W; reused by E_step when
         select_Hprimes just computed them for the same W and data."""
@@ -180,9 +191,9 @@ class BSC_ET(DeviceCAModel):
             return A
         rows = min(N, self._chunk_rows(N))
         stream = torch.cuda.current_stream(self.device)
+        self._scores_chunk(res, par, A[:rows], 0, rows, rows, 2 if rows < N else 1, stream)
         if rows < N:
             self._scores_chunk(res, par, A[rows:], rows, N, rows, 2, stream)
-        self._scores_chunk(res, par, A[:rows], 0, rows, rows, 2 if rows < N else 1, stream)
         self._a0 = tag
         return A
 
