@@ -3,7 +3,7 @@
 
 #include "prosper_hip.h"
 
-extern "C" int pm_version(void) { return 1000; }
+extern "C" int pm_version(void) { return 1004; }  // 1001 spd inverse, 1002 MMCA (pm_mca_params.signed_w), 1003 DSC, 1004 fused MCA pass + column moments
 
 extern "C" const char *pm_error_string(int code) {
     if (code == PM_OK) return "ok";
