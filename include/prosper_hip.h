@@ -212,7 +212,8 @@ int64_t pm_mca_stats_len(int64_t H, int64_t D);
  * G1 = q1^T.Y is then one pm_gemm_tn_acc_f64 into stats[0..H*D)), scatters the multi-cause
  * terms Aid (mca_et.py:309) into Wp_multi / Wq_multi, accumulates the scalars.  W_new = Wp/Wq is
  * an element-wise ratio, so only weights that underflow to 0 (as in the reference) are dropped.
- * Wrm1 = W^(rho-1) (H,D).  `stats` is zeroed by the caller once per EM step. */
+ * Wrm1 = W^(rho-1) (H,D).  `stats` is zeroed by the caller once per EM step.  Hprime <= 12; any D
+ * (the observed dimensions are walked in slabs of 512, one launch each). */
 int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse1, const double *lseb,
                           double lse_cut, const double *Y, int64_t ldy, const double *Wrho,
                           const double *Wrm1, const int32_t *cand, const uint16_t *state_masks, int64_t S,

@@ -457,8 +457,10 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
                                       const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
                                       const double *__restrict__ Wrm1, const int32_t *__restrict__ cand,
                                       const uint16_t *__restrict__ masks, int S, pm_mca_params P, int64_t N, int H,
-                                      int D, int Hp, double *__restrict__ q1, int64_t ldq,
+                                      int D, int d0, int Dl, int Hp, double *__restrict__ q1, int64_t ldq,
                                       double *__restrict__ stats) {
+    // this launch covers the observed dimensions [d0, d0 + Dl) (Dl <= 64 * DPL); D is the row length of the
+    // tables and of Wp / Wq.  The singleton weights and the scalar statistics belong to the slab d0 == 0.
     // HP = register-tile height (Hp rounded up to 4 / 8 / 12); state masks only use bits < Hp
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [ q1sum (H) | red (4 * waves) | per wave: wr (HP * DS) ]
@@ -479,6 +481,7 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
     // factors are ~1e-100 there.  Only weights that underflow to exactly 0 -- as they do in the
     // reference -- may be dropped.
     const double qcut = -745.2;
+    const bool first = d0 == 0;
     double st_pi = 0.0, st_sigma = 0.0, st_ld = 0.0, st_cnt = 0.0;
 
     const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
@@ -487,19 +490,20 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
         double *qrow = q1 + n * ldq;
         const double lb = lseb[n];
         if (!(lb >= lse_cut)) {  // truncated (mca_et.py:243-253)
-            for (int h = lane; h < H; h += 64) qrow[h] = 0.0;
+            if (first)
+                for (int h = lane; h < H; h += 64) qrow[h] = 0.0;
             continue;
         }
         const double *f = logpj + n * ldl;
         const int32_t *cn = cand + n * Hp;
-        if (lane == 0) {
+        if (first && lane == 0) {
             const double f0 = f[0];
             const double dlt = P.beta * f0 - lb;
             st_sigma += exp(dlt) * (f0 / P.pre1);
             st_ld += lse1[n];
             st_cnt += 1.0;
         }
-        for (int h = lane; h < H; h += 64) {
+        for (int h = lane; first && h < H; h += 64) {
             const double fh = f[1 + h];
             const double dlt = P.beta * fh - lb;
             const double q = exp(dlt);       // singletons are never dropped (underflow aside)
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
                 const unsigned mask = masks[s];
                 const double fs = pm_readlane_f64(fl, src);
                 const double q = pm_readlane_f64(ql, src);
-                if (lane == 0) {
+                if (first && lane == 0) {
                     const double ns = (double)__builtin_popcount(mask);
                     st_pi += q * ns;
                     st_sigma += q * ((fs - P.pil_bar * ns) / P.pre1);
@@ -544,15 +548,15 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
 #pragma unroll
                     for (int i = 0; i < DPL; ++i) {
                         const int d = lane + 64 * i;
-                        y[i] = (d < D) ? Y[n * ldy + d] : 0.0;
+                        y[i] = (d < Dl) ? Y[n * ldy + d0 + d] : 0.0;
                     }
                     for (int j = 0; j < Hp; ++j) {
-                        const double *srcw = Wrho + (int64_t)cn[j] * D;
+                        const double *srcw = Wrho + (int64_t)cn[j] * D + d0;
 #pragma unroll
                         for (int i = 0; i < DPL; ++i) {
                             const int d = lane + 64 * i;
-                            s_wr[j * DS + d] = (d < D) ? srcw[d] : 1.0;
-                            if (SIGNED) s_wm[j * DS + d] = (d < D) ? Wrm1[(int64_t)cn[j] * D + d] : 1.0;
+                            s_wr[j * DS + d] = (d < Dl) ? srcw[d] : 1.0;
+                            if (SIGNED) s_wm[j * DS + d] = (d < Dl) ? Wrm1[(int64_t)cn[j] * D + d0 + d] : 1.0;
                         }
                     }
                     wave_sync_lds();
@@ -593,11 +597,11 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
 #pragma unroll
             for (int j = 0; j < HP; ++j) {
                 if ((touched >> j) & 1u) {
-                    const int64_t base = (int64_t)cn[j] * D;
+                    const int64_t base = (int64_t)cn[j] * D + d0;
 #pragma unroll
                     for (int i = 0; i < DPL; ++i) {
                         const int d = lane + 64 * i;
-                        if (d < D) {
+                        if (d < Dl) {
                             const double aid = SIGNED ? V[j][i] : V[j][i] * Wrm1[base + d];  // Aid[j,d] (mca_et.py:309)
                             pm_atomic_add(Wp + base + d, aid * y[i]);
                             pm_atomic_add(Wq + base + d, aid);
@@ -708,14 +712,14 @@ template <int DPL, bool SIGNED>
 int launch_mstep_hp(int hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, const double *logpj, int64_t ldl,
                     const double *lse1, const double *lseb, double lse_cut, const double *Y, int64_t ldy,
                     const double *Wrho, const double *Wrm1, const int32_t *cand, const uint16_t *masks, int S,
-                    pm_mca_params P, int64_t N, int H, int D, double *q1, int64_t ldq, double *stats) {
+                    pm_mca_params P, int64_t N, int H, int D, int d0, int Dl, double *q1, int64_t ldq, double *stats) {
     const int Hp = hp;
     hp = hp <= 4 ? 4 : hp <= 8 ? 8 : 12;
 #define PM_CASE(HPV)                                                                                              \
     case HPV: {                                                                                                   \
         if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_mstep_rows_kernel<DPL, HPV, SIGNED>), shmem)) return e; \
         hipLaunchKernelGGL((mca_mstep_rows_kernel<DPL, HPV, SIGNED>), grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, \
-                           ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, q1, ldq, stats);                      \
+                           ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, d0, Dl, Hp, q1, ldq, stats);               \
         return (int)hipGetLastError();                                                                            \
     }
     switch (hp) {
@@ -735,27 +739,35 @@ extern "C" int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
     if (!logpj || !lse1 || !lseb || !Y || !Wrho || !Wrm1 || !cand || !params_host || !q1 || !stats || N < 0 ||
         H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || ldl < 1 + H + S || ldy < D || ldq < H || (S > 0 && !state_masks))
         return PM_EINVAL;
-    if (D > 512 || Hprime > 12 || Hprime > H || S > 65535) return PM_ERANGE;
-    const int dpl = D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : 8;
+    if (D > (1 << 20) || Hprime > 12 || Hprime > H || S > 65535) return PM_ERANGE;
     const int hp_tile = Hprime <= 4 ? 4 : Hprime <= 8 ? 8 : 12;
-    if ((int64_t)dpl * hp_tile > 48) return PM_ERANGE;  // V[HP][DPL] register tile
+    // observed dimensions are walked in slabs whose V[HP][DPL] register tile stays within 48 doubles per lane
+    const int dpl_max = hp_tile == 12 ? 4 : 8;
+    const int slab = 64 * dpl_max;
     const bool sgn = params_host->signed_w != 0.0;
-    const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl) * (sgn ? 2 : 1);
-    const size_t shared = sizeof(double) * (H + 16);
-    const int waves = pick_waves(per_wave, shared);
-    const size_t shmem = shared + per_wave * waves;
-    if (shmem > 150 * 1024) return PM_ERANGE;
-    dim3 grid((unsigned)grid_waves(N, waves)), block(64 * waves);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int64_t d0 = 0; d0 < D; d0 += slab) {
+        const int Dl = (int)((D - d0) < slab ? (D - d0) : slab);
+        const int dpl = Dl <= 64 ? 1 : Dl <= 128 ? 2 : Dl <= 256 ? 4 : 8;
+        const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl) * (sgn ? 2 : 1);
+        const size_t shared = sizeof(double) * (H + 16);
+        const int waves = pick_waves(per_wave, shared);
+        const size_t shmem = shared + per_wave * waves;
+        if (shmem > 150 * 1024) return PM_ERANGE;
+        dim3 grid((unsigned)grid_waves(N, waves)), block(64 * waves);
 #define PM_ARGS (int)Hprime, grid, block, shmem, s, logpj, ldl, lse1, lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, state_masks, \
-                (int)S, *params_host, N, (int)H, (int)D, q1, ldq, stats
-    switch (dpl) {
-        case 1: return sgn ? launch_mstep_hp<1, true>(PM_ARGS) : launch_mstep_hp<1, false>(PM_ARGS);
-        case 2: return sgn ? launch_mstep_hp<2, true>(PM_ARGS) : launch_mstep_hp<2, false>(PM_ARGS);
-        case 4: return sgn ? launch_mstep_hp<4, true>(PM_ARGS) : launch_mstep_hp<4, false>(PM_ARGS);
-        default: return sgn ? launch_mstep_hp<8, true>(PM_ARGS) : launch_mstep_hp<8, false>(PM_ARGS);
-    }
+                (int)S, *params_host, N, (int)H, (int)D, (int)d0, Dl, q1, ldq, stats
+        int rc;
+        switch (dpl) {
+            case 1: rc = sgn ? launch_mstep_hp<1, true>(PM_ARGS) : launch_mstep_hp<1, false>(PM_ARGS); break;
+            case 2: rc = sgn ? launch_mstep_hp<2, true>(PM_ARGS) : launch_mstep_hp<2, false>(PM_ARGS); break;
+            case 4: rc = sgn ? launch_mstep_hp<4, true>(PM_ARGS) : launch_mstep_hp<4, false>(PM_ARGS); break;
+            default: rc = sgn ? launch_mstep_hp<8, true>(PM_ARGS) : launch_mstep_hp<8, false>(PM_ARGS); break;
+        }
 #undef PM_ARGS
+        if (rc) return rc;
+    }
+    return PM_OK;
 }
 
 namespace {

@@ -59,7 +59,8 @@ def test_mca_step_matches_reference_golden(case):
 
 
 @pytest.mark.parametrize("D,H,Hp,gamma,N,T,ncut", [(256, 128, 8, 3, 1500, 1.0, 0.0), (100, 70, 5, 4, 333, 1.6, 0.6),
-                                                    (40, 20, 3, 2, 65, 1.0, 1.0)])
+                                                    (40, 20, 3, 2, 65, 1.0, 1.0), (700, 24, 4, 3, 90, 1.2, 0.0),
+                                                    (1000, 16, 10, 2, 50, 1.0, 0.4)])
 def test_mca_step_matches_oracle(D, H, Hp, gamma, N, T, ncut):
     from oracle import mca_oracle as M
     from prosper_amd.em.camodels.mca_et import MCA_ET
@@ -75,7 +76,17 @@ def test_mca_step_matches_oracle(D, H, Hp, gamma, N, T, ncut):
     np.testing.assert_allclose(new["W"], ref["W"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(new["pi"], ref["pi"], rtol=1e-9)
     np.testing.assert_allclose(new["sigma"], ref["sigma"], rtol=1e-9)
-    np.testing.assert_allclose(new["Q"], ref["Q"], rtol=1e-10)
+    if np.isfinite(ref["Q"]):
+        np.testing.assert_allclose(new["Q"], ref["Q"], rtol=1e-10)
+    else:
+        # the reference's log(sum(exp(logpj))) (mca_et.py:327) underflows to -inf once logpj < -745 (large D);
+        # the device keeps the stabilised log-evidence (documented deviation)
+        from scipy.special import logsumexp
+        lp = log["logpj"]
+        lb = logsumexp(lp / T, axis=1)
+        keep = lb >= np.sort(lb)[-log["N_use"]]
+        lAi = (H * np.log(1. - ref["pi"])) - ((D / 2) * np.log(2 * np.pi)) - (D * np.log(ref["sigma"]))
+        np.testing.assert_allclose(new["Q"], lAi * log["N_use"] + logsumexp(lp[keep], axis=1).sum(), rtol=1e-10)
 
 
 def test_mca_generate_data_rng_stream():

@@ -79,7 +79,7 @@ def test_mmca_generate_from_hidden_matches_reference():
 
 
 @pytest.mark.parametrize("D,H,Hp,gamma,N,T,ncut", [(256, 128, 8, 3, 1200, 1.0, 0.0), (100, 70, 5, 4, 333, 1.6, 0.6),
-                                                    (40, 20, 3, 2, 65, 3.0, 1.0)])
+                                                    (40, 20, 3, 2, 65, 3.0, 1.0), (700, 24, 4, 3, 90, 1.2, 0.0)])
 def test_mmca_step_matches_oracle(D, H, Hp, gamma, N, T, ncut):
     from oracle import mmca_oracle as M
     from prosper_amd.em.camodels.mmca_et import MMCA_ET
@@ -87,7 +87,7 @@ def test_mmca_step_matches_oracle(D, H, Hp, gamma, N, T, ncut):
     W_gt = rng.normal(size=(D, H)) * 3.0
     s = rng.random_sample((N, H)) < 2.0 / H
     y = M.generate_from_hidden(W_gt, s) + rng.normal(size=(N, D))
-    params = {"W": W_gt * (1 + (0.2 if D < 200 else 0.02) * rng.uniform(-1, 1, size=(D, H))), "pi": 2.4 / H, "sigma": 1.1}
+    params = {"W": W_gt * (1 + (0.2 if D < 200 else 0.02 if D < 600 else 0.005) * rng.uniform(-1, 1, size=(D, H))), "pi": 2.4 / H, "sigma": 1.1}
     model = M.make_model(D, H, Hp, gamma)
     an = M.Anneal(T=T, Ncut_factor=ncut)
     # oracle on the device's candidates (Gram-form ranking may swap exact near-ties)
