@@ -66,6 +66,11 @@ int pm_row_sqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, double
 int pm_col_moments_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *center,
                        double *sums, void *stream);
 
+/* out[n] = sum_d w[d] Y[n,d]^2 -- y^T Sigma^-1 y of GSC with a diagonal noise covariance
+ * (gsc_et.py:418-419, 476, 780-781). */
+int pm_row_wsqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *w, double *out,
+                       void *stream);
+
 /* inv = (U + U^T - diag(U) + diag(diag_add))^-1 for a symmetric positive definite n x n matrix given
  * by its upper triangle `upper` (n <= 256, one workgroup, Gauss-Jordan in registers, no pivoting).
  * `full` (optional) receives the assembled matrix, `pivots` (optional, 2 doubles) the smallest and

@@ -1,9 +1,9 @@
 """ORACLE -- test infrastructure, not product code.
 
 CPU restatement (NumPy, float64) of the reference's Gaussian (spike-and-slab) Sparse Coding
-truncated-EM hot path, prosper/em/camodels/gsc_et.py (class ``GSC``, reference v0.1.0), for the
-scalar observation noise ``sigma_sq_type='scalar'`` (BASELINE config 4).  Imported only by tests/,
-__graft_entry__.smoke() and bench.py's cpu_baseline leg.
+truncated-EM hot path, prosper/em/camodels/gsc_et.py (class ``GSC``, reference v0.1.0), for the three
+observation-noise types: scalar (BASELINE config 4), diagonal (D,) and full (D,D) ``sigma_sq``.  Imported only
+by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 
 The reference buckets datapoints by candidate set and returns its statistics in bucket order
 (gsc_et.py:721-749, 572-573); everything the M-step consumes is a sum over datapoints, so this
@@ -15,6 +15,9 @@ restatement keeps the original order.  It uses the scores + Gram algebra the ker
     kappa = Lambda^-1 b / s2 + mu_a,   E[z z^T] = kappa kappa^T + Lambda^-1
 Weights are the reference's UN-stabilised exp(beta * lp), NaN / underflow clamped to ``tiny``
 (gsc_et.py:354-356, 518-522); the null state's weight exp(-beta |y|^2 / s2) is not clamped (:476-478).
+
+For a diagonal / full noise covariance Sigma every inner product above becomes Sigma^-1-weighted:
+a = W^T Sigma^-1 y, G = W^T Sigma^-1 W, |y|^2 -> y^T Sigma^-1 y, and s2 = 1 (gsc_et.py:321-346, 414-425).
 
 Pinned against outputs of the reference itself (tests/golden/gsc_step_*.npz).
 """
@@ -38,11 +41,25 @@ def make_model(D, H, Hprime, gamma):
     return {'D': D, 'H': H, 'Hprime': Hprime, 'gamma': gamma, 'SM': SM, 'state_abs': state_abs, 'S': S}
 
 
+def noise_terms(params, Y=None):
+    """(Ws, s2, yn): Ws = Sigma^-1 W for a diagonal / full sigma_sq (W itself for a scalar one, with its
+    1/s2 kept explicit as upstream), s2 the remaining scalar, yn = y^T Sigma^-1 y (|y|^2 for scalar)."""
+    W, sig = params['W'], np.asarray(params['sigma_sq'], dtype=np.float64)
+    if sig.ndim == 0:
+        return W, float(sig), None if Y is None else (Y * Y).sum(axis=1)
+    if sig.ndim == 1:
+        sinv = 1. / sig
+        return W * sinv[:, None], 1.0, None if Y is None else (Y * Y * sinv[None, :]).sum(axis=1)
+    Sinv = np.linalg.inv(sig)
+    return Sinv @ W, 1.0, None if Y is None else ((Y @ Sinv) * Y).sum(axis=1)
+
+
 def _singleton_terms(params):
     """Per-latent constants of the one-cause states (gsc_et.py:481-511, 777-799)."""
-    W, mu, s2 = params['W'], params['mu'], float(params['sigma_sq'])
+    W, mu = params['W'], params['mu']
+    Ws, s2, _ = noise_terms(params)
     psi = np.diag(params['psi_sq'])
-    Gd = (W * W).sum(axis=0)
+    Gd = (Ws * W).sum(axis=0)
     lam = Gd / s2 + 1. / psi
     norm_const = -(np.log(psi) + np.log(lam))
     return Gd, lam, norm_const
@@ -50,10 +67,10 @@ def _singleton_terms(params):
 
 def component_scores(params, Y):
     """gsc_et.py:752-809: singleton log-posterior without the prior, NaN/-inf -> float min, inf -> 0."""
-    W, mu, s2 = params['W'], params['mu'], float(params['sigma_sq'])
+    W, mu = params['W'], params['mu']
+    Ws, s2, yn = noise_terms(params, Y)
     Gd, lam, norm_const = _singleton_terms(params)
-    A = Y @ W
-    yn = (Y * Y).sum(axis=1)
+    A = Y @ Ws
     r2 = yn[:, None] - 2. * mu[None, :] * A + (mu * mu * Gd)[None, :]
     b = A - (Gd * mu)[None, :]
     post = norm_const[None, :] - r2 / s2 + b * b / lam[None, :] / s2 ** 2
@@ -72,17 +89,19 @@ def select_hprimes(params, Y, Hprime):
 def _state_quantities(params, Y, cand, act):
     """For the multi-cause state using candidate positions ``act`` (tuple): lp without prior
     (N,), kappa (N,g), Lambda^-1 (N,g,g), and the latent indices (N,g)."""
-    W, mu, psi, s2 = params['W'], params['mu'], params['psi_sq'], float(params['sigma_sq'])
+    W, mu, psi = params['W'], params['mu'], params['psi_sq']
+    Ws, s2, yn = noise_terms(params, Y)
     idx = cand[:, list(act)]                                        # (N, g)
     N, g = idx.shape
     Wa = W[:, idx].transpose(1, 0, 2)                               # (N, D, g)
+    Wsa = Ws[:, idx].transpose(1, 0, 2)
     mua = mu[idx]                                                   # (N, g)
     Psia = psi[idx[:, :, None], idx[:, None, :]]                    # (N, g, g)
-    Gaa = np.einsum('ndi,ndj->nij', Wa, Wa)
-    aa = np.einsum('ndi,nd->ni', Wa, Y)
+    Gaa = np.einsum('ndi,ndj->nij', Wsa, Wa)
+    Gaa = 0.5 * (Gaa + Gaa.transpose(0, 2, 1)) if Ws is not W else Gaa
+    aa = np.einsum('ndi,nd->ni', Wsa, Y)
     Lam = Gaa / s2 + np.linalg.inv(Psia)
     Lam_inv = np.linalg.inv(Lam)
-    yn = (Y * Y).sum(axis=1)
     r2 = yn - 2. * (mua * aa).sum(axis=1) + np.einsum('ni,nij,nj->n', mua, Gaa, mua)
     b = aa - np.einsum('nij,nj->ni', Gaa, mua)
     quad = np.einsum('ni,nij,nj->n', b, Lam_inv, b)
@@ -95,15 +114,14 @@ def _state_quantities(params, Y, cand, act):
 def compute_lpj(model, params, Y, cand):
     """gsc_et.py:811-944 -> logpj (N, 1+H+S) (no beta, prior included)."""
     H, SM = model['H'], model['SM']
-    s2 = float(params['sigma_sq'])
+    Ws, s2, yn = noise_terms(params, Y)
     lpi = np.log(params['pi']) - np.log(1 - np.array(params['pi']))
     N = Y.shape[0]
     out = np.zeros((N, 1 + H + SM.shape[0]))
-    out[:, 0] = -(Y * Y).sum(axis=1) / s2
+    out[:, 0] = -yn / s2
     W, mu = params['W'], params['mu']
     Gd, lam, norm_const = _singleton_terms(params)
-    A = Y @ W
-    yn = (Y * Y).sum(axis=1)
+    A = Y @ Ws
     r2 = yn[:, None] - 2. * mu[None, :] * A + (mu * mu * Gd)[None, :]
     b = A - (Gd * mu)[None, :]
     out[:, 1:H + 1] = norm_const[None, :] - r2 / s2 + b * b / lam[None, :] / s2 ** 2 + lpi[None, :]
@@ -119,7 +137,7 @@ def e_step(anneal, model, params, Y, cand):
     xpt_szsz (N,H,H)."""
     H, SM = model['H'], model['SM']
     beta = 1. / anneal['T']
-    s2 = float(params['sigma_sq'])
+    Ws, s2, yn = noise_terms(params, Y)
     N = Y.shape[0]
     lpi = np.log(params['pi']) - np.log(1 - np.array(params['pi']))
     W, mu = params['W'], params['mu']
@@ -134,11 +152,10 @@ def e_step(anneal, model, params, Y, cand):
     pstr_ss = np.zeros((N, H, H))
     pstr_sz = np.zeros((N, H))
     pstr_szsz = np.zeros((N, H, H))
-    yn = (Y * Y).sum(axis=1)
     nfac = np.exp(-yn / s2 * beta)                                   # null state, not clamped
 
     Gd, lam, norm_const = _singleton_terms(params)
-    A = Y @ W
+    A = Y @ Ws
     r2 = yn[:, None] - 2. * mu[None, :] * A + (mu * mu * Gd)[None, :]
     b = A - (Gd * mu)[None, :]
     lp1 = norm_const[None, :] - r2 / s2 + b * b / lam[None, :] / s2 ** 2 + lpi[None, :]
@@ -170,7 +187,7 @@ def e_step(anneal, model, params, Y, cand):
 
 
 def m_step(model, params, suff, Y, to_learn=('W', 'pi', 'mu', 'sigma_sq', 'psi_sq'), N_total=None):
-    """gsc_et.py:584-718 (scalar sigma_sq).  Returns the updated parameter dict."""
+    """gsc_et.py:584-718.  Returns the updated parameter dict."""
     H, D = model['H'], model['D']
     eps = 1e-5
     xs, xsz, xss, xszsz = suff['xpt_s'], suff['xpt_sz'], suff['xpt_ss'], suff['xpt_szsz']
@@ -195,9 +212,16 @@ def m_step(model, params, suff, Y, to_learn=('W', 'pi', 'mu', 'sigma_sq', 'psi_s
         psi = np.outer(mu, mu) * sum_ss + sum_szsz - 2 * (mu[:, None] * (xs.T @ xsz))
         new['psi_sq'] = (psi * np.linalg.inv(sum_ss + eps * np.eye(H))) + (eps * np.eye(H))
     if 'sigma_sq' in to_learn:
-        WT_outer = np.dot(W_n.T, W_n)
-        my = (Y * Y).sum() - np.trace((xsz.T @ xsz) @ WT_outer)
-        new['sigma_sq'] = my / N / D + eps
+        U = xsz.T @ xsz                                               # sum_n xpt_sz xpt_sz^T
+        kind = np.ndim(params['sigma_sq'])
+        if kind == 2:                                                 # full (gsc_et.py:677-688)
+            new['sigma_sq'] = (Y.T @ Y - W_n @ U @ W_n.T) / N + eps * np.eye(D)
+        elif kind == 1:                                               # diagonal (gsc_et.py:690-701)
+            new['sigma_sq'] = ((Y * Y).sum(axis=0) - ((W_n @ U) * W_n).sum(axis=1)) / N + eps
+        else:                                                         # scalar (gsc_et.py:703-713)
+            WT_outer = np.dot(W_n.T, W_n)
+            my = (Y * Y).sum() - np.trace(U @ WT_outer)
+            new['sigma_sq'] = my / N / D + eps
     return new
 
 

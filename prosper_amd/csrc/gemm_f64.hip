@@ -511,6 +511,22 @@ __global__ __launch_bounds__(256) void row_sqnorm_f64_kernel(const double *__res
     }
 }
 
+// out[n] = sum_d w[d] Y[n,d]^2: y^T Sigma^-1 y for a diagonal noise covariance (gsc_et.py:418-419, 476).
+__global__ __launch_bounds__(256) void row_wsqnorm_f64_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N,
+                                                               int D, const double *__restrict__ w,
+                                                               double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t n = wave0; n < N; n += nwaves) {
+        const double *y = Y + n * ldy;
+        double s = 0.0;
+        for (int d = lane; d < D; d += 64) s = fma(y[d] * w[d], y[d], s);
+        s = pm_wave_sum(s);
+        if (lane == 0) out[n] = s;
+    }
+}
+
 // sums[d] += sum_n (Y[n,d] - center[d])^2 (center given) or sum_n Y[n,d] (center null): the two passes of
 // CAModel.standard_init (camodels/__init__.py:209-217).  A workgroup walks a slab of rows with 256
 // consecutive columns per pass (coalesced 2 KB row segments) and adds its partial column sums atomically.
@@ -672,5 +688,17 @@ extern "C" int pm_col_moments_f64(const double *Y, int64_t ldy, int64_t N, int64
     gy = (N + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(col_moments_f64_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), Y,
                        ldy, N, (int)D, center, sums, rows_per_block);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_row_wsqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *w, double *out,
+                                  void *stream) {
+    if (N == 0) return PM_OK;
+    if (!Y || !w || !out || N < 0 || D <= 0 || ldy < D) return PM_EINVAL;
+    if (D > INT32_MAX) return PM_ERANGE;
+    int64_t blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(row_wsqnorm_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       Y, ldy, N, (int)D, w, out);
     return (int)hipGetLastError();
 }

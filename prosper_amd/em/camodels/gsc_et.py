@@ -13,7 +13,8 @@ Differences a caller can observe: datapoints keep their order (the
 its statistics in candidate-bucket order and rewrites ``my_data['y']``, gsc_et.py:572-573; every
 consumer only sums over datapoints), and the per-datapoint (N,H,H) moments ``xpt_ss`` / ``xpt_szsz``
 are handed over as ``SummedMoments`` (their sum over datapoints), never materialised.
-``sigma_sq_type`` 'diagonal' / 'full' are not on the GPU path yet and raise.
+``sigma_sq_type`` 'diagonal' / 'full' run through the same kernel on Sigma^-1-weighted scores, Gram matrix
+and norms (the kernel then sees sigma^2 = 1).
 """
 import ctypes
 
@@ -146,8 +147,8 @@ class GSC(DeviceCAModel):
 
     # ------------------------------------------------------------------ device tables
     def _require_scalar(self):
-        if self.sigma_sq_type != 'scalar':
-            raise _lib.HipError("GSC on the GPU covers sigma_sq_type='scalar'; %r is not built yet" % self.sigma_sq_type)
+        if self.sigma_sq_type not in ('scalar', 'diagonal', 'full'):
+            raise _lib.HipError("GSC: unknown sigma_sq_type %r" % (self.sigma_sq_type,))
         if not _lib.load().pm_gsc_supported(self.H, self.Hprime, self.gamma):
             raise _lib.HipError("GSC kernel range: H <= 512, gamma <= 4 (got H=%d Hprime=%d gamma=%d)"
                                 % (self.H, self.Hprime, self.gamma))
@@ -161,28 +162,61 @@ class GSC(DeviceCAModel):
         return self._masks_dev[1]
 
     def _tables_for(self, model_params, res):
+        """Per-step device tables.  A diagonal / full noise covariance Sigma turns every inner product into a
+        Sigma^-1-weighted one (gsc_et.py:321-346, 414-425): the scores GEMM runs against Sigma^-1 W, the Gram
+        matrix is W^T Sigma^-1 W, |y|^2 becomes y^T Sigma^-1 y, and the kernel sees sigma^2 = 1."""
         W = np.asarray(model_params['W'], dtype=np.float64)
         mu = np.asarray(model_params['mu'], dtype=np.float64)
         psi = np.asarray(model_params['psi_sq'], dtype=np.float64)
         pi = np.asarray(model_params['pi'], dtype=np.float64)
-        s2 = float(model_params['sigma_sq'])
+        sig = np.asarray(model_params['sigma_sq'], dtype=np.float64)
         par = self._par
         same = (par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape
                 and np.array_equal(par["W"], W) and np.array_equal(par["mu"], mu) and np.array_equal(par["psi"], psi)
-                and np.array_equal(par["pi"], pi) and par["s2"] == s2)
+                and np.array_equal(par["pi"], pi) and par["sig"].shape == sig.shape and np.array_equal(par["sig"], sig))
         if same:
             return par
-        Gd = (W * W).sum(axis=0)
+        Y = res["Y"]
+        N, D = Y.shape
+        Wt = self._upload("gsc_W", W).t().contiguous()          # (H, D): rows = latents
+        if sig.ndim == 0:
+            s2, Wst, Gd, yn = float(sig), Wt, (W * W).sum(axis=0), res["ynorm2"]
+            G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
+        else:
+            s2 = 1.0
+            if sig.ndim == 1:
+                assert sig.shape == (D,)
+                sinv = 1. / sig
+                Ws = W * sinv[:, None]
+                yn = torch.empty(N, dtype=torch.float64, device=self.device)
+                if N:
+                    self._call("row_wsqnorm", "pm_row_wsqnorm_f64", _ptr(Y), Y.stride(0), N, D,
+                               _ptr(self._upload("gsc_sinv", sinv)), _ptr(yn), self._stream())
+            else:
+                assert sig.shape == (D, D)
+                with small_blas():
+                    Sinv = np.linalg.inv(sig)
+                    Sinv = 0.5 * (Sinv + Sinv.T)
+                    C = np.linalg.cholesky(Sinv)                # Sinv = C C^T  ->  y^T Sinv y = |C^T y|^2
+                    Ws = Sinv @ W
+                yn = torch.empty(N, dtype=torch.float64, device=self.device)
+                if N:
+                    Ct = self._upload("gsc_chol", np.ascontiguousarray(C.T))
+                    Z = self._gemm_nt(Y, Ct, self._buf("gsc_white", (N, D)), "whiten_gemm")
+                    self._call("row_sqnorm", "pm_row_sqnorm_f64", _ptr(Z), D, N, D, _ptr(yn), self._stream())
+            Gd = (Ws * W).sum(axis=0)
+            Wst = self._upload("gsc_Ws", Ws).t().contiguous()
+            G = self._gemm_nt(Wst, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
+            G.copy_(0.5 * (G + G.t()))                           # symmetric up to rounding; the kernel reads both halves
         psid = np.diag(psi)
         lam = Gd / s2 + 1. / psid
         with np.errstate(divide='ignore', invalid='ignore'):
             c0 = -(np.log(psid) + np.log(lam)) - mu * mu * Gd / s2
             lpi = np.log(pi) - np.log(1 - pi)
         tables = np.stack([c0, 2. * mu / s2, Gd * mu, 1. / (lam * s2 * s2), 1. / (lam * s2), 1. / lam, mu, lpi])
-        Wt = self._upload("gsc_W", W).t().contiguous()          # (H, D): rows = latents
-        G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
-        self._par = {"ykey": res["key"], "W": W.copy(), "mu": mu.copy(), "psi": psi.copy(), "pi": pi.copy(), "s2": s2,
-                     "Wt": Wt, "G": G, "psi_d": self._upload("gsc_psi", psi), "tables": self._upload("gsc_tab", tables)}
+        self._par = {"ykey": res["key"], "W": W.copy(), "mu": mu.copy(), "psi": psi.copy(), "pi": pi.copy(),
+                     "sig": sig.copy(), "s2": s2, "Wt": Wt, "Wst": Wst, "G": G, "yn": yn,
+                     "psi_d": self._upload("gsc_psi", psi), "tables": self._upload("gsc_tab", tables)}
         return self._par
 
     # ------------------------------------------------------------------ hot path
@@ -204,8 +238,8 @@ class GSC(DeviceCAModel):
         else:
             cand, do_select = cand_in, 0
         if N:
-            A = self._gemm_nt(Y, par["Wt"], self._buf("scores", (N, H)), "scores_gemm")
-            self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(par["G"]), _ptr(par["psi_d"]), _ptr(res["ynorm2"]),
+            A = self._gemm_nt(Y, par["Wst"], self._buf("scores", (N, H)), "scores_gemm")
+            self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(par["G"]), _ptr(par["psi_d"]), _ptr(par["yn"]),
                        _ptr(par["tables"]), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
                        ctypes.c_double(par["s2"]), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), H,
                        _ptr(stats), self._stream())
@@ -295,6 +329,7 @@ class GSC(DeviceCAModel):
         packed[o2 + H:o2 + 2 * H] = xsz.sum(dim=0)
         packed[o2 + 2 * H] = res["ynorm2"].sum()
         comm.allreduce_device(packed)      # replaces gsc_et.py:608-610,620,668,671,713
+        data_sq = self._data_second_moment(res) if 'sigma_sq' in self.to_learn else None
         host = self._download(packed) if packed.is_cuda else packed.numpy()
         Wp = host[:nWp].reshape(D, H)
         xs_xsz = host[nWp:nWp + nHH].reshape(H, H)
@@ -306,9 +341,34 @@ class GSC(DeviceCAModel):
 
         with small_blas():
             return self._update(model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss,
-                                sum_xpt_szsz, sum_yy)
+                                sum_xpt_szsz, sum_yy, data_sq)
 
-    def _update(self, model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss, sum_xpt_szsz, sum_yy):
+    def _data_second_moment(self, res):
+        """sum_n y_n^2 per dimension (diagonal) / sum_n y_n y_n^T (full) over ALL ranks -- constants of the
+        data set (gsc_et.py:681, 694), computed once per resident shard."""
+        if self.sigma_sq_type == 'scalar':
+            return None
+        key = "data_sq_" + self.sigma_sq_type
+        if res.get(key) is None:
+            Y = res["Y"]
+            N, D = Y.shape
+            if self.sigma_sq_type == 'diagonal':
+                acc = torch.zeros(D, dtype=torch.float64, device=self.device)
+                zero = torch.zeros(D, dtype=torch.float64, device=self.device)
+                if N:
+                    self._call("col_moments", "pm_col_moments_f64", _ptr(Y), Y.stride(0), N, D, _ptr(zero), _ptr(acc),
+                               self._stream())
+            else:
+                acc = torch.zeros((D, D), dtype=torch.float64, device=self.device)
+                if N:
+                    self._call("data_gram", "pm_gemm_tn_acc_f64", _ptr(Y), Y.stride(0), _ptr(Y), Y.stride(0), _ptr(acc), D,
+                               D, D, N, self._stream())
+            self.comm.allreduce_device(acc)
+            res[key] = acc.cpu().numpy()
+        return res[key]
+
+    def _update(self, model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss, sum_xpt_szsz, sum_yy,
+                data_sq=None):
         """The H x H parameter algebra of gsc_et.py:624-716 on the host."""
         D, eps = self.D, 1e-5
         try:
@@ -335,9 +395,12 @@ class GSC(DeviceCAModel):
             psi_sq = np.outer(mu, mu) * sum_xpt_ss + sum_xpt_szsz - 2 * (mu[:, None] * xs_xsz)
             model_params['psi_sq'] = (psi_sq * np.linalg.inv(sum_xpt_ss + eps * np.eye(self.H))) + (eps * np.eye(self.H))
         if 'sigma_sq' in self.to_learn:
-            if self.sigma_sq_type != 'scalar':
-                raise _lib.HipError("sigma_sq_type %r is not built yet" % self.sigma_sq_type)
-            WT_outer = np.dot(W_n.T, W_n)
-            my_sigma_sq = sum_yy - np.trace(np.dot(xsz_xsz, WT_outer))
-            model_params['sigma_sq'] = (my_sigma_sq / N / D) + eps
+            if self.sigma_sq_type == 'full':            # gsc_et.py:677-688
+                model_params['sigma_sq'] = (data_sq - W_n @ xsz_xsz @ W_n.T) / N + (eps * np.eye(self.D))
+            elif self.sigma_sq_type == 'diagonal':      # gsc_et.py:690-701
+                model_params['sigma_sq'] = (data_sq - ((W_n @ xsz_xsz) * W_n).sum(axis=1)) / N + eps
+            else:                                       # gsc_et.py:703-713
+                WT_outer = np.dot(W_n.T, W_n)
+                my_sigma_sq = sum_yy - np.trace(np.dot(xsz_xsz, WT_outer))
+                model_params['sigma_sq'] = (my_sigma_sq / N / D) + eps
         return model_params

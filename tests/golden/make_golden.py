@@ -51,7 +51,7 @@ class Capture(DataHandler):
 dlog.set_handler(("L", "N", "N_use", "prior_mass"), Capture)
 
 
-def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False):
+def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False, sigma_type="scalar"):
     """select_Hprimes -> E_step -> M_step (+ compute_lpj) of GSC with scalar sigma_sq.  The reference
     returns its statistics in candidate-bucket order; they are mapped back to datapoint order here."""
     rng = np.random.RandomState(seed)
@@ -68,8 +68,13 @@ def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False):
         psi0 = psi0 + Q @ Q.T
     params = {"W": W_gt + 0.2 * rng.normal(size=(D, H)), "pi": np.clip(pi_gt * rng.uniform(0.7, 1.4, size=H), 0.02, 0.9),
               "mu": mu_gt + 0.2 * rng.normal(size=H), "psi_sq": psi0, "sigma_sq": 1.3}
+    if sigma_type == "diagonal":
+        params["sigma_sq"] = rng.uniform(0.8, 1.8, size=D)
+    elif sigma_type == "full":
+        Qs = 0.15 * rng.normal(size=(D, D))
+        params["sigma_sq"] = np.diag(rng.uniform(0.8, 1.8, size=D)) + Qs @ Qs.T
     inp = {k: np.array(v, copy=True) for k, v in params.items()}
-    model = GSC(D, H, Hp, gamma, "scalar")
+    model = GSC(D, H, Hp, gamma, sigma_type)
     anneal = FixedAnneal(T=T)
     logpj, cands = model.compute_lpj(anneal, {k: np.array(v, copy=True) for k, v in inp.items()}, {"y": y.copy()})
     data = model.select_Hprimes(params, {"y": y.copy()})
@@ -78,7 +83,8 @@ def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False):
     assert np.array_equal(data["y"], y[order])
     inv = np.argsort(order)
     new = model.M_step(anneal, params, suff, data)
-    out = dict(D=D, H=H, Hprime=model.Hprime, gamma=model.gamma, T=T, y=y, candidates=cands.astype(np.int64),
+    out = dict(D=D, H=H, Hprime=model.Hprime, gamma=model.gamma, T=T, y=y, sigma_type=sigma_type,
+               candidates=cands.astype(np.int64),
                logpj=logpj, xpt_s=suff["xpt_s"][inv], xpt_sz=suff["xpt_sz"][inv],
                sum_xpt_ss=suff["xpt_ss"].sum(axis=0), sum_xpt_szsz=suff["xpt_szsz"].sum(axis=0),
                state_matrix=model.state_matrix)
@@ -88,8 +94,9 @@ def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False):
         out[k + "_new"] = np.asarray(new[k])
     assert all(np.isfinite(out[k + "_new"]).all() for k in ("W", "pi", "mu", "psi_sq", "sigma_sq")), name
     np.savez_compressed(os.path.join(HERE, "gsc_step_%s.npz" % name), **out)
-    print("gsc_step_%s: N=%d K=%d clusters=%d sigma_sq_new=%.6f" % (name, N, logpj.shape[1], len(data["data_clusters"]),
-                                                                   float(new["sigma_sq"])))
+    s2n = np.asarray(new["sigma_sq"])
+    print("gsc_step_%s: N=%d K=%d clusters=%d mean sigma_sq_new=%.6f" % (
+        name, N, logpj.shape[1], len(data["data_clusters"]), float(np.diag(s2n).mean() if s2n.ndim == 2 else s2n.mean())))
 
 
 def bsc_inference_case():
@@ -346,6 +353,10 @@ def main(only=None):
     gsc_step_case("h24", 40, 24, 5, 3, 120, seed=33, T=1.0, full_psi=True)
     gsc_step_case("g4", 30, 12, 5, 4, 100, seed=34, T=1.2)
     gsc_step_case("h128", 64, 128, 6, 3, 64, seed=35, T=1.0)
+    gsc_step_case("diag", 16, 8, 4, 3, 200, seed=36, T=1.0, sigma_type="diagonal")
+    gsc_step_case("diag_T", 40, 24, 5, 3, 120, seed=37, T=1.4, full_psi=True, sigma_type="diagonal")
+    gsc_step_case("full", 16, 8, 4, 3, 200, seed=38, T=1.0, sigma_type="full")
+    gsc_step_case("full_T", 40, 24, 5, 3, 120, seed=39, T=1.3, full_psi=True, sigma_type="full")
     mca_step_case("small", 16, 8, 4, 3, 300, seed=21, T=1.0, Ncut=0.0)
     mca_step_case("small_cut", 16, 8, 4, 3, 257, seed=22, T=1.4, Ncut=0.5)
     mca_step_case("bars", 25, 10, 5, 3, 300, seed=23, T=1.0, Ncut=1.0, bars=True)

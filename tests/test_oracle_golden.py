@@ -209,7 +209,9 @@ def _gsc_cases():
 
 
 def _gsc_params(g):
-    return {"W": g["W"], "pi": g["pi"], "mu": g["mu"], "psi_sq": g["psi_sq"], "sigma_sq": float(g["sigma_sq"])}
+    sig = g["sigma_sq"]
+    return {"W": g["W"], "pi": g["pi"], "mu": g["mu"], "psi_sq": g["psi_sq"],
+            "sigma_sq": float(sig) if sig.ndim == 0 else sig}
 
 
 @pytest.mark.parametrize("case", _gsc_cases())
