@@ -81,13 +81,17 @@ class DSC_ET(DeviceCAModel):
                 continue
             ss = np.concatenate((ss, np.eye(self.H, dtype=np.int8) * states[i]))
         self.single_state_matrix = ss[np.sum(np.abs(np.sign(ss)), 1) == 1]
+        self._build_state_tables()
+        self._tab = None
+
+    def _build_state_tables(self):
+        """state_matrix / no_states / state_abs (K, S) for the current Hprime, gamma (dsc_et.py:177-191)."""
         self.state_matrix = get_states(self.states, self.Hprime, self.gamma)
         self.no_states = self.state_matrix.shape[0]
         self.state_abs = np.empty((self.K, self.no_states))
         for i in range(self.K):
             self.state_abs[i, :] = (self.state_matrix == self.states[i]).sum(axis=1)
         self.state_abs[self._K_0, :] = self.H - self.state_abs.sum(0) + self.state_abs[self._K_0, :]
-        self._tab = None
 
     # ------------------------------------------------------------------ reference-shaped helpers
     def check_params(self, model_params):
@@ -417,10 +421,104 @@ class DSC_ET(DeviceCAModel):
         dlog.append('N_use', N_use)
         return {'W': W_out, 'pi': pi_new, 'sigma': sigma_new, 'Q': 0.}
 
-    def inference(self, *args, **kwargs):
-        """DSC's own top-K inference (dsc_et.py:927-1059) is not built yet; the base-class version assumes
-        binary states and would be wrong here."""
-        raise NotImplementedError("DSC_ET.inference is not available in this build")
+    def inference(self, anneal, model_params, test_data, topK=10, logprob=False, adaptive=True,
+                  Hprime_max=None, gamma_max=None):
+        """Top-K posterior states and marginals per datapoint (dsc_et.py:927-1059); same return dict
+        (``s`` (N,topK,H) int8 with the latent VALUES, ``m`` (N,H), ``p`` (N,topK), ``gamma``, ``Hprime``).
+
+        Upstream behaviour that is reproduced as it is: ``p`` without ``logprob`` is exp(logpj - max);
+        re-run datapoints keep earlier entries of ``s``; the marginal of a candidate combines its FIRST
+        non-zero value's singleton state with the multi-cause states in which it takes the value 1
+        (:1010-1016); and in the adaptive re-runs ``state_abs`` is the 1-D count of non-zeros
+        (``generate_state_matrix``, :1048), so every multi-cause state gets the same prior there.  Unlike
+        upstream the proper (K, S) ``state_abs`` is restored afterwards (upstream leaves the 1-D one behind)."""
+        assert 'y' in test_data, "Key 'y' in test_data dict not defined."
+        model_params = self.check_params(model_params)
+        comm = self.comm
+        my_y = test_data['y']
+        if isinstance(my_y, DeviceArray):
+            my_y = my_y.tensor
+        my_N, D = my_y.shape
+        H, K = self.H, self.K
+        nss = (K - 1) * H
+        Hprime_start, gamma_start = self.Hprime, self.gamma
+        if topK == -1:
+            topK = self.state_matrix.shape[0]
+        dev = self.device
+        res_s = torch.zeros((my_N, topK, H), dtype=torch.int8, device=dev)
+        res_m = torch.zeros((my_N, H), dtype=torch.float64, device=dev)
+        res_p = torch.zeros((my_N, topK), dtype=torch.float64, device=dev)
+        res_gamma = torch.zeros((my_N,), dtype=torch.float64, device=dev)
+        res_Hprime = torch.zeros((my_N,), dtype=torch.float64, device=dev)
+        nz_vals = torch.tensor([self.states[k] for k in range(K) if k != self._K_0], dtype=torch.int8, device=dev)
+
+        cur_y = my_y
+        which = torch.ones(my_N, dtype=torch.bool, device=dev)
+        try:
+            while bool(which.any()):
+                ind_n = torch.nonzero(which).flatten()
+                logpj, cand = self.compute_lpj(anneal, model_params, {'y': cur_y})
+                lp = logpj.tensor if isinstance(logpj, DeviceArray) else torch.as_tensor(np.asarray(logpj)).to(dev)
+                cd = (cand.tensor if isinstance(cand, DeviceArray) else torch.as_tensor(np.asarray(cand)).to(dev)).long()
+                n_cur, Kt = lp.shape
+                Hp = self.Hprime
+                rel = lp - lp.max(dim=1, keepdim=True).values
+                lpc = rel - torch.log(torch.exp(rel).sum(dim=1, keepdim=True))      # as :983-987
+                k_eff = min(topK, Kt)
+                top_val, top_idx = torch.topk(lpc, k_eff, dim=1, largest=True, sorted=True)
+                res_Hprime[ind_n] = float(self.Hprime)
+                res_gamma[ind_n] = float(self.gamma)
+                SM = torch.from_numpy(self.state_matrix.astype(np.int8)).to(dev) if self.no_states else \
+                    torch.zeros((1, Hp), dtype=torch.int8, device=dev)
+                s_blk = res_s[ind_n, :k_eff].clone()
+                single = (top_idx >= 1) & (top_idx <= nss)
+                if bool(single.any()):
+                    nn_, mm_ = torch.nonzero(single, as_tuple=True)
+                    si = top_idx[nn_, mm_] - 1
+                    s_blk[nn_, mm_, si % H] = nz_vals[si // H]
+                multi = top_idx > nss
+                if bool(multi.any()):
+                    nn_, mm_ = torch.nonzero(multi, as_tuple=True)
+                    rows = SM[top_idx[nn_, mm_] - nss - 1]                           # (M, Hp) latent values
+                    s_blk[nn_[:, None].expand(-1, Hp), mm_[:, None].expand(-1, Hp), cd[nn_]] = rows
+                res_s[ind_n, :k_eff] = s_blk
+                res_p[ind_n, :k_eff] = top_val if logprob else torch.exp(torch.gather(rel, 1, top_idx))
+                # marginals (:1010-1016)
+                m_blk = lpc[:, 1:H + 1].clone()
+                if self.no_states:
+                    multi_lp = lpc[:, nss + 1:]
+                    is_one = (SM == 1)
+                    rows_n = torch.arange(n_cur, device=dev)
+                    for j in range(Hp):
+                        lj = torch.logsumexp(torch.where(is_one[:, j][None, :], multi_lp,
+                                                         torch.full_like(multi_lp, float("-inf"))), dim=1)
+                        hj = cd[:, j]
+                        m_blk[rows_n, hj] = torch.logaddexp(lpc[rows_n, 1 + hj], lj)
+                res_m[ind_n] = m_blk
+                if not adaptive:
+                    break
+                which = ((res_s[:, 0, :] != 0).sum(-1) == self.gamma)
+                if not bool(which.any()):
+                    break
+                if (Hprime_max is not None and self.Hprime == Hprime_max) and \
+                        (gamma_max is not None and self.gamma == gamma_max):
+                    break
+                cur_y = my_y[which.cpu().numpy()] if not torch.is_tensor(my_y) else my_y[which]
+                print("Rank %i: For %i data points MAP state has activity equal to gamma." % (comm.rank, int(which.sum())))
+                if not ((self.Hprime == self.H) or (Hprime_max is not None and self.Hprime == Hprime_max)):
+                    self.Hprime += 1
+                if (self.gamma == self.H) or (gamma_max is not None and self.gamma == gamma_max):
+                    continue
+                self.gamma += 1
+                print("Rank %i: Updating state matrix and running again." % comm.rank)
+                self.no_states, self.state_matrix, self.state_abs = generate_state_matrix(self.Hprime, self.gamma,
+                                                                                           self.states)
+        finally:
+            self.Hprime, self.gamma = Hprime_start, gamma_start
+            self._build_state_tables()
+        m_out = res_m if logprob else torch.exp(res_m)
+        return {'s': res_s.cpu().numpy(), 'm': m_out.cpu().numpy(), 'p': res_p.cpu().numpy(),
+                'gamma': res_gamma.cpu().numpy(), 'Hprime': res_Hprime.cpu().numpy()}
 
     def calculate_respons(self, anneal, model_params, data):
         """Posterior over the truncated states (dsc_et.py:776-784)."""

@@ -221,6 +221,33 @@ def dsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior, states,
                                                       Capture.rows["N_use"][0]))
 
 
+def dsc_inference_case():
+    """DSC_ET.inference (dsc_et.py:927-1059): top-K states, marginals, adaptive H'/gamma -- including what the
+    adaptive rounds really compute (the regenerated ``state_abs`` is 1-D there, dsc_et.py:1048)."""
+    import io, contextlib, warnings
+    warnings.simplefilter("ignore")
+    D, H, Hp, gamma, N = 20, 9, 4, 2, 50
+    rng = np.random.RandomState(71)
+    states = np.array([-1., 0., 1.])
+    pi = np.array([0.12, 0.76, 0.12])
+    W = rng.normal(size=(D, H)) * 3.0
+    s = rng.choice(states, size=(N, H), p=pi)
+    y = s @ W.T + rng.normal(size=(N, D))
+    params = {"W": W + 0.2 * rng.normal(size=(D, H)), "pi": pi, "sigma": 1.1}
+    anneal = FixedAnneal(T=1.0)
+    out = {}
+    for tag, kw in (("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
+                    ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True))):
+        model = DSC_ET(D, H, Hp, gamma, states=states)          # fresh: inference leaves state_abs 1-D behind
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = model.inference(anneal, {k: np.array(v, copy=True) for k, v in params.items()}, {"y": y.copy()}, **kw)
+        for k, v in res.items():
+            out["%s_%s" % (tag, k)] = v
+    np.savez_compressed(os.path.join(HERE, "dsc_inference.npz"), D=D, H=H, Hprime=Hp, gamma=gamma, y=y, states=states,
+                        W=params["W"], pi=pi, sigma=params["sigma"], **out)
+    print("dsc_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
+
+
 class FixedAnneal(dict):
     """One annealing position; unknown keys -> 0.0 like LinearAnnealing.__getitem__."""
     crit_params = []
@@ -333,7 +360,7 @@ def main(only=None):
     """``only``: regenerate just the fixtures whose name starts with this prefix (e.g. ``mmca``)."""
     want = lambda fn: only is None or fn.__name__.startswith(only)
     g = globals()
-    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "bsc_inference_case",
+    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "bsc_inference_case",
                "bsc_trajectory", "bsc_init", "anneal_tracks"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
@@ -363,6 +390,7 @@ def main(only=None):
     mca_step_case("h40", 48, 40, 6, 3, 150, seed=24, T=2.0, Ncut=0.7)
     mca_step_case("h128", 64, 128, 8, 3, 96, seed=25, T=1.0, Ncut=0.0)
     bsc_inference_case()
+    dsc_inference_case()
     bsc_trajectory()
     bsc_init()
     anneal_tracks()

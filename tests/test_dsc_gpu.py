@@ -144,3 +144,22 @@ def test_dsc_em_recovers_parameters():
     assert L[-1] > L[0] and all(b > a - 1e-9 for a, b in zip(L[5:], L[6:]))
     assert p["sigma"] < 1.9 and np.isfinite(p["W"]).all()
     np.testing.assert_allclose(p["pi"], [0.1, 0.8, 0.1], atol=0.05)
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
+                                    ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True))])
+def test_dsc_inference_matches_reference(tag, kw, capsys):
+    """DSC_ET.inference (dsc_et.py:927-1059) against the reference's golden outputs, adaptive re-runs
+    (with their 1-D state_abs prior) included."""
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    g = golden("dsc_inference.npz")
+    D, H, Hp, gamma = int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"])
+    m = DSC_ET(D, H, Hp, gamma, states=g["states"])
+    S0, abs0 = m.no_states, m.state_abs.copy()
+    res = m.inference(_An(T=1.0), {"W": g["W"].copy(), "pi": g["pi"].copy(), "sigma": float(g["sigma"])},
+                      {"y": g["y"]}, **kw)
+    assert (m.Hprime, m.gamma, m.no_states) == (Hp, gamma, S0) and np.array_equal(m.state_abs, abs0)
+    assert np.array_equal(res["gamma"], g[tag + "_gamma"]) and np.array_equal(res["Hprime"], g[tag + "_Hprime"])
+    assert res["s"].dtype == np.int8 and np.array_equal(res["s"], g[tag + "_s"])
+    np.testing.assert_allclose(res["p"], g[tag + "_p"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(res["m"], g[tag + "_m"], rtol=1e-8, atol=1e-12)
