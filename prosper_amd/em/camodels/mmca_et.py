@@ -15,7 +15,6 @@ import numpy as np
 
 from ._device import DeviceArray, _ptr
 from .mca_et import MCA_ET
-from ... import _lib
 from ...utils import parallel
 from ...utils import tracing
 from ...utils.datalog import dlog
