@@ -77,6 +77,19 @@ class StoreToNpz(StoreInMemory):
         np.savez(self.destination, **{k: np.stack(v) for k, v in self.tables.items()})
 
 
+def resume_params(destination, names=None):
+    """Last logged row of every table of a ``StoreToNpz`` file as a parameter dict -- the ``lparams`` to
+    hand to ``EM`` to continue a run (stand-in for reading ``result.h5``, autotable.py:234-278: PyTables and
+    h5py are not in the image).  ``names`` restricts the keys (e.g. ``('W', 'pi', 'sigma')``)."""
+    with np.load(destination if str(destination).endswith(".npz") else str(destination) + ".npz") as f:
+        keys = [k for k in f.files if names is None or k in names]
+        out = {}
+        for k in keys:
+            last = f[k][-1]
+            out[k] = last.item() if last.ndim == 0 else np.array(last)
+    return out
+
+
 class DataLog(object):
     def __init__(self, comm=COMM_WORLD):
         self.comm = comm

@@ -155,3 +155,21 @@ def test_standard_init_and_generate_data_rng_stream():
     np.testing.assert_allclose(init["W"], g["W0"], rtol=1e-13)
     np.testing.assert_allclose(init["sigma"], g["sigma0"], rtol=1e-13)
     assert init["pi"] == float(g["pi0"])
+
+
+def test_store_to_npz_and_resume(tmp_path):
+    """StoreToNpz rows + resume_params: the npz stand-in for result.h5 (one array per logged name, one row
+    per EM step) and reading the last row back as lparams."""
+    from prosper_amd.utils.datalog import DataLog, StoreToNpz, resume_params
+    log = DataLog()
+    dest = str(tmp_path / "result")
+    log.set_handler(("W", "pi", "sigma", "L"), StoreToNpz, dest)
+    for step in range(3):
+        log.append_all({"W": np.full((4, 2), float(step)), "pi": 0.1 * (step + 1), "sigma": 1.0 + step})
+        log.append("L", -10.0 + step)
+    log.close()
+    f = np.load(dest + ".npz")
+    assert f["W"].shape == (3, 4, 2) and f["L"].tolist() == [-10.0, -9.0, -8.0]
+    p = resume_params(dest, names=("W", "pi", "sigma"))
+    assert sorted(p) == ["W", "pi", "sigma"] and p["sigma"] == 3.0 and abs(p["pi"] - 0.3) < 1e-15
+    assert np.array_equal(p["W"], np.full((4, 2), 2.0))
