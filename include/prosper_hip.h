@@ -250,7 +250,24 @@ typedef struct pm_dsc_params {
     double pre1;                     /* -1 / (2 sigma^2) (selection only)                         */
     double ecoef;                    /* beta * pre1: logpj = ecoef * e + pscale * prior           */
     double pscale;                   /* beta if anneal['anneal_prior'] else 1 (dsc_et.py:579-584)  */
+    int32_t flags;                   /* PM_DSC_TABLE_ONLY | PM_DSC_LAST_POSITION (Ternary Sparse Coding) */
+    int32_t reserved;
 } pm_dsc_params;
+
+/* Ternary Sparse Coding (prosper/em/camodels/tsc_et.py) runs on the DSC kernels with two flags:
+ * PM_DSC_TABLE_ONLY     logpj has one column per row of the state table and nothing else (tsc_et.py:340-349:
+ *                       the table holds the null and one-cause states too; no global singleton block);
+ * PM_DSC_LAST_POSITION  a latent that occurs twice among a datapoint's candidates contributes to Wp / Wq
+ *                       only through its LAST position, as NumPy's fancy-index `+=` does (tsc_et.py:471-475). */
+#define PM_DSC_TABLE_ONLY 1
+#define PM_DSC_LAST_POSITION 2
+
+/* select_Hprimes of TSC, tsc_et.py:142-213: R (N, 2H) = minus the squared distance of every one-cause
+ * state up to |y|^2 -- R[n,h] = -(G_hh + 2 scores[n,h]) (value -1), R[n,H+h] = -(G_hh - 2 scores[n,h])
+ * (value +1).  The candidates are the latents (index mod H) of the Hprime largest entries, best last:
+ * pm_bsc_select_estep_f64(mode = 1|8) on R with 2H columns. */
+int pm_tsc_select_scores_f64(const double *scores, int64_t lds, const double *gram, int64_t N, int64_t H,
+                             double *R, int64_t ldr, void *stream);
 
 /* select_Hprimes, dsc_et.py:347-410: R[n,h] = -max_{k != K0} (pre1 (v_k^2 G_hh - 2 v_k scores[n,h]) + log pi_k),
  * the negated best singleton log-joint of latent h up to per-datapoint constants.  The candidates are

@@ -22,7 +22,8 @@ class McaParams(C.Structure):
 class DscParams(C.Structure):
     """struct pm_dsc_params"""
     _fields_ = [("K", C.c_int32), ("K0", C.c_int32), ("values", C.c_double * 8), ("logpi", C.c_double * 8),
-                ("pre1", C.c_double), ("ecoef", C.c_double), ("pscale", C.c_double)]
+                ("pre1", C.c_double), ("ecoef", C.c_double), ("pscale", C.c_double),
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class EStepParams(C.Structure):
@@ -67,6 +68,7 @@ SIGNATURES = {
                                           C.POINTER(McaParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp,
                                           c_dp, i64, c_dp, c_dp]),
     "pm_dsc_select_scores_f64": (C.c_int, [c_dp, i64, c_dp, C.POINTER(DscParams), i64, i64, c_dp, i64, c_dp]),
+    "pm_tsc_select_scores_f64": (C.c_int, [c_dp, i64, c_dp, i64, i64, c_dp, i64, c_dp]),
     "pm_dsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp, C.POINTER(DscParams), i64, i64, i64,
                                    c_dp, i64, c_dp, c_dp]),
     "pm_dsc_stats_len": (i64, [i64, i64]),

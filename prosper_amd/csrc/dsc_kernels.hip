@@ -51,6 +51,20 @@ __global__ __launch_bounds__(256) void dsc_select_scores_kernel(const double *__
     }
 }
 
+__global__ __launch_bounds__(256) void tsc_select_scores_kernel(const double *__restrict__ scores, int64_t lds,
+                                                                 const double *__restrict__ gram, int64_t N, int H,
+                                                                 double *__restrict__ R, int64_t ldr) {
+    const int64_t total = N * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / H;
+        const int h = (int)(i - n * H);
+        const double a2 = 2.0 * scores[n * lds + h];
+        const double w2 = gram[(int64_t)h * H + h];
+        R[n * ldr + h] = -(w2 + a2);
+        R[n * ldr + H + h] = -(w2 - a2);
+    }
+}
+
 // energy of multi-cause state `row` (H' value indices) from the candidate block in LDS
 __device__ __forceinline__ double state_energy(const uint8_t *row, int Hp, const pm_dsc_params &P,
                                                const double *s_a, const double *s_G, double yn) {
@@ -85,6 +99,8 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
     __syncthreads();
 
     const int nss = (P.K - 1) * H;
+    const bool tab = P.flags & PM_DSC_TABLE_ONLY;        // TSC: columns = rows of the state table, nothing else
+    const int base = tab ? 0 : 1 + nss;
     for (int64_t n = (int64_t)blockIdx.x * WAVES + wave; n < N; n += (int64_t)gridDim.x * WAVES) {
         const double *arow = scores + n * lds;
         const int32_t *cn = cand + n * Hp;
@@ -95,14 +111,14 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
 
         double *out = logpj + n * ldl;
         double m = -INFINITY;
-        if (lane == 0) {
+        if (!tab && lane == 0) {
             const double f0 = P.ecoef * yn + P.pscale * prior[0];
             out[0] = f0;
             m = f0;
         }
         // singletons: column 1 + c*H + h for the c-th non-zero value (dsc_et.py:566-568)
         int c = 0;
-        for (int k = 0; k < P.K; ++k) {
+        for (int k = 0; k < P.K && !tab; ++k) {
             if (k == P.K0) continue;
             const double v = P.values[k];
             for (int h = lane; h < H; h += 64) {
@@ -115,21 +131,21 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
         }
         for (int s = lane; s < S; s += 64) {
             const double e = state_energy(s_tab + s * Hp, Hp, P, s_a, s_G, yn);
-            const double f = P.ecoef * e + P.pscale * prior[1 + nss + s];
-            out[1 + nss + s] = f;
+            const double f = P.ecoef * e + P.pscale * prior[base + s];
+            out[base + s] = f;
             m = fmax(m, f);
         }
         m = pm_wave_max(m);
         // second pass over this lane's own stores
         double sum = 0.0;
-        if (lane == 0) sum += exp(out[0] - m);
+        if (!tab && lane == 0) sum += exp(out[0] - m);
         c = 0;
-        for (int k = 0; k < P.K; ++k) {
+        for (int k = 0; k < P.K && !tab; ++k) {
             if (k == P.K0) continue;
             for (int h = lane; h < H; h += 64) sum += exp(out[1 + c * H + h] - m);
             ++c;
         }
-        for (int s = lane; s < S; s += 64) sum += exp(out[1 + nss + s] - m);
+        for (int s = lane; s < S; s += 64) sum += exp(out[base + s] - m);
         sum = pm_wave_sum(sum);
         if (lane == 0) lse[n] = m + log(sum);
         wave_sync_lds_dsc();
@@ -157,6 +173,8 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
     __syncthreads();
 
     const int nss = (P.K - 1) * H;
+    const bool tab = P.flags & PM_DSC_TABLE_ONLY;
+    const int base = tab ? 0 : 1 + nss;
     const double inv_ecoef = 1.0 / P.ecoef;
     const double qcut = -60.0;     // multi-cause weights below e^-60 of the evidence add nothing in f64
     double sig = 0.0, fs = 0.0, kept = 0.0;
@@ -175,9 +193,16 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
         const int32_t *cn = cand + n * Hp;
         if (lane < Hp) s_m[lane] = 0.0;
         for (int p = lane; p < Hp * Hp; p += 64) s_B[p] = 0.0;
+        // positions that are the last occurrence of their latent (all of them unless candidates repeat)
+        bool mine_last = lane < Hp;
+        for (int k = lane + 1; k < Hp && lane < Hp; ++k) mine_last = mine_last && (cn[k] != cn[lane]);
+        const unsigned long long lastmask =
+            (P.flags & PM_DSC_LAST_POSITION) ? __ballot(mine_last) : ((1ull << Hp) - 1ull);
         if (lane == 0) {
-            const double f0 = f[0];
-            sig += exp(f0 - l) * ((f0 - P.pscale * prior[0]) * inv_ecoef);
+            if (!tab) {
+                const double f0 = f[0];
+                sig += exp(f0 - l) * ((f0 - P.pscale * prior[0]) * inv_ecoef);
+            }
             fs += l;
             kept += 1.0;
         }
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
             int c = 0;
 #pragma unroll
             for (int k = 0; k < PM_DSC_MAX_K; ++k) {
-                if (k >= P.K || k == P.K0) continue;
+                if (tab || k >= P.K || k == P.K0) continue;
                 const double fh = f[1 + c * H + h];
                 const double q = exp(fh - l);
                 const double v = P.values[k];
@@ -201,11 +226,11 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
         }
         wave_sync_lds_dsc();
         for (int s = lane; s < S; s += 64) {
-            const double fsv = f[1 + nss + s];
+            const double fsv = f[base + s];
             const double dl = fsv - l;
             if (!(dl > qcut)) continue;
             const double q = exp(dl);
-            sig += q * ((fsv - P.pscale * prior[1 + nss + s]) * inv_ecoef);
+            sig += q * ((fsv - P.pscale * prior[base + s]) * inv_ecoef);
             const uint8_t *row = s_tab + s * Hp;
             for (int j = 0; j < Hp; ++j) {
                 const int kj = row[j];
@@ -222,13 +247,13 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
             }
         }
         wave_sync_lds_dsc();
-        if (lane < Hp) s_row[cn[lane]] += s_m[lane];     // candidates of one datapoint are distinct
+        if (lane < Hp && ((lastmask >> lane) & 1ull)) s_row[cn[lane]] += s_m[lane];   // distinct latents
         wave_sync_lds_dsc();
         for (int h = lane; h < H; h += 64) erow[h] = s_row[h];
         double *Wq = stats + (int64_t)H * D;
         for (int p = lane; p < Hp * Hp; p += 64) {
             const int j = p / Hp, k2 = p - j * Hp;
-            if (k2 < j) continue;
+            if (k2 < j || !((lastmask >> j) & 1ull) || !((lastmask >> k2) & 1ull)) continue;
             const double v = s_B[p];
             if (v == 0.0) continue;
             const int cj = cn[j], ck = cn[k2];
@@ -300,7 +325,7 @@ extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double 
     if (!scores || !gram || !ynorm2 || !cand || !prior || !logpj || !lse || N < 0 || H <= 0 || Hprime <= 0 || S < 0 ||
         lds < H || bad_params(params_host) || (S > 0 && !state_idx))
         return PM_EINVAL;
-    if (ldl < 1 + (params_host->K - 1) * H + S) return PM_EINVAL;
+    if (ldl < ((params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S)) return PM_EINVAL;
     if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
     const size_t shmem = sizeof(double) * (H + WAVES * (Hprime + Hprime * Hprime)) + align8((size_t)S * Hprime);
     if (shmem > 150 * 1024) return PM_ERANGE;
@@ -319,7 +344,9 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
     if (!logpj || !lse || !cand || !prior || !expect || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 ||
         lde < H || bad_params(params_host) || (S > 0 && !state_idx))
         return PM_EINVAL;
-    if (ldl < 1 + (params_host->K - 1) * H + S || params_host->ecoef == 0.0) return PM_EINVAL;
+    if (ldl < ((params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S) ||
+        params_host->ecoef == 0.0)
+        return PM_EINVAL;
     if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
     const size_t shmem = sizeof(double) * (H + PM_DSC_MAX_K + 4 + WAVES * (H + Hprime + Hprime * Hprime)) +
                          align8((size_t)S * Hprime);
@@ -328,5 +355,16 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
     hipLaunchKernelGGL(dsc_mstep_rows_kernel, dim3(row_grid(N)), dim3(64 * WAVES), shmem,
                        static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior,
                        *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_tsc_select_scores_f64(const double *scores, int64_t lds, const double *gram, int64_t N, int64_t H,
+                                        double *R, int64_t ldr, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!scores || !gram || !R || N < 0 || H <= 0 || lds < H || ldr < 2 * H) return PM_EINVAL;
+    if (H > INT32_MAX / 2) return PM_ERANGE;
+    const int64_t blocks = (N * H + 255) / 256;
+    hipLaunchKernelGGL(tsc_select_scores_kernel, dim3((unsigned)(blocks > 256 * 16 ? 256 * 16 : blocks)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), scores, lds, gram, N, (int)H, R, ldr);
     return (int)hipGetLastError();
 }

@@ -38,6 +38,8 @@ from prosper.em.camodels.mca_et import MCA_ET                # noqa: E402
 from prosper.em.camodels.gsc_et import GSC                   # noqa: E402
 from prosper.em.camodels.mmca_et import MMCA_ET              # noqa: E402
 from prosper.em.camodels.dsc_et import DSC_ET                # noqa: E402
+from prosper.em.camodels import tsc_et as _tsc               # noqa: E402
+from prosper.em import Model as _Model                       # noqa: E402
 from prosper.utils.barstest import generate_bars_dict        # noqa: E402
 
 
@@ -248,6 +250,51 @@ def dsc_inference_case():
     print("dsc_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
 
 
+def _make_tsc(D, H, Hp, gamma):
+    """TSC_ET cannot be constructed upstream (``states`` is undefined in tsc_et.py:131): build the
+    object without __init__ and set what __init__ would set, with ``self.states`` in place of ``states``."""
+    from mpi4py import MPI
+    m = object.__new__(_tsc.TSC_ET)
+    _Model.__init__(m, MPI.COMM_WORLD)
+    m.to_learn = ['W', 'pi', 'sigma']
+    m.states = np.array([-1., 0., 1.])
+    m.gamma, m.D, m.H, m.Hprime = gamma, D, H, Hp
+    m.single_state_matrix, m.state_matrix, m.no_states, m.state_abs = _tsc.generate_state_matrix(Hp, gamma, H, m.states)
+    tol = 1e-5
+    m.noise_policy = {'W': (-np.inf, +np.inf, False), 'pi': (tol, 1. - tol, False), 'sigma': (0., +np.inf, False)}
+    return m
+
+
+def tsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior):
+    """One select_Hprimes -> E_step -> M_step of TSC_ET (ternary sparse coding, scalar pi)."""
+    import warnings
+    warnings.simplefilter("ignore")
+    rng = np.random.RandomState(seed)
+    W_gt = rng.normal(size=(D, H)) * 2.5
+    pi_gt, sigma_gt = min(0.4, 2.5 / H), 1.0
+    s = rng.choice([-1., 0., 1.], size=(N, H), p=[pi_gt / 2, 1 - pi_gt, pi_gt / 2])
+    y = s @ W_gt.T + rng.normal(scale=sigma_gt, size=(N, D))
+    model = _make_tsc(D, H, Hp, gamma)
+    params = {"W": W_gt + 0.3 * rng.normal(size=(D, H)), "pi": pi_gt * 1.2, "sigma": sigma_gt * 1.15}
+    inp = {k: np.array(v, copy=True) for k, v in params.items()}
+    anneal = FixedAnneal(T=T, Ncut_factor=Ncut, anneal_prior=anneal_prior)
+    Capture.rows.clear()
+    data = model.select_Hprimes(params, {"y": y.copy()})
+    ss = model.E_step(anneal, params, data)
+    new = model.M_step(anneal, params, ss, data)
+    assert np.isfinite(new["W"]).all(), name
+    cand = data["candidates"].astype(np.int64)
+    dup = np.mean([len(set(r)) < len(r) for r in cand])
+    np.savez_compressed(os.path.join(HERE, "tsc_step_%s.npz" % name), D=D, H=H, Hprime=Hp, gamma=gamma, T=T,
+                        Ncut_factor=Ncut, anneal_prior=anneal_prior, y=y, W=inp["W"], pi=inp["pi"], sigma=inp["sigma"],
+                        candidates=cand, logpj=ss["logpj"], W_new=new["W"], pi_new=new["pi"], sigma_new=new["sigma"],
+                        Q=new["Q"], L=Capture.rows["L"][0], N_use=Capture.rows["N_use"][0],
+                        state_matrix=model.state_matrix, single_state_matrix=model.single_state_matrix,
+                        no_states=model.no_states, state_abs=model.state_abs)
+    print("tsc_step_%s: N=%d states=%d L=%.6f N_use=%d, %.0f%% rows with a repeated candidate" % (
+        name, N, ss["logpj"].shape[1], Capture.rows["L"][0], Capture.rows["N_use"][0], 100 * dup))
+
+
 class FixedAnneal(dict):
     """One annealing position; unknown keys -> 0.0 like LinearAnnealing.__getitem__."""
     crit_params = []
@@ -360,7 +407,7 @@ def main(only=None):
     """``only``: regenerate just the fixtures whose name starts with this prefix (e.g. ``mmca``)."""
     want = lambda fn: only is None or fn.__name__.startswith(only)
     g = globals()
-    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "bsc_inference_case",
+    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "bsc_inference_case",
                "bsc_trajectory", "bsc_init", "anneal_tracks"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
@@ -389,6 +436,10 @@ def main(only=None):
     mca_step_case("bars", 25, 10, 5, 3, 300, seed=23, T=1.0, Ncut=1.0, bars=True)
     mca_step_case("h40", 48, 40, 6, 3, 150, seed=24, T=2.0, Ncut=0.7)
     mca_step_case("h128", 64, 128, 8, 3, 96, seed=25, T=1.0, Ncut=0.0)
+    tsc_step_case("small", 16, 8, 4, 3, 300, seed=81, T=1.0, Ncut=0.0, anneal_prior=False)
+    tsc_step_case("cut", 24, 12, 5, 3, 257, seed=82, T=1.4, Ncut=0.6, anneal_prior=True)
+    tsc_step_case("g2", 30, 20, 6, 2, 200, seed=83, T=1.0, Ncut=1.0, anneal_prior=False)
+    tsc_step_case("h64", 48, 64, 6, 3, 120, seed=84, T=1.2, Ncut=0.0, anneal_prior=False)
     bsc_inference_case()
     dsc_inference_case()
     bsc_trajectory()

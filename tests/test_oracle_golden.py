@@ -201,6 +201,47 @@ def test_dsc_step_matches_reference(case, flavour):
     assert new["Q"] == float(g["Q"]) == 0.0
 
 
+# ----------------------------------------------------------------------------- TSC (tsc_et.py)
+def _tsc_cases():
+    import glob, os
+    from conftest import GOLDEN
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "tsc_step_*.npz")))
+
+
+@pytest.mark.parametrize("case", _tsc_cases())
+@pytest.mark.parametrize("flavour", ["loop", "vec"])
+def test_tsc_step_matches_reference(case, flavour):
+    from oracle import tsc_oracle as M
+    g = golden(case)
+    model = M.make_model(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    assert np.array_equal(model["SM"], g["state_matrix"]) and np.array_equal(model["SSM"], g["single_state_matrix"])
+    assert model["no_states"] == int(g["no_states"]) and np.array_equal(model["state_abs"], g["state_abs"])
+    an = M.Anneal(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
+    W, pi, sigma = g["W"], float(g["pi"]), float(g["sigma"])
+    vec = flavour == "vec"
+    cand = (M.select_hprimes_vec if vec else M.select_hprimes_loop)(model, W, pi, sigma, g["y"])
+    if vec:   # Gram form: rounding may swap near-ties only
+        R = M.select_scores_vec(model, W, g["y"])
+        H = model["H"]
+        for n in np.where((cand != g["candidates"]).any(axis=1))[0]:
+            best = np.maximum(R[n, :H], R[n, H:])
+            np.testing.assert_allclose(np.sort(best[cand[n]]), np.sort(best[g["candidates"][n]]), rtol=1e-9)
+        cand = g["candidates"]
+    else:
+        assert np.array_equal(cand, g["candidates"])
+    logpj = (M.e_step_vec if vec else M.e_step_loop)(an, model, W, pi, sigma, g["y"], cand)
+    np.testing.assert_allclose(logpj, g["logpj"], rtol=1e-10, atol=1e-9)
+    new, log = M.m_step(an, model, W, pi, sigma, g["y"], cand, g["logpj"], vec=vec)
+    assert log["N_use"] == int(g["N_use"])
+    np.testing.assert_allclose(log["L"], float(g["L"]), rtol=1e-12)
+    cond = np.linalg.cond(log["stats"]["Wq"])
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=0, atol=max(1e-9, 1e-14 * cond) * np.abs(g["W_new"]).max())
+    np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=1e-10)
+    np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=1e-10)
+    assert (M.last_position_mask(g["candidates"]).all(axis=1).mean() < 1.0) == \
+        bool(np.any([len(set(r)) < len(r) for r in g["candidates"]]))
+
+
 # ----------------------------------------------------------------------------- GSC (gsc_et.py)
 def _gsc_cases():
     import glob, os

@@ -1,0 +1,110 @@
+"""TSC parity on the GPU: HIP path (through the C ABI) vs golden vectors minted by running the reference's
+TSC_ET methods on an object built without its broken constructor (tests/golden/tsc_step_*.npz) and vs the oracle.
+Includes datapoints whose candidates repeat a latent (upstream's last-position semantics in the W update)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden, GOLDEN
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class _An(dict):
+    crit_params = []
+
+    def __missing__(self, k):
+        return 0.0
+
+    def as_dict(self):
+        return dict(self)
+
+
+def _cases():
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "tsc_step_*.npz")))
+
+
+def _check_candidates(cand, ref, R, H):
+    """Latents of the best one-cause states, best last; rows may differ from the reference's only where the
+    state scores tie to rounding (the device ranks the Gram form)."""
+    cand = np.asarray(cand)
+    bad = np.where((cand != ref).any(axis=1))[0]
+    best = np.maximum(R[:, :H], R[:, H:])
+    for n in bad:
+        np.testing.assert_allclose(np.sort(best[n, cand[n]]), np.sort(best[n, ref[n]]), rtol=1e-9)
+    return bad.size
+
+
+@pytest.mark.parametrize("case", _cases())
+def test_tsc_step_matches_reference_golden(case):
+    assert torch.cuda.is_available()
+    from oracle import tsc_oracle as M
+    from prosper_amd.em.camodels.tsc_et import TSC_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    g = golden(case)
+    D, H, Hp, gamma = int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"])
+    m = TSC_ET(D, H, Hp, gamma)
+    assert np.array_equal(m.state_matrix, g["state_matrix"]) and m.no_states == int(g["no_states"])
+    assert np.array_equal(m.single_state_matrix, g["single_state_matrix"]) and np.array_equal(m.state_abs, g["state_abs"])
+    an = _An(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
+    params = {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])}
+    h = dlog.set_handler(("N_use", "L"), StoreInMemory)
+    try:
+        data = m.select_Hprimes(params, {"y": g["y"]})
+        R = M.select_scores_vec(M.make_model(D, H, Hp, gamma), params["W"], g["y"])
+        assert _check_candidates(data["candidates"], g["candidates"], R, H) == 0
+        ss = m.E_step(an, params, data)
+        new = m.M_step(an, params, ss, data)
+    finally:
+        dlog.remove_handler(h)
+    np.testing.assert_allclose(np.asarray(ss["logpj"]), g["logpj"], rtol=1e-10, atol=1e-9)
+    assert int(h.tables["N_use"][0]) == int(g["N_use"])
+    np.testing.assert_allclose(h.tables["L"][0], float(g["L"]), rtol=1e-10)
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=0, atol=1e-8 * np.abs(g["W_new"]).max())
+    np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=1e-9)
+    np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=1e-9)
+    assert new["Q"] == 0.0 and new["W"].shape == (D, H)
+    # foreign NumPy inputs take the same kernels
+    new2 = m.M_step(an, params, {"logpj": g["logpj"]}, {"y": g["y"], "candidates": g["candidates"]})
+    np.testing.assert_allclose(new2["W"], g["W_new"], rtol=0, atol=1e-8 * np.abs(g["W_new"]).max())
+
+
+@pytest.mark.parametrize("D,H,Hp,gamma,N,T,ncut", [(256, 128, 6, 3, 1500, 1.0, 0.0), (100, 70, 5, 4, 600, 1.5, 0.5),
+                                                    (40, 12, 4, 2, 400, 1.0, 0.0)])
+def test_tsc_step_matches_oracle(D, H, Hp, gamma, N, T, ncut):
+    from oracle import tsc_oracle as M
+    from prosper_amd.em.camodels.tsc_et import TSC_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    rng = np.random.RandomState(D + H + N)
+    pi_gt = 2.0 / H
+    W_gt = rng.normal(size=(D, H)) * 2.0
+    s = rng.choice([-1., 0., 1.], size=(N, H), p=[pi_gt / 2, 1 - pi_gt, pi_gt / 2])
+    y = s @ W_gt.T + rng.normal(size=(N, D))
+    params = {"W": W_gt + 0.2 * rng.normal(size=(D, H)), "pi": pi_gt * 1.2, "sigma": 1.1}
+    model = M.make_model(D, H, Hp, gamma)
+    an = M.Anneal(T=T, Ncut_factor=ncut, anneal_prior=(T != 1.0))
+    dan = _An(T=T, Ncut_factor=ncut, anneal_prior=(T != 1.0))
+    m = TSC_ET(D, H, Hp, gamma)
+    data = m.select_Hprimes(params, {"y": y})
+    ref_cand = M.select_hprimes_vec(model, params["W"], params["pi"], params["sigma"], y)
+    _check_candidates(data["candidates"], ref_cand, M.select_scores_vec(model, params["W"], y), H)
+    cand = np.asarray(data["candidates"])
+    if H <= 12:
+        assert np.any([len(set(r)) < len(r) for r in cand])         # the repeated-candidate path is exercised
+    logpj = M.e_step_vec(an, model, params["W"], params["pi"], params["sigma"], y, cand)
+    ss = m.E_step(dan, params, data)
+    np.testing.assert_allclose(np.asarray(ss["logpj"]), logpj, rtol=1e-10, atol=1e-9)
+    ref, log = M.m_step(an, model, params["W"], params["pi"], params["sigma"], y, cand, logpj, vec=True)
+    h = dlog.set_handler(("N_use",), StoreInMemory)
+    try:
+        new = m.M_step(dan, params, ss, data)
+    finally:
+        dlog.remove_handler(h)
+    assert int(h.tables["N_use"][0]) == log["N_use"]
+    cond = np.linalg.cond(log["stats"]["Wq"])
+    np.testing.assert_allclose(new["W"], ref["W"], rtol=0, atol=max(1e-8, 1e-13 * cond) * np.abs(ref["W"]).max())
+    np.testing.assert_allclose(new["pi"], ref["pi"], rtol=1e-9)
+    np.testing.assert_allclose(new["sigma"], ref["sigma"], rtol=1e-9)
