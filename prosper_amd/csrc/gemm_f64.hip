@@ -496,6 +496,110 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(const double *__res
         tn_tile<ALIGNED, false>(A, lda, B, ldb, C, ldc, M, N, kbeg, kend, m0, n0, sm);
 }
 
+// ---------------------------------------------------------------------------------------------
+// C += A^T . B with the LDS-DMA ring of the NT kernel: interior 128 x 128 tiles, 16-byte aligned
+// operands, every K-split a whole number of 8-row steps.  A K-step is 8 rows of A and 8 rows of B; one
+// `global_load_lds_dwordx4` moves one 1 KB row segment (64 lanes x 16 B), its LDS destination row is padded
+// to TN_LD doubles so that the four k-rows a fragment read touches fall into different banks.
+// Same loop as gemm_nt_f64_dma_kernel: 4 DMA instructions, 16 ds_read_b64 and 32 MFMAs per wavefront and
+// K-step, one raw s_barrier, counted s_waitcnt vmcnt.  Partial tiles are added with f64 atomics.
+// ---------------------------------------------------------------------------------------------
+constexpr int TDSTAGE = 2 * DK * TN_LD;  // doubles per stage (18 KB)
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_f64_dma_kernel(const double *__restrict__ A, int64_t lda,
+                                                                  const double *__restrict__ B, int64_t ldb,
+                                                                  double *__restrict__ C, int64_t ldc, int tiles_n,
+                                                                  int64_t K, int64_t k_per_split) {
+    __shared__ __attribute__((aligned(1024))) double sm[DSTAGES * TDSTAGE];
+    int tile = blockIdx.x, split = blockIdx.y;
+    if (gridDim.y % 8 == 0) {   // all tiles of a K-split on one XCD (see gemm_tn_f64_kernel)
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned r = L & 7u, q = L >> 3;
+        tile = (int)(q % gridDim.x);
+        split = (int)(r + 8u * (q / gridDim.x));
+    }
+    const int bn = tile % tiles_n, bm = tile / tiles_n;
+    const int m0 = bm * TN_BM, n0 = bn * BN;
+    const int64_t kbeg = (int64_t)split * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    if (kbeg >= kend) return;
+    const int nk = (int)((kend - kbeg) / DK);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // this wavefront moves rows {wave, wave + 4} of the A slab and of the B slab of every K-step
+    const double *srca = A + (kbeg + wave) * lda + m0 + 2 * lane;
+    const double *srcb = B + (kbeg + wave) * ldb + n0 + 2 * lane;
+    auto dma = [&](int kt, int stage) {
+        double *dst = sm + stage * TDSTAGE + wave * TN_LD;
+        const int64_t k0 = (int64_t)kt * DK;
+        __builtin_amdgcn_global_load_lds(srca + k0 * lda, dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srca + (k0 + 4) * lda, dst + 4 * TN_LD, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srcb + k0 * ldb, dst + DK * TN_LD, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srcb + (k0 + 4) * ldb, dst + (DK + 4) * TN_LD, 16, 0, 0);
+    };
+    const int fcol = lane & 15, fk = lane >> 4;
+    const int a_off = fk * TN_LD + wm * 64 + fcol;
+    const int b_off = DK * TN_LD + fk * TN_LD + wn * 64 + fcol;
+    double fa[2][4], fb[2][4];
+    auto fread = [&](int stage, int kk, int slot) {
+        const double *sa = sm + stage * TDSTAGE + a_off + kk * 4 * TN_LD;
+        const double *sb = sm + stage * TDSTAGE + b_off + kk * 4 * TN_LD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[slot][i] = sa[i * 16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[slot][j] = sb[j * 16];
+    };
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+#pragma unroll
+    for (int t = 0; t < DSTAGES; ++t)
+        if (t < nk) dma(t, t);
+    if (nk >= 4) PM_WAIT_VMCNT(12);
+    else if (nk == 3) PM_WAIT_VMCNT(8);
+    else if (nk == 2) PM_WAIT_VMCNT(4);
+    else PM_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    fread(0, 0, 0);
+
+    for (int t = 0; t < nk; ++t) {
+        const int stage = t & (DSTAGES - 1);
+        fread(stage, 1, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[0][i], fb[0][j], acc[i][j]);
+        if (t + 1 < nk) {
+            const int ahead = nk - t - 2;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ahead >= 2) PM_WAIT_VMCNT(8);
+            else if (ahead == 1) PM_WAIT_VMCNT(4);
+            else PM_WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            fread((t + 1) & (DSTAGES - 1), 0, 0);
+            if (t + DSTAGES < nk) dma(t + DSTAGES, stage);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[1][i], fb[1][j], acc[i][j]);
+    }
+
+    double *cbase = C + (int64_t)(m0 + wm * 64 + fk) * ldc + n0 + wn * 64 + fcol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pm_atomic_add(cbase + (int64_t)(i * 16 + 4 * r) * ldc + j * 16, acc[i][j][r]);
+}
+
 // out[n] = sum_d Y[n,d]^2; one wavefront per row, lanes stride the row.
 __global__ __launch_bounds__(256) void row_sqnorm_f64_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N,
                                                               int D, double *__restrict__ out) {
@@ -656,7 +760,16 @@ extern "C" int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B,
     const bool al = aligned16(A) && aligned16(B) && (lda % 2 == 0) && (ldb % 2 == 0) && (M % 2 == 0) && (N % 2 == 0);
     dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (al)
+    if (al && M % TN_BM == 0 && N % BN == 0 && K >= 8 * DK) {
+        // LDS-DMA kernel over the first K - K % 8 rows (every split a whole number of 8-row steps, kps is a
+        // multiple of 16); the last K % 8 rows go through the register-staged kernel
+        const int64_t K8 = K - K % DK;
+        dim3 g8((unsigned)tiles, (unsigned)((K8 + kps - 1) / kps));
+        hipLaunchKernelGGL(gemm_tn_f64_dma_kernel, g8, block, 0, s, A, lda, B, ldb, C, ldc, tiles_n, K8, kps);
+        if (K8 < K)
+            hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, dim3((unsigned)tiles, 1), block, 0, s, A + K8 * lda, lda,
+                               B + K8 * ldb, ldb, C, ldc, (int)M, (int)N, K - K8, tiles_n, (int64_t)BK);
+    } else if (al)
         hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K,
                            tiles_n, kps);
     else
