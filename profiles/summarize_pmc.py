@@ -23,7 +23,7 @@ import sys
 KERNELS = {
     "gemm_nt_f64_dma_kernel<false>": "scores_gemm",
     "gemm_nt_f64_dma_kernel<true>": "scores_gemm_splitk",
-    "gemm_tn_f64_kernel": "stats_gemm",
+    "gemm_tn_f64": "stats_gemm",
     "bsc_select_estep16_kernel": "select_estep",
     "bsc_mstep_rows16_kernel": "mstep_rows",
 }
