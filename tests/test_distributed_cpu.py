@@ -1,6 +1,6 @@
 """N > 1 path on CPU: two processes over torch.distributed/gloo exercise the communicator the
 models use (mpi4py call surface), data sharding, the global truncation threshold and the
-pack -> all-reduce -> finalize half of BSC_ET.M_step.  Per-shard statistics come from the
+pack -> all-reduce -> finalize half of BSC_ET.M_step and DSC_ET.M_step.  Per-shard statistics come from the
 oracle (as the checker's stand-in for the GPU kernels); the result must equal the reference's
 single-process golden output."""
 import os
@@ -104,6 +104,38 @@ def _worker(rank, port, q):
             assert int(h.tables["N_use"][0]) == int(g["N_use"])
         else:
             assert h is None
+        # -- DSC: the same pack -> all-reduce -> finalize half across 2 ranks (dsc_et.py:736-774)
+        from oracle import dsc_oracle as DO
+        from prosper_amd.em.camodels.dsc_et import DSC_ET
+        from scipy.special import logsumexp
+        g = golden("dsc_step_ternary.npz")
+        D, H, Hp, gamma = int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"])
+        dmodel = DSC_ET(D, H, Hp, gamma, states=g["states"], comm=comm, device="cpu")
+        omodel = DO.make_model(D, H, Hp, gamma, g["states"])
+        first, last = parallel.stride_data(g["y"].shape[0], comm=comm)
+        sl = slice(first, last)
+        an = DO.Anneal(T=float(g["T"]), Ncut_factor=0.0, anneal_prior=bool(g["anneal_prior"]))
+        _, olog = DO.m_step(an, omodel, g["W"], g["pi"], float(g["sigma"]), g["y"][sl], g["candidates"][sl],
+                            g["logpj"][sl], vec=True)
+        st = olog["stats"]
+        packed = torch.zeros(lib.pm_dsc_stats_len(H, D), dtype=torch.float64)
+        o_wq, o_qd = H * D, H * D + H * H
+        packed[:o_wq] = torch.from_numpy(st["Wp"]).reshape(-1)
+        packed[o_wq:o_qd] = torch.from_numpy(np.triu(st["Wq"])).reshape(-1)
+        for k in range(omodel["K"]):
+            if k != omodel["K_0"]:
+                packed[o_qd + H + k] = st["pi"][k]
+        packed[o_qd + H + 8 + 0] = st["sigma"] * D
+        packed[o_qd + H + 8 + 1] = float(logsumexp(g["logpj"][sl], axis=1).sum())
+        packed[o_qd + H + 8 + 2] = float(last - first)
+        comm.allreduce_device(packed)
+        h2 = dlog.set_handler(("L", "N_use"), StoreInMemory)
+        dnew = dmodel._finalize(packed, {"W": g["W"], "pi": g["pi"], "sigma": float(g["sigma"])})
+        np.testing.assert_allclose(dnew["W"], g["W_new"], rtol=0, atol=1e-9 * np.abs(g["W_new"]).max())
+        np.testing.assert_allclose(dnew["pi"], g["pi_new"], rtol=1e-10)
+        np.testing.assert_allclose(dnew["sigma"], g["sigma_new"], rtol=1e-10)
+        if rank == 0:
+            np.testing.assert_allclose(float(h2.tables["L"][0]), float(g["L"]), rtol=1e-11)
         q.put((rank, "ok"))
     except Exception as e:  # surface the failure in the parent
         import traceback
