@@ -75,9 +75,103 @@ class TSC_ET(DeviceCAModel):
         y += np.random.normal(scale=model_params['sigma'], size=(my_N, self.D))
         return {'y': y, 's': s}
 
-    def inference(self, *args, **kwargs):
-        """Upstream's own inference (tsc_et.py:546-680) is not built."""
-        raise NotImplementedError("TSC_ET.inference is not available in this build")
+    def inference(self, anneal, model_params, test_data, topK=10, logprob=False, abs_marginal=True,
+                  adaptive=True, Hprime_max=None, gamma_max=None):
+        """Top-K posterior states, signed marginal ``m`` and absolute marginal ``am`` per datapoint
+        (tsc_et.py:546-680); same return dict.  As upstream: ``p`` is the normalised probability (its log with
+        ``logprob``), a repeated candidate's LAST position wins the writes into ``s`` / ``m`` / ``am``, re-run
+        datapoints keep earlier entries, and datapoints whose best state has exactly gamma non-zeros are re-run
+        with Hprime+1 / gamma+1."""
+        assert 'y' in test_data, "Key 'y' in test_data dict not defined."
+        comm = self.comm
+        my_y = test_data['y']
+        if isinstance(my_y, DeviceArray):
+            my_y = my_y.tensor
+        my_N, D = my_y.shape
+        H = self.H
+        Hprime_start, gamma_start = self.Hprime, self.gamma
+        if topK == -1:
+            topK = self.state_matrix.shape[0]
+        dev = self.device
+        res_s = torch.zeros((my_N, topK, H), dtype=torch.int8, device=dev)
+        res_m = torch.zeros((my_N, H), dtype=torch.float64, device=dev)
+        res_am = torch.zeros((my_N, H), dtype=torch.float64, device=dev)
+        res_p = torch.zeros((my_N, topK), dtype=torch.float64, device=dev)
+        res_gamma = torch.zeros((my_N,), dtype=torch.float64, device=dev)
+        res_Hprime = torch.zeros((my_N,), dtype=torch.float64, device=dev)
+
+        def regenerate():
+            (self.single_state_matrix, self.state_matrix, self.no_states,
+             self.state_abs) = generate_state_matrix(self.Hprime, self.gamma, self.H, self.states)
+
+        cur_y = my_y
+        which = torch.ones(my_N, dtype=torch.bool, device=dev)
+        try:
+            while bool(which.any()):
+                ind_n = torch.nonzero(which).flatten()
+                logpj, cand = self.compute_lpj(anneal, model_params, {'y': cur_y})
+                lp = logpj.tensor if isinstance(logpj, DeviceArray) else torch.as_tensor(np.asarray(logpj)).to(dev)
+                cd = (cand.tensor if isinstance(cand, DeviceArray) else torch.as_tensor(np.asarray(cand)).to(dev)).long()
+                n_cur, S = lp.shape
+                Hp = self.Hprime
+                rel = lp - lp.max(dim=1, keepdim=True).values
+                pjc = torch.exp(rel)
+                denom = pjc.sum(dim=1, keepdim=True)
+                lpc = rel - torch.log(denom)
+                post = pjc / denom
+                k_eff = min(topK, S)
+                # states that differ only in WHICH position of a repeated candidate is active tie exactly; their
+                # order is whatever NumPy's argsort makes of it upstream (tsc_et.py:626) -- rank on the host
+                order = np.argsort(lpc.cpu().numpy(), axis=-1)[:, ::-1][:, :k_eff]
+                top_idx = torch.from_numpy(np.ascontiguousarray(order)).to(dev)
+                top_val = torch.gather(lpc, 1, top_idx)
+                res_Hprime[ind_n] = float(self.Hprime)
+                res_gamma[ind_n] = float(self.gamma)
+                SM = torch.from_numpy(self.state_matrix.astype(np.int8)).to(dev)
+                SMf = SM.to(torch.float64)
+                s_blk = res_s[ind_n, :k_eff].clone()
+                rows = SM[top_idx]                                        # (n, k_eff, Hp) latent values
+                marg = post @ SMf                                         # (n, Hp)
+                amarg = post @ SMf.abs()
+                m_blk, am_blk = res_m[ind_n].clone(), res_am[ind_n].clone()
+                rn = torch.arange(n_cur, device=dev)
+                for j in range(Hp):                                       # in order: the last position wins
+                    s_blk[rn[:, None], torch.arange(k_eff, device=dev)[None, :], cd[:, j][:, None]] = rows[:, :, j]
+                    m_blk[rn, cd[:, j]] = marg[:, j]
+                    if abs_marginal:
+                        am_blk[rn, cd[:, j]] = amarg[:, j]
+                res_s[ind_n, :k_eff] = s_blk
+                res_m[ind_n] = m_blk
+                res_am[ind_n] = am_blk
+                res_p[ind_n, :k_eff] = top_val if logprob else torch.gather(post, 1, top_idx)
+                if not adaptive:
+                    break
+                which = ((res_s[:, 0, :] != 0).sum(-1) == self.gamma)
+                if not bool(which.any()):
+                    break
+                if (Hprime_max is not None and self.Hprime == Hprime_max) and \
+                        (gamma_max is not None and self.gamma == gamma_max):
+                    break
+                cur_y = my_y[which.cpu().numpy()] if not torch.is_tensor(my_y) else my_y[which]
+                print("Rank %i: For %i data points MAP state has activity equal to gamma." % (comm.rank, int(which.sum())))
+                if not ((self.Hprime == self.H) or (Hprime_max is not None and self.Hprime == Hprime_max)):
+                    self.Hprime += 1
+                if (self.gamma == self.H) or (gamma_max is not None and self.gamma == gamma_max):
+                    continue
+                self.gamma += 1
+                print("Rank %i: Updating state matrix and running again." % comm.rank)
+                regenerate()
+        finally:
+            comm.Barrier()
+            self.Hprime, self.gamma = Hprime_start, gamma_start
+            regenerate()
+        with np.errstate(divide='ignore'):
+            m_out = res_m.cpu().numpy()
+            am_out = res_am.cpu().numpy()
+            if logprob:
+                m_out, am_out = np.log(m_out), np.log(am_out)
+        return {'s': res_s.cpu().numpy(), 'm': m_out, 'am': am_out, 'p': res_p.cpu().numpy(),
+                'gamma': res_gamma.cpu().numpy(), 'Hprime': res_Hprime.cpu().numpy()}
 
     # ------------------------------------------------------------------ plumbing
     def _tables(self):

@@ -295,6 +295,32 @@ def tsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior):
         name, N, ss["logpj"].shape[1], Capture.rows["L"][0], Capture.rows["N_use"][0], 100 * dup))
 
 
+def tsc_inference_case():
+    """TSC_ET.inference (tsc_et.py:546-680) on the constructor-bypassed object: top-K states, signed and
+    absolute marginals, adaptive H'/gamma."""
+    import io, contextlib, warnings
+    warnings.simplefilter("ignore")
+    D, H, Hp, gamma, N = 20, 9, 4, 2, 50
+    rng = np.random.RandomState(91)
+    pi = 0.25
+    W = rng.normal(size=(D, H)) * 3.0
+    s = rng.choice([-1., 0., 1.], size=(N, H), p=[pi / 2, 1 - pi, pi / 2])
+    y = s @ W.T + rng.normal(size=(N, D))
+    params = {"W": W + 0.2 * rng.normal(size=(D, H)), "pi": pi, "sigma": 1.1}
+    anneal = FixedAnneal(T=1.0)
+    out = {}
+    for tag, kw in (("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
+                    ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True))):
+        model = _make_tsc(D, H, Hp, gamma)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = model.inference(anneal, {k: np.array(v, copy=True) for k, v in params.items()}, {"y": y.copy()}, **kw)
+        for k, v in res.items():
+            out["%s_%s" % (tag, k)] = v
+    np.savez_compressed(os.path.join(HERE, "tsc_inference.npz"), D=D, H=H, Hprime=Hp, gamma=gamma, y=y,
+                        W=params["W"], pi=pi, sigma=params["sigma"], **out)
+    print("tsc_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
+
+
 class FixedAnneal(dict):
     """One annealing position; unknown keys -> 0.0 like LinearAnnealing.__getitem__."""
     crit_params = []
@@ -407,7 +433,7 @@ def main(only=None):
     """``only``: regenerate just the fixtures whose name starts with this prefix (e.g. ``mmca``)."""
     want = lambda fn: only is None or fn.__name__.startswith(only)
     g = globals()
-    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "bsc_inference_case",
+    for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
                "bsc_trajectory", "bsc_init", "anneal_tracks"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
@@ -440,6 +466,7 @@ def main(only=None):
     tsc_step_case("cut", 24, 12, 5, 3, 257, seed=82, T=1.4, Ncut=0.6, anneal_prior=True)
     tsc_step_case("g2", 30, 20, 6, 2, 200, seed=83, T=1.0, Ncut=1.0, anneal_prior=False)
     tsc_step_case("h64", 48, 64, 6, 3, 120, seed=84, T=1.2, Ncut=0.0, anneal_prior=False)
+    tsc_inference_case()
     bsc_inference_case()
     dsc_inference_case()
     bsc_trajectory()
