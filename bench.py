@@ -16,7 +16,8 @@ GEMM) by algorithmic flops / its average launch duration measured with HIP event
 timed region; `cpu_baseline` is the oracle's faithful per-datapoint restatement of the
 reference timed on this box's host cores on a bounded sample (rank 0, N=1 only); `parity` compares
 the HIP path with the oracle's answer (minted by that same leg) after 3 EM steps on a seeded sample at
-the bench's dimensions -- outside every timed region.
+the bench's dimensions -- outside every timed region; `other_models` adds the EM-iteration wall-clock of GSC
+(config 4) and MCA (config 5) on this GPU, measured after the headline (N=1 only; `--no-other-models` skips it).
 """
 import argparse
 import gc
@@ -43,8 +44,68 @@ def parse():
     ap.add_argument("--n-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--em-steps", type=int, default=20, help="full EM iterations timed for em_iter_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-models", action="store_true", help="skip the GSC / MCA EM-iteration side measurements")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
     return ap.parse_args()
+
+
+def other_models(dev, Anneal, steps=8):
+    """EM-iteration wall-clock of the other §8(a) models at BASELINE configs 4 and 5 (one GPU's share), after the
+    headline timing: GSC D=256 H=128 H'=6 gamma=3 N=200k, MCA D=256 H=128 H'=8 gamma=3 N=100k.  Informational."""
+    import numpy as np
+    import torch
+    from prosper_amd.em.camodels.gsc_et import GSC
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    out = {}
+    try:
+        Dm, Hm = 256, 128
+        g = torch.Generator(device=dev).manual_seed(3)
+        rng = np.random.RandomState(3)
+        # --- GSC, config 4
+        N = 200_000
+        W_gt = torch.randn(Dm, Hm, generator=g, device=dev, dtype=torch.float64)
+        Y = torch.empty(N, Dm, dtype=torch.float64, device=dev)
+        for lo in range(0, N, 50_000):
+            S = (torch.rand(50_000, Hm, generator=g, device=dev) < 2.0 / Hm).to(torch.float64)
+            Z = S * (1.5 + torch.randn(50_000, Hm, generator=g, device=dev, dtype=torch.float64))
+            Y[lo:lo + 50_000] = Z @ W_gt.t() + torch.randn(50_000, Dm, generator=g, device=dev, dtype=torch.float64)
+        p = {"W": W_gt.cpu().numpy() + 0.1 * rng.normal(size=(Dm, Hm)), "pi": np.full(Hm, 2.0 / Hm),
+             "mu": np.full(Hm, 1.4), "psi_sq": np.eye(Hm) * 1.1, "sigma_sq": 1.2}
+        m = GSC(Dm, Hm, 6, 3, 'scalar')
+        for _ in range(3):
+            p = m.step(Anneal(T=1.0), p, {"y": Y})
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            p = m.step(Anneal(T=1.0), p, {"y": Y})
+        torch.cuda.synchronize()
+        out["gsc_c4_em_iter_ms"] = (time.perf_counter() - t) / steps * 1e3
+        out["gsc_c4"] = "GSC D=256 H=128 H'=6 gamma=3 scalar sigma_sq, N=%d" % N
+        del Y, m
+        # --- MCA, config 5 (N = 800k over 8 GPUs)
+        N = 100_000
+        W_gt = torch.randn(Dm, Hm, generator=g, device=dev, dtype=torch.float64).abs() * 2 + 0.1
+        Y = torch.empty(N, Dm, dtype=torch.float64, device=dev)
+        for lo in range(0, N, 25_000):
+            S = torch.rand(25_000, Hm, generator=g, device=dev) < 2.0 / Hm
+            Wm = torch.where(S[:, None, :], W_gt[None, :, :].expand(25_000, Dm, Hm),
+                             torch.zeros((), dtype=torch.float64, device=dev)).max(dim=2).values
+            Y[lo:lo + 25_000] = Wm + torch.randn(25_000, Dm, generator=g, device=dev, dtype=torch.float64)
+        p = {"W": (W_gt * (1 + 0.1 * (2 * torch.rand(Dm, Hm, generator=g, device=dev, dtype=torch.float64) - 1))).cpu().numpy(),
+             "pi": 2.0 / Hm, "sigma": 1.0}
+        m = MCA_ET(Dm, Hm, 8, 3)
+        for _ in range(3):
+            p = m.step(Anneal(T=1.0), p, {"y": Y})
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            p = m.step(Anneal(T=1.0), p, {"y": Y})
+        torch.cuda.synchronize()
+        out["mca_c5_em_iter_ms"] = (time.perf_counter() - t) / steps * 1e3
+        out["mca_c5"] = "MCA_ET D=256 H=128 H'=8 gamma=3, N=%d (one GPU's share of 800k)" % N
+    except Exception as e:   # never lose the headline over the side measurements
+        out["error"] = repr(e)
+    return out
 
 
 PARITY_FILE = os.path.join(tempfile.gettempdir(), "prosper_amd_parity_%d.npz" % os.getpid())
@@ -220,6 +281,13 @@ def main():
     em_kern = em_timer.summary()
 
     parity = parity_report(BSC_ET, Anneal) if (rank == 0 and cpu is not None) else None
+    others = None
+    if rank == 0 and world == 1 and not args.no_other_models:
+        del Y
+        data.clear()
+        model.invalidate_data()
+        torch.cuda.empty_cache()
+        others = other_models(dev, Anneal)
 
     t = torch.tensor([elapsed, em_elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -266,6 +334,7 @@ def main():
             "em_kernels_ms": {k: round(v[1], 4) for k, v in sorted(em_kern.items())},
             "cpu_baseline": cpu,
             "parity": parity,
+            "other_models": others,
         }
         print(json.dumps(out))
     if world > 1:
