@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 2) void bsc_select_estep16_ker
 // M_step, per-datapoint part
 // ---------------------------------------------------------------------------------------------
 template <int VPL>
-__global__ __launch_bounds__(256, VPL <= 16 ? 3 : 1) void bsc_mstep_rows16_kernel(
+__global__ __launch_bounds__(256, VPL <= 16 ? 4 : 1) void bsc_mstep_rows16_kernel(
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint16_t *__restrict__ masks, int S, pm_bsc_estep_params P, int64_t N,
     int H, int D, int Hp, double *__restrict__ expect, int64_t lde, double *__restrict__ stats) {
@@ -317,10 +317,6 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 3 : 1) void bsc_mstep_rows16_kerne
         const double *f = logpj + nn * ldl;
 
         int myc = (j < Hp) ? cand[nn * Hp + j] : 0;
-        int cpos[PM_MAX_HPRIME];
-#pragma unroll
-        for (int k = 0; k < PM_MAX_HPRIME; ++k)
-            cpos[k] = (k < Hp) ? __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc) : 0;
 
         double es[VPL];
 #pragma unroll
@@ -371,16 +367,15 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 3 : 1) void bsc_mstep_rows16_kerne
         }
         wave_lds_sync16();
         // scatter E[s_i s_k] of the candidate block into Wq (upper triangle), add E[s_c] to the row
-        for (int p = j; p < Hp * Hp; p += 16) {
-            const int i = p / Hp, k = p - i * Hp;
-            const double m2 = s_m2[p];
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {            // uniform trip count: every lane feeds the bpermutes
+            const int p = p0 + j;
+            const bool valid = p < Hp * Hp;
+            const int i = valid ? p / Hp : 0, k = valid ? p - i * Hp : 0;
+            const double m2 = valid ? s_m2[p] : 0.0;
+            // candidates i and k of this datapoint, from the lanes that hold them
+            const int ci = __builtin_amdgcn_ds_bpermute(((lane & 48) + i) << 2, myc);
+            const int ck = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc);
             if (k >= i && m2 != 0.0) {
-                int ci = 0, ck = 0;
-#pragma unroll
-                for (int q = 0; q < PM_MAX_HPRIME; ++q) {
-                    ci = (q == i) ? cpos[q] : ci;
-                    ck = (q == k) ? cpos[q] : ck;
-                }
                 const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
                 pm_atomic_add(Wq + (int64_t)lo * H + hi, m2);
             }
@@ -390,25 +385,19 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 3 : 1) void bsc_mstep_rows16_kerne
             const double m1 = s_m2[j * Hp + j];
             if (m1 != 0.0) atomicAdd(&s_mus[myc], m1);
         }
-#pragma unroll
-        for (int k = 0; k < PM_MAX_HPRIME; ++k) {
-            if (k < Hp) {
-                const int c = cpos[k];
-                const double m1 = s_m2[k * Hp + k];
-                if ((c & 15) == j) {
-#pragma unroll
-                    for (int i = 0; i < VPL; ++i)
-                        if ((c >> 4) == i) es[i] += m1;
-                }
-            }
-        }
-        wave_lds_sync16();
-        for (int p = j; p < Hp * Hp; p += 16) s_m2[p] = 0.0;
+        // the row of singleton weights goes out first; the candidates' multi-cause terms are added to it by the
+        // lanes that own them once those stores have completed (8 f64 atomics per datapoint instead of a
+        // 16 x VPL select chain into the register row)
+        const double m1c = (j < Hp) ? s_m2[j * Hp + j] : 0.0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
             if (live && h < H) erow[h] = es[i];
         }
+        wave_lds_sync16();
+        for (int p = j; p < Hp * Hp; p += 16) s_m2[p] = 0.0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (keep && j < Hp && m1c != 0.0) pm_atomic_add(erow + myc, m1c);
         wave_lds_sync16();
     }
 
