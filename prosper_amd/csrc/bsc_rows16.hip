@@ -171,24 +171,19 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 2) void bsc_select_estep16_ker
 
         // ---------------- candidate block: d_k and G[c_i,c_k] -> LDS ------------------------
         if (ymu) yn = yn - 2.0 * ymu[nn] + P.mu_sqnorm;
-        int cpos[PM_MAX_HPRIME];  // every lane learns all candidates of its datapoint (row broadcast)
-#pragma unroll
-        for (int k = 0; k < PM_MAX_HPRIME; ++k)
-            cpos[k] = (k < Hp) ? __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc) : 0;
         if (j < Hp) {
             const int c = myc;
             const double ac = arow[c] - (wmu ? wmu[c] : 0.0);
             s_d[j] = gram[(int64_t)c * H + c] - 2.0 * ac;
         }
-        for (int p = j; p < Hp * Hp; p += 16) {
-            const int i = p / Hp, k = p - i * Hp;
-            int ci = 0, ck = 0;
-#pragma unroll
-            for (int q = 0; q < PM_MAX_HPRIME; ++q) {
-                ci = (q == i) ? cpos[q] : ci;
-                ck = (q == k) ? cpos[q] : ck;
-            }
-            s_G[p] = gram[(int64_t)ci * H + ck];
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {            // uniform trip count: every lane feeds the bpermutes
+            const int p = p0 + j;
+            const bool valid = p < Hp * Hp;
+            const int i = valid ? p / Hp : 0, k = valid ? p - i * Hp : 0;
+            // candidates i and k of this datapoint, from the lanes of its DPP row that hold them
+            const int ci = __builtin_amdgcn_ds_bpermute(((lane & 48) + i) << 2, myc);
+            const int ck = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc);
+            if (valid) s_G[p] = gram[(int64_t)ci * H + ck];
         }
         wave_lds_sync16();
 
