@@ -56,6 +56,12 @@ __device__ __forceinline__ double g_row_sum(double v) {
     v += gdppf<0x140>(v);
     return v;
 }
+// sum over the four 16-lane rows of a wave (lanes j, j+16, j+32, j+48); epilogue only
+__device__ __forceinline__ double g_col_sum(double v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
 __device__ __forceinline__ void g_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -402,13 +408,22 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         g_sync();
     }
 
-    // flush per-lane column sums / singleton diagonals
+    // flush per-lane column sums / singleton diagonals: lanes of different rows / waves own the same latent, so
+    // fold them in LDS first (the parameter tables are dead by now: s_c0 takes the xpt_szsz diagonal) and send
+    // ONE global atomic per latent and block -- a per-lane flush puts 256 * VPL atomics per block on H addresses
+    // and serialises the whole grid's tail on them.
+    __syncthreads();
+    for (int h = tid; h < H; h += 256) s_c0[h] = 0.0;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int h = j + 16 * i;
-        if (h < H) {
-            atomicAdd(&s_cs[h], cs[i]);
-            atomicAdd(&s_csz[h], csz[i]);
+        // rows of the wave first (lanes j, j+16, j+32, j+48), then one LDS atomic per wave and latent
+        const double c_s = g_col_sum(cs[i]), c_sz = g_col_sum(csz[i]), c_d = g_col_sum(dszsz[i]);
+        if (row == 0 && h < H) {
+            atomicAdd(&s_cs[h], c_s);
+            atomicAdd(&s_csz[h], c_sz);
+            atomicAdd(&s_c0[h], c_d);
         }
     }
     __syncthreads();
@@ -416,12 +431,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     for (int h = tid; h < H; h += 256) {
         if (s_cs[h] != 0.0) pm_atomic_add(g_cs + h, s_cs[h]);
         if (s_csz[h] != 0.0) pm_atomic_add(g_csz + h, s_csz[h]);
-    }
-    // singleton diagonal of sum xpt_szsz: lanes of different rows/waves own the same latent
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int h = j + 16 * i;
-        if (h < H && dszsz[i] != 0.0) pm_atomic_add(g_dszsz + h, dszsz[i]);
+        if (s_c0[h] != 0.0) pm_atomic_add(g_dszsz + h, s_c0[h]);
     }
 }
 
