@@ -308,8 +308,11 @@ int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma);
 
 /* stats (float64): [ sum_n xpt_ss, upper triangle, multi-cause part (H*H) |
  *                    sum_n xpt_szsz, upper triangle, multi-cause part (H*H) |
- *                    sum_n xpt_s (H) | sum_n xpt_sz (H) | singleton diagonal of sum_n xpt_szsz (H) ]
- * diag(sum xpt_ss) = sum_n xpt_s (s_h^2 = s_h). */
+ *                    sum_n xpt_s (H) | sum_n xpt_sz (H) | singleton diagonal of sum_n xpt_szsz (H) |
+ *                    scratch: seven more copies of the first 2*H*H entries ]
+ * diag(sum xpt_ss) = sum_n xpt_s (s_h^2 = s_h).  The kernel accumulates the (H,H) blocks per XCD (one L2 each)
+ * and folds the copies into the first 2*H*H entries (clearing the scratch) before it returns: the caller zeroes the
+ * whole buffer once; the documented entries accumulate across calls as before. */
 int64_t pm_gsc_stats_len(int64_t H);
 
 /* select_Hprimes + E_step of GSC in one pass (gsc_et.py:721-809, 401-580, 260-398):

@@ -27,6 +27,7 @@
 namespace {
 
 constexpr int ROWS = 16;
+constexpr int PM_GSC_XCD_COPIES = 8;   // MI355X: 8 XCDs, one L2 each
 
 template <int CTRL>
 __device__ __forceinline__ unsigned gdpp32(unsigned v) {
@@ -62,8 +63,11 @@ __device__ __forceinline__ double g_col_sum(double v) {
     v += __shfl_xor(v, 32);
     return v;
 }
+// Ordering point for the per-datapoint LDS arrays, which only the lanes of ONE wavefront touch: the LDS pipeline
+// executes a wavefront's operations in issue order, so a wavefront-scope fence (a compiler barrier; a
+// workgroup-scope one also drains the vector-memory counter and with it the pending global atomics) suffices.
 __device__ __forceinline__ void g_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ uint64_t g_order_key(double x) {
@@ -71,16 +75,36 @@ __device__ __forceinline__ uint64_t g_order_key(double x) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// In-place inverse and log|det| of a symmetric G x G matrix whose leading g x g block is live (the
-// rest is the identity): Gauss-Jordan without pivoting, fully unrolled (symmetric positive systems).
+// 1 / x for a normal x of either sign: hardware reciprocal + two Newton steps (full f64 accuracy up to the
+// last bit or two; the IEEE division sequence costs four times as many instructions)
+__device__ __forceinline__ double g_recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// log|det| accumulated as a product of pivot mantissas and a sum of pivot exponents: ONE log per state instead
+// of one per pivot (mantissas lie in [0.5, 1): sixteen of them cannot underflow)
+struct LogDet {
+    double mant = 1.0;
+    int expo = 0;
+    __device__ __forceinline__ void times(double piv) {
+        mant *= __builtin_amdgcn_frexp_mant(piv);
+        expo += __builtin_amdgcn_frexp_exp(piv);
+    }
+    __device__ __forceinline__ double value() const { return log(fabs(mant)) + (double)expo * 0.6931471805599453; }
+};
+
+// In-place inverse of a symmetric G x G matrix whose leading g x g block is live (the rest is the identity),
+// pivots multiplied into `ld`: Gauss-Jordan without pivoting, fully unrolled (symmetric positive systems).
 template <int G>
-__device__ __forceinline__ double sym_inverse(double (&M)[G][G]) {
-    double logdet = 0.0;
+__device__ __forceinline__ void sym_inverse(double (&M)[G][G], LogDet &ld) {
 #pragma unroll
     for (int p = 0; p < G; ++p) {
         const double piv = M[p][p];
-        logdet += log(fabs(piv));
-        const double ip = 1.0 / piv;
+        ld.times(piv);
+        const double ip = g_recip(piv);
 #pragma unroll
         for (int c = 0; c < G; ++c) M[p][c] *= ip;
         M[p][p] = ip;
@@ -96,7 +120,6 @@ __device__ __forceinline__ double sym_inverse(double (&M)[G][G]) {
             M[r][p] = -f * ip;
         }
     }
-    return logdet;
 }
 
 struct GscOffsets {
@@ -126,22 +149,24 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                                                          double *__restrict__ xpt_sz, int64_t ldx,
                                                          double *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [ 8 tables (H) | colsum_s (H) | colsum_sz (H) | per datapoint: ac (16) cidx(16 as double slots) Gc Pc as asz ass aszsz ]
+    // [ 8 tables (H) | per datapoint: ac (16) Gc Pc ass aszsz as (16) asz (16) | state masks (S x u16) ]
     double *s_tab = reinterpret_cast<double *>(smem);
     double *s_c0 = s_tab, *s_c1 = s_tab + H, *s_gm = s_tab + 2 * H, *s_il = s_tab + 3 * H, *s_kl = s_tab + 4 * H;
     double *s_ilam = s_tab + 5 * H, *s_mu = s_tab + 6 * H, *s_lpi = s_tab + 7 * H;
-    double *s_cs = s_tab + 8 * H, *s_csz = s_tab + 9 * H;
     const int HH = Hp * Hp;
     const int dp_stride = 16 + 4 * HH + 2 * 16;
-    double *s_dp = s_tab + 10 * H;
+    double *s_dp = s_tab + 8 * H;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, row = lane >> 4;
     for (int h = tid; h < H; h += 256) {
         s_c0[h] = T.c0[h]; s_c1[h] = T.c1[h]; s_gm[h] = T.gm[h]; s_il[h] = T.il[h]; s_kl[h] = T.kl[h];
         s_ilam[h] = T.ilam[h]; s_mu[h] = T.mu[h]; s_lpi[h] = T.lpi[h];
-        s_cs[h] = 0.0; s_csz[h] = 0.0;
     }
+    // the state masks sit in LDS behind the per-datapoint arrays: the multi-cause loop then issues no
+    // vector-memory operation at all (see the deferred pair atomics below)
+    uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_dp + ROWS * dp_stride);
+    for (int s = tid; s < S; s += 256) s_masks[s] = masks[s];
     double *s_ac = s_dp + (wave * 4 + row) * dp_stride;   // a at the candidates
     double *s_Gc = s_ac + 16, *s_Pc = s_Gc + HH;
     double *s_ass = s_Pc + HH, *s_aszsz = s_ass + HH;
@@ -149,12 +174,49 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     __syncthreads();
 
     const double tiny = 2.2250738585072014e-308, fmin_ = -1.7976931348623157e308;
-    double *g_ss = stats, *g_szsz = stats + (int64_t)H * H;
-    // per-lane sums over datapoints: columns of xpt_s / xpt_sz, singleton diagonal of xpt_szsz.
-    // (diag of sum xpt_ss needs no accumulator: s_h^2 = s_h, so it equals the column sum of xpt_s)
-    double dszsz[VPL], cs[VPL], csz[VPL];
+    // The block sums are accumulated per XCD: every XCD has its own L2, and f64 atomics from eight XCDs on the same
+    // few thousand lines bounce those lines between the L2s (measured: a third of this kernel's time).  Copy 0 is
+    // the caller-visible slot, copies 1..7 sit behind the documented layout; gsc_fold_kernel adds them up.
+    const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);   // HW_REG_XCC_ID[3:0]
+    double *g_ss = xcc == 0 ? stats : stats + (2 * (int64_t)H * H + 3 * H) + (int64_t)(xcc - 1) * 2 * H * H;
+    double *g_szsz = g_ss + (int64_t)H * H;
+    // the ONLY per-lane state carried across datapoints: the singleton diagonal of sum xpt_szsz.  (diag of
+    // sum xpt_ss = column sum of xpt_s; the column sums of xpt_s / xpt_sz come from gsc_colsum_kernel.)  Phases
+    // are ordered so that nothing per-latent is live across the multi-cause loop: the kernel's occupancy is set
+    // by that loop's g x g algebra (two waves per SIMD) and not by VPL.
+    double dszsz[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) dszsz[i] = cs[i] = csz[i] = 0.0;
+    for (int i = 0; i < VPL; ++i) dszsz[i] = 0.0;
+    const int rowbase = lane & 48;
+    // The block sums of xpt_ss / xpt_szsz go to global memory as f64 atomics whose round trip is microseconds; any
+    // vector-memory wait after them (vmcnt counts in issue order) exposes it.  So a datapoint's atomics are
+    // DEFERRED: its LDS accumulators stay put and are sent at the top of the row's NEXT datapoint, after that
+    // datapoint's last loads and right before its multi-cause loop, which hides the round trip.
+    int myc_prev = 0;
+    double nf_prev = 0.0;
+    bool pend = false;
+
+    // previous datapoint's blocks -> global sums (upper triangle, mirrored by the host; candidates are sorted by
+    // index, so ci <= ck for i <= k); accumulators cleared for the next one
+    auto flush_pairs = [&](bool clear) {
+        for (int p0 = 0; p0 < HH; p0 += 16) {
+            const int p = p0 + j;
+            const bool ok = p < HH;
+            const int i = ok ? p / Hp : 0, k = ok ? p - i * Hp : 0;
+            const int ci = __builtin_amdgcn_ds_bpermute((rowbase + i) << 2, myc_prev);
+            const int ck = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc_prev);
+            if (ok) {
+                if (pend && k >= i) {
+                    pm_atomic_add(g_ss + (int64_t)ci * H + ck, s_ass[p] * nf_prev);
+                    pm_atomic_add(g_szsz + (int64_t)ci * H + ck, s_aszsz[p] * nf_prev);
+                }
+                if (clear) {
+                    s_ass[p] = 0.0;
+                    s_aszsz[p] = 0.0;
+                }
+            }
+        }
+    };
 
     const int64_t groups = (N + ROWS - 1) / ROWS;
     for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
@@ -163,20 +225,6 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         const int64_t nn = live ? n : N - 1;
         const double *arow = scores + nn * lds;
         const double yn = ynorm2[nn];
-        double a[VPL], sc[VPL];
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int h = j + 16 * i;
-            a[i] = (h < H) ? arow[h] : 0.0;
-            double v = fmin_;
-            if (h < H) {  // singleton log-posterior without prior (gsc_et.py:795-805)
-                const double bb = a[i] - s_gm[h];
-                v = s_c0[h] - yn * inv_s2 + s_c1[h] * a[i] + bb * bb * s_il[h];
-                if (v != v || v < fmin_) v = fmin_;
-                if (isinf(v)) v = 0.0;
-            }
-            sc[i] = v;
-        }
 
         // ---- candidates: top-H' scores, then sorted by latent index (gsc_et.py:726-728)
         int myc = 0;
@@ -186,8 +234,13 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
             for (int i = 0; i < VPL; ++i) {
                 const int h = j + 16 * i;
                 uint64_t k = 0;
-                if (h < H) {
-                    k = (g_order_key(sc[i]) & ~0x3FFull) | (uint64_t)h;
+                if (h < H) {  // singleton log-posterior without prior (gsc_et.py:795-805)
+                    const double ai = arow[h];
+                    const double bb = ai - s_gm[h];
+                    double v = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h];
+                    if (v != v || v < fmin_) v = fmin_;
+                    if (isinf(v)) v = 0.0;
+                    k = (g_order_key(v) & ~0x3FFull) | (uint64_t)h;
                     if (k < 0x400ull) k |= 0x400ull;
                 }
                 key[i] = k;
@@ -203,24 +256,17 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                     if (key[i] == m) { key[i] = 0; mine |= 1ull << i; }
             }
             // rank of each selected latent among the selected = number of selected latents with a smaller index:
-            // prefix over lanes of popcounts is awkward in j + 16 i order, so count directly: latent h = j + 16 i
-            // precedes h' = j' + 16 i' iff i < i' or (i == i' and j < j').
-            int cnt_i[VPL];  // selected latents in "slot" i across the row
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                double c = (double)((mine >> i) & 1ull);
-                cnt_i[i] = (int)(g_row_sum(c) + 0.5);
-            }
+            // latent h = j + 16 i precedes h' = j' + 16 i' iff i < i' or (i == i' and j < j').
             int before_slot = 0;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 const bool sel = (mine >> i) & 1ull;
-                // selected lanes j' < j in the same slot: ballot restricted to this row
+                // selected lanes of this row in slot i: ballot restricted to the row
                 const unsigned long long bal = __ballot(sel);
                 const unsigned rowbits = (unsigned)((bal >> (row * 16)) & 0xFFFFull);
                 const int lower = __builtin_popcount(rowbits & ((1u << j) - 1u));
                 if (sel) s_as[before_slot + lower] = (double)(j + 16 * i);   // s_as reused as index scratch
-                before_slot += cnt_i[i];
+                before_slot += __builtin_popcount(rowbits);
             }
             g_sync();
             if (j < Hp) myc = (int)s_as[j];
@@ -230,55 +276,37 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
             if (j < Hp) myc = cand[nn * Hp + j];
         }
 
-        // ---- candidate blocks -> LDS, accumulators cleared
-        int cpos[PM_MAX_HPRIME];
-#pragma unroll
-        for (int k = 0; k < PM_MAX_HPRIME; ++k)
-            cpos[k] = (k < Hp) ? __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc) : 0;
+        // ---- candidate blocks -> LDS, accumulators cleared.  Candidate k of this datapoint sits in lane
+        // rowbase + k: ds_bpermute fetches it (uniform trip counts: every source lane stays active)
         if (j < Hp) {
             s_ac[j] = arow[myc];
             s_as[j] = 0.0;
             s_asz[j] = 0.0;
         }
-        for (int p = j; p < HH; p += 16) {
-            const int i = p / Hp, k = p - i * Hp;
-            int ci = 0, ck = 0;
-#pragma unroll
-            for (int q = 0; q < PM_MAX_HPRIME; ++q) {
-                ci = (q == i) ? cpos[q] : ci;
-                ck = (q == k) ? cpos[q] : ck;
+        for (int p0 = 0; p0 < HH; p0 += 16) {
+            const int p = p0 + j;
+            const bool ok = p < HH;
+            const int i = ok ? p / Hp : 0, k = ok ? p - i * Hp : 0;
+            const int ci = __builtin_amdgcn_ds_bpermute((rowbase + i) << 2, myc);
+            const int ck = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc);
+            if (ok) {
+                s_Gc[p] = gram[(int64_t)ci * H + ck];
+                s_Pc[p] = psi[(int64_t)ci * H + ck];
             }
-            s_Gc[p] = gram[(int64_t)ci * H + ck];
-            s_Pc[p] = psi[(int64_t)ci * H + ck];
-            s_ass[p] = 0.0;
-            s_aszsz[p] = 0.0;
         }
+        // every load of this datapoint has landed before the atomics below are issued -- said explicitly, so that
+        // the compiler has no reason to drain the counter (and with it the atomics) further down
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), other counters untouched
+        g_sync();
+        flush_pairs(true);
         g_sync();
 
-        // ---- null state + singletons
-        double Z = (j == 0) ? exp(-yn * inv_s2 * beta) : 0.0;
-        double xs[VPL], xsz[VPL], qzz[VPL];
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int h = j + 16 * i;
-            double p = 0.0, kap = 0.0;
-            if (h < H) {
-                // recompute the un-clamped singleton log-posterior (the score clamps are selection-only)
-                const double bb = a[i] - s_gm[h];
-                const double lp = s_c0[h] - yn * inv_s2 + s_c1[h] * a[i] + bb * bb * s_il[h] + s_lpi[h];
-                p = exp(lp * beta);
-                if (p != p || p < tiny) p = tiny;
-                kap = bb * s_kl[h] + s_mu[h];
-                Z += p;
-            }
-            xs[i] = p;
-            xsz[i] = p * kap;
-            qzz[i] = p * (kap * kap + ((h < H) ? s_ilam[h] : 0.0));
-        }
-
         // ---- multi-cause states
-        for (int s = j; s < S; s += 16) {
-            const unsigned mask = masks[s];
+        double Z = (j == 0) ? exp(-yn * inv_s2 * beta) : 0.0;       // null state
+        for (int s0 = 0; s0 < S; s0 += 16) {
+            const int s = s0 + j;
+            const bool valid = s < S;
+            const unsigned mask = valid ? s_masks[s] : 0u;
             int pos[GMAX];
             int g = 0;
 #pragma unroll
@@ -299,9 +327,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
 #pragma unroll
             for (int r = 0; r < GMAX; ++r) {
                 const bool lr = r < g;
-                int cr = 0;
-#pragma unroll
-                for (int q = 0; q < PM_MAX_HPRIME; ++q) cr = (q == pos[r]) ? cpos[q] : cr;
+                const int cr = __builtin_amdgcn_ds_bpermute((rowbase + pos[r]) << 2, myc);
                 av[r] = lr ? s_ac[pos[r]] : 0.0;
                 muv[r] = lr ? s_mu[cr] : 0.0;
                 prior += lr ? s_lpi[cr] : 0.0;
@@ -312,13 +338,15 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                     Lm[r][c] = lc ? s_Pc[pos[r] * Hp + pos[c]] : ((r == c) ? 1.0 : 0.0);
                 }
             }
-            double C_det = sym_inverse<GMAX>(Lm);              // Lm = Psi_a^-1, log|det Psi_a|
+            LogDet ldet;
+            sym_inverse<GMAX>(Lm, ldet);                       // Lm = Psi_a^-1, |det Psi_a|
 #pragma unroll
             for (int r = 0; r < GMAX; ++r)
 #pragma unroll
                 for (int c = 0; c < GMAX; ++c)
                     Lm[r][c] = (r < g && c < g) ? Lm[r][c] + Gm[r][c] * inv_s2 : ((r == c) ? 1.0 : 0.0);
-            C_det += sym_inverse<GMAX>(Lm);                    // Lm = Lambda^-1, + log|det Lambda|
+            sym_inverse<GMAX>(Lm, ldet);                       // Lm = Lambda^-1, * |det Lambda|
+            const double C_det = ldet.value();
             double bvec[GMAX], r2 = yn, quad = 0.0;
 #pragma unroll
             for (int r = 0; r < GMAX; ++r) {
@@ -340,10 +368,10 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
             const double lp = -C_det - r2 * inv_s2 + quad * inv_s2 * inv_s2 + prior;
             double p = exp(lp * beta);
             if (p != p || p < tiny) p = tiny;
-            Z += p;
+            if (valid) Z += p;
 #pragma unroll
             for (int r = 0; r < GMAX; ++r) {
-                if (r < g) {
+                if (r < g) {                                   // g == 0 for the padding lanes of the last trip
                     atomicAdd(&s_as[pos[r]], p);
                     atomicAdd(&s_asz[pos[r]], p * kap[r]);
 #pragma unroll
@@ -356,82 +384,138 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                 }
             }
         }
+
+        // ---- singletons (gsc_et.py:752-809 with the prior): the scores row is read again (it is still in L2 /
+        // the vector cache) rather than held in registers across the loop above
+        int64_t row_off = nn * lds;
+        asm volatile("" : "+v"(row_off));
+        const double *arow2 = scores + row_off;
+        double av1[VPL], xs[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            double p = 0.0, ai = 0.0;
+            if (h < H) {
+                // the un-clamped singleton log-posterior (the score clamps are selection-only)
+                ai = arow2[h];
+                const double bb = ai - s_gm[h];
+                const double lp = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h] + s_lpi[h];
+                p = exp(lp * beta);
+                if (p != p || p < tiny) p = tiny;
+                Z += p;
+            }
+            av1[i] = ai;
+            xs[i] = p;
+        }
         Z = g_row_sum(Z);
         const double nf = 1.0 / (Z + tiny);
         g_sync();
 
-        // ---- expectations of this datapoint; sums over datapoints
-        if (live) {
-            for (int p = j; p < HH; p += 16) {
-                const int i = p / Hp, k = p - i * Hp;
-                if (k < i) continue;   // symmetric blocks: upper triangle, mirrored by the host
-                int ci = 0, ck = 0;
+        // ---- expectations of this datapoint; sums over datapoints (the block sums: see flush_pairs)
+        double xsz[VPL];
 #pragma unroll
-                for (int q = 0; q < PM_MAX_HPRIME; ++q) {
-                    ci = (q == i) ? cpos[q] : ci;
-                    ck = (q == k) ? cpos[q] : ck;
-                }
-                // candidates are sorted by index, so ci <= ck for i <= k
-                pm_atomic_add(g_ss + (int64_t)ci * H + ck, s_ass[p] * nf);
-                pm_atomic_add(g_szsz + (int64_t)ci * H + ck, s_aszsz[p] * nf);
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            double kap = 0.0, il = 0.0;
+            if (h < H) {
+                kap = (av1[i] - s_gm[h]) * s_kl[h] + s_mu[h];
+                il = s_ilam[h];
             }
+            xsz[i] = xs[i] * kap;
+            // singles contribute to the diagonals of sum xpt_ss / xpt_szsz (multi-cause diagonal terms went
+            // through the block atomics above)
+            if (live) dszsz[i] += xs[i] * (kap * kap + il) * nf;
         }
+        for (int k = 0; k < Hp; ++k) {
+            const int c = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc);
+            const double as = s_as[k], asz = s_asz[k];
+            const bool mine = (c & 15) == j;
 #pragma unroll
-        for (int k = 0; k < PM_MAX_HPRIME; ++k) {
-            if (k < Hp) {
-                const int c = cpos[k];
-                if ((c & 15) == j) {
-                    const double as = s_as[k], asz = s_asz[k];
-#pragma unroll
-                    for (int i = 0; i < VPL; ++i)
-                        if ((c >> 4) == i) {
-                            xs[i] += as;
-                            xsz[i] += asz;
-                        }
+            for (int i = 0; i < VPL; ++i)
+                if (mine && (c >> 4) == i) {
+                    xs[i] += as;
+                    xsz[i] += asz;
                 }
-            }
         }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
             if (live && h < H) {
-                // singles contribute to the diagonals of sum xpt_ss / xpt_szsz (multi-cause diagonal
-                // terms went through the block atomics above)
-                const double ps = xs[i] * nf;
-                xpt_s[n * ldx + h] = ps;
+                xpt_s[n * ldx + h] = xs[i] * nf;
                 xpt_sz[n * ldx + h] = xsz[i] * nf;
-                cs[i] += ps;
-                csz[i] += xsz[i] * nf;
-                dszsz[i] += qzz[i] * nf;
             }
         }
+        myc_prev = myc;
+        nf_prev = nf;
+        pend = live;
         g_sync();
     }
+    flush_pairs(false);
 
-    // flush per-lane column sums / singleton diagonals: lanes of different rows / waves own the same latent, so
-    // fold them in LDS first (the parameter tables are dead by now: s_c0 takes the xpt_szsz diagonal) and send
-    // ONE global atomic per latent and block -- a per-lane flush puts 256 * VPL atomics per block on H addresses
-    // and serialises the whole grid's tail on them.
+    // flush the singleton diagonal of sum xpt_szsz: lanes of different rows / waves own the same latent, so fold
+    // them in LDS first (the parameter tables are dead by now) and send ONE global atomic per latent and block --
+    // a per-lane flush puts 256 * VPL atomics per block on H addresses and serialises the grid's tail on them.
     __syncthreads();
     for (int h = tid; h < H; h += 256) s_c0[h] = 0.0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int h = j + 16 * i;
-        // rows of the wave first (lanes j, j+16, j+32, j+48), then one LDS atomic per wave and latent
-        const double c_s = g_col_sum(cs[i]), c_sz = g_col_sum(csz[i]), c_d = g_col_sum(dszsz[i]);
-        if (row == 0 && h < H) {
-            atomicAdd(&s_cs[h], c_s);
-            atomicAdd(&s_csz[h], c_sz);
-            atomicAdd(&s_c0[h], c_d);
-        }
+        const double c_d = g_col_sum(dszsz[i]);             // rows of the wave first
+        if (row == 0 && h < H) atomicAdd(&s_c0[h], c_d);
     }
     __syncthreads();
-    double *g_cs = stats + 2 * (int64_t)H * H, *g_csz = g_cs + H, *g_dszsz = g_csz + H;
-    for (int h = tid; h < H; h += 256) {
-        if (s_cs[h] != 0.0) pm_atomic_add(g_cs + h, s_cs[h]);
-        if (s_csz[h] != 0.0) pm_atomic_add(g_csz + h, s_csz[h]);
+    double *g_dszsz = stats + 2 * (int64_t)H * H + 2 * H;
+    for (int h = tid; h < H; h += 256)
         if (s_c0[h] != 0.0) pm_atomic_add(g_dszsz + h, s_c0[h]);
+}
+
+// stats[0 .. 2 H^2) += the seven per-XCD copies behind the documented layout
+__global__ __launch_bounds__(256) void gsc_fold_kernel(double *__restrict__ stats, int64_t HH2, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HH2) return;
+    double a = stats[i];
+#pragma unroll
+    for (int c = 0; c < PM_GSC_XCD_COPIES - 1; ++c) {
+        a += stats[base + (int64_t)c * HH2 + i];
+        stats[base + (int64_t)c * HH2 + i] = 0.0;      // a later call accumulating into the same buffer starts clean
+    }
+    stats[i] = a;
+}
+
+// Column sums of xpt_s and xpt_sz (N,H) into stats[2 H^2 ..) : one block per slab of rows, threads over columns.
+__global__ __launch_bounds__(256) void gsc_colsum_kernel(const double *__restrict__ xpt_s,
+                                                         const double *__restrict__ xpt_sz, int64_t ldx, int64_t N,
+                                                         int H, int64_t rows_per_block, double *__restrict__ g_cs,
+                                                         double *__restrict__ g_csz) {
+    __shared__ double s_part[2][256];
+    const int tid = threadIdx.x;
+    const int cols = H < 256 ? H : 256;                     // columns walked at once
+    const int lanes_r = 256 / cols;                         // row-parallel groups inside the block (H <= 128)
+    const int c = tid % cols, rr = tid / cols;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+    for (int h0 = 0; h0 < H; h0 += cols) {
+        const int h = h0 + c;
+        double a = 0.0, b = 0.0;
+        if (h < H && rr < lanes_r)
+            for (int64_t r = r0 + rr; r < r1; r += lanes_r) {
+                a += xpt_s[r * ldx + h];
+                b += xpt_sz[r * ldx + h];
+            }
+        s_part[0][tid] = a;
+        s_part[1][tid] = b;
+        __syncthreads();
+        if (tid < cols && h0 + tid < H) {
+            double sa = 0.0, sb = 0.0;
+            for (int q = 0; q < lanes_r; ++q) {
+                sa += s_part[0][q * cols + tid];
+                sb += s_part[1][q * cols + tid];
+            }
+            if (sa != 0.0) pm_atomic_add(g_cs + h0 + tid, sa);
+            if (sb != 0.0) pm_atomic_add(g_csz + h0 + tid, sb);
+        }
+        __syncthreads();
     }
 }
 
@@ -442,12 +526,20 @@ static int allow_lds_gsc(const void *kernel, size_t bytes) {
 
 }  // namespace
 
-extern "C" int64_t pm_gsc_stats_len(int64_t H) { return 2 * H * H + 3 * H; }
+extern "C" int64_t pm_gsc_stats_len(int64_t H) { return 2 * H * H + 3 * H + (PM_GSC_XCD_COPIES - 1) * 2 * H * H; }
+
+static size_t gsc_shmem(int64_t H, int64_t Hprime, int64_t S) {
+    return sizeof(double) * (8 * H + ROWS * (48 + 4 * Hprime * Hprime) + (S + 3) / 4);
+}
 
 extern "C" int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma) {
     if (H <= 0 || H > 512 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || Hprime > H || gamma < 1 || gamma > 4) return 0;
-    const size_t shmem = sizeof(double) * (10 * H + ROWS * (48 + 4 * Hprime * Hprime));
-    return shmem <= 64 * 1024 ? 1 : 0;
+    int64_t S = 0, c = Hprime;                       // multi-cause states: sum_{g=2..gamma} C(H', g)
+    for (int64_t g = 2; g <= gamma && g <= Hprime; ++g) {
+        c = c * (Hprime - g + 1) / g;
+        S += c;
+    }
+    return gsc_shmem(H, Hprime, S) <= 64 * 1024 ? 1 : 0;
 }
 
 extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
@@ -462,7 +554,8 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
     if (!pm_gsc_supported(H, Hprime, gamma)) return PM_ERANGE;
     GscTables T{tables, tables + H, tables + 2 * H, tables + 3 * H, tables + 4 * H, tables + 5 * H, tables + 6 * H,
                 tables + 7 * H};
-    const size_t shmem = sizeof(double) * (10 * H + ROWS * (48 + 4 * Hprime * Hprime));
+    const size_t shmem = gsc_shmem(H, Hprime, S);
+    if (shmem > 64 * 1024) return PM_ERANGE;
     int64_t groups = (N + ROWS - 1) / ROWS;
     if (groups > 2048) groups = 2048;
     dim3 grid((unsigned)groups), block(256);
@@ -489,5 +582,15 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
     else PM_BY_G(32);
 #undef PM_BY_G
 #undef PM_LAUNCH
+    {
+        const int64_t rows_per_block = 256;
+        const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
+        double *g_cs = stats + 2 * H * H;
+        const int64_t HH2 = 2 * H * H;
+        hipLaunchKernelGGL(gsc_fold_kernel, dim3((unsigned)((HH2 + 255) / 256)), dim3(256), 0, s, stats, HH2,
+                           HH2 + 3 * H);
+        hipLaunchKernelGGL(gsc_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xpt_s, xpt_sz, ldx, N, (int)H,
+                           rows_per_block, g_cs, g_cs + H);
+    }
     return (int)hipGetLastError();
 }

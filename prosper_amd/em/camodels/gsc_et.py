@@ -279,7 +279,7 @@ class GSC(DeviceCAModel):
         st = stats
         U_ss = st[:H * H].view(H, H)
         U_zz = st[H * H:2 * H * H].view(H, H)
-        cs, csz, dzz = st[2 * H * H:2 * H * H + H], st[2 * H * H + H:2 * H * H + 2 * H], st[2 * H * H + 2 * H:]
+        cs, csz, dzz = (st[2 * H * H + i * H:2 * H * H + (i + 1) * H] for i in range(3))   # per-XCD scratch follows
         off = torch.triu(U_ss, 1)
         sum_ss = off + off.t() + torch.diag(cs)                            # diag(sum xpt_ss) = sum xpt_s
         offz = torch.triu(U_zz, 1)
@@ -325,8 +325,9 @@ class GSC(DeviceCAModel):
         packed[o:o + nHH] = sum_ss.reshape(-1)
         packed[o + nHH:o + 2 * nHH] = sum_zz.reshape(-1)
         o2 = o + 2 * nHH
-        packed[o2:o2 + H] = xs.sum(dim=0)
-        packed[o2 + H:o2 + 2 * H] = xsz.sum(dim=0)
+        sums = suff_stats.get('_sums')               # column sums from the E-step kernel, when it made suff_stats
+        packed[o2:o2 + H] = sums[0] if sums is not None else xs.sum(dim=0)
+        packed[o2 + H:o2 + 2 * H] = sums[1] if sums is not None else xsz.sum(dim=0)
         packed[o2 + 2 * H] = res["ynorm2"].sum()
         comm.allreduce_device(packed)      # replaces gsc_et.py:608-610,620,668,671,713
         data_sq = self._data_second_moment(res) if 'sigma_sq' in self.to_learn else None
