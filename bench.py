@@ -52,11 +52,14 @@ def parse():
 def other_models(dev, Anneal, steps=8):
     """EM-iteration wall-clock of the other §8(a) models at BASELINE configs 4 and 5 (one GPU's share), after the
     headline timing: GSC D=256 H=128 H'=6 gamma=3 N=200k, MCA D=256 H=128 H'=8 gamma=3 N=100k.  Informational."""
+    import gc
     import numpy as np
     import torch
     from prosper_amd.em.camodels.gsc_et import GSC
     from prosper_amd.em.camodels.mca_et import MCA_ET
     out = {}
+    gc.collect()
+    gc.disable()               # as in the headline loops: a full collection is a ~70-80 ms host stall
     try:
         Dm, Hm = 256, 128
         g = torch.Generator(device=dev).manual_seed(3)
@@ -105,6 +108,7 @@ def other_models(dev, Anneal, steps=8):
         out["mca_c5"] = "MCA_ET D=256 H=128 H'=8 gamma=3, N=%d (one GPU's share of 800k)" % N
     except Exception as e:   # never lose the headline over the side measurements
         out["error"] = repr(e)
+    gc.enable()
     return out
 
 

@@ -208,7 +208,10 @@ int pm_mca_estep_f64(const double *scores, int64_t lds, const double *wnorm2, co
 
 /* Packed MCA statistics (float64): [ G1 = Q1^T.Y (H*D) | Wp_multi (H*D) | Wq_multi (H*D) |
  * q1sum (H) | scalars: sum E|s| (pi), sum_nk q e (sigma), sum lse1 (Q), kept count ].
- * Wp = G1 * W^2 + Wp_multi, Wq = q1sum (x) 1 * W^2 + Wq_multi (mca_et.py:293-321). */
+ * Wp = G1 * W^2 + Wp_multi, Wq = q1sum (x) 1 * W^2 + Wq_multi (mca_et.py:293-321).
+ * Those 3*H*D + H + 4 entries are the result (and what a multi-GPU job all-reduces); pm_mca_stats_len also
+ * counts a scratch tail of 7 * 2*H*D entries: the kernels accumulate [Wp_multi | Wq_multi] once per XCD (one L2
+ * each) and fold the copies into the documented slot, clearing the tail, before they return. */
 #define PM_MCA_NSCALARS 4
 int64_t pm_mca_stats_len(int64_t H, int64_t D);
 

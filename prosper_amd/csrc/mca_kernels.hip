@@ -23,6 +23,9 @@
 #include "prosper_hip.h"
 #include "pm_common.h"
 
+// documented part of the statistics buffer; the per-XCD copies of [Wp | Wq] follow it (pm_common.h)
+__host__ __device__ static inline int64_t mca_stats_base(int64_t H, int64_t D) { return 3 * H * D + H + PM_MCA_NSCALARS; }
+
 namespace {
 
 __device__ __forceinline__ void wave_sync_lds() {
@@ -246,8 +249,9 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
     for (int h = tid; h < H; h += blockDim.x) s_q1sum[h] = 0.0;
     __syncthreads();
 
-    double *Wp = stats + (int64_t)H * D;
-    double *Wq = stats + 2 * (int64_t)H * D;
+    // multi-cause numerator / denominator: this XCD's copy (pm_common.h), folded by the launcher
+    double *Wp = pm_xcd_copy(stats + (int64_t)H * D, stats + mca_stats_base(H, D), 2 * (int64_t)H * D);
+    double *Wq = Wp + (int64_t)H * D;
     double st_pi = 0.0, st_sigma = 0.0, st_ld = 0.0, st_cnt = 0.0;
 
     const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
@@ -474,8 +478,10 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
     for (int h = tid; h < H; h += blockDim.x) s_q1sum[h] = 0.0;
     __syncthreads();
 
-    double *Wp = stats + (int64_t)H * D;       // multi-cause numerator   (stats[0 .. H*D) = Q1^T Y by the GEMM)
-    double *Wq = stats + 2 * (int64_t)H * D;   // multi-cause denominator
+    // multi-cause numerator / denominator (stats[0 .. H*D) = Q1^T Y by the GEMM): this XCD's copy, folded by
+    // the launcher
+    double *Wp = pm_xcd_copy(stats + (int64_t)H * D, stats + mca_stats_base(H, D), 2 * (int64_t)H * D);
+    double *Wq = Wp + (int64_t)H * D;
     // W_new = Wp / Wq is an ELEMENT-wise ratio (mca_et.py:348): an element (h,d) can be dominated by a
     // state of vanishing posterior whose factor (W_hd / Wbar_sd)^(rho-1) is ~1 while the likely states'
     // factors are ~1e-100 there.  Only weights that underflow to exactly 0 -- as they do in the
@@ -657,7 +663,15 @@ inline int64_t grid_waves(int64_t N, int waves) {
 
 }  // namespace
 
-extern "C" int64_t pm_mca_stats_len(int64_t H, int64_t D) { return 3 * H * D + H + PM_MCA_NSCALARS; }
+extern "C" int64_t pm_mca_stats_len(int64_t H, int64_t D) {
+    return mca_stats_base(H, D) + (PM_XCD_COPIES - 1) * 2 * H * D;
+}
+
+static void mca_fold(double *stats, int64_t H, int64_t D, hipStream_t s) {
+    const int64_t len = 2 * H * D;
+    hipLaunchKernelGGL(pm_fold_copies_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, stats + H * D,
+                       stats + mca_stats_base(H, D), len);
+}
 
 extern "C" int pm_mca_select_scores_f64(const double *Y, int64_t ldy, const double *W, int64_t ldw, double *R,
                                         int64_t ldr, int64_t N, int64_t H, int64_t D, void *stream) {
@@ -767,7 +781,8 @@ extern "C" int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
 #undef PM_ARGS
         if (rc) return rc;
     }
-    return PM_OK;
+    mca_fold(stats, H, D, s);
+    return (int)hipGetLastError();
 }
 
 namespace {
@@ -820,11 +835,15 @@ extern "C" int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PM_ARGS (int)Hprime, grid, block, shmem, s, scores, lds, wnorm2, ynorm2, Y, ldy, Wrho, Wrm1, cand, state_masks, \
                 (int)S, *params_host, N, (int)H, (int)D, logpj, ldl, lse1, lseb, q1, ldq, stats
+    int rc;
     switch (dpl) {
-        case 1: return sgn ? launch_fused_hp<1, true>(PM_ARGS) : launch_fused_hp<1, false>(PM_ARGS);
-        case 2: return sgn ? launch_fused_hp<2, true>(PM_ARGS) : launch_fused_hp<2, false>(PM_ARGS);
-        case 4: return sgn ? launch_fused_hp<4, true>(PM_ARGS) : launch_fused_hp<4, false>(PM_ARGS);
-        default: return sgn ? launch_fused_hp<8, true>(PM_ARGS) : launch_fused_hp<8, false>(PM_ARGS);
+        case 1: rc = sgn ? launch_fused_hp<1, true>(PM_ARGS) : launch_fused_hp<1, false>(PM_ARGS); break;
+        case 2: rc = sgn ? launch_fused_hp<2, true>(PM_ARGS) : launch_fused_hp<2, false>(PM_ARGS); break;
+        case 4: rc = sgn ? launch_fused_hp<4, true>(PM_ARGS) : launch_fused_hp<4, false>(PM_ARGS); break;
+        default: rc = sgn ? launch_fused_hp<8, true>(PM_ARGS) : launch_fused_hp<8, false>(PM_ARGS); break;
     }
 #undef PM_ARGS
+    if (rc) return rc;
+    mca_fold(stats, H, D, s);
+    return (int)hipGetLastError();
 }

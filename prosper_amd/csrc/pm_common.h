@@ -13,6 +13,33 @@ __device__ __forceinline__ void pm_atomic_add(double *p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// MI355X has 8 XCDs with one L2 each.  f64 atomics from all of them on the same few thousand lines bounce those
+// lines between the L2s; hot (H,H) / (H,D) accumulators are therefore kept once per XCD -- copy 0 in the
+// documented slot, copies 1..7 in a scratch tail of the statistics buffer -- and folded by pm_fold_copies_kernel.
+#define PM_XCD_COPIES 8
+__device__ __forceinline__ int pm_xcc_id() {
+    return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (PM_XCD_COPIES - 1));   // HW_REG_XCC_ID[3:0]
+}
+// this XCD's copy of an accumulator region of `len` doubles: `slot` for XCD 0, else tail + (xcc - 1) * len
+__device__ __forceinline__ double *pm_xcd_copy(double *slot, double *tail, int64_t len) {
+    const int x = pm_xcc_id();
+    return x == 0 ? slot : tail + (int64_t)(x - 1) * len;
+}
+// slot[0 .. len) += the seven tail copies, which are cleared (a later call accumulating into the same buffer
+// starts clean)
+static __global__ __launch_bounds__(256) void pm_fold_copies_kernel(double *__restrict__ slot,
+                                                                     double *__restrict__ tail, int64_t len) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    double a = slot[i];
+#pragma unroll
+    for (int c = 0; c < PM_XCD_COPIES - 1; ++c) {
+        a += tail[(int64_t)c * len + i];
+        tail[(int64_t)c * len + i] = 0.0;
+    }
+    slot[i] = a;
+}
+
 __device__ __forceinline__ double pm_wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, PM_WAVE);

@@ -231,6 +231,7 @@ class MCA_ET(DeviceCAModel):
         if my_N:
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(q1), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N,
                        self._stream())
+        stats = stats[:3 * H * D + H + 4]   # the per-XCD scratch tail is already folded in (and zero)
         comm.allreduce_device(stats)      # replaces mca_et.py:208,253,340,341,357,366,371
         return self._finalize(stats, model_params, par, A_pi_gamma, B_pi_gamma)
 

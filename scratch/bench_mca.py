@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from prosper_amd.em.camodels.mca_et import MCA_ET
 from prosper_amd.em.camodels._device import KernelTimer
 D,H,HP,GAMMA,N=256,128,8,3,100000

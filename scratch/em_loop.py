@@ -1,6 +1,6 @@
 """8 EM iterations of BSC config 2 (for rocprofv3 --kernel-trace --memory-copy-trace timelines)."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from prosper_amd.em.camodels.bsc_et import BSC_ET
 D,H,HP,GAMMA,N = 1024,256,8,4,200000
 dev=torch.device('cuda',0)
@@ -27,3 +27,9 @@ for _ in range(8):
     q=m.step(an,q,data)
 torch.cuda.synchronize()
 print("ms/iter", (time.perf_counter()-t)/8*1e3)
+from prosper_amd.em.camodels._device import KernelTimer
+m.timer = KernelTimer()
+for _ in range(4):
+    q = m.step(an, q, data)
+torch.cuda.synchronize()
+print({k: round(v[1], 3) for k, v in m.timer.summary().items()})
