@@ -24,3 +24,9 @@ for _ in range(10):
     m._run(1.0, p, res, None)
 torch.cuda.synchronize()
 print({k: round(v[1], 3) for k, v in m.timer.summary().items()})
+cand = m._run(1.0, p, res, None)[0]
+m.timer = KernelTimer()
+for _ in range(10):
+    m._run(1.0, p, res, cand)
+torch.cuda.synchronize()
+print("given candidates:", {k: round(v[1], 3) for k, v in m.timer.summary().items()})
