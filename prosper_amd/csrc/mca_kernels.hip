@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
 
         for (int s = 0; s < S; ++s) {
             const unsigned mask = masks[s];  // wave-uniform
-            double T[DPL], wbar[DPL];
+            double T[DPL], wbar[DPL];   // wbar holds r = |T|^(1/rho - 1)
 #pragma unroll
             for (int i = 0; i < DPL; ++i) T[i] = 0.0;
 #pragma unroll
@@ -297,8 +297,12 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
             double part = 0.0;
 #pragma unroll
             for (int i = 0; i < DPL; ++i) {
-                wbar[i] = pm_pow_pos(fabs(T[i]), P.inv_rho);          // |Wbar|
-                const double df = copysign(wbar[i], T[i]) - y[i];
+                // ONE power per element: r = |T|^(1/rho - 1) gives |Wbar| = |T| r here and Wbar / T = r for the
+                // M-step weights below (no division).  Padding dimensions have T = 0: Wbar = 0.
+                const double aT = fabs(T[i]);
+                wbar[i] = pm_pow_pos(aT, P.inv_rho - 1.0);
+                const double wb = (aT > 0.0) ? aT * wbar[i] : 0.0;
+                const double df = copysign(wb, T[i]) - y[i];
                 part = fma(df, df, part);
             }
             part = pm_wave_sum_dpp(part);                               // wave-uniform
@@ -318,8 +322,8 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
             for (int i = 0; i < DPL; ++i) {
                 const double aT = fabs(T[i]);
                 // padding dimensions have T = 0: contribute nothing (never scattered)
-                if (!SIGNED) v[i] = (aT > 0.0) ? w * pm_div_pos(wbar[i], aT) : 0.0;
-                else v[i] = (aT > 0.0) ? w * pm_div_pos(wbar[i], aT) : INFINITY;
+                if (!SIGNED) v[i] = (aT > 0.0) ? w * wbar[i] : 0.0;
+                else v[i] = (aT > 0.0) ? w * wbar[i] : INFINITY;
             }
 #pragma unroll
             for (int j = 0; j < HP; ++j)
