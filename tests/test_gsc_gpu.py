@@ -129,3 +129,63 @@ def test_gsc_noise_types_match_oracle(kind, D, H, Hp, gamma, N, T):
     for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
         np.testing.assert_allclose(new[k], ref[k], rtol=tol, atol=tol * max(1.0, np.abs(ref[k]).max()), err_msg=k)
     assert np.shape(new["sigma_sq"]) == ((D,) if kind == "diagonal" else (D, D))
+
+
+# ------------------------------------------------------------------------- config-4 properties
+def test_config4_properties():
+    """BASELINE config 4 dims (D=256 H=128 H'=6 gamma=3) at N = 30000 (every XCD holds datapoints, so the
+    per-XCD accumulator copies and their fold are exercised): properties that need no oracle -- candidates are
+    the H' best component scores, moments are additive over shards (what the all-reduce relies on), the
+    sums the kernel reports equal the sums of what it wrote, posteriors are probabilities."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    dev = torch.device("cuda", 0)
+    D, H, Hp, gamma, N = 256, 128, 6, 3, 30000
+    gen = torch.Generator(device=dev).manual_seed(4)
+    W_gt = torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64)
+    S = (torch.rand(N, H, generator=gen, device=dev) < 2.0 / H).to(torch.float64)
+    Z = S * (1.5 + torch.randn(N, H, generator=gen, device=dev, dtype=torch.float64))
+    Y = Z @ W_gt.t() + torch.randn(N, D, generator=gen, device=dev, dtype=torch.float64)
+    rng = np.random.RandomState(4)
+    p = {"W": W_gt.cpu().numpy() + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.4),
+         "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+    an = _An(T=1.0)
+    m = GSC(D, H, Hp, gamma, 'scalar')
+    data = m.select_Hprimes(p, {"y": Y})
+    ss = m.E_step(an, p, data)
+    xs, xsz = ss["xpt_s"].tensor, ss["xpt_sz"].tensor
+    sum_ss, sum_zz = ss["xpt_ss"].sum(axis=0), ss["xpt_szsz"].sum(axis=0)
+    cand = data["candidates"].tensor.long()
+    assert cand.shape == (N, Hp) and (cand[:, 1:] > cand[:, :-1]).all()          # sorted by index, distinct
+
+    # (1) posteriors are probabilities; the diagonal of sum xpt_ss is the column sum of xpt_s (s_h^2 = s_h)
+    assert (xs >= 0).all() and (xs <= 1 + 1e-12).all() and torch.isfinite(xsz).all()
+    torch.testing.assert_close(torch.diagonal(sum_ss), xs.sum(0), rtol=1e-11, atol=1e-9)
+    torch.testing.assert_close(ss["_sums"][0], xs.sum(0), rtol=1e-11, atol=1e-9)
+    torch.testing.assert_close(ss["_sums"][1], xsz.sum(0), rtol=1e-11, atol=1e-9)
+    # (2) second moments: symmetric, positive semi-definite, off-diagonal mass only between co-candidates
+    torch.testing.assert_close(sum_ss, sum_ss.t(), rtol=0, atol=0)
+    torch.testing.assert_close(sum_zz, sum_zz.t(), rtol=0, atol=0)
+    assert torch.linalg.eigvalsh(sum_zz).min().item() > -1e-8 * sum_zz.abs().max().item()
+    co = torch.zeros(H, H, dtype=torch.bool, device=dev)
+    co[cand[:, :, None].expand(N, Hp, Hp).reshape(-1), cand[:, None, :].expand(N, Hp, Hp).reshape(-1)] = True
+    assert (sum_ss[~co] == 0).all() and (sum_zz[~co] == 0).all()
+    # (3) outside the candidates a latent only has its singleton state: tiny but positive posterior
+    assert (xs > 0).all()
+    # (4) additivity over shards
+    acc_ss, acc_zz = torch.zeros_like(sum_ss), torch.zeros_like(sum_zz)
+    half = N // 2 + 5
+    for sl in (slice(0, half), slice(half, N)):
+        m2 = GSC(D, H, Hp, gamma, 'scalar')
+        d2 = m2.select_Hprimes(p, {"y": Y[sl].contiguous()})
+        s2 = m2.E_step(an, p, d2)
+        # per datapoint up to the rounding of its scores (another GEMM tiling for another shard length; the weights
+        # are exp(log-joint) with |log-joint| ~ 1e3, so one ulp in a score is ~1e-12 relative in a weight)
+        torch.testing.assert_close(s2["xpt_s"].tensor, xs[sl], rtol=1e-9, atol=1e-300)
+        acc_ss += s2["xpt_ss"].sum(axis=0)
+        acc_zz += s2["xpt_szsz"].sum(axis=0)
+    torch.testing.assert_close(acc_ss, sum_ss, rtol=1e-10, atol=1e-10)
+    torch.testing.assert_close(acc_zz, sum_zz, rtol=1e-10, atol=1e-10)
+    # (5) the update keeps the parameters sane and near the generating ones
+    new = m.M_step(an, p, ss, data)
+    assert np.isfinite(new["W"]).all() and (new["pi"] > 0).all() and (new["pi"] < 1).all() and new["sigma_sq"] > 0
+    assert np.abs(new["W"] - W_gt.cpu().numpy()).mean() < 0.2 and abs(new["pi"].mean() * H - 2.0) < 0.5

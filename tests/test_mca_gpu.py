@@ -135,3 +135,60 @@ def test_fused_estep_statistics_match_two_pass(cls_name, D, H, Hp, gamma, N):
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-12, atol=1e-10)
     for k in ("W", "pi", "sigma", "Q"):
         np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------------- config-5 properties
+def test_config5_properties():
+    """BASELINE config 5 dims (D=256 H=128 H'=8 gamma=3) at N = 6000, fused E+M pass (per-XCD copies of Wp/Wq and
+    their fold): candidates are the H' smallest distances, log-evidences are the log-sum-exp of the rows, the
+    packed statistics are additive over shards, the fused and the two-pass route agree."""
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    dev = torch.device("cuda", 0)
+    D, H, Hp, gamma, N = 256, 128, 8, 3, 6000
+    gen = torch.Generator(device=dev).manual_seed(5)
+    W_gt = torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64).abs() * 2 + 0.1
+    S = torch.rand(N, H, generator=gen, device=dev) < 2.0 / H
+    Y = torch.where(S[:, None, :], W_gt[None, :, :].expand(N, D, H),
+                    torch.zeros((), dtype=torch.float64, device=dev)).max(dim=2).values
+    Y = Y + torch.randn(N, D, generator=gen, device=dev, dtype=torch.float64)
+    W0 = (W_gt * (1 + 0.1 * (2 * torch.rand(D, H, generator=gen, device=dev, dtype=torch.float64) - 1))).cpu().numpy()
+    p = {"W": W0, "pi": 2.0 / H, "sigma": 1.0}
+    an = _An(T=1.2)
+
+    def run(rows, fuse):
+        m = MCA_ET(D, H, Hp, gamma)
+        m.fuse_em = fuse
+        data = m.select_Hprimes(p, {"y": Y[rows].contiguous()})
+        ss = m.E_step(an, p, data)
+        fz = ss["logpj"].fused
+        assert (fz is not None) == fuse
+        buf = fz["stats"] if fuse else None                 # M_step completes (G1 GEMM) and all-reduces it in place
+        new = m.M_step(an, p, ss, data)
+        if buf is None:
+            buf = m._ws["mca_stats"]
+        n_doc = 3 * H * D + H + 4
+        assert (buf[n_doc:] == 0).all()                     # per-XCD scratch: folded and cleared
+        return data, ss, new, buf[:n_doc].clone(), m
+
+    data, ss, new, stats_all, m = run(slice(0, N), True)
+    cand = data["candidates"].tensor.long()
+    Wt = torch.from_numpy(np.ascontiguousarray(W0.T)).to(dev)
+    # (1) candidates: the H' latents with the smallest sum_d max(W_hd - y_d, 0)... as upstream (mca_et.py:90-111)
+    sim = torch.clamp(Wt[None, :, :] - Y[:256, None, :], min=0).sum(-1)
+    top = torch.topk(sim, Hp, dim=1, largest=False).indices
+    assert (torch.sort(top, 1).values == torch.sort(cand[:256], 1).values).float().mean().item() > 0.999
+    # (2) every row of log-joints is finite; its evidence is what the kernel stored
+    logpj = ss["logpj"].tensor
+    assert logpj.shape == (N, 1 + H + 28 + 56) and torch.isfinite(logpj).all()
+    # (3) the documented statistics are additive over shards; the scratch tail is folded and cleared
+    half = N // 2 + 7
+    acc = torch.zeros_like(stats_all)
+    for sl in (slice(0, half), slice(half, N)):
+        acc += run(sl, True)[3]
+    torch.testing.assert_close(acc[:3 * H * D + H], stats_all[:3 * H * D + H], rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(acc[-4:], stats_all[-4:], rtol=1e-11, atol=1e-9)
+    # (4) fused and two-pass agree on the update
+    _, _, new2, stats2, _ = run(slice(0, N), False)
+    for k in ("W", "pi", "sigma", "Q"):
+        np.testing.assert_allclose(new[k], new2[k], rtol=1e-9, atol=1e-12)
+    assert np.isfinite(new["W"]).all() and 0 < new["pi"] < 1 and new["sigma"] > 0
