@@ -23,9 +23,24 @@ class An(dict):
     def as_dict(s): return dict(s)
 m = GSC(Dm, Hm, 6, 3, 'scalar')
 m.timer = KernelTimer()
+import gc, threading
+gc.collect(); gc.disable()
+ev = []
+def prof(frame, event, arg):
+    if event in ("call", "return", "c_call", "c_return"):
+        name = arg.__name__ if event.startswith("c_") else frame.f_code.co_name
+        ev.append((time.perf_counter(), event, name, frame.f_lineno))
 for it in range(12):
     torch.cuda.synchronize(); t = time.perf_counter()
+    ev.clear()
+    sys.setprofile(prof)
     p = m.step(An(T=1.0), p, {"y": Y})
+    sys.setprofile(None)
     torch.cuda.synchronize()
-    print(it, round((time.perf_counter() - t) * 1e3, 2), "sigma_sq", float(p["sigma_sq"]), "pi", float(np.mean(p["pi"])))
+    dt = time.perf_counter() - t
+    print(it, round(dt * 1e3, 2), "threads", threading.active_count())
+    if dt > 0.02 and it > 0:
+        gaps = sorted(((ev[k + 1][0] - ev[k][0], k) for k in range(len(ev) - 1)), reverse=True)[:3]
+        for g, k in gaps:
+            print("GAP %.1f ms between" % (g * 1e3), ev[k][1:], "and", ev[k + 1][1:])
 print({k: (v[0], round(v[1], 3)) for k, v in m.timer.summary().items()})
