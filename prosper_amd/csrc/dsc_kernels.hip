@@ -65,23 +65,30 @@ __global__ __launch_bounds__(256) void tsc_select_scores_kernel(const double *__
     }
 }
 
-// energy of multi-cause state `row` (H' value indices) from the candidate block in LDS
-__device__ __forceinline__ double state_energy(const uint8_t *row, int Hp, const pm_dsc_params &P,
-                                               const double *s_a, const double *s_G, double yn) {
+// energy of multi-cause state `row` (H' value indices) from the candidate block in LDS.  The state's values are
+// gathered first (s_val: the K values in LDS -- indexing the kernel-argument struct per lane compiles to a
+// dependent global load per element), then every position is visited with static register indices; zero values
+// add exact zeros, so the result equals the reference's sum over the non-zero positions bit for bit.
+template <int MAXHP>
+__device__ __forceinline__ double state_energy(const uint8_t *row, int Hp, const double *s_val, const double *s_a,
+                                               const double *s_G, double yn) {
+    double v[MAXHP];
+#pragma unroll
+    for (int j = 0; j < MAXHP; ++j) v[j] = (j < Hp) ? s_val[row[j]] : 0.0;
     double e = yn;
-    for (int j = 0; j < Hp; ++j) {
-        const double vj = P.values[row[j]];
-        if (vj == 0.0) continue;
-        double t = vj * s_G[j * Hp + j] - 2.0 * s_a[j];
-        for (int k = 0; k < j; ++k) {
-            const double vk = P.values[row[k]];
-            if (vk != 0.0) t += 2.0 * vk * s_G[j * Hp + k];
+#pragma unroll
+    for (int j = 0; j < MAXHP; ++j) {
+        if (j < Hp) {
+            double t = v[j] * s_G[j * Hp + j] - 2.0 * s_a[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t += 2.0 * v[k] * s_G[j * Hp + k];
+            e += v[j] * t;
         }
-        e += vj * t;
     }
     return e;
 }
 
+template <int MAXHP>
 __global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
     const double *__restrict__ ynorm2, const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S,
@@ -94,8 +101,10 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
     double *s_a = s_w2 + H + wave * (Hp + Hp * Hp);
     double *s_G = s_a + Hp;
     uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_w2 + H + WAVES * (Hp + Hp * Hp));
+    __shared__ double s_val[PM_DSC_MAX_K];
     for (int h = tid; h < H; h += blockDim.x) s_w2[h] = gram[(int64_t)h * H + h];
     for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
+    if (tid < PM_DSC_MAX_K) s_val[tid] = (tid < P.K) ? P.values[tid] : 0.0;
     __syncthreads();
 
     const int nss = (P.K - 1) * H;
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
             ++c;
         }
         for (int s = lane; s < S; s += 64) {
-            const double e = state_energy(s_tab + s * Hp, Hp, P, s_a, s_G, yn);
+            const double e = state_energy<MAXHP>(s_tab + s * Hp, Hp, s_val, s_a, s_G, yn);
             const double f = P.ecoef * e + P.pscale * prior[base + s];
             out[base + s] = f;
             m = fmax(m, f);
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
     }
 }
 
+template <int MAXHP>
 __global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior,
@@ -168,8 +178,10 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
     double *s_m = s_row + H;
     double *s_B = s_m + Hp;
     uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_scal + 4 + WAVES * per_wave);
+    __shared__ double s_val[PM_DSC_MAX_K];
     for (int h = tid; h < H + PM_DSC_MAX_K + 4; h += blockDim.x) s_qdiag[h] = 0.0;
     for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
+    if (tid < PM_DSC_MAX_K) s_val[tid] = (tid < P.K) ? P.values[tid] : 0.0;
     __syncthreads();
 
     const int nss = (P.K - 1) * H;
@@ -232,17 +244,24 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
             const double q = exp(dl);
             sig += q * ((fsv - P.pscale * prior[base + s]) * inv_ecoef);
             const uint8_t *row = s_tab + s * Hp;
-            for (int j = 0; j < Hp; ++j) {
-                const int kj = row[j];
-                if (kj == P.K0) continue;
-                const double vj = P.values[kj];
+            // the state's value indices and values first (LDS lookups, static register indices), then the scatter
+            int ki[MAXHP];
+            double vv[MAXHP];
 #pragma unroll
-                for (int k = 0; k < PM_DSC_MAX_K; ++k)
-                    if (k == kj) cnt[k] += q;
-                atomicAdd(&s_m[j], q * vj);
-                for (int k2 = j; k2 < Hp; ++k2) {
-                    const int kk = row[k2];
-                    if (kk != P.K0) atomicAdd(&s_B[j * Hp + k2], q * vj * P.values[kk]);
+            for (int j = 0; j < MAXHP; ++j) {
+                ki[j] = (j < Hp) ? (int)row[j] : P.K0;
+                vv[j] = (j < Hp) ? s_val[ki[j]] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < MAXHP; ++j) {
+                if (j < Hp && ki[j] != P.K0) {
+#pragma unroll
+                    for (int k = 0; k < PM_DSC_MAX_K; ++k)
+                        if (k == ki[j]) cnt[k] += q;
+                    atomicAdd(&s_m[j], q * vv[j]);
+#pragma unroll
+                    for (int k2 = j; k2 < MAXHP; ++k2)
+                        if (k2 < Hp && ki[k2] != P.K0) atomicAdd(&s_B[j * Hp + k2], q * vv[j] * vv[k2]);
                 }
             }
         }
@@ -329,10 +348,16 @@ extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double 
     if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
     const size_t shmem = sizeof(double) * (H + WAVES * (Hprime + Hprime * Hprime)) + align8((size_t)S * Hprime);
     if (shmem > 150 * 1024) return PM_ERANGE;
-    if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_estep_kernel), shmem)) return e;
-    hipLaunchKernelGGL(dsc_estep_kernel, dim3(row_grid(N)), dim3(64 * WAVES), shmem, static_cast<hipStream_t>(stream),
-                       scores, lds, gram, ynorm2, cand, state_idx, (int)S, prior, *params_host, N, (int)H, (int)Hprime,
-                       logpj, ldl, lse);
+#define PM_LAUNCH(M)                                                                                                 \
+    do {                                                                                                             \
+        if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_estep_kernel<M>), shmem)) return e;             \
+        hipLaunchKernelGGL(dsc_estep_kernel<M>, dim3(row_grid(N)), dim3(64 * WAVES), shmem,                          \
+                           static_cast<hipStream_t>(stream), scores, lds, gram, ynorm2, cand, state_idx, (int)S, prior, \
+                           *params_host, N, (int)H, (int)Hprime, logpj, ldl, lse);                                   \
+    } while (0)
+    if (Hprime <= 8) PM_LAUNCH(8);
+    else PM_LAUNCH(PM_MAX_HPRIME);
+#undef PM_LAUNCH
     return (int)hipGetLastError();
 }
 
@@ -351,10 +376,16 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
     const size_t shmem = sizeof(double) * (H + PM_DSC_MAX_K + 4 + WAVES * (H + Hprime + Hprime * Hprime)) +
                          align8((size_t)S * Hprime);
     if (shmem > 150 * 1024) return PM_ERANGE;
-    if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows_kernel), shmem)) return e;
-    hipLaunchKernelGGL(dsc_mstep_rows_kernel, dim3(row_grid(N)), dim3(64 * WAVES), shmem,
-                       static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior,
-                       *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats);
+#define PM_LAUNCH(M)                                                                                                 \
+    do {                                                                                                             \
+        if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows_kernel<M>), shmem)) return e;        \
+        hipLaunchKernelGGL(dsc_mstep_rows_kernel<M>, dim3(row_grid(N)), dim3(64 * WAVES), shmem,                     \
+                           static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior, \
+                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats);                        \
+    } while (0)
+    if (Hprime <= 8) PM_LAUNCH(8);
+    else PM_LAUNCH(PM_MAX_HPRIME);
+#undef PM_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 """EM-iteration timing of DSC_ET (ternary) at D=256, H=128, H'=6, gamma=3, N=100k."""
 import sys, time, numpy as np, torch
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from prosper_amd.em.camodels.dsc_et import DSC_ET
 from prosper_amd.em.camodels._device import KernelTimer
 D,H,HP,GAMMA,N=256,128,6,3,100000
