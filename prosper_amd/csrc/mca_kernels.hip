@@ -132,8 +132,12 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
         // multi-cause states: e_s = sum_d (Wbar_sd - y_d)^2.  Padding dimensions hold W^rho = 0 and y = 0:
         // Wbar = 0 there and they add nothing, so the loop body is branch-free and the DPL powers of a
         // lane are independent instruction streams.
+        unsigned mask_next = S > 0 ? masks[0] : 0u;
         for (int s = 0; s < S; ++s) {
-            const unsigned mask = masks[s];  // wave-uniform
+            // wave-uniform; the next state's mask is requested now so that its (vector-memory) latency is covered
+            // by this state's powers instead of stalling the top of the next trip
+            const unsigned mask = mask_next;
+            mask_next = masks[s + 1 < S ? s + 1 : s];
             double T[DPL];
 #pragma unroll
             for (int i = 0; i < DPL; ++i) T[i] = 0.0;
@@ -283,8 +287,12 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
             for (int i = 0; i < DPL; ++i) V[j][i] = 0.0;
         double M = -INFINITY;   // running maximum of beta * f_s over the multi-cause states seen so far
 
+        unsigned mask_next = S > 0 ? masks[0] : 0u;
         for (int s = 0; s < S; ++s) {
-            const unsigned mask = masks[s];  // wave-uniform
+            // wave-uniform; the next state's mask is requested now so that its (vector-memory) latency is covered
+            // by this state's powers instead of stalling the top of the next trip
+            const unsigned mask = mask_next;
+            mask_next = masks[s + 1 < S ? s + 1 : s];
             double T[DPL], wbar[DPL];   // wbar holds r = |T|^(1/rho - 1)
 #pragma unroll
             for (int i = 0; i < DPL; ++i) T[i] = 0.0;
