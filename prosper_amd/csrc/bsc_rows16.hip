@@ -86,7 +86,7 @@ struct SizeOffsets {  // multi-cause states of size g occupy [off[g-2], off[g-1]
 //               distance |W_h|^2 - 2 a_h (MMCA, mmca_et.py:119-120)
 // ---------------------------------------------------------------------------------------------
 template <int VPL>
-__global__ __launch_bounds__(256, VPL <= 16 ? 4 : 2) void bsc_select_estep16_kernel(
+__global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_select_estep16_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
     const double *__restrict__ ynorm2, const double *__restrict__ wmu, const double *__restrict__ ymu,
     const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents, SizeOffsets so, int S, int gamma,
