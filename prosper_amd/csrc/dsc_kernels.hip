@@ -89,7 +89,7 @@ __device__ __forceinline__ double state_energy(const uint8_t *row, int Hp, const
 }
 
 template <int MAXHP>
-__global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
+__global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
     const double *__restrict__ ynorm2, const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S,
     const double *__restrict__ prior, pm_dsc_params P, int64_t N, int H, int Hp, double *__restrict__ logpj,
@@ -161,8 +161,10 @@ __global__ __launch_bounds__(64 * WAVES) void dsc_estep_kernel(
     }
 }
 
+// one wave per datapoint and several dependent memory round trips per datapoint: latency-bound, so waves per SIMD
+// are what counts (4 for H' <= 8)
 template <int MAXHP>
-__global__ __launch_bounds__(64 * WAVES) void dsc_mstep_rows_kernel(
+__global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows_kernel(
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior,
     pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ expect, int64_t lde,
@@ -314,9 +316,12 @@ inline bool bad_params(const pm_dsc_params *P) {
     return !P || P->K < 2 || P->K > PM_DSC_MAX_K || P->K0 < 0 || P->K0 >= P->K || P->values[P->K0] != 0.0;
 }
 
-inline unsigned row_grid(int64_t N) {
+// one round of resident workgroups (the kernels stride over the datapoints): `per_cu` workgroups fit a CU at the
+// kernel's register count, and a second, partly filled round would only add a tail
+inline unsigned row_grid(int64_t N, int per_cu) {
     const int64_t blocks = (N + WAVES - 1) / WAVES;
-    return (unsigned)(blocks < 1 ? 1 : blocks > 256 * 8 ? 256 * 8 : blocks);
+    const int64_t cap = 256 * (int64_t)per_cu;
+    return (unsigned)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
 }
 
 }  // namespace
@@ -351,7 +356,7 @@ extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double 
 #define PM_LAUNCH(M)                                                                                                 \
     do {                                                                                                             \
         if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_estep_kernel<M>), shmem)) return e;             \
-        hipLaunchKernelGGL(dsc_estep_kernel<M>, dim3(row_grid(N)), dim3(64 * WAVES), shmem,                          \
+        hipLaunchKernelGGL(dsc_estep_kernel<M>, dim3(row_grid(N, M <= 8 ? 5 : 4)), dim3(64 * WAVES), shmem,            \
                            static_cast<hipStream_t>(stream), scores, lds, gram, ynorm2, cand, state_idx, (int)S, prior, \
                            *params_host, N, (int)H, (int)Hprime, logpj, ldl, lse);                                   \
     } while (0)
@@ -379,7 +384,7 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
 #define PM_LAUNCH(M)                                                                                                 \
     do {                                                                                                             \
         if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows_kernel<M>), shmem)) return e;        \
-        hipLaunchKernelGGL(dsc_mstep_rows_kernel<M>, dim3(row_grid(N)), dim3(64 * WAVES), shmem,                     \
+        hipLaunchKernelGGL(dsc_mstep_rows_kernel<M>, dim3(row_grid(N, M <= 8 ? 4 : 3)), dim3(64 * WAVES), shmem,       \
                            static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior, \
                            *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats);                        \
     } while (0)
