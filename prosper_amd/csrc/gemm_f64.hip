@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *__res
 // position l%4, and fetches k-pair (l%4) ^ ((l/16)%4) of that row -- an XOR swizzle applied on the
 // SOURCE address (the LDS side of an LDS-DMA is linear), undone by the fragment reads, which makes
 // the 16 rows of a ds_read_b64 half-wave hit 16 distinct bank pairs.
-// Per K-step and wavefront: 4 DMA instructions, 16 ds_read_b64, 32 MFMAs, one raw s_barrier placed
+// Per K-step and wavefront: 4 DMA instructions, 8 ds_read_b128, 32 MFMAs, one raw s_barrier placed
 // before the last 16 MFMAs (their operands are already in registers), counted s_waitcnt vmcnt.
 // Rows/columns past M/N are clamped on load (garbage accumulators that are never stored).
 // ---------------------------------------------------------------------------------------------
@@ -256,25 +256,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
         __builtin_amdgcn_global_load_lds(src[3] + k0, dst + 12 * 128, 16, 0, 0);
     };
 
-    // fragment reads: element q = kk*4 + fk of row R sits at R*8 + (((q>>1) ^ ((R>>2)&3)) << 1) + (q&1)
+    // fragment reads.  The two MFMAs of a K-step may take the 8 K-columns in any order as long as A and B agree:
+    // k-group fk of the first MFMA takes column 2 fk, of the second column 2 fk + 1 -- exactly the 16-byte slot
+    // (k-pair fk) the DMA wrote, so ONE ds_read_b128 per 16-row block feeds both MFMAs (8 LDS reads per K-step
+    // and wavefront instead of 16).  Pair p of row R sits at R*8 + ((p ^ ((R>>2)&3)) << 1).
     const int frow = lane & 15, fk = lane >> 4;
     const int sw = (frow >> 2) & 3;
-    int a_off[2], b_off[2];  // per kk
+    const int a_off = (wm * 64 + frow) * DK + ((fk ^ sw) << 1);
+    const int b_off = 128 * DK + (wn * 64 + frow) * DK + ((fk ^ sw) << 1);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    struct Frag {
+        d2 a[4], b[4];
+    };
+    auto fread = [&](int stage, Frag &f) {
+        const double *sa = sm + stage * DSTAGE + a_off;
+        const double *sb = sm + stage * DSTAGE + b_off;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int q = kk * 4 + fk;
-        const int col = (((q >> 1) ^ sw) << 1) + (q & 1);
-        a_off[kk] = (wm * 64 + frow) * DK + col;
-        b_off[kk] = 128 * DK + (wn * 64 + frow) * DK + col;
-    }
-    double fa[2][4], fb[2][4];
-    auto fread = [&](int stage, int kk, int slot) {
-        const double *sa = sm + stage * DSTAGE + a_off[kk];
-        const double *sb = sm + stage * DSTAGE + b_off[kk];
+        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const d2 *>(sa + i * 16 * DK);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[slot][i] = sa[i * 16 * DK];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[slot][j] = sb[j * 16 * DK];
+        for (int j = 0; j < 4; ++j) f.b[j] = *reinterpret_cast<const d2 *>(sb + j * 16 * DK);
     };
 
     d4 acc[4][4];
@@ -295,15 +295,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     else if (nk == 2) PM_WAIT_VMCNT(4);
     else PM_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
-    fread(0, 0, 0);
+    Frag f0, f1;
+    fread(0, f0);
 
-    for (int t = 0; t < nk; ++t) {
+    // one K-step: 16 MFMAs on the first column of every pair, hand-over (barrier, next step's fragments, refill of
+    // the stage just consumed), 16 MFMAs on the second column
+    auto kstep = [&](int t, const Frag &cur, Frag &nxt) {
         const int stage = t & (DSTAGES - 1);
-        fread(stage, 1, 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[0][i], fb[0][j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(cur.a[i].x, cur.b[j].x, acc[i][j]);
         if (t + 1 < nk) {
             // my reads of this stage are done (lgkmcnt) and my share of K-step t+1 has landed (vmcnt);
             // after the barrier that holds for every wavefront: stage t may be refilled, t+1 may be read
@@ -313,13 +315,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
             else if (ahead == 1) PM_WAIT_VMCNT(4);
             else PM_WAIT_VMCNT(0);
             __builtin_amdgcn_s_barrier();
-            fread((t + 1) & (DSTAGES - 1), 0, 0);
+            fread((t + 1) & (DSTAGES - 1), nxt);
             if (t + DSTAGES < nk) dma(t + DSTAGES, stage);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fa[1][i], fb[1][j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(cur.a[i].y, cur.b[j].y, acc[i][j]);
+    };
+    for (int t = 0; t < nk; t += 2) {
+        kstep(t, f0, f1);
+        if (t + 1 < nk) kstep(t + 1, f1, f0);
     }
 
     constexpr bool split = SPLITK;
