@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     __shared__ __attribute__((aligned(1024))) double sm[DSTAGES * DSTAGE];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    // the wavefront index is uniform: say so, and the LDS-DMA destinations (M0) become scalar arithmetic
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its L2).  With two
     // column tiles per row panel, remap so that both tiles of a panel run back-to-back on ONE XCD: the
