@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void bsc_estep_kernel(const double *__restrict
     double *s_wave = s_w2 + H;
     uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_wave + WAVES * (16 + 256));
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     for (int h = tid; h < H; h += 256) s_w2[h] = gram[(int64_t)h * H + h] + (wmu ? 2.0 * wmu[h] : 0.0);
     for (int s = tid; s < S; s += 256) s_masks[s] = masks[s];
     __syncthreads();
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows_kernel(const double *__res
     uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_pptr + npairs + 1);
     uint16_t *s_plist = s_masks + S;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     for (int h = tid; h < H; h += 256) {
         s_qdiag[h] = 0.0;
         s_mus[h] = 0.0;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_sel
     const int dp_stride = 16 + Hp * Hp + S;
     uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_dp + ROWS * dp_stride);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int j = lane & 15, row = lane >> 4;
     for (int h = tid; h < H; h += 256) {
         const double g = gram[(int64_t)h * H + h];
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 1) void bsc_mstep_rows16_kerne
     double *s_red = s_m2all + ROWS * Hp * Hp;
     uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_red + 12);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int j = lane & 15, row = lane >> 4;
     for (int h = tid; h < H; h += 256) {
         s_qdiag[h] = 0.0;

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [ w2 (H) | per wave: a (Hp) G (Hp*Hp) | state table (S*Hp bytes) ]
     double *s_w2 = reinterpret_cast<double *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     double *s_a = s_w2 + H + wave * (Hp + Hp * Hp);
     double *s_G = s_a + Hp;
     uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_w2 + H + WAVES * (Hp + Hp * Hp));

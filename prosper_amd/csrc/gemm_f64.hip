@@ -57,7 +57,7 @@ __device__ __forceinline__ void nt_tile(const double *__restrict__ A, int64_t ld
     constexpr int STAGE = (BM + BN) * NT_LD;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int wm = wave >> 1, wn = wave & 1;
 
     // staging map: thread -> (row = tid/8 + 32 c, k pair = 2 (tid % 8))
@@ -369,7 +369,7 @@ __device__ __forceinline__ void tn_tile(const double *__restrict__ A, int64_t ld
                                         int64_t kend, int m0, int n0, double *sm) {
     constexpr int STAGE = 2 * BK * TN_LD;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int wm = wave >> 1, wn = wave & 1;
 
     // staging map: thread -> (k = tid/64 + 4 c, column pair = 2 (tid % 64)), c = 0..3
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_dma_kernel(const double *_
     const int nk = (int)((kend - kbeg) / DK);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int wm = wave >> 1, wn = wave & 1;
     // this wavefront moves rows {wave, wave + 4} of the A slab and of the B slab of every K-step
     const double *srca = A + (kbeg + wave) * lda + m0 + 2 * lane;

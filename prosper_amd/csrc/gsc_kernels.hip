@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     const int dp_stride = 16 + 4 * HH + 2 * 16;
     double *s_dp = s_tab + 8 * H;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int j = lane & 15, row = lane >> 4;
     for (int h = tid; h < H; h += 256) {
         s_c0[h] = T.c0[h]; s_c1[h] = T.c1[h]; s_gm[h] = T.gm[h]; s_il[h] = T.il[h]; s_kl[h] = T.kl[h];
