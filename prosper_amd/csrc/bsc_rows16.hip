@@ -136,31 +136,41 @@ __global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_sel
         if (do_select) {
             const double sy = 1.0 / sqrt(yn);
             const bool smallest = mode & 4, raw = mode & 8, dist = mode & 16;
-            uint64_t key[VPL];
+            // Ranking keys are DOUBLES whose low 10 mantissa bits carry the latent index (v_max_f64 is one
+            // instruction, a 64-bit integer maximum three; the keys keep 42 mantissa bits either way).  Ties resolve
+            // as a stable argsort would: largest-first keeps the larger index last-best, smallest-first the smaller
+            // index first -- the index code counts up for non-negative keys and down for negative ones, whose
+            // magnitude grows with the low bits.  NaN ranks below every number, +-inf are clamped to the largest
+            // finite magnitudes (their low bits must stay free), -inf itself marks "taken".
+            double key[VPL];
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 const int h = j + 16 * i;
-                uint64_t k = 0;
+                double kx = -INFINITY;
                 if (h < H) {
                     double x = raw ? a[i] : dist ? s_w2[h] - 2.0 * a[i] : a[i] * s_sw[h] * sy;
                     if (smallest) x = -x;
-                    k = (x == x) ? order_key(x) : 0x0000000000000400ull;  // NaN ranks below every number
-                    // low 10 bits carry the latent index; ties resolve as a stable argsort would:
-                    // largest-first keeps the larger index last-best, smallest-first the smaller index first
-                    k = (k & ~0x3FFull) | (uint64_t)(smallest ? 0x3FF - h : h);
-                    if (k < 0x400ull) k |= 0x400ull;       // keep valid keys above the "taken" value 0
+                    uint64_t b = (uint64_t)__double_as_longlong(x);
+                    if (x != x) b = 0xFFEFFFFFFFFFFC00ull;
+                    else if ((b & 0x7FF0000000000000ull) == 0x7FF0000000000000ull)
+                        b = (b & 0x8000000000000000ull) | 0x7FEFFFFFFFFFF800ull;
+                    const uint64_t code = (uint64_t)(smallest ? 0x3FF - h : h);
+                    b = (b & ~0x3FFull) | ((b >> 63) ? 0x3FFull - code : code);
+                    kx = __longlong_as_double((long long)b);
                 }
-                key[i] = k;
+                key[i] = kx;
             }
             for (int r = 0; r < Hp; ++r) {
-                uint64_t m = key[0];
+                double m = key[0];
 #pragma unroll
-                for (int i = 1; i < VPL; ++i) m = umax64(m, key[i]);
-                m = row_max_u64(m);
+                for (int i = 1; i < VPL; ++i) m = __builtin_fmax(m, key[i]);
+                m = row_max_f64(m);
 #pragma unroll
                 for (int i = 0; i < VPL; ++i)
-                    if (key[i] == m) key[i] = 0;
-                const int win = (int)(m & 0x3FFull);
+                    if (key[i] == m) key[i] = -INFINITY;
+                const uint64_t mb = (uint64_t)__double_as_longlong(m);
+                const int code = (int)(mb & 0x3FFull);
+                const int win = (mb >> 63) ? 0x3FF - code : code;
                 if (j == (smallest ? r : Hp - 1 - r)) myc = smallest ? 0x3FF - win : win;
             }
             if (live && j < Hp) cand[n * Hp + j] = myc;
