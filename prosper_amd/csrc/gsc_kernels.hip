@@ -50,6 +50,13 @@ __device__ __forceinline__ uint64_t g_row_max_u64(uint64_t v) {
     o = gdpp64<0x140>(v); v = v > o ? v : o;
     return v;
 }
+__device__ __forceinline__ double g_row_max_f64(double v) {
+    v = __builtin_fmax(v, gdppf<0xB1>(v));
+    v = __builtin_fmax(v, gdppf<0x4E>(v));
+    v = __builtin_fmax(v, gdppf<0x141>(v));
+    v = __builtin_fmax(v, gdppf<0x140>(v));
+    return v;
+}
 __device__ __forceinline__ double g_row_sum(double v) {
     v += gdppf<0xB1>(v);
     v += gdppf<0x4E>(v);
@@ -229,31 +236,35 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         // ---- candidates: top-H' scores, then sorted by latent index (gsc_et.py:726-728)
         int myc = 0;
         if (do_select) {
-            uint64_t key[VPL];
+            // keys are doubles whose low 10 mantissa bits carry the latent index (one v_max_f64 instead of a
+            // three-instruction 64-bit integer maximum; as in bsc_rows16.hip): equal scores resolve towards the
+            // larger index, like the reference's argsort; scores are finite here (clamped above), -inf = taken
+            double key[VPL];
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 const int h = j + 16 * i;
-                uint64_t k = 0;
+                double kx = -INFINITY;
                 if (h < H) {  // singleton log-posterior without prior (gsc_et.py:795-805)
                     const double ai = arow[h];
                     const double bb = ai - s_gm[h];
                     double v = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h];
                     if (v != v || v < fmin_) v = fmin_;
                     if (isinf(v)) v = 0.0;
-                    k = (g_order_key(v) & ~0x3FFull) | (uint64_t)h;
-                    if (k < 0x400ull) k |= 0x400ull;
+                    uint64_t b = (uint64_t)__double_as_longlong(v);
+                    b = (b & ~0x3FFull) | ((b >> 63) ? 0x3FFull - (uint64_t)h : (uint64_t)h);
+                    kx = __longlong_as_double((long long)b);
                 }
-                key[i] = k;
+                key[i] = kx;
             }
             uint64_t mine = 0;                                // this lane's own selected latents, bit i
             for (int r = 0; r < Hp; ++r) {
-                uint64_t m = key[0];
+                double m = key[0];
 #pragma unroll
-                for (int i = 1; i < VPL; ++i) m = m > key[i] ? m : key[i];
-                m = g_row_max_u64(m);
+                for (int i = 1; i < VPL; ++i) m = __builtin_fmax(m, key[i]);
+                m = g_row_max_f64(m);
 #pragma unroll
                 for (int i = 0; i < VPL; ++i)
-                    if (key[i] == m) { key[i] = 0; mine |= 1ull << i; }
+                    if (key[i] == m) { key[i] = -INFINITY; mine |= 1ull << i; }
             }
             // rank of each selected latent among the selected = number of selected latents with a smaller index:
             // latent h = j + 16 i precedes h' = j' + 16 i' iff i < i' or (i == i' and j < j').
