@@ -81,7 +81,8 @@ def test_dsc_step_matches_reference_golden(case):
     (256, 128, 6, 3, 1500, 1.0, 0.0, [-1., 0., 1.]),
     (100, 70, 5, 4, 333, 1.6, 0.6, [0., 1., 2.]),
     (40, 20, 3, 2, 65, 1.0, 1.0, [-2., -1., 0., 1., 2.]),
-    (64, 256, 8, 3, 3000, 1.0, 0.0, [-1., 0., 1.])])
+    (64, 256, 8, 3, 3000, 1.0, 0.0, [-1., 0., 1.]),
+    (48, 24, 10, 2, 130, 1.0, 0.0, [-1., 0., 1.])])       # H' > 8: the 16-wide instantiation of the row kernels
 def test_dsc_step_matches_oracle(D, H, Hp, gamma, N, T, ncut, states):
     from oracle import dsc_oracle as M
     from prosper_amd.em.camodels.dsc_et import DSC_ET
