@@ -64,7 +64,8 @@ def test_gsc_step_matches_reference_golden(case):
     np.testing.assert_allclose(np.asarray(suff2["xpt_sz"]), g["xpt_sz"], rtol=1e-8, atol=1e-12)
 
 
-@pytest.mark.parametrize("D,H,Hp,gamma,N,T", [(256, 128, 6, 3, 1000, 1.0), (60, 50, 5, 4, 333, 1.3), (20, 10, 3, 2, 70, 1.0)])
+@pytest.mark.parametrize("D,H,Hp,gamma,N,T", [(256, 128, 6, 3, 1000, 1.0), (60, 50, 5, 4, 333, 1.3), (20, 10, 3, 2, 70, 1.0),
+                                              (64, 200, 4, 2, 101, 1.0), (40, 40, 8, 2, 90, 1.1)])   # 16 latents per lane; H' = 8
 def test_gsc_step_matches_oracle(D, H, Hp, gamma, N, T):
     from oracle import gsc_oracle as G
     from prosper_amd.em.camodels.gsc_et import GSC
