@@ -48,12 +48,7 @@ __device__ __forceinline__ double dppf64(double v) {
     v = OP(v, F<0x4E>(v));                  \
     v = OP(v, F<0x141>(v));                 \
     v = OP(v, F<0x140>(v));
-__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
 __device__ __forceinline__ double fadd(double a, double b) { return a + b; }
-__device__ __forceinline__ uint64_t row_max_u64(uint64_t v) {
-    PM_ROW_BUTTERFLY(umax64, uint64_t, dpp64)
-    return v;
-}
 __device__ __forceinline__ double row_max_f64(double v) {
     PM_ROW_BUTTERFLY(fmax, double, dppf64)
     return v;
@@ -68,11 +63,6 @@ __device__ __forceinline__ void wave_lds_sync16() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// total order on doubles as unsigned integers (NaN handled by the caller)
-__device__ __forceinline__ uint64_t order_key(double x) {
-    const uint64_t b = (uint64_t)__double_as_longlong(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
 
 struct SizeOffsets {  // multi-cause states of size g occupy [off[g-2], off[g-1]) ; g = 2..gamma
     int off[PM_MAX_HPRIME];

@@ -42,14 +42,6 @@ template <int CTRL>
 __device__ __forceinline__ double gdppf(double v) {
     return __longlong_as_double((long long)gdpp64<CTRL>((uint64_t)__double_as_longlong(v)));
 }
-__device__ __forceinline__ uint64_t g_row_max_u64(uint64_t v) {
-    uint64_t o;
-    o = gdpp64<0xB1>(v); v = v > o ? v : o;
-    o = gdpp64<0x4E>(v); v = v > o ? v : o;
-    o = gdpp64<0x141>(v); v = v > o ? v : o;
-    o = gdpp64<0x140>(v); v = v > o ? v : o;
-    return v;
-}
 __device__ __forceinline__ double g_row_max_f64(double v) {
     v = __builtin_fmax(v, gdppf<0xB1>(v));
     v = __builtin_fmax(v, gdppf<0x4E>(v));
@@ -76,10 +68,6 @@ __device__ __forceinline__ double g_col_sum(double v) {
 __device__ __forceinline__ void g_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ uint64_t g_order_key(double x) {
-    const uint64_t b = (uint64_t)__double_as_longlong(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
 // 1 / x for a normal x of either sign: hardware reciprocal + two Newton steps (full f64 accuracy up to the
@@ -129,9 +117,6 @@ __device__ __forceinline__ void sym_inverse(double (&M)[G][G], LogDet &ld) {
     }
 }
 
-struct GscOffsets {
-    int off[PM_MAX_HPRIME];
-};
 
 // per-latent tables (H doubles each), prepared on the host per EM step
 struct GscTables {

@@ -222,13 +222,6 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
 // moves, like an online softmax) and normalised by exp(M - lse_beta) at the end.  A stored term is never
 // smaller than its final value, so nothing underflows that would survive in the two-pass form.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double pm_div_pos(double a, double b) {   // a / b for normal positive b
-    double r = __builtin_amdgcn_rcp(b);
-    r = fma(fma(-b, r, 1.0), r, r);
-    r = fma(fma(-b, r, 1.0), r, r);
-    const double q = a * r;
-    return fma(fma(-b, q, a), r, q);
-}
 
 template <int DPL, int HP, bool SIGNED>
 __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
