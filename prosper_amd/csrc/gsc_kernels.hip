@@ -27,7 +27,6 @@
 namespace {
 
 constexpr int ROWS = 16;
-constexpr int PM_GSC_XCD_COPIES = 8;   // MI355X: 8 XCDs, one L2 each
 
 template <int CTRL>
 __device__ __forceinline__ unsigned gdpp32(unsigned v) {
@@ -166,11 +165,10 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     __syncthreads();
 
     const double tiny = 2.2250738585072014e-308, fmin_ = -1.7976931348623157e308;
-    // The block sums are accumulated per XCD: every XCD has its own L2, and f64 atomics from eight XCDs on the same
-    // few thousand lines bounce those lines between the L2s (measured: a third of this kernel's time).  Copy 0 is
-    // the caller-visible slot, copies 1..7 sit behind the documented layout; gsc_fold_kernel adds them up.
-    const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);   // HW_REG_XCC_ID[3:0]
-    double *g_ss = xcc == 0 ? stats : stats + (2 * (int64_t)H * H + 3 * H) + (int64_t)(xcc - 1) * 2 * H * H;
+    // The block sums are accumulated per XCD (pm_common.h: f64 atomics from eight XCDs on the same few thousand
+    // lines bounce those lines between the L2s -- measured: a third of this kernel's time).  Copy 0 is the
+    // caller-visible slot, copies 1..7 sit behind the documented layout; the launcher folds them.
+    double *g_ss = pm_xcd_copy(stats, stats + (2 * (int64_t)H * H + 3 * H), 2 * (int64_t)H * H);
     double *g_szsz = g_ss + (int64_t)H * H;
     // the ONLY per-lane state carried across datapoints: the singleton diagonal of sum xpt_szsz.  (diag of
     // sum xpt_ss = column sum of xpt_s; the column sums of xpt_s / xpt_sz come from gsc_colsum_kernel.)  Phases
@@ -466,19 +464,6 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         if (s_c0[h] != 0.0) pm_atomic_add(g_dszsz + h, s_c0[h]);
 }
 
-// stats[0 .. 2 H^2) += the seven per-XCD copies behind the documented layout
-__global__ __launch_bounds__(256) void gsc_fold_kernel(double *__restrict__ stats, int64_t HH2, int64_t base) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= HH2) return;
-    double a = stats[i];
-#pragma unroll
-    for (int c = 0; c < PM_GSC_XCD_COPIES - 1; ++c) {
-        a += stats[base + (int64_t)c * HH2 + i];
-        stats[base + (int64_t)c * HH2 + i] = 0.0;      // a later call accumulating into the same buffer starts clean
-    }
-    stats[i] = a;
-}
-
 // Column sums of xpt_s and xpt_sz (N,H) into stats[2 H^2 ..) : one block per slab of rows, threads over columns.
 __global__ __launch_bounds__(256) void gsc_colsum_kernel(const double *__restrict__ xpt_s,
                                                          const double *__restrict__ xpt_sz, int64_t ldx, int64_t N,
@@ -522,7 +507,7 @@ static int allow_lds_gsc(const void *kernel, size_t bytes) {
 
 }  // namespace
 
-extern "C" int64_t pm_gsc_stats_len(int64_t H) { return 2 * H * H + 3 * H + (PM_GSC_XCD_COPIES - 1) * 2 * H * H; }
+extern "C" int64_t pm_gsc_stats_len(int64_t H) { return 2 * H * H + 3 * H + (PM_XCD_COPIES - 1) * 2 * H * H; }
 
 static size_t gsc_shmem(int64_t H, int64_t Hprime, int64_t S) {
     return sizeof(double) * (8 * H + ROWS * (48 + 4 * Hprime * Hprime) + (S + 3) / 4);
@@ -583,8 +568,8 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
         const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
         double *g_cs = stats + 2 * H * H;
         const int64_t HH2 = 2 * H * H;
-        hipLaunchKernelGGL(gsc_fold_kernel, dim3((unsigned)((HH2 + 255) / 256)), dim3(256), 0, s, stats, HH2,
-                           HH2 + 3 * H);
+        hipLaunchKernelGGL(pm_fold_copies_kernel, dim3((unsigned)((HH2 + 255) / 256)), dim3(256), 0, s, stats,
+                           stats + HH2 + 3 * H, HH2);
         hipLaunchKernelGGL(gsc_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xpt_s, xpt_sz, ldx, N, (int)H,
                            rows_per_block, g_cs, g_cs + H);
     }
