@@ -17,6 +17,7 @@ are handed over as ``SummedMoments`` (their sum over datapoints), never material
 and norms (the kernel then sees sigma^2 = 1).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -68,6 +69,8 @@ class GSC(DeviceCAModel):
         self.sigma_sq_type = sigma_sq_type
         self.dtype_precision = np.float64
         self._masks_dev = None
+        self._seed = None        # next step's W^T / Gram / scores left on the device by M_step (_speculate)
+        self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
 
     # ------------------------------------------------------------------ host-side mirror
     @tracing.traced
@@ -178,8 +181,18 @@ class GSC(DeviceCAModel):
             return par
         Y = res["Y"]
         N, D = Y.shape
-        Wt = self._upload("gsc_W", W).t().contiguous()          # (H, D): rows = latents
-        if sig.ndim == 0:
+        seed, self._seed = self._seed, None
+        scores = None
+        if seed is not None and seed["ykey"] == res["key"] and sig.ndim == 0 and seed["W_host"] is not None \
+                and seed["W_host"].shape == W.shape and np.array_equal(seed["W_host"], W):
+            # the W the last M-step returned: its transpose, Gram matrix and scores are already on the device
+            Wt, G, scores = seed["Wt"], seed["G"], seed["A"]
+            s2, Wst, Gd, yn = float(sig), Wt, (W * W).sum(axis=0), res["ynorm2"]
+        else:
+            Wt = self._upload("gsc_W", W).t().contiguous()      # (H, D): rows = latents
+        if scores is not None:
+            pass
+        elif sig.ndim == 0:
             s2, Wst, Gd, yn = float(sig), Wt, (W * W).sum(axis=0), res["ynorm2"]
             G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
         else:
@@ -216,8 +229,19 @@ class GSC(DeviceCAModel):
         tables = np.stack([c0, 2. * mu / s2, Gd * mu, 1. / (lam * s2 * s2), 1. / (lam * s2), 1. / lam, mu, lpi])
         self._par = {"ykey": res["key"], "W": W.copy(), "mu": mu.copy(), "psi": psi.copy(), "pi": pi.copy(),
                      "sig": sig.copy(), "s2": s2, "Wt": Wt, "Wst": Wst, "G": G, "yn": yn,
-                     "psi_d": self._upload("gsc_psi", psi), "tables": self._upload("gsc_tab", tables)}
+                     "psi_d": self._upload("gsc_psi", psi), "tables": self._upload("gsc_tab", tables),
+                     "scores": scores}
         return self._par
+
+    def _speculate(self, res, Wt):
+        """Next step's Gram matrix and scores from the W^T the M-step has just solved on the device, enqueued
+        behind the M-step's download: they run while the host unpacks the result and prepares the next tables.
+        ``_tables_for`` picks them up if the caller hands the returned W back unchanged (plain EM)."""
+        Y = res["Y"]
+        N, H = Y.shape[0], self.H
+        G = self._gemm_nt(Wt, Wt, torch.empty((H, H), dtype=torch.float64, device=self.device), "gram_gemm")
+        A = self._gemm_nt(Y, Wt, self._buf("scores_spec", (N, H)), "scores_gemm") if N else None
+        self._seed = {"ykey": res["key"], "Wt": Wt, "G": G, "A": A, "W_host": None}
 
     # ------------------------------------------------------------------ hot path
     def _run(self, anneal_T, model_params, res, cand_in):
@@ -238,7 +262,10 @@ class GSC(DeviceCAModel):
         else:
             cand, do_select = cand_in, 0
         if N:
-            A = self._gemm_nt(Y, par["Wst"], self._buf("scores", (N, H)), "scores_gemm")
+            A = par.pop("scores", None)          # left by the previous M-step (_speculate); good for one pass
+            par["scores"] = None
+            if A is None:
+                A = self._gemm_nt(Y, par["Wst"], self._buf("scores", (N, H)), "scores_gemm")
             self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(par["G"]), _ptr(par["psi_d"]), _ptr(par["yn"]),
                        _ptr(par["tables"]), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
                        ctypes.c_double(par["s2"]), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), H,
@@ -344,7 +371,23 @@ class GSC(DeviceCAModel):
                        ctypes.c_void_p(inv_dev.data_ptr() + 8 * nHH), H,
                        ctypes.c_void_p(inv_dev.data_ptr() + 8 * (2 * nHH + 2)), st)
             packed = torch.cat([packed, inv_dev])
-        host = self._download(packed) if packed.is_cuda else packed.numpy()
+        Wt_next = None
+        self._seed = None
+        if inv_dev is not None and 'W' in self.to_learn and self.sigma_sq_type == 'scalar' and self.speculate:
+            # W_new^T = (sum xpt_szsz)^-1 . Wp^T on the device too (gsc_et.py:625): the next step's scores GEMM can
+            # then start before the host has even seen this step's result
+            Wt_next = torch.empty((H, D), dtype=torch.float64, device=self.device)
+            n0 = packed.numel() - inv_dev.numel()
+            self._gemm_nt(packed[n0:n0 + nHH].view(H, H), packed[:nWp].view(D, H), Wt_next, "solve_gemm")
+            packed = torch.cat([packed, Wt_next.reshape(-1)])
+        if packed.is_cuda:
+            host = self._download(packed, then=(lambda: self._speculate(res, Wt_next)) if Wt_next is not None else None)
+        else:
+            host = packed.numpy()
+        W_given = None
+        if Wt_next is not None:
+            W_given = host[-nWp:].reshape(H, D).T.copy()
+            host = host[:-nWp]
         Wp = host[:nWp].reshape(D, H)
         xs_xsz = host[nWp:nWp + nHH].reshape(H, H)
         xsz_xsz = host[nWp + nHH:nWp + 2 * nHH].reshape(H, H)
@@ -361,9 +404,14 @@ class GSC(DeviceCAModel):
                 and piv[2] / piv[3] > 1e-12
             if good:        # well-conditioned SPD: use the device inverses; else LAPACK on the host as upstream
                 inverses = (tail[:nHH].reshape(H, H), tail[nHH:2 * nHH].reshape(H, H))
+        if inverses is None or W_given is None or not np.isfinite(W_given).all():
+            W_given, self._seed = None, None       # host fallback: whatever was speculated is void
+        elif self._seed is not None:
+            self._seed["W_host"] = W_given.copy()  # private snapshot of what model_params['W'] will hold: an in-place
+                                                   # edit by the caller must be seen as a different W
         with small_blas():
             return self._update(model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss,
-                                sum_xpt_szsz, sum_yy, data_sq, inverses)
+                                sum_xpt_szsz, sum_yy, data_sq, inverses, W_given)
 
     def _data_second_moment(self, res):
         """sum_n y_n^2 per dimension (diagonal) / sum_n y_n y_n^T (full) over ALL ranks -- constants of the
@@ -390,12 +438,15 @@ class GSC(DeviceCAModel):
         return res[key]
 
     def _update(self, model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss, sum_xpt_szsz, sum_yy,
-                data_sq=None, inverses=None):
+                data_sq=None, inverses=None, W_given=None):
         """The H x H parameter algebra of gsc_et.py:624-716 on the host.  ``inverses``: (sum_xpt_szsz^-1,
         (sum_xpt_ss + eps I)^-1) when the device already produced them."""
         D, eps = self.D, 1e-5
         try:
-            W_n = np.dot(Wp, inverses[0] if inverses is not None else np.linalg.inv(sum_xpt_szsz))
+            if W_given is not None:       # Wp . (sum xpt_szsz)^-1 as the device computed it (and already uses it)
+                W_n = W_given
+            else:
+                W_n = np.dot(Wp, inverses[0] if inverses is not None else np.linalg.inv(sum_xpt_szsz))
         except np.linalg.LinAlgError:
             try:
                 noise = np.random.normal(0, eps, self.H)

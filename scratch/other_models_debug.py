@@ -22,25 +22,11 @@ class An(dict):
     def __missing__(s,k): return 0.0
     def as_dict(s): return dict(s)
 m = GSC(Dm, Hm, 6, 3, 'scalar')
-m.timer = KernelTimer()
-import gc, threading
+import gc
 gc.collect(); gc.disable()
-ev = []
-def prof(frame, event, arg):
-    if event in ("call", "return", "c_call", "c_return"):
-        name = arg.__name__ if event.startswith("c_") else frame.f_code.co_name
-        ev.append((time.perf_counter(), event, name, frame.f_lineno))
-for it in range(12):
+for rep in range(3):
+    for _ in range(10): p = m.step(An(T=1.0), p, {"y": Y})
     torch.cuda.synchronize(); t = time.perf_counter()
-    ev.clear()
-    sys.setprofile(prof)
-    p = m.step(An(T=1.0), p, {"y": Y})
-    sys.setprofile(None)
+    for _ in range(20): p = m.step(An(T=1.0), p, {"y": Y})
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t
-    print(it, round(dt * 1e3, 2), "threads", threading.active_count())
-    if dt > 0.02 and it > 0:
-        gaps = sorted(((ev[k + 1][0] - ev[k][0], k) for k in range(len(ev) - 1)), reverse=True)[:3]
-        for g, k in gaps:
-            print("GAP %.1f ms between" % (g * 1e3), ev[k][1:], "and", ev[k + 1][1:])
-print({k: (v[0], round(v[1], 3)) for k, v in m.timer.summary().items()})
+    print("GSC c4 EM iter ms", round((time.perf_counter() - t) / 20 * 1e3, 3))

@@ -190,3 +190,35 @@ def test_config4_properties():
     new = m.M_step(an, p, ss, data)
     assert np.isfinite(new["W"]).all() and (new["pi"] > 0).all() and (new["pi"] < 1).all() and new["sigma_sq"] > 0
     assert np.abs(new["W"] - W_gt.cpu().numpy()).mean() < 0.2 and abs(new["pi"].mean() * H - 2.0) < 0.5
+
+
+def test_gsc_em_loop_speculation_is_transparent():
+    """The M-step leaves the next step's W^T, Gram matrix and scores on the device (GSC._speculate).  That must not
+    change a trajectory -- whether the caller feeds the returned parameters straight back or edits them first."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    D, H, Hp, gamma, N = 48, 24, 4, 3, 700
+    rng = np.random.RandomState(11)
+    W_gt = rng.normal(size=(D, H))
+    S = rng.random_sample((N, H)) < 2.0 / H
+    y = (S * (1.5 + rng.normal(size=(N, H)))) @ W_gt.T + rng.normal(size=(N, D))
+    p0 = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.4),
+          "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+    an = _An(T=1.0)
+    runs = []
+    for spec in (True, False):
+        m = GSC(D, H, Hp, gamma, 'scalar')
+        m.speculate = spec
+        p = {k: np.array(v, copy=True) for k, v in p0.items()}
+        used = []
+        for it in range(5):
+            if it == 3:                                   # the caller edits W: the speculated scores must be dropped
+                p["W"] = p["W"] * (1.0 + 1e-3 * np.cos(np.arange(D * H).reshape(D, H)))
+            if it == 4:                                   # an in-place edit of the very array the M-step returned
+                p["W"][0, 0] += 0.01
+            p = m.step(an, p, {"y": y})
+            used.append(m._par.get("scores", "absent"))
+        runs.append(p)
+        if spec:
+            assert m._seed is not None and m._seed["W_host"] is not p["W"] and np.array_equal(m._seed["W_host"], p["W"])
+    for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
+        np.testing.assert_allclose(runs[0][k], runs[1][k], rtol=1e-8, atol=1e-11, err_msg=k)
