@@ -4,6 +4,7 @@ launch bookkeeping and the NumPy-compatible handles (``DeviceArray``) results ar
 PyTorch supplies memory, streams and process groups; every computation on the hot path is a call
 into libprosper_hip.so (include/prosper_hip.h)."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -190,6 +191,9 @@ class DeviceCAModel(CAModel):
         self.timer = None        # optional KernelTimer (bench.py)
         self._pin = {}           # pinned staging buffers for asynchronous parameter uploads
         self._pin_out = {}       # pinned buffers of the device->host copies (one per M-step), by slot
+        self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'   # next step's GEMMs behind the M-step download
+        self._seed_rec = None    # what _seed_next left on the device for the next select_Hprimes
+        self._mstep_res = None   # resident shard of the M-step in progress (for _seed_next)
 
     def _state_masks(self):
         """uint16 mask per multi-cause state: bit j <=> candidate position j is on."""
@@ -342,6 +346,30 @@ class DeviceCAModel(CAModel):
             then()
         ev.synchronize()
         return dst.numpy()
+
+    # ---- EM-loop pipelining shared by the linear models whose M-step solves W^T on the device (DSC, TSC) ----
+    def _seed_next(self, res, Wt):
+        """Next step's Gram matrix and scores from ``Wt`` = W_new^T (H,D), which the M-step has just solved on the
+        device -- enqueued behind the M-step's download so they run while the host unpacks it.  ``_take_seed``
+        hands them to the next ``select_Hprimes`` if the caller feeds the returned W back unchanged."""
+        Y = res["Y"]
+        N, H = Y.shape[0], self.H
+        A = self._buf("scores_spec", (N, H))
+        if self._par.get("A") is A:
+            self._par = {}                 # the cached parameters' scores live in the buffer overwritten now
+        G = self._gemm_nt(Wt, Wt, torch.empty((H, H), dtype=torch.float64, device=self.device), "gram_gemm")
+        if N:
+            self._gemm_nt(Y, Wt, A, "scores_gemm")
+        self._seed_rec = {"ykey": res["key"], "Wt": Wt, "G": G, "A": A, "W": None}
+
+    def _take_seed(self, W, res):
+        """The seeded parameter record if ``W`` (D,H) is what the last M-step returned (compared with a private
+        snapshot, so in-place edits by the caller are seen); the seed is consumed either way."""
+        seed, self._seed_rec = getattr(self, "_seed_rec", None), None
+        if seed is None or seed["W"] is None or seed["ykey"] != res["key"] or seed["W"].shape != W.shape \
+                or not np.array_equal(seed["W"], W):
+            return None
+        return {"ykey": res["key"], "W": seed["W"], "Wt": seed["Wt"], "G": seed["G"], "A": seed["A"]}
 
     def _solve_normal_eq(self, Wq_u, qdiag, rhs):
         """X = Wq^-1 . rhs, enqueued on the device, for the symmetric second-moment matrix

@@ -204,6 +204,10 @@ class TSC_ET(DeviceCAModel):
         if par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape \
                 and np.array_equal(par["W"], W):
             return par
+        seeded = self._take_seed(W, res)
+        if seeded is not None:               # W^T, Gram matrix and scores left on the device by the last M-step
+            self._par = seeded
+            return seeded
         Wt = self._upload("W", W).t().contiguous()
         G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
         Y = res["Y"]
@@ -316,6 +320,7 @@ class TSC_ET(DeviceCAModel):
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N,
                        self._stream())
         comm.allreduce_device(stats)      # replaces tsc_et.py:412,446,453,486,487,497,527
+        self._mstep_res = res
         return self._finalize(stats, model_params, A_pi_gamma, E_pi_gamma)
 
     def _finalize(self, stats, model_params, A_pi_gamma, E_pi_gamma):
@@ -335,7 +340,12 @@ class TSC_ET(DeviceCAModel):
             X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, Wp.contiguous())
             parts += [status, X.reshape(-1)]
         flat = torch.cat(parts)
-        host = self._download(flat) if flat.is_cuda else flat.numpy()
+        self._seed_rec = None
+        res = getattr(self, "_mstep_res", None)
+        if flat.is_cuda and learn_W and res is not None and self.speculate:
+            host = self._download(flat, then=lambda: self._seed_next(res, X))
+        else:
+            host = self._download(flat) if flat.is_cuda else flat.numpy()
         cnt = host[:8]
         my_sigma, Fs, N_use = float(host[8]), float(host[9]), int(round(host[10]))
 
@@ -346,7 +356,10 @@ class TSC_ET(DeviceCAModel):
             ok = host[12] == 0 and host[13] > 1e-11 and np.isfinite(host[13])
             if ok:
                 W_new = host[14:14 + H * D].reshape(H, D).copy()
+                if self._seed_rec is not None:
+                    self._seed_rec["W"] = W_new.transpose().copy()   # private snapshot of the W handed back
             else:   # singular Wq: the reference's pseudo-inverse (tsc_et.py:488)
+                self._seed_rec = None
                 with small_blas():
                     W_new = np.dot(np.linalg.pinv(Wq.cpu().numpy()), Wp.cpu().numpy())
             W_out = W_new.transpose()

@@ -164,3 +164,41 @@ def test_dsc_inference_matches_reference(tag, kw, capsys):
     assert res["s"].dtype == np.int8 and np.array_equal(res["s"], g[tag + "_s"])
     np.testing.assert_allclose(res["p"], g[tag + "_p"], rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(res["m"], g[tag + "_m"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("model", ["dsc", "tsc"])
+def test_em_loop_speculation_is_transparent(model):
+    """The M-step leaves the next step's W^T, Gram matrix and scores on the device (DeviceCAModel._seed_next).  A
+    trajectory must not depend on it -- also when the caller replaces W, or edits the returned array in place."""
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    from prosper_amd.em.camodels.tsc_et import TSC_ET
+    D, H, Hp, gamma, N = 40, 20, 4, 3, 600
+    rng = np.random.RandomState(21)
+    W_gt = rng.normal(size=(D, H)) * 2.0
+    u = rng.random_sample((N, H))
+    S = (u < 1.0 / H).astype(float) - (u > 1 - 1.0 / H).astype(float)
+    y = S @ W_gt.T + rng.normal(size=(N, D))
+    W0 = W_gt + 0.1 * rng.normal(size=(D, H))
+    runs = []
+    for spec in (True, False):
+        if model == "dsc":
+            m = DSC_ET(D, H, Hp, gamma, states=np.array([-1., 0., 1.]))
+            p = {"W": W0.copy(), "pi": np.array([1.0 / H, 1 - 2.0 / H, 1.0 / H]), "sigma": 1.0}
+        else:
+            m = TSC_ET(D, H, Hp, gamma)
+            p = {"W": W0.copy(), "pi": 2.0 / H, "sigma": 1.0}
+        m.speculate = spec
+        taken = []
+        take = m._take_seed
+        m._take_seed = lambda W, res: taken.append(take(W, res)) or taken[-1]
+        for it in range(5):
+            if it == 3:
+                p["W"] = p["W"] * (1.0 + 1e-3 * np.cos(np.arange(D * H).reshape(D, H)))
+            if it == 4:
+                p["W"][0, 0] += 0.01
+            p = m.step(_An(T=1.0), p, {"y": y})
+        # steps 1 and 2 ran on the seeded parameters, 0 (nothing seeded yet), 3 and 4 (W edited) must not
+        assert [t is not None for t in taken] == ([False, True, True, False, False] if spec else [False] * 5)
+        runs.append(p)
+    for k in ("W", "pi", "sigma"):
+        np.testing.assert_allclose(runs[0][k], runs[1][k], rtol=1e-8, atol=1e-11, err_msg=k)
