@@ -80,6 +80,14 @@ int pm_row_wsqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const
 int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, double *full,
                        double *inv, int64_t ldo, double *pivots, void *stream);
 
+/* `batch` independent inverses in one launch, one workgroup each (they run on different CUs at once): matrix b is
+ * read at upper + b*stride_in, written at inv (and full, if given) + b*stride_out; diag_add (optional) holds n
+ * doubles and pivots 2 doubles per matrix.  GSC's M-step needs (sum xpt_szsz)^-1 and (sum xpt_ss + eps I)^-1
+ * (gsc_et.py:625, 673). */
+int pm_spd_inverse_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
+                             double *full, double *inv, int64_t ldo, int64_t stride_out, double *pivots,
+                             int64_t batch, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Binary Sparse Coding (prosper/em/camodels/bsc_et.py)
  * ------------------------------------------------------------------------------------- */

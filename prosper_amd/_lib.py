@@ -42,6 +42,7 @@ SIGNATURES = {
     "pm_col_moments_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp, c_dp]),
     "pm_row_wsqnorm_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp, c_dp]),
     "pm_spd_inverse_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp]),
+    "pm_spd_inverse_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, c_dp, i64, i64, c_dp, i64, c_dp]),
     "pm_bsc_select_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp, c_dp]),
     "pm_bsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64,
                                    C.POINTER(EStepParams), i64, i64, i64, c_dp, i64, c_dp, c_dp]),

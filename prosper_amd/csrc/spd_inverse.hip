@@ -28,7 +28,14 @@ constexpr int TS = 32, EL = 8, NMAX = TS * EL;  // 256
 __global__ __launch_bounds__(1024) void spd_inverse_kernel(const double *__restrict__ upper, int64_t ldu,
                                                             const double *__restrict__ diag_add, int n,
                                                             double *__restrict__ full, double *__restrict__ inv,
-                                                            int64_t ldo, double *__restrict__ pivots) {
+                                                            int64_t ldo, double *__restrict__ pivots,
+                                                            int64_t stride_in, int64_t stride_out) {
+    // one workgroup per matrix of a batch (blockIdx.x): independent inverses run on different CUs at once
+    upper += blockIdx.x * stride_in;
+    inv += blockIdx.x * stride_out;
+    if (full) full += blockIdx.x * stride_out;
+    if (diag_add) diag_add += (int64_t)blockIdx.x * n;
+    pivots += 2 * blockIdx.x;
     __shared__ double s_c[2][NMAX];
     const int tid = threadIdx.x;
     const int ti = tid >> 5, tj = tid & 31;
@@ -118,6 +125,19 @@ extern "C" int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double
     if (!upper || !inv || n <= 0 || ldu < n || ldo < n) return PM_EINVAL;
     if (n > NMAX) return PM_ERANGE;
     hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), upper, ldu,
-                       diag_add, (int)n, full, inv, ldo, pivots);
+                       diag_add, (int)n, full, inv, ldo, pivots, (int64_t)0, (int64_t)0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_spd_inverse_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add,
+                                        int64_t n, double *full, double *inv, int64_t ldo, int64_t stride_out,
+                                        double *pivots, int64_t batch, void *stream) {
+    if (batch == 0) return PM_OK;
+    if (!upper || !inv || !pivots || n <= 0 || ldu < n || ldo < n || batch < 0 || stride_in < ldu * (n - 1) + n ||
+        stride_out < ldo * (n - 1) + n)
+        return PM_EINVAL;
+    if (n > NMAX || batch > 65535) return PM_ERANGE;
+    hipLaunchKernelGGL(spd_inverse_kernel, dim3((unsigned)batch), dim3(1024), 0, static_cast<hipStream_t>(stream), upper,
+                       ldu, diag_add, (int)n, full, inv, ldo, pivots, stride_in, stride_out);
     return (int)hipGetLastError();
 }

@@ -254,8 +254,10 @@ class GSC(DeviceCAModel):
         masks = self._masks()
         n_stats = _lib.load().pm_gsc_stats_len(H)
         stats = torch.zeros(n_stats, dtype=torch.float64, device=self.device)
-        xs = torch.empty((N, H), dtype=torch.float64, device=self.device)
-        xsz = torch.empty((N, H), dtype=torch.float64, device=self.device)
+        # xpt_s and xpt_sz side by side in ONE (N, 2H) buffer: the M-step then gets both moment contractions
+        # ([xs | xsz]^T . xsz) from a single GEMM launch
+        both = torch.empty((N, 2 * H), dtype=torch.float64, device=self.device)
+        xs, xsz = both[:, :H], both[:, H:]
         if cand_in is None:
             cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
             do_select = 1
@@ -268,7 +270,7 @@ class GSC(DeviceCAModel):
                 A = self._gemm_nt(Y, par["Wst"], self._buf("scores", (N, H)), "scores_gemm")
             self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(par["G"]), _ptr(par["psi_d"]), _ptr(par["yn"]),
                        _ptr(par["tables"]), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
-                       ctypes.c_double(par["s2"]), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), H,
+                       ctypes.c_double(par["s2"]), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), 2 * H,
                        _ptr(stats), self._stream())
         return cand, xs, xsz, stats
 
@@ -335,7 +337,12 @@ class GSC(DeviceCAModel):
                 return x.to(self.device)
             return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float64)).to(self.device)
 
-        xs, xsz = dev(suff_stats['xpt_s']).contiguous(), dev(suff_stats['xpt_sz']).contiguous()
+        xs, xsz = dev(suff_stats['xpt_s']), dev(suff_stats['xpt_sz'])
+        paired = (xs.dim() == 2 and xs.stride() == (2 * H, 1) and xsz.stride() == (2 * H, 1) and H % 2 == 0
+                  and xsz.data_ptr() == xs.data_ptr() + 8 * H)       # the E-step's own (N, 2H) buffer
+        if not paired:
+            xs, xsz = xs.contiguous(), xsz.contiguous()
+        ldx = xs.stride(0) if my_N else H
         sum_ss = dev(suff_stats['xpt_ss'].sum(axis=0))
         sum_zz = dev(suff_stats['xpt_szsz'].sum(axis=0))
         # packed: [Wp (D,H) | xs^T xsz (H,H) | xsz^T xsz (H,H) | sum_ss | sum_zz | sum_s | sum_sz | sum |y|^2]
@@ -343,11 +350,15 @@ class GSC(DeviceCAModel):
         packed = torch.zeros(nWp + 4 * nHH + 2 * H + 1, dtype=torch.float64, device=self.device)
         if my_N:
             s = self._stream()
-            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(Y), D, _ptr(xsz), H, _ptr(packed), H, D, H, my_N, s)
-            self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xs), H, _ptr(xsz), H,
-                       ctypes.c_void_p(packed.data_ptr() + 8 * nWp), H, H, H, my_N, s)
-            self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xsz), H, _ptr(xsz), H,
-                       ctypes.c_void_p(packed.data_ptr() + 8 * (nWp + nHH)), H, H, H, my_N, s)
+            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(Y), D, _ptr(xsz), ldx, _ptr(packed), H, D, H, my_N, s)
+            if paired:      # [xs | xsz]^T . xsz -> the (2H, H) block [xs^T xsz ; xsz^T xsz] of the packed buffer
+                self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xs), ldx, _ptr(xsz), ldx,
+                           ctypes.c_void_p(packed.data_ptr() + 8 * nWp), H, 2 * H, H, my_N, s)
+            else:
+                self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xs), H, _ptr(xsz), H,
+                           ctypes.c_void_p(packed.data_ptr() + 8 * nWp), H, H, H, my_N, s)
+                self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xsz), H, _ptr(xsz), H,
+                           ctypes.c_void_p(packed.data_ptr() + 8 * (nWp + nHH)), H, H, H, my_N, s)
         o = nWp + 2 * nHH
         packed[o:o + nHH] = sum_ss.reshape(-1)
         packed[o + nHH:o + 2 * nHH] = sum_zz.reshape(-1)
@@ -363,13 +374,11 @@ class GSC(DeviceCAModel):
             # the two H x H inverses of the update (gsc_et.py:625, 673) on the device, ahead of the download: a
             # 128 x 128 LAPACK inverse costs 0.4 ms of host time each while the GPU idles
             inv_dev = torch.empty(2 * nHH + 4, dtype=torch.float64, device=self.device)
-            ss_eps = packed[o:o + nHH].view(H, H) + eps * torch.eye(H, dtype=torch.float64, device=self.device)
-            st = self._stream()
-            self._call("spd_inverse", "pm_spd_inverse_f64", ctypes.c_void_p(packed.data_ptr() + 8 * (o + nHH)), H, None, H,
-                       None, _ptr(inv_dev), H, ctypes.c_void_p(inv_dev.data_ptr() + 8 * 2 * nHH), st)
-            self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(ss_eps), H, None, H, None,
-                       ctypes.c_void_p(inv_dev.data_ptr() + 8 * nHH), H,
-                       ctypes.c_void_p(inv_dev.data_ptr() + 8 * (2 * nHH + 2)), st)
+            both = torch.stack([packed[o + nHH:o + 2 * nHH].view(H, H),
+                                packed[o:o + nHH].view(H, H) + eps * torch.eye(H, dtype=torch.float64, device=self.device)])
+            # ONE launch, one workgroup per matrix: the two inverses run side by side on two CUs
+            self._call("spd_inverse", "pm_spd_inverse_batch_f64", _ptr(both), H, nHH, None, H, None, _ptr(inv_dev), H,
+                       nHH, ctypes.c_void_p(inv_dev.data_ptr() + 8 * 2 * nHH), 2, self._stream())
             packed = torch.cat([packed, inv_dev])
         Wt_next = None
         self._seed = None

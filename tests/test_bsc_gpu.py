@@ -105,6 +105,36 @@ def test_spd_inverse(dev, n):
     np.testing.assert_allclose(piv.cpu().numpy(), [d2.min(), d2.max()], rtol=1e-9)
 
 
+def test_spd_inverse_batch(dev):
+    """pm_spd_inverse_batch_f64: three matrices, one workgroup each, strided in and out (GSC's M-step uses two)."""
+    from prosper_amd import _lib
+    n, batch, pad = 40, 3, 7
+    rs = np.random.RandomState(5)
+    mats, dadd = [], rs.uniform(0.1, 1.0, size=(batch, n))
+    for b in range(batch):
+        B = rs.normal(size=(n, 2 * n + b))
+        mats.append(B @ B.T)
+    inp = torch.zeros((batch, n * n + pad), dtype=torch.float64, device=dev)
+    for b in range(batch):
+        inp[b, :n * n] = torch.from_numpy(np.triu(mats[b]) + np.tril(rs.normal(size=(n, n)), -1)).to(dev).reshape(-1)
+    da = torch.from_numpy(dadd).to(dev).contiguous()
+    full = torch.zeros((batch, n * n + pad), dtype=torch.float64, device=dev)
+    inv = torch.zeros((batch, n * n + pad), dtype=torch.float64, device=dev)
+    piv = torch.zeros(2 * batch, dtype=torch.float64, device=dev)
+    _lib.call("pm_spd_inverse_batch_f64", _p(inp), n, n * n + pad, _p(da), n, _p(full), _p(inv), n, n * n + pad, _p(piv),
+              batch, _stream())
+    for b in range(batch):
+        Af = mats[b] + np.diag(dadd[b])
+        np.testing.assert_array_equal(full[b, :n * n].view(n, n).cpu().numpy(), Af)
+        ref, got = np.linalg.inv(Af), inv[b, :n * n].view(n, n).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-14 * np.linalg.cond(Af) * np.abs(ref).max())
+        d2 = np.diag(np.linalg.cholesky(Af)) ** 2
+        np.testing.assert_allclose(piv[2 * b:2 * b + 2].cpu().numpy(), [d2.min(), d2.max()], rtol=1e-9)
+    assert (inv[:, n * n:] == 0).all() and (full[:, n * n:] == 0).all()          # nothing written between matrices
+    with pytest.raises(_lib.HipError):                                            # overlapping strides
+        _lib.call("pm_spd_inverse_batch_f64", _p(inp), n, n, None, n, None, _p(inv), n, n * n, _p(piv), 2, _stream())
+
+
 def test_spd_inverse_rejects_large(dev):
     from prosper_amd import _lib
     t = torch.zeros((300, 300), dtype=torch.float64, device=dev)
