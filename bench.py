@@ -58,8 +58,6 @@ def other_models(dev, Anneal, steps=8):
     from prosper_amd.em.camodels.gsc_et import GSC
     from prosper_amd.em.camodels.mca_et import MCA_ET
     out = {}
-    warm = 10    # the HIP runtime stalls one asynchronous copy for ~80 ms once, 100-150 ms into a process's first
-                 # EM loop (scratch/other_models_debug.py): keep that one-off out of an 8-step average
     gc.collect()
     gc.disable()               # as in the headline loops: a full collection is a ~70-80 ms host stall
     try:
@@ -77,7 +75,8 @@ def other_models(dev, Anneal, steps=8):
         p = {"W": W_gt.cpu().numpy() + 0.1 * rng.normal(size=(Dm, Hm)), "pi": np.full(Hm, 2.0 / Hm),
              "mu": np.full(Hm, 1.4), "psi_sq": np.eye(Hm) * 1.1, "sigma_sq": 1.2}
         m = GSC(Dm, Hm, 6, 3, 'scalar')
-        for _ in range(warm):
+        t_warm = time.perf_counter()     # warm up by TIME: the HIP runtime stalls one asynchronous copy for ~80 ms
+        while time.perf_counter() - t_warm < 0.5:   # once, 100-150 ms into a model's first EM loop
             p = m.step(Anneal(T=1.0), p, {"y": Y})
         torch.cuda.synchronize()
         t = time.perf_counter()
@@ -99,7 +98,8 @@ def other_models(dev, Anneal, steps=8):
         p = {"W": (W_gt * (1 + 0.1 * (2 * torch.rand(Dm, Hm, generator=g, device=dev, dtype=torch.float64) - 1))).cpu().numpy(),
              "pi": 2.0 / Hm, "sigma": 1.0}
         m = MCA_ET(Dm, Hm, 8, 3)
-        for _ in range(warm):
+        t_warm = time.perf_counter()     # warm up by TIME: the HIP runtime stalls one asynchronous copy for ~80 ms
+        while time.perf_counter() - t_warm < 0.5:   # once, 100-150 ms into a model's first EM loop
             p = m.step(Anneal(T=1.0), p, {"y": Y})
         torch.cuda.synchronize()
         t = time.perf_counter()
