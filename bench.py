@@ -243,7 +243,7 @@ def main():
         estep_pass()
     # HIP events around the dominant kernel only (first scores-GEMM launch of every step): an event
     # pair costs ~10 us of stream time, so the other kernels are timed in a separate, untimed pass
-    chunks_per_step = max(1, N // model._chunk_rows(N))
+    chunks_per_step = max(1, N // model._launch_rows(N))
     timer = KernelTimer(only={"scores_gemm"}, stride=chunks_per_step)
     model.timer = timer
     gc.collect()
@@ -306,15 +306,16 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            key = "scores_gemm@grid%d" % (min(N, model._chunk_rows(N)) // 128 * ((H + 127) // 128) * 256)
-            key = key if key in pmc else None
-            traffic = pmc[key]["hbm_bytes"] if (key and N == N_PER_GPU) else None
+            # the launch is recognised by its grid: whole rounds of tiles + K-slices of the ragged last round
+            cands = [k for k, v in pmc.items() if k.startswith("scores_gemm@grid") and
+                     v.get("datapoints_per_launch") == model._launch_rows(N)]
+            traffic = pmc[cands[0]]["hbm_bytes"] if (cands and N == N_PER_GPU) else None
         except Exception:
             traffic = None
         ms_step = elapsed / args.steps * 1e3
         value = world * N * args.steps / elapsed
         # dominant kernel: the scores GEMM, launched once per pipeline chunk of `chunk` datapoints
-        chunk = min(N, model._chunk_rows(N))
+        chunk = model._launch_rows(N)
         gemm_ms = kern["scores_gemm"][1]
         flops = 2.0 * chunk * D * H                        # algorithmic flops of one such launch (524 288 / datapoint)
         achieved = flops / (gemm_ms * 1e-3) / 1e12

@@ -49,6 +49,8 @@ def main():
         w_b = 1024.0 * sum(w) / len(w)
         res["%s@grid%d" % (lab, grid)] = {"launches": len(v), "fetch_factor": FETCH_FACTOR[lab], "fetch_bytes": f_b,
                                          "write_bytes": w_b, "hbm_bytes": f_b + w_b}
+        if lab == "scores_gemm" and f_b + w_b > 1e9:   # the headline launch: all 200000 datapoints of the shard (whole
+            res["%s@grid%d" % (lab, grid)]["datapoints_per_launch"] = 200000   # rounds + the fused ragged round)
     json.dump({"note": "per-launch HBM-side bytes (FETCH_SIZE x per-kernel gfx950 factor, see summarize_pmc.py, "
                        "+ WRITE_SIZE), rocprofv3 --pmc, separate passes; bench.py --steps 5 --warmup 2 --em-steps 3", "kernels": res}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -26,6 +26,7 @@
 //   A: lane l holds A[i = l & 15][k = l >> 4]      B: lane l holds B[k = l >> 4][j = l & 15]
 //   C/D: 4 f64 per lane, col = l & 15, row = (l >> 4) + 4 * reg
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "prosper_hip.h"
@@ -217,9 +218,13 @@ template <bool SPLITK>  // SPLITK: grid.y K-slices added to a zeroed C with atom
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *__restrict__ A, int64_t lda,
                                                                   const double *__restrict__ B, int64_t ldb,
                                                                   double *__restrict__ C, int64_t ldc, int M, int N,
-                                                                  int K, int tiles_n, int kps) {
+                                                                  int K, int tiles_n, int kps, int main_tiles,
+                                                                  int rest_kps) {
     // gridDim.y > 1: split-K -- this workgroup covers K-steps [blockIdx.y*kps, +kps) and ADDS its
-    // partial tile to C with f64 atomics (C zeroed by the launcher)
+    // partial tile to C with f64 atomics (C zeroed by the launcher).
+    // Fused remainder (SPLITK == false, main_tiles < all tiles): workgroups [0, main_tiles) are whole rounds of
+    // un-split tiles; the ones behind them are K-slices of the ragged last round's tiles (rows zeroed by the
+    // launcher, atomics), dispatched as the last main round drains instead of in a launch of their own.
     __shared__ __attribute__((aligned(1024))) double sm[DSTAGES * DSTAGE];
 
     const int tid = threadIdx.x;
@@ -231,8 +236,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     // A panel is then fetched from the fabric once and the second tile hits it in that XCD's L2
     // (speed / traffic only; any placement is correct).
     int tile = blockIdx.x;
-    if (tiles_n == 2 && ((tile >> 4) + 1) * 16 <= (int)gridDim.x)
+    int kt0 = blockIdx.y * kps;
+    bool slice = SPLITK;
+    if (!SPLITK && tile >= main_tiles) {                       // K-slice of a remainder tile
+        const int rest_tiles = ((M + 127) / 128) * tiles_n - main_tiles;
+        const int u = tile - main_tiles;
+        tile = main_tiles + u % rest_tiles;
+        kt0 = (u / rest_tiles) * rest_kps;
+        kps = rest_kps;
+        slice = true;
+    } else if (tiles_n == 2 && ((tile >> 4) + 1) * 16 <= main_tiles) {
         tile = (tile & ~15) + ((tile & 7) << 1) + ((tile >> 3) & 1);
+    }
     const int bn = tile % tiles_n, bm = tile / tiles_n;
     const int m0 = bm * 128, n0 = bn * 128;
 
@@ -247,7 +262,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
         src[q] = A + (int64_t)ra * lda + 2 * dj;
         src[2 + q] = B + (int64_t)rb * ldb + 2 * dj;
     }
-    const int kt0 = blockIdx.y * kps;
     auto dma = [&](int kt, int stage) {
         double *dst = sm + stage * DSTAGE + wave * 128;  // chunk = 128 doubles
         const int k0 = (kt0 + kt) * DK;
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
         if (t + 1 < nk) kstep(t + 1, f1, f0);
     }
 
-    constexpr bool split = SPLITK;
+    const bool split = slice;
     const bool interior = (m0 + 128 <= M) && (n0 + 128 <= N);
     double *cbase = C + (int64_t)(m0 + wm * 64 + fk) * ldc + n0 + wn * 64 + frow;
     if (!split && interior) {  // the common case: plain stores, no guards
@@ -677,6 +691,16 @@ int resident_slots() {  // workgroups of these kernels resident at once: 2 per C
     return slots;
 }
 
+// PM_GEMM_FUSE_REMAINDER=0 restores the two-launch form (main rounds, then the split-K remainder)
+bool fuse_remainder() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PM_GEMM_FUSE_REMAINDER");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+
 template <int MT>
 void launch_nt_mt(bool al, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int M,
                   int N, int K, hipStream_t s) {
@@ -699,9 +723,26 @@ void launch_nt_dma(const double *A, int64_t lda, const double *B, int64_t ldb, d
     if (nsplit > 1) (void)hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)N * sizeof(double), (size_t)M, s);
     dim3 grid((unsigned)((int64_t)tiles_m * tiles_n), (unsigned)nsplit), block(256);
     if (nsplit > 1)
-        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, kps);
+        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, kps,
+                           (int)grid.x, 0);
     else
-        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, kps);
+        hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n,
+                           kps, (int)grid.x, 0);
+}
+
+// whole rounds of un-split tiles + K-slices of the ragged last round's tiles in ONE launch (see the kernel)
+void launch_nt_dma_fused(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int M, int N,
+                         int K, int main_panels, int nsplit, hipStream_t s) {
+    const int tiles_m = (M + 127) / 128, tiles_n = (N + BN - 1) / BN;
+    const int nk = K / DK;
+    int rest_kps = (nk + nsplit - 1) / nsplit;
+    nsplit = (nk + rest_kps - 1) / rest_kps;
+    const int main_tiles = main_panels * tiles_n, rest_tiles = (tiles_m - main_panels) * tiles_n;
+    (void)hipMemset2DAsync(C + (int64_t)main_panels * 128 * ldc, (size_t)ldc * sizeof(double), 0, (size_t)N * sizeof(double),
+                           (size_t)(M - main_panels * 128), s);
+    dim3 grid((unsigned)(main_tiles + rest_tiles * nsplit)), block(256);
+    hipLaunchKernelGGL(gemm_nt_f64_dma_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, nk,
+                       main_tiles, rest_kps);
 }
 
 }  // namespace
@@ -724,16 +765,22 @@ extern "C" int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int
         const int64_t per_round = slots / tiles_n > 0 ? slots / tiles_n : 1;
         const int64_t main_panels = (M / 128) / per_round * per_round;
         const int64_t rest_rows = M - main_panels * 128;
-        if (main_panels > 0) launch_nt_dma(A, lda, B, ldb, C, ldc, (int)(main_panels * 128), (int)N, (int)K, 1, s);
+        int64_t nsplit = 1;
         if (rest_rows > 0) {
             const int64_t rest_tiles = (panels - main_panels) * tiles_n;
-            int64_t nsplit = slots / rest_tiles;           // fill the slots once
+            nsplit = slots / rest_tiles;                   // fill the slots once
             const int64_t max_split = (K / DK) / 8;        // at least 8 K-steps per workgroup
             if (nsplit > max_split) nsplit = max_split;
             if (nsplit < 1 || rest_tiles * 10 >= (int64_t)slots * 7) nsplit = 1;
+        }
+        if (main_panels > 0 && rest_rows > 0 && nsplit > 1 && fuse_remainder()) {
+            launch_nt_dma_fused(A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)main_panels, (int)nsplit, s);
+            return (int)hipGetLastError();
+        }
+        if (main_panels > 0) launch_nt_dma(A, lda, B, ldb, C, ldc, (int)(main_panels * 128), (int)N, (int)K, 1, s);
+        if (rest_rows > 0)
             launch_nt_dma(A + main_panels * 128 * lda, lda, B, ldb, C + main_panels * 128 * ldc, ldc, (int)rest_rows,
                           (int)N, (int)K, (int)nsplit, s);
-        }
         return (int)hipGetLastError();
     }
     // register-staged kernels: any alignment, any K; small tiles for small problems

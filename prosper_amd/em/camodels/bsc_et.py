@@ -48,6 +48,7 @@ class BSC_ET(DeviceCAModel):
         self._a0 = None          # (par, data key, rows): whose first-chunk scores the scores_c0 buffer holds
         self._spec_ok = False    # the last M-step's seeded parameters were used as they were
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
+        self.fused_remainder = os.environ.get('PM_GEMM_FUSE_REMAINDER', '1') == '1'   # ragged last round inside the main launch
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
         self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
         self.max_chunk_rows = 1 << 20
@@ -189,13 +190,21 @@ class BSC_ET(DeviceCAModel):
         tag = (par, res["key"], "all", N)
         if self._a0 is not None and self._a0[0] is par and self._a0[1:] == tag[1:]:
             return A
-        rows = min(N, self._chunk_rows(N))
         stream = torch.cuda.current_stream(self.device)
-        self._scores_chunk(res, par, A[:rows], 0, rows, rows, 2 if rows < N else 1, stream)
-        if rows < N:
-            self._scores_chunk(res, par, A[rows:], rows, N, rows, 2, stream)
+        if self.fused_remainder:
+            # one call: pm_gemm_nt_f64 runs whole rounds of tiles and K-slices of the ragged last round in ONE launch
+            self._scores_chunk(res, par, A, 0, N, N, 1, stream)
+        else:
+            rows = min(N, self._chunk_rows(N))
+            self._scores_chunk(res, par, A[:rows], 0, rows, rows, 2 if rows < N else 1, stream)
+            if rows < N:
+                self._scores_chunk(res, par, A[rows:], rows, N, rows, 2, stream)
         self._a0 = tag
         return A
+
+    def _launch_rows(self, N):
+        """Datapoints one ``scores_gemm`` launch covers (bench.py's roofline accounting)."""
+        return N if (self._whole_shard(N) and self.fused_remainder) else min(N, self._chunk_rows(N))
 
     def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None):
         """Scores GEMM + fused select/E-step kernel.  Whole-shard mode: the scores of all rows, then ONE pass of

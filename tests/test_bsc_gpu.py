@@ -35,7 +35,9 @@ def _stream():
 
 # ------------------------------------------------------------------------- dense kernels
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (200, 256, 1024), (333, 10, 25), (1, 1, 1), (130, 129, 18),
-                                   (5000, 256, 1024), (64, 100, 48), (257, 12, 30)])
+                                   (5000, 256, 1024), (64, 100, 48), (257, 12, 30),
+                                   (35768, 256, 256),    # one whole round of tiles + a ragged one: the fused launch
+                                   (33000, 200, 512)])   # ... with edge tiles in both directions
 def test_gemm_nt_matches_numpy(dev, M, N, K):
     from prosper_amd import _lib
     rng = np.random.RandomState(M + 7 * N + K)
