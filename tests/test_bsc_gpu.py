@@ -476,3 +476,35 @@ def test_inference_matches_reference(dev, tag, kw, capsys):
     assert res["s"].dtype == np.int8 and np.array_equal(res["s"], g[tag + "_s"])
     np.testing.assert_allclose(res["p"], g[tag + "_p"], rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(res["m"], g[tag + "_m"], rtol=1e-8, atol=1e-12)
+
+
+# ------------------------------------------------------------------------- chunked pipeline
+@pytest.mark.parametrize("overlap", [False, True])
+def test_chunked_pipeline_matches_whole_shard(dev, overlap):
+    """Shards beyond ``max_chunk_rows`` (or ``PM_CHUNK_ROUNDS``) go through the E-step in chunks of whole GEMM
+    rounds with two alternating score buffers, optionally with the next chunk's GEMM on a side stream: same
+    candidates, same log-joints as the one-buffer whole-shard mode."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, gamma, N = 32, 256, 3, 2, 70000          # one round of resident tiles = 32768 rows at H = 256
+    gen = torch.Generator(device=dev).manual_seed(7)
+    W_gt = torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64)
+    S = (torch.rand(N, H, generator=gen, device=dev) < 2.0 / H).to(torch.float64)
+    Y = S @ W_gt.t() + torch.randn(N, D, generator=gen, device=dev, dtype=torch.float64)
+    params = {"W": (W_gt + 0.1 * torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64)).cpu().numpy(),
+              "pi": 2.0 / H, "sigma": 1.0}
+    an = _An(T=1.0)
+    ref = BSC_ET(D, H, Hp, gamma)
+    assert ref._whole_shard(N)
+    d0 = ref.select_Hprimes(params, {"y": Y})
+    s0 = ref.E_step(an, params, d0)
+    m = BSC_ET(D, H, Hp, gamma)
+    m.chunk_rounds, m.overlap_streams = 1, overlap
+    assert not m._whole_shard(N) and m._chunk_rows(N) == 32768
+    d1 = m.select_Hprimes(params, {"y": Y})
+    s1 = m.E_step(an, params, d1)
+    assert torch.equal(d0["candidates"].tensor, d1["candidates"].tensor)
+    torch.testing.assert_close(s1["logpj"].tensor, s0["logpj"].tensor, rtol=1e-12, atol=1e-10)
+    torch.testing.assert_close(s1["logpj"].lse, s0["logpj"].lse, rtol=1e-12, atol=1e-10)
+    new0, new1 = ref.M_step(an, params, s0, d0), m.M_step(an, params, s1, d1)
+    for k in ("W", "pi", "sigma"):
+        np.testing.assert_allclose(new1[k], new0[k], rtol=1e-9, atol=1e-12)
