@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_sel
     const bool do_select = mode & 1, do_estep = mode & 2;
 
     const int64_t groups = (N + ROWS - 1) / ROWS;
-    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    for (int64_t g0 = blockIdx.x; g0 < groups; g0 += gridDim.x) {
+        // last rows first: the scores GEMM has just written the shard front to back, so its tail is what the
+        // memory-side cache still holds
+        const int64_t grp = groups - 1 - g0;
         const int64_t n = grp * ROWS + wave * 4 + row;
         const bool live = n < N;               // uniform per DPP row
         const int64_t nn = live ? n : N - 1;   // dead rows shadow the last datapoint, write nothing
