@@ -92,10 +92,13 @@ template <int MAXHP>
 __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
     const double *__restrict__ ynorm2, const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S,
-    const double *__restrict__ prior, pm_dsc_params P, int64_t N, int H, int Hp, double *__restrict__ logpj,
-    int64_t ldl, double *__restrict__ lse) {
+    const double *__restrict__ prior_g, pm_dsc_params P, int64_t N, int H, int Hp, double *__restrict__ logpj,
+    int64_t ldl, double *__restrict__ lse, int stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [ w2 (H) | per wave: a (Hp) G (Hp*Hp) | state table (S*Hp bytes) ]
+    // [ w2 (H) | per wave: a (Hp) G (Hp*Hp) | state table (S*Hp bytes, padded to 8) | staged: prior (Kt) | per wave: f (Kt) ]
+    // staged (when it fits): the log-prior table is read from LDS instead of global memory for every datapoint, and
+    // the row of log-joints is kept in LDS for the log-sum-exp pass instead of being read back from global memory
+    // behind its own stores (two dependent memory round trips per datapoint less)
     double *s_w2 = reinterpret_cast<double *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     double *s_a = s_w2 + H + wave * (Hp + Hp * Hp);
@@ -110,6 +113,14 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     const int nss = (P.K - 1) * H;
     const bool tab = P.flags & PM_DSC_TABLE_ONLY;        // TSC: columns = rows of the state table, nothing else
     const int base = tab ? 0 : 1 + nss;
+    const int Kt = base + S;
+    double *s_prior = reinterpret_cast<double *>(smem + (((size_t)(H + WAVES * (Hp + Hp * Hp)) * 8 + (size_t)S * Hp + 7) & ~size_t(7)));
+    double *s_f = s_prior + Kt + (size_t)wave * Kt;
+    if (stage) {
+        for (int i = tid; i < Kt; i += blockDim.x) s_prior[i] = prior_g[i];
+        __syncthreads();
+    }
+    const double *prior = stage ? s_prior : prior_g;
     for (int64_t n = (int64_t)blockIdx.x * WAVES + wave; n < N; n += (int64_t)gridDim.x * WAVES) {
         const double *arow = scores + n * lds;
         const int32_t *cn = cand + n * Hp;
@@ -123,6 +134,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
         if (!tab && lane == 0) {
             const double f0 = P.ecoef * yn + P.pscale * prior[0];
             out[0] = f0;
+            if (stage) s_f[0] = f0;
             m = f0;
         }
         // singletons: column 1 + c*H + h for the c-th non-zero value (dsc_et.py:566-568)
@@ -134,6 +146,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
                 const double e = v * v * s_w2[h] - 2.0 * v * arow[h] + yn;
                 const double f = P.ecoef * e + P.pscale * prior[1 + c * H + h];
                 out[1 + c * H + h] = f;
+                if (stage) s_f[1 + c * H + h] = f;
                 m = fmax(m, f);
             }
             ++c;
@@ -142,19 +155,21 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
             const double e = state_energy<MAXHP>(s_tab + s * Hp, Hp, s_val, s_a, s_G, yn);
             const double f = P.ecoef * e + P.pscale * prior[base + s];
             out[base + s] = f;
+            if (stage) s_f[base + s] = f;
             m = fmax(m, f);
         }
         m = pm_wave_max(m);
-        // second pass over this lane's own stores
+        // second pass over this lane's own values
+        const double *src = stage ? s_f : out;
         double sum = 0.0;
-        if (!tab && lane == 0) sum += exp(out[0] - m);
+        if (!tab && lane == 0) sum += exp(src[0] - m);
         c = 0;
         for (int k = 0; k < P.K && !tab; ++k) {
             if (k == P.K0) continue;
-            for (int h = lane; h < H; h += 64) sum += exp(out[1 + c * H + h] - m);
+            for (int h = lane; h < H; h += 64) sum += exp(src[1 + c * H + h] - m);
             ++c;
         }
-        for (int s = lane; s < S; s += 64) sum += exp(out[base + s] - m);
+        for (int s = lane; s < S; s += 64) sum += exp(src[base + s] - m);
         sum = pm_wave_sum(sum);
         if (lane == 0) lse[n] = m + log(sum);
         wave_sync_lds_dsc();
@@ -351,14 +366,18 @@ extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double 
         return PM_EINVAL;
     if (ldl < ((params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S)) return PM_EINVAL;
     if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
-    const size_t shmem = sizeof(double) * (H + WAVES * (Hprime + Hprime * Hprime)) + align8((size_t)S * Hprime);
+    size_t shmem = sizeof(double) * (H + WAVES * (Hprime + Hprime * Hprime)) + align8((size_t)S * Hprime);
     if (shmem > 150 * 1024) return PM_ERANGE;
+    const int64_t Kt = (params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S;
+    const size_t staged = shmem + sizeof(double) * (size_t)(WAVES + 1) * (size_t)Kt;
+    const int stage = staged <= 30 * 1024 ? 1 : 0;       // keep five workgroups per CU
+    if (stage) shmem = staged;
 #define PM_LAUNCH(M)                                                                                                 \
     do {                                                                                                             \
         if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_estep_kernel<M>), shmem)) return e;             \
         hipLaunchKernelGGL(dsc_estep_kernel<M>, dim3(row_grid(N, M <= 8 ? 5 : 4)), dim3(64 * WAVES), shmem,            \
                            static_cast<hipStream_t>(stream), scores, lds, gram, ynorm2, cand, state_idx, (int)S, prior, \
-                           *params_host, N, (int)H, (int)Hprime, logpj, ldl, lse);                                   \
+                           *params_host, N, (int)H, (int)Hprime, logpj, ldl, lse, stage);                            \
     } while (0)
     if (Hprime <= 8) PM_LAUNCH(8);
     else PM_LAUNCH(PM_MAX_HPRIME);
