@@ -181,9 +181,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
 template <int MAXHP>
 __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows_kernel(
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
-    const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior,
+    const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior_g,
     pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ expect, int64_t lde,
-    double *__restrict__ stats) {
+    double *__restrict__ stats, int stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [ qdiag (H) | cnt (8) | scal (4) | per wave: row (H) m (Hp) B (Hp*Hp) | state table ]
     double *s_qdiag = reinterpret_cast<double *>(smem);
@@ -204,6 +204,13 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
     const int nss = (P.K - 1) * H;
     const bool tab = P.flags & PM_DSC_TABLE_ONLY;
     const int base = tab ? 0 : 1 + nss;
+    // staged (when it fits): the log-prior table in LDS behind the state table, as in the E-step kernel
+    double *s_prior = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(s_tab) + (((size_t)S * Hp + 7) & ~size_t(7)));
+    if (stage) {
+        for (int i = tid; i < base + S; i += blockDim.x) s_prior[i] = prior_g[i];
+        __syncthreads();
+    }
+    const double *prior = stage ? s_prior : prior_g;
     const double inv_ecoef = 1.0 / P.ecoef;
     const double qcut = -60.0;     // multi-cause weights below e^-60 of the evidence add nothing in f64
     double sig = 0.0, fs = 0.0, kept = 0.0;
@@ -397,15 +404,18 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
         params_host->ecoef == 0.0)
         return PM_EINVAL;
     if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
-    const size_t shmem = sizeof(double) * (H + PM_DSC_MAX_K + 4 + WAVES * (H + Hprime + Hprime * Hprime)) +
-                         align8((size_t)S * Hprime);
+    size_t shmem = sizeof(double) * (H + PM_DSC_MAX_K + 4 + WAVES * (H + Hprime + Hprime * Hprime)) +
+                   align8((size_t)S * Hprime);
     if (shmem > 150 * 1024) return PM_ERANGE;
+    const int64_t Kt = (params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S;
+    const int stage = shmem + sizeof(double) * (size_t)Kt <= 36 * 1024 ? 1 : 0;     // four workgroups per CU stay
+    if (stage) shmem += sizeof(double) * (size_t)Kt;
 #define PM_LAUNCH(M)                                                                                                 \
     do {                                                                                                             \
         if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows_kernel<M>), shmem)) return e;        \
         hipLaunchKernelGGL(dsc_mstep_rows_kernel<M>, dim3(row_grid(N, M <= 8 ? 4 : 3)), dim3(64 * WAVES), shmem,       \
                            static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior, \
-                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats);                        \
+                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, stage);                 \
     } while (0)
     if (Hprime <= 8) PM_LAUNCH(8);
     else PM_LAUNCH(PM_MAX_HPRIME);
