@@ -125,8 +125,14 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
         const double *arow = scores + n * lds;
         const int32_t *cn = cand + n * Hp;
         const double yn = ynorm2[n];
-        if (lane < Hp) s_a[lane] = arow[cn[lane]];
-        for (int p = lane; p < Hp * Hp; p += 64) s_G[p] = gram[(int64_t)cn[p / Hp] * H + cn[p % Hp]];
+        const int myc = lane < Hp ? cn[lane] : 0;        // candidate `lane` of this datapoint: ONE load, shuffles after
+        if (lane < Hp) s_a[lane] = arow[myc];
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 64) {         // uniform trip count: every lane feeds the shuffles
+            const int p = p0 + lane;
+            const bool ok = p < Hp * Hp;
+            const int ci = __shfl(myc, ok ? p / Hp : 0), ck = __shfl(myc, ok ? p % Hp : 0);
+            if (ok) s_G[p] = gram[(int64_t)ci * H + ck];
+        }
         wave_sync_lds_dsc();
 
         double *out = logpj + n * ldl;
@@ -231,7 +237,11 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
         for (int p = lane; p < Hp * Hp; p += 64) s_B[p] = 0.0;
         // positions that are the last occurrence of their latent (all of them unless candidates repeat)
         bool mine_last = lane < Hp;
-        for (int k = lane + 1; k < Hp && lane < Hp; ++k) mine_last = mine_last && (cn[k] != cn[lane]);
+        const int myc = lane < Hp ? cn[lane] : -1;       // ONE load of the candidates; the comparisons are shuffles
+        for (int k = 1; k < Hp; ++k) {                     // uniform trip count
+            const int other = __shfl(myc, k);
+            if (k > lane && other == myc) mine_last = false;
+        }
         const unsigned long long lastmask =
             (P.flags & PM_DSC_LAST_POSITION) ? __ballot(mine_last) : ((1ull << Hp) - 1ull);
         if (lane == 0) {
@@ -290,16 +300,18 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
             }
         }
         wave_sync_lds_dsc();
-        if (lane < Hp && ((lastmask >> lane) & 1ull)) s_row[cn[lane]] += s_m[lane];   // distinct latents
+        if (lane < Hp && ((lastmask >> lane) & 1ull)) s_row[myc] += s_m[lane];   // distinct latents
         wave_sync_lds_dsc();
         for (int h = lane; h < H; h += 64) erow[h] = s_row[h];
         double *Wq = stats + (int64_t)H * D;
-        for (int p = lane; p < Hp * Hp; p += 64) {
-            const int j = p / Hp, k2 = p - j * Hp;
-            if (k2 < j || !((lastmask >> j) & 1ull) || !((lastmask >> k2) & 1ull)) continue;
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 64) {          // uniform trip count: every lane feeds the shuffles
+            const int p = p0 + lane;
+            const bool ok = p < Hp * Hp;
+            const int j = ok ? p / Hp : 0, k2 = ok ? p - j * Hp : 0;
+            const int cj = __shfl(myc, j), ck = __shfl(myc, k2);
+            if (!ok || k2 < j || !((lastmask >> j) & 1ull) || !((lastmask >> k2) & 1ull)) continue;
             const double v = s_B[p];
             if (v == 0.0) continue;
-            const int cj = cn[j], ck = cn[k2];
             const int r = cj < ck ? cj : ck, cc = cj < ck ? ck : cj;
             pm_atomic_add(Wq + (int64_t)r * H + cc, v);      // upper triangle (pm_spd_inverse_f64 layout)
         }
