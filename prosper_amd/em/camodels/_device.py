@@ -374,9 +374,9 @@ class DeviceCAModel(CAModel):
     def _solve_normal_eq(self, Wq_u, qdiag, rhs):
         """X = Wq^-1 . rhs, enqueued on the device, for the symmetric second-moment matrix
         Wq = triu(Wq_u) + triu(Wq_u, 1)^T + diag(qdiag) -- the models' ``np.linalg.lstsq(Wq, Wp)``
-        (bsc_et.py:380, dsc_et.py:741).  Returns (X (H,D), status (2,) = [failure flag, smallest / largest
-        pivot], Wq (H,H)); the caller fetches status with its one download and falls back to LAPACK's lstsq
-        on the host when the flag is set or the ratio is below 1e-11 (numerically singular)."""
+        (bsc_et.py:380, dsc_et.py:741).  Returns (X (H,D), pivots (2,) = [smallest, largest pivot of the
+        elimination; smallest <= 0 marks a failed factorisation], Wq (H,H)); the caller fetches the pivots with its
+        one download (``_solve_ok``) and falls back to LAPACK's lstsq on the host when they say "singular"."""
         H, D = rhs.shape
         if rhs.is_cuda and H <= 256:
             # one-workgroup SPD inverse + GEMMs (csrc/spd_inverse.hip) instead of ~40 rocSOLVER launches
@@ -386,22 +386,28 @@ class DeviceCAModel(CAModel):
             st = self._stream()
             self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
                        H, _ptr(piv), st)
-            X = torch.zeros((H, D), dtype=torch.float64, device=rhs.device)
+            XT = torch.zeros((2, H, D), dtype=torch.float64, device=rhs.device)     # X and the refinement's Wq.X: one fill
+            X, T = XT[0], XT[1]
             self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(rhs), D, _ptr(X), D, H, D, H, st)
             # one step of iterative refinement: X += Winv (rhs - Wq X)
-            T = torch.zeros((H, D), dtype=torch.float64, device=rhs.device)
             self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Wq), H, _ptr(X), D, _ptr(T), D, H, D, H, st)
             R = rhs - T
             self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(R), D, _ptr(X), D, H, D, H, st)
-            status = torch.stack([(piv[0] <= 0).to(torch.float64), piv[0] / piv[1]])
-            return X, status, Wq
+            return X, piv, Wq
         Wq = torch.triu(Wq_u, 1)
         Wq = Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)
         Lc, info = torch.linalg.cholesky_ex(Wq)
-        d = torch.diagonal(Lc)
+        d = torch.diagonal(Lc) ** 2                       # squared Cholesky diagonal = the elimination's pivots
         X = torch.cholesky_solve(rhs, Lc).contiguous()    # garbage if the factorisation failed
-        status = torch.stack([info.to(torch.float64).reshape(()), (d.min() / d.max()) ** 2])
-        return X, status, Wq
+        piv = torch.stack([torch.where(info.reshape(()) == 0, d.min(), -torch.ones((), dtype=d.dtype, device=d.device)),
+                           d.max()])
+        return X, piv, Wq
+
+    @staticmethod
+    def _solve_ok(piv_min, piv_max):
+        """The pivots of ``_solve_normal_eq`` describe a usable solution (positive definite, ratio above 1e-11)."""
+        ratio = piv_min / piv_max if piv_max != 0 else 0.0
+        return piv_min > 0 and np.isfinite(ratio) and ratio > 1e-11
 
     def _device_candidates(self, cand, N):
         if isinstance(cand, DeviceArray):

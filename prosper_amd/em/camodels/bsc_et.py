@@ -490,7 +490,7 @@ class BSC_ET(DeviceCAModel):
         mus = packed[o_mus:o_sc]
         learn_W, learn_mu = 'W' in self.to_learn, 'mu' in self.to_learn
 
-        parts = [packed[o_sc:o_sc + 4], mus.sum().reshape(1)]
+        parts = [packed[o_mus:o_sc + 4]]          # [mus (H) | 4 scalars], contiguous in the packed buffer; summed on the host
         Wq = rhs = seed = None
         if learn_W:
             tracing.tracepoint("M_step:update W")
@@ -503,7 +503,7 @@ class BSC_ET(DeviceCAModel):
             if packed.is_cuda and res is not None:   # next step's W^T and Gram matrix are already here: no upload then
                 seed = (X, self._gemm_nt(X, X, self._buf("gram", (H, H)), "gram_gemm"))
         if learn_mu:
-            parts += [mus, packed[n_stats:]]
+            parts += [packed[n_stats:]]
         flat = torch.cat(parts)
         if flat.is_cuda:                                        # the one synchronisation of the EM step
             spec = []
@@ -515,16 +515,17 @@ class BSC_ET(DeviceCAModel):
         else:
             host = flat.numpy()
 
-        my_sigma, Fs, N_use = float(host[0]), float(host[1]), int(round(host[2]))
-        mus_sum = float(host[4])
+        mus_h = host[:H].copy()
+        my_sigma, Fs, N_use = float(host[H]), float(host[H + 1]), int(round(host[H + 2]))
+        mus_sum = float(mus_h.sum())
         dlog.append('N', N_use)
         L = H * np.log(1 - pies) - 0.5 * D * np.log(2 * _PI * sigma ** 2) - np.log(A_pi_gamma)
         L += Fs / N_use
         dlog.append('L', L)
 
-        pos = 5
+        pos = H + 4
         if learn_W:
-            ok = host[pos] == 0 and host[pos + 1] > 1e-11 and np.isfinite(host[pos + 1])
+            ok = self._solve_ok(float(host[pos]), float(host[pos + 1]))
             if ok:
                 Wt_host = host[pos + 2:pos + 2 + H * D].reshape(H, D)
                 W_new = Wt_host.copy()
@@ -555,7 +556,7 @@ class BSC_ET(DeviceCAModel):
             tracing.tracepoint("M_step:update mu")
             # the reference divides by the rank-local kept count (bsc_et.py:428), which is only
             # meaningful on one rank; with several ranks the global count is used
-            mus_h, dsum = host[pos:pos + H], host[pos + H:pos + H + D]
+            dsum = host[pos:pos + D]
             mu_new = dsum / N_use - np.inner(W_new.T / N_use, mus_h)
         else:
             mu_new = mu

@@ -353,7 +353,7 @@ class TSC_ET(DeviceCAModel):
         dlog.append('L', L)
 
         if learn_W:
-            ok = host[12] == 0 and host[13] > 1e-11 and np.isfinite(host[13])
+            ok = self._solve_ok(float(host[12]), float(host[13]))
             if ok:
                 W_new = host[14:14 + H * D].reshape(H, D).copy()
                 if self._seed_rec is not None:
