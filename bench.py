@@ -52,7 +52,7 @@ def parse():
     return ap.parse_args()
 
 
-def other_models(dev, Anneal, steps=8):
+def other_models(dev, Anneal, steps=20):
     """EM-iteration wall-clock of the other §8(a) models at BASELINE configs 4 and 5 (one GPU's share), after the
     headline timing: GSC D=256 H=128 H'=6 gamma=3 N=200k, MCA D=256 H=128 H'=8 gamma=3 N=100k.  Informational."""
     import gc
