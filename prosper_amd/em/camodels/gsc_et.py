@@ -485,6 +485,8 @@ class GSC(DeviceCAModel):
                 model_params['sigma_sq'] = (data_sq - ((W_n @ xsz_xsz) * W_n).sum(axis=1)) / N + eps
             else:                                       # gsc_et.py:703-713
                 WT_outer = np.dot(W_n.T, W_n)
-                my_sigma_sq = sum_yy - np.trace(np.dot(xsz_xsz, WT_outer))
+                # trace(xsz_xsz . W^T W) without the H^3 product the reference forms for it (gsc_et.py:706): this line
+                # sits on the host's critical path between the M-step's download and the next E-step launch
+                my_sigma_sq = sum_yy - float(np.einsum('ij,ji->', xsz_xsz, WT_outer))
                 model_params['sigma_sq'] = (my_sigma_sq / N / D) + eps
         return model_params
