@@ -34,4 +34,4 @@ pr=cProfile.Profile(); pr.enable()
 q=cp(p)
 for _ in range(3): q=m.step(an,q,data)
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+pstats.Stats(pr).sort_stats('tottime').print_stats(16)
