@@ -219,6 +219,16 @@ def m_step_stats_vec(W_DH, mu, Y, candidates, logpj_all, SM):
             'data_sum': Y.sum(axis=0)}
 
 
+def reference_rcond():
+    """The singular-value cutoff the reference hands to lstsq (bsc_et.py:377-380): ``None`` when
+    ``float(np.__version__[2:]) >= 14.0`` (NumPy 1.14 .. 1.x), else -1 = machine precision -- which is what
+    that expression yields under NumPy 2.x ('2.2.6'[2:] = '2.6').  Only matters for a rank-deficient Wq."""
+    try:
+        return None if float(np.__version__[2:]) >= 14.0 else -1
+    except ValueError:
+        return None
+
+
 def m_step(anneal, model, W_DH, pies, sigma, mu, Y, candidates, logpj_all,
            to_learn=('W', 'pi', 'sigma'), stats_fn=m_step_stats_loop, shards=None):
     """bsc_et.py:195-438.  ``model`` = dict(H, gamma, SM).  ``shards`` (optional list of
@@ -251,7 +261,7 @@ def m_step(anneal, model, W_DH, pies, sigma, mu, Y, candidates, logpj_all,
         tot = st if tot is None else {k: tot[k] + st[k] for k in tot}
 
     if 'W' in to_learn:
-        W_new = np.linalg.lstsq(tot['Wq'], tot['Wp'], rcond=None)[0]
+        W_new = np.linalg.lstsq(tot['Wq'], tot['Wp'], rcond=reference_rcond())[0]
     else:
         W_new = W
     pi_new = E_pg * tot['pi'] / H / N_use if 'pi' in to_learn else pies

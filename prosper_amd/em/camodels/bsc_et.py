@@ -401,6 +401,11 @@ class BSC_ET(DeviceCAModel):
         sigma = model_params['sigma']
         mu = np.asarray(model_params['mu'], dtype=np.float64)
 
+        if anneal['data_noise'] > 0:
+            # upstream adds my_data['data_noise'] to y for the M-step only (bsc_et.py:228-230), a key nothing in
+            # the reference ever sets (KeyError there); not carried over -- refuse instead of ignoring the schedule
+            raise NotImplementedError("anneal['data_noise'] > 0 is not supported by the HIP M-step "
+                                      "(reference bsc_et.py:228-230 reads an undefined my_data['data_noise'])")
         res = self._resident(my_data['y'])
         Y = res["Y"]
         my_N = Y.shape[0]

@@ -90,6 +90,37 @@ def resume_params(destination, names=None):
     return out
 
 
+class StoreToH5(DataHandler):
+    """``result.h5`` writer of the reference (datalog.py:53-93 over autotable.py:87-127: one EArray per logged
+    name, one row per EM step).  Needs h5py or PyTables, neither of which is in this image: constructing it
+    without one raises with a pointer to ``StoreToNpz`` (same one-array-per-name, one-row-per-step layout).
+    With h5py present the rows are written as resizable datasets ``/<name>`` of shape (steps, ...)."""
+
+    def __init__(self, destination):
+        try:
+            import h5py
+        except Exception as e:   # pragma: no cover - h5py is absent from the target image
+            raise ImportError("StoreToH5 needs h5py (not installed here); use StoreToNpz(destination) -- same "
+                              "one-array-per-name, one-row-per-step layout, read back by resume_params()") from e
+        self._h5 = h5py.File(destination, "w")   # pragma: no cover
+        self._sets = {}                          # pragma: no cover
+
+    def append(self, tblname, value):            # pragma: no cover
+        v = np.asarray(value)
+        ds = self._sets.get(tblname)
+        if ds is None:
+            ds = self._sets[tblname] = self._h5.create_dataset(tblname, shape=(0,) + v.shape, maxshape=(None,) + v.shape,
+                                                               dtype=v.dtype, compression="gzip", compression_opts=1,
+                                                               shuffle=True)
+        if tuple(ds.shape[1:]) != v.shape:
+            raise TypeError("Wrong shape for table %s: %s, expected %s" % (tblname, v.shape, ds.shape[1:]))
+        ds.resize(ds.shape[0] + 1, axis=0)
+        ds[-1] = v
+
+    def close(self):                             # pragma: no cover
+        self._h5.close()
+
+
 class DataLog(object):
     def __init__(self, comm=COMM_WORLD):
         self.comm = comm

@@ -330,7 +330,11 @@ class FixedAnneal(dict):
 
 
 def bsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior, bars=False,
-                  mu=False, to_learn=("W", "pi", "sigma"), sigma_gt=1.0, amp=1.0):
+                  mu=False, to_learn=("W", "pi", "sigma"), sigma_gt=1.0, amp=1.0, big=False):
+    """``big`` (config-2 dimensions): the inputs are rounded to float32-representable values and stored as float32
+    (the reference runs on their exact float64 upcasts), and the all-reduced statistics Wq / Wp the reference hands
+    to ``np.linalg.lstsq`` (bsc_et.py:373-380) are captured: with N < H datapoints Wq is rank-deficient and W_new
+    is then only defined up to the SVD cutoff -- the statistics are what pins the path."""
     rng = np.random.RandomState(seed)
     if bars:
         W_gt = 10 * generate_bars_dict(H)
@@ -347,13 +351,25 @@ def bsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior, bars=Fa
     params = {"W": W_gt + 0.3 * amp * rng.normal(size=(D, H)), "pi": pi_gt * 1.3, "sigma": sigma_gt * 1.2}
     if mu:
         params["mu"] = mu_vec + 0.05 * rng.normal(size=D)
+    if big:
+        y = y.astype(np.float32).astype(np.float64)
+        params["W"] = params["W"].astype(np.float32).astype(np.float64)
     anneal = FixedAnneal(T=T, Ncut_factor=Ncut, anneal_prior=anneal_prior)
     inp = {k: np.array(v, copy=True) for k, v in params.items()}
     data = {"y": y.copy()}
     Capture.rows.clear()
     data = model.select_Hprimes(params, data)
     ss = model.E_step(anneal, params, data)
-    new = model.M_step(anneal, params, ss, data)
+    seen, lstsq = {}, np.linalg.lstsq
+
+    def spy(a, b, rcond=None):
+        seen["Wq"], seen["Wp"], seen["rcond"] = np.array(a, copy=True), np.array(b, copy=True), rcond
+        return lstsq(a, b, rcond=rcond)
+    np.linalg.lstsq = spy
+    try:
+        new = model.M_step(anneal, params, ss, data)
+    finally:
+        np.linalg.lstsq = lstsq
     assert np.isfinite(new["W"]).all() and np.isfinite(Capture.rows["L"][0]), name
     out = dict(D=D, H=H, Hprime=Hp, gamma=gamma, T=T, Ncut_factor=Ncut, anneal_prior=bool(anneal_prior),
                to_learn=np.array(list(to_learn)), y=y, W=inp["W"], pi=inp["pi"], sigma=inp["sigma"],
@@ -362,8 +378,14 @@ def bsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior, bars=Fa
                W_new=new["W"], pi_new=new["pi"], sigma_new=new["sigma"], mu_new=new["mu"],
                L=Capture.rows["L"][0], N=Capture.rows["N"][0], N_use=Capture.rows["N_use"][0],
                state_matrix=model.state_matrix, state_abs=model.state_abs)
+    if big:
+        sv = np.linalg.svd(seen["Wq"], compute_uv=False)
+        out.update(y=y.astype(np.float32), W=inp["W"].astype(np.float32), Wq=seen["Wq"], Wp=seen["Wp"],
+                   rcond=-1.0 if seen["rcond"] is not None else np.nan, Wq_rank_ratio=sv[-1] / sv[0])
+        assert np.array_equal(out["y"].astype(np.float64), y) and np.array_equal(out["W"].astype(np.float64), inp["W"])
     np.savez_compressed(os.path.join(HERE, "bsc_step_%s.npz" % name), **out)
-    print("bsc_step_%s: N=%d K=%d L=%.6f N_use=%d" % (name, N, ss["logpj"].shape[1], out["L"], out["N_use"]))
+    print("bsc_step_%s: N=%d K=%d L=%.6f N_use=%d%s" % (name, N, ss["logpj"].shape[1], out["L"], out["N_use"],
+                                                         " smin/smax(Wq)=%.2e" % out["Wq_rank_ratio"] if big else ""))
 
 
 def bsc_trajectory():
@@ -429,14 +451,18 @@ def anneal_tracks():
     print("anneal_tracks ok", names)
 
 
-def main(only=None):
-    """``only``: regenerate just the fixtures whose name starts with this prefix (e.g. ``mmca``)."""
+def main(only=None, cases=None):
+    """``only``: regenerate just the fixtures whose maker's name starts with this prefix (e.g. ``mmca``);
+    ``cases``: of those, just the named step cases (e.g. ``c2_plain,c2_cut``)."""
     want = lambda fn: only is None or fn.__name__.startswith(only)
     g = globals()
     for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
                "bsc_trajectory", "bsc_init", "anneal_tracks"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
+    if cases:
+        for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "tsc_step_case"):
+            g[_n] = (lambda fn: (lambda name, *a, **k: fn(name, *a, **k) if name in cases else None))(g[_n])
     # BASELINE config-1 dims (D=25 H=10 H'=5 gamma=3)
     bsc_step_case("c1_plain", 25, 10, 5, 3, 400, seed=1, T=1.0, Ncut=0.0, anneal_prior=False, bars=True)
     bsc_step_case("c1_anneal_cut", 25, 10, 5, 3, 333, seed=2, T=1.7, Ncut=0.6, anneal_prior=True, bars=True)
@@ -448,11 +474,16 @@ def main(only=None):
     bsc_step_case("mu", 40, 16, 5, 3, 180, seed=8, T=1.1, Ncut=0.5, anneal_prior=False, mu=True,
                   to_learn=("W", "pi", "sigma", "mu"))
     bsc_step_case("h256", 96, 256, 8, 4, 96, seed=9, T=1.0, Ncut=0.0, anneal_prior=False, amp=0.5)
+    # BASELINE config-2 dims (D=1024 H=256 H'=8 gamma=4, K=411); sigma_gt = 2 keeps the reference's
+    # un-stabilised exp(logpj) sums above the underflow threshold for every datapoint of the sample
+    bsc_step_case("c2_plain", 1024, 256, 8, 4, 128, seed=12, T=1.0, Ncut=0.0, anneal_prior=False, sigma_gt=2.0, big=True)
+    bsc_step_case("c2_cut", 1024, 256, 8, 4, 128, seed=13, T=1.2, Ncut=0.7, anneal_prior=False, sigma_gt=2.0, big=True)
     gsc_step_case("small", 16, 8, 4, 3, 200, seed=31, T=1.0)
     gsc_step_case("small_T", 16, 8, 4, 3, 151, seed=32, T=1.5, full_psi=True)
     gsc_step_case("h24", 40, 24, 5, 3, 120, seed=33, T=1.0, full_psi=True)
     gsc_step_case("g4", 30, 12, 5, 4, 100, seed=34, T=1.2)
     gsc_step_case("h128", 64, 128, 6, 3, 64, seed=35, T=1.0)
+    gsc_step_case("c4", 256, 128, 6, 3, 96, seed=40, T=1.0)           # BASELINE config-4 dims
     gsc_step_case("diag", 16, 8, 4, 3, 200, seed=36, T=1.0, sigma_type="diagonal")
     gsc_step_case("diag_T", 40, 24, 5, 3, 120, seed=37, T=1.4, full_psi=True, sigma_type="diagonal")
     gsc_step_case("full", 16, 8, 4, 3, 200, seed=38, T=1.0, sigma_type="full")
@@ -462,6 +493,8 @@ def main(only=None):
     mca_step_case("bars", 25, 10, 5, 3, 300, seed=23, T=1.0, Ncut=1.0, bars=True)
     mca_step_case("h40", 48, 40, 6, 3, 150, seed=24, T=2.0, Ncut=0.7)
     mca_step_case("h128", 64, 128, 8, 3, 96, seed=25, T=1.0, Ncut=0.0)
+    mca_step_case("c5", 256, 128, 8, 3, 96, seed=26, T=1.0, Ncut=0.0)    # BASELINE config-5 dims
+    mca_step_case("c5_cut", 256, 128, 8, 3, 80, seed=27, T=1.3, Ncut=0.6)
     tsc_step_case("small", 16, 8, 4, 3, 300, seed=81, T=1.0, Ncut=0.0, anneal_prior=False)
     tsc_step_case("cut", 24, 12, 5, 3, 257, seed=82, T=1.4, Ncut=0.6, anneal_prior=True)
     tsc_step_case("g2", 30, 20, 6, 2, 200, seed=83, T=1.0, Ncut=1.0, anneal_prior=False)
@@ -489,4 +522,4 @@ def main(only=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else None)
+    main(sys.argv[1] if len(sys.argv) > 1 else None, sys.argv[2].split(",") if len(sys.argv) > 2 else None)

@@ -21,7 +21,8 @@ BASELINE_RTOL = 1e-4
 
 @pytest.fixture(scope="module")
 def dev():
-    assert torch.cuda.is_available(), "these tests need the GPU box"
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
     return torch.device("cuda", 0)
 
 

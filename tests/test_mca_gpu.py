@@ -29,7 +29,8 @@ def _cases():
 
 @pytest.mark.parametrize("case", _cases())
 def test_mca_step_matches_reference_golden(case):
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
     from prosper_amd.em.camodels.mca_et import MCA_ET
     from prosper_amd.utils.datalog import dlog, StoreInMemory
     g = golden(case)

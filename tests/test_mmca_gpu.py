@@ -40,7 +40,8 @@ def _same_candidates(cand, ref, W_DH, y):
 
 @pytest.mark.parametrize("case", _cases())
 def test_mmca_step_matches_reference_golden(case):
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
     from prosper_amd.em.camodels.mmca_et import MMCA_ET
     from prosper_amd.utils.datalog import dlog, StoreInMemory
     g = golden(case)
