@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-models", action="store_true", help="skip the GSC / MCA EM-iteration side measurements")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
+    ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed E-step passes by wall time before the warm-up")
     return ap.parse_args()
 
 
@@ -60,6 +61,7 @@ def other_models(dev, Anneal, steps=20):
     import torch
     from prosper_amd.em.camodels.gsc_et import GSC
     from prosper_amd.em.camodels.mca_et import MCA_ET
+    from prosper_amd.em.camodels._device import KernelTimer
     out = {}
     gc.collect()
     gc.disable()               # as in the headline loops: a full collection is a ~70-80 ms host stall
@@ -88,6 +90,22 @@ def other_models(dev, Anneal, steps=20):
         torch.cuda.synchronize()
         out["gsc_c4_em_iter_ms"] = (time.perf_counter() - t) / steps * 1e3
         out["gsc_c4"] = "GSC D=256 H=128 H'=6 gamma=3 scalar sigma_sq, N=%d" % N
+        m.timer = kt = KernelTimer()
+        for _ in range(3):
+            p = m.step(Anneal(T=1.0), p, {"y": Y})
+        m.timer = None
+        ks = kt.summary()
+        out["gsc_c4_kernels_ms"] = {k: round(v[1], 4) for k, v in sorted(ks.items())}
+        if "estep" in ks:
+            # dominant kernel: gsc_estep_kernel.  Algorithmic HBM bytes per launch: the scores row in (H f64), xpt_s | xpt_sz
+            # rows out (2H f64), candidates (H' int32) per datapoint; the (H,H) moment sums stay on chip.
+            nbytes = N * (3 * Hm * 8 + 6 * 4)
+            gbs = nbytes / (ks["estep"][1] * 1e-3) / 1e9
+            out["gsc_c4_roofline"] = {"bound": "hbm", "kernel": "gsc_estep_kernel (select + E-step, one pass over the scores)",
+                                      "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                      "avg_launch_ms": ks["estep"][1], "algorithmic_bytes": nbytes, "traffic": None,
+                                      "note": "latency / f64-VALU bound row kernel (35 multi-cause states with g x g solves in "
+                                              "registers per datapoint): far from the HBM roof by construction, DESIGN section 4"}
         del Y, m
         # --- MCA, config 5 (N = 800k over 8 GPUs)
         N = 100_000
@@ -111,6 +129,27 @@ def other_models(dev, Anneal, steps=20):
         torch.cuda.synchronize()
         out["mca_c5_em_iter_ms"] = (time.perf_counter() - t) / steps * 1e3
         out["mca_c5"] = "MCA_ET D=256 H=128 H'=8 gamma=3, N=%d (one GPU's share of 800k)" % N
+        m.timer = kt = KernelTimer()
+        for _ in range(3):
+            p = m.step(Anneal(T=1.0), p, {"y": Y})
+        m.timer = None
+        ks = kt.summary()
+        out["mca_c5_kernels_ms"] = {k: round(v[1], 4) for k, v in sorted(ks.items())}
+        lab = "estep_mstats" if "estep_mstats" in ks else ("estep" if "estep" in ks else None)
+        if lab:
+            # dominant kernel: the fused E-step + M-statistics pass.  Its algorithmic work is one f64 power
+            # Wbar_sd = (sum_j W_jd^rho)^(1/rho) per multi-cause state and observed dimension (mca_et.py:170): S x D per
+            # datapoint, ~50 f64 VALU instructions each (pm_pow_pos).  Peak: the f64 vector rate, 78.6 TFLOP/s = 39.3 T
+            # FMA-class instructions/s chip-wide, / 50 per power.
+            S_mca = m.no_states
+            npow = float(N) * S_mca * Dm
+            ach = npow / (ks[lab][1] * 1e-3) / 1e9
+            peak = MFMA_F64_PEAK_TFLOPS * 1e12 / 2 / 50 / 1e9
+            out["mca_c5_roofline"] = {"bound": "valu_f64", "kernel": "mca_estep_fused_kernel (E-step + M-step statistics)",
+                                      "achieved": ach, "peak": peak, "unit": "Gpow/s", "frac": ach / peak,
+                                      "avg_launch_ms": ks[lab][1], "algorithmic_pows": npow, "traffic": None,
+                                      "note": "f64 transcendental bound (S*D powers per datapoint at ~50 VALU instructions "
+                                              "each, peak derived from the 78.6 TFLOP/s f64 vector rate); not an HBM or MFMA kernel"}
     except Exception as e:   # never lose the headline over the side measurements
         out["error"] = repr(e)
     gc.enable()
@@ -198,6 +237,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     comm = parallel.Comm()
+    comm.time_collectives(True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -242,12 +282,24 @@ def main():
         d = model.select_Hprimes(params, data)
         return model.E_step(anneal, params, d)
 
+    # Pre-warm by TIME (disclosed as prewarm_ms): the chip needs ~35 ms of sustained load to reach the clock it then
+    # holds and the first ~20 passes of a process run 5-7 % slow; without this a short run (--steps 20 --warmup 5 is a
+    # 40 ms timed region) would be measured inside the ramp.  Then the W counted warm-up passes, then the K timed ones.
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < args.prewarm_ms * 1e-3:
+        for _ in range(5):
+            estep_pass()
+        torch.cuda.synchronize()
+    prewarm_ms = (time.perf_counter() - tw) * 1e3
     for _ in range(args.warmup):
         estep_pass()
-    # HIP events around the dominant kernel only (first scores-GEMM launch of every step): an event
-    # pair costs ~10 us of stream time, so the other kernels are timed in a separate, untimed pass
-    chunks_per_step = max(1, N // model._launch_rows(N))
-    timer = KernelTimer(only={"scores_gemm"}, stride=chunks_per_step)
+    # HIP events around the dominant kernel only (every 4th launch): an event pair costs ~10 us of stream time, so
+    # the other kernels are timed in a separate, untimed pass
+    fused = model._fused()
+    dom = "estep_fused" if fused else "scores_gemm"
+    chunks_per_step = 1 if fused else max(1, N // model._launch_rows(N))
+    timer = KernelTimer(only={dom}, stride=4 * chunks_per_step)
     model.timer = timer
     gc.collect()
     gc.disable()           # a full collection of a torch process is a ~70 ms host stall; keep it out of the timed loops
@@ -298,34 +350,54 @@ def main():
         torch.cuda.empty_cache()
         others = other_models(dev, Anneal)
 
-    t = torch.tensor([elapsed, em_elapsed], dtype=torch.float64, device=dev)
+    # the all-reduce of the M-step statistics, timed with events around the collective (EM loop above)
+    ar = comm.collective_times()
+    allreduce_us = 1e3 * sum(ar) / len(ar) if ar else 0.0
+    # per-rank record: what every rank generated and measured (a SCALE record stays attributable)
+    mine = torch.tensor([elapsed, em_elapsed, allreduce_us, float(100 + rank), float(N)], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, em_elapsed = float(t[0]), float(t[1])
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu().numpy()
+    else:
+        per_rank = mine.cpu().numpy()[None, :]
+    elapsed, em_elapsed = float(per_rank[:, 0].max()), float(per_rank[:, 1].max())   # MAX over ranks
 
     if rank == 0:
-        # HBM-side bytes of the dominant kernel from the committed rocprofv3 --pmc passes
+        fused = model._fused()
+        dom = "estep_fused" if fused else "scores_gemm"
+        chunk = N if fused else model._launch_rows(N)
+        # HBM-side bytes of the dominant kernel: NOT measured in this run -- from the committed rocprofv3 --pmc passes
         # (profiles/summarize_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), per launch
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            # the launch is recognised by its grid: whole rounds of tiles + K-slices of the ragged last round
-            cands = [k for k, v in pmc.items() if k.startswith("scores_gemm@grid") and
-                     v.get("datapoints_per_launch") == model._launch_rows(N)]
-            traffic = pmc[cands[0]]["hbm_bytes"] if (cands and N == N_PER_GPU) else None
-        except Exception:
-            traffic = None
+        traffic, traffic_source = None, None
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]
+                cands = [k for k, v in pmc.items() if k.startswith(dom) and v.get("datapoints_per_launch") == chunk]
+                if cands and N == N_PER_GPU:
+                    traffic = pmc[cands[0]]["hbm_bytes"]
+                    traffic_source = "profiles/%s (separate rocprofv3 --pmc passes of this command, not this run)" % fn
+                    break
+            except Exception:
+                pass
         ms_step = elapsed / args.steps * 1e3
         value = world * N * args.steps / elapsed
-        # dominant kernel: the scores GEMM, launched once per pipeline chunk of `chunk` datapoints
-        chunk = model._launch_rows(N)
-        gemm_ms = kern["scores_gemm"][1]
+        dom_ms = kern[dom][1]
         flops = 2.0 * chunk * D * H                        # algorithmic flops of one such launch (524 288 / datapoint)
-        achieved = flops / (gemm_ms * 1e-3) / 1e12
-        estep_bytes = N * (D * 8 + HP * 4 + (1 + H + 154) * 8)   # 11 512 B/datapoint
+        achieved = flops / (dom_ms * 1e-3) / 1e12
+        K_states = 1 + H + model.no_states
+        estep_bytes = N * (D * 8 + HP * 4 + K_states * 8)   # 11 512 B/datapoint
+        mfma_roof_dps = MFMA_F64_PEAK_TFLOPS * 1e12 / (2.0 * D * H)      # 150 M datapoints/s
+        if fused:
+            kname = "bsc_estep_fused_kernel (scores GEMM + select_Hprimes + E_step, one launch per pass)"
+            alg_bytes = chunk * (D * 8 + HP * 4 + (K_states + 1) * 8) + H * D * 8
+        else:
+            kname = "gemm_nt_f64_dma_kernel (scores A = Y.W^T)"
+            alg_bytes = chunk * (D + H) * 8 + H * D * 8
         out = {
             "metric": "E-step datapoints/sec (+ EM-iter wall-clock) BSC D=1024 H=256 H'=8",
             "value": value, "unit": "datapoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "prewarm_ms": prewarm_ms,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BSC_ET synthetic Gaussian D=1024 H=256 H'=8 gamma=4 (K=411 states), "
@@ -333,15 +405,24 @@ def main():
                        "global_datapoints": world * N, "parallelism": "dp%d" % world},
             "em_iter_ms": em_elapsed / args.em_steps * 1e3,
             "em_iter_datapoints_per_s": world * N * args.em_steps / em_elapsed,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f64_dma_kernel (scores A = Y.W^T)",
+            "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (algorithmic: %d)" % (chunk * (D + H) * 8 + H * D * 8),
-                         "avg_launch_ms": gemm_ms, "datapoints_per_launch": chunk,
-                         "launches_per_step": chunks_per_step, "launches_timed": kern["scores_gemm"][0],
-                         "estep_hbm_frac": (estep_bytes / (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS},
+                         "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_unit": "bytes/launch (algorithmic: %d)" % alg_bytes,
+                         "avg_launch_ms": dom_ms, "datapoints_per_launch": chunk,
+                         "launches_per_step": chunks_per_step, "launches_timed": kern[dom][0],
+                         # the whole pass (Gram matrix + dominant kernel [+ row kernel]) against both roofs
+                         "estep_mfma_frac": (value / world) / mfma_roof_dps,
+                         "estep_hbm_frac": (estep_bytes / (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                         "note": "north_star's '>= 80 % of the HBM roofline' cannot be met in float64: the E-step carries "
+                                 "524 288 flop per datapoint against 11 512 B (45 flop/B; machine balance 10 flop/B), so the "
+                                 "f64 MFMA roof (150 M datapoints/s) binds at 22 % of the HBM roof; estep_mfma_frac is the "
+                                 "whole-pass fraction of that roof, frac the dominant kernel's"},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(all_kern.items())},
             "em_kernels_ms": {k: round(v[1], 4) for k, v in sorted(em_kern.items())},
+            "per_rank": [{"rank": r, "ms_per_step": per_rank[r, 0] / args.steps * 1e3,
+                          "em_iter_ms": per_rank[r, 1] / args.em_steps * 1e3, "allreduce_us": per_rank[r, 2],
+                          "data_seed": int(per_rank[r, 3]), "rows": int(per_rank[r, 4])} for r in range(world)],
             "cpu_baseline": cpu,
             "parity": parity,
             "other_models": others,

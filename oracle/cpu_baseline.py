@@ -58,6 +58,29 @@ def _worker(args):
     return done, t_e, m_done, t_m
 
 
+def _vectorised(D, H, Hp, gamma, budget, rows=4096):
+    """The "fair CPU" figure: the oracle's GEMM + Gram-matrix E-step (select_hprimes_vec +
+    e_step_vec) on chunks of `rows` datapoints with multi-threaded BLAS, in THIS process."""
+    rng = np.random.RandomState(0)
+    W_gt = rng.normal(size=(D, H))
+    rng = np.random.RandomState(2000)
+    pi_gt = 4.0 / H
+    model = O.make_model(D, H, Hp, gamma)
+    W = W_gt + 0.1 * rng.normal(size=(D, H))
+    an = O.Anneal(T=1.0)
+    mu = np.zeros(D)
+    y, _ = O.generate_bsc_data(W_gt, pi_gt, 1.0, rows, rng)
+    O.select_hprimes_vec(W, y[:64], Hp)            # first-call overheads (thread pool) out of the clock
+    done, t = 0, 0.0
+    while t < budget:
+        t0 = time.perf_counter()
+        cand = O.select_hprimes_vec(W, y, Hp)
+        O.e_step_vec(an, W, pi_gt, 1.0, mu, y, cand, model["SM"], model["state_abs"])
+        t += time.perf_counter() - t0
+        done += rows
+    return done / t, done
+
+
 def parity_case(path, D, H, Hp, gamma, N=1536, steps=3):
     """Reference answer for bench.py's parity report: `steps` EM steps of the (vectorised, golden-pinned)
     oracle on a seeded sample at the bench's dimensions.  Written as plain arrays to `path`; bench.py runs
@@ -91,10 +114,37 @@ def main():
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--cores", type=int, default=0)
     ap.add_argument("--parity-out", default="", help="also write the oracle's answer for bench.py's parity report")
+    ap.add_argument("--solo-budget", type=float, default=3.0, help="seconds of E-step work of ONE uncontended process")
+    ap.add_argument("--vec-budget", type=float, default=3.0, help="seconds of the vectorised multi-threaded leg")
+    ap.add_argument("--vec-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.vec_only:      # child of this script, started with a multi-threaded BLAS environment
+        rate, rows = _vectorised(a.D, a.H, a.Hprime, a.gamma, a.vec_budget)
+        print(json.dumps({"value": rate, "rows": rows}))
+        return
     if a.parity_out:
         parity_case(a.parity_out, a.D, a.H, a.Hprime, a.gamma)
     cores = a.cores or len(os.sched_getaffinity(0))
+    # one process alone on the box: the per-core rate without the memory-system contention of `cores` workers
+    solo = None
+    if a.solo_budget > 0:
+        d, t, _, _ = _worker((997, a.D, a.H, a.Hprime, a.gamma, a.solo_budget, 0.0, a.chunk))
+        solo = d / t
+    vec = None
+    if a.vec_budget > 0:
+        import subprocess
+        threads = min(cores, 64)
+        env = dict(os.environ, OPENBLAS_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--vec-only", "--D", str(a.D), "--H", str(a.H),
+                                  "--Hprime", str(a.Hprime), "--gamma", str(a.gamma), "--vec-budget", str(a.vec_budget)],
+                                 env=env, check=True, capture_output=True, text=True, timeout=120).stdout.strip().splitlines()
+            v = json.loads(out[-1])
+            vec = {"value": v["value"], "unit": "datapoints/s", "blas_threads": threads, "rows": v["rows"],
+                   "what": "oracle select_hprimes_vec + e_step_vec (one GEMM + Gram-matrix algebra, NumPy/OpenBLAS), "
+                           "chunks of 4096 datapoints"}
+        except Exception as e:   # the faithful figure is still worth reporting
+            vec = {"value": None, "error": repr(e)}
     ctx = mp.get_context("spawn")
     jobs = [(r, a.D, a.H, a.Hprime, a.gamma, a.budget, a.full_budget, a.chunk) for r in range(cores)]
     t0 = time.perf_counter()
@@ -113,6 +163,7 @@ def main():
                   "per core; faithful per-datapoint NumPy loops, 1 BLAS thread per process" % (
                       rows, a.D, a.H, a.Hprime, a.gamma, a.chunk, a.budget),
         "per_core_estep": per_core_e, "per_core_mstep": per_core_m, "full_step_value": full,
+        "uncontended_per_core": solo, "vectorised": vec,
         "wall_s": wall,
     }))
 

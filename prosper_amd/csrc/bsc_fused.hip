@@ -1,0 +1,338 @@
+// Binary Sparse Coding: scores GEMM + select_Hprimes + E_step in ONE kernel (bsc_et.py:98-192).
+//
+// The two-kernel path (gemm_f64.hip -> bsc_rows16.hip) writes the (N,H) scores to HBM and reads them back
+// (820 MB per pass at config 2) and runs the row kernel strictly after the GEMM.  Here a workgroup owns 64
+// datapoints x ALL H latents: wavefront w accumulates rows 16 w .. 16 w + 15 against every latent, and
+// v_mfma_f64_16x16x4_f64 leaves that block in exactly the layout the row pass works in (bsc_rows16_body.h): the four
+// 16-lane DPP rows of the wavefront each hold one datapoint, lane j of a row holds latents j, j + 16, ... .  So the
+// epilogue -- top-H', Gram gather, state energies, log-joints, log-sum-exp -- runs out of the accumulators: no scores
+// buffer, no second launch, no cross-wavefront exchange.
+//
+// K-loop: LDS-DMA ring as in gemm_nt_f64_dma_kernel (global_load_lds_dwordx4, XOR swizzle on the source address,
+// counted s_waitcnt vmcnt, one raw s_barrier per K-step).  Stage = [64 datapoint rows | 16 NJ latent rows] x 8 doubles.
+// Per K-step and wavefront: 1 + NJ/4 DMA instructions, 1 + NJ ds_read_b128, 2 NJ MFMAs; the latent fragments are read
+// four column blocks at a time, one group ahead of the MFMAs that consume them.
+// Two workgroups per CU: while one is in its epilogue (VALU, memory latency) the other keeps the matrix pipe busy.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "prosper_hip.h"
+#include "pm_common.h"
+#include "bsc_rows16_body.h"
+
+namespace {
+
+using namespace pm_rows16;
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int DK = 8;          // K columns per ring stage
+constexpr int AROWS = 64;      // datapoints per workgroup: 4 wavefronts x 16 rows
+
+__device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#ifdef PM_FUSED_STAMPS   // diagnostic build (scratch/fused_stamps.sh): per-workgroup timeline, never in the shipped library
+__device__ unsigned long long pm_fused_stamps[8192][8];
+#define PM_STAMP(slot)                                                                      \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 8192)                                          \
+            pm_fused_stamps[blockIdx.x][slot] = __builtin_amdgcn_s_memrealtime();           \
+    } while (0)
+#else
+#define PM_STAMP(slot)
+#endif
+
+template <int NJ, int STAGES>
+__global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
+    const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wt, int64_t ldw, int D,
+    const double *__restrict__ gram, const double *__restrict__ ynorm2, const double *__restrict__ wmu,
+    const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
+    SizeOffsets so, int S, int gamma, pm_bsc_estep_params P, int64_t N, int H, int Hp, int mode,
+    int32_t *__restrict__ cand, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse) {
+    constexpr int STAGE = (AROWS + 16 * NJ) * DK;   // doubles per stage
+    constexpr int L = 1 + NJ / 4;                   // DMA instructions per K-step and wavefront
+    constexpr int NG = NJ / 4;                      // groups of four column blocks
+    static_assert(NG % 2 == 0, "fragment buffers alternate per group; a K-step must start on buffer 0");
+    extern __shared__ __attribute__((aligned(1024))) double sm[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * AROWS;
+    PM_STAMP(0);
+#ifdef PM_FUSED_STAMPS
+    if (tid == 0 && blockIdx.x < 8192)
+        pm_fused_stamps[blockIdx.x][7] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                                         __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+#endif
+
+    // per-thread table entries, fetched now (unconditional, clamped loads: no wait before the K-loop) and parked in
+    // registers until the epilogue
+    const int th = tid < H ? tid : H - 1;
+    const double t_g = gram[(int64_t)th * H + th];
+    double t_wmu = 0.0;
+    if (wmu) t_wmu = wmu[th];
+    uint32_t t_tab = 0;
+    if (S > 0) {
+        const int ts = tid < S ? tid : S - 1;
+        t_tab = (uint32_t)masks[ts] | ((uint32_t)parents[ts] << 16);
+    }
+
+    // DMA sources: this wavefront moves its own 16 datapoint rows and latent blocks wave, wave + 4, ...
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((lane >> 4) & 3);
+    // (a fixed bound: with a template-dependent array type the LDS-DMA builtin is only checked when the kernel is
+    // instantiated -- also for the host, where it does not exist -- and hipcc then silently drops the host stub)
+    const double *src[5];
+    static_assert(L <= 5, "src[] holds the datapoint rows + NJ/4 latent blocks");
+    {
+        int64_t ra = m0 + 16 * wave + dr;
+        ra = ra < N ? ra : N - 1;
+        src[0] = Y + ra * ldy + 2 * dj;
+#pragma unroll
+        for (int q = 0; q < NJ / 4; ++q) {
+            int rb = 16 * (wave + 4 * q) + dr;
+            rb = rb < H ? rb : H - 1;
+            src[1 + q] = Wt + (int64_t)rb * ldw + 2 * dj;
+        }
+    }
+    auto dma = [&](int kt, int stage) {
+        double *dst = sm + stage * STAGE + wave * 128;  // chunk = 16 rows x 8 doubles
+        const int k0 = kt * DK;
+        __builtin_amdgcn_global_load_lds(src[0] + k0, dst, 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NJ / 4; ++q)
+            __builtin_amdgcn_global_load_lds(src[1 + q] + k0, dst + (4 + 4 * q) * 128, 16, 0, 0);
+    };
+
+    // fragment reads (see gemm_nt_f64_dma_kernel): k-group fk of the first MFMA of a K-step takes column 2 fk, of the
+    // second column 2 fk + 1 -- the 16-byte slot the DMA wrote; pair p of row R sits at R*8 + ((p ^ ((R>>2)&3)) << 1)
+    const int frow = lane & 15, fk = lane >> 4;
+    const int sw = (frow >> 2) & 3;
+    const int a_off = (wave * 16 + frow) * DK + ((fk ^ sw) << 1);
+    const int b_off = AROWS * DK + frow * DK + ((fk ^ sw) << 1);
+    auto read_a = [&](int stage) { return *reinterpret_cast<const d2 *>(sm + stage * STAGE + a_off); };
+    auto read_b = [&](int stage, int g, d2 (&f)[4]) {
+        const double *sb = sm + stage * STAGE + b_off + g * 4 * 16 * DK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const d2 *>(sb + q * 16 * DK);
+    };
+
+    d4 acc[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int nk = D / DK;   // host guarantees D % DK == 0, D >= DK
+#pragma unroll
+    for (int t = 0; t < STAGES; ++t)
+        if (t < nk) dma(t, t);
+    // this wavefront's part of K-step 0 has landed
+    {
+        const int behind = (nk < STAGES ? nk : STAGES) - 1;   // K-steps issued beyond step 0
+        if (behind >= 3) wait_vmcnt<3 * L>();
+        else if (behind == 2) wait_vmcnt<2 * L>();
+        else if (behind == 1) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+
+    d2 fa = read_a(0), fa_next = fa;
+    d2 fb[2][4];
+    read_b(0, 0, fb[0]);
+
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        const int nstage = (stage + 1 == STAGES) ? 0 : stage + 1;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+                read_b(stage, g + 1, fb[(g + 1) & 1]);
+            } else if (t + 1 < nk) {
+                // my reads of this stage are done (lgkmcnt) and my share of K-step t+1 has landed (vmcnt); after the
+                // barrier that holds for every wavefront: stage t may be refilled, t+1 may be read
+                int ahead = nk - t - 2;
+                ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ahead >= 2) wait_vmcnt<2 * L>();
+                else if (ahead == 1) wait_vmcnt<L>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                fa_next = read_a(nstage);
+                read_b(nstage, 0, fb[0]);
+                if (t + STAGES < nk) dma(t + STAGES, stage);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa.x, fb[g & 1][q].x, acc[4 * g + q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa.y, fb[g & 1][q].y, acc[4 * g + q]);
+        }
+        fa = fa_next;
+        stage = nstage;
+    }
+
+    PM_STAMP(1);
+    // ---------------- epilogue: the row passes, straight from the accumulators --------------------------------
+    // every wavefront is done with the ring: its LDS becomes the row kernels' scratch
+    // [ w2 (16 NJ) | sw (16 NJ) | per datapoint (16 of them): d (16) G (Hp*Hp) e (S) | tab (S x u32) ]
+    __builtin_amdgcn_s_barrier();
+    double *s_w2 = sm;
+    double *s_sw = s_w2 + 16 * NJ;
+    double *s_dp = s_sw + 16 * NJ;
+    const int dp_stride = 16 + Hp * Hp + S;
+    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_dp + ROWS * dp_stride);
+    if (tid < 16 * NJ) {
+        s_w2[tid] = t_g + 2.0 * t_wmu;
+        s_sw[tid] = 1.0 / sqrt(t_g);
+    }
+    if (tid < S) s_tab[tid] = t_tab;
+    for (int s = 256 + tid; s < S; s += 256) s_tab[s] = (uint32_t)masks[s] | ((uint32_t)parents[s] << 16);
+    __syncthreads();
+
+    PM_STAMP(2);
+    double *s_d = s_dp + (wave * 4 + fk) * dp_stride;
+    const RowParams A{gram, ynorm2, wmu, ymu, S, gamma, P, N, H, Hp, mode, cand, logpj, ldl, lse};
+    const RowLds Lds{s_w2, s_sw, s_tab, s_d, s_d + 16, s_d + 16 + Hp * Hp};
+
+    // DPP row fk of this wavefront holds datapoint m0 + 16 wave + fk + 4 r in element r of every accumulator.
+    // Selection for all four passes first, then the E-step passes: the ranking keys and the E-step temporaries are
+    // never live together with all four sets of scores.
+    int mycs[4];
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        double a[NJ];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) a[i] = r == 0 ? acc[i][0] : r == 1 ? acc[i][1] : r == 2 ? acc[i][2] : acc[i][3];
+        const int c = row_select<NJ>(a, A, Lds, lane, m0 + 16 * wave + fk + 4 * r);
+        mycs[0] = r == 0 ? c : mycs[0];
+        mycs[1] = r == 1 ? c : mycs[1];
+        mycs[2] = r == 2 ? c : mycs[2];
+        mycs[3] = r == 3 ? c : mycs[3];
+    }
+    PM_STAMP(3);
+    if (!(mode & 2)) return;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        double a[NJ];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) a[i] = r == 0 ? acc[i][0] : r == 1 ? acc[i][1] : r == 2 ? acc[i][2] : acc[i][3];
+        const int c = r == 0 ? mycs[0] : r == 1 ? mycs[1] : r == 2 ? mycs[2] : mycs[3];
+        row_estep<NJ, true>(a, nullptr, c, A, so, Lds, lane, m0 + 16 * wave + fk + 4 * r);
+    }
+    PM_STAMP(4);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// PM_FUSED_STAGES=3 selects a three-stage ring (60 KB at H = 256 instead of 80 KB)
+int fused_stages() {
+    static int v = 0;
+    if (!v) {
+        const char *e = getenv("PM_FUSED_STAGES");
+        v = (e && e[0] == '3') ? 3 : 4;
+    }
+    return v;
+}
+
+template <int NJ, int ST>
+size_t fused_lds_bytes(int64_t Hp, int64_t S) {
+    const size_t ring = sizeof(double) * ST * (AROWS + 16 * NJ) * DK;
+    const size_t epi = sizeof(double) * (2 * 16 * NJ + ROWS * (16 + Hp * Hp + S)) + sizeof(uint32_t) * S;
+    return ring > epi ? ring : epi;
+}
+
+}  // namespace
+
+// The fused kernel covers H <= 256 latents (16 accumulator tiles per wavefront), D a multiple of 8, 16-byte aligned
+// rows, and whatever pm_bsc_rows16_supported admits for the row passes.
+extern "C" int pm_bsc_fused_supported(int64_t H, int64_t D, int64_t Hprime, int64_t S) {
+    if (H <= 0 || H > 256 || D < DK || D % DK != 0) return 0;
+    return pm_bsc_rows16_supported(H, Hprime, S);
+}
+
+#ifdef PM_FUSED_STAMPS
+extern "C" int pm_fused_read_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pm_fused_stamps), sizeof(unsigned long long) * 8 * n);
+}
+#endif
+
+// Workgroups of the fused kernel one CU holds at once for this shape (LDS- and register-limited; 2 is the design
+// point: one in its K-loop on the matrix pipe while the other runs its row passes).  <= 0: not supported / error.
+extern "C" int pm_bsc_fused_occupancy(int64_t H, int64_t D, int64_t Hprime, int64_t S) {
+    if (!pm_bsc_fused_supported(H, D, Hprime, S)) return 0;
+    int n = 0;
+    const bool three = fused_stages() == 3;
+    hipError_t e;
+#define PM_OCC(NJ, ST)                                                                                                 \
+    do {                                                                                                               \
+        const size_t shmem = fused_lds_bytes<NJ, ST>(Hprime, S);                                                       \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                               \
+        if (e == hipSuccess)                                                                                           \
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bsc_estep_fused_kernel<NJ, ST>, 256, shmem);          \
+    } while (0)
+    if (H <= 128) {
+        if (three) PM_OCC(8, 3);
+        else PM_OCC(8, 4);
+    } else {
+        if (three) PM_OCC(16, 3);
+        else PM_OCC(16, 4);
+    }
+#undef PM_OCC
+    return e == hipSuccess ? n : -(int)e;
+}
+
+extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
+                                      const double *ynorm2, const double *wmu, const double *ymu,
+                                      const uint16_t *state_masks, const uint16_t *state_parents,
+                                      const int32_t *size_offsets_host, int64_t S, int64_t gamma,
+                                      const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
+                                      int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
+                                      void *stream) {
+    if (!Y || !Wt || !gram || !ynorm2 || !cand || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || ldy < D ||
+        ldw < D || !(mode & 3) || ((wmu == nullptr) != (ymu == nullptr)))
+        return PM_EINVAL;
+    if ((mode & 2) && (!params_host || !logpj || ldl < 1 + H + S || gamma < 1 || gamma > Hprime ||
+                       (S > 0 && (!state_masks || !state_parents || !size_offsets_host))))
+        return PM_EINVAL;
+    if (!pm_bsc_fused_supported(H, D, Hprime, S)) return PM_ERANGE;
+    if (!aligned16(Y) || !aligned16(Wt) || (ldy % 2) || (ldw % 2)) return PM_EINVAL;
+    if (N == 0) return PM_OK;
+    SizeOffsets so;
+    for (int g = 0; g < PM_MAX_HPRIME; ++g) so.off[g] = (int)S;
+    if ((mode & 2) && S > 0)
+        for (int g = 0; g < gamma; ++g) so.off[g] = size_offsets_host[g];  // off[g-2] = first state of size g
+    pm_bsc_estep_params P = params_host ? *params_host : pm_bsc_estep_params{0, 0, 0, 0};
+    const int64_t tiles = (N + AROWS - 1) / AROWS;
+    if (tiles > INT32_MAX) return PM_ERANGE;
+    dim3 grid((unsigned)tiles), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PM_LAUNCH(NJ, ST)                                                                                              \
+    do {                                                                                                               \
+        const size_t shmem = fused_lds_bytes<NJ, ST>(Hprime, S);                                                       \
+        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST>),           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))                  \
+            return e;                                                                                                  \
+        hipLaunchKernelGGL((bsc_estep_fused_kernel<NJ, ST>), grid, block, shmem, s, Y, ldy, Wt, ldw, (int)D, gram,     \
+                           ynorm2, wmu, ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H,        \
+                           (int)Hprime, mode, cand, logpj, ldl, lse);                                                  \
+    } while (0)
+    const bool three = fused_stages() == 3;
+    if (H <= 128) {
+        if (three) PM_LAUNCH(8, 3);
+        else PM_LAUNCH(8, 4);
+    } else {
+        if (three) PM_LAUNCH(16, 3);
+        else PM_LAUNCH(16, 4);
+    }
+#undef PM_LAUNCH
+    return (int)hipGetLastError();
+}

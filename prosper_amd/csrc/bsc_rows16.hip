@@ -11,69 +11,22 @@
 //                               the two, candidates never round-trip through HBM
 //   bsc_mstep_rows16_kernel     per-datapoint part of M_step (bsc_et.py:271-272,334-366,395-415)
 //
-// Multi-cause state energies are built incrementally by state size (pairs, triples, ...):
-//   e'(s) = e'(s minus its highest candidate k) + d_k + 2 sum_{i in s, i<k} G[c_i, c_k],
-//   d_k = G[c_k,c_k] - 2 a_{c_k},   e(s) = |y|^2 + e'(s)
-// with the parent's index precomputed on the host; a state costs |s|+1 LDS reads instead of
-// |s|(|s|+3)/2.  Posterior terms below exp(-37) (< 1e-16 of the largest) are skipped wave-wide.
+// The per-datapoint pass of the first kernel lives in bsc_rows16_body.h (shared with the fused
+// scores-GEMM + E-step kernel of bsc_fused.hip).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
 #include "prosper_hip.h"
 #include "pm_common.h"
+#include "bsc_rows16_body.h"
 
 namespace {
 
-constexpr int ROWS = 16;          // datapoints per 256-thread workgroup (4 wavefronts x 4 DPP rows)
-constexpr double NEGLIGIBLE = -37.0;
-
-// ---- DPP helpers (all-reduce butterflies inside a 16-lane row) -------------------------------
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp32(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
-template <int CTRL>
-__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
-    const unsigned lo = dpp32<CTRL>((unsigned)v), hi = dpp32<CTRL>((unsigned)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-template <int CTRL>
-__device__ __forceinline__ double dppf64(double v) {
-    return __longlong_as_double((long long)dpp64<CTRL>((uint64_t)__double_as_longlong(v)));
-}
-// xor 1, xor 2 (quad_perm), reverse within 8 (row_half_mirror), reverse within 16 (row_mirror)
-#define PM_ROW_BUTTERFLY(OP, T, F)          \
-    v = OP(v, F<0xB1>(v));                  \
-    v = OP(v, F<0x4E>(v));                  \
-    v = OP(v, F<0x141>(v));                 \
-    v = OP(v, F<0x140>(v));
-__device__ __forceinline__ double fadd(double a, double b) { return a + b; }
-__device__ __forceinline__ double row_max_f64(double v) {
-    PM_ROW_BUTTERFLY(fmax, double, dppf64)
-    return v;
-}
-__device__ __forceinline__ double row_sum_f64(double v) {
-    PM_ROW_BUTTERFLY(fadd, double, dppf64)
-    return v;
-}
-
-__device__ __forceinline__ void wave_lds_sync16() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-
-
-struct SizeOffsets {  // multi-cause states of size g occupy [off[g-2], off[g-1]) ; g = 2..gamma
-    int off[PM_MAX_HPRIME];
-};
+using namespace pm_rows16;
 
 // ---------------------------------------------------------------------------------------------
-// select_Hprimes + E_step
-//   mode bit 0: select (compute + write candidates); else candidates are read from `cand`
-//   mode bit 1: E-step (write logpj / lse)
-//   mode bit 2: rank smallest first; bit 3: rank the scores as they are; bit 4: rank the squared
-//               distance |W_h|^2 - 2 a_h (MMCA, mmca_et.py:119-120)
+// select_Hprimes + E_step: pm_rows16::row_select / row_estep per group of 16 datapoints (mode bits: see RowParams)
 // ---------------------------------------------------------------------------------------------
 template <int VPL>
 __global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_select_estep16_kernel(
@@ -101,10 +54,8 @@ __global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_sel
     __syncthreads();
 
     double *s_d = s_dp + (wave * 4 + row) * dp_stride;
-    double *s_G = s_d + 16;
-    double *s_e = s_G + Hp * Hp;
-    const double ppil = P.prior_scale * P.pil_bar;
-    const bool do_select = mode & 1, do_estep = mode & 2;
+    const RowParams A{gram, ynorm2, wmu, ymu, S, gamma, P, N, H, Hp, mode, cand, logpj, ldl, lse};
+    const RowLds L{s_w2, s_sw, s_tab, s_d, s_d + 16, s_d + 16 + Hp * Hp};
 
     const int64_t groups = (N + ROWS - 1) / ROWS;
     for (int64_t g0 = blockIdx.x; g0 < groups; g0 += gridDim.x) {
@@ -112,158 +63,16 @@ __global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_sel
         // memory-side cache still holds
         const int64_t grp = groups - 1 - g0;
         const int64_t n = grp * ROWS + wave * 4 + row;
-        const bool live = n < N;               // uniform per DPP row
-        const int64_t nn = live ? n : N - 1;   // dead rows shadow the last datapoint, write nothing
+        const int64_t nn = n < N ? n : N - 1;   // dead rows shadow the last datapoint, write nothing
         const double *arow = scores + nn * lds;
-
         double a[VPL];
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
             a[i] = (h < H) ? arow[h] : 0.0;
         }
-        double yn = ynorm2[nn];
-
-        // ---------------- top-H' of a / |W_h| / |y| (ascending, best last) -------------------
-        int myc = 0;  // lane j < Hp ends up with candidate position j
-        if (do_select) {
-            const double sy = 1.0 / sqrt(yn);
-            const bool smallest = mode & 4, raw = mode & 8, dist = mode & 16;
-            // Ranking keys are DOUBLES whose low 10 mantissa bits carry the latent index (v_max_f64 is one
-            // instruction, a 64-bit integer maximum three; the keys keep 42 mantissa bits either way).  Ties resolve
-            // as a stable argsort would: largest-first keeps the larger index last-best, smallest-first the smaller
-            // index first -- the index code counts up for non-negative keys and down for negative ones, whose
-            // magnitude grows with the low bits.  NaN ranks below every number, +-inf are clamped to the largest
-            // finite magnitudes (their low bits must stay free), -inf itself marks "taken".
-            double key[VPL];
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                const int h = j + 16 * i;
-                double kx = -INFINITY;
-                if (h < H) {
-                    double x = raw ? a[i] : dist ? s_w2[h] - 2.0 * a[i] : a[i] * s_sw[h] * sy;
-                    if (smallest) x = -x;
-                    uint64_t b = (uint64_t)__double_as_longlong(x);
-                    if (x != x) b = 0xFFEFFFFFFFFFFC00ull;
-                    else if ((b & 0x7FF0000000000000ull) == 0x7FF0000000000000ull)
-                        b = (b & 0x8000000000000000ull) | 0x7FEFFFFFFFFFF800ull;
-                    const uint64_t code = (uint64_t)(smallest ? 0x3FF - h : h);
-                    b = (b & ~0x3FFull) | ((b >> 63) ? 0x3FFull - code : code);
-                    kx = __longlong_as_double((long long)b);
-                }
-                key[i] = kx;
-            }
-            for (int r = 0; r < Hp; ++r) {
-                double m = key[0];
-#pragma unroll
-                for (int i = 1; i < VPL; ++i) m = __builtin_fmax(m, key[i]);
-                m = row_max_f64(m);
-#pragma unroll
-                for (int i = 0; i < VPL; ++i)
-                    if (key[i] == m) key[i] = -INFINITY;
-                const uint64_t mb = (uint64_t)__double_as_longlong(m);
-                const int code = (int)(mb & 0x3FFull);
-                const int win = (mb >> 63) ? 0x3FF - code : code;
-                if (j == (smallest ? r : Hp - 1 - r)) myc = smallest ? 0x3FF - win : win;
-            }
-            if (live && j < Hp) cand[n * Hp + j] = myc;
-        } else {
-            if (j < Hp) myc = cand[nn * Hp + j];
-        }
-        if (!do_estep) continue;
-
-        // ---------------- candidate block: d_k and G[c_i,c_k] -> LDS ------------------------
-        if (ymu) yn = yn - 2.0 * ymu[nn] + P.mu_sqnorm;
-        if (j < Hp) {
-            const int c = myc;
-            const double ac = arow[c] - (wmu ? wmu[c] : 0.0);
-            s_d[j] = gram[(int64_t)c * H + c] - 2.0 * ac;
-        }
-        for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {            // uniform trip count: every lane feeds the bpermutes
-            const int p = p0 + j;
-            const bool valid = p < Hp * Hp;
-            const int i = valid ? p / Hp : 0, k = valid ? p - i * Hp : 0;
-            // candidates i and k of this datapoint, from the lanes of its DPP row that hold them
-            const int ci = __builtin_amdgcn_ds_bpermute(((lane & 48) + i) << 2, myc);
-            const int ck = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc);
-            if (valid) s_G[p] = gram[(int64_t)ci * H + ck];
-        }
-        wave_lds_sync16();
-
-        // ---------------- multi-cause energies by size --------------------------------------
-        for (int g = 2; g <= gamma; ++g) {
-            for (int s = so.off[g - 2] + j; s < so.off[g - 1]; s += 16) {
-                const uint32_t t = s_tab[s];
-                const unsigned mask = t & 0xFFFFu;
-                const int k = 31 - __builtin_clz(mask);  // highest candidate position of the state
-                unsigned rest = mask & ~(1u << k);
-                double e = s_d[k];
-                if (g == 2) {
-                    const int i = __builtin_ctz(rest);
-                    e += s_d[i] + 2.0 * s_G[i * Hp + k];
-                } else {
-                    e += s_e[t >> 16];
-                    double off = 0.0;
-                    while (rest) {
-                        const int i = __builtin_ctz(rest);
-                        rest &= rest - 1;
-                        off += s_G[i * Hp + k];
-                    }
-                    e += 2.0 * off;
-                }
-                s_e[s] = e;
-            }
-            wave_lds_sync16();
-        }
-
-        // ---------------- log-pseudo-joints ---------------------------------------------------
-        double *out = logpj + nn * ldl;
-        double mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {  // a[i] becomes the singleton log-joint of latent h
-            const int h = j + 16 * i;
-            double f = -INFINITY;
-            if (h < H) {
-                const double e = s_w2[h] - 2.0 * a[i] + yn;
-                f = ppil + P.ecoef * e;
-                if (live) out[1 + h] = f;
-            }
-            a[i] = f;
-            mx = fmax(mx, f);
-        }
-        const double f0 = P.ecoef * yn;
-        if (j == 0) {
-            if (live) out[0] = f0;
-            mx = fmax(mx, f0);
-        }
-        for (int s = j; s < S; s += 16) {
-            const unsigned mask = s_tab[s] & 0xFFFFu;
-            const double f = ppil * (double)__builtin_popcount(mask) + P.ecoef * (yn + s_e[s]);
-            if (live) out[1 + H + s] = f;
-            s_e[s] = f;  // kept for the log-sum-exp pass (same lane re-reads it)
-            mx = fmax(mx, f);
-        }
-        if (!lse) {
-            wave_lds_sync16();
-            continue;
-        }
-        mx = row_max_f64(mx);
-        double sum = (j == 0) ? exp(f0 - mx) : 0.0;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const double dlt = a[i] - mx;
-            const bool need = dlt > NEGLIGIBLE;
-            if (__any(need)) sum += need ? exp(dlt) : 0.0;
-        }
-        for (int s0 = 0; s0 < S; s0 += 16) {  // uniform trip count
-            const int s = s0 + j;
-            const double dlt = (s < S) ? s_e[s] - mx : -INFINITY;
-            const bool need = dlt > NEGLIGIBLE;
-            if (__any(need)) sum += need ? exp(dlt) : 0.0;
-        }
-        sum = row_sum_f64(sum);
-        if (live && j == 0) lse[n] = mx + log(sum);
-        wave_lds_sync16();  // per-datapoint LDS areas are reused by the next group
+        const int myc = row_select<VPL>(a, A, L, lane, n);
+        if (mode & 2) row_estep<VPL, false>(a, arow, myc, A, so, L, lane, n);
     }
 }
 

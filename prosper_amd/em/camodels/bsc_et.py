@@ -49,6 +49,7 @@ class BSC_ET(DeviceCAModel):
         self._spec_ok = False    # the last M-step's seeded parameters were used as they were
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.fused_remainder = os.environ.get('PM_GEMM_FUSE_REMAINDER', '1') == '1'   # ragged last round inside the main launch
+        self.use_fused = os.environ.get('PM_FUSED', '1') == '1'   # scores GEMM + select + E-step as ONE kernel (bsc_fused.hip)
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
         self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
         self.max_chunk_rows = 1 << 20
@@ -160,7 +161,38 @@ class BSC_ET(DeviceCAModel):
             par["A"] = A
         return par
 
-    # ---- fused, chunked select + E-step (fast path) -------------------------------------------
+    # ---- scores GEMM + select + E-step in one kernel ---------------------------------------------
+    def _fused(self):
+        """The one-kernel E-step applies (H <= 256 and the row passes' LDS areas fit); the K dimension is zero-padded
+        to a multiple of 8 where D is not one."""
+        if not (self.use_fused and self._state_tables()["fast"]):
+            return False
+        D8 = (self.D + 7) // 8 * 8
+        return bool(_lib.load().pm_bsc_fused_supported(self.H, D8, self.Hprime, self.no_states))
+
+    def _k8(self, holder, name, t):
+        """``t`` (rows, D) with its rows zero-padded to a multiple of 8 columns (cached in ``holder``)."""
+        D8 = (self.D + 7) // 8 * 8
+        if D8 == self.D and t.stride(0) % 2 == 0 and t.data_ptr() % 16 == 0:
+            return t
+        p = holder.get(name)
+        if p is None or p[0] is not t:
+            buf = torch.zeros((t.shape[0], D8), dtype=torch.float64, device=self.device)
+            buf[:, :self.D] = t
+            p = holder[name] = (t, buf)
+        return p[1]
+
+    def _fused_estep(self, res, par, mode, cand, P, wmu, ymu, logpj, lse):
+        tab = self._state_tables()
+        Y8, W8 = self._k8(res, "Y8", res["Y"]), self._k8(par, "Wt8", par["Wt"])
+        N = Y8.shape[0]
+        ldl = logpj.stride(0) if logpj is not None else 0
+        self._call("estep_fused", "pm_bsc_estep_fused_f64", _ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
+                   _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
+                   self.no_states, self.gamma, ctypes.byref(P) if P is not None else None, N, Y8.shape[1], self.H,
+                   self.Hprime, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse), self._stream())
+
+    # ---- scores GEMM, then the fused, chunked select + E-step (two-kernel path) -------------------
     def _round_rows(self):
         """Rows of one round of resident 128x128 GEMM tiles (2 workgroups per CU)."""
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
@@ -213,6 +245,9 @@ class BSC_ET(DeviceCAModel):
         straight away, so the scores buffer is bounded (two alternating buffers).  Measured: chunk size barely
         matters (one round per chunk 2.27 ms, whole shard 2.15 ms per pass at config 2).
         ``overlap``: GEMM of chunk c+1 on a side stream while the row kernel of chunk c runs."""
+        if self._fused():
+            self._fused_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse)
+            return
         Y = res["Y"]
         N, H, Hp, S = Y.shape[0], self.H, self.Hprime, self.no_states
         tab = self._state_tables()
@@ -270,7 +305,7 @@ class BSC_ET(DeviceCAModel):
         """Enqueue the scores GEMMs as soon as W is known (select_Hprimes, or speculatively at the end of an
         M-step), so the device is busy while the host walks on to E_step."""
         N = res["Y"].shape[0]
-        if N and self._whole_shard(N):
+        if N and self._whole_shard(N) and not self._fused():
             self._ensure_scores(res, par)
 
     def _materialize_candidates(self, ticket):

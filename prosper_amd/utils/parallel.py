@@ -57,6 +57,7 @@ class Comm(object):
 
     def __init__(self, group=None):
         self._group = group
+        self._timed = None      # [(start event, end event)] of the device all-reduces when timing is on (bench.py)
 
     # -- topology ---------------------------------------------------------
     def _live(self):
@@ -151,8 +152,28 @@ class Comm(object):
         is a single ncclAllReduce over xGMI; replaces the eight MPI calls of
         bsc_et.py:225-417."""
         if self.size > 1:
-            dist.all_reduce(tensor, group=self._group)
+            if self._timed is not None and tensor.is_cuda:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                dist.all_reduce(tensor, group=self._group)
+                b.record()
+                self._timed.append((a, b))
+            else:
+                dist.all_reduce(tensor, group=self._group)
         return tensor
+
+    def time_collectives(self, on=True):
+        """Record HIP events around every device all-reduce from now on (``collective_times`` reads them)."""
+        self._timed = [] if on else None
+
+    def collective_times(self):
+        """Milliseconds of every timed device all-reduce so far (synchronises); the list is cleared."""
+        if not self._timed:
+            return []
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._timed]
+        self._timed = []
+        return out
 
 
 COMM_WORLD = Comm()

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import golden, bsc_step_cases
+from conftest import golden, bsc_step_cases, rank_deficient
 
 pytestmark = pytest.mark.gpu
 
@@ -180,12 +180,31 @@ class _An(dict):
         return dict(self)
 
 
-def _run_step(g, to_learn=None, rows16=True):
+PATHS = ["fused", "rows16", "wave64"]   # one-kernel E-step | scores GEMM + 16-lane row kernel | generic kernels
+
+
+def _set_path(m, path):
+    m.use_rows16 = path != "wave64"     # False: the generic one-wavefront-per-datapoint kernels
+    m.use_fused = path == "fused"       # scores GEMM + select + E-step in one kernel (bsc_fused.hip)
+    return m
+
+
+def _device_stats(m):
+    """(Wp (H,D), Wq (H,H)) assembled from the packed statistics buffer of the model's last M-step."""
+    from prosper_amd import _lib
+    lib = _lib.load()
+    H, D = m.H, m.D
+    st = m._ws["stats"].cpu().numpy()
+    o_wq, o_qd, o_mus = lib.pm_bsc_stats_offset_wq(H, D), lib.pm_bsc_stats_offset_qdiag(H, D), lib.pm_bsc_stats_offset_mus(H, D)
+    U = st[o_wq:o_qd].reshape(H, H)
+    return st[:o_wq].reshape(H, D).copy(), np.triu(U) + np.triu(U, 1).T + np.diag(st[o_qd:o_mus])
+
+
+def _run_step(g, to_learn=None, path="fused"):
     from prosper_amd.em.camodels.bsc_et import BSC_ET
     from prosper_amd.utils.datalog import dlog, StoreInMemory
     to_learn = to_learn or [str(s) for s in g["to_learn"]]
-    m = BSC_ET(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]), to_learn=to_learn)
-    m.use_rows16 = rows16    # False: the generic one-wavefront-per-datapoint kernels
+    m = _set_path(BSC_ET(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]), to_learn=to_learn), path)
     an = _An(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
     params = {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])}
     if bool(g["has_mu"]):
@@ -201,11 +220,11 @@ def _run_step(g, to_learn=None, rows16=True):
 
 
 @pytest.mark.parametrize("case", bsc_step_cases())
-@pytest.mark.parametrize("rows16", [True, False], ids=["rows16", "wave64"])
-def test_bsc_step_matches_reference_golden(dev, case, rows16):
+@pytest.mark.parametrize("path", PATHS)
+def test_bsc_step_matches_reference_golden(dev, case, path):
     g = golden(case)
-    m, params, data, ss, new, log = _run_step(g, rows16=rows16)
-    assert m._state_tables()["fast"] == rows16
+    m, params, data, ss, new, log = _run_step(g, path=path)
+    assert m._state_tables()["fast"] == (path != "wave64") and m._fused() == (path == "fused")
     cand = np.asarray(data["candidates"])
     assert cand.dtype == np.int64 and np.array_equal(cand, g["candidates"])
     logpj = np.asarray(ss["logpj"])
@@ -215,7 +234,12 @@ def test_bsc_step_matches_reference_golden(dev, case, rows16):
     assert int(log["N"][0]) == int(g["N"]) and int(log["N_use"][0]) == int(g["N_use"])
     np.testing.assert_allclose(float(log["L"][0]), float(g["L"]), rtol=1e-11)
     scale = np.abs(g["W_new"]).max()
-    np.testing.assert_allclose(new["W"], g["W_new"], rtol=RTOL_STEP, atol=RTOL_STEP * scale)
+    if "Wq" in g:      # config-2 fixtures: the all-reduced statistics the reference handed to lstsq (bsc_et.py:373-380)
+        Wp, Wq = _device_stats(m)
+        np.testing.assert_allclose(Wq, g["Wq"], rtol=1e-9, atol=1e-12 * np.abs(g["Wq"]).max())
+        np.testing.assert_allclose(Wp, g["Wp"], rtol=1e-9, atol=1e-12 * np.abs(g["Wp"]).max())
+    if not rank_deficient(g):      # (else W_new is defined only up to lstsq's SVD cutoff: the statistics pin it)
+        np.testing.assert_allclose(new["W"], g["W_new"], rtol=RTOL_STEP, atol=RTOL_STEP * scale)
     np.testing.assert_allclose(new["pi"], g["pi_new"], rtol=RTOL_STEP)
     np.testing.assert_allclose(new["sigma"], g["sigma_new"], rtol=RTOL_STEP)
     np.testing.assert_allclose(new["mu"], g["mu_new"], rtol=1e-7, atol=1e-9)
@@ -387,6 +411,113 @@ def test_bsc_step_matches_oracle(dev, D, H, Hp, gamma, N, T, ncut, ap):
     np.testing.assert_allclose(new["W"], ref["W"], rtol=10 * tol, atol=tol * np.abs(ref["W"]).max())
     np.testing.assert_allclose(new["pi"], ref["pi"], rtol=1e-9)
     np.testing.assert_allclose(new["sigma"], ref["sigma"], rtol=1e-9)
+
+
+# ------------------------------------------------------------------------- one-kernel E-step vs the two-kernel path
+@pytest.mark.parametrize("D,H,Hp,gamma,N,with_mu", [
+    (1024, 256, 8, 4, 4500, False),     # config-2 dims, ragged last tile (4500 = 70 * 64 + 20)
+    (64, 200, 7, 3, 1000, False),       # H not a multiple of 16: clamped latent rows, masked columns
+    (40, 100, 5, 3, 333, True),         # H <= 128 instantiation, D padded to 40 -> 40, data offset mu
+    (25, 10, 5, 3, 129, False),         # config-1 dims: K dimension zero-padded 25 -> 32
+    (512, 256, 6, 6, 64, False),        # gamma = H' (2^H' - H' - 1 multi-cause states), exactly one tile
+])
+def test_fused_estep_matches_two_kernel_path(dev, D, H, Hp, gamma, N, with_mu):
+    """pm_bsc_estep_fused_f64 (scores GEMM + select + E-step in one launch) against pm_gemm_nt_f64 followed by
+    pm_bsc_select_estep_f64: same candidates, same log-joints, same log-evidence -- in all three modes (selection only,
+    E-step on given candidates, both)."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    rng = np.random.RandomState(D + H + N)
+    W_gt = rng.normal(size=(D, H))
+    y = (rng.random_sample((N, H)) < 2.5 / H) @ W_gt.T + rng.normal(size=(N, D))
+    params = {"W": W_gt + 0.2 * rng.normal(size=(D, H)), "pi": 2.5 / H, "sigma": 1.1}
+    if with_mu:
+        params["mu"] = 0.3 * rng.normal(size=D)
+    an = _An(T=1.3, anneal_prior=True)
+    out = {}
+    for path in ("fused", "rows16"):
+        m = _set_path(BSC_ET(D, H, Hp, gamma), path)
+        assert m._fused() == (path == "fused")
+        p = dict(params)
+        d = m.select_Hprimes(p, {"y": y})
+        ss = m.E_step(an, p, d)                                    # mode 3: selection + log-joints in one pass
+        cand, lp, lse = np.asarray(d["candidates"]), np.asarray(ss["logpj"]), ss["logpj"].lse.cpu().numpy()
+        m2 = _set_path(BSC_ET(D, H, Hp, gamma), path)
+        c1 = np.asarray(m2.select_Hprimes(dict(params), {"y": y})["candidates"])      # mode 1: selection alone
+        ss2 = m2.E_step(an, dict(params), {"y": y, "candidates": cand})               # mode 2: given candidates
+        assert np.array_equal(c1, cand)
+        # (not bit for bit: small shards of the two-kernel path go through the split-K GEMM, whose f64 atomics sum in
+        # run-to-run order)
+        np.testing.assert_allclose(np.asarray(ss2["logpj"]), lp, rtol=1e-12, atol=1e-10)
+        out[path] = (cand, lp, lse)
+    assert np.array_equal(out["fused"][0], out["rows16"][0])
+    np.testing.assert_allclose(out["fused"][1], out["rows16"][1], rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(out["fused"][2], out["rows16"][2], rtol=1e-12, atol=1e-10)
+
+
+def test_config2_full_shard_against_oracle(dev):
+    """BASELINE config 2 at its real size -- D=1024 H=256 H'=8 gamma=4, N = 200 000 on the bench's generator -- through
+    the shipped launches (one fused E-step launch of 3125 tiles; with PM_FUSED=0: 196 608 rows of whole GEMM rounds +
+    3 392 rows as fused K-slices).  Datapoints are independent given the parameters, so the vectorised oracle is run
+    on ~1000 sampled rows (spread over the shard, dense around the whole-rounds / remainder boundary and at the end):
+    candidates exact, log-joints to 1e-10; the M-step statistics of the sample as its own shard against the oracle's,
+    and additivity of the full shard's statistics over two halves."""
+    from oracle import bsc_oracle as O
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, gamma, N = 1024, 256, 8, 4, 200_000
+    g0 = torch.Generator(device=dev).manual_seed(0)
+    W_gt = torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)
+    W0 = (W_gt + 0.1 * torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)).cpu().numpy()
+    gr = torch.Generator(device=dev).manual_seed(100)
+    Y = torch.empty(N, D, dtype=torch.float64, device=dev)
+    for lo in range(0, N, 25_000):
+        S = (torch.rand(25_000, H, generator=gr, device=dev) < 4.0 / H).to(torch.float64)
+        Y[lo:lo + 25_000] = S @ W_gt.t() + torch.randn(25_000, D, generator=gr, device=dev, dtype=torch.float64)
+    del S
+    params = {"W": W0, "pi": 4.0 / H, "sigma": 1.0, "mu": np.zeros(D)}
+    an = _An(T=1.0)
+    rng = np.random.RandomState(5)
+    rows = np.unique(np.concatenate([rng.randint(0, N, size=600), np.arange(196_608 - 100, 196_608 + 100),
+                                     np.arange(N - 100, N), np.arange(0, 64)]))
+    y_s = Y[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    om = O.make_model(D, H, Hp, gamma)
+    cand_ref = O.select_hprimes_vec(W0, y_s, Hp)
+    lp_ref = O.e_step_vec(O.Anneal(T=1.0), W0, params["pi"], params["sigma"], params["mu"], y_s, cand_ref,
+                          om["SM"], om["state_abs"])
+    st_ref = O.m_step_stats_vec(W0, params["mu"], y_s, cand_ref, lp_ref, om["SM"])
+
+    for path in ("fused", "rows16"):
+        m = _set_path(BSC_ET(D, H, Hp, gamma), path)
+        d = m.select_Hprimes(dict(params), {"y": Y})
+        ss = m.E_step(an, dict(params), d)
+        idx = torch.from_numpy(rows).to(dev)
+        cand = d["candidates"].tensor[idx].cpu().numpy()
+        assert np.array_equal(cand, cand_ref), path
+        np.testing.assert_allclose(ss["logpj"].tensor[idx].cpu().numpy(), lp_ref, rtol=1e-10, atol=1e-9, err_msg=path)
+        torch.testing.assert_close(ss["logpj"].lse, torch.logsumexp(ss["logpj"].tensor, dim=1), rtol=1e-12, atol=1e-10)
+        # M-step statistics: the full shard, then additivity over two halves
+        m.M_step(an, dict(params), ss, d)
+        full = m._ws["stats"].clone()
+        if path == "fused":
+            acc = torch.zeros_like(full)
+            for sl in (slice(0, 98_765), slice(98_765, N)):
+                mh = _set_path(BSC_ET(D, H, Hp, gamma), path)
+                dh = mh.select_Hprimes(dict(params), {"y": Y[sl]})
+                mh.M_step(an, dict(params), mh.E_step(an, dict(params), dh), dh)
+                acc += mh._ws["stats"]
+                del mh, dh
+            torch.testing.assert_close(acc, full, rtol=1e-9, atol=1e-8)
+        del m, d, ss
+    # the sampled rows as a shard of their own: statistics against the oracle's
+    ms = _set_path(BSC_ET(D, H, Hp, gamma), "fused")
+    ds = ms.select_Hprimes(dict(params), {"y": y_s})
+    ms.M_step(an, dict(params), ms.E_step(an, dict(params), ds), ds)
+    Wp, Wq = _device_stats(ms)
+    np.testing.assert_allclose(Wp, st_ref["Wp"], rtol=1e-9, atol=1e-11 * np.abs(st_ref["Wp"]).max())
+    np.testing.assert_allclose(Wq, st_ref["Wq"], rtol=1e-9, atol=1e-12 * np.abs(st_ref["Wq"]).max())
+    from prosper_amd import _lib
+    sc = ms._ws["stats"].cpu().numpy()[_lib.load().pm_bsc_stats_offset_scalars(H, D):][:3]
+    np.testing.assert_allclose(sc[0], st_ref["sigma"], rtol=1e-10)
+    assert int(round(sc[2])) == len(rows)
 
 
 def test_empty_and_tiny_shards(dev):
