@@ -181,71 +181,53 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
 
     PM_STAMP(1);
     // ---------------- epilogue: the row passes, straight from the accumulators --------------------------------
-    // every wavefront is done with the ring: its LDS becomes the row kernels' scratch
-    // [ w2 (16 NJ) | sw (16 NJ) | per datapoint (16 of them): d (16) G (Hp*Hp) e (S) | tab (S x u32) ]
+    // every wavefront is done with the ring: its LDS becomes the row passes' tables and datapoint areas
     __builtin_amdgcn_s_barrier();
-    double *s_w2 = sm;
-    double *s_sw = s_w2 + 16 * NJ;
-    double *s_dp = s_sw + 16 * NJ;
-    const int dp_stride = 16 + Hp * Hp + S;
-    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_dp + ROWS * dp_stride);
-    if (tid < 16 * NJ) {
-        s_w2[tid] = t_g + 2.0 * t_wmu;
-        s_sw[tid] = 1.0 / sqrt(t_g);
-    }
-    if (tid < S) s_tab[tid] = t_tab;
-    for (int s = 256 + tid; s < S; s += 256) s_tab[s] = (uint32_t)masks[s] | ((uint32_t)parents[s] << 16);
+    unsigned char *smem = reinterpret_cast<unsigned char *>(sm);
+    const Layout lay = make_layout(H, Hp, S, 1);
+    build_tables(smem, lay, tid, t_g, t_wmu, t_tab, gram, wmu, H, masks, parents, S, Hp);
     __syncthreads();
 
     PM_STAMP(2);
-    double *s_d = s_dp + (wave * 4 + fk) * dp_stride;
     const RowParams A{gram, ynorm2, wmu, ymu, S, gamma, P, N, H, Hp, mode, cand, logpj, ldl, lse};
-    const RowLds Lds{s_w2, s_sw, s_tab, s_d, s_d + 16, s_d + 16 + Hp * Hp};
+    const RowLds Lds = row_lds(smem, lay, wave * 4 + fk);
 
-    // DPP row fk of this wavefront holds datapoint m0 + 16 wave + fk + 4 r in element r of every accumulator.
-    // Selection for all four passes first, then the E-step passes: the ranking keys and the E-step temporaries are
-    // never live together with all four sets of scores.
-    int mycs[4];
-#pragma unroll 1
+    // Row fk (16 lanes) of this wavefront holds datapoint m0 + 16 wave + fk + 4 r in element r of every accumulator.
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
+        const int64_t n = m0 + 16 * wave + fk + 4 * r;
         double a[NJ];
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) a[i] = r == 0 ? acc[i][0] : r == 1 ? acc[i][1] : r == 2 ? acc[i][2] : acc[i][3];
-        const int c = row_select<NJ>(a, A, Lds, lane, m0 + 16 * wave + fk + 4 * r);
-        mycs[0] = r == 0 ? c : mycs[0];
-        mycs[1] = r == 1 ? c : mycs[1];
-        mycs[2] = r == 2 ? c : mycs[2];
-        mycs[3] = r == 3 ? c : mycs[3];
-    }
-    PM_STAMP(3);
-    if (!(mode & 2)) return;
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        double a[NJ];
+        for (int i = 0; i < NJ; ++i) a[i] = acc[i][r];
+        const int c = row_select<NJ>(a, A, Lds, lane, n);
+        if (mode & 2) {
+            // the scores as an indexable row: the candidates' scores are looked up by latent index
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) a[i] = r == 0 ? acc[i][0] : r == 1 ? acc[i][1] : r == 2 ? acc[i][2] : acc[i][3];
-        const int c = r == 0 ? mycs[0] : r == 1 ? mycs[1] : r == 2 ? mycs[2] : mycs[3];
-        row_estep<NJ, true>(a, nullptr, c, A, so, Lds, lane, m0 + 16 * wave + fk + 4 * r);
+            for (int i = 0; i < NJ; ++i)
+                if (16 * i < lay.HT) Lds.row[frow + 16 * i] = a[i];
+            wave_lds_sync16();
+            row_estep<NJ>(a, Lds.row, c, A, so, Lds, lane, n);
+        }
     }
     PM_STAMP(4);
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// PM_FUSED_STAGES=3 selects a three-stage ring (60 KB at H = 256 instead of 80 KB)
+// three ring stages (60 KB at H = 256; measured: a fourth changes nothing); PM_FUSED_STAGES=4 selects four
 int fused_stages() {
     static int v = 0;
     if (!v) {
         const char *e = getenv("PM_FUSED_STAGES");
-        v = (e && e[0] == '3') ? 3 : 4;
+        v = (e && e[0] == '4') ? 4 : 3;
     }
     return v;
 }
 
 template <int NJ, int ST>
-size_t fused_lds_bytes(int64_t Hp, int64_t S) {
+size_t fused_lds_bytes(int64_t H, int64_t Hp, int64_t S) {
     const size_t ring = sizeof(double) * ST * (AROWS + 16 * NJ) * DK;
-    const size_t epi = sizeof(double) * (2 * 16 * NJ + ROWS * (16 + Hp * Hp + S)) + sizeof(uint32_t) * S;
+    const size_t epi = (size_t)make_layout((int)H, (int)Hp, (int)S, 1).bytes;
     return ring > epi ? ring : epi;
 }
 
@@ -255,7 +237,8 @@ size_t fused_lds_bytes(int64_t Hp, int64_t S) {
 // rows, and whatever pm_bsc_rows16_supported admits for the row passes.
 extern "C" int pm_bsc_fused_supported(int64_t H, int64_t D, int64_t Hprime, int64_t S) {
     if (H <= 0 || H > 256 || D < DK || D % DK != 0) return 0;
-    return pm_bsc_rows16_supported(H, Hprime, S);
+    if (!pm_bsc_rows16_supported(H, Hprime, S)) return 0;
+    return make_layout((int)H, (int)Hprime, (int)S, 1).bytes <= 80 * 1024 ? 1 : 0;   // two workgroups per CU
 }
 
 #ifdef PM_FUSED_STAMPS
@@ -273,7 +256,7 @@ extern "C" int pm_bsc_fused_occupancy(int64_t H, int64_t D, int64_t Hprime, int6
     hipError_t e;
 #define PM_OCC(NJ, ST)                                                                                                 \
     do {                                                                                                               \
-        const size_t shmem = fused_lds_bytes<NJ, ST>(Hprime, S);                                                       \
+        const size_t shmem = fused_lds_bytes<NJ, ST>(H, Hprime, S);                                                       \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST>),                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                               \
         if (e == hipSuccess)                                                                                           \
@@ -317,7 +300,7 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PM_LAUNCH(NJ, ST)                                                                                              \
     do {                                                                                                               \
-        const size_t shmem = fused_lds_bytes<NJ, ST>(Hprime, S);                                                       \
+        const size_t shmem = fused_lds_bytes<NJ, ST>(H, Hprime, S);                                                       \
         if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST>),           \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))                  \
             return e;                                                                                                  \

@@ -28,34 +28,31 @@ using namespace pm_rows16;
 // ---------------------------------------------------------------------------------------------
 // select_Hprimes + E_step: pm_rows16::row_select / row_estep per group of 16 datapoints (mode bits: see RowParams)
 // ---------------------------------------------------------------------------------------------
-template <int VPL>
-__global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_select_estep16_kernel(
+// ESTEP = false: the selection-only instantiation (mode bit 1 clear: what MCA / MMCA / DSC / TSC and a stand-alone
+// select_Hprimes call) -- a third of the registers, twice the wavefronts per SIMD.
+template <int VPL, bool ESTEP>
+__global__ __launch_bounds__(256, ESTEP ? (VPL <= 4 ? 4 : VPL <= 8 ? 3 : VPL <= 16 ? 2 : 1)
+                                        : (VPL <= 8 ? 4 : VPL <= 16 ? 3 : 1)) void bsc_select_estep16_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
     const double *__restrict__ ynorm2, const double *__restrict__ wmu, const double *__restrict__ ymu,
     const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents, SizeOffsets so, int S, int gamma,
     pm_bsc_estep_params P, int64_t N, int H, int Hp, int mode, int32_t *__restrict__ cand,
     double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [ w2 (H) | sw (H) | per datapoint: d (16) G (Hp*Hp) e (S) | tab (S x u32) ]
-    double *s_w2 = reinterpret_cast<double *>(smem);
-    double *s_sw = s_w2 + H;
-    double *s_dp = s_sw + H;
-    const int dp_stride = 16 + Hp * Hp + S;
-    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_dp + ROWS * dp_stride);
+    const Layout lay = make_layout(H, Hp, S, 0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int j = lane & 15, row = lane >> 4;
-    for (int h = tid; h < H; h += 256) {
-        const double g = gram[(int64_t)h * H + h];
-        s_w2[h] = g + (wmu ? 2.0 * wmu[h] : 0.0);
-        s_sw[h] = 1.0 / sqrt(g);   // ranking uses a * (1/|W_h|) * (1/|y|): keys keep 42 mantissa bits anyway
+    {
+        const int th = tid < H ? tid : H - 1, ts = tid < S ? tid : S - 1;
+        const uint32_t tab_s = S > 0 ? ((uint32_t)masks[ts] | ((uint32_t)parents[ts] << 16)) : 0u;
+        build_tables(smem, lay, tid, gram[(int64_t)th * H + th], wmu ? wmu[th] : 0.0, tab_s, gram, wmu, H, masks, parents,
+                     S, Hp);
     }
-    for (int s = tid; s < S; s += 256) s_tab[s] = (uint32_t)masks[s] | ((uint32_t)parents[s] << 16);
     __syncthreads();
 
-    double *s_d = s_dp + (wave * 4 + row) * dp_stride;
     const RowParams A{gram, ynorm2, wmu, ymu, S, gamma, P, N, H, Hp, mode, cand, logpj, ldl, lse};
-    const RowLds L{s_w2, s_sw, s_tab, s_d, s_d + 16, s_d + 16 + Hp * Hp};
+    const RowLds L = row_lds(smem, lay, wave * 4 + row);
 
     const int64_t groups = (N + ROWS - 1) / ROWS;
     for (int64_t g0 = blockIdx.x; g0 < groups; g0 += gridDim.x) {
@@ -72,7 +69,7 @@ __global__ __launch_bounds__(256, VPL <= 8 ? 4 : VPL <= 16 ? 3 : 2) void bsc_sel
             a[i] = (h < H) ? arow[h] : 0.0;
         }
         const int myc = row_select<VPL>(a, A, L, lane, n);
-        if (mode & 2) row_estep<VPL, false>(a, arow, myc, A, so, L, lane, n);
+        if (ESTEP) row_estep<VPL>(a, arow, myc, A, so, L, lane, n);
     }
 }
 
@@ -256,9 +253,8 @@ static int allow_lds16(const void *kernel, size_t bytes) {
 
 // The fast path covers H <= 512 (VPL <= 32 scores per lane) and states that fit the LDS areas.
 extern "C" int pm_bsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S) {
-    if (H <= 0 || H > 512 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || Hprime > H || S < 0) return 0;
-    const size_t shmem = sizeof(double) * (2 * H + ROWS * (16 + Hprime * Hprime + S)) + sizeof(uint32_t) * S;
-    return shmem <= 64 * 1024 ? 1 : 0;
+    if (H <= 0 || H > 512 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || Hprime > H || S < 0 || S > 4096) return 0;
+    return make_layout((int)H, (int)Hprime, (int)S, 0).bytes <= 64 * 1024 ? 1 : 0;
 }
 
 extern "C" int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
@@ -280,15 +276,23 @@ extern "C" int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const 
     if ((mode & 2) && S > 0)
         for (int g = 0; g < gamma; ++g) so.off[g] = size_offsets_host[g];  // off[g-2] = first state of size g
     pm_bsc_estep_params P = params_host ? *params_host : pm_bsc_estep_params{0, 0, 0, 0};
-    const size_t shmem = sizeof(double) * (2 * H + ROWS * (16 + Hprime * Hprime + S)) + sizeof(uint32_t) * S;
+    const size_t shmem = (size_t)make_layout((int)H, (int)Hprime, (int)S, 0).bytes;
     dim3 grid((unsigned)grid_groups(N)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define PM_LAUNCH(V)                                                                                                 \
-    do {                                                                                                             \
-        if (int e = allow_lds16(reinterpret_cast<const void *>(bsc_select_estep16_kernel<V>), shmem)) return e;      \
-        hipLaunchKernelGGL(bsc_select_estep16_kernel<V>, grid, block, shmem, s, scores, lds, gram, ynorm2, wmu, ymu, \
-                           state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H, (int)Hprime, mode,     \
-                           cand, logpj, ldl, lse);                                                                  \
+#define PM_LAUNCH_E(V, E)                                                                                           \
+    do {                                                                                                            \
+        if (int e = allow_lds16(reinterpret_cast<const void *>(bsc_select_estep16_kernel<V, E>), shmem)) return e;  \
+        hipLaunchKernelGGL((bsc_select_estep16_kernel<V, E>), grid, block, shmem, s, scores, lds, gram, ynorm2, wmu,\
+                           ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H, (int)Hprime,     \
+                           mode, cand, logpj, ldl, lse);                                                            \
+    } while (0)
+#define PM_LAUNCH(V)                \
+    do {                            \
+        if (mode & 2) {             \
+            PM_LAUNCH_E(V, true);   \
+        } else {                    \
+            PM_LAUNCH_E(V, false);  \
+        }                           \
     } while (0)
     if (H <= 16) PM_LAUNCH(1);
     else if (H <= 32) PM_LAUNCH(2);
@@ -297,6 +301,7 @@ extern "C" int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const 
     else if (H <= 256) PM_LAUNCH(16);
     else PM_LAUNCH(32);
 #undef PM_LAUNCH
+#undef PM_LAUNCH_E
     return (int)hipGetLastError();
 }
 
