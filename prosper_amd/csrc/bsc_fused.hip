@@ -53,13 +53,14 @@ __device__ unsigned long long pm_fused_stamps[8192][8];
 #define PM_STAMP(slot)
 #endif
 
-template <int NJ, int STAGES>
+template <int NJ, int STAGES, bool FULL>   // FULL: H == 16 NJ, no latent-index guards in the row passes
 __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wt, int64_t ldw, int D,
     const double *__restrict__ gram, const double *__restrict__ ynorm2, const double *__restrict__ wmu,
     const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
     SizeOffsets so, int S, int gamma, pm_bsc_estep_params P, int64_t N, int H, int Hp, int mode,
-    int32_t *__restrict__ cand, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse) {
+    int32_t *__restrict__ cand, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse, int stagger_lo,
+    int stagger_hi, int stagger_ticks) {
     constexpr int STAGE = (AROWS + 16 * NJ) * DK;   // doubles per stage
     constexpr int L = 1 + NJ / 4;                   // DMA instructions per K-step and wavefront
     constexpr int NG = NJ / 4;                      // groups of four column blocks
@@ -69,6 +70,13 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * AROWS;
+    // Optional (off by default, see the launcher): the workgroups of the SECOND resident set (the dispatcher deals blocks
+    // 0 .. CUs-1 one per CU, then CUs .. 2 CUs-1) start later, so that one workgroup of a CU is in its K-loop while the
+    // other runs its row passes (speed only; any placement is correct).
+    if ((int)blockIdx.x >= stagger_lo && (int)blockIdx.x < stagger_hi) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(32);
+    }
     PM_STAMP(0);
 #ifdef PM_FUSED_STAMPS
     if (tid == 0 && blockIdx.x < 8192)
@@ -185,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     __builtin_amdgcn_s_barrier();
     unsigned char *smem = reinterpret_cast<unsigned char *>(sm);
     const Layout lay = make_layout(H, Hp, S, 1);
-    build_tables(smem, lay, tid, t_g, t_wmu, t_tab, gram, wmu, H, masks, parents, S, Hp);
+    build_tables(smem, lay, tid, t_g, t_wmu, t_tab, P.ecoef, P.prior_scale * P.pil_bar, gram, wmu, H, masks, parents, S,
+                 Hp);
     __syncthreads();
 
     PM_STAMP(2);
@@ -199,14 +208,14 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
         double a[NJ];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) a[i] = acc[i][r];
-        const int c = row_select<NJ>(a, A, Lds, lane, n);
+        const int c = row_select<NJ, 0, FULL>(a, A, Lds, lane, n);
         if (mode & 2) {
             // the scores as an indexable row: the candidates' scores are looked up by latent index
 #pragma unroll
             for (int i = 0; i < NJ; ++i)
                 if (16 * i < lay.HT) Lds.row[frow + 16 * i] = a[i];
             wave_lds_sync16();
-            row_estep<NJ>(a, Lds.row, c, A, so, Lds, lane, n);
+            row_estep<NJ, FULL>(a, Lds.row, c, A, so, Lds, lane, n);
         }
     }
     PM_STAMP(4);
@@ -220,6 +229,16 @@ int fused_stages() {
     if (!v) {
         const char *e = getenv("PM_FUSED_STAGES");
         v = (e && e[0] == '4') ? 4 : 3;
+    }
+    return v;
+}
+
+double fused_stagger_us() {
+    static double v = -1.0;
+    if (v < 0.0) {
+        const char *e = getenv("PM_FUSED_STAGGER_US");
+        v = e ? atof(e) : 0.0;
+        if (v < 0.0) v = 0.0;
     }
     return v;
 }
@@ -257,10 +276,10 @@ extern "C" int pm_bsc_fused_occupancy(int64_t H, int64_t D, int64_t Hprime, int6
 #define PM_OCC(NJ, ST)                                                                                                 \
     do {                                                                                                               \
         const size_t shmem = fused_lds_bytes<NJ, ST>(H, Hprime, S);                                                       \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST>),                        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST, false>),                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                               \
         if (e == hipSuccess)                                                                                           \
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bsc_estep_fused_kernel<NJ, ST>, 256, shmem);          \
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bsc_estep_fused_kernel<NJ, ST, false>, 256, shmem);   \
     } while (0)
     if (H <= 128) {
         if (three) PM_OCC(8, 3);
@@ -286,7 +305,7 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
     if ((mode & 2) && (!params_host || !logpj || ldl < 1 + H + S || gamma < 1 || gamma > Hprime ||
                        (S > 0 && (!state_masks || !state_parents || !size_offsets_host))))
         return PM_EINVAL;
-    if (!pm_bsc_fused_supported(H, D, Hprime, S)) return PM_ERANGE;
+    if (!pm_bsc_fused_supported(H, D, Hprime, S) || (mode & ~3)) return PM_ERANGE;   // (BSC's own ranking only)
     if (!aligned16(Y) || !aligned16(Wt) || (ldy % 2) || (ldw % 2)) return PM_EINVAL;
     if (N == 0) return PM_OK;
     SizeOffsets so;
@@ -298,16 +317,40 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
     if (tiles > INT32_MAX) return PM_ERANGE;
     dim3 grid((unsigned)tiles), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define PM_LAUNCH(NJ, ST)                                                                                              \
+#define PM_LAUNCH_F(NJ, ST, F)                                                                                         \
     do {                                                                                                               \
-        const size_t shmem = fused_lds_bytes<NJ, ST>(H, Hprime, S);                                                       \
-        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST>),           \
+        const size_t shmem = fused_lds_bytes<NJ, ST>(H, Hprime, S);                                                    \
+        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST, F>),        \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))                  \
             return e;                                                                                                  \
-        hipLaunchKernelGGL((bsc_estep_fused_kernel<NJ, ST>), grid, block, shmem, s, Y, ldy, Wt, ldw, (int)D, gram,     \
+        hipLaunchKernelGGL((bsc_estep_fused_kernel<NJ, ST, F>), grid, block, shmem, s, Y, ldy, Wt, ldw, (int)D, gram,  \
                            ynorm2, wmu, ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H,        \
-                           (int)Hprime, mode, cand, logpj, ldl, lse);                                                  \
+                           (int)Hprime, mode, cand, logpj, ldl, lse, stagger_lo, stagger_hi, stagger_ticks);           \
     } while (0)
+#define PM_LAUNCH(NJ, ST)                  \
+    do {                                   \
+        if (H == 16 * NJ) {                \
+            PM_LAUNCH_F(NJ, ST, true);     \
+        } else {                           \
+            PM_LAUNCH_F(NJ, ST, false);    \
+        }                                  \
+    } while (0)
+    // Optional start stagger of the second resident set of workgroups (PM_FUSED_STAGGER_US=<microseconds>; default off).
+    // Measured: with both workgroups of a CU in phase a tile pair takes 240 us of K-loops (96 % of the matrix pipe at the
+    // sustained clock) + 47 us of row passes; half a tile apart the row passes hide behind the partner's K-loop, but a
+    // K-loop with no second K-loop beside it exposes its per-K-step barrier (137 instead of 115 us): 288 us either way.
+    int stagger_lo = 0, stagger_hi = 0, stagger_ticks = 0;
+    {
+        int dev = 0, cus = 0;
+        const double us = fused_stagger_us();
+        if (us > 0.0 && hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+            tiles >= 2 * (int64_t)cus) {
+            stagger_lo = cus;
+            stagger_hi = 2 * cus;
+            stagger_ticks = (int)(us * 100.0);
+        }
+    }
     const bool three = fused_stages() == 3;
     if (H <= 128) {
         if (three) PM_LAUNCH(8, 3);
@@ -317,5 +360,6 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
         else PM_LAUNCH(16, 4);
     }
 #undef PM_LAUNCH
+#undef PM_LAUNCH_F
     return (int)hipGetLastError();
 }

@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256, ESTEP ? (VPL <= 4 ? 4 : VPL <= 8 ? 3 : VPL <= 
     {
         const int th = tid < H ? tid : H - 1, ts = tid < S ? tid : S - 1;
         const uint32_t tab_s = S > 0 ? ((uint32_t)masks[ts] | ((uint32_t)parents[ts] << 16)) : 0u;
-        build_tables(smem, lay, tid, gram[(int64_t)th * H + th], wmu ? wmu[th] : 0.0, tab_s, gram, wmu, H, masks, parents,
-                     S, Hp);
+        build_tables(smem, lay, tid, gram[(int64_t)th * H + th], wmu ? wmu[th] : 0.0, tab_s, P.ecoef,
+                     P.prior_scale * P.pil_bar, gram, wmu, H, masks, parents, S, Hp);
     }
     __syncthreads();
 

@@ -43,6 +43,20 @@ constexpr int ROWS = 16;          // datapoints per 256-thread workgroup (4 wave
 constexpr double NEGLIGIBLE = -37.0;
 constexpr int LIST_ROWS = 17;     // sorted keys parked per lane: up to 16 + one -inf sentinel
 
+// v_max_f64 / v_min_f64 as single instructions: fmax()/fmin() first canonicalise operands the compiler cannot prove
+// quiet (anything loaded or bit-cast), three instructions instead of one -- and every vector instruction here costs
+// the matrix pipe ~5.5 cycles.  Operands are never signalling NaNs.
+__device__ __forceinline__ double vmax64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmin64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---- reductions inside a 16-lane row through the LDS crossbar (ds_swizzle, bit mode: lane ^ XOR) ------------------
 template <int XOR>
 __device__ __forceinline__ double swz_xor_f64(double v) {
@@ -52,10 +66,10 @@ __device__ __forceinline__ double swz_xor_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ double row_max_f64(double v) {
-    v = __builtin_fmax(v, swz_xor_f64<1>(v));
-    v = __builtin_fmax(v, swz_xor_f64<2>(v));
-    v = __builtin_fmax(v, swz_xor_f64<4>(v));
-    v = __builtin_fmax(v, swz_xor_f64<8>(v));
+    v = vmax64(v, swz_xor_f64<1>(v));
+    v = vmax64(v, swz_xor_f64<2>(v));
+    v = vmax64(v, swz_xor_f64<4>(v));
+    v = vmax64(v, swz_xor_f64<8>(v));
     return v;
 }
 __device__ __forceinline__ double row_sum_f64(double v) {
@@ -149,7 +163,7 @@ struct RowParams {
 };
 
 // ---- LDS layout of a workgroup ------------------------------------------------------------------------------------
-//   [ w2 (HT) | sw (HT) | 16 datapoint areas of `area` doubles | tab (S u32) | st (S x 8 u16) | ik (Hp*Hp u16) ]
+//   [ w2 (HT) | sw (HT) | ew (HT) | 16 datapoint areas of `area` doubles | tab (S u32) | st (S x 8 u16) | ik (Hp*Hp u16) ]
 // HT = latents rounded up to 16.  A datapoint area:
 //   P    = [ zero | d (16) | G (Hp*Hp) | e (S) ]   byte-addressed by the state table; during selection the same bytes
 //                                                  hold the lanes' sorted key lists (LIST_ROWS x 16 doubles)
@@ -166,7 +180,7 @@ __host__ __device__ inline Layout make_layout(int H, int Hp, int S, int rowbuf) 
     const int p = 1 + 16 + Hp * Hp + S, lists = LIST_ROWS * 16;
     L.p_len = p > lists ? p : lists;
     L.area = L.p_len + 16 + (rowbuf ? L.HT : 0);
-    L.off_dp = 2 * L.HT * 8;
+    L.off_dp = 3 * L.HT * 8;
     L.off_tab = L.off_dp + ROWS * L.area * 8;
     L.off_st = (L.off_tab + 4 * S + 15) / 16 * 16;
     L.off_ik = L.off_st + 16 * S;
@@ -178,6 +192,7 @@ __host__ __device__ inline Layout make_layout(int H, int Hp, int S, int rowbuf) 
 struct RowLds {
     const double *w2;     // (HT) |W_h|^2 (+ 2 W_h.mu)
     const double *sw;     // (HT) 1 / |W_h|
+    const double *ew;     // (HT) ecoef |W_h|^2 (+ 2 ecoef W_h.mu) + prior: the singleton log-joint up to -2 ecoef a_h + ecoef |y|^2
     const uint32_t *tab;  // (S)  state mask | parent << 16
     const uint16_t *st;   // (S x 8) byte offsets into P: parent term, d_k, three Gram terms (unused ones -> zero slot)
     const uint16_t *ik;   // (Hp*Hp) i | k << 8 of the Gram block's entry p = i Hp + k
@@ -189,7 +204,7 @@ struct RowLds {
 __device__ __forceinline__ RowLds row_lds(unsigned char *smem, const Layout &L, int dp /* 0..15 */) {
     double *base = reinterpret_cast<double *>(smem);
     double *area = reinterpret_cast<double *>(smem + L.off_dp) + dp * L.area;
-    return RowLds{base, base + L.HT, reinterpret_cast<const uint32_t *>(smem + L.off_tab),
+    return RowLds{base, base + L.HT, base + 2 * L.HT, reinterpret_cast<const uint32_t *>(smem + L.off_tab),
                   reinterpret_cast<const uint16_t *>(smem + L.off_st), reinterpret_cast<const uint16_t *>(smem + L.off_ik),
                   area, area + L.p_len, area + L.p_len + 16};
 }
@@ -198,21 +213,26 @@ __device__ __forceinline__ RowLds row_lds(unsigned char *smem, const Layout &L, 
 // of latent h = min(tid, H-1) and tab_s = mask | parent << 16 of state s = min(tid, S-1) are handed in (loaded by
 // the caller, possibly long before); latents and states beyond 256 are read here.
 __device__ __forceinline__ void build_tables(unsigned char *smem, const Layout &L, int tid, double g_h, double wmu_h,
-                                             uint32_t tab_s, const double *__restrict__ gram,
+                                             uint32_t tab_s, double ecoef, double ppil,
+                                             const double *__restrict__ gram,
                                              const double *__restrict__ wmu, int H,
                                              const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
                                              int S, int Hp) {
     double *w2 = reinterpret_cast<double *>(smem);
-    double *sw = w2 + L.HT;
+    double *sw = w2 + L.HT, *ew = w2 + 2 * L.HT;
     if (tid < L.HT) {
-        w2[tid] = g_h + 2.0 * wmu_h;
+        const double w = g_h + 2.0 * wmu_h;
+        w2[tid] = w;
         sw[tid] = 1.0 / sqrt(g_h);   // ranking uses a * (1/|W_h|): keys keep 42 mantissa bits anyway
+        ew[tid] = fma(ecoef, w, ppil);
     }
     for (int h = 256 + tid; h < L.HT; h += 256) {
         const int hc = h < H ? h : H - 1;
         const double g = gram[(int64_t)hc * H + hc];
-        w2[h] = g + (wmu ? 2.0 * wmu[hc] : 0.0);
+        const double w = g + (wmu ? 2.0 * wmu[hc] : 0.0);
+        w2[h] = w;
         sw[h] = 1.0 / sqrt(g);
+        ew[h] = fma(ecoef, w, ppil);
     }
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem + L.off_tab);
     uint16_t *st = reinterpret_cast<uint16_t *>(smem + L.off_st);
@@ -263,8 +283,8 @@ __device__ __forceinline__ void sort_desc(double (&k)[n]) {
 #pragma unroll
                 for (int i = 0; i < q; ++i) {
                     if (i + j + q < n && (i + j) / (2 * p) == (i + j + q) / (2 * p)) {
-                        const double hi = __builtin_fmax(k[i + j], k[i + j + q]);
-                        const double lo = __builtin_fmin(k[i + j], k[i + j + q]);
+                        const double hi = vmax64(k[i + j], k[i + j + q]);
+                        const double lo = vmin64(k[i + j], k[i + j + q]);
                         k[i + j] = hi;
                         k[i + j + q] = lo;
                     }
@@ -277,7 +297,9 @@ __device__ __forceinline__ void sort_desc(double (&k)[n]) {
 // select_Hprimes for one datapoint per row of 16 lanes (bsc_et.py:98-115).  a[i] = score of latent h = j + 16 i
 // (j = lane & 15); n = this row's datapoint (rows with n >= N shadow the last datapoint and write nothing).
 // Returns, in lane j < Hp, the latent at candidate position j -- selected here (mode bit 0) or read from A.cand.
-template <int VPL>
+// SEL >= 0: the ranking mode (A.mode >> 2) is a compile-time constant (0 = Binary Sparse Coding's own); SEL < 0: read
+// from A.mode.  FULL: H == 16 VPL, every lane register holds a latent.
+template <int VPL, int SEL = -1, bool FULL = false>
 __device__ __forceinline__ int row_select(const double (&a)[VPL], const RowParams &A, const RowLds &L, int lane,
                                           int64_t n) {
     const int j = lane & 15;
@@ -291,7 +313,8 @@ __device__ __forceinline__ int row_select(const double (&a)[VPL], const RowParam
     }
     // ---------------- top-H' of a / |W_h| (ascending, best last) ------------------------------------------
     // (the reference divides by |y| too -- a positive factor per datapoint, the ranking is the same)
-    const bool smallest = A.mode & 4, raw = A.mode & 8, dist = A.mode & 16;
+    const int flags = SEL >= 0 ? SEL : (A.mode >> 2);
+    const bool smallest = flags & 1, raw = flags & 2, dist = flags & 4;
     // Ranking keys are DOUBLES whose low 10 mantissa bits carry the latent index (the keys keep 42 mantissa bits).
     // Ties resolve as a stable argsort would: largest-first keeps the larger index last-best, smallest-first the
     // smaller index first -- the index code counts up for non-negative keys and down for negative ones, whose
@@ -302,7 +325,7 @@ __device__ __forceinline__ int row_select(const double (&a)[VPL], const RowParam
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int h = j + 16 * i;
-        const int hc = h < H ? h : H - 1;
+        const int hc = (FULL || h < H) ? h : H - 1;
         double x = raw ? a[i] : dist ? L.w2[hc] - 2.0 * a[i] : a[i] * L.sw[hc];
         if (smallest) x = -x;
         odd |= __builtin_amdgcn_class(x, 0x207);         // NaN, -inf, +inf
@@ -310,7 +333,7 @@ __device__ __forceinline__ int row_select(const double (&a)[VPL], const RowParam
         const uint32_t flip = (uint32_t)((int32_t)(b >> 32) >> 31) & 0x3FFu;
         const uint32_t code = (uint32_t)(smallest ? 0x3FF - h : h) ^ flip;
         const uint64_t kb = (b & ~0x3FFull) | code;
-        key[i] = (h < H) ? __longlong_as_double((long long)kb) : -INFINITY;
+        key[i] = (FULL || h < H) ? __longlong_as_double((long long)kb) : -INFINITY;
     }
     if (__any(odd)) {   // rare: redo the keys of non-finite scores
 #pragma unroll
@@ -361,7 +384,7 @@ __device__ __forceinline__ int row_select(const double (&a)[VPL], const RowParam
 // `arow`: the datapoint's scores as an indexable row (global memory, or L.row in LDS).  a[] is overwritten (singleton
 // log-joints).  `so` is taken by reference so that its dynamic indexing stays a scalar load from the kernel-argument
 // segment (a copy would live in scratch).
-template <int VPL>
+template <int VPL, bool FULL = false>
 __device__ __forceinline__ void row_estep(double (&a)[VPL], const double *arow, int myc, const RowParams &A,
                                           const SizeOffsets &so, const RowLds &L, int lane, int64_t n) {
     const int j = lane & 15;
@@ -408,7 +431,7 @@ __device__ __forceinline__ void row_estep(double (&a)[VPL], const double *arow, 
                 Pe[s] = e;
                 const double f = fma(ecoef, yn + e, pg);
                 if (live) out[1 + H + s] = f;
-                mx = fmax(mx, f);
+                mx = vmax64(mx, f);
             }
         } else {
             for (int s = so.off[g - 2] + j; s < s1; s += 16) {
@@ -426,49 +449,60 @@ __device__ __forceinline__ void row_estep(double (&a)[VPL], const double *arow, 
                 Pe[s] = e;
                 const double f = fma(ecoef, yn + e, pg);
                 if (live) out[1 + H + s] = f;
-                mx = fmax(mx, f);
+                mx = vmax64(mx, f);
             }
         }
         wave_lds_sync16();
     }
 
     // ---------------- null state and singletons ---------------------------------------------------
+    // f_h = prior + ecoef (|W_h|^2 - 2 a_h + |y|^2), with ecoef |W_h|^2 + prior tabulated per workgroup
+    const double f0 = ecoef * yn, m2e = -2.0 * ecoef;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {  // a[i] becomes the singleton log-joint of latent h
         const int h = j + 16 * i;
         double f = -INFINITY;
-        if (h < H) {
-            const double e = fma(-2.0, a[i], L.w2[h]) + yn;
-            f = fma(ecoef, e, ppil);
+        if (FULL || h < H) {
+            f = fma(m2e, a[i], L.ew[h]) + f0;
             if (live) out[1 + h] = f;
         }
         a[i] = f;
-        mx = fmax(mx, f);
+        mx = vmax64(mx, f);
     }
-    const double f0 = ecoef * yn;
     if (j == 0) {
         if (live) out[0] = f0;
-        mx = fmax(mx, f0);
+        mx = vmax64(mx, f0);
     }
     if (!A.lse) return;
 
     // ---------------- log-sum-exp: only terms within exp(-37) of the largest are evaluated ------------
     mx = row_max_f64(mx);
     const double thr = mx + NEGLIGIBLE;
-    double sum = (j == 0 && f0 > thr) ? exp_neg(f0 - mx) : 0.0;
+    double sum = 0.0;
+    {
+        const bool need = (j == 0) && f0 > thr;
+        if (__any(need)) sum = need ? exp_neg(f0 - mx) : 0.0;
+    }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const bool need = a[i] > thr;
         if (__any(need)) sum += need ? exp_neg(a[i] - mx) : 0.0;
     }
+    // multi-cause states: the test runs on the energies (f > thr  <=>  e < te_g for ecoef < 0, one compare per state);
+    // the log-joint is rebuilt -- with the arithmetic that produced the stored value -- only where an exp is due
+    const double inv_ecoef = 1.0 / ecoef;
     for (int g = 2; g <= A.gamma; ++g) {
         const double pg = ppil * (double)g;
+        const double te = (thr - pg) * inv_ecoef - yn;
         const int s0 = so.off[g - 2], s1 = so.off[g - 1];
         for (int sb = s0; sb < s1; sb += 16) {  // uniform trip count
             const int s = sb + j;
-            const double f = (s < s1) ? fma(ecoef, yn + Pe[s], pg) : -INFINITY;
-            const bool need = f > thr;
-            if (__any(need)) sum += need ? exp_neg(f - mx) : 0.0;
+            const double e = Pe[s < s1 ? s : s1 - 1];
+            const bool need = (s < s1) && (ecoef < 0.0 ? e < te : e > te);
+            if (__any(need)) {
+                const double f = fma(ecoef, yn + e, pg);
+                sum += (need && f > thr) ? exp_neg(f - mx) : 0.0;
+            }
         }
     }
     sum = row_sum_f64(sum);

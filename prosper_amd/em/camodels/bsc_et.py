@@ -182,15 +182,48 @@ class BSC_ET(DeviceCAModel):
             p = holder[name] = (t, buf)
         return p[1]
 
+    def _fused_rows(self, N):
+        """Rows of the shard the one-kernel E-step takes: whole rounds of resident workgroups (2 per CU, 64 datapoints
+        each).  A ragged last round would run a fraction of the chip for a whole tile time (tiles cannot be split over
+        K: the row passes need complete scores), so those rows go through the two-kernel path, whose GEMM does split K
+        -- unless they fill most of a round anyway, or the shard is smaller than one round."""
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        rnd = 2 * cus * 64
+        if N < rnd or os.environ.get("PM_FUSED_SPLIT", "1") != "1":
+            return N
+        main = N // rnd * rnd
+        return N if (N - main) * 10 >= rnd * 7 else main
+
     def _fused_estep(self, res, par, mode, cand, P, wmu, ymu, logpj, lse):
         tab = self._state_tables()
         Y8, W8 = self._k8(res, "Y8", res["Y"]), self._k8(par, "Wt8", par["Wt"])
-        N = Y8.shape[0]
+        N, H, Hp, S = Y8.shape[0], self.H, self.Hprime, self.no_states
         ldl = logpj.stride(0) if logpj is not None else 0
+        main = self._fused_rows(N)
+        Pref = ctypes.byref(P) if P is not None else None
+        cur = torch.cuda.current_stream(self.device)
+        side = None
+        if main < N:      # the ragged last round: split-K scores GEMM + row kernel on those rows (on a side stream beside the big launch it is slower: 2.01 vs 1.89 ms)
+            if os.environ.get("PM_FUSED_SIDE", "0") == "1":
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                side = self._side
+                side.wait_stream(cur)
+            st = ctypes.c_void_p((side or cur).cuda_stream)
+            off = lambda t, w=1: ctypes.c_void_p(t.data_ptr() + main * w * t.element_size()) if t is not None else None
+            A = self._buf("scores_rest", (N - main, H))
+            Yr = res["Y"][main:]
+            self._call("scores_gemm_rest", "pm_gemm_nt_f64", _ptr(Yr), Yr.stride(0), _ptr(par["Wt"]), par["Wt"].stride(0),
+                       _ptr(A), H, N - main, H, Yr.shape[1], st)
+            self._call("select_estep_rest", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
+                       _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S, self.gamma,
+                       Pref, N - main, H, Hp, mode, off(cand, Hp), off(logpj, ldl), ldl, off(lse), st)
         self._call("estep_fused", "pm_bsc_estep_fused_f64", _ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
                    _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
-                   self.no_states, self.gamma, ctypes.byref(P) if P is not None else None, N, Y8.shape[1], self.H,
-                   self.Hprime, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse), self._stream())
+                   S, self.gamma, Pref, main, Y8.shape[1], H, Hp, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse),
+                   self._stream())
+        if side is not None:
+            cur.wait_stream(side)
 
     # ---- scores GEMM, then the fused, chunked select + E-step (two-kernel path) -------------------
     def _round_rows(self):
