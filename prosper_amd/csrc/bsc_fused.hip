@@ -97,29 +97,43 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     }
 
     // DMA sources: this wavefront moves its own 16 datapoint rows and latent blocks wave, wave + 4, ...
+    // An address is (wave-uniform base, advanced per K-step on the scalar unit) + (per-lane 32-bit byte offset, fixed):
+    // the saddr form of global_load_lds, issued through inline assembly (the builtin only takes a 64-bit vector address,
+    // five 64-bit vector adds per K-step -- and every vector instruction in this loop delays the next MFMA).
     const int dr = lane >> 2, dj = (lane & 3) ^ ((lane >> 4) & 3);
-    // (a fixed bound: with a template-dependent array type the LDS-DMA builtin is only checked when the kernel is
-    // instantiated -- also for the host, where it does not exist -- and hipcc then silently drops the host stub)
-    const double *src[5];
-    static_assert(L <= 5, "src[] holds the datapoint rows + NJ/4 latent blocks");
+    const char *sbase[5];
+    uint32_t soff[5];
+    static_assert(L <= 5, "sbase[] holds the datapoint rows + NJ/4 latent blocks");
     {
-        int64_t ra = m0 + 16 * wave + dr;
+        int64_t r0 = m0 + 16 * wave;
+        r0 = r0 < N ? r0 : N - 1;
+        int64_t ra = r0 + dr;
         ra = ra < N ? ra : N - 1;
-        src[0] = Y + ra * ldy + 2 * dj;
+        sbase[0] = reinterpret_cast<const char *>(Y + r0 * ldy);
+        soff[0] = (uint32_t)((ra - r0) * ldy * 8 + 16 * dj);
 #pragma unroll
         for (int q = 0; q < NJ / 4; ++q) {
-            int rb = 16 * (wave + 4 * q) + dr;
+            int b0 = 16 * (wave + 4 * q);
+            b0 = b0 < H ? b0 : H - 1;
+            int rb = b0 + dr;
             rb = rb < H ? rb : H - 1;
-            src[1 + q] = Wt + (int64_t)rb * ldw + 2 * dj;
+            sbase[1 + q] = reinterpret_cast<const char *>(Wt + (int64_t)b0 * ldw);
+            soff[1 + q] = (uint32_t)((int64_t)(rb - b0) * ldw * 8 + 16 * dj);
         }
     }
+    // LDS byte address of this wavefront's first chunk in stage 0 (chunk = 16 rows x 8 doubles = 1 KB)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) double *)(sm)) + (unsigned)wave * 1024u;
+    auto dma1 = [&](unsigned dst, uint32_t voff, const char *base) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(base)
+                     : "memory");
+    };
     auto dma = [&](int kt, int stage) {
-        double *dst = sm + stage * STAGE + wave * 128;  // chunk = 16 rows x 8 doubles
-        const int k0 = kt * DK;
-        __builtin_amdgcn_global_load_lds(src[0] + k0, dst, 16, 0, 0);
+        const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8);
+        const int64_t k0 = (int64_t)kt * (DK * 8);
+        dma1(dst, soff[0], sbase[0] + k0);
 #pragma unroll
-        for (int q = 0; q < NJ / 4; ++q)
-            __builtin_amdgcn_global_load_lds(src[1 + q] + k0, dst + (4 + 4 * q) * 128, 16, 0, 0);
+        for (int q = 0; q < NJ / 4; ++q) dma1(dst + (4 + 4 * q) * 1024u, soff[1 + q], sbase[1 + q] + k0);
     };
 
     // fragment reads (see gemm_nt_f64_dma_kernel): k-group fk of the first MFMA of a K-step takes column 2 fk, of the
@@ -153,13 +167,15 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     }
     __builtin_amdgcn_s_barrier();
 
-    d2 fa = read_a(0), fa_next = fa;
+    d2 fa[2];
     d2 fb[2][4];
+    fa[0] = read_a(0);
     read_b(0, 0, fb[0]);
 
-    int stage = 0;
-    for (int t = 0; t < nk; ++t) {
-        const int nstage = (stage + 1 == STAGES) ? 0 : stage + 1;
+    // One K-step.  `stage`, `nstage` (ring slots of K-steps t and t+1) and `par` (which of fa[] holds step t's datapoint
+    // fragment) are compile-time constants in the unrolled main loop -- LDS addresses become immediates, no register
+    // copies -- and run-time values in the generic loop.
+    auto kstep = [&](int t, int stage, int nstage, int par) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) {
@@ -174,16 +190,29 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
                 else if (ahead == 1) wait_vmcnt<L>();
                 else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
-                fa_next = read_a(nstage);
+                const d2 an = read_a(nstage);
+                if (par) fa[0] = an;
+                else fa[1] = an;
                 read_b(nstage, 0, fb[0]);
                 if (t + STAGES < nk) dma(t + STAGES, stage);
             }
+            const d2 af = par ? fa[1] : fa[0];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa.x, fb[g & 1][q].x, acc[4 * g + q]);
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.x, fb[g & 1][q].x, acc[4 * g + q]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa.y, fb[g & 1][q].y, acc[4 * g + q]);
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.y, fb[g & 1][q].y, acc[4 * g + q]);
         }
-        fa = fa_next;
+    };
+    int t = 0;
+    if (STAGES % 2 == 0) {
+        for (; t + STAGES <= nk; t += STAGES) {
+#pragma unroll
+            for (int u = 0; u < STAGES; ++u) kstep(t + u, u, (u + 1) % STAGES, u & 1);
+        }
+    }
+    for (int stage = t % STAGES; t < nk; ++t) {       // (STAGES even: t is a multiple of STAGES here, its parity is 0)
+        const int nstage = (stage + 1 == STAGES) ? 0 : stage + 1;
+        kstep(t, stage, nstage, t & 1);
         stage = nstage;
     }
 
@@ -202,20 +231,54 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     const RowLds Lds = row_lds(smem, lay, wave * 4 + fk);
 
     // Row fk (16 lanes) of this wavefront holds datapoint m0 + 16 wave + fk + 4 r in element r of every accumulator.
+    const int64_t nbase = m0 + 16 * wave + fk;
+    if (Hp <= 8) {
+        // Up to 8 candidates (a Gram block of <= 64 entries, 4 per lane): three phases over the four passes, so that the
+        // global loads of ALL passes (|y|^2, Gram entries of the candidates) are in flight together instead of one
+        // dependent round trip per pass.
+        int mycs[4];
+        double acs[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t n = m0 + 16 * wave + fk + 4 * r;
-        double a[NJ];
+        for (int r = 0; r < 4; ++r) {      // 1. selection; the score of the candidate each lane holds, through the LDS row
+            double a[NJ];
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) a[i] = acc[i][r];
-        const int c = row_select<NJ, 0, FULL>(a, A, Lds, lane, n);
-        if (mode & 2) {
-            // the scores as an indexable row: the candidates' scores are looked up by latent index
+            for (int i = 0; i < NJ; ++i) a[i] = acc[i][r];
 #pragma unroll
             for (int i = 0; i < NJ; ++i)
                 if (16 * i < lay.HT) Lds.row[frow + 16 * i] = a[i];
+            mycs[r] = row_select<NJ, 0, FULL>(a, A, Lds, lane, nbase + 4 * r);
+            acs[r] = Lds.row[frow < Hp ? mycs[r] : 0];
             wave_lds_sync16();
-            row_estep<NJ, FULL>(a, Lds.row, c, A, so, Lds, lane, n);
+        }
+        PM_STAMP(3);
+        if (!(mode & 2)) return;
+        RowFetch<4> F[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) F[r] = row_fetch<4>(mycs[r], A, Lds, lane, nbase + 4 * r);      // 2. loads
+        PM_STAMP(5);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {      // 3. energies, log-joints, log-sum-exp
+            double a[NJ];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) a[i] = acc[i][r];
+            row_estep_fetched<NJ, FULL, 4>(a, acs[r], F[r], A, so, Lds, lane, nbase + 4 * r);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t n = nbase + 4 * r;
+            double a[NJ];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) a[i] = acc[i][r];
+            const int c = row_select<NJ, 0, FULL>(a, A, Lds, lane, n);
+            if (mode & 2) {
+                // the scores as an indexable row: the candidates' scores are looked up by latent index
+#pragma unroll
+                for (int i = 0; i < NJ; ++i)
+                    if (16 * i < lay.HT) Lds.row[frow + 16 * i] = a[i];
+                wave_lds_sync16();
+                row_estep<NJ, FULL>(a, Lds.row, c, A, so, Lds, lane, n);
+            }
         }
     }
     PM_STAMP(4);
@@ -223,12 +286,13 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// three ring stages (60 KB at H = 256; measured: a fourth changes nothing); PM_FUSED_STAGES=4 selects four
+// four ring stages (80 KB at H = 256): the K-loop is unrolled over the ring, every LDS address an immediate;
+// PM_FUSED_STAGES=3 selects the three-stage ring (60 KB, generic loop)
 int fused_stages() {
     static int v = 0;
     if (!v) {
         const char *e = getenv("PM_FUSED_STAGES");
-        v = (e && e[0] == '4') ? 4 : 3;
+        v = (e && e[0] == '3') ? 3 : 4;
     }
     return v;
 }

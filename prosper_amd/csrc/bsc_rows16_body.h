@@ -384,6 +384,60 @@ __device__ __forceinline__ int row_select(const double (&a)[VPL], const RowParam
 // `arow`: the datapoint's scores as an indexable row (global memory, or L.row in LDS).  a[] is overwritten (singleton
 // log-joints).  `so` is taken by reference so that its dynamic indexing stays a scalar load from the kernel-argument
 // segment (a copy would live in scratch).
+// What a pass fetches from global memory once its candidates are known: |y|^2, G[c,c] and the score offset (W.mu)_c of the
+// candidate this lane holds, and this lane's share of the candidates' Gram block (entries p = 16 it + j of Hp x Hp).
+// Split from the arithmetic so that a caller with several passes in hand can have all of their loads in flight at once.
+template <int GI>
+struct RowFetch {
+    double yn, gdiag, wmuc;
+    double G[GI];
+};
+template <int GI>
+__device__ __forceinline__ RowFetch<GI> row_fetch(int myc, const RowParams &A, const RowLds &L, int lane, int64_t n) {
+    const int j = lane & 15;
+    const int H = A.H, Hp = A.Hp;
+    const int64_t nn = n < A.N ? n : A.N - 1;
+    RowFetch<GI> F;
+    F.yn = A.ynorm2[nn];
+    if (A.ymu) F.yn = F.yn - 2.0 * A.ymu[nn] + A.P.mu_sqnorm;
+    const int c = (j < Hp) ? myc : 0;
+    F.gdiag = A.gram[(int64_t)c * H + c];
+    F.wmuc = A.wmu ? A.wmu[c] : 0.0;
+#pragma unroll
+    for (int it = 0; it < GI; ++it) {                   // every lane feeds the bpermutes
+        const int p = 16 * it + j;
+        const bool valid = p < Hp * Hp;
+        const unsigned ik = valid ? L.ik[p] : 0u;
+        // candidates i and k of this datapoint, from the lanes of its row that hold them
+        const int ci = __builtin_amdgcn_ds_bpermute(((lane & 48) + (int)(ik & 0xFF)) << 2, myc);
+        const int ck = __builtin_amdgcn_ds_bpermute(((lane & 48) + (int)(ik >> 8)) << 2, myc);
+        F.G[it] = (16 * it < Hp * Hp) ? A.gram[(int64_t)ci * H + ck] : 0.0;
+    }
+    return F;
+}
+
+template <int VPL, bool FULL>
+__device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, const RowParams &A, const SizeOffsets &so,
+                                                  const RowLds &L, int lane, int64_t n);
+
+// E_step with fetched values: ac = the score of this lane's candidate (lanes j < Hp).  GI * 16 >= Hp * Hp.
+template <int VPL, bool FULL, int GI>
+__device__ __forceinline__ void row_estep_fetched(double (&a)[VPL], double ac, const RowFetch<GI> &F, const RowParams &A,
+                                                  const SizeOffsets &so, const RowLds &L, int lane, int64_t n) {
+    const int j = lane & 15;
+    const int Hp = A.Hp;
+    double *Pd = L.P + 1, *PG = L.P + 17;
+    if (j == 0) L.P[0] = 0.0;
+    if (j < Hp) Pd[j] = F.gdiag - 2.0 * (ac - F.wmuc);
+#pragma unroll
+    for (int it = 0; it < GI; ++it) {
+        const int p = 16 * it + j;
+        if (p < Hp * Hp) PG[p] = F.G[it];
+    }
+    wave_lds_sync16();
+    row_estep_compute<VPL, FULL>(a, F.yn, A, so, L, lane, n);
+}
+
 template <int VPL, bool FULL = false>
 __device__ __forceinline__ void row_estep(double (&a)[VPL], const double *arow, int myc, const RowParams &A,
                                           const SizeOffsets &so, const RowLds &L, int lane, int64_t n) {
@@ -391,13 +445,11 @@ __device__ __forceinline__ void row_estep(double (&a)[VPL], const double *arow, 
     const int H = A.H, Hp = A.Hp;
     const bool live = n < A.N;               // uniform per row
     const int64_t nn = live ? n : A.N - 1;
-    const double ppil = A.P.prior_scale * A.P.pil_bar, ecoef = A.P.ecoef;
     double yn = A.ynorm2[nn];
     if (A.ymu) yn = yn - 2.0 * A.ymu[nn] + A.P.mu_sqnorm;
 
     // ---------------- candidate block: d_k and G[c_i,c_k] -> LDS ------------------------
-    double *Pd = L.P + 1, *PG = L.P + 17, *Pe = L.P + 17 + Hp * Hp;
-    const unsigned char *Pb = reinterpret_cast<const unsigned char *>(L.P);
+    double *Pd = L.P + 1, *PG = L.P + 17;
     if (j == 0) L.P[0] = 0.0;
     if (j < Hp) {
         const int c = myc;
@@ -414,6 +466,20 @@ __device__ __forceinline__ void row_estep(double (&a)[VPL], const double *arow, 
         if (valid) PG[p] = A.gram[(int64_t)ci * H + ck];
     }
     wave_lds_sync16();
+    row_estep_compute<VPL, FULL>(a, yn, A, so, L, lane, n);
+}
+
+// The arithmetic of the E-step: P = [ zero | d | G ] of this datapoint is in LDS.
+template <int VPL, bool FULL>
+__device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, const RowParams &A, const SizeOffsets &so,
+                                                  const RowLds &L, int lane, int64_t n) {
+    const int j = lane & 15;
+    const int H = A.H, Hp = A.Hp;
+    const bool live = n < A.N;               // uniform per row
+    const int64_t nn = live ? n : A.N - 1;
+    const double ppil = A.P.prior_scale * A.P.pil_bar, ecoef = A.P.ecoef;
+    double *Pd = L.P + 1, *PG = L.P + 17, *Pe = L.P + 17 + Hp * Hp;
+    const unsigned char *Pb = reinterpret_cast<const unsigned char *>(L.P);
 
     // ---------------- multi-cause energies and log-joints, by state size ------------------------------
     double *out = A.logpj + nn * A.ldl;

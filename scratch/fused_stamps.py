@@ -28,7 +28,12 @@ fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(buf, nb) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
 t0 = st[:, 0].min()
+st = st[st[:, 0] > 0]
+t0 = st[:, 0].min()
+nb = st.shape[0]
 us5 = (st[:, :5] - t0) / 100.0
+us6 = (st[:, 5] - t0) / 100.0
+print('select x4 %.1f | fetch issue %.1f | compute x4 %.1f' % ((us5[:,3]-us5[:,2]).mean(), (us6-us5[:,3]).mean(), (us5[:,4]-us6).mean()))
 us = us5[:, [0, 1, 4]]
 print('phases us (mean): K-loop %.1f | tables+barrier %.1f | select x4 %.1f | estep x4 %.1f' % tuple((us5[:, i + 1] - us5[:, i]).mean() for i in range(4)))          # s_memrealtime ticks at 100 MHz
 hw = st[:, 7] & 0xFFFFFFFF
