@@ -196,7 +196,8 @@ def cpu_baseline(args):
     """Oracle leg, run as a child process BEFORE this process touches the GPU."""
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--D", str(D), "--H", str(H),
            "--Hprime", str(HP), "--gamma", str(GAMMA), "--budget", str(args.cpu_budget),
-           "--full-budget", str(min(6.0, args.cpu_budget)), "--parity-out", PARITY_FILE]
+           "--full-budget", str(min(6.0, args.cpu_budget)), "--solo-budget", "3", "--vec-budget", "3",
+           "--parity-out", PARITY_FILE]
     # the child is plain NumPy: keep profiler / tool injection (rocprofv3 preloads its library into every
     # descendant) out of its 100+ worker processes
     env = {k: v for k, v in os.environ.items()
@@ -249,7 +250,8 @@ def main():
     N = args.n_per_gpu
     g0 = torch.Generator(device=dev).manual_seed(0)
     W_gt = torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)
-    W0 = (W_gt + 0.1 * torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)).cpu().numpy()
+    # (D,H) parameter matrix laid out as an M-step returns it: the transposed view of a C-contiguous (H,D) array
+    W0 = np.ascontiguousarray((W_gt + 0.1 * torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)).cpu().numpy().T).T
     gr = torch.Generator(device=dev).manual_seed(100 + rank)
     Y = torch.empty(N, D, dtype=torch.float64, device=dev)
     for lo in range(0, N, 25_000):      # chunked so the generator temporaries stay small
@@ -285,7 +287,9 @@ def main():
     # Pre-warm by TIME (disclosed as prewarm_ms): the chip needs ~35 ms of sustained load to reach the clock it then
     # holds and the first ~20 passes of a process run 5-7 % slow; without this a short run (--steps 20 --warmup 5 is a
     # 40 ms timed region) would be measured inside the ramp.  Then the W counted warm-up passes, then the K timed ones.
-    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()           # a full collection of a torch process is a ~70 ms host stall (an idle GPU drops its clock): none
+    torch.cuda.synchronize()   # between here and the end of the timed loop
     tw = time.perf_counter()
     while time.perf_counter() - tw < args.prewarm_ms * 1e-3:
         for _ in range(5):
@@ -301,8 +305,6 @@ def main():
     chunks_per_step = 1 if fused else max(1, N // model._launch_rows(N))
     timer = KernelTimer(only={dom}, stride=4 * chunks_per_step)
     model.timer = timer
-    gc.collect()
-    gc.disable()           # a full collection of a torch process is a ~70 ms host stall; keep it out of the timed loops
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -397,29 +397,45 @@ class DeviceCAModel(CAModel):
             return None
         return {"ykey": res["key"], "W": seed["W"], "Wt": seed["Wt"], "G": seed["G"], "A": seed["A"]}
 
-    def _solve_normal_eq(self, Wq_u, qdiag, rhs):
+    def _invert_normal_matrix(self, Wq_u, qdiag):
+        """Wq = triu(Wq_u) + triu(Wq_u, 1)^T + diag(qdiag) and its inverse, enqueued on the CURRENT stream:
+        ``(Wq, Winv, pivots)`` -- one-workgroup SPD inverse (csrc/spd_inverse.hip) instead of ~40 rocSOLVER launches.
+        Only for device tensors with H <= 256.  It needs nothing but the (all-reduced) second moments, so a caller can
+        run it on a side stream beside the statistics GEMM, which needs nothing but E[s] (BSC_ET.M_step)."""
+        H = qdiag.shape[0]
+        Wq = torch.empty((H, H), dtype=torch.float64, device=Wq_u.device)
+        Winv = torch.empty((H, H), dtype=torch.float64, device=Wq_u.device)
+        piv = torch.empty(2, dtype=torch.float64, device=Wq_u.device)
+        self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
+                   H, _ptr(piv), self._stream())
+        return Wq, Winv, piv
+
+    def _apply_inverse(self, Wq, Winv, rhs):
+        """X = Winv . rhs with one step of iterative refinement, X += Winv (rhs - Wq X).  Every product is accumulated
+        into a ZEROED buffer and added once: the K-slices of pm_gemm_tn_acc_f64 are summed with f64 atomics, and
+        slices added to a non-zero X in run-to-run order would make ranks that solve the same all-reduced system
+        differ in the last bit (and drift apart over EM steps)."""
+        H, D = rhs.shape
+        st = self._stream()
+        XT = torch.zeros((3, H, D), dtype=torch.float64, device=rhs.device)     # X0, Wq.X0 and the correction: one fill
+        X0, T, C = XT[0], XT[1], XT[2]
+        self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(rhs), D, _ptr(X0), D, H, D, H, st)
+        self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Wq), H, _ptr(X0), D, _ptr(T), D, H, D, H, st)
+        R = rhs - T
+        self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(R), D, _ptr(C), D, H, D, H, st)
+        return X0 + C
+
+    def _solve_normal_eq(self, Wq_u, qdiag, rhs, pre=None):
         """X = Wq^-1 . rhs, enqueued on the device, for the symmetric second-moment matrix
         Wq = triu(Wq_u) + triu(Wq_u, 1)^T + diag(qdiag) -- the models' ``np.linalg.lstsq(Wq, Wp)``
         (bsc_et.py:380, dsc_et.py:741).  Returns (X (H,D), pivots (2,) = [smallest, largest pivot of the
         elimination; smallest <= 0 marks a failed factorisation], Wq (H,H)); the caller fetches the pivots with its
-        one download (``_solve_ok``) and falls back to LAPACK's lstsq on the host when they say "singular"."""
+        one download (``_solve_ok``) and falls back to LAPACK's lstsq on the host when they say "singular".
+        ``pre``: the result of ``_invert_normal_matrix`` when the caller has already run it."""
         H, D = rhs.shape
         if rhs.is_cuda and H <= 256:
-            # one-workgroup SPD inverse + GEMMs (csrc/spd_inverse.hip) instead of ~40 rocSOLVER launches
-            Wq = torch.empty((H, H), dtype=torch.float64, device=rhs.device)
-            Winv = torch.empty((H, H), dtype=torch.float64, device=rhs.device)
-            piv = torch.empty(2, dtype=torch.float64, device=rhs.device)
-            st = self._stream()
-            self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
-                       H, _ptr(piv), st)
-            XT = torch.zeros((2, H, D), dtype=torch.float64, device=rhs.device)     # X and the refinement's Wq.X: one fill
-            X, T = XT[0], XT[1]
-            self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(rhs), D, _ptr(X), D, H, D, H, st)
-            # one step of iterative refinement: X += Winv (rhs - Wq X)
-            self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Wq), H, _ptr(X), D, _ptr(T), D, H, D, H, st)
-            R = rhs - T
-            self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(R), D, _ptr(X), D, H, D, H, st)
-            return X, piv, Wq
+            Wq, Winv, piv = pre if pre is not None else self._invert_normal_matrix(Wq_u, qdiag)
+            return self._apply_inverse(Wq, Winv, rhs), piv, Wq
         Wq = torch.triu(Wq_u, 1)
         Wq = Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)
         Lc, info = torch.linalg.cholesky_ex(Wq)

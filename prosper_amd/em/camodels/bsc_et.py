@@ -49,6 +49,8 @@ class BSC_ET(DeviceCAModel):
         self._spec_ok = False    # the last M-step's seeded parameters were used as they were
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.fused_remainder = os.environ.get('PM_GEMM_FUSE_REMAINDER', '1') == '1'   # ragged last round inside the main launch
+        self.overlap_inverse = os.environ.get('PM_OVERLAP_INVERSE', '0') == '1'   # Wq inverse beside the statistics GEMM (no gain, see M_step)
+        self._inv_stream = None
         self.use_fused = os.environ.get('PM_FUSED', '1') == '1'   # scores GEMM + select + E-step as ONE kernel (bsc_fused.hip)
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
         self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
@@ -521,16 +523,36 @@ class BSC_ET(DeviceCAModel):
         stats.zero_()
         expect = self._buf("expect", (my_N, H))
         P = self._estep_params(anneal, pies, sigma, mu)
+        st = self._stream()
         if my_N and tab["fast"]:
             self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut),
                        _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,
-                       _ptr(stats), self._stream())
-            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, self._stream())
+                       _ptr(stats), st)
         elif my_N:
             self._call("mstep_rows", "pm_bsc_mstep_rows_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand),
                       _ptr(tab["masks"]), S, _ptr(tab["pair_ptr"]), _ptr(tab["pair_states"]), tab["pair_len"],
-                      ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats), self._stream())
-            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, self._stream())
+                      ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats), st)
+        # Everything but Wp is final now, and the H x H inverse (0.31 ms, one workgroup) needs only the (all-reduced)
+        # second moments.  PM_OVERLAP_INVERSE=1 puts it on a high-priority side stream ahead of the statistics GEMM (and,
+        # on several ranks, all-reduces [Wq | qdiag | mus | scalars] there, Wp behind the GEMM).  Measured: no gain --
+        # the inverse's 1024-thread workgroup needs a whole CU's registers, the GEMM's workgroups refill every slot as it
+        # frees, so the inverse still starts when the GEMM has drained (4.88 vs 4.87 ms per EM iteration).  Off by default.
+        o_wq = _lib.load().pm_bsc_stats_offset_wq(H, D)
+        pre = None
+        split = ('W' in self.to_learn and H <= 256 and self.overlap_inverse)
+        if split:
+            cur = torch.cuda.current_stream(self.device)
+            if self._inv_stream is None:
+                self._inv_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            side = self._inv_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                comm.allreduce_device(stats[o_wq:])
+                lib = _lib.load()
+                o_qd, o_mus = lib.pm_bsc_stats_offset_qdiag(H, D), lib.pm_bsc_stats_offset_mus(H, D)
+                pre = self._invert_normal_matrix(stats[o_wq:o_qd].view(H, H), stats[o_qd:o_mus])
+        if my_N:
+            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, st)
         need_mu = 'mu' in self.to_learn
         if need_mu:
             keep = (lse >= lse_cut).to(torch.float64)
@@ -539,11 +561,21 @@ class BSC_ET(DeviceCAModel):
         else:
             packed = stats
 
-        # the ONE exchange of the step (replaces bsc_et.py:225,258,266,373,374,387,417,426,427)
-        comm.allreduce_device(packed)
-        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res)
+        # the exchange of the step (replaces bsc_et.py:225,258,266,373,374,387,417,426,427)
+        if split:
+            if need_mu:
+                wp_mu = torch.cat([stats[:o_wq], data_sum])
+                comm.allreduce_device(wp_mu)
+                packed[:o_wq] = wp_mu[:o_wq]
+                packed[stats.numel():] = wp_mu[o_wq:]
+            else:
+                comm.allreduce_device(packed[:o_wq])
+            cur.wait_stream(side)
+        else:
+            comm.allreduce_device(packed)
+        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res, pre)
 
-    def _finalize(self, packed, model_params, A_pi_gamma, E_pi_gamma, res=None):
+    def _finalize(self, packed, model_params, A_pi_gamma, E_pi_gamma, res=None, pre=None):
         """Parameter updates from the all-reduced statistics (bsc_et.py:264-267, 369-438).
         Everything is enqueued on the device first (Wq assembly, Cholesky solve, reductions) and
         fetched with ONE device->host copy, so an EM step synchronises with the GPU exactly once.
@@ -571,7 +603,7 @@ class BSC_ET(DeviceCAModel):
             if np.any(mu):   # Wp was accumulated against y, the reference uses y - mu
                 rhs = Wp - torch.outer(mus, torch.from_numpy(mu).to(packed.device))
             rhs = rhs.contiguous()
-            X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, rhs)
+            X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, rhs, pre)
             parts += [status, X.reshape(-1)]
             if packed.is_cuda and res is not None:   # next step's W^T and Gram matrix are already here: no upload then
                 seed = (X, self._gemm_nt(X, X, self._buf("gram", (H, H)), "gram_gemm"))

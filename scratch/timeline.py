@@ -10,7 +10,7 @@ for f in glob.glob(root + "/**/*memory_copy_trace.csv", recursive=True):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") + " " + r.get("Bytes", r.get("Size", ""))))
 ev.sort()
 # iterations are delimited by the scores GEMM (largest grid dma kernel); take the last complete one
-idx = [i for i, e in enumerate(ev) if "gemm_nt_f64_dma_kernel" in e[2] and (e[1] - e[0]) > 1_000_000]
+idx = [i for i, e in enumerate(ev) if ("bsc_estep_fused" in e[2] or "gemm_nt_f64_dma_kernel" in e[2]) and (e[1] - e[0]) > 1_000_000]
 lo, hi = idx[-2], idx[-1]
 # walk back to include the uploads preceding the GEMM
 t0 = ev[lo][0]
