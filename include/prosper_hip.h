@@ -181,8 +181,14 @@ int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const double *gra
 /* Scores GEMM + select_Hprimes + E_step in ONE kernel (bsc_et.py:98-115 and :119-192): what pm_gemm_nt_f64 followed by
  * pm_bsc_select_estep_f64 computes, without the (N,H) scores buffer -- a workgroup owns 64 datapoints x all H latents
  * and runs the row pass out of its MFMA accumulators.  Y (N,D) data, Wt (H,D) = W^T; the other arguments, the
- * `mode` bits and the outputs are those of pm_bsc_select_estep_f64.  Needs pm_bsc_fused_supported(H, D, Hprime, S):
- * H <= 256, D a multiple of 8 (callers zero-pad the K dimension), 16-byte aligned rows (ldy, ldw even). */
+ * `mode` bits 0 and 1 and the outputs are those of pm_bsc_select_estep_f64 (BSC's own ranking only).  Needs
+ * pm_bsc_fused_supported(H, D, Hprime, S): H <= 256, D a multiple of 8 (callers zero-pad the K dimension), 16-byte
+ * aligned rows (ldy, ldw even).
+ * M-step statistics in the same pass (stats != NULL; Hprime <= 8, mode & 2, lse given): for EVERY datapoint -- i.e. when
+ * no data truncation follows (bsc_et.py:247-258 skipped) -- what pm_bsc_mstep_rows16_f64 computes from logpj:
+ * E[s] rows into expect (N,H), and into the packed buffer `stats` of a model with D_stats observed dimensions (layout
+ * above): the multi-cause part of Wq's upper triangle INCLUDING its diagonal, mus = sum_n E[s], the scalars.  The
+ * qdiag block is not written: qdiag = mus - diag(Wq block) (s_h^2 = s_h).  `stats` is accumulated into. */
 int pm_bsc_fused_supported(int64_t H, int64_t D, int64_t Hprime, int64_t S);
 /* Workgroups of that kernel one CU holds at once for this shape (2 by design: one on the matrix pipe, one in its row
  * passes); diagnostic, <= 0 when unsupported. */
@@ -193,7 +199,7 @@ int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double *Wt, int64
                            const int32_t *size_offsets_host, int64_t S, int64_t gamma,
                            const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
                            int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
-                           void *stream);
+                           double *expect, int64_t lde, double *stats, int64_t D_stats, void *stream);
 
 /* Fast-path twin of pm_bsc_mstep_rows_f64 (same outputs, same `stats` layout). */
 int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,

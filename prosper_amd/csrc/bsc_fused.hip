@@ -53,14 +53,17 @@ __device__ unsigned long long pm_fused_stamps[8192][8];
 #define PM_STAMP(slot)
 #endif
 
-template <int NJ, int STAGES, bool FULL>   // FULL: H == 16 NJ, no latent-index guards in the row passes
+// FULL: H == 16 NJ, no latent-index guards in the row passes.  MSTATS: the row passes also produce the per-datapoint part
+// of the M-step (E[s] rows into `expect`, statistics into the packed buffer `stats`): see row_estep_compute.
+template <int NJ, int STAGES, bool FULL, bool MSTATS>
 __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wt, int64_t ldw, int D,
     const double *__restrict__ gram, const double *__restrict__ ynorm2, const double *__restrict__ wmu,
     const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
     SizeOffsets so, int S, int gamma, pm_bsc_estep_params P, int64_t N, int H, int Hp, int mode,
-    int32_t *__restrict__ cand, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse, int stagger_lo,
-    int stagger_hi, int stagger_ticks) {
+    int32_t *__restrict__ cand, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse,
+    double *__restrict__ expect, int64_t lde, double *__restrict__ stats, int Dstats, int stagger_lo, int stagger_hi,
+    int stagger_ticks) {
     constexpr int STAGE = (AROWS + 16 * NJ) * DK;   // doubles per stage
     constexpr int L = 1 + NJ / 4;                   // DMA instructions per K-step and wavefront
     constexpr int NG = NJ / 4;                      // groups of four column blocks
@@ -227,8 +230,10 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     __syncthreads();
 
     PM_STAMP(2);
-    const RowParams A{gram, ynorm2, wmu, ymu, S, gamma, P, N, H, Hp, mode, cand, logpj, ldl, lse};
+    const RowParams A{gram, ynorm2, wmu, ymu, S, gamma, P, N, H, Hp, mode, cand, logpj, ldl, lse, expect, lde,
+                      MSTATS ? stats + pm_bsc_stats_offset_wq_dev(H, Dstats) : nullptr};
     const RowLds Lds = row_lds(smem, lay, wave * 4 + fk);
+    MAcc macc{0.0, 0.0, 0.0};
 
     // Row fk (16 lanes) of this wavefront holds datapoint m0 + 16 wave + fk + 4 r in element r of every accumulator.
     const int64_t nbase = m0 + 16 * wave + fk;
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
             double a[NJ];
 #pragma unroll
             for (int i = 0; i < NJ; ++i) a[i] = acc[i][r];
-            row_estep_fetched<NJ, FULL, 4>(a, acs[r], F[r], A, so, Lds, lane, nbase + 4 * r);
+            row_estep_fetched<NJ, FULL, 4, MSTATS>(a, acs[r], mycs[r], F[r], A, so, Lds, lane, nbase + 4 * r, &macc);
         }
     } else {
 #pragma unroll
@@ -279,6 +284,29 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
                 wave_lds_sync16();
                 row_estep<NJ, FULL>(a, Lds.row, c, A, so, Lds, lane, n);
             }
+        }
+    }
+    if (MSTATS) {
+        // column sums of E[s] and the scalar statistics of this tile -> packed statistics buffer
+        double sig = pm_wave_sum(macc.sig), fs = pm_wave_sum(macc.fs), cnt = pm_wave_sum(macc.cnt);
+        __syncthreads();                     // every wavefront's LDS atomics into mus are done
+        double *red = reinterpret_cast<double *>(smem + lay.off_dp);     // (datapoint areas are free now)
+        if (lane == 0) {
+            red[wave * 3 + 0] = sig;
+            red[wave * 3 + 1] = fs;
+            red[wave * 3 + 2] = cnt;
+        }
+        __syncthreads();
+        double *sc = stats + pm_bsc_stats_offset_scalars_dev(H, Dstats);
+        if (tid < 3) {
+            double v = 0.0;
+            for (int w = 0; w < 4; ++w) v += red[w * 3 + tid];
+            if (v != 0.0) pm_atomic_add(sc + tid, v);
+        }
+        double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, Dstats);
+        if (tid < H) {
+            const double v = Lds.mus[tid];
+            if (v != 0.0) pm_atomic_add(g_mus + tid, v);
         }
     }
     PM_STAMP(4);
@@ -340,10 +368,11 @@ extern "C" int pm_bsc_fused_occupancy(int64_t H, int64_t D, int64_t Hprime, int6
 #define PM_OCC(NJ, ST)                                                                                                 \
     do {                                                                                                               \
         const size_t shmem = fused_lds_bytes<NJ, ST>(H, Hprime, S);                                                       \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST, false>),                 \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST, false, false>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                               \
         if (e == hipSuccess)                                                                                           \
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bsc_estep_fused_kernel<NJ, ST, false>, 256, shmem);   \
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bsc_estep_fused_kernel<NJ, ST, false, false>, 256,    \
+                                                             shmem);                                                   \
     } while (0)
     if (H <= 128) {
         if (three) PM_OCC(8, 3);
@@ -362,7 +391,7 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
                                       const int32_t *size_offsets_host, int64_t S, int64_t gamma,
                                       const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
                                       int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
-                                      void *stream) {
+                                      double *expect, int64_t lde, double *stats, int64_t D_stats, void *stream) {
     if (!Y || !Wt || !gram || !ynorm2 || !cand || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || ldy < D ||
         ldw < D || !(mode & 3) || ((wmu == nullptr) != (ymu == nullptr)))
         return PM_EINVAL;
@@ -370,6 +399,8 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
                        (S > 0 && (!state_masks || !state_parents || !size_offsets_host))))
         return PM_EINVAL;
     if (!pm_bsc_fused_supported(H, D, Hprime, S) || (mode & ~3)) return PM_ERANGE;   // (BSC's own ranking only)
+    if (stats && (!expect || lde < H || !lse || !(mode & 2) || D_stats <= 0)) return PM_EINVAL;
+    if (stats && Hprime > 8) return PM_ERANGE;          // (the M-statistics ride on the three-phase row passes)
     if (!aligned16(Y) || !aligned16(Wt) || (ldy % 2) || (ldw % 2)) return PM_EINVAL;
     if (N == 0) return PM_OK;
     SizeOffsets so;
@@ -381,15 +412,24 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
     if (tiles > INT32_MAX) return PM_ERANGE;
     dim3 grid((unsigned)tiles), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define PM_LAUNCH_F(NJ, ST, F)                                                                                         \
+#define PM_LAUNCH_FM(NJ, ST, F, M)                                                                                     \
     do {                                                                                                               \
         const size_t shmem = fused_lds_bytes<NJ, ST>(H, Hprime, S);                                                    \
-        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST, F>),        \
+        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused_kernel<NJ, ST, F, M>),     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))                  \
             return e;                                                                                                  \
-        hipLaunchKernelGGL((bsc_estep_fused_kernel<NJ, ST, F>), grid, block, shmem, s, Y, ldy, Wt, ldw, (int)D, gram,  \
-                           ynorm2, wmu, ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H,        \
-                           (int)Hprime, mode, cand, logpj, ldl, lse, stagger_lo, stagger_hi, stagger_ticks);           \
+        hipLaunchKernelGGL((bsc_estep_fused_kernel<NJ, ST, F, M>), grid, block, shmem, s, Y, ldy, Wt, ldw, (int)D,     \
+                           gram, ynorm2, wmu, ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H,  \
+                           (int)Hprime, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, stagger_lo,    \
+                           stagger_hi, stagger_ticks);                                                                 \
+    } while (0)
+#define PM_LAUNCH_F(NJ, ST, F)              \
+    do {                                    \
+        if (stats) {                        \
+            PM_LAUNCH_FM(NJ, ST, F, true);  \
+        } else {                            \
+            PM_LAUNCH_FM(NJ, ST, F, false); \
+        }                                   \
     } while (0)
 #define PM_LAUNCH(NJ, ST)                  \
     do {                                   \
@@ -425,5 +465,6 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
     }
 #undef PM_LAUNCH
 #undef PM_LAUNCH_F
+#undef PM_LAUNCH_FM
     return (int)hipGetLastError();
 }

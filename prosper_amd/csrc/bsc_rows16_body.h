@@ -90,6 +90,7 @@ __device__ __forceinline__ void wave_lds_sync16() {
 
 // exp(x) for x in [-745, 0] (used on [-37, 0]): n = rint(x log2 e), r = x - n ln 2, degree-13 Taylor, ldexp.
 __device__ __forceinline__ double exp_neg(double x) {
+    x = vmax64(x, -745.0);     // lanes whose result is discarded may hold anything: keep the int conversion defined
     const double n = rint(x * 1.4426950408889634);
     double t = fma(-n, 6.9314718036912382e-01, x);
     t = fma(-n, 1.9082149292705877e-10, t);
@@ -160,10 +161,21 @@ struct RowParams {
     double *logpj;
     int64_t ldl;
     double *lse;
+    // M-step statistics produced in the same pass (fused kernel, no data truncation ahead): E[s] rows and the upper
+    // triangle of sum_n E[s s^T] over the multi-cause states (bsc_et.py:334-366); null when not wanted
+    double *expect;
+    int64_t lde;
+    double *wq;
+};
+
+// per-lane partial sums of the scalar M-step statistics over the passes of a wavefront
+struct MAcc {
+    double sig, fs, cnt;   // sum_nk q e (bsc_et.py:395-415), sum_n log-evidence, datapoints
 };
 
 // ---- LDS layout of a workgroup ------------------------------------------------------------------------------------
-//   [ w2 (HT) | sw (HT) | ew (HT) | 16 datapoint areas of `area` doubles | tab (S u32) | st (S x 8 u16) | ik (Hp*Hp u16) ]
+//   [ w2 (HT) | sw (HT) | ew (HT) | mus (HT) | 16 datapoint areas of `area` doubles | tab (S u32) | st (S x 8 u16) |
+//     ik (Hp*Hp u16) ]
 // HT = latents rounded up to 16.  A datapoint area:
 //   P    = [ zero | d (16) | G (Hp*Hp) | e (S) ]   byte-addressed by the state table; during selection the same bytes
 //                                                  hold the lanes' sorted key lists (LIST_ROWS x 16 doubles)
@@ -180,7 +192,7 @@ __host__ __device__ inline Layout make_layout(int H, int Hp, int S, int rowbuf) 
     const int p = 1 + 16 + Hp * Hp + S, lists = LIST_ROWS * 16;
     L.p_len = p > lists ? p : lists;
     L.area = L.p_len + 16 + (rowbuf ? L.HT : 0);
-    L.off_dp = 3 * L.HT * 8;
+    L.off_dp = 4 * L.HT * 8;
     L.off_tab = L.off_dp + ROWS * L.area * 8;
     L.off_st = (L.off_tab + 4 * S + 15) / 16 * 16;
     L.off_ik = L.off_st + 16 * S;
@@ -193,6 +205,7 @@ struct RowLds {
     const double *w2;     // (HT) |W_h|^2 (+ 2 W_h.mu)
     const double *sw;     // (HT) 1 / |W_h|
     const double *ew;     // (HT) ecoef |W_h|^2 (+ 2 ecoef W_h.mu) + prior: the singleton log-joint up to -2 ecoef a_h + ecoef |y|^2
+    double *mus;          // (HT) sum of E[s_h] over the workgroup's datapoints (M-statistics mode)
     const uint32_t *tab;  // (S)  state mask | parent << 16
     const uint16_t *st;   // (S x 8) byte offsets into P: parent term, d_k, three Gram terms (unused ones -> zero slot)
     const uint16_t *ik;   // (Hp*Hp) i | k << 8 of the Gram block's entry p = i Hp + k
@@ -204,7 +217,7 @@ struct RowLds {
 __device__ __forceinline__ RowLds row_lds(unsigned char *smem, const Layout &L, int dp /* 0..15 */) {
     double *base = reinterpret_cast<double *>(smem);
     double *area = reinterpret_cast<double *>(smem + L.off_dp) + dp * L.area;
-    return RowLds{base, base + L.HT, base + 2 * L.HT, reinterpret_cast<const uint32_t *>(smem + L.off_tab),
+    return RowLds{base, base + L.HT, base + 2 * L.HT, base + 3 * L.HT, reinterpret_cast<const uint32_t *>(smem + L.off_tab),
                   reinterpret_cast<const uint16_t *>(smem + L.off_st), reinterpret_cast<const uint16_t *>(smem + L.off_ik),
                   area, area + L.p_len, area + L.p_len + 16};
 }
@@ -225,6 +238,7 @@ __device__ __forceinline__ void build_tables(unsigned char *smem, const Layout &
         w2[tid] = w;
         sw[tid] = 1.0 / sqrt(g_h);   // ranking uses a * (1/|W_h|): keys keep 42 mantissa bits anyway
         ew[tid] = fma(ecoef, w, ppil);
+        w2[3 * L.HT + tid] = 0.0;    // mus
     }
     for (int h = 256 + tid; h < L.HT; h += 256) {
         const int hc = h < H ? h : H - 1;
@@ -233,6 +247,7 @@ __device__ __forceinline__ void build_tables(unsigned char *smem, const Layout &
         w2[h] = w;
         sw[h] = 1.0 / sqrt(g);
         ew[h] = fma(ecoef, w, ppil);
+        w2[3 * L.HT + h] = 0.0;
     }
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem + L.off_tab);
     uint16_t *st = reinterpret_cast<uint16_t *>(smem + L.off_st);
@@ -416,14 +431,15 @@ __device__ __forceinline__ RowFetch<GI> row_fetch(int myc, const RowParams &A, c
     return F;
 }
 
-template <int VPL, bool FULL>
-__device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, const RowParams &A, const SizeOffsets &so,
-                                                  const RowLds &L, int lane, int64_t n);
+template <int VPL, bool FULL, bool MSTATS>
+__device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, int myc, const RowParams &A,
+                                                  const SizeOffsets &so, const RowLds &L, int lane, int64_t n, MAcc *acc);
 
 // E_step with fetched values: ac = the score of this lane's candidate (lanes j < Hp).  GI * 16 >= Hp * Hp.
-template <int VPL, bool FULL, int GI>
-__device__ __forceinline__ void row_estep_fetched(double (&a)[VPL], double ac, const RowFetch<GI> &F, const RowParams &A,
-                                                  const SizeOffsets &so, const RowLds &L, int lane, int64_t n) {
+template <int VPL, bool FULL, int GI, bool MSTATS = false>
+__device__ __forceinline__ void row_estep_fetched(double (&a)[VPL], double ac, int myc, const RowFetch<GI> &F,
+                                                  const RowParams &A, const SizeOffsets &so, const RowLds &L, int lane,
+                                                  int64_t n, MAcc *acc = nullptr) {
     const int j = lane & 15;
     const int Hp = A.Hp;
     double *Pd = L.P + 1, *PG = L.P + 17;
@@ -435,7 +451,7 @@ __device__ __forceinline__ void row_estep_fetched(double (&a)[VPL], double ac, c
         if (p < Hp * Hp) PG[p] = F.G[it];
     }
     wave_lds_sync16();
-    row_estep_compute<VPL, FULL>(a, F.yn, A, so, L, lane, n);
+    row_estep_compute<VPL, FULL, MSTATS>(a, F.yn, myc, A, so, L, lane, n, acc);
 }
 
 template <int VPL, bool FULL = false>
@@ -466,13 +482,16 @@ __device__ __forceinline__ void row_estep(double (&a)[VPL], const double *arow, 
         if (valid) PG[p] = A.gram[(int64_t)ci * H + ck];
     }
     wave_lds_sync16();
-    row_estep_compute<VPL, FULL>(a, yn, A, so, L, lane, n);
+    row_estep_compute<VPL, FULL, false>(a, yn, myc, A, so, L, lane, n, nullptr);
 }
 
-// The arithmetic of the E-step: P = [ zero | d | G ] of this datapoint is in LDS.
-template <int VPL, bool FULL>
-__device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, const RowParams &A, const SizeOffsets &so,
-                                                  const RowLds &L, int lane, int64_t n) {
+// The arithmetic of the E-step: P = [ zero | d | G ] of this datapoint is in LDS.  MSTATS: also the per-datapoint part
+// of the M-step (bsc_et.py:271-272, 334-366, 395-415) for a datapoint that is certainly kept -- posterior weights from
+// the exponentials the log-sum-exp has just evaluated, E[s] row (through L.row), second-moment block of the candidates
+// scattered into A.wq, column sums into L.mus, scalar sums into *acc.  Needs L.row.
+template <int VPL, bool FULL, bool MSTATS>
+__device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, int myc, const RowParams &A,
+                                                  const SizeOffsets &so, const RowLds &L, int lane, int64_t n, MAcc *acc) {
     const int j = lane & 15;
     const int H = A.H, Hp = A.Hp;
     const bool live = n < A.N;               // uniform per row
@@ -527,7 +546,7 @@ __device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, c
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {  // a[i] becomes the singleton log-joint of latent h
         const int h = j + 16 * i;
-        double f = -INFINITY;
+        double f = -1.0e300;     // a register without a latent: never the maximum, never counted (finite: 0 x f stays 0)
         if (FULL || h < H) {
             f = fma(m2e, a[i], L.ew[h]) + f0;
             if (live) out[1 + h] = f;
@@ -544,19 +563,33 @@ __device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, c
     // ---------------- log-sum-exp: only terms within exp(-37) of the largest are evaluated ------------
     mx = row_max_f64(mx);
     const double thr = mx + NEGLIGIBLE;
-    double sum = 0.0;
+    double sum = 0.0, qe = 0.0;          // qe: sum of exp(f - mx) (f - prior) = ecoef sum of exp(.) e
     {
         const bool need = (j == 0) && f0 > thr;
-        if (__any(need)) sum = need ? exp_neg(f0 - mx) : 0.0;
+        if (__any(need)) {
+            sum = need ? exp_neg(f0 - mx) : 0.0;
+            if (MSTATS) qe = sum * f0;
+        }
     }
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
+    for (int i = 0; i < VPL; ++i) {      // MSTATS: a[i] becomes exp(f - mx) of a term that counts, else 0
         const bool need = a[i] > thr;
-        if (__any(need)) sum += need ? exp_neg(a[i] - mx) : 0.0;
+        double ex = 0.0;
+        if (__any(need)) {
+            ex = need ? exp_neg(a[i] - mx) : 0.0;
+            sum += ex;
+            if (MSTATS) qe = need ? fma(ex, a[i] - ppil, qe) : qe;     // (a padded latent holds -inf: 0 x -inf)
+        }
+        if (MSTATS) a[i] = ex;
     }
     // multi-cause states: the test runs on the energies (f > thr  <=>  e < te_g for ecoef < 0, one compare per state);
     // the log-joint is rebuilt -- with the arithmetic that produced the stored value -- only where an exp is due
     const double inv_ecoef = 1.0 / ecoef;
+    double *m2 = PG;                     // MSTATS: the Gram block's bytes become the candidates' second-moment block
+    if (MSTATS) {
+        for (int p = j; p < Hp * Hp; p += 16) m2[p] = 0.0;
+        wave_lds_sync16();
+    }
     for (int g = 2; g <= A.gamma; ++g) {
         const double pg = ppil * (double)g;
         const double te = (thr - pg) * inv_ecoef - yn;
@@ -567,12 +600,76 @@ __device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, c
             const bool need = (s < s1) && (ecoef < 0.0 ? e < te : e > te);
             if (__any(need)) {
                 const double f = fma(ecoef, yn + e, pg);
-                sum += (need && f > thr) ? exp_neg(f - mx) : 0.0;
+                const double ex = (need && f > thr) ? exp_neg(f - mx) : 0.0;
+                sum += ex;
+                if (MSTATS && ex != 0.0) {
+                    qe = fma(ex, f - pg, qe);
+                    unsigned mi = L.tab[s] & 0xFFFFu;
+                    while (mi) {             // E[s_i s_k] += weight for every pair i <= k of the state (LDS atomics)
+                        const int i = __builtin_ctz(mi);
+                        mi &= mi - 1;
+                        atomicAdd(&m2[i * Hp + i], ex);
+                        unsigned mk = mi;
+                        while (mk) {
+                            const int k = __builtin_ctz(mk);
+                            mk &= mk - 1;
+                            atomicAdd(&m2[i * Hp + k], ex);
+                        }
+                    }
+                }
             }
         }
     }
     sum = row_sum_f64(sum);
-    if (live && j == 0) A.lse[n] = mx + log_ge1(sum);
+    const double lse_n = mx + log_ge1(sum);
+    if (live && j == 0) A.lse[n] = lse_n;
+    if (MSTATS) {
+        const double inv = 1.0 / sum;
+        if (live) {
+            acc->sig += qe * inv * inv_ecoef;
+            if (j == 0) {
+                acc->fs += lse_n;
+                acc->cnt += 1.0;
+            }
+        }
+        // E[s] row: singleton weights through the LDS row, the candidates' multi-cause weights added there
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            if (FULL || j + 16 * i < H) L.row[j + 16 * i] = a[i] * inv;
+        wave_lds_sync16();
+        if (j < Hp) {
+            const double m1 = m2[j * Hp + j] * inv;
+            if (m1 != 0.0) L.row[myc] += m1;
+        }
+        // the candidates' second-moment block -> upper triangle of Wq
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {          // uniform trip count: every lane feeds the bpermutes
+            const int p = p0 + j;
+            const bool valid = p < Hp * Hp;
+            const unsigned ik = valid ? L.ik[p] : 0u;
+            const int ci = __builtin_amdgcn_ds_bpermute(((lane & 48) + (int)(ik & 0xFF)) << 2, myc);
+            const int ck = __builtin_amdgcn_ds_bpermute(((lane & 48) + (int)(ik >> 8)) << 2, myc);
+            const double v = valid ? m2[p] * inv : 0.0;
+            if (live && v != 0.0) {
+                const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
+                pm_atomic_add(A.wq + (int64_t)lo * H + hi, v);
+            }
+        }
+        wave_lds_sync16();
+        double *erow = A.expect + nn * A.lde;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            if (FULL || h < H) {
+                const double v = L.row[h];
+                if (live) {
+                    erow[h] = v;
+                    if (__any(v != 0.0)) {
+                        if (v != 0.0) atomicAdd(&L.mus[h], v);
+                    }
+                }
+            }
+        }
+    }
     wave_lds_sync16();  // the datapoint area is reused by the next pass
 }
 

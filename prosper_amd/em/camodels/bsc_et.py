@@ -51,6 +51,8 @@ class BSC_ET(DeviceCAModel):
         self.fused_remainder = os.environ.get('PM_GEMM_FUSE_REMAINDER', '1') == '1'   # ragged last round inside the main launch
         self.overlap_inverse = os.environ.get('PM_OVERLAP_INVERSE', '0') == '1'   # Wq inverse beside the statistics GEMM (no gain, see M_step)
         self._inv_stream = None
+        self._in_step = False
+        self.fuse_mstats = os.environ.get('PM_FUSE_MSTATS', '1') == '1'   # M-step row statistics inside the fused E-step
         self.use_fused = os.environ.get('PM_FUSED', '1') == '1'   # scores GEMM + select + E-step as ONE kernel (bsc_fused.hip)
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
         self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
@@ -196,7 +198,9 @@ class BSC_ET(DeviceCAModel):
         main = N // rnd * rnd
         return N if (N - main) * 10 >= rnd * 7 else main
 
-    def _fused_estep(self, res, par, mode, cand, P, wmu, ymu, logpj, lse):
+    def _fused_estep(self, res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats=None):
+        """``mstats`` = (expect (N,H), stats): also produce the per-datapoint M-step statistics of the rows the fused
+        kernel takes (E_step inside ``step`` with no data truncation ahead)."""
         tab = self._state_tables()
         Y8, W8 = self._k8(res, "Y8", res["Y"]), self._k8(par, "Wt8", par["Wt"])
         N, H, Hp, S = Y8.shape[0], self.H, self.Hprime, self.no_states
@@ -223,9 +227,10 @@ class BSC_ET(DeviceCAModel):
         self._call("estep_fused", "pm_bsc_estep_fused_f64", _ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
                    _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
                    S, self.gamma, Pref, main, Y8.shape[1], H, Hp, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse),
-                   self._stream())
+                   _ptr(mstats[0]) if mstats else None, H, _ptr(mstats[1]) if mstats else None, self.D, self._stream())
         if side is not None:
             cur.wait_stream(side)
+        return main
 
     # ---- scores GEMM, then the fused, chunked select + E-step (two-kernel path) -------------------
     def _round_rows(self):
@@ -273,7 +278,7 @@ class BSC_ET(DeviceCAModel):
         """Datapoints one ``scores_gemm`` launch covers (bench.py's roofline accounting)."""
         return N if (self._whole_shard(N) and self.fused_remainder) else min(N, self._chunk_rows(N))
 
-    def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None):
+    def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None, mstats=None):
         """Scores GEMM + fused select/E-step kernel.  Whole-shard mode: the scores of all rows, then ONE pass of
         the row kernel.  Chunked mode (``chunk_rounds`` / shards beyond ``max_chunk_rows``): a chunk is a whole
         number of rounds of resident GEMM tiles; its (chunk, H) score block is consumed by the row kernel
@@ -281,8 +286,7 @@ class BSC_ET(DeviceCAModel):
         matters (one round per chunk 2.27 ms, whole shard 2.15 ms per pass at config 2).
         ``overlap``: GEMM of chunk c+1 on a side stream while the row kernel of chunk c runs."""
         if self._fused():
-            self._fused_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse)
-            return
+            return self._fused_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats)
         Y = res["Y"]
         N, H, Hp, S = Y.shape[0], self.H, self.Hprime, self.no_states
         tab = self._state_tables()
@@ -365,6 +369,14 @@ class BSC_ET(DeviceCAModel):
         return {'y': y, 's': s}
 
     # ------------------------------------------------------------------ hot path
+    def step(self, anneal, model_params, my_data):
+        """CAModel.step (camodels/__init__.py:163-193); E_step knows that M_step follows with the same arguments."""
+        self._in_step = True
+        try:
+            return DeviceCAModel.step(self, anneal, model_params, my_data)
+        finally:
+            self._in_step = False
+
     @tracing.traced
     def select_Hprimes(self, model_params, data):
         """Annotate ``data`` with ``data['candidates']`` (N, Hprime): per datapoint the
@@ -442,12 +454,25 @@ class BSC_ET(DeviceCAModel):
             else:
                 cand = self._device_candidates(cobj, N)
                 mode = 2
+            # inside CAModel.step with no data truncation ahead the M-step's per-datapoint statistics are produced by
+            # the same pass (fused kernel): posterior weights from the exponentials the log-sum-exp evaluates anyway, no
+            # second pass over the 665 MB of log-joints
+            mstats, rows = None, 0
+            if (N and self._in_step and self.fuse_mstats and anneal['Ncut_factor'] <= 0.0 and self._fused()
+                    and Hp <= 8 and 'mu' not in self.to_learn):
+                n_stats = _lib.load().pm_bsc_stats_len(H, D)
+                stats = self._buf("stats", (n_stats,))
+                stats.zero_()
+                mstats = (self._buf("expect", (N, H)), stats)
             if N:
-                self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse)
+                rows = self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats)
             if fuse:
                 cobj._ticket["cand"] = cand
             out = DeviceArray(logpj)
             out.lse = lse
+            if mstats is not None:
+                out.mstats = {"expect": mstats[0], "stats": mstats[1], "rows": rows, "res": res, "cand": cand,
+                              "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm)}
             return {'logpj': out}
         par = self._scores(model_params, res)
         cand = self._device_candidates(cobj, N)
@@ -520,11 +545,33 @@ class BSC_ET(DeviceCAModel):
         _lib.load()
         n_stats = _lib.load().pm_bsc_stats_len(H, D)
         stats = self._buf("stats", (n_stats,))
-        stats.zero_()
         expect = self._buf("expect", (my_N, H))
         P = self._estep_params(anneal, pies, sigma, mu)
         st = self._stream()
-        if my_N and tab["fast"]:
+        # statistics the E-step pass has already produced for its first `done` rows (same shard, candidates, scalars)
+        ms = getattr(logpj, "mstats", None) if isinstance(logpj, DeviceArray) else None
+        done = 0
+        if (ms is not None and ms["res"] is res and ms["stats"] is stats and ms["expect"] is expect and ms["cand"] is cand
+                and ms["P"] == (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm) and lse_cut == float("-inf")
+                and tab["fast"]):
+            done = ms["rows"]
+            logpj.mstats = None
+            lib = _lib.load()
+            o_wq, o_qd, o_mus = (lib.pm_bsc_stats_offset_wq(H, D), lib.pm_bsc_stats_offset_qdiag(H, D),
+                                 lib.pm_bsc_stats_offset_mus(H, D))
+            # the pass leaves mus = sum E[s] and the multi-cause block of Wq incl. its diagonal; qdiag (the singletons'
+            # share of the diagonal, s_h^2 = s_h) is the difference
+            stats[o_qd:o_mus] = stats[o_mus:o_mus + H] - torch.diagonal(stats[o_wq:o_qd].view(H, H))
+        else:
+            stats.zero_()
+        if done:
+            if done < my_N:
+                r = my_N - done
+                off = lambda t, w=1: ctypes.c_void_p(t.data_ptr() + done * w * t.element_size())
+                self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", off(lp, ldl), ldl, off(lse), ctypes.c_double(lse_cut),
+                           off(cand, Hp), _ptr(tab["masks"]), S, ctypes.byref(P), r, H, D, Hp, off(expect, H), H,
+                           _ptr(stats), st)
+        elif my_N and tab["fast"]:
             self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut),
                        _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,
                        _ptr(stats), st)

@@ -454,6 +454,37 @@ def test_fused_estep_matches_two_kernel_path(dev, D, H, Hp, gamma, N, with_mu):
     np.testing.assert_allclose(out["fused"][2], out["rows16"][2], rtol=1e-12, atol=1e-10)
 
 
+@pytest.mark.parametrize("D,H,Hp,gamma,N", [(1024, 256, 8, 4, 40000), (64, 200, 7, 3, 3000), (25, 10, 5, 3, 333)])
+def test_step_with_fused_mstep_statistics(dev, D, H, Hp, gamma, N):
+    """Inside ``step`` with no data truncation ahead the fused E-step kernel also produces the M-step's per-datapoint
+    statistics (E[s] rows, Wq block, mus, scalars; the ragged last round of a large shard still goes through
+    pm_bsc_mstep_rows16_f64): same new parameters, free energy and statistics buffer as the separate M-step pass."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    rng = np.random.RandomState(N + H)
+    W_gt = rng.normal(size=(D, H))
+    y = (rng.random_sample((N, H)) < 3.0 / H) @ W_gt.T + rng.normal(size=(N, D))
+    params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 3.0 / H, "sigma": 1.05}
+    out = {}
+    for fuse in (True, False):
+        m = BSC_ET(D, H, Hp, gamma)
+        m.fuse_mstats = fuse
+        h = dlog.set_handler(("L", "N_use"), StoreInMemory)
+        try:
+            new = m.step(_An(T=1.1), dict(params), {"y": y})
+        finally:
+            dlog.remove_handler(h)
+        out[fuse] = (new, float(h.tables["L"][0]), int(h.tables["N_use"][0]), m._ws["stats"].cpu().numpy().copy(),
+                     m._ws["expect"].cpu().numpy().copy())
+    a, b = out[True], out[False]
+    assert a[2] == b[2] == N
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-12)
+    np.testing.assert_allclose(a[4], b[4], rtol=1e-10, atol=1e-14)                       # E[s]
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9, atol=1e-9 * np.abs(b[3]).max())    # packed statistics
+    for k in ("W", "pi", "sigma"):
+        np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-8, atol=1e-10)
+
+
 def test_config2_full_shard_against_oracle(dev):
     """BASELINE config 2 at its real size -- D=1024 H=256 H'=8 gamma=4, N = 200 000 on the bench's generator -- through
     the shipped launches (one fused E-step launch of 3125 tiles; with PM_FUSED=0: 196 608 rows of whole GEMM rounds +
