@@ -89,6 +89,21 @@ int pm_spd_inverse_batch_f64(const double *upper, int64_t ldu, int64_t stride_in
                              int64_t batch, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Distributed k-th largest (the data-truncation cut): parallel.allsort(all_denoms)[-N_use], prosper/utils/parallel.py:87-110
+ * with its consumers bsc_et.py:252, mca_et.py:252, dsc_et.py:832.  Radix select over an order-preserving 64-bit key
+ * of the doubles, one digit per round: every rank histograms the digit at bit `shift` (`bits` wide, <= 12) of its
+ * values that agree with the digits decided so far (state[0]); the caller sum-all-reduces the 4096 bins (RCCL) and
+ * pm_kth_scan picks the bin that holds the k-th largest: state[0] |= digit << shift, state[1] = rank inside that bin;
+ * `hist` is cleared.  Rounds (shift, bits) = (52,12) (40,12) (28,12) (16,12) (4,12) (0,4) decide all 64 bits;
+ * pm_kth_value_f64 converts state[0] back: exactly the value a full sort returns.
+ *   state (2 x uint64): [0] digits decided so far (0 before the first round), [1] k, 1-based from the largest.
+ *   hist  (4096 x uint64), zeroed by the caller before the first round.
+ * ------------------------------------------------------------------------------------- */
+int pm_kth_hist_f64(const double *x, int64_t n, const uint64_t *state, int shift, int bits, uint64_t *hist, void *stream);
+int pm_kth_scan(uint64_t *hist, uint64_t *state, int shift, int bits, void *stream);
+int pm_kth_value_f64(const uint64_t *state, double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Binary Sparse Coding (prosper/em/camodels/bsc_et.py)
  * ------------------------------------------------------------------------------------- */
 

@@ -43,6 +43,9 @@ SIGNATURES = {
     "pm_row_wsqnorm_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp, c_dp]),
     "pm_spd_inverse_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp]),
     "pm_spd_inverse_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, c_dp, i64, i64, c_dp, i64, c_dp]),
+    "pm_kth_hist_f64": (C.c_int, [c_dp, i64, c_dp, C.c_int, C.c_int, c_dp, c_dp]),
+    "pm_kth_scan": (C.c_int, [c_dp, c_dp, C.c_int, C.c_int, c_dp]),
+    "pm_kth_value_f64": (C.c_int, [c_dp, c_dp, c_dp]),
     "pm_bsc_select_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp, c_dp]),
     "pm_bsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64,
                                    C.POINTER(EStepParams), i64, i64, i64, c_dp, i64, c_dp, c_dp]),

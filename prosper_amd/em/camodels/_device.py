@@ -461,23 +461,51 @@ class DeviceCAModel(CAModel):
         assert tuple(t.shape) == (N, self.Hprime)
         return t.contiguous()
 
+    KTH_ROUNDS = ((52, 12), (40, 12), (28, 12), (16, 12), (4, 12), (0, 4))     # (shift, bits) of the radix digits
+
     def _kth_largest_global(self, lse, N_use):
-        """sort(all log-evidences)[-N_use] across ranks (bsc_et.py:252 via
-        parallel.allsort).  Shards are padded to equal length for the all-gather."""
+        """sort(all log-evidences over all ranks)[-N_use] (bsc_et.py:252 via parallel.allsort) by distributed radix
+        select (csrc/kth_select.hip): per round one histogram pass over the local shard, ONE all-reduce of 4096 bins
+        (32 KB, instead of gathering 8 N bytes to every rank and sorting them there), a one-workgroup scan; six rounds
+        decide all 64 bits of the order statistic, so the value is exactly the one a full sort returns.  Only the
+        final double reaches the host.  (CPU tensors -- the gloo tests -- walk the same protocol with torch ops.)"""
         comm = self.comm
-        if comm.size > 1:
-            import torch.distributed as dist
-            sizes = comm.allgather(int(lse.shape[0]))
-            n_max = max(sizes)
-            pad = torch.full((n_max,), float("-inf"), dtype=torch.float64, device=lse.device)
-            pad[:lse.shape[0]] = lse
-            parts = [torch.empty_like(pad) for _ in range(comm.size)]
-            dist.all_gather(parts, pad, group=comm._group)
-            pool = torch.cat(parts)
-        else:
-            pool = lse
-        vals = torch.topk(pool, N_use, largest=True, sorted=True).values
-        return float(vals[-1])
+        lse = lse.contiguous()
+        dev = lse.device
+        state = torch.zeros(2, dtype=torch.int64, device=dev)
+        state[1] = int(N_use)
+        hist = torch.zeros(4096, dtype=torch.int64, device=dev)
+        n = int(lse.shape[0])
+        if lse.is_cuda:
+            st = self._stream()
+            for shift, bits in self.KTH_ROUNDS:
+                self._call("kth_hist", "pm_kth_hist_f64", _ptr(lse) if n else None, n, _ptr(state), shift, bits, _ptr(hist), st)
+                comm.allreduce_device(hist)
+                self._call("kth_scan", "pm_kth_scan", _ptr(hist), _ptr(state), shift, bits, st)
+            out = torch.empty(1, dtype=torch.float64, device=dev)
+            self._call("kth_value", "pm_kth_value_f64", _ptr(state), _ptr(out), st)
+            return float(out.item())
+        # host tensors (tests): the same rounds on the same 64-bit keys
+        b = lse.view(torch.int64)
+        key = torch.where(b < 0, ~b, b | torch.iinfo(torch.int64).min)          # order-preserving as UNSIGNED 64-bit
+        ukey = key.numpy().view(np.uint64)
+        prefix, k = np.uint64(0), int(N_use)
+        for shift, bits in self.KTH_ROUNDS:
+            top = shift + bits
+            match = np.ones(n, dtype=bool) if top >= 64 else ((ukey >> np.uint64(top)) == (prefix >> np.uint64(top)))
+            digit = ((ukey[match] >> np.uint64(shift)) & np.uint64((1 << bits) - 1)).astype(np.int64)
+            hist = torch.from_numpy(np.bincount(digit, minlength=4096).astype(np.int64))
+            comm.allreduce_device(hist)
+            h = hist.numpy()
+            above = 0
+            for d in range((1 << bits) - 1, -1, -1):
+                if above + int(h[d]) >= k:
+                    break
+                above += int(h[d])
+            prefix |= np.uint64(d) << np.uint64(shift)
+            k -= above
+        bits64 = (prefix & np.uint64(0x7FFFFFFFFFFFFFFF)) if (prefix >> np.uint64(63)) else ~prefix
+        return float(np.array([bits64], dtype=np.uint64).view(np.float64)[0])
 
     # ------------------------------------------------------------------ inference ("next" row, SURVEY 8f)
     def inference(self, anneal, model_params, test_data, topK=10, logprob=False, adaptive=True,

@@ -116,7 +116,8 @@ class BSC_ET(DeviceCAModel):
         """Device copy of W^T (H,D) and the Gram matrix G = W.W^T for the current W.  The M-step leaves
         its solution on the device (``_seed_params``), so inside an EM loop nothing is uploaded."""
         par = self._par
-        if par.get("ykey") == res["key"] and self._same_W(par, W):
+        if par.get("ykey") == res["key"] and ((self._in_step and par.get("checked") is W) or self._same_W(par, W)):
+            par["checked"] = W       # (inside step() nothing can touch W between select_Hprimes and E_step)
             if par.pop("seeded", False):
                 self._spec_ok = True         # the EM loop fed the M-step's W straight back: keep speculating
             return par
@@ -217,10 +218,7 @@ class BSC_ET(DeviceCAModel):
                 side.wait_stream(cur)
             st = ctypes.c_void_p((side or cur).cuda_stream)
             off = lambda t, w=1: ctypes.c_void_p(t.data_ptr() + main * w * t.element_size()) if t is not None else None
-            A = self._buf("scores_rest", (N - main, H))
-            Yr = res["Y"][main:]
-            self._call("scores_gemm_rest", "pm_gemm_nt_f64", _ptr(Yr), Yr.stride(0), _ptr(par["Wt"]), par["Wt"].stride(0),
-                       _ptr(A), H, N - main, H, Yr.shape[1], st)
+            A = self._rest_scores(res, par, main, st)
             self._call("select_estep_rest", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
                        _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S, self.gamma,
                        Pref, N - main, H, Hp, mode, off(cand, Hp), off(logpj, ldl), ldl, off(lse), st)
@@ -344,8 +342,26 @@ class BSC_ET(DeviceCAModel):
         """Enqueue the scores GEMMs as soon as W is known (select_Hprimes, or speculatively at the end of an
         M-step), so the device is busy while the host walks on to E_step."""
         N = res["Y"].shape[0]
-        if N and self._whole_shard(N) and not self._fused():
+        if N and self._fused():
+            self._rest_scores(res, par, self._fused_rows(N), self._stream())     # the ragged last round's split-K GEMM
+        elif N and self._whole_shard(N):
             self._ensure_scores(res, par)
+
+    def _rest_scores(self, res, par, main, st):
+        """Scores of the rows behind the fused kernel's whole rounds (needs W only: enqueued as soon as W is known,
+        speculatively behind an M-step's download); cached on the parameter record."""
+        N, H = res["Y"].shape[0], self.H
+        if main >= N:
+            return None
+        got = par.get("A_rest")
+        if got is not None and got[0] == main and got[2] == res["key"]:
+            return got[1]
+        A = self._buf("scores_rest", (N - main, H))
+        Yr = res["Y"][main:]
+        self._call("scores_gemm_rest", "pm_gemm_nt_f64", _ptr(Yr), Yr.stride(0), _ptr(par["Wt"]), par["Wt"].stride(0),
+                   _ptr(A), H, N - main, H, Yr.shape[1], st)
+        par["A_rest"] = (main, A, res["key"])
+        return A
 
     def _materialize_candidates(self, ticket):
         """Selection on its own (someone looked at the lazy candidates before E_step ran)."""

@@ -55,9 +55,17 @@ class Comm(object):
     is what every serial script and the single-GPU bench use.
     """
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force_collectives=None):
         self._group = group
         self._timed = None      # [(start event, end event)] of the device all-reduces when timing is on (bench.py)
+        # a one-rank world normally short-cuts every collective; PM_FORCE_COLLECTIVES=1 (or force_collectives=True)
+        # sends them through the process group anyway -- how the one-GPU box exercises the RCCL code path
+        import os
+        self._force = (os.environ.get("PM_FORCE_COLLECTIVES", "0") == "1") if force_collectives is None else bool(force_collectives)
+
+    def _solo(self):
+        """No collective needed: a one-rank world (unless collectives are forced through the process group)."""
+        return self.size == 1 and not (self._force and self._live())
 
     # -- topology ---------------------------------------------------------
     def _live(self):
@@ -86,7 +94,7 @@ class Comm(object):
     def allreduce(self, value, op=SUM):
         """Sum a python scalar or ndarray over ranks (mpi4py's pickled allreduce:
         bsc_et.py:225,258,266,387,417)."""
-        if self.size == 1:
+        if self._solo():
             return value
         arr = np.asarray(value)
         is_int = arr.dtype.kind in "iub"
@@ -106,14 +114,14 @@ class Comm(object):
         return d.cpu().numpy().reshape(work.shape)
 
     def allgather(self, value):
-        if self.size == 1:
+        if self._solo():
             return [value]
         out = [None] * self.size
         dist.all_gather_object(out, value, group=self._group)
         return out
 
     def bcast(self, value, root=0):
-        if self.size == 1:
+        if self._solo():
             return value
         box = [value]
         dist.broadcast_object_list(box, src=root, group=self._group)
@@ -122,7 +130,7 @@ class Comm(object):
     # -- buffer API (upper-case mpi4py) --------------------------------------
     def Allreduce(self, sendbuf, recvbuf, op=SUM):
         send, recv = _buf(sendbuf), _buf(recvbuf)
-        if self.size == 1:
+        if self._solo():
             recv[...] = send
             return
         recv[...] = self._host_allreduce(np.ascontiguousarray(send)).reshape(recv.shape)
@@ -130,7 +138,7 @@ class Comm(object):
     def Allgather(self, sendbuf, recvbuf):
         """Equal-count gather along the leading layout of ``recv`` (parallel.py:107)."""
         send, recv = _buf(sendbuf), _buf(recvbuf)
-        if self.size == 1:
+        if self._solo():
             recv[...] = np.asarray(send).reshape(recv.shape)
             return
         parts = self.allgather(np.ascontiguousarray(send))
@@ -138,12 +146,12 @@ class Comm(object):
 
     def Bcast(self, buf, root=0):
         arr = _buf(buf)
-        if self.size == 1:
+        if self._solo():
             return
         arr[...] = self.bcast(arr if self.rank == root else None, root=root)
 
     def Barrier(self):
-        if self.size > 1:
+        if not self._solo():
             dist.barrier(group=self._group)
 
     # -- device path: the one fused statistics exchange per EM step -------------
@@ -151,7 +159,7 @@ class Comm(object):
         """In-place sum-all-reduce of a device (or CPU) torch tensor.  On GPUs this
         is a single ncclAllReduce over xGMI; replaces the eight MPI calls of
         bsc_et.py:225-417."""
-        if self.size > 1:
+        if not self._solo():
             if self._timed is not None and tensor.is_cuda:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
