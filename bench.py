@@ -368,7 +368,7 @@ def main():
     if rank == 0:
         fused = model._fused()
         dom = "estep_fused" if fused else "scores_gemm"
-        chunk = N if fused else model._launch_rows(N)
+        chunk = model._fused_rows(N) if fused else model._launch_rows(N)     # datapoints the dominant launch covers
         # HBM-side bytes of the dominant kernel: NOT measured in this run -- from the committed rocprofv3 --pmc passes
         # (profiles/summarize_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), per launch
         traffic, traffic_source = None, None

@@ -21,13 +21,17 @@ import json
 import sys
 
 KERNELS = {
+    # (order matters: first match wins)
+    "bsc_estep_fused_kernel<16, 4, true, true>": "estep_fused_mstats",   # E-step + M-step statistics (inside EM steps)
+    "bsc_estep_fused_kernel": "estep_fused",                              # scores GEMM + select + E-step in one launch
     "gemm_nt_f64_dma_kernel<false>": "scores_gemm",
     "gemm_nt_f64_dma_kernel<true>": "scores_gemm_splitk",
     "gemm_tn_f64": "stats_gemm",
     "bsc_select_estep16_kernel": "select_estep",
     "bsc_mstep_rows16_kernel": "mstep_rows",
 }
-FETCH_FACTOR = {"scores_gemm": 2.0, "scores_gemm_splitk": 2.0, "stats_gemm": 2.0, "select_estep": 1.0, "mstep_rows": 2.0}
+FETCH_FACTOR = {"estep_fused": 2.0, "estep_fused_mstats": 2.0,    # reads are the LDS-DMA stream of Y (16 B per lane)
+                "scores_gemm": 2.0, "scores_gemm_splitk": 2.0, "stats_gemm": 2.0, "select_estep": 1.0, "mstep_rows": 2.0}
 
 
 def load(d):
@@ -37,6 +41,7 @@ def load(d):
         for pat, lab in KERNELS.items():
             if pat in r["Kernel_Name"]:
                 agg[(lab, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+                break
     return agg
 
 
@@ -51,8 +56,11 @@ def main():
                                          "write_bytes": w_b, "hbm_bytes": f_b + w_b}
         if lab == "scores_gemm" and f_b + w_b > 1e9:   # the headline launch: all 200000 datapoints of the shard (whole
             res["%s@grid%d" % (lab, grid)]["datapoints_per_launch"] = 200000   # rounds + the fused ragged round)
+        if lab.startswith("estep_fused"):              # one 256-thread workgroup per 64 datapoints
+            res["%s@grid%d" % (lab, grid)]["datapoints_per_launch"] = grid // 256 * 64
     json.dump({"note": "per-launch HBM-side bytes (FETCH_SIZE x per-kernel gfx950 factor, see summarize_pmc.py, "
-                       "+ WRITE_SIZE), rocprofv3 --pmc, separate passes; bench.py --steps 5 --warmup 2 --em-steps 3", "kernels": res}, open(out, "w"), indent=1)
+                       "+ WRITE_SIZE), rocprofv3 --pmc, separate passes; bench.py --steps 5 --warmup 2 --em-steps 3 "
+                       "--prewarm-ms 0", "kernels": res}, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
