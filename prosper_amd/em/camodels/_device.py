@@ -312,6 +312,52 @@ class DeviceCAModel(CAModel):
         W_init = W_mean[:, None] + np.random.normal(scale=sigma_init / 4., size=[D, self.H])
         return {'W': W_init, 'pi': 1. / self.H, 'sigma': sigma_init}
 
+    # ------------------------------------------------------------------ data generation on the device
+    def generate_data(self, model_params, my_N, device=False, seed=None):
+        """``device=False``: the reference's host generator, same NumPy RNG stream (camodels/__init__.py:104-122 and
+        the models' own versions).  ``device=True``: the same distribution drawn on the GPU (Philox streams of a
+        ``torch.Generator``; ``seed`` makes it reproducible) -- the reference's generators are Python loops over
+        datapoints (minutes at the sizes of BASELINE configs 3 / 5); returns ``DeviceArray`` handles."""
+        if not device:
+            return self._generate_data_host(model_params, my_N)
+        return self.generate_data_device(model_params, my_N, seed)
+
+    def _generate_data_host(self, model_params, my_N):
+        return CAModel.generate_data(self, model_params, my_N)
+
+    def _gen(self, seed):
+        g = torch.Generator(device=self.device)
+        if seed is None:
+            g.seed()
+        else:
+            g.manual_seed(int(seed))
+        return g
+
+    def _mix_linear(self, S, W_DH):
+        """y = S . W^T for latent values S (N,H) f64 on the device and W (D,H): the f64 MFMA GEMM of the hot path."""
+        W = torch.from_numpy(np.ascontiguousarray(np.asarray(W_DH, dtype=np.float64))).to(self.device)      # (D,H)
+        y = torch.empty((S.shape[0], W.shape[0]), dtype=torch.float64, device=self.device)
+        if S.shape[0]:
+            self._gemm_nt(S.contiguous(), W, y, "generate_gemm")
+        return y
+
+    def _draw_latents(self, model_params, my_N, g):
+        """Binary latents, P(s_h = 1) = pi (scalar or per latent) -> (N,H) bool on the device."""
+        pi = torch.as_tensor(np.asarray(model_params['pi'], dtype=np.float64)).to(self.device)
+        return torch.rand((my_N, self.H), generator=g, device=self.device, dtype=torch.float64) < pi
+
+    def _superpose(self, model_params, s, g):
+        """Noise-free data for latents ``s`` (N,H) on the device; the linear superposition s . W^T here, models with
+        another combination rule override it."""
+        return self._mix_linear(s.to(torch.float64), model_params['W'])
+
+    def generate_data_device(self, model_params, my_N, seed=None):
+        g = self._gen(seed)
+        s = self._draw_latents(model_params, my_N, g)
+        y = self._superpose(model_params, s, g)
+        y += float(model_params['sigma']) * torch.randn(y.shape, generator=g, device=self.device, dtype=torch.float64)
+        return {'y': DeviceArray(y), 's': DeviceArray(s)}
+
     def invalidate_data(self):
         """Forget the resident shard (call after modifying ``my_data['y']`` in place)."""
         self._data = {}

@@ -102,9 +102,18 @@ class DSC_ET(DeviceCAModel):
         assert model_params['sigma'] >= 0.
         return model_params
 
-    def generate_data(self, model_params, my_N, noise_on=True, gs=None, gp=None):
+    def _draw_latents(self, model_params, my_N, g):
+        """Every latent takes value states[k] with probability pi[k] (dsc_et.py:277-292)."""
+        pi = torch.as_tensor(np.asarray(model_params['pi'], dtype=np.float64)).to(self.device)
+        vals = torch.as_tensor(np.asarray(self.states, dtype=np.float64)).to(self.device)
+        idx = torch.multinomial(pi / pi.sum(), my_N * self.H, replacement=True, generator=g)
+        return vals[idx].view(my_N, self.H)
+
+    def generate_data(self, model_params, my_N, noise_on=True, gs=None, gp=None, device=False, seed=None):
         """Latents drawn per datapoint with ``np.random.choice(states, H, p=pi)``, y = s.W^T (+ noise);
-        RNG stream as upstream (dsc_et.py:238-299)."""
+        RNG stream as upstream (dsc_et.py:238-299).  ``device=True``: drawn on the GPU (DeviceCAModel.generate_data)."""
+        if device:
+            return self.generate_data_device(model_params, my_N, seed)
         D, H, states = self.D, self.H, self.states
         pi = model_params['pi']
         W = model_params['W'].T

@@ -115,8 +115,28 @@ class GSC(DeviceCAModel):
             assert np.all(np.asarray(model_params['sigma_sq']) > 0) or self.sigma_sq_type == 'full'
         return model_params
 
+    def generate_data_device(self, model_params, my_N, seed=None):
+        """Spike-and-slab data on the device: s_h ~ Bernoulli(pi_h) (``<=`` as upstream), z = s * (mu + L n) with
+        L L^T = psi_sq -- the marginal of N(mu, psi_sq) over the active latents is the Gaussian the reference draws for
+        them (gsc_et.py:204-257) -- y = z.W^T + sd * n'.  Kept quirks: with a full noise covariance only its diagonal
+        is used, and a datapoint whose active INDICES sum to 0 (none, or only latent 0) stays all zero."""
+        g = self._gen(seed)
+        dev, H, D = self.device, self.H, self.D
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)).to(dev)
+        pi, mu, psi = t(model_params['pi']), t(model_params['mu']), t(model_params['psi_sq'])
+        s = torch.rand((my_N, H), generator=g, device=dev, dtype=torch.float64) <= pi
+        L = torch.linalg.cholesky(psi)
+        zfull = mu[None, :] + torch.randn((my_N, H), generator=g, device=dev, dtype=torch.float64) @ L.t()
+        live = (s.to(torch.float64) @ torch.arange(H, dtype=torch.float64, device=dev)) != 0
+        z = torch.where(s & live[:, None], zfull, torch.zeros((), dtype=torch.float64, device=dev))
+        sig = np.asarray(model_params['sigma_sq'], dtype=np.float64)
+        sd = t(np.sqrt(np.diagonal(sig)) if sig.ndim == 2 else np.sqrt(sig) * np.ones(D))
+        y = self._mix_linear(z, model_params['W'])
+        y += live[:, None].to(torch.float64) * sd[None, :] * torch.randn((my_N, D), generator=g, device=dev, dtype=torch.float64)
+        return {'y': DeviceArray(y), 's': DeviceArray(s), 'z': DeviceArray(z)}
+
     @tracing.traced
-    def generate_data(self, model_params, my_N):
+    def _generate_data_host(self, model_params, my_N):
         """gsc_et.py:186-202: one ``random(H)`` draw per datapoint, ``p <= pi``."""
         s = np.zeros((my_N, self.H), dtype=bool)
         for n in range(my_N):

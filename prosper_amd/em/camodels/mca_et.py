@@ -54,7 +54,18 @@ class MCA_ET(DeviceCAModel):
         return model_params
 
     @tracing.traced
-    def generate_data(self, model_params, my_N):
+    def _superpose(self, model_params, s, g):
+        """y_d = max(0, max over the active causes of W_dh) (mca_et.py:76-80), in chunks of datapoints."""
+        W = torch.from_numpy(np.ascontiguousarray(np.asarray(model_params['W'], dtype=np.float64))).to(self.device)   # (D,H)
+        y = torch.zeros((s.shape[0], self.D), dtype=torch.float64, device=self.device)
+        neg = torch.full((), float("-inf"), dtype=torch.float64, device=self.device)
+        step = max(1, (1 << 25) // (self.D * self.H))
+        for lo in range(0, s.shape[0], step):
+            blk = s[lo:lo + step]
+            y[lo:lo + step] = torch.where(blk[:, None, :], W[None, :, :], neg).amax(dim=2).clamp_min(0.0)
+        return y
+
+    def _generate_data_host(self, model_params, my_N):
         """Max-rule superposition + Gaussian noise; RNG stream as upstream (mca_et.py:58-85):
         one ``random(H)`` per datapoint, then one ``normal((my_N, D))``.  Does not obey gamma."""
         H, D = self.H, self.D

@@ -54,7 +54,18 @@ class MMCA_ET(MCA_ET):
         W[np.logical_and(W <= 0., W > -tol)] = -tol
         return model_params
 
-    def generate_data(self, model_params, my_N):
+    def _superpose(self, model_params, s, g):
+        """Per dimension the active cause of largest magnitude, first one on ties (mmca_et.py:66-93), in chunks."""
+        Wt = torch.from_numpy(np.ascontiguousarray(np.asarray(model_params['W'], dtype=np.float64).T)).to(self.device)  # (H,D)
+        y = torch.zeros((s.shape[0], self.D), dtype=torch.float64, device=self.device)
+        step = max(1, (1 << 25) // (self.D * self.H))
+        for lo in range(0, s.shape[0], step):
+            t0 = s[lo:lo + step].to(torch.float64)[:, :, None] * Wt[None, :, :]          # (n,H,D)
+            idx = t0.abs().argmax(dim=1, keepdim=True)
+            y[lo:lo + step] = torch.gather(t0, 1, idx)[:, 0, :]
+        return y
+
+    def _generate_data_host(self, model_params, my_N):
         """CAModel.generate_data (camodels/__init__.py:104-122): one ``random((my_N, H))`` draw for the
         latents, then ``generate_from_hidden``."""
         p = np.random.random(size=(my_N, self.H))

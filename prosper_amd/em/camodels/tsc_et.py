@@ -64,7 +64,13 @@ class TSC_ET(DeviceCAModel):
         }
         self._tab = None
 
-    def generate_data(self, model_params, my_N):
+    def _draw_latents(self, model_params, my_N, g):
+        pi = float(model_params['pi'])
+        p = torch.rand((my_N, self.H), generator=g, device=self.device, dtype=torch.float64)
+        one = torch.ones((), dtype=torch.float64, device=self.device)
+        return torch.where(p < pi / 2, -one, torch.where(p < pi, one, 0 * one))
+
+    def _generate_data_host(self, model_params, my_N):
         """s_h = -1 / +1 / 0 for p < pi/2, p < pi, else; y = s.W^T + noise.  RNG stream as upstream
         (tsc_et.py:215-275): ``random(H)`` per datapoint, then one ``normal((my_N, D))``."""
         pi = model_params['pi']
