@@ -772,6 +772,10 @@ extern "C" int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int
             const int64_t max_split = (K / DK) / 8;        // at least 8 K-steps per workgroup
             if (nsplit > max_split) nsplit = max_split;
             if (nsplit < 1 || rest_tiles * 10 >= (int64_t)slots * 7) nsplit = 1;
+            // many K-slices of many tiles: the slices' f64 atomics (16 K per workgroup) outweigh the shorter K-loops
+            // (3392 x 256 x 1024: 9 slices 67 us, 4 slices 56 us, 2 slices 77 us)
+            if (nsplit > 4 && rest_tiles >= 32) nsplit = nsplit / 2 > 4 ? nsplit / 2 : 4;
+            if (const char *e = getenv("PM_GEMM_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;   // (experiments)
         }
         if (main_panels > 0 && rest_rows > 0 && nsplit > 1 && fuse_remainder()) {
             launch_nt_dma_fused(A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)main_panels, (int)nsplit, s);

@@ -390,6 +390,23 @@ class DeviceCAModel(CAModel):
         ev.record(torch.cuda.current_stream(self.device))
         return (dev, view) if keep else dev
 
+    def _download_async(self, flat, slot):
+        """Device -> pinned host copy on the copy stream, behind what the main stream holds NOW.  Returns (NumPy view,
+        event to ``synchronize()`` on before reading it)."""
+        n = flat.numel()
+        buf = self._pin_out.get(slot)
+        if buf is None or buf.numel() < n:
+            buf = self._pin_out[slot] = torch.empty(n, dtype=torch.float64).pin_memory()
+        cs = getattr(self, "_copy_stream", None)
+        if cs is None:
+            cs = self._copy_stream = torch.cuda.Stream(device=self.device)
+        cs.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(cs):
+            buf[:n].copy_(flat, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        return buf[:n].numpy(), ev
+
     def _download(self, flat, slot="default", then=None):
         """Device -> pinned host copy + wait; returns a NumPy view valid until the next call
         with the same ``slot``.  ``then()`` runs after the copy is enqueued and before the wait:

@@ -52,6 +52,11 @@ class BSC_ET(DeviceCAModel):
         self.overlap_inverse = os.environ.get('PM_OVERLAP_INVERSE', '0') == '1'   # Wq inverse beside the statistics GEMM (no gain, see M_step)
         self._inv_stream = None
         self._in_step = False
+        self._spec_estep = None  # next step's E-step, launched by the M-step (_speculate_estep)
+        self._anneal_sig = None  # annealing point of the previous step() (speculate only on a flat schedule)
+        self._flat_schedule = False
+        self.spec_hits = 0
+        self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
         self.fuse_mstats = os.environ.get('PM_FUSE_MSTATS', '1') == '1'   # M-step row statistics inside the fused E-step
         self.use_fused = os.environ.get('PM_FUSED', '1') == '1'   # scores GEMM + select + E-step as ONE kernel (bsc_fused.hip)
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
@@ -388,6 +393,9 @@ class BSC_ET(DeviceCAModel):
     def step(self, anneal, model_params, my_data):
         """CAModel.step (camodels/__init__.py:163-193); E_step knows that M_step follows with the same arguments."""
         self._in_step = True
+        sig = (anneal['T'], bool(anneal['anneal_prior']), anneal['Ncut_factor'], anneal['partial'])
+        self._flat_schedule = (sig == self._anneal_sig)      # same annealing point as the previous step
+        self._anneal_sig = sig
         try:
             return DeviceCAModel.step(self, anneal, model_params, my_data)
         finally:
@@ -434,6 +442,55 @@ class BSC_ET(DeviceCAModel):
             self._gemm_nt(res["Y"], mu_d, ymu)
         return wmu, ymu
 
+    def _estep_outputs(self, N):
+        """Fresh result tensors (handed to the caller; the caching allocator recycles last step's).  Rows padded to whole
+        128-byte lines: unaligned rows made every row store straddle two lines (WRITE_SIZE 1.8x the bytes); the caller
+        sees the (N, K) view."""
+        K = 1 + self.H + self.no_states
+        Kpad = (K + 15) // 16 * 16
+        logpj = torch.empty((N, Kpad), dtype=torch.float64, device=self.device)[:, :K]
+        return logpj, torch.empty((N,), dtype=torch.float64, device=self.device)
+
+    def _launch_estep(self, res, par, P, cand, wmu, ymu, want_ms):
+        """Enqueue the fast-path E-step for parameter record ``par``: selection too when ``cand`` is None.  Returns the
+        DeviceArray of log-joints with ``.lse``, ``.cand`` and (``want_ms``, fused kernel only) ``.mstats``."""
+        N, D = res["Y"].shape
+        H, Hp = self.H, self.Hprime
+        logpj, lse = self._estep_outputs(N)
+        mode = 2
+        if cand is None:      # selection + log-joints in one pass
+            cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
+            mode = 3
+        mstats, rows = None, 0
+        if N and want_ms and self.fuse_mstats and self._fused() and Hp <= 8 and 'mu' not in self.to_learn:
+            n_stats = _lib.load().pm_bsc_stats_len(H, D)
+            stats = self._buf("stats", (n_stats,))
+            stats.zero_()
+            mstats = (self._buf("expect", (N, H)), stats)
+        if N:
+            rows = self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats)
+        out = DeviceArray(logpj)
+        out.lse = lse
+        out.cand = cand
+        if mstats is not None:
+            out.mstats = {"expect": mstats[0], "stats": mstats[1], "rows": rows, "res": res, "cand": cand,
+                          "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm)}
+        return out
+
+    def _speculate_estep(self, res, par, anneal, pies, sigma):
+        """Called by the M-step as soon as its scalar statistics are on the host, while the device still solves for
+        W: the NEXT step's E-step for (W_new on the device, pi_new, sigma_new, the same annealing point), enqueued
+        behind the solve.  The device then walks from one EM step into the next without waiting for the host's
+        turnaround (download, bookkeeping, the next step's Python); E_step adopts the pass iff it is called with exactly
+        these parameters, else the pass is dropped (wasted device time, never a wrong result)."""
+        if not (np.isfinite(pies) and np.isfinite(sigma) and 0.0 < pies < 1.0 and sigma > 0.0):
+            return
+        P = self._estep_params(anneal, pies, sigma, np.zeros(1))
+        want_ms = anneal['Ncut_factor'] <= 0.0
+        out = self._launch_estep(res, par, P, None, None, None, want_ms)
+        self._spec_estep = {"par": par, "res": res, "want_ms": want_ms, "out": out,
+                            "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm)}
+
     @tracing.traced
     def E_step(self, anneal, model_params, my_data):
         """Log-pseudo-joints of the truncated state set -> ``{'logpj': (N, 1+H+S)}``
@@ -450,49 +507,32 @@ class BSC_ET(DeviceCAModel):
         W = np.asarray(model_params['W'])
         mu64 = np.asarray(mu, dtype=np.float64)
         P = self._estep_params(anneal, model_params['pi'], model_params['sigma'], mu64)
-        K = 1 + H + S
-        # results are handed to the caller: fresh tensors (the caching allocator recycles last step's)
-        # rows padded to whole 128-byte lines: unaligned rows made every row store straddle two lines
-        # (WRITE_SIZE 1.8x the bytes); the caller sees the (N, K) view
-        Kpad = (K + 15) // 16 * 16
-        logpj = torch.empty((N, Kpad), dtype=torch.float64, device=self.device)[:, :K]
-        lse = torch.empty((N,), dtype=torch.float64, device=self.device)
         tracing.tracepoint("E_step:iterating")
         cobj = my_data['candidates']
         if tab["fast"]:
             par = self._params_dev(W, res)
-            wmu, ymu = self._mu_terms(par, res, mu64)
             fuse = (isinstance(cobj, LazyCandidates) and cobj.pending and cobj._model is self
                     and cobj._ticket["res"] is res and cobj._ticket["par"] is par)
-            if fuse:      # selection + log-joints in one pass
-                cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
-                mode = 3
-            else:
-                cand = self._device_candidates(cobj, N)
-                mode = 2
             # inside CAModel.step with no data truncation ahead the M-step's per-datapoint statistics are produced by
             # the same pass (fused kernel): posterior weights from the exponentials the log-sum-exp evaluates anyway, no
             # second pass over the 665 MB of log-joints
-            mstats, rows = None, 0
-            if (N and self._in_step and self.fuse_mstats and anneal['Ncut_factor'] <= 0.0 and self._fused()
-                    and Hp <= 8 and 'mu' not in self.to_learn):
-                n_stats = _lib.load().pm_bsc_stats_len(H, D)
-                stats = self._buf("stats", (n_stats,))
-                stats.zero_()
-                mstats = (self._buf("expect", (N, H)), stats)
-            if N:
-                rows = self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats)
+            want_ms = self._in_step and anneal['Ncut_factor'] <= 0.0
+            sp, self._spec_estep = self._spec_estep, None
+            if (sp is not None and fuse and sp["par"] is par and sp["res"] is res and sp["want_ms"] == want_ms
+                    and sp["P"] == (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm) and not np.any(mu64)):
+                out = sp["out"]          # the previous M-step has already launched exactly this pass (_speculate_estep)
+                self.spec_hits += 1
+            else:
+                wmu, ymu = self._mu_terms(par, res, mu64)
+                cand = None if fuse else self._device_candidates(cobj, N)
+                out = self._launch_estep(res, par, P, cand, wmu, ymu, want_ms)
             if fuse:
-                cobj._ticket["cand"] = cand
-            out = DeviceArray(logpj)
-            out.lse = lse
-            if mstats is not None:
-                out.mstats = {"expect": mstats[0], "stats": mstats[1], "rows": rows, "res": res, "cand": cand,
-                              "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm)}
+                cobj._ticket["cand"] = out.cand
             return {'logpj': out}
         par = self._scores(model_params, res)
         cand = self._device_candidates(cobj, N)
         wmu, ymu = self._mu_terms(par, res, mu64)
+        logpj, lse = self._estep_outputs(N)
         if N:
             self._call("estep", "pm_bsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]),
                       _ptr(wmu), _ptr(ymu), _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P),
@@ -636,9 +676,19 @@ class BSC_ET(DeviceCAModel):
             cur.wait_stream(side)
         else:
             comm.allreduce_device(packed)
-        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res, pre)
+        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res, pre, anneal)
 
-    def _finalize(self, packed, model_params, A_pi_gamma, E_pi_gamma, res=None, pre=None):
+    def _scalar_updates(self, host, pies, sigma, E_pi_gamma):
+        """pi and sigma updates (bsc_et.py:393-420) from the head of the downloaded statistics, ``host`` =
+        [mus (H) | sum of squared residuals, sum of free energies, N_use, -]."""
+        H, D = self.H, self.D
+        mus_h = host[:H].copy()
+        my_sigma, Fs, N_use = float(host[H]), float(host[H + 1]), int(round(host[H + 2]))
+        pi_new = E_pi_gamma * float(mus_h.sum()) / H / N_use if 'pi' in self.to_learn else pies
+        sigma_new = np.sqrt(my_sigma / D / N_use) if 'sigma' in self.to_learn else sigma
+        return mus_h, my_sigma, Fs, N_use, pi_new, sigma_new
+
+    def _finalize(self, packed, model_params, A_pi_gamma, E_pi_gamma, res=None, pre=None, anneal=None):
         """Parameter updates from the all-reduced statistics (bsc_et.py:264-267, 369-438).
         Everything is enqueued on the device first (Wq assembly, Cholesky solve, reductions) and
         fetched with ONE device->host copy, so an EM step synchronises with the GPU exactly once.
@@ -660,6 +710,14 @@ class BSC_ET(DeviceCAModel):
 
         parts = [packed[o_mus:o_sc + 4]]          # [mus (H) | 4 scalars], contiguous in the packed buffer; summed on the host
         Wq = rhs = seed = None
+        # A plain EM loop on a flat annealing schedule: the scalar statistics travel to the host AHEAD of the W solve, so
+        # pi_new / sigma_new are known while the device still inverts Wq, and the next step's E-step is enqueued right
+        # behind the solve (_speculate_estep) -- the device never waits for the host between two EM steps.
+        early = None
+        if (packed.is_cuda and res is not None and anneal is not None and learn_W and not learn_mu and not np.any(mu)
+                and self._in_step and self._flat_schedule and self._spec_ok and self.speculate and self.speculate_estep
+                and self._state_tables()["fast"] and self._fused()):
+            early = self._download_async(parts[0], slot="mstep_early")
         if learn_W:
             tracing.tracepoint("M_step:update W")
             rhs = Wp
@@ -678,14 +736,17 @@ class BSC_ET(DeviceCAModel):
             if learn_W:
                 self._par = {}                                  # its host snapshot may live in the buffer reused now
                 self._a0 = None
-            then = (lambda: spec.append(self._seed_params(res, seed[0], seed[1], self._spec_ok and self.speculate))) if seed else None
-            host = self._download(flat, slot="mstep", then=then)
+            def then():
+                spec.append(self._seed_params(res, seed[0], seed[1], self._spec_ok and self.speculate))
+                if early is not None:
+                    early[1].synchronize()
+                    _, _, _, _, pi_e, sigma_e = self._scalar_updates(early[0], pies, sigma, E_pi_gamma)
+                    self._speculate_estep(res, spec[0], anneal, pi_e, sigma_e)
+            host = self._download(flat, slot="mstep", then=then if seed else None)
         else:
             host = flat.numpy()
 
-        mus_h = host[:H].copy()
-        my_sigma, Fs, N_use = float(host[H]), float(host[H + 1]), int(round(host[H + 2]))
-        mus_sum = float(mus_h.sum())
+        mus_h, my_sigma, Fs, N_use, pi_new, sigma_new = self._scalar_updates(host, pies, sigma, E_pi_gamma)
         dlog.append('N', N_use)
         L = H * np.log(1 - pies) - 0.5 * D * np.log(2 * _PI * sigma ** 2) - np.log(A_pi_gamma)
         L += Fs / N_use
@@ -710,15 +771,8 @@ class BSC_ET(DeviceCAModel):
 
         if 'pi' in self.to_learn:
             tracing.tracepoint("M_step:update pi")
-            pi_new = E_pi_gamma * mus_sum / H / N_use
-        else:
-            pi_new = pies
-
         if 'sigma' in self.to_learn:
             tracing.tracepoint("M_step:update sigma")
-            sigma_new = np.sqrt(my_sigma / D / N_use)
-        else:
-            sigma_new = sigma
 
         if learn_mu:
             tracing.tracepoint("M_step:update mu")

@@ -485,6 +485,49 @@ def test_step_with_fused_mstep_statistics(dev, D, H, Hp, gamma, N):
         np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("D,H,Hp,gamma,N", [(256, 64, 6, 3, 40000), (25, 10, 5, 3, 333)])
+def test_em_loop_with_speculative_estep(dev, D, H, Hp, gamma, N):
+    """On a flat annealing schedule the M-step launches the next step's E-step itself, as soon as pi_new / sigma_new
+    are on the host and while the device still solves for W (``_speculate_estep``); ``E_step`` adopts that pass when it
+    is called with exactly those parameters and drops it otherwise (here: a temperature change, a data-truncation
+    step, a caller that edits pi).  Same parameters and free energies as the loop that never speculates."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    rng = np.random.RandomState(N + H)
+    W_gt = rng.normal(size=(D, H))
+    y = (rng.random_sample((N, H)) < 2.0 / H) @ W_gt.T + rng.normal(size=(N, D))
+    params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 2.0 / H, "sigma": 1.05}
+    #        T, Ncut_factor, edit pi before the step
+    plan = [(1.2, 0.0, False), (1.0, 0.0, False), (1.0, 0.0, False), (1.0, 0.0, False), (1.0, 0.0, False),
+            (1.0, 0.0, True), (1.0, 0.0, False), (1.0, 0.0, False), (1.1, 0.0, False), (1.1, 0.0, False),
+            (1.1, 0.0, False), (1.1, 0.9, False), (1.1, 0.9, False), (1.1, 0.9, False)]
+    out = {}
+    for spec in (True, False):
+        m = BSC_ET(D, H, Hp, gamma)
+        m.speculate_estep = spec
+        h = dlog.set_handler(("L", "N_use"), StoreInMemory)
+        p, trace = dict(params), []
+        try:
+            for T, ncut, edit in plan:
+                if edit:
+                    p = dict(p, pi=p["pi"] * 1.01)
+                p = m.step(_An(T=T, Ncut_factor=ncut), p, {"y": y})
+                trace.append((np.array(p["W"]), float(p["pi"]), float(p["sigma"])))
+        finally:
+            dlog.remove_handler(h)
+        out[spec] = (trace, np.array(h.tables["L"]), np.array(h.tables["N_use"]), m.spec_hits)
+    a, b = out[True], out[False]
+    assert b[3] == 0
+    if BSC_ET(D, H, Hp, gamma)._fused():
+        # adopted: steps 4, 5 (flat since step 2/3), 8 (flat again after the edit), 11 (flat T=1.1), 14 (flat Ncut)
+        assert a[3] >= 4, a[3]
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-11)
+    for (Wa, pa, sa), (Wb, pb, sb) in zip(a[0], b[0]):
+        np.testing.assert_allclose(Wa, Wb, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose([pa, sa], [pb, sb], rtol=1e-10)
+
+
 def test_config2_full_shard_against_oracle(dev):
     """BASELINE config 2 at its real size -- D=1024 H=256 H'=8 gamma=4, N = 200 000 on the bench's generator -- through
     the shipped launches (one fused E-step launch of 3125 tiles; with PM_FUSED=0: 196 608 rows of whole GEMM rounds +
