@@ -80,6 +80,19 @@ int pm_row_wsqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const
 int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, double *full,
                        double *inv, int64_t ldo, double *pivots, void *stream);
 
+/* The same inverse, warm-started: `prev_inv` (n x n, leading dimension n) is the inverse of a nearby matrix -- the
+ * previous EM step's second moments.  Three Newton-Schulz steps X <- X + X (I - A X) on the matrix cores refine it into
+ * `inv` (symmetrised); the Gauss-Jordan sweep is launched behind them and returns at once when the start residual
+ * ||I - A prev_inv||_F was below 0.1 (then ||I - A inv|| < 1e-8 and pivots = {1, 1}), else it overwrites `inv` with
+ * the exact inverse as pm_spd_inverse_f64 would.  The decision is taken on the device from sums formed in a fixed
+ * order.  `work`: pm_spd_inverse_warm_work_len(n) doubles; `full` (required, leading dimension ldo = n) receives the
+ * assembled matrix.  Same role as pm_spd_inverse_f64 (np.linalg.lstsq(Wq, Wp), bsc_et.py:380); callers follow it with
+ * a step of iterative refinement of the solve. */
+int64_t pm_spd_inverse_warm_work_len(int64_t n);
+int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, const double *prev_inv,
+                            int64_t ldp, double *work, double *full, double *inv, int64_t ldo, double *pivots,
+                            void *stream);
+
 /* `batch` independent inverses in one launch, one workgroup each (they run on different CUs at once): matrix b is
  * read at upper + b*stride_in, written at inv (and full, if given) + b*stride_out; diag_add (optional) holds n
  * doubles and pivots 2 doubles per matrix.  GSC's M-step needs (sum xpt_szsz)^-1 and (sum xpt_ss + eps I)^-1

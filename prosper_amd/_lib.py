@@ -42,6 +42,8 @@ SIGNATURES = {
     "pm_col_moments_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp, c_dp]),
     "pm_row_wsqnorm_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp, c_dp]),
     "pm_spd_inverse_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp]),
+    "pm_spd_inverse_warm_work_len": (i64, [i64]),
+    "pm_spd_inverse_warm_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp]),
     "pm_spd_inverse_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, c_dp, i64, i64, c_dp, i64, c_dp]),
     "pm_kth_hist_f64": (C.c_int, [c_dp, i64, c_dp, C.c_int, C.c_int, c_dp, c_dp]),
     "pm_kth_scan": (C.c_int, [c_dp, c_dp, C.c_int, C.c_int, c_dp]),

@@ -29,7 +29,35 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const double *__restr
                                                             const double *__restrict__ diag_add, int n,
                                                             double *__restrict__ full, double *__restrict__ inv,
                                                             int64_t ldo, double *__restrict__ pivots,
-                                                            int64_t stride_in, int64_t stride_out) {
+                                                            int64_t stride_in, int64_t stride_out,
+                                                            const double *__restrict__ guard, int guard_n, double guard_tol2,
+                                                            const double *__restrict__ refined) {
+    // warm start (pm_spd_inverse_warm_f64): `inv` already holds a Newton-Schulz refinement of the previous inverse
+    // that started from a residual ||I - A X0||_F^2 = sum(guard[0 .. guard_n)) -- summed in a fixed order, so every
+    // rank holding the same matrices decides alike.  Small enough: nothing to do.
+    if (guard) {
+        __shared__ double s_g[NMAX];
+        __shared__ int s_skip;
+        if (threadIdx.x < NMAX) s_g[threadIdx.x] = (int)threadIdx.x < guard_n ? guard[threadIdx.x] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double r2 = 0.0;
+            for (int q = 0; q < NMAX; ++q) r2 += s_g[q];
+            s_skip = (r2 < guard_tol2) ? 1 : 0;           // (NaN compares false: the sweep runs)
+            if (s_skip && pivots) {
+                pivots[0] = 1.0;
+                pivots[1] = 1.0;
+            }
+        }
+        __syncthreads();
+        if (s_skip) {       // inv = (X + X^T) / 2: the next step's start and the solve both treat it as symmetric
+            for (int e = threadIdx.x; e < n * n; e += 1024) {
+                const int i = e / n, j = e - i * n;
+                inv[(int64_t)i * ldo + j] = 0.5 * (refined[(int64_t)i * n + j] + refined[(int64_t)j * n + i]);
+            }
+            return;
+        }
+    }
     // one workgroup per matrix of a batch (blockIdx.x): independent inverses run on different CUs at once
     upper += blockIdx.x * stride_in;
     inv += blockIdx.x * stride_out;
@@ -118,6 +146,138 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const double *__restr
     }
 }
 
+// ---- warm start: Newton-Schulz refinement of the previous EM step's inverse ---------------------------------------
+// The sweep above is a chain of n dependent pivots (publish -> barrier -> read -> divide -> update, 1.1 us each: 0.3 ms
+// at n = 256 however the work is spread -- ablations in scratch/spd_bench.hip: its LDS reads cost 10 us, the division
+// 18 us, the f64 VALU work 80 us).  Between two EM steps the second-moment matrix moves little, so the previous step's
+// inverse X0 is an excellent approximate inverse: with R0 = I - A X0,
+//     X_{k+1} = X_k + X_k R_k,    R_{k+1} = R_k^2        =>   ||R_3|| <= ||R_0||^8
+// and every step is two small GEMMs on the matrix cores of 64 CUs (v_mfma_f64_16x16x4_f64 straight from L2), no
+// dependent chain.  The sweep kernel still runs behind it and returns at once if ||R_0||_F < 0.1 (guard above); the
+// caller's solve adds a step of iterative refinement against A itself (DeviceCAModel._apply_inverse).
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int NS_T = 16;      // a workgroup owns one 16 x 16 output tile; its four wavefronts split K
+
+// acc0 += sum_k Pt0[k][i0 + .] * Q[k][j0 + .] (and acc1 with Pt1, if given) over this wavefront's quarter of k
+// (row-major, leading dimension ld; rows / columns >= n count as 0).  Fragment maps of v_mfma_f64_16x16x4_f64:
+// A lane l = (i = l & 15, k = l >> 4), B lane l = (k = l >> 4, j = l & 15).  All of a wavefront's operands are
+// requested before the first MFMA: the kernel is one L2 round trip long, not one per K-step.
+template <bool TWO, bool UPPER>
+__device__ __forceinline__ void ns_tile(const double *__restrict__ Pt0, const double *__restrict__ Pt1,
+                                        const double *__restrict__ Q, const double *__restrict__ diag_add, int i0, int j0,
+                                        int n, int64_t ldp, int64_t ld, int lane, int wave, d4 &acc0, d4 &acc1) {
+    constexpr int KSTEPS = NMAX / 4 / 4;                       // 16 K-steps of 4 per wavefront
+    const int i = i0 + (lane & 15), j = j0 + (lane & 15), kq = lane >> 4;
+    const int ic = min(i, n - 1), jc = min(j, n - 1);
+    double a0[KSTEPS], a1[KSTEPS], b[KSTEPS];
+#pragma unroll
+    for (int u = 0; u < KSTEPS; ++u) {
+        const int k = (wave * KSTEPS + u) * 4 + kq;
+        const int kc = min(k, n - 1);
+        if (UPPER) {      // Pt0 is the upper triangle of a symmetric matrix (+ diag_add on the diagonal)
+            a0[u] = Pt0[(int64_t)min(kc, ic) * ldp + max(kc, ic)];
+            if (kc == ic && diag_add) a0[u] += diag_add[ic];
+        } else {
+            a0[u] = Pt0[(int64_t)kc * ldp + ic];
+        }
+        if (TWO) a1[u] = Pt1[(int64_t)kc * ld + ic];
+        b[u] = Q[(int64_t)kc * ld + jc];
+        const bool kv = k < n;
+        a0[u] = (kv && i < n) ? a0[u] : 0.0;
+        if (TWO) a1[u] = (kv && i < n) ? a1[u] : 0.0;
+        b[u] = (kv && j < n) ? b[u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < KSTEPS; ++u) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b[u], acc0, 0, 0, 0);
+        if (TWO) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b[u], acc1, 0, 0, 0);
+    }
+}
+
+// the four wavefronts' partial tiles summed in a fixed order; every wavefront returns the total
+__device__ __forceinline__ d4 ns_reduce(d4 acc, double (*s_t)[4][64], int lane, int wave) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_t[wave][r][lane] = acc[r];
+    __syncthreads();
+    d4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = ((s_t[0][r][lane] + s_t[1][r][lane]) + s_t[2][r][lane]) + s_t[3][r][lane];
+    return t;
+}
+
+// A = U + U^T - diag(U) + diag(diag_add) -> full;  R = I - A X (A, X symmetric),  L = R^T,
+// partial[tile] = sum of the tile's R^2
+__global__ __launch_bounds__(256) void ns_residual_kernel(const double *__restrict__ upper, int64_t ldu,
+                                                          const double *__restrict__ diag_add,
+                                                          const double *__restrict__ X, int n, int64_t ld,
+                                                          double *__restrict__ full, double *__restrict__ R,
+                                                          double *__restrict__ L, double *__restrict__ partial) {
+    __shared__ double s_t[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.y * NS_T, j0 = blockIdx.x * NS_T;
+    {   // this tile of the assembled matrix: one element per thread
+        const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
+        if (i < n && j < n) {
+            double v = (i <= j) ? upper[(int64_t)i * ldu + j] : upper[(int64_t)j * ldu + i];
+            if (i == j && diag_add) v += diag_add[i];
+            full[(int64_t)i * ld + j] = v;
+        }
+    }
+    d4 t = {0, 0, 0, 0}, unused = {0, 0, 0, 0};
+    ns_tile<false, true>(upper, nullptr, X, diag_add, i0, j0, n, ldu, ld, lane, wave, t, unused);
+    t = ns_reduce(t, s_t, lane, wave);
+    if (wave != 0) return;
+    const int j = j0 + (lane & 15);
+    double sq = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + (lane >> 4) + 4 * r;
+        if (i < n && j < n) {
+            const double v = (i == j ? 1.0 : 0.0) - t[r];
+            R[(int64_t)i * ld + j] = v;
+            L[(int64_t)j * ld + i] = v;
+            sq += v * v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    if (lane == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+}
+
+// Xn = X + X R,  Rn = R R (= L^T R),  Ln = Rn^T  (LAST: only Xn)
+template <bool LAST>
+__global__ __launch_bounds__(256) void ns_step_kernel(const double *__restrict__ X, const double *__restrict__ R,
+                                                      const double *__restrict__ L, int n, int64_t ld,
+                                                      double *__restrict__ Xn, double *__restrict__ Rn,
+                                                      double *__restrict__ Ln) {
+    __shared__ double s_t[2][4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.y * NS_T, j0 = blockIdx.x * NS_T;
+    d4 xr = {0, 0, 0, 0}, rr = {0, 0, 0, 0};
+    ns_tile<!LAST, false>(X, L, R, nullptr, i0, j0, n, ld, ld, lane, wave, xr, rr);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s_t[0][wave][r][lane] = xr[r];
+        if (!LAST) s_t[1][wave][r][lane] = rr[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int j = j0 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + (lane >> 4) + 4 * r;
+        if (i < n && j < n) {
+            const double dx = ((s_t[0][0][r][lane] + s_t[0][1][r][lane]) + s_t[0][2][r][lane]) + s_t[0][3][r][lane];
+            Xn[(int64_t)i * ld + j] = X[(int64_t)i * ld + j] + dx;
+            if (!LAST) {
+                const double v = ((s_t[1][0][r][lane] + s_t[1][1][r][lane]) + s_t[1][2][r][lane]) + s_t[1][3][r][lane];
+                Rn[(int64_t)i * ld + j] = v;
+                Ln[(int64_t)j * ld + i] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, double *full,
@@ -125,7 +285,40 @@ extern "C" int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double
     if (!upper || !inv || n <= 0 || ldu < n || ldo < n) return PM_EINVAL;
     if (n > NMAX) return PM_ERANGE;
     hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), upper, ldu,
-                       diag_add, (int)n, full, inv, ldo, pivots, (int64_t)0, (int64_t)0);
+                       diag_add, (int)n, full, inv, ldo, pivots, (int64_t)0, (int64_t)0, (const double *)nullptr, 0, 0.0,
+                       (const double *)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int64_t pm_spd_inverse_warm_work_len(int64_t n) {
+    const int64_t tiles = (n + NS_T - 1) / NS_T;
+    return n > 0 ? 6 * n * n + tiles * tiles : 0;
+}
+
+extern "C" int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n,
+                                       const double *prev_inv, int64_t ldp, double *work, double *full, double *inv,
+                                       int64_t ldo, double *pivots, void *stream) {
+    if (!upper || !inv || !prev_inv || !work || !full || !pivots || n <= 0 || ldu < n || ldo < n || ldp < n) return PM_EINVAL;
+    if (n > NMAX) return PM_ERANGE;
+    if (ldp != n || ldo != n) return PM_EINVAL;          // the work matrices share one leading dimension with them
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int tiles = (int)((n + NS_T - 1) / NS_T);
+    const int64_t nn = n * n;
+    // work: two (X, R, L) triples, then the residual's per-tile sums of squares
+    double *X[2] = {work, work + 3 * nn}, *R[2] = {work + nn, work + 4 * nn}, *L[2] = {work + 2 * nn, work + 5 * nn};
+    double *partial = work + 6 * nn;
+    const dim3 grid((unsigned)tiles, (unsigned)tiles);
+    hipLaunchKernelGGL(ns_residual_kernel, grid, dim3(256), 0, s, upper, ldu, diag_add, prev_inv, (int)n, n, full, R[0], L[0],
+                       partial);
+    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, prev_inv, (const double *)R[0], (const double *)L[0],
+                       (int)n, n, X[1], R[1], L[1]);
+    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
+                       (const double *)L[1], (int)n, n, X[0], R[0], L[0]);
+    hipLaunchKernelGGL(ns_step_kernel<true>, grid, dim3(256), 0, s, (const double *)X[0], (const double *)R[0],
+                       (const double *)L[0], (int)n, n, X[1], (double *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), 0, s, upper, ldu, diag_add, (int)n, (double *)nullptr, inv,
+                       ldo, pivots, (int64_t)0, (int64_t)0, (const double *)partial, tiles * tiles, 0.01,
+                       (const double *)X[1]);
     return (int)hipGetLastError();
 }
 
@@ -138,6 +331,7 @@ extern "C" int pm_spd_inverse_batch_f64(const double *upper, int64_t ldu, int64_
         return PM_EINVAL;
     if (n > NMAX || batch > 65535) return PM_ERANGE;
     hipLaunchKernelGGL(spd_inverse_kernel, dim3((unsigned)batch), dim3(1024), 0, static_cast<hipStream_t>(stream), upper,
-                       ldu, diag_add, (int)n, full, inv, ldo, pivots, stride_in, stride_out);
+                       ldu, diag_add, (int)n, full, inv, ldo, pivots, stride_in, stride_out, (const double *)nullptr, 0, 0.0,
+                       (const double *)nullptr);
     return (int)hipGetLastError();
 }

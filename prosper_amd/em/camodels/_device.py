@@ -464,13 +464,24 @@ class DeviceCAModel(CAModel):
         """Wq = triu(Wq_u) + triu(Wq_u, 1)^T + diag(qdiag) and its inverse, enqueued on the CURRENT stream:
         ``(Wq, Winv, pivots)`` -- one-workgroup SPD inverse (csrc/spd_inverse.hip) instead of ~40 rocSOLVER launches.
         Only for device tensors with H <= 256.  It needs nothing but the (all-reduced) second moments, so a caller can
-        run it on a side stream beside the statistics GEMM, which needs nothing but E[s] (BSC_ET.M_step)."""
+        run it on a side stream beside the statistics GEMM, which needs nothing but E[s] (BSC_ET.M_step).
+        From the second call on the previous call's inverse warm-starts a Newton-Schulz refinement
+        (pm_spd_inverse_warm_f64: ~40 us instead of the sweep's 0.3 ms when the matrix has moved little -- an EM loop;
+        the device falls back to the sweep by itself otherwise).  ``PM_WARM_INVERSE=0`` disables it."""
         H = qdiag.shape[0]
         Wq = torch.empty((H, H), dtype=torch.float64, device=Wq_u.device)
         Winv = torch.empty((H, H), dtype=torch.float64, device=Wq_u.device)
         piv = torch.empty(2, dtype=torch.float64, device=Wq_u.device)
-        self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
-                   H, _ptr(piv), self._stream())
+        prev = getattr(self, "_winv_prev", None)
+        if (prev is not None and tuple(prev.shape) == (H, H) and prev.device == Wq_u.device
+                and os.environ.get("PM_WARM_INVERSE", "1") == "1"):
+            work = self._buf("spd_warm_work", (int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
+            self._call("spd_inverse", "pm_spd_inverse_warm_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(prev), H, _ptr(work),
+                       _ptr(Wq), _ptr(Winv), H, _ptr(piv), self._stream())
+        else:
+            self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
+                       H, _ptr(piv), self._stream())
+        self._winv_prev = Winv
         return Wq, Winv, piv
 
     def _apply_inverse(self, Wq, Winv, rhs):

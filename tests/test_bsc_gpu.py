@@ -138,6 +138,46 @@ def test_spd_inverse_batch(dev):
         _lib.call("pm_spd_inverse_batch_f64", _p(inp), n, n, None, n, None, _p(inv), n, n * n, _p(piv), 2, _stream())
 
 
+@pytest.mark.parametrize("n", [1, 7, 33, 100, 256])
+@pytest.mark.parametrize("rel", [0.0, 1e-3, 2e-2, 0.5])
+def test_spd_inverse_warm(dev, n, rel):
+    """pm_spd_inverse_warm_f64: the inverse of a nearby matrix (relative distance ``rel``) refined by Newton-Schulz
+    steps on the matrix cores; the device itself falls back to the exact sweep when the start residual is too large
+    (rel = 0.5) -- either way the result is an inverse to ~1e-8 relative or better (the caller's solve refines once more against
+    A), symmetric, and the pivots say "usable"."""
+    from prosper_amd import _lib
+    rs = np.random.RandomState(n)
+    B = rs.normal(size=(n, 3 * n + 5))
+    A = B @ B.T + np.diag(rs.uniform(0.1, 1.0, size=n))
+    B0 = B + rel * rs.normal(size=B.shape)
+    A0 = B0 @ B0.T + np.diag(np.diag(A) - np.diag(B @ B.T))
+    dadd = rs.uniform(0.1, 1.0, size=n)
+    Af = A + np.diag(dadd)
+    prev = torch.from_numpy(np.linalg.inv(A0 + np.diag(dadd))).to(dev)
+    prev = 0.5 * (prev + prev.t())
+    u = torch.from_numpy(np.triu(A) + np.tril(rs.normal(size=(n, n)), -1)).to(dev)
+    da = torch.from_numpy(dadd).to(dev)
+    work = torch.zeros(int(_lib.load().pm_spd_inverse_warm_work_len(n)), dtype=torch.float64, device=dev)
+    full = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    inv = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    piv = torch.zeros(2, dtype=torch.float64, device=dev)
+    _lib.call("pm_spd_inverse_warm_f64", _p(u), n, _p(da), n, _p(prev), n, _p(work), _p(full), _p(inv), n, _p(piv), _stream())
+    np.testing.assert_array_equal(full.cpu().numpy(), Af)
+    got, pv = inv.cpu().numpy(), piv.cpu().numpy()
+    np.testing.assert_array_equal(got, got.T)
+    r0 = np.linalg.norm(np.eye(n) - Af @ prev.cpu().numpy())
+    if r0 < 0.0999:
+        np.testing.assert_array_equal(pv, [1.0, 1.0])                 # refined, sweep skipped
+        assert np.linalg.norm(np.eye(n) - Af @ got) < max(2.0 * r0 ** 8, 1e-11 * np.linalg.cond(Af))
+    elif r0 > 0.1001:
+        d2 = np.diag(np.linalg.cholesky(Af)) ** 2                     # the exact sweep ran
+        np.testing.assert_allclose(pv, [d2.min(), d2.max()], rtol=1e-9)
+        ref = np.linalg.inv(Af)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-14 * np.linalg.cond(Af) * np.abs(ref).max())
+    assert rel != 0.5 or r0 > 0.1001 or n == 1
+    assert rel > 1e-3 or r0 < 0.0999
+
+
 def test_spd_inverse_rejects_large(dev):
     from prosper_amd import _lib
     t = torch.zeros((300, 300), dtype=torch.float64, device=dev)
