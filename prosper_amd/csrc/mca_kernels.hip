@@ -26,6 +26,10 @@
 // documented part of the statistics buffer; the per-XCD copies of [Wp | Wq] follow it (pm_common.h)
 __host__ __device__ static inline int64_t mca_stats_base(int64_t H, int64_t D) { return 3 * H * D + H + PM_MCA_NSCALARS; }
 
+#ifndef PM_MCA_ABL
+#define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates
+#endif
+
 namespace {
 
 __device__ __forceinline__ void wave_sync_lds() {
@@ -102,12 +106,15 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
                                  int Hp, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse1,
                                  double *__restrict__ lseb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [ per wave: wr (Hp * DS) | e (S) ] ; DS = 64 * DPL
+    // [ power tables (PM_POWTAB_LEN) | per wave: wr (Hp * DS) | e (S) ] ; DS = 64 * DPL
     constexpr int DS = 64 * DPL;
     const int waves = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *s_wr = reinterpret_cast<double *>(smem) + (size_t)wave * (Hp * DS + S);
+    double *s_tab = reinterpret_cast<double *>(smem);
+    double *s_wr = s_tab + PM_POWTAB_LEN + (size_t)wave * (Hp * DS + S);
     double *s_e = s_wr + Hp * DS;
+    pm_load_powtab(s_tab, tid, blockDim.x);
+    __syncthreads();
 
     const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
     const int64_t nwaves = (int64_t)gridDim.x * waves;
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
 #pragma unroll
             for (int i = 0; i < DPL; ++i) {
                 // MMCA: T may be negative or 0 (mmca_et.py:191: sign(t) exp(log|t| / rho)); for MCA T > 0
-                const double wbar = copysign(pm_pow_pos(fabs(T[i]), P.inv_rho), T[i]);
+                const double aT = fabs(T[i]);
+                const double wbar = (aT > 0.0) ? copysign(pm_pow_tab(aT, P.inv_rho, s_tab), T[i]) : 0.0;
                 const double df = wbar - y[i];
                 part = fma(df, df, part);
             }
@@ -233,11 +241,13 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                                        double *__restrict__ lse1, double *__restrict__ lseb,
                                        double *__restrict__ q1, int64_t ldq, double *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [ q1sum (H) | red (4 * waves) | per wave: wr (HP*DS) [wm (HP*DS)] e (S) ]
+    // [ power tables (PM_POWTAB_LEN) | q1sum (H) | red (4 * waves) | per wave: wr (HP*DS) [wm (HP*DS)] e (S) ]
     constexpr int DS = 64 * DPL;
     const int waves = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *s_q1sum = reinterpret_cast<double *>(smem);
+    double *s_tab = reinterpret_cast<double *>(smem);
+    double *s_q1sum = s_tab + PM_POWTAB_LEN;
+    pm_load_powtab(s_tab, tid, blockDim.x);
     double *s_red = s_q1sum + H;
     const size_t per_wave = (size_t)(SIGNED ? 2 : 1) * HP * DS + S;
     double *s_wr = s_red + 4 * waves + (size_t)wave * per_wave;
@@ -278,61 +288,102 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
         for (int j = 0; j < HP; ++j)
 #pragma unroll
             for (int i = 0; i < DPL; ++i) V[j][i] = 0.0;
-        double M = -INFINITY;   // running maximum of beta * f_s over the multi-cause states seen so far
+        // M: reference level of beta * f_s for the stored terms.  It follows the running maximum LAZILY -- only when a
+        // state exceeds it by more than 50 (terms up to e^50 relative to it are stored meanwhile: nothing overflows, and
+        // a stored term is still never smaller than its final value) -- so the rescaling branch is all but never taken
+        // after the first state.
+        double M = -INFINITY;
 
-        unsigned mask_next = S > 0 ? masks[0] : 0u;
-        for (int s = 0; s < S; ++s) {
-            // wave-uniform; the next state's mask is requested now so that its (vector-memory) latency is covered
-            // by this state's powers instead of stalling the top of the next trip
-            const unsigned mask = mask_next;
-            mask_next = masks[s + 1 < S ? s + 1 : s];
-            double T[DPL], wbar[DPL];   // wbar holds r = |T|^(1/rho - 1)
+        // Two-stage software pipeline over the states.  Stage A (state s + 1): T = sum of the state's W^rho rows, one
+        // power per element, the lane's share of the squared error.  Stage B (state s): wave reduction of that error,
+        // beta * f_s, its weight e^(beta f_s - M), the V updates.  Each stage is a long dependent chain (a 36-deep power;
+        // a 6-step DPP reduction feeding a 14-deep exponential), and two wavefronts per SIMD (183 VGPRs, 17 KB of LDS
+        // each) cannot hide either: 5100 cycles per state for ~300 instructions.  A(s + 1) does not depend on B(s), so
+        // both sit in ONE straight-line block and the scheduler interleaves them; the V update is predicated with 0/1
+        // factors instead of per-candidate branches for the same reason.
+        double wbP[DPL], partP = 0.0;      // state s: |T|^(1/rho - 1) (0 / +inf for T = 0, see below), squared error
+        unsigned maskP = S > 0 ? (unsigned)__builtin_amdgcn_readfirstlane((int)masks[0]) : 0u;      // (scalar registers)
+        unsigned mask_load = S > 0 ? masks[S > 1 ? 1 : 0] : 0u;
+        {
+            double T[DPL];
 #pragma unroll
             for (int i = 0; i < DPL; ++i) T[i] = 0.0;
 #pragma unroll
             for (int j = 0; j < HP; ++j)
-                if ((mask >> j) & 1u) {
+                if ((maskP >> j) & 1u) {
 #pragma unroll
                     for (int i = 0; i < DPL; ++i) T[i] += s_wr[j * DS + lane + 64 * i];
                 }
-            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const double aT = fabs(T[i]);
+                const double r = (PM_MCA_ABL == 2) ? aT * 0.37 : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab);
+                const double df = copysign((aT > 0.0) ? aT * r : 0.0, T[i]) - y[i];
+                partP = fma(df, df, partP);
+                wbP[i] = (aT > 0.0) ? r : (SIGNED ? INFINITY : 0.0);
+            }
+        }
+        for (int s = 0; s < S; ++s) {
+            // wave-uniform masks; the one after next is requested now (vector-memory latency under this trip's work)
+            const unsigned maskN = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_load);
+            mask_load = masks[s + 2 < S ? s + 2 : S - 1];
+            // ---- stage A, state s + 1 (the last trip computes a dummy) ----
+            double T[DPL], wbN[DPL], partN = 0.0;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < HP; ++j)
+                if ((maskN >> j) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) T[i] += s_wr[j * DS + lane + 64 * i];
+                }
 #pragma unroll
             for (int i = 0; i < DPL; ++i) {
                 // ONE power per element: r = |T|^(1/rho - 1) gives |Wbar| = |T| r here and Wbar / T = r for the
-                // M-step weights below (no division).  Padding dimensions have T = 0: Wbar = 0.
+                // M-step weights (no division).  Padding dimensions have T = 0: Wbar = 0, never scattered.
                 const double aT = fabs(T[i]);
-                wbar[i] = pm_pow_pos(aT, P.inv_rho - 1.0);
-                const double wb = (aT > 0.0) ? aT * wbar[i] : 0.0;
-                const double df = copysign(wb, T[i]) - y[i];
-                part = fma(df, df, part);
+                const double r = (PM_MCA_ABL == 2) ? aT * 0.37 : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab);
+                const double df = copysign((aT > 0.0) ? aT * r : 0.0, T[i]) - y[i];
+                partN = fma(df, df, partN);
+                wbN[i] = (aT > 0.0) ? r : (SIGNED ? INFINITY : 0.0);
             }
-            part = pm_wave_sum_dpp(part);                               // wave-uniform
+            // ---- stage B, state s ----
+            const double part = pm_wave_sum_dpp(partP);                 // wave-uniform
             if (lane == 0) s_e[s] = part;
-            const double bf = P.beta * (P.pil_bar * (double)__builtin_popcount(mask) + P.pre1 * part);
-            if (bf > M) {                                               // uniform branch; rare after the first states
+            const double bf = P.beta * (P.pil_bar * (double)__builtin_popcount(maskP) + P.pre1 * part);
+            double w = pm_exp_tab(bf - M, s_tab);                       // (meaningless if the branch below is taken)
+            if (bf > M + 50.0) {                                        // uniform; the first state, then hardly ever
                 const double sc = exp(M - bf);
 #pragma unroll
                 for (int j = 0; j < HP; ++j)
 #pragma unroll
                     for (int i = 0; i < DPL; ++i) V[j][i] *= sc;
                 M = bf;
+                w = 1.0;
             }
-            const double w = exp(bf - M);
-            double v[DPL];
+            if (!SIGNED) {
+                double v[DPL];
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const double aT = fabs(T[i]);
-                // padding dimensions have T = 0: contribute nothing (never scattered)
-                if (!SIGNED) v[i] = (aT > 0.0) ? w * wbar[i] : 0.0;
-                else v[i] = (aT > 0.0) ? w * wbar[i] : INFINITY;
-            }
+                for (int i = 0; i < DPL; ++i) v[i] = w * wbP[i];
 #pragma unroll
-            for (int j = 0; j < HP; ++j)
-                if ((mask >> j) & 1u) {
+                for (int j = 0; j < HP; ++j) {
+                    const double sel = (((maskP >> j) & 1u) && (PM_MCA_ABL != 3 || w == 1.2345e-300)) ? 1.0 : 0.0;   // uniform
 #pragma unroll
-                    for (int i = 0; i < DPL; ++i)
-                        V[j][i] += SIGNED ? fmin(w, v[i] * s_wm[j * DS + lane + 64 * i]) : v[i];
+                    for (int i = 0; i < DPL; ++i) V[j][i] = fma(sel, v[i], V[j][i]);
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < HP; ++j)
+                    if ((maskP >> j) & 1u) {
+#pragma unroll
+                        for (int i = 0; i < DPL; ++i)   // T = 0: w * inf = inf (w > 0) or NaN (w = 0); fmin returns w
+                            V[j][i] += fmin(w, w * wbP[i] * s_wm[j * DS + lane + 64 * i]);
+                    }
+            }
+            partP = partN;
+            maskP = maskN;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) wbP[i] = wbN[i];
         }
         wave_sync_lds();
 
@@ -421,7 +472,7 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                         const int d = lane + 64 * i;
                         if (d < D) {
                             const double aid = SIGNED ? V[j][i] * g : V[j][i] * g * Wrm1[base + d];
-                            if (aid != 0.0) {
+                            if (aid != 0.0 && (PM_MCA_ABL != 1 || aid == 1.2345e-300)) {
                                 pm_atomic_add(Wp + base + d, aid * y[i]);
                                 pm_atomic_add(Wq + base + d, aid);
                             }
@@ -472,11 +523,13 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
     // tables and of Wp / Wq.  The singleton weights and the scalar statistics belong to the slab d0 == 0.
     // HP = register-tile height (Hp rounded up to 4 / 8 / 12); state masks only use bits < Hp
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [ q1sum (H) | red (4 * waves) | per wave: wr (HP * DS) ]
+    // [ power tables (PM_POWTAB_LEN) | q1sum (H) | red (4 * waves) | per wave: wr (HP * DS) ]
     constexpr int DS = 64 * DPL;
     const int waves = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *s_q1sum = reinterpret_cast<double *>(smem);
+    double *s_tab = reinterpret_cast<double *>(smem);
+    double *s_q1sum = s_tab + PM_POWTAB_LEN;
+    pm_load_powtab(s_tab, tid, blockDim.x);
     double *s_red = s_q1sum + H;
     double *s_wr = s_red + 4 * waves + (size_t)wave * ((SIGNED ? 2 : 1) * HP * DS);
     double *s_wm = s_wr + HP * DS;   // SIGNED only: |W|^(rho-1)[cand]
@@ -587,12 +640,12 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
 #pragma unroll
                 for (int i = 0; i < DPL; ++i) {
                     if (!SIGNED) {
-                        v[i] = q * pm_pow_pos(T[i], P.inv_rho - 1.0);  // q_s * Wbar_sd / T_sd = q_s T^(1/rho - 1)
+                        v[i] = (T[i] > 0.0) ? q * pm_pow_tab(T[i], P.inv_rho - 1.0, s_tab) : 0.0;  // q_s Wbar_sd / T_sd = q_s T^(1/rho - 1); padding: T = 0
                     } else {
                         // q_s min(1, (|W_jd| / |Wbar_sd|)^(rho-1)), (.)^(rho-1) = |W_jd|^(rho-1) |Wbar_sd| / |t_sd|;
                         // t = 0 gives Wbar = 0 and the factor 1 (mmca_et.py:316-324: max(-inf - Wl, 0) = 0)
                         const double aT = fabs(T[i]);
-                        v[i] = (aT > 0.0) ? q * pm_pow_pos(aT, P.inv_rho - 1.0) : INFINITY;
+                        v[i] = (aT > 0.0) ? q * pm_pow_tab(aT, P.inv_rho - 1.0, s_tab) : INFINITY;
                     }
                 }
 #pragma unroll
@@ -704,8 +757,9 @@ extern "C" int pm_mca_estep_f64(const double *scores, int64_t lds, const double 
     const int dpl = D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : D <= 512 ? 8 : 16;
     const size_t per_wave = sizeof(double) * ((size_t)Hprime * 64 * dpl + S);
     if (per_wave > 150 * 1024) return PM_ERANGE;
-    const int waves = pick_waves(per_wave, 0);
-    const size_t shmem = per_wave * waves;
+    const size_t shared = sizeof(double) * PM_POWTAB_LEN;
+    const int waves = pick_waves(per_wave, shared);
+    const size_t shmem = shared + per_wave * waves;
     dim3 grid((unsigned)grid_waves(N, waves)), block(64 * waves);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PM_LAUNCH(V)                                                                                            \
@@ -769,7 +823,7 @@ extern "C" int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
         const int Dl = (int)((D - d0) < slab ? (D - d0) : slab);
         const int dpl = Dl <= 64 ? 1 : Dl <= 128 ? 2 : Dl <= 256 ? 4 : 8;
         const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl) * (sgn ? 2 : 1);
-        const size_t shared = sizeof(double) * (H + 16);
+        const size_t shared = sizeof(double) * (PM_POWTAB_LEN + H + 16);
         const int waves = pick_waves(per_wave, shared);
         const size_t shmem = shared + per_wave * waves;
         if (shmem > 150 * 1024) return PM_ERANGE;
@@ -832,7 +886,7 @@ extern "C" int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const 
     if ((int64_t)dpl * hp_tile > 48) return PM_ERANGE;  // V[HP][DPL] register tile
     const bool sgn = params_host->signed_w != 0.0;
     const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl * (sgn ? 2 : 1) + S);
-    const size_t shared = sizeof(double) * (H + 16);
+    const size_t shared = sizeof(double) * (PM_POWTAB_LEN + H + 16);
     const int waves = pick_waves(per_wave, shared);
     const size_t shmem = shared + per_wave * waves;
     if (shmem > 150 * 1024) return PM_ERANGE;

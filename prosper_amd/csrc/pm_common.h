@@ -143,6 +143,74 @@ __device__ __forceinline__ double pm_pow_pos(double x, double c) {
     return x == 0.0 ? 0.0 : res;
 }
 
+// x^c for NORMAL x > 0 with |c log2 x| < 1000, table-driven (pm_powtab.h, generated by gen_powtab.py): 36 VALU slots
+// and two LDS lookups instead of pm_pow_pos's ~80 slots (its ten- and thirteen-term series plus seven quarter-rate
+// conversions); the MCA row kernels spend half their time in this function (S * D powers per datapoint).
+//   log2 x = e + L_i + log2(1 + d),  d = m r_i - 1, |d| < 2^-8  (i = top 7 mantissa bits, r_i ~ 1/m_i in 24 bits,
+//            L_i = -log2 r_i), degree-6 polynomial; carried as a double-double (s, t)
+//   2^y    = 2^N E_j 2^f,  y = N + j/128 + f, |f| <= 2^-8, degree-5 polynomial; 2^N by an exponent-field add
+// Relative error <= 2.3e-16 against a 200-bit reference over x in [e^-30, e^30], c in {1/rho, 1/rho - 1} (the series
+// version reaches 2e-15 there: its log is a single double).  x = 0 returns a finite value the callers discard.
+// `tab`: the workgroup's LDS copy of pm_powtab_dev (pm_load_powtab).
+#include "pm_powtab.h"
+__device__ const double pm_powtab_dev[PM_POWTAB_LEN] = {PM_POWTAB_VALUES};
+
+__device__ __forceinline__ void pm_load_powtab(double *s_tab, int tid, int nthreads) {
+    for (int i = tid; i < PM_POWTAB_LEN; i += nthreads) s_tab[i] = pm_powtab_dev[i];
+}
+
+__device__ __forceinline__ double pm_pow_tab(double x, double c, const double *tab) {
+    typedef double pm_d2 __attribute__((ext_vector_type(2)));
+    const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
+    const unsigned idx = (hi >> 13) & 127u;
+    const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), (int)lo);       // [1, 2)
+    const pm_d2 rl = reinterpret_cast<const pm_d2 *>(tab)[idx];
+    // e = biased exponent - 1023 as a double without v_cvt: (2^52 + 2^31 + (e ^ 2^31)) - (2^52 + 2^31)
+    const double e = __hiloint2double(0x43300000, (int)(((hi >> 20) - 1023u) ^ 0x80000000u)) - 4503601774854144.0;
+    const double d = fma(m, rl.x, -1.0);
+    double p = PM_POW_A6;
+    p = fma(p, d, PM_POW_A5);
+    p = fma(p, d, PM_POW_A4);
+    p = fma(p, d, PM_POW_A3);
+    p = fma(p, d, PM_POW_A2);
+    p = fma(p, d, PM_POW_A1);
+    const double s = e + rl.y;                          // |e| >= 1 > L_i or e == 0: (e - s) + L_i is the exact error
+    const double t = fma(d, p, (e - s) + rl.y);
+    const double yh = c * s;
+    const double yl = fma(c, t, fma(c, s, -yh));
+    const double sh = fma(yh, 128.0, 6755399441055744.0);          // 1.5 * 2^52: the integer lands in the low word
+    const int k = __double2loint(sh);
+    const double f = fma(sh - 6755399441055744.0, -0.0078125, yh) + yl;
+    double q = PM_POW_B5;
+    q = fma(q, f, PM_POW_B4);
+    q = fma(q, f, PM_POW_B3);
+    q = fma(q, f, PM_POW_B2);
+    q = fma(q, f, PM_POW_B1);
+    const double E = tab[256 + (k & 127)];
+    const double r = fma(E, f * q, E);
+    return __hiloint2double(__double2hiint(r) + ((k >> 7) << 20), __double2loint(r));
+}
+
+// e^x for x <= ~700 from the same tables: x = k ln2/128 + r (two-part ln2/128, |r| <= ln2/256), e^r by a degree-5
+// polynomial, 2^(k/128) = 2^N E_j.  Arguments below -708 return ~1e-308 (callers only scale by it).  14 VALU slots and one
+// LDS lookup; relative error <= 2.3e-16.
+__device__ __forceinline__ double pm_exp_tab(double x, const double *tab) {
+    x = x < -708.0 ? -708.0 : x;
+    const double sh = fma(x, 184.6649652337873, 6755399441055744.0);       // 128 / ln 2
+    const int k = __double2loint(sh);
+    const double kf = sh - 6755399441055744.0;
+    double r = fma(kf, -0.00541521234663378, x);                            // ln2/128, high part (32 significant bits)
+    r = fma(kf, -1.4907929134926466e-12, r);                                // ... low part
+    double q = 1.0 / 120.0;
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    const double E = tab[256 + (k & 127)];
+    const double v = fma(E, r * q, E);
+    return __hiloint2double(__double2hiint(v) + ((k >> 7) << 20), __double2loint(v));
+}
+
 // Packed BSC statistics buffer: [ Wp (H*D) | Wq (H*H) | qdiag (H) | mus (H) | scalars ]
 __host__ __device__ inline int64_t pm_bsc_stats_offset_wq_dev(int64_t H, int64_t D) { return H * D; }
 __host__ __device__ inline int64_t pm_bsc_stats_offset_qdiag_dev(int64_t H, int64_t D) { return H * D + H * H; }
