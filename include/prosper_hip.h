@@ -93,6 +93,14 @@ int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag
                             int64_t ldp, double *work, double *full, double *inv, int64_t ldo, double *pivots,
                             void *stream);
 
+/* `batch` warm-started inverses at once (every kernel of pm_spd_inverse_warm_f64 gets a batch dimension): matrix b is
+ * read at upper + b*stride_in (diag_add + b*n), its previous inverse at prev_inv + b*stride_prev (dense n x n), its
+ * result written at inv + b*stride_out (dense n x n), pivots 2 doubles per matrix; `work`: batch *
+ * pm_spd_inverse_warm_work_len(n) doubles.  GSC's M-step: (sum xpt_szsz)^-1 and (sum xpt_ss + eps I)^-1. */
+int pm_spd_inverse_warm_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
+                                  const double *prev_inv, int64_t stride_prev, double *work, double *inv,
+                                  int64_t stride_out, double *pivots, int64_t batch, void *stream);
+
 /* `batch` independent inverses in one launch, one workgroup each (they run on different CUs at once): matrix b is
  * read at upper + b*stride_in, written at inv (and full, if given) + b*stride_out; diag_add (optional) holds n
  * doubles and pivots 2 doubles per matrix.  GSC's M-step needs (sum xpt_szsz)^-1 and (sum xpt_ss + eps I)^-1
@@ -377,6 +385,17 @@ int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma);
  * whole buffer once; the documented entries accumulate across calls as before. */
 int64_t pm_gsc_stats_len(int64_t H);
 
+/* The H- and H x H-sized tail of GSC's M-step for scalar sigma_sq (gsc_et.py:640-713) and the tables of the next
+ * E-step, on the device (one workgroup): pi clip, mu, psi_sq (with (sum_ss + eps I)^-1 from pm_spd_inverse_batch_f64),
+ * sigma_sq = (sum |y|^2 - trace(xsz_xsz . gram)) / N / D + eps, gram = W_new^T W_new.  `old` / `params`:
+ * [pi (H) | mu (H) | psi_sq (H*H) | sigma_sq (1)]; `learn` bits 1 pi, 2 mu, 4 psi_sq, 8 sigma_sq (others copied from `old`).
+ * `tables`: 9 x H doubles -- the eight rows pm_gsc_estep_f64 takes and a ninth holding 1 / sigma_sq, which that
+ * function reads when it is called with sigma_sq == 0. */
+int pm_gsc_mstep_finish_f64(const double *xs_xsz, const double *xsz_xsz, const double *sum_ss, const double *sum_zz,
+                            const double *ss_inv, const double *sum_s, const double *sum_sz, const double *sum_yy,
+                            const double *gram, const double *old, double N, int64_t D, int64_t H, int learn,
+                            double *params, double *tables, void *stream);
+
 /* select_Hprimes + E_step of GSC in one pass (gsc_et.py:721-809, 401-580, 260-398):
  *   scores (N,H) = Y.W;  gram = W^T.W (H,H);  psi_sq (H,H);
  *   tables (8*H): per-latent constants [c0 | c1 | gm | il | kl | ilam | mu | lpi] with
@@ -384,6 +403,8 @@ int64_t pm_gsc_stats_len(int64_t H);
  *     gm = G_hh mu, il = 1/(lam s2^2), kl = 1/(lam s2), ilam = 1/lam, lpi = log(pi/(1-pi))
  *   do_select != 0: candidates = the Hprime best component scores, sorted by latent index,
  *     written to `cand`; otherwise `cand` (sorted) is an input.
+ *   sigma_sq == 0: `tables` has a ninth row whose first entry is 1/sigma_sq (left on the device by
+ *     pm_gsc_mstep_finish_f64).
  * Outputs: xpt_s, xpt_sz (N,H) and the sums over datapoints accumulated into `stats`
  * (zeroed by the caller).  The (N,H,H) moments of the reference are never materialised. */
 int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pm_spd_inverse_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp]),
     "pm_spd_inverse_warm_work_len": (i64, [i64]),
     "pm_spd_inverse_warm_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp]),
+    "pm_spd_inverse_warm_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp]),
     "pm_spd_inverse_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, c_dp, i64, i64, c_dp, i64, c_dp]),
     "pm_kth_hist_f64": (C.c_int, [c_dp, i64, c_dp, C.c_int, C.c_int, c_dp, c_dp]),
     "pm_kth_scan": (C.c_int, [c_dp, c_dp, C.c_int, C.c_int, c_dp]),
@@ -87,6 +88,7 @@ SIGNATURES = {
                                         i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
     "pm_gsc_supported": (C.c_int, [i64, i64, i64]),
     "pm_gsc_stats_len": (i64, [i64]),
+    "pm_gsc_mstep_finish_f64": (C.c_int, [c_dp] * 10 + [C.c_double, i64, i64, C.c_int, c_dp, c_dp, c_dp]),
     "pm_gsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
                                    i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp]),
 }

@@ -135,11 +135,13 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                                                          const double *__restrict__ psi,
                                                          const double *__restrict__ ynorm2, GscTables T,
                                                          const uint16_t *__restrict__ masks, int S, double beta,
-                                                         double inv_s2, int64_t N, int H, int Hp, int do_select,
+                                                         double inv_s2_host, int64_t N, int H, int Hp, int do_select,
                                                          int32_t *__restrict__ cand, double *__restrict__ xpt_s,
                                                          double *__restrict__ xpt_sz, int64_t ldx,
                                                          double *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // 1 / sigma^2 from the host, or (0 there) from the ninth table row an M-step on the device has left
+    const double inv_s2 = (inv_s2_host != 0.0) ? inv_s2_host : T.c0[8 * (int64_t)H];
     // [ 8 tables (H) | per datapoint: ac (16) Gc Pc ass aszsz as (16) asz (16) | state masks (S x u16) ]
     double *s_tab = reinterpret_cast<double *>(smem);
     double *s_c0 = s_tab, *s_c1 = s_tab + H, *s_gm = s_tab + 2 * H, *s_il = s_tab + 3 * H, *s_kl = s_tab + 4 * H;
@@ -523,6 +525,96 @@ extern "C" int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma) {
     return gsc_shmem(H, Hprime, S) <= 64 * 1024 ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The H- and H x H-sized tail of the M-step (gsc_et.py:640-713, scalar sigma_sq) and the tables of the NEXT E-step, in
+// one workgroup: with them on the device the next E-step is launched before the host has seen this step's result.
+//   pi   = clip(sum_s / N, 5e-5, 1 - 5e-5)                                   (gsc_et.py:640-646)
+//   mu   = sum_sz / (sum_s + DBL_EPSILON)                                    (:654)
+//   psi  = (mu mu^T o sum_ss + sum_zz - 2 mu[:,None] o xs_xsz) o (sum_ss + eps I)^-1 + eps I     (:660-675)
+//   s2   = (sum |y|^2 - trace(xsz_xsz . W^T W)) / N / D + eps                (:703-713)
+//   tables: c0, 2 mu / s2, G_hh mu, 1 / (lam s2^2), 1 / (lam s2), 1 / lam, mu, logit(pi), [1 / s2]   (GscTables)
+// A parameter that is not learned is taken from `old`.  Every sum is formed in a fixed order.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(1024) void gsc_mstep_finish_kernel(
+    const double *__restrict__ xs_xsz, const double *__restrict__ xsz_xsz, const double *__restrict__ sum_ss,
+    const double *__restrict__ sum_zz, const double *__restrict__ ss_inv, const double *__restrict__ sum_s,
+    const double *__restrict__ sum_sz, const double *__restrict__ sum_yy, const double *__restrict__ gram,
+    const double *__restrict__ old, double N, double D, int H, int learn, double *__restrict__ params,
+    double *__restrict__ tables) {
+    __shared__ double s_mu[256], s_psid[256], s_red[1024];
+    __shared__ double s_s2;
+    const double eps = 1e-5;
+    const int tid = threadIdx.x;
+    const double *old_pi = old, *old_mu = old + H, *old_psi = old + 2 * H, *old_s2 = old + 2 * H + (int64_t)H * H;
+    double *p_pi = params, *p_mu = params + H, *p_psi = params + 2 * H, *p_s2 = params + 2 * H + (int64_t)H * H;
+    if (tid < H) {
+        double pi = old_pi[tid];
+        if (learn & 1) {
+            pi = sum_s[tid] / N;
+            pi = pi <= 5e-5 ? 5e-5 : pi;
+            pi = pi >= 1.0 - 5e-5 ? 1.0 - 5e-5 : pi;
+        }
+        p_pi[tid] = pi;
+        const double mu = (learn & 2) ? sum_sz[tid] / (sum_s[tid] + 2.220446049250313e-16) : old_mu[tid];
+        p_mu[tid] = mu;
+        s_mu[tid] = mu;
+    }
+    __syncthreads();
+    double tr = 0.0;
+    for (int e = tid; e < H * H; e += 1024) {
+        const int i = e / H, j = e - i * H;
+        double v = old_psi[e];
+        if (learn & 4) {
+            v = (s_mu[i] * s_mu[j] * sum_ss[e] + sum_zz[e] - 2.0 * (s_mu[i] * xs_xsz[e])) * ss_inv[e];
+            if (i == j) v += eps;
+        }
+        p_psi[e] = v;
+        if (i == j) s_psid[i] = v;
+        tr += xsz_xsz[e] * gram[(int64_t)j * H + i];
+    }
+    s_red[tid] = tr;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) s_red[tid] += s_red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double s2 = (learn & 8) ? (sum_yy[0] - s_red[0]) / N / D + eps : old_s2[0];
+        p_s2[0] = s2;
+        s_s2 = s2;
+    }
+    __syncthreads();
+    if (tid < H) {
+        const double s2 = s_s2, mu = s_mu[tid], psid = s_psid[tid], gd = gram[(int64_t)tid * H + tid], pi = p_pi[tid];
+        const double lam = gd / s2 + 1.0 / psid;
+        tables[tid] = -(log(psid) + log(lam)) - mu * mu * gd / s2;
+        tables[H + tid] = 2.0 * mu / s2;
+        tables[2 * H + tid] = gd * mu;
+        tables[3 * H + tid] = 1.0 / (lam * s2 * s2);
+        tables[4 * H + tid] = 1.0 / (lam * s2);
+        tables[5 * H + tid] = 1.0 / lam;
+        tables[6 * H + tid] = mu;
+        tables[7 * H + tid] = log(pi) - log(1.0 - pi);
+        tables[8 * H + tid] = 1.0 / s2;
+    }
+}
+}  // namespace
+
+extern "C" int pm_gsc_mstep_finish_f64(const double *xs_xsz, const double *xsz_xsz, const double *sum_ss,
+                                       const double *sum_zz, const double *ss_inv, const double *sum_s,
+                                       const double *sum_sz, const double *sum_yy, const double *gram, const double *old,
+                                       double N, int64_t D, int64_t H, int learn, double *params, double *tables,
+                                       void *stream) {
+    if (!xs_xsz || !xsz_xsz || !sum_ss || !sum_zz || !ss_inv || !sum_s || !sum_sz || !sum_yy || !gram || !old || !params ||
+        !tables || !(N > 0.0) || D <= 0 || H <= 0)
+        return PM_EINVAL;
+    if (H > 256) return PM_ERANGE;
+    hipLaunchKernelGGL(gsc_mstep_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), xs_xsz, xsz_xsz,
+                       sum_ss, sum_zz, ss_inv, sum_s, sum_sz, sum_yy, gram, old, N, (double)D, (int)H, learn, params, tables);
+    return (int)hipGetLastError();
+}
+
 extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
                                 const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
                                 int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
@@ -530,7 +622,7 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
                                 double *stats, void *stream) {
     if (N == 0) return PM_OK;
     if (!scores || !gram || !psi_sq || !ynorm2 || !tables || !cand || !xpt_s || !xpt_sz || !stats || N < 0 || H <= 0 ||
-        Hprime <= 0 || S < 0 || lds < H || ldx < H || (S > 0 && !state_masks) || !(sigma_sq > 0.0))
+        Hprime <= 0 || S < 0 || lds < H || ldx < H || (S > 0 && !state_masks) || !(sigma_sq >= 0.0))
         return PM_EINVAL;
     if (!pm_gsc_supported(H, Hprime, gamma)) return PM_ERANGE;
     GscTables T{tables, tables + H, tables + 2 * H, tables + 3 * H, tables + 4 * H, tables + 5 * H, tables + 6 * H,
@@ -541,7 +633,7 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
     if (groups > 2048) groups = 2048;
     dim3 grid((unsigned)groups), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const double inv_s2 = 1.0 / sigma_sq;
+    const double inv_s2 = sigma_sq > 0.0 ? 1.0 / sigma_sq : 0.0;   // 0: tables[8 H] holds it (pm_gsc_mstep_finish_f64)
 #define PM_LAUNCH(V, G)                                                                                             \
     do {                                                                                                            \
         if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G>), shmem)) return e;          \

@@ -27,7 +27,7 @@
 __host__ __device__ static inline int64_t mca_stats_base(int64_t H, int64_t D) { return 3 * H * D + H + PM_MCA_NSCALARS; }
 
 #ifndef PM_MCA_ABL
-#define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates
+#define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates, 4 T sums from candidate 0 only
 #endif
 
 namespace {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
             for (int i = 0; i < DPL; ++i) T[i] = 0.0;
 #pragma unroll
             for (int j = 0; j < HP; ++j)
-                if ((maskN >> j) & 1u) {
+                if (((maskN >> j) & 1u) && (PM_MCA_ABL != 4 || j == 0)) {
 #pragma unroll
                     for (int i = 0; i < DPL; ++i) T[i] += s_wr[j * DS + lane + 64 * i];
                 }

@@ -31,29 +31,32 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const double *__restr
                                                             int64_t ldo, double *__restrict__ pivots,
                                                             int64_t stride_in, int64_t stride_out,
                                                             const double *__restrict__ guard, int guard_n, double guard_tol2,
-                                                            const double *__restrict__ refined) {
+                                                            const double *__restrict__ refined, int64_t guard_stride) {
     // warm start (pm_spd_inverse_warm_f64): `inv` already holds a Newton-Schulz refinement of the previous inverse
     // that started from a residual ||I - A X0||_F^2 = sum(guard[0 .. guard_n)) -- summed in a fixed order, so every
     // rank holding the same matrices decides alike.  Small enough: nothing to do.
     if (guard) {
         __shared__ double s_g[NMAX];
         __shared__ int s_skip;
+        guard += blockIdx.x * guard_stride;              // (matrix blockIdx.x of a batch)
+        refined += blockIdx.x * guard_stride;
+        double *inv_b = inv + blockIdx.x * stride_out, *piv_b = pivots ? pivots + 2 * blockIdx.x : nullptr;
         if (threadIdx.x < NMAX) s_g[threadIdx.x] = (int)threadIdx.x < guard_n ? guard[threadIdx.x] : 0.0;
         __syncthreads();
         if (threadIdx.x == 0) {
             double r2 = 0.0;
             for (int q = 0; q < NMAX; ++q) r2 += s_g[q];
             s_skip = (r2 < guard_tol2) ? 1 : 0;           // (NaN compares false: the sweep runs)
-            if (s_skip && pivots) {
-                pivots[0] = 1.0;
-                pivots[1] = 1.0;
+            if (s_skip && piv_b) {
+                piv_b[0] = 1.0;
+                piv_b[1] = 1.0;
             }
         }
         __syncthreads();
         if (s_skip) {       // inv = (X + X^T) / 2: the next step's start and the solve both treat it as symmetric
             for (int e = threadIdx.x; e < n * n; e += 1024) {
                 const int i = e / n, j = e - i * n;
-                inv[(int64_t)i * ldo + j] = 0.5 * (refined[(int64_t)i * n + j] + refined[(int64_t)j * n + i]);
+                inv_b[(int64_t)i * ldo + j] = 0.5 * (refined[(int64_t)i * n + j] + refined[(int64_t)j * n + i]);
             }
             return;
         }
@@ -211,11 +214,20 @@ __global__ __launch_bounds__(256) void ns_residual_kernel(const double *__restri
                                                           const double *__restrict__ diag_add,
                                                           const double *__restrict__ X, int n, int64_t ld,
                                                           double *__restrict__ full, double *__restrict__ R,
-                                                          double *__restrict__ L, double *__restrict__ partial) {
+                                                          double *__restrict__ L, double *__restrict__ partial,
+                                                          int64_t stride_in, int64_t stride_x, int64_t stride_full,
+                                                          int64_t stride_work) {
     __shared__ double s_t[4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.y * NS_T, j0 = blockIdx.x * NS_T;
-    {   // this tile of the assembled matrix: one element per thread
+    upper += blockIdx.z * stride_in;                     // matrix blockIdx.z of a batch
+    if (diag_add) diag_add += (int64_t)blockIdx.z * n;
+    X += blockIdx.z * stride_x;
+    if (full) full += blockIdx.z * stride_full;
+    R += blockIdx.z * stride_work;
+    L += blockIdx.z * stride_work;
+    partial += blockIdx.z * stride_work;
+    if (full) {   // this tile of the assembled matrix: one element per thread
         const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
         if (i < n && j < n) {
             double v = (i <= j) ? upper[(int64_t)i * ldu + j] : upper[(int64_t)j * ldu + i];
@@ -249,10 +261,18 @@ template <bool LAST>
 __global__ __launch_bounds__(256) void ns_step_kernel(const double *__restrict__ X, const double *__restrict__ R,
                                                       const double *__restrict__ L, int n, int64_t ld,
                                                       double *__restrict__ Xn, double *__restrict__ Rn,
-                                                      double *__restrict__ Ln) {
+                                                      double *__restrict__ Ln, int64_t stride_x, int64_t stride_work) {
     __shared__ double s_t[2][4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.y * NS_T, j0 = blockIdx.x * NS_T;
+    X += blockIdx.z * stride_x;                          // matrix blockIdx.z of a batch
+    R += blockIdx.z * stride_work;
+    L += blockIdx.z * stride_work;
+    Xn += blockIdx.z * stride_work;
+    if (!LAST) {
+        Rn += blockIdx.z * stride_work;
+        Ln += blockIdx.z * stride_work;
+    }
     d4 xr = {0, 0, 0, 0}, rr = {0, 0, 0, 0};
     ns_tile<!LAST, false>(X, L, R, nullptr, i0, j0, n, ld, ld, lane, wave, xr, rr);
 #pragma unroll
@@ -286,7 +306,7 @@ extern "C" int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double
     if (n > NMAX) return PM_ERANGE;
     hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), upper, ldu,
                        diag_add, (int)n, full, inv, ldo, pivots, (int64_t)0, (int64_t)0, (const double *)nullptr, 0, 0.0,
-                       (const double *)nullptr);
+                       (const double *)nullptr, (int64_t)0);
     return (int)hipGetLastError();
 }
 
@@ -295,31 +315,48 @@ extern "C" int64_t pm_spd_inverse_warm_work_len(int64_t n) {
     return n > 0 ? 6 * n * n + tiles * tiles : 0;
 }
 
+static int launch_warm(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
+                       const double *prev_inv, int64_t stride_prev, double *work, double *full, double *inv,
+                       int64_t stride_out, double *pivots, int64_t batch, hipStream_t s) {
+    const int tiles = (int)((n + NS_T - 1) / NS_T);
+    const int64_t nn = n * n, wl = pm_spd_inverse_warm_work_len(n);
+    // work, per matrix: two (X, R, L) triples, then the residual's per-tile sums of squares
+    double *X[2] = {work, work + 3 * nn}, *R[2] = {work + nn, work + 4 * nn}, *L[2] = {work + 2 * nn, work + 5 * nn};
+    double *partial = work + 6 * nn;
+    const dim3 grid((unsigned)tiles, (unsigned)tiles, (unsigned)batch);
+    hipLaunchKernelGGL(ns_residual_kernel, grid, dim3(256), 0, s, upper, ldu, diag_add, prev_inv, (int)n, n, full, R[0], L[0],
+                       partial, stride_in, stride_prev, stride_out, wl);
+    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, prev_inv, (const double *)R[0], (const double *)L[0],
+                       (int)n, n, X[1], R[1], L[1], stride_prev, wl);
+    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
+                       (const double *)L[1], (int)n, n, X[0], R[0], L[0], wl, wl);
+    hipLaunchKernelGGL(ns_step_kernel<true>, grid, dim3(256), 0, s, (const double *)X[0], (const double *)R[0],
+                       (const double *)L[0], (int)n, n, X[1], (double *)nullptr, (double *)nullptr, wl, wl);
+    hipLaunchKernelGGL(spd_inverse_kernel, dim3((unsigned)batch), dim3(1024), 0, s, upper, ldu, diag_add, (int)n,
+                       (double *)nullptr, inv, n, pivots, stride_in, stride_out, (const double *)partial, tiles * tiles, 0.01,
+                       (const double *)X[1], wl);
+    return (int)hipGetLastError();
+}
+
 extern "C" int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n,
                                        const double *prev_inv, int64_t ldp, double *work, double *full, double *inv,
                                        int64_t ldo, double *pivots, void *stream) {
     if (!upper || !inv || !prev_inv || !work || !full || !pivots || n <= 0 || ldu < n || ldo < n || ldp < n) return PM_EINVAL;
     if (n > NMAX) return PM_ERANGE;
     if (ldp != n || ldo != n) return PM_EINVAL;          // the work matrices share one leading dimension with them
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int tiles = (int)((n + NS_T - 1) / NS_T);
-    const int64_t nn = n * n;
-    // work: two (X, R, L) triples, then the residual's per-tile sums of squares
-    double *X[2] = {work, work + 3 * nn}, *R[2] = {work + nn, work + 4 * nn}, *L[2] = {work + 2 * nn, work + 5 * nn};
-    double *partial = work + 6 * nn;
-    const dim3 grid((unsigned)tiles, (unsigned)tiles);
-    hipLaunchKernelGGL(ns_residual_kernel, grid, dim3(256), 0, s, upper, ldu, diag_add, prev_inv, (int)n, n, full, R[0], L[0],
-                       partial);
-    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, prev_inv, (const double *)R[0], (const double *)L[0],
-                       (int)n, n, X[1], R[1], L[1]);
-    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
-                       (const double *)L[1], (int)n, n, X[0], R[0], L[0]);
-    hipLaunchKernelGGL(ns_step_kernel<true>, grid, dim3(256), 0, s, (const double *)X[0], (const double *)R[0],
-                       (const double *)L[0], (int)n, n, X[1], (double *)nullptr, (double *)nullptr);
-    hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), 0, s, upper, ldu, diag_add, (int)n, (double *)nullptr, inv,
-                       ldo, pivots, (int64_t)0, (int64_t)0, (const double *)partial, tiles * tiles, 0.01,
-                       (const double *)X[1]);
-    return (int)hipGetLastError();
+    return launch_warm(upper, ldu, 0, diag_add, n, prev_inv, 0, work, full, inv, 0, pivots, 1, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pm_spd_inverse_warm_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add,
+                                             int64_t n, const double *prev_inv, int64_t stride_prev, double *work,
+                                             double *inv, int64_t stride_out, double *pivots, int64_t batch, void *stream) {
+    if (batch == 0) return PM_OK;
+    if (!upper || !inv || !prev_inv || !work || !pivots || n <= 0 || ldu < n || batch < 0 ||
+        stride_in < ldu * (n - 1) + n || stride_out < n * n || stride_prev < n * n)
+        return PM_EINVAL;
+    if (n > NMAX || batch > 65535) return PM_ERANGE;
+    return launch_warm(upper, ldu, stride_in, diag_add, n, prev_inv, stride_prev, work, nullptr, inv, stride_out, pivots, batch,
+                       static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pm_spd_inverse_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add,
@@ -332,6 +369,6 @@ extern "C" int pm_spd_inverse_batch_f64(const double *upper, int64_t ldu, int64_
     if (n > NMAX || batch > 65535) return PM_ERANGE;
     hipLaunchKernelGGL(spd_inverse_kernel, dim3((unsigned)batch), dim3(1024), 0, static_cast<hipStream_t>(stream), upper,
                        ldu, diag_add, (int)n, full, inv, ldo, pivots, stride_in, stride_out, (const double *)nullptr, 0, 0.0,
-                       (const double *)nullptr);
+                       (const double *)nullptr, (int64_t)0);
     return (int)hipGetLastError();
 }

@@ -71,6 +71,12 @@ class GSC(DeviceCAModel):
         self._masks_dev = None
         self._seed = None        # next step's W^T / Gram / scores left on the device by M_step (_speculate)
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
+        self._spec = None        # next step's whole E-step, launched by M_step from device-side parameters
+        self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
+        self.spec_hits = 0
+        self._in_step = False
+        self._anneal_sig = None
+        self._flat_schedule = False
 
     # ------------------------------------------------------------------ host-side mirror
     @tracing.traced
@@ -271,6 +277,19 @@ class GSC(DeviceCAModel):
         N, D = Y.shape
         H, Hp, S = self.H, self.Hprime, self.no_states
         par = self._tables_for(model_params, res)
+        A = None
+        if N:
+            A = par.pop("scores", None)          # left by the previous M-step (_speculate); good for one pass
+            par["scores"] = None
+            if A is None:
+                A = self._gemm_nt(Y, par["Wst"], self._buf("scores", (N, H)), "scores_gemm")
+        return self._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], par["tables"], par["s2"], anneal_T, cand_in)
+
+    def _launch_estep(self, res, A, G, psi_d, yn, tables, s2, anneal_T, cand_in):
+        """The fused select / E-step kernel on scores ``A``; ``s2 == 0.0``: 1/sigma_sq sits in the ninth row of
+        ``tables`` (an M-step that finished on the device).  Returns (cand, xpt_s, xpt_sz, stats)."""
+        N = res["Y"].shape[0]
+        H, Hp, S = self.H, self.Hprime, self.no_states
         masks = self._masks()
         n_stats = _lib.load().pm_gsc_stats_len(H)
         stats = torch.zeros(n_stats, dtype=torch.float64, device=self.device)
@@ -284,15 +303,33 @@ class GSC(DeviceCAModel):
         else:
             cand, do_select = cand_in, 0
         if N:
-            A = par.pop("scores", None)          # left by the previous M-step (_speculate); good for one pass
-            par["scores"] = None
-            if A is None:
-                A = self._gemm_nt(Y, par["Wst"], self._buf("scores", (N, H)), "scores_gemm")
-            self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(par["G"]), _ptr(par["psi_d"]), _ptr(par["yn"]),
-                       _ptr(par["tables"]), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
-                       ctypes.c_double(par["s2"]), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), 2 * H,
+            self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(G), _ptr(psi_d), _ptr(yn),
+                       _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
+                       ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), 2 * H,
                        _ptr(stats), self._stream())
         return cand, xs, xsz, stats
+
+    def step(self, anneal, model_params, my_data):
+        """CAModel.step; M_step knows that an E_step of the next EM step is likely to follow."""
+        self._in_step = True
+        sig = (anneal['T'], anneal['partial'])
+        self._flat_schedule = (sig == self._anneal_sig)      # same annealing point as the previous step
+        self._anneal_sig = sig
+        try:
+            return DeviceCAModel.step(self, anneal, model_params, my_data)
+        finally:
+            self._in_step = False
+
+    _PARAM_KEYS = ('W', 'pi', 'mu', 'psi_sq', 'sigma_sq')
+
+    def _spec_matches(self, sp, anneal, model_params, res):
+        if sp["res"] is not res or sp["T"] != anneal['T']:
+            return False
+        for k in self._PARAM_KEYS:
+            a, b = np.asarray(model_params[k]), sp["params"][k]
+            if a.shape != b.shape or not np.array_equal(a, b):
+                return False
+        return True
 
     @tracing.traced
     def select_Hprimes(self, model_params, my_data):
@@ -322,7 +359,12 @@ class GSC(DeviceCAModel):
         if 'candidates' in my_data and 'data_clusters' not in my_data:   # candidates handed in (sorted, as upstream)
             cand_in = self._device_candidates(np.sort(np.asarray(my_data['candidates']).astype(np.int64), axis=1), N)
         tracing.tracepoint("E_step:iterating")
-        cand, xs, xsz, stats = self._run(anneal['T'], model_params, res, cand_in)
+        sp, self._spec = self._spec, None
+        if sp is not None and cand_in is None and self._spec_matches(sp, anneal, model_params, res):
+            cand, xs, xsz, stats = sp["out"]       # the previous M-step has already launched exactly this pass
+            self.spec_hits += 1
+        else:
+            cand, xs, xsz, stats = self._run(anneal['T'], model_params, res, cand_in)
         my_data['candidates'] = DeviceArray(cand, np.float64)             # float array upstream (gsc_et.py:431)
         H = self.H
         st = stats
@@ -367,7 +409,12 @@ class GSC(DeviceCAModel):
         sum_zz = dev(suff_stats['xpt_szsz'].sum(axis=0))
         # packed: [Wp (D,H) | xs^T xsz (H,H) | xsz^T xsz (H,H) | sum_ss | sum_zz | sum_s | sum_sz | sum |y|^2]
         nWp, nHH = D * H, H * H
-        packed = torch.zeros(nWp + 4 * nHH + 2 * H + 1, dtype=torch.float64, device=self.device)
+        n_stat = nWp + 4 * nHH + 2 * H + 1
+        # one buffer, one download: [statistics (all-reduced) | 2 inverses + 4 pivots | W_new^T | pi mu psi_sq sigma_sq]
+        n_inv, n_par = 2 * nHH + 4, 2 * H + nHH + 1
+        o_inv = n_stat + (n_stat & 1)               # (16-byte alignment for the GEMM's vector loads)
+        whole = torch.zeros(o_inv + n_inv + nWp + n_par, dtype=torch.float64, device=self.device)
+        packed = whole[:n_stat]
         if my_N:
             s = self._stream()
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(Y), D, _ptr(xsz), ldx, _ptr(packed), H, D, H, my_N, s)
@@ -389,34 +436,69 @@ class GSC(DeviceCAModel):
         packed[o2 + 2 * H] = res["ynorm2"].sum()
         comm.allreduce_device(packed)      # replaces gsc_et.py:608-610,620,668,671,713
         data_sq = self._data_second_moment(res) if 'sigma_sq' in self.to_learn else None
-        inv_dev = None
-        if packed.is_cuda and H <= 256:
+        st = self._stream()
+        at = lambda off: ctypes.c_void_p(whole.data_ptr() + 8 * off)
+        o_wt, o_par = o_inv + n_inv, o_inv + n_inv + nWp
+        have_inv = packed.is_cuda and H <= 256
+        if have_inv:
             # the two H x H inverses of the update (gsc_et.py:625, 673) on the device, ahead of the download: a
-            # 128 x 128 LAPACK inverse costs 0.4 ms of host time each while the GPU idles
-            inv_dev = torch.empty(2 * nHH + 4, dtype=torch.float64, device=self.device)
-            both = torch.stack([packed[o + nHH:o + 2 * nHH].view(H, H),
-                                packed[o:o + nHH].view(H, H) + eps * torch.eye(H, dtype=torch.float64, device=self.device)])
-            # ONE launch, one workgroup per matrix: the two inverses run side by side on two CUs
-            self._call("spd_inverse", "pm_spd_inverse_batch_f64", _ptr(both), H, nHH, None, H, None, _ptr(inv_dev), H,
-                       nHH, ctypes.c_void_p(inv_dev.data_ptr() + 8 * 2 * nHH), 2, self._stream())
-            packed = torch.cat([packed, inv_dev])
+            # 128 x 128 LAPACK inverse costs 0.4 ms of host time each while the GPU idles.  [sum_ss ; sum_zz] sit back
+            # to back in the statistics; inverses are stored in that order: [(sum_ss + eps I)^-1 ; sum_zz^-1 ; 4 pivots]
+            dadd = self._eps_diag(H, eps)
+            prev = getattr(self, "_inv_prev", None)
+            if prev is not None and tuple(prev.shape) == (2, H, H) and os.environ.get("PM_WARM_INVERSE", "1") == "1":
+                # warm start from the previous EM step's inverses (Newton-Schulz on the matrix cores, the sweep as the
+                # device-side fallback): both matrices in every launch
+                work = self._buf("spd_warm_work", (2 * int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
+                self._call("spd_inverse", "pm_spd_inverse_warm_batch_f64", at(o), H, nHH, _ptr(dadd), H, _ptr(prev), nHH,
+                           _ptr(work), at(o_inv), nHH, at(o_inv + 2 * nHH), 2, st)
+            else:
+                # ONE launch, one workgroup per matrix: the two inverses run side by side on two CUs
+                self._call("spd_inverse", "pm_spd_inverse_batch_f64", at(o), H, nHH, _ptr(dadd), H, None, at(o_inv), H, nHH,
+                           at(o_inv + 2 * nHH), 2, st)
+            self._inv_prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H).clone()
         Wt_next = None
         self._seed = None
-        if inv_dev is not None and 'W' in self.to_learn and self.sigma_sq_type == 'scalar' and self.speculate:
+        if have_inv and 'W' in self.to_learn and self.sigma_sq_type == 'scalar' and self.speculate:
             # W_new^T = (sum xpt_szsz)^-1 . Wp^T on the device too (gsc_et.py:625): the next step's scores GEMM can
             # then start before the host has even seen this step's result
-            Wt_next = torch.empty((H, D), dtype=torch.float64, device=self.device)
-            n0 = packed.numel() - inv_dev.numel()
-            self._gemm_nt(packed[n0:n0 + nHH].view(H, H), packed[:nWp].view(D, H), Wt_next, "solve_gemm")
-            packed = torch.cat([packed, Wt_next.reshape(-1)])
+            Wt_next = whole[o_wt:o_wt + nWp].view(H, D)
+            self._gemm_nt(whole[o_inv + nHH:o_inv + 2 * nHH].view(H, H), whole[:nWp].view(D, H), Wt_next, "solve_gemm")
+        # The rest of the update is H- and H x H-sized (gsc_et.py:640-713): done on the device as well
+        # (pm_gsc_mstep_finish_f64), the next E-step's tables exist there before the host has seen anything, and inside
+        # an EM loop on a flat annealing schedule that E-step is launched right here (E_step adopts it iff it is called
+        # with exactly the parameters this M-step returns).  The host still receives everything with the one download.
+        fin = None
+        if Wt_next is not None and self.speculate_estep and my_N:
+            G_next = self._gemm_nt(Wt_next, Wt_next, torch.empty((H, H), dtype=torch.float64, device=self.device),
+                                   "gram_gemm")
+            old = np.concatenate([np.asarray(model_params[k], dtype=np.float64).reshape(-1)
+                                  for k in ('pi', 'mu', 'psi_sq', 'sigma_sq')])
+            learn = sum(bit for bit, k in ((1, 'pi'), (2, 'mu'), (4, 'psi_sq'), (8, 'sigma_sq')) if k in self.to_learn)
+            tdev = torch.empty(9 * H, dtype=torch.float64, device=self.device)
+            self._call("mstep_finish", "pm_gsc_mstep_finish_f64", at(nWp), at(nWp + nHH), at(o), at(o + nHH), at(o_inv),
+                       at(o2), at(o2 + H), at(o2 + 2 * H), _ptr(G_next), _ptr(self._upload("gsc_old", old)),
+                       ctypes.c_double(float(N)), D, H, learn, at(o_par), _ptr(tdev), st)
+            fin = {"G": G_next, "psi": whole[o_par + 2 * H:o_par + 2 * H + nHH].view(H, H), "tdev": tdev, "out": None}
+
+        def after_copy():
+            if fin is None:
+                self._speculate(res, Wt_next)
+                return
+            A = self._gemm_nt(Y, Wt_next, self._buf("scores_spec", (my_N, H)), "scores_gemm")
+            self._seed = {"ykey": res["key"], "Wt": Wt_next, "G": fin["G"], "A": A, "W_host": None}
+            if self._in_step and self._flat_schedule:
+                fin["out"] = self._launch_estep(res, A, fin["G"], fin["psi"], res["ynorm2"], fin["tdev"], 0.0,
+                                                anneal['T'], None)
+
         if packed.is_cuda:
-            host = self._download(packed, then=(lambda: self._speculate(res, Wt_next)) if Wt_next is not None else None)
+            n_down = o_par + n_par if fin is not None else (o_par if Wt_next is not None else
+                                                            (o_wt if have_inv else n_stat))
+            host = self._download(whole[:n_down], then=after_copy if Wt_next is not None else None)
         else:
             host = packed.numpy()
-        W_given = None
-        if Wt_next is not None:
-            W_given = host[-nWp:].reshape(H, D).T.copy()
-            host = host[:-nWp]
+        dev_params = host[o_par:o_par + n_par] if fin is not None else None
+        W_given = host[o_wt:o_wt + nWp].reshape(H, D).T.copy() if Wt_next is not None else None
         Wp = host[:nWp].reshape(D, H)
         xs_xsz = host[nWp:nWp + nHH].reshape(H, H)
         xsz_xsz = host[nWp + nHH:nWp + 2 * nHH].reshape(H, H)
@@ -426,21 +508,42 @@ class GSC(DeviceCAModel):
         sum_yy = float(host[o2 + 2 * H])
 
         inverses = None
-        if inv_dev is not None:
-            tail = host[-(2 * nHH + 4):]
+        if have_inv:
+            tail = host[o_inv:o_inv + n_inv]
             piv = tail[2 * nHH:]
             good = np.isfinite(tail).all() and piv[0] > 0 and piv[2] > 0 and piv[0] / piv[1] > 1e-12 \
                 and piv[2] / piv[3] > 1e-12
             if good:        # well-conditioned SPD: use the device inverses; else LAPACK on the host as upstream
-                inverses = (tail[:nHH].reshape(H, H), tail[nHH:2 * nHH].reshape(H, H))
+                inverses = (tail[nHH:2 * nHH].reshape(H, H), tail[:nHH].reshape(H, H))    # (zz^-1, (ss + eps I)^-1)
         if inverses is None or W_given is None or not np.isfinite(W_given).all():
-            W_given, self._seed = None, None       # host fallback: whatever was speculated is void
+            W_given, self._seed, dev_params = None, None, None       # host fallback: whatever was speculated is void
         elif self._seed is not None:
             self._seed["W_host"] = W_given.copy()  # private snapshot of what model_params['W'] will hold: an in-place
                                                    # edit by the caller must be seen as a different W
+        if dev_params is not None and np.isfinite(dev_params).all() and dev_params[-1] > 0:
+            # the device's own update: what the caller gets is exactly what the launched E-step has used
+            model_params['W'] = W_given
+            for k, lo, hi, shape in (('pi', 0, H, (H,)), ('mu', H, 2 * H, (H,)), ('psi_sq', 2 * H, 2 * H + nHH, (H, H))):
+                if k in self.to_learn:
+                    model_params[k] = dev_params[lo:hi].reshape(shape).copy()
+            if 'sigma_sq' in self.to_learn:
+                model_params['sigma_sq'] = float(dev_params[-1])
+            if fin["out"] is not None:
+                self._spec = {"res": res, "T": anneal['T'], "out": fin["out"],
+                              "params": {k: np.array(model_params[k], dtype=np.float64, copy=True) for k in self._PARAM_KEYS}}
+            return model_params
         with small_blas():
             return self._update(model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss,
                                 sum_xpt_szsz, sum_yy, data_sq, inverses, W_given)
+
+    def _eps_diag(self, H, eps):
+        """[eps ... eps | 0 ... 0]: the diagonal terms of the batched inverse of (sum_ss + eps I, sum_zz)."""
+        d = getattr(self, "_eps_diag_dev", None)
+        if d is None or d.numel() != 2 * H:
+            d = torch.zeros(2 * H, dtype=torch.float64, device=self.device)
+            d[:H] = eps
+            self._eps_diag_dev = d
+        return d
 
     def _data_second_moment(self, res):
         """sum_n y_n^2 per dimension (diagonal) / sum_n y_n y_n^T (full) over ALL ranks -- constants of the

@@ -2,8 +2,8 @@
 # Timing ablations of the fused MCA E-step + M-statistics kernel (run on the GPU box): rebuilds the library with
 # -DPM_MCA_ABL=n and times scratch/bench_mca.py.  The ablated builds compute wrong results by design.
 cd "$(dirname "$0")/.."
-for a in 0 1 2 3; do
+for a in 0 1 2 3 4; do
   touch prosper_amd/csrc/mca_kernels.hip
   PM_EXTRA_FLAGS=-DPM_MCA_ABL=$a bash prosper_amd/csrc/build.sh > /dev/null 2>&1
-  echo "ABL $a: $(python scratch/bench_mca.py 2>/dev/null | tr '\n' ' ')"
+  echo "ABL $a: $(python scratch/mca_phases.py 2>/dev/null | tail -1 | tr '\n' ' ')"
 done

@@ -178,6 +178,40 @@ def test_spd_inverse_warm(dev, n, rel):
     assert rel > 1e-3 or r0 < 0.0999
 
 
+def test_spd_inverse_warm_batch(dev):
+    """pm_spd_inverse_warm_batch_f64: two matrices per launch (GSC's M-step), one refined from a close start, the other
+    recomputed by the sweep because its start is far off."""
+    from prosper_amd import _lib
+    n, batch, pad = 40, 2, 6
+    rs = np.random.RandomState(9)
+    mats, starts = [], []
+    for b, rel in enumerate((1e-3, 0.7)):
+        B = rs.normal(size=(n, 2 * n + b))
+        B0 = B + rel * rs.normal(size=B.shape)
+        mats.append(B @ B.T)
+        starts.append(np.linalg.inv(B0 @ B0.T + 0.3 * np.eye(n)))
+    dadd = np.full((batch, n), 0.3)
+    inp = torch.zeros((batch, n * n + pad), dtype=torch.float64, device=dev)
+    for b in range(batch):
+        inp[b, :n * n] = torch.from_numpy(np.triu(mats[b]) + np.tril(rs.normal(size=(n, n)), -1)).to(dev).reshape(-1)
+    prev = torch.from_numpy(np.stack([0.5 * (x + x.T) for x in starts])).to(dev).contiguous()
+    da = torch.from_numpy(dadd).to(dev).contiguous()
+    work = torch.zeros(batch * int(_lib.load().pm_spd_inverse_warm_work_len(n)), dtype=torch.float64, device=dev)
+    inv = torch.zeros((batch, n * n), dtype=torch.float64, device=dev)
+    piv = torch.zeros(2 * batch, dtype=torch.float64, device=dev)
+    _lib.call("pm_spd_inverse_warm_batch_f64", _p(inp), n, n * n + pad, _p(da), n, _p(prev), n * n, _p(work), _p(inv),
+              n * n, _p(piv), batch, _stream())
+    pv = piv.cpu().numpy()
+    for b in range(batch):
+        Af = mats[b] + np.diag(dadd[b])
+        got = inv[b].view(n, n).cpu().numpy()
+        np.testing.assert_array_equal(got, got.T)
+        assert np.linalg.norm(np.eye(n) - Af @ got) < 1e-9 * np.linalg.cond(Af)
+    np.testing.assert_array_equal(pv[:2], [1.0, 1.0])                  # refined
+    d2 = np.diag(np.linalg.cholesky(mats[1] + np.diag(dadd[1]))) ** 2  # swept
+    np.testing.assert_allclose(pv[2:], [d2.min(), d2.max()], rtol=1e-9)
+
+
 def test_spd_inverse_rejects_large(dev):
     from prosper_amd import _lib
     t = torch.zeros((300, 300), dtype=torch.float64, device=dev)

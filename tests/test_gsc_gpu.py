@@ -193,9 +193,55 @@ def test_config4_properties():
     assert np.abs(new["W"] - W_gt.cpu().numpy()).mean() < 0.2 and abs(new["pi"].mean() * H - 2.0) < 0.5
 
 
+@pytest.mark.parametrize("H,D,learn", [(24, 48, 15), (128, 256, 15), (10, 7, 5), (10, 7, 0)])
+def test_gsc_mstep_finish_kernel(H, D, learn):
+    """pm_gsc_mstep_finish_f64 -- pi clip, mu, psi_sq, scalar sigma_sq and the next E-step's tables on the device --
+    against the host formulas of GSC._update / GSC._tables_for (gsc_et.py:640-713, 260-398)."""
+    import ctypes
+    from prosper_amd import _lib
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(H + learn)
+    N = 5000.0
+    sum_s = rs.uniform(0.0, 400.0, H)
+    sum_s[0] = 0.01                                   # clipped from below
+    sum_s[1] = N                                      # ... and from above
+    sum_sz = sum_s * rs.normal(1.4, 0.2, H)
+    sq = lambda: (lambda B: B @ B.T)(rs.normal(size=(H, H + 3)))
+    sum_ss, sum_zz, xs_xsz, xsz_xsz = sq() + np.diag(sum_s), sq(), rs.normal(size=(H, H)), sq()
+    ss_inv = np.linalg.inv(sum_ss + 1e-5 * np.eye(H))
+    W = rs.normal(size=(D, H))
+    G = W.T @ W
+    sum_yy = float(np.trace(xsz_xsz @ G) * 1.3 + 100.0)
+    old = {"pi": rs.uniform(0.01, 0.2, H), "mu": rs.normal(size=H), "psi_sq": sq() / H + np.eye(H), "sigma_sq": 1.7}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))).to(dev)
+    oldv = t(np.concatenate([old["pi"], old["mu"], old["psi_sq"].reshape(-1), [old["sigma_sq"]]]))
+    params = torch.zeros(2 * H + H * H + 1, dtype=torch.float64, device=dev)
+    tables = torch.zeros(9 * H, dtype=torch.float64, device=dev)
+    args = [t(x) for x in (xs_xsz, xsz_xsz, sum_ss, sum_zz, ss_inv, sum_s, sum_sz, [sum_yy], G)]
+    _lib.call("pm_gsc_mstep_finish_f64", *[ctypes.c_void_p(a.data_ptr()) for a in args], ctypes.c_void_p(oldv.data_ptr()),
+              ctypes.c_double(N), D, H, learn, ctypes.c_void_p(params.data_ptr()), ctypes.c_void_p(tables.data_ptr()),
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    got, tab = params.cpu().numpy(), tables.cpu().numpy().reshape(9, H)
+    pi = np.clip(sum_s / N, 5e-5, 1 - 5e-5) if learn & 1 else old["pi"]
+    mu = sum_sz / (sum_s + np.finfo(np.float64).eps) if learn & 2 else old["mu"]
+    psi = ((np.outer(mu, mu) * sum_ss + sum_zz - 2 * (mu[:, None] * xs_xsz)) * ss_inv + 1e-5 * np.eye(H)) if learn & 4 \
+        else old["psi_sq"]
+    s2 = (sum_yy - np.einsum('ij,ji->', xsz_xsz, G)) / N / D + 1e-5 if learn & 8 else old["sigma_sq"]
+    np.testing.assert_allclose(got[:H], pi, rtol=1e-14)
+    np.testing.assert_allclose(got[H:2 * H], mu, rtol=1e-14)
+    np.testing.assert_allclose(got[2 * H:2 * H + H * H].reshape(H, H), psi, rtol=1e-12, atol=1e-12 * np.abs(psi).max())
+    np.testing.assert_allclose(got[-1], s2, rtol=1e-11)
+    psid, Gd = np.diag(psi), np.diag(G)
+    lam = Gd / s2 + 1. / psid
+    want = np.stack([-(np.log(psid) + np.log(lam)) - mu * mu * Gd / s2, 2. * mu / s2, Gd * mu, 1. / (lam * s2 * s2),
+                     1. / (lam * s2), 1. / lam, mu, np.log(pi) - np.log(1 - pi), np.full(H, 1. / s2)])
+    np.testing.assert_allclose(tab, want, rtol=1e-10, atol=1e-12)
+
+
 def test_gsc_em_loop_speculation_is_transparent():
-    """The M-step leaves the next step's W^T, Gram matrix and scores on the device (GSC._speculate).  That must not
-    change a trajectory -- whether the caller feeds the returned parameters straight back or edits them first."""
+    """The M-step leaves the next step's W^T, Gram matrix and scores on the device (GSC._speculate), finishes its
+    H x H algebra there (pm_gsc_mstep_finish_f64) and, inside an EM loop, launches the next E-step itself.  That must
+    not change a trajectory -- whether the caller feeds the returned parameters straight back or edits them first."""
     from prosper_amd.em.camodels.gsc_et import GSC
     D, H, Hp, gamma, N = 48, 24, 4, 3, 700
     rng = np.random.RandomState(11)
@@ -211,7 +257,7 @@ def test_gsc_em_loop_speculation_is_transparent():
         m.speculate = spec
         p = {k: np.array(v, copy=True) for k, v in p0.items()}
         used = []
-        for it in range(5):
+        for it in range(8):
             if it == 3:                                   # the caller edits W: the speculated scores must be dropped
                 p["W"] = p["W"] * (1.0 + 1e-3 * np.cos(np.arange(D * H).reshape(D, H)))
             if it == 4:                                   # an in-place edit of the very array the M-step returned
@@ -221,5 +267,10 @@ def test_gsc_em_loop_speculation_is_transparent():
         runs.append(p)
         if spec:
             assert m._seed is not None and m._seed["W_host"] is not p["W"] and np.array_equal(m._seed["W_host"], p["W"])
+            # the M-step also finishes on the device and launches the next E-step itself: adopted at steps 2, 5, 6, 7
+            # (step 1 follows the first step: no flat schedule yet; 3 and 4 follow an edit)
+            assert m.spec_hits == 4, m.spec_hits
+        else:
+            assert m.spec_hits == 0
     for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
         np.testing.assert_allclose(runs[0][k], runs[1][k], rtol=1e-8, atol=1e-11, err_msg=k)
