@@ -11,13 +11,17 @@ with no data-path collective, so scaling is weak (config 3 = 8 x 200k = 1.6 M). 
 EM iteration (CAModel.step incl. the one RCCL all-reduce and the H x H solve) is timed in a
 second region and reported as `em_iter_ms`.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the f64 MFMA scores
-GEMM) by algorithmic flops / its average launch duration measured with HIP events inside the
-timed region; `cpu_baseline` is the oracle's faithful per-datapoint restatement of the
-reference timed on this box's host cores on a bounded sample (rank 0, N=1 only); `parity` compares
-the HIP path with the oracle's answer (minted by that same leg) after 3 EM steps on a seeded sample at
-the bench's dimensions -- outside every timed region; `other_models` adds the EM-iteration wall-clock of GSC
-(config 4) and MCA (config 5) on this GPU, measured after the headline (N=1 only; `--no-other-models` skips it).
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- bsc_estep_fused_kernel: scores GEMM,
+selection and E-step of 196 608 datapoints in one launch -- by its algorithmic flops / its average launch duration
+measured with HIP events on its stream inside the timed region, and reports the whole pass against the MFMA and HBM
+roofs beside it (`estep_mfma_frac`, `estep_hbm_frac`); `traffic` comes from committed PMC passes (`traffic_source`).
+`cpu_baseline` is the oracle's faithful per-datapoint restatement of the reference timed on this box's host cores on
+a bounded sample (rank 0, N=1 only), with the rate of one uncontended process and of the oracle's vectorised
+multi-threaded form beside it; `parity` compares the HIP path with the oracle's answer (minted by that same leg) after
+3 EM steps on a seeded sample at the bench's dimensions -- outside every timed region; `per_rank` lists every rank's
+own ms_per_step / em_iter_ms / all-reduce time / data seed; `other_models` adds the EM-iteration wall-clock, kernel
+times and rooflines of GSC (config 4) and MCA (config 5) on this GPU, measured after the headline (N=1 only;
+`--no-other-models` skips it).
 """
 import argparse
 import gc
