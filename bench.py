@@ -143,17 +143,19 @@ def other_models(dev, Anneal, steps=20):
         if lab:
             # dominant kernel: the fused E-step + M-statistics pass.  Its algorithmic work is one f64 power
             # Wbar_sd = (sum_j W_jd^rho)^(1/rho) per multi-cause state and observed dimension (mca_et.py:170): S x D per
-            # datapoint, ~50 f64 VALU instructions each (pm_pow_pos).  Peak: the f64 vector rate, 78.6 TFLOP/s = 39.3 T
-            # FMA-class instructions/s chip-wide, / 50 per power.
+            # datapoint, 36 f64-VALU issue slots each (pm_pow_tab).  Peak: the f64 vector issue rate, 78.6 TFLOP/s =
+            # 39.3 T FMA-class lane-instructions/s chip-wide, / 36 per power -- a roof for the powers alone; the state
+            # loop's other ~150 instructions per state and its latency at 2 wavefronts per SIMD are inside `frac`.
             S_mca = m.no_states
             npow = float(N) * S_mca * Dm
             ach = npow / (ks[lab][1] * 1e-3) / 1e9
-            peak = MFMA_F64_PEAK_TFLOPS * 1e12 / 2 / 50 / 1e9
+            peak = MFMA_F64_PEAK_TFLOPS * 1e12 / 2 / 36 / 1e9
             out["mca_c5_roofline"] = {"bound": "valu_f64", "kernel": "mca_estep_fused_kernel (E-step + M-step statistics)",
                                       "achieved": ach, "peak": peak, "unit": "Gpow/s", "frac": ach / peak,
                                       "avg_launch_ms": ks[lab][1], "algorithmic_pows": npow, "traffic": None,
-                                      "note": "f64 transcendental bound (S*D powers per datapoint at ~50 VALU instructions "
-                                              "each, peak derived from the 78.6 TFLOP/s f64 vector rate); not an HBM or MFMA kernel"}
+                                      "note": "f64 VALU issue roof of the powers alone (S*D per datapoint at 36 issue slots "
+                                              "each, from the 78.6 TFLOP/s f64 vector rate); the kernel is instruction-latency "
+                                              "bound at 2 wavefronts per SIMD (DESIGN 4.4); not an HBM or MFMA kernel"}
     except Exception as e:   # never lose the headline over the side measurements
         out["error"] = repr(e)
     gc.enable()
