@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Without a GPU every ``gpu``-marked test is reported as skipped (a plain ``pytest`` run on a CPU box stays green)."""
+    if has_gpu():
+        return
+    skip = pytest.mark.skip(reason="needs the GPU box (MI355X)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def golden(name):
     """Fixture arrays by name.  Inputs stored as float32 (the config-2 cases: the reference ran on their exact
     float64 upcasts) come back as float64."""
