@@ -27,7 +27,7 @@
 __host__ __device__ static inline int64_t mca_stats_base(int64_t H, int64_t D) { return 3 * H * D + H + PM_MCA_NSCALARS; }
 
 #ifndef PM_MCA_ABL
-#define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates, 4 T sums from candidate 0 only
+#define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates, 4 T sums from candidate 0 only, 5 no wave reduction, 6 no exponential, 7 no states at all (S = 0)
 #endif
 
 namespace {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                 wbP[i] = (aT > 0.0) ? r : (SIGNED ? INFINITY : 0.0);
             }
         }
-        for (int s = 0; s < S; ++s) {
+        for (int s = 0; s < ((PM_MCA_ABL == 7) ? 0 : S); ++s) {
             // wave-uniform masks; the one after next is requested now (vector-memory latency under this trip's work)
             const unsigned maskN = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_load);
             mask_load = masks[s + 2 < S ? s + 2 : S - 1];
@@ -348,10 +348,10 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                 wbN[i] = (aT > 0.0) ? r : (SIGNED ? INFINITY : 0.0);
             }
             // ---- stage B, state s ----
-            const double part = pm_wave_sum_dpp(partP);                 // wave-uniform
+            const double part = (PM_MCA_ABL == 5) ? partP * 64.0 : pm_wave_sum_dpp(partP);   // wave-uniform
             if (lane == 0) s_e[s] = part;
             const double bf = P.beta * (P.pil_bar * (double)__builtin_popcount(maskP) + P.pre1 * part);
-            double w = pm_exp_tab(bf - M, s_tab);                       // (meaningless if the branch below is taken)
+            double w = (PM_MCA_ABL == 6) ? (bf - M) * 0.001 + 1.0 : pm_exp_tab(bf - M, s_tab);   // (meaningless if the branch below is taken)
             if (bf > M + 50.0) {                                        // uniform; the first state, then hardly ever
                 const double sc = exp(M - bf);
 #pragma unroll
