@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
                 if (ahead >= 2) wait_vmcnt<2 * L>();
                 else if (ahead == 1) wait_vmcnt<L>();
                 else wait_vmcnt<0>();
+#ifndef PM_FUSED_NO_BARRIER          // timing-only ablation (wrong results): what the hand-over barrier costs
                 __builtin_amdgcn_s_barrier();
+#endif
                 const d2 an = read_a(nstage);
                 if (par) fa[0] = an;
                 else fa[1] = an;
