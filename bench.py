@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-other-models", action="store_true", help="skip the GSC / MCA EM-iteration side measurements")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed E-step passes by wall time before the warm-up")
+    ap.add_argument("--data", choices=("numpy", "device"), default="numpy",
+                    help="numpy: SURVEY 8d's np.random.RandomState recipe (host draws, ~5 s); device: torch.Generator on the GPU")
     return ap.parse_args()
 
 
@@ -254,16 +256,34 @@ def main():
 
     # ---- synthetic workload: same W_gt everywhere, rank-seeded rows
     N = args.n_per_gpu
-    g0 = torch.Generator(device=dev).manual_seed(0)
-    W_gt = torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)
-    # (D,H) parameter matrix laid out as an M-step returns it: the transposed view of a C-contiguous (H,D) array
-    W0 = np.ascontiguousarray((W_gt + 0.1 * torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)).cpu().numpy().T).T
-    gr = torch.Generator(device=dev).manual_seed(100 + rank)
     Y = torch.empty(N, D, dtype=torch.float64, device=dev)
-    for lo in range(0, N, 25_000):      # chunked so the generator temporaries stay small
-        hi = min(N, lo + 25_000)
-        S = (torch.rand(hi - lo, H, generator=gr, device=dev) < 4.0 / H).to(torch.float64)
-        Y[lo:hi] = S @ W_gt.t() + torch.randn(hi - lo, D, generator=gr, device=dev, dtype=torch.float64)
+    if args.data == "numpy":
+        # the survey's recipe: np.random.RandomState(0) -> W_gt = randn(D, H), start W = W_gt + 0.1 randn; rows of rank r
+        # from RandomState(r) in the reference generator's order (latents, then noise: camodels/__init__.py:119-120,
+        # bsc_et.py:92); the products run on the device
+        rs0 = np.random.RandomState(0)
+        W_gt_h = rs0.randn(D, H)
+        W0 = np.ascontiguousarray((W_gt_h + 0.1 * rs0.randn(D, H)).T).T
+        W_gt = torch.from_numpy(W_gt_h).to(dev)
+        data_seed = rank
+        rs = np.random.RandomState(data_seed)
+        for lo in range(0, N, 25_000):
+            hi = min(N, lo + 25_000)
+            S = torch.from_numpy((rs.random_sample((hi - lo, H)) < 4.0 / H).astype(np.float64)).to(dev)
+            noise = torch.from_numpy(rs.normal(size=(hi - lo, D))).to(dev)
+            Y[lo:hi] = torch.addmm(noise, S, W_gt.t())
+        del noise
+    else:
+        g0 = torch.Generator(device=dev).manual_seed(0)
+        W_gt = torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)
+        # (D,H) parameter matrix laid out as an M-step returns it: the transposed view of a C-contiguous (H,D) array
+        W0 = np.ascontiguousarray((W_gt + 0.1 * torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)).cpu().numpy().T).T
+        data_seed = 100 + rank
+        gr = torch.Generator(device=dev).manual_seed(data_seed)
+        for lo in range(0, N, 25_000):      # chunked so the generator temporaries stay small
+            hi = min(N, lo + 25_000)
+            S = (torch.rand(hi - lo, H, generator=gr, device=dev) < 4.0 / H).to(torch.float64)
+            Y[lo:hi] = S @ W_gt.t() + torch.randn(hi - lo, D, generator=gr, device=dev, dtype=torch.float64)
     del S
     params = {"W": W0, "pi": 4.0 / H, "sigma": 1.0, "mu": np.zeros(D)}
 
@@ -362,7 +382,7 @@ def main():
     ar = comm.collective_times()
     allreduce_us = 1e3 * sum(ar) / len(ar) if ar else 0.0
     # per-rank record: what every rank generated and measured (a SCALE record stays attributable)
-    mine = torch.tensor([elapsed, em_elapsed, allreduce_us, float(100 + rank), float(N)], dtype=torch.float64, device=dev)
+    mine = torch.tensor([elapsed, em_elapsed, allreduce_us, float(data_seed), float(N)], dtype=torch.float64, device=dev)
     if world > 1:
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -407,7 +427,7 @@ def main():
             "value": value, "unit": "datapoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "prewarm_ms": prewarm_ms,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if args.data == "device" else "synthetic (np.random.RandomState recipe of SURVEY 8d: W_gt seed 0, rows of rank r seed r)",
             "config": {"workload": "BSC_ET synthetic Gaussian D=1024 H=256 H'=8 gamma=4 (K=411 states), "
                                    "N=%d datapoints per GPU, select_Hprimes+E_step per step" % N,
                        "global_datapoints": world * N, "parallelism": "dp%d" % world},
