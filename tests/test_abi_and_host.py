@@ -207,3 +207,89 @@ def test_model_classes_build_the_reference_state_tables_on_cpu():
     pr = np.random.random(size=(6, t.H))
     assert np.array_equal(dt["s"], np.where(pr < 0.2, -1, np.where(pr < 0.4, 1, 0)))
     np.testing.assert_allclose(dt["y"], dt["s"].sum(axis=1, keepdims=True) * np.ones((6, t.D)))
+
+
+def test_powtab_header_is_what_the_generator_writes():
+    """prosper_amd/csrc/pm_powtab.h (tables and polynomial coefficients of pm_pow_tab / pm_exp_tab, the MCA kernels'
+    power function) is exactly the output of gen_powtab.py."""
+    import contextlib
+    import importlib.util
+    import io
+    path = os.path.join(ROOT, "prosper_amd", "csrc", "gen_powtab.py")
+    spec = importlib.util.spec_from_file_location("gen_powtab", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mod.main()
+    with open(os.path.join(ROOT, "prosper_amd", "csrc", "pm_powtab.h")) as f:
+        assert f.read() == buf.getvalue()
+
+
+def test_pow_tab_algorithm_is_accurate_to_one_ulp():
+    """The arithmetic of pm_pow_tab / pm_exp_tab (pm_common.h) restated operation by operation -- every fused
+    multiply-add evaluated exactly and rounded once -- against a 200-bit reference: x^c for the exponents the MCA
+    kernels use (1/rho, 1/rho - 1) and e^x on the online softmax's range."""
+    mp = pytest.importorskip("mpmath")
+    import re
+    mp.mp.prec = 200
+    src = open(os.path.join(ROOT, "prosper_amd", "csrc", "pm_powtab.h")).read()
+    body = src.split("#define PM_POWTAB_VALUES")[1].split("#define PM_POW_A1")[0]
+    tab = np.array([float.fromhex(x) for x in re.findall(r"-?0x1\.[0-9a-f]+p[+-]\d+", body)])
+    assert tab.size == 384
+    A = [float.fromhex(re.search(r"PM_POW_A%d (\S+)" % k, src).group(1)) for k in range(1, 7)]
+    B = [float.fromhex(re.search(r"PM_POW_B%d (\S+)" % k, src).group(1)) for k in range(1, 6)]
+    MAGIC = 6755399441055744.0
+
+    def fma(a, b, c):
+        return float(mp.mpf(a) * mp.mpf(b) + mp.mpf(c))
+
+    def low_word(x):
+        k = int(np.float64(x).view(np.uint64) & np.uint64(0xFFFFFFFF))
+        return k - (1 << 32) if k >= (1 << 31) else k
+
+    def pow_tab(x, c):
+        hi = int(np.float64(x).view(np.uint64) >> np.uint64(32))
+        e = float((hi >> 20) - 1023)
+        idx = (hi >> 13) & 127
+        m = float(x) / 2.0 ** e
+        r, L = tab[2 * idx], tab[2 * idx + 1]
+        d = fma(m, r, -1.0)
+        p = A[5]
+        for k in (4, 3, 2, 1, 0):
+            p = fma(p, d, A[k])
+        s = e + L
+        t = fma(d, p, (e - s) + L)
+        yh = c * s
+        yl = fma(c, t, fma(c, s, -yh))
+        sh = fma(yh, 128.0, MAGIC)
+        k = low_word(sh)
+        f = fma(sh - MAGIC, -0.0078125, yh) + yl
+        q = B[4]
+        for kk in (3, 2, 1, 0):
+            q = fma(q, f, B[kk])
+        E = tab[256 + (k & 127)]
+        return float(np.ldexp(fma(E, f * q, E), k >> 7))
+
+    def exp_tab(x):
+        x = max(x, -708.0)
+        sh = fma(x, 184.6649652337873, MAGIC)
+        k = low_word(sh)
+        kf = sh - MAGIC
+        r = fma(kf, -1.4907929134926466e-12, fma(kf, -0.00541521234663378, x))
+        q = 1.0 / 120.0
+        for c in (1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0):
+            q = fma(q, r, c)
+        E = tab[256 + (k & 127)]
+        return float(np.ldexp(fma(E, r * q, E), k >> 7))
+
+    rng = np.random.RandomState(0)
+    xs = np.concatenate([np.exp(rng.uniform(-30, 30, 250)), 1.0 + rng.uniform(-1e-3, 1e-3, 30),
+                         2.0 ** rng.randint(-20, 20, 20) * (1 + rng.uniform(-1e-12, 1e-12, 20))])
+    for c in (1 / 21.0, 1 / 21.0 - 1.0, 0.5 - 1.0):
+        worst = max(abs(mp.mpf(pow_tab(x, c)) / mp.power(mp.mpf(x), mp.mpf(c)) - 1) for x in xs)
+        assert worst < 2.3e-16, (c, float(worst))
+    ys = np.concatenate([rng.uniform(-700, 50, 250), rng.uniform(-1, 1, 50), [0.0, -1e-300]])
+    worst = max(abs(mp.mpf(exp_tab(y)) / mp.exp(mp.mpf(y)) - 1) for y in ys)
+    assert worst < 2.3e-16, float(worst)
+    assert exp_tab(0.0) == 1.0
