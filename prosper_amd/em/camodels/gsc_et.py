@@ -112,6 +112,34 @@ class GSC(DeviceCAModel):
         return comm.bcast(model_params)
 
     @tracing.traced
+    def resume_init(self, h5_result_file):
+        """Model parameters from the last logged EM step of a ``result.h5`` (gsc_et.py:112-160; upstream's version
+        refers to undefined names and cannot run -- this is what it sets out to do): W, pi, mu, psi_sq as stored,
+        sigma_sq converted to this model's ``sigma_sq_type`` when the file holds another one."""
+        from ...utils.datalog import resume_params
+        last = resume_params(h5_result_file, ('W', 'pi', 'mu', 'psi_sq', 'sigma_sq'))
+        sigma_sq, D = np.asarray(last['sigma_sq']), self.D
+        if sigma_sq.ndim == 2:
+            if self.sigma_sq_type == 'diagonal':
+                sigma_sq = sigma_sq.diagonal()
+            elif self.sigma_sq_type == 'scalar':
+                sigma_sq = np.mean(sigma_sq.diagonal())
+        elif sigma_sq.ndim == 1:
+            if self.sigma_sq_type == 'full':
+                sigma_sq = np.diag(sigma_sq)
+            elif self.sigma_sq_type == 'scalar':
+                sigma_sq = np.mean(sigma_sq)
+        else:
+            if self.sigma_sq_type == 'full':
+                sigma_sq = sigma_sq * np.eye(D)
+            elif self.sigma_sq_type == 'diagonal':
+                sigma_sq = sigma_sq * np.ones(D)
+        if np.ndim(sigma_sq) == 0:
+            sigma_sq = float(sigma_sq)
+        model_params = {'W': last['W'], 'pi': last['pi'], 'sigma_sq': sigma_sq, 'mu': last['mu'], 'psi_sq': last['psi_sq']}
+        return self.comm.bcast(model_params)
+
+    @tracing.traced
     def check_params(self, model_params):
         """gsc_et.py:164-184: finiteness / positivity asserts on rank 0."""
         if self.comm.rank == 0:

@@ -4,10 +4,11 @@ The hot path logs ``N``, ``L`` (free energy), ``N_use`` (bsc_et.py:261,267,436) 
 every parameter / annealing value per step (camodels/__init__.py:190-191).  This keeps
 prosper/utils/datalog.py's policy model: rank-0 only (:181,193), ordered
 ``(tblname, handler)`` policy with the ``'*'`` wildcard (:153-163), ``append`` /
-``append_all`` / ``set_handler`` / ``remove_handler`` / ``ignored``.  HDF5 storage
-(StoreToH5/AutoTable) is out of scope (PyTables is not in the image); ``StoreToNpz``
-is the stand-in.
+``append_all`` / ``set_handler`` / ``remove_handler`` / ``ignored``.  ``StoreToH5`` writes
+the reference's ``result.h5`` layout through ``utils/autotable.py`` (HDF5 C library via
+ctypes: PyTables is not in the image); ``StoreToNpz`` is the dependency-free alternative.
 """
+import os
 from time import strftime
 
 import numpy as np
@@ -78,10 +79,15 @@ class StoreToNpz(StoreInMemory):
 
 
 def resume_params(destination, names=None):
-    """Last logged row of every table of a ``StoreToNpz`` file as a parameter dict -- the ``lparams`` to
-    hand to ``EM`` to continue a run (stand-in for reading ``result.h5``, autotable.py:234-278: PyTables and
-    h5py are not in the image).  ``names`` restricts the keys (e.g. ``('W', 'pi', 'sigma')``)."""
-    with np.load(destination if str(destination).endswith(".npz") else str(destination) + ".npz") as f:
+    """Last logged row of every table of a result file as a parameter dict -- the ``lparams`` to hand to ``EM`` to
+    continue a run (``h5.root.W[steps-1]``, gsc_et.py:113-160).  ``destination``: a ``result.h5`` written by
+    ``StoreToH5`` / ``AutoTable`` (or by the reference through PyTables), or a ``StoreToNpz`` file.  ``names`` restricts
+    the keys (e.g. ``('W', 'pi', 'sigma')``)."""
+    path = str(destination)
+    if path.endswith((".h5", ".hdf5")) or (not path.endswith(".npz") and not os.path.exists(path + ".npz")):
+        from . import autotable
+        return autotable.read_last(path, names)
+    with np.load(path if path.endswith(".npz") else path + ".npz") as f:
         keys = [k for k in f.files if names is None or k in names]
         out = {}
         for k in keys:
@@ -91,34 +97,45 @@ def resume_params(destination, names=None):
 
 
 class StoreToH5(DataHandler):
-    """``result.h5`` writer of the reference (datalog.py:53-93 over autotable.py:87-127: one EArray per logged
-    name, one row per EM step).  Needs h5py or PyTables, neither of which is in this image: constructing it
-    without one raises with a pointer to ``StoreToNpz`` (same one-array-per-name, one-row-per-step layout).
-    With h5py present the rows are written as resizable datasets ``/<name>`` of shape (steps, ...)."""
+    """``result.h5`` writer of the reference (datalog.py:53-93): every logged name becomes an extendable array with
+    one row per EM step, through ``AutoTable`` -- here on the HDF5 C library via ctypes (utils/autotable.py; PyTables
+    and h5py are not in the image), same file layout.  ``destination``: a file name, an ``AutoTable``, or None (the
+    first handler's table, else a file named after the running script), as upstream.  Rank 0 writes."""
+    default_autotbl = None
 
-    def __init__(self, destination):
-        try:
-            import h5py
-        except Exception as e:   # pragma: no cover - h5py is absent from the target image
-            raise ImportError("StoreToH5 needs h5py (not installed here); use StoreToNpz(destination) -- same "
-                              "one-array-per-name, one-row-per-step layout, read back by resume_params()") from e
-        self._h5 = h5py.File(destination, "w")   # pragma: no cover
-        self._sets = {}                          # pragma: no cover
+    def __init__(self, destination=None):
+        from .autotable import AutoTable
+        self.destination = destination
+        self.autotbl = None
+        if COMM_WORLD.rank != 0:
+            return
+        if isinstance(destination, AutoTable):
+            self.autotbl = destination
+        elif isinstance(destination, str):
+            self.autotbl = AutoTable(destination)
+        elif destination is None:
+            self.autotbl = StoreToH5.default_autotbl if StoreToH5.default_autotbl is not None else AutoTable()
+        else:
+            raise TypeError("Expects an AutoTable instance or a string as argument")
+        if StoreToH5.default_autotbl is None:
+            StoreToH5.default_autotbl = self.autotbl
 
-    def append(self, tblname, value):            # pragma: no cover
-        v = np.asarray(value)
-        ds = self._sets.get(tblname)
-        if ds is None:
-            ds = self._sets[tblname] = self._h5.create_dataset(tblname, shape=(0,) + v.shape, maxshape=(None,) + v.shape,
-                                                               dtype=v.dtype, compression="gzip", compression_opts=1,
-                                                               shuffle=True)
-        if tuple(ds.shape[1:]) != v.shape:
-            raise TypeError("Wrong shape for table %s: %s, expected %s" % (tblname, v.shape, ds.shape[1:]))
-        ds.resize(ds.shape[0] + 1, axis=0)
-        ds[-1] = v
+    def __repr__(self):
+        return "StoreToH5 into file %s" % self.destination
 
-    def close(self):                             # pragma: no cover
-        self._h5.close()
+    def append(self, tblname, value):
+        if self.autotbl is not None:
+            self.autotbl.append(tblname, np.asarray(value) if not isinstance(value, str) else value)
+
+    def append_all(self, valdict):
+        for key, val in valdict.items():
+            self.append(key, val)
+
+    def close(self):
+        if self.autotbl is not None:
+            self.autotbl.close()
+            if StoreToH5.default_autotbl is self.autotbl:
+                StoreToH5.default_autotbl = None
 
 
 class DataLog(object):

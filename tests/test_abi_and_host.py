@@ -293,3 +293,84 @@ def test_pow_tab_algorithm_is_accurate_to_one_ulp():
     worst = max(abs(mp.mpf(exp_tab(y)) / mp.exp(mp.mpf(y)) - 1) for y in ys)
     assert worst < 2.3e-16, float(worst)
     assert exp_tab(0.0) == 1.0
+
+
+def _h5_or_skip():
+    from prosper_amd.utils import autotable
+    try:
+        autotable._Lib.get()
+    except autotable.HDF5Unavailable as e:
+        pytest.skip(str(e))
+    return autotable
+
+
+def test_autotable_writes_the_reference_result_h5_layout(tmp_path):
+    """AutoTable / StoreToH5 (prosper/utils/autotable.py:87-127, 234-278, datalog.py:53-93) on the HDF5 C library:
+    one extendable array per name, one row per append, shuffle + zlib level 1, PyTables' EArray attributes -- checked
+    by reading the file back and, independently, with the HDF5 tools' h5dump."""
+    import shutil
+    import subprocess
+    at = _h5_or_skip()
+    from prosper_amd.utils.datalog import StoreToH5, resume_params, dlog
+    fname = str(tmp_path / "result.h5")
+    rs = np.random.RandomState(3)
+    rows_W = [rs.normal(size=(6, 4)) for _ in range(5)]
+    h = dlog.set_handler(('W', 'pi', 'L', 'N_use', 'note'), StoreToH5, fname)
+    try:
+        for t, W in enumerate(rows_W):
+            dlog.append('W', W)
+            dlog.append_all({'pi': 0.1 + 0.01 * t, 'L': -100.0 + t})
+            dlog.append('N_use', 1000 - t)
+            dlog.append('note', "step %d" % t)
+    finally:
+        dlog.remove_handler(h)
+        h.close()
+    assert sorted(at.table_names(fname)) == ['L', 'N_use', 'W', 'note', 'pi']
+    np.testing.assert_array_equal(at.read_table(fname, 'W'), np.stack(rows_W))
+    np.testing.assert_array_equal(at.read_table(fname, 'N_use'), 1000 - np.arange(5))
+    assert at.read_table(fname, 'N_use').dtype == np.int64 and at.read_table(fname, 'pi').dtype == np.float64
+    np.testing.assert_array_equal(at.read_table(fname, 'W', rows=(1, 3)), np.stack(rows_W[1:3]))
+    assert list(at.read_table(fname, 'note')) == ["step %d" % t for t in range(5)]
+    last = resume_params(fname, ('W', 'pi', 'L'))
+    np.testing.assert_array_equal(last['W'], rows_W[-1])
+    assert last['pi'] == 0.1 + 0.04 and last['L'] == -96.0
+    with pytest.raises(TypeError):          # a row of another shape, as upstream
+        with at.AutoTable(str(tmp_path / "bad.h5")) as tbl:
+            tbl.append('x', np.zeros(3))
+            tbl.append('x', np.zeros(4))
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        head = subprocess.run([h5dump, "-H", "-p", fname], capture_output=True, text=True, check=True).stdout
+        assert "( 5, 6, 4 ) / ( H5S_UNLIMITED, 6, 4 )" in head and "PREPROCESSING SHUFFLE" in head
+        assert "COMPRESSION DEFLATE { LEVEL 1 }" in head and "H5T_IEEE_F64LE" in head and "H5T_STD_I64LE" in head
+        attrs = subprocess.run([h5dump, "-a", "/W/CLASS", "-a", "/W/EXTDIM", "-a", "/PYTABLES_FORMAT_VERSION", fname],
+                               capture_output=True, text=True, check=True).stdout
+        assert '"EARRAY"' in attrs and '"2.1"' in attrs
+        data = subprocess.run([h5dump, "-d", "/L", "-y", "-w", "200", fname], capture_output=True, text=True, check=True).stdout
+        assert "-100, -99, -98, -97, -96" in data
+
+
+def test_gsc_resume_init_from_result_h5(tmp_path):
+    """GSC.resume_init (gsc_et.py:112-160): parameters of the last logged step, sigma_sq converted between noise types."""
+    at = _h5_or_skip()
+    from prosper_amd.em.camodels.gsc_et import GSC
+    from prosper_amd.utils.parallel import Comm
+    D, H = 6, 4
+    rs = np.random.RandomState(1)
+    steps = [{'W': rs.normal(size=(D, H)), 'pi': rs.uniform(0.1, 0.3, H), 'mu': rs.normal(size=H),
+              'psi_sq': np.eye(H) * (1 + t), 'sigma_sq': rs.uniform(0.5, 1.5, D)} for t in range(3)]
+    fname = str(tmp_path / "result.h5")
+    with at.AutoTable(fname) as tbl:
+        for p in steps:
+            tbl.append_all(p)
+    try:
+        for kind, want in (('diagonal', steps[-1]['sigma_sq']), ('scalar', steps[-1]['sigma_sq'].mean()),
+                           ('full', np.diag(steps[-1]['sigma_sq']))):
+            m = GSC.__new__(GSC)                      # host-only: no device needed for reading parameters back
+            m.D, m.H, m.sigma_sq_type, m.comm = D, H, kind, Comm()
+            p = GSC.resume_init.__wrapped__(m, fname) if hasattr(GSC.resume_init, "__wrapped__") else m.resume_init(fname)
+            np.testing.assert_array_equal(p['W'], steps[-1]['W'])
+            np.testing.assert_array_equal(p['psi_sq'], steps[-1]['psi_sq'])
+            np.testing.assert_allclose(p['sigma_sq'], want)
+    finally:
+        pass
