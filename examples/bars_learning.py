@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reference's bars test (examples/barstests/bars-learning.py + param-bars-*.py) on the MI355X path.
 
-    python examples/bars_learning.py [bsc|mca|mmca|dsc|tsc|gsc] [--steps 50] [--N 2000]
+    python examples/bars_learning.py [bsc|mca|mmca|dsc|tsc|gsc] [--steps 50] [--N 2000] [--h5]
 
 Generates bars data from ground-truth parameters, runs the annealed EM loop through the drop-in classes and
 reports how well the learned dictionary matches the bars (mean absolute error after the best permutation).
@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--N", type=int, default=2000)
     ap.add_argument("--size", type=int, default=5)
+    ap.add_argument("--h5", action="store_true", help="store every parameter and the objective per EM step in "
+                    "output/<script>.<date>/result.h5, as the reference's bars-learning.py does")
     a = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
@@ -77,8 +79,19 @@ def main():
     anneal['Ncut_factor'] = [(0, 0.), (2. / 3, 1.)]
     anneal['anneal_prior'] = False
     log = dlog.set_handler(('L', 'Q'), StoreInMemory)
+    store = None
+    if a.h5:
+        from prosper_amd.utils import create_output_path
+        from prosper_amd.utils.datalog import StoreToH5
+        out_dir = create_output_path("bars_learning_" + a.model, comm=comm)
+        store = dlog.set_handler(('W', 'pi', 'sigma', 'sigma_sq', 'mu', 'psi_sq', 'L', 'Q', 'N_use', 'T'), StoreToH5,
+                                 out_dir + "result.h5")
     em = EM(model=model, anneal=anneal, data={'y': my_data['y']}, lparams=init)
     em.run()
+    if store is not None:
+        store.close()
+        if comm.rank == 0:
+            print("parameters of every EM step in %sresult.h5" % out_dir)
     W = np.asarray(em.lparams['W'])
     W_gt = np.asarray(gt['W'])
     if a.model == "gsc":      # the scale of a column trades against the scale of its latent: compare shapes
