@@ -274,3 +274,44 @@ def test_gsc_em_loop_speculation_is_transparent():
             assert m.spec_hits == 0
     for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
         np.testing.assert_allclose(runs[0][k], runs[1][k], rtol=1e-8, atol=1e-11, err_msg=k)
+
+
+def test_config4_full_shard_against_oracle():
+    """BASELINE config 4 at its real size -- D=256 H=128 H'=6 gamma=3, N = 200 000 -- through the shipped launches.
+    The oracle runs on ~400 sampled rows: candidates identical, posterior moments xpt_s / xpt_sz to 1e-9; the sampled rows
+    as a shard of their own reproduce the oracle's whole EM step (device M-step tail included)."""
+    from oracle import gsc_oracle as G
+    from prosper_amd.em.camodels.gsc_et import GSC
+    dev = torch.device("cuda", 0)
+    D, H, Hp, gamma, N = 256, 128, 6, 3, 200_000
+    gen = torch.Generator(device=dev).manual_seed(44)
+    W_gt = torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64)
+    Y = torch.empty(N, D, dtype=torch.float64, device=dev)
+    for lo in range(0, N, 50_000):
+        S = (torch.rand(50_000, H, generator=gen, device=dev) < 2.0 / H).to(torch.float64)
+        Z = S * (1.5 + torch.randn(50_000, H, generator=gen, device=dev, dtype=torch.float64))
+        Y[lo:lo + 50_000] = Z @ W_gt.t() + torch.randn(50_000, D, generator=gen, device=dev, dtype=torch.float64)
+    rng = np.random.RandomState(44)
+    p = {"W": W_gt.cpu().numpy() + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.4),
+         "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+    an = _An(T=1.0)
+    m = GSC(D, H, Hp, gamma, 'scalar')
+    cp = lambda q: {k: np.array(v, copy=True) for k, v in q.items()}
+    data = m.select_Hprimes(cp(p), {"y": Y})
+    ss = m.E_step(an, cp(p), data)
+    rows = np.unique(np.concatenate([rng.randint(0, N, size=300), np.arange(0, 48), np.arange(N - 48, N)]))
+    idx = torch.from_numpy(rows).to(dev)
+    y_s = Y[idx].cpu().numpy()
+    model = G.make_model(D, H, Hp, gamma)
+    cand_ref = G.select_hprimes(p, y_s, Hp)
+    assert np.array_equal(data["candidates"].tensor[idx].cpu().numpy().astype(np.int64), cand_ref)
+    suff = G.e_step(G.Anneal(T=1.0), model, p, y_s, cand_ref)
+    np.testing.assert_allclose(ss["xpt_s"].tensor[idx].cpu().numpy(), suff["xpt_s"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ss["xpt_sz"].tensor[idx].cpu().numpy(), suff["xpt_sz"], rtol=1e-9, atol=1e-12)
+    new = m.M_step(an, cp(p), ss, data)
+    assert np.isfinite(new["W"]).all() and (new["pi"] > 0).all() and new["sigma_sq"] > 0
+    ref, log = G.em_step(G.Anneal(T=1.0), model, cp(p), y_s)
+    got = GSC(D, H, Hp, gamma, 'scalar').step(an, cp(p), {"y": y_s})
+    tol = max(1e-8, 50 * np.linalg.cond(log["suff"]["xpt_szsz"].sum(0)) * np.finfo(float).eps)
+    for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=10 * tol, atol=tol * max(1.0, np.abs(ref[k]).max()), err_msg=k)

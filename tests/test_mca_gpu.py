@@ -193,3 +193,46 @@ def test_config5_properties():
     for k in ("W", "pi", "sigma", "Q"):
         np.testing.assert_allclose(new[k], new2[k], rtol=1e-9, atol=1e-12)
     assert np.isfinite(new["W"]).all() and 0 < new["pi"] < 1 and new["sigma"] > 0
+
+
+def test_config5_full_shard_against_oracle():
+    """BASELINE config 5 at one GPU's real share -- D=256 H=128 H'=8 gamma=3, N = 100 000 of the 800 000 -- through
+    the shipped launches (selection scores, fused E-step + M-statistics pass).  Datapoints are independent given the
+    parameters, so the vectorised oracle runs on ~500 sampled rows: candidate sets identical, log-joints to 1e-10;
+    the sampled rows as a shard of their own reproduce the oracle's whole EM step."""
+    from oracle import mca_oracle as M
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    dev = torch.device("cuda", 0)
+    D, H, Hp, gamma, N = 256, 128, 8, 3, 100_000
+    gen = torch.Generator(device=dev).manual_seed(55)
+    W_gt = torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64).abs() * 2 + 0.1
+    Y = torch.empty(N, D, dtype=torch.float64, device=dev)
+    for lo in range(0, N, 20_000):
+        S = torch.rand(20_000, H, generator=gen, device=dev) < 2.0 / H
+        Y[lo:lo + 20_000] = torch.where(S[:, None, :], W_gt[None, :, :].expand(20_000, D, H),
+                                        torch.zeros((), dtype=torch.float64, device=dev)).max(dim=2).values
+    Y += torch.randn(N, D, generator=gen, device=dev, dtype=torch.float64)
+    W0 = (W_gt * (1 + 0.1 * (2 * torch.rand(D, H, generator=gen, device=dev, dtype=torch.float64) - 1))).cpu().numpy()
+    params = {"W": W0, "pi": 2.0 / H, "sigma": 1.0}
+    an = _An(T=1.0)
+    m = MCA_ET(D, H, Hp, gamma)
+    data = m.select_Hprimes(dict(params), {"y": Y})
+    ss = m.E_step(an, dict(params), data)
+    assert ss["logpj"].fused is not None                      # the one-pass E-step + M-statistics kernel ran
+    rng = np.random.RandomState(5)
+    rows = np.unique(np.concatenate([rng.randint(0, N, size=400), np.arange(0, 64), np.arange(N - 64, N)]))
+    idx = torch.from_numpy(rows).to(dev)
+    y_s = Y[idx].cpu().numpy()
+    model = M.make_model(D, H, Hp, gamma)
+    cand_ref = M.select_hprimes_vec(W0, y_s, Hp)
+    cand = data["candidates"].tensor[idx].cpu().numpy()
+    assert np.array_equal(np.sort(cand, 1), np.sort(cand_ref, 1))
+    lp_ref = M.e_step_vec(M.Anneal(T=1.0), W0, params["pi"], params["sigma"], y_s, cand, model["SM"], model["state_abs"])
+    np.testing.assert_allclose(ss["logpj"].tensor[idx].cpu().numpy(), lp_ref, rtol=1e-10, atol=1e-9)
+    new = m.M_step(an, dict(params), ss, data)
+    assert np.isfinite(new["W"]).all() and 0 < new["pi"] < 1 and new["sigma"] > 0
+    # the sample as its own shard: a whole EM step against the oracle
+    ref, _ = M.em_step(M.Anneal(T=1.0), model, dict(params), y_s, vec=True)
+    got = MCA_ET(D, H, Hp, gamma).step(an, dict(params), {"y": y_s})
+    np.testing.assert_allclose(got["W"], ref["W"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose([got["pi"], got["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-9)
