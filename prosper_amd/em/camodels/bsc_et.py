@@ -49,8 +49,6 @@ class BSC_ET(DeviceCAModel):
         self._spec_ok = False    # the last M-step's seeded parameters were used as they were
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.fused_remainder = os.environ.get('PM_GEMM_FUSE_REMAINDER', '1') == '1'   # ragged last round inside the main launch
-        self.overlap_inverse = os.environ.get('PM_OVERLAP_INVERSE', '0') == '1'   # Wq inverse beside the statistics GEMM (no gain, see M_step)
-        self._inv_stream = None
         self._in_step = False
         self._spec_estep = None  # next step's E-step, launched by the M-step (_speculate_estep)
         self._anneal_sig = None  # annealing point of the previous step() (speculate only on a flat schedule)
@@ -214,14 +212,9 @@ class BSC_ET(DeviceCAModel):
         main = self._fused_rows(N)
         Pref = ctypes.byref(P) if P is not None else None
         cur = torch.cuda.current_stream(self.device)
-        side = None
-        if main < N:      # the ragged last round: split-K scores GEMM + row kernel on those rows (on a side stream beside the big launch it is slower: 2.01 vs 1.89 ms)
-            if os.environ.get("PM_FUSED_SIDE", "0") == "1":
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                side = self._side
-                side.wait_stream(cur)
-            st = ctypes.c_void_p((side or cur).cuda_stream)
+        if main < N:      # the ragged last round: split-K scores GEMM + row kernel on those rows, ahead of the big launch
+            # (on a side stream beside it they steal slots from whole rounds: 2.01 vs 1.89 ms per pass)
+            st = ctypes.c_void_p(cur.cuda_stream)
             off = lambda t, w=1: ctypes.c_void_p(t.data_ptr() + main * w * t.element_size()) if t is not None else None
             A = self._rest_scores(res, par, main, st)
             self._call("select_estep_rest", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
@@ -231,8 +224,6 @@ class BSC_ET(DeviceCAModel):
                    _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
                    S, self.gamma, Pref, main, Y8.shape[1], H, Hp, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse),
                    _ptr(mstats[0]) if mstats else None, H, _ptr(mstats[1]) if mstats else None, self.D, self._stream())
-        if side is not None:
-            cur.wait_stream(side)
         return main
 
     # ---- scores GEMM, then the fused, chunked select + E-step (two-kernel path) -------------------
@@ -635,25 +626,10 @@ class BSC_ET(DeviceCAModel):
             self._call("mstep_rows", "pm_bsc_mstep_rows_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand),
                       _ptr(tab["masks"]), S, _ptr(tab["pair_ptr"]), _ptr(tab["pair_states"]), tab["pair_len"],
                       ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats), st)
-        # Everything but Wp is final now, and the H x H inverse (0.31 ms, one workgroup) needs only the (all-reduced)
-        # second moments.  PM_OVERLAP_INVERSE=1 puts it on a high-priority side stream ahead of the statistics GEMM (and,
-        # on several ranks, all-reduces [Wq | qdiag | mus | scalars] there, Wp behind the GEMM).  Measured: no gain --
-        # the inverse's 1024-thread workgroup needs a whole CU's registers, the GEMM's workgroups refill every slot as it
-        # frees, so the inverse still starts when the GEMM has drained (4.88 vs 4.87 ms per EM iteration).  Off by default.
-        o_wq = _lib.load().pm_bsc_stats_offset_wq(H, D)
-        pre = None
-        split = ('W' in self.to_learn and H <= 256 and self.overlap_inverse)
-        if split:
-            cur = torch.cuda.current_stream(self.device)
-            if self._inv_stream is None:
-                self._inv_stream = torch.cuda.Stream(device=self.device, priority=-1)
-            side = self._inv_stream
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                comm.allreduce_device(stats[o_wq:])
-                lib = _lib.load()
-                o_qd, o_mus = lib.pm_bsc_stats_offset_qdiag(H, D), lib.pm_bsc_stats_offset_mus(H, D)
-                pre = self._invert_normal_matrix(stats[o_wq:o_qd].view(H, H), stats[o_qd:o_mus])
+        # (Everything but Wp is final here, and the H x H inverse needs only the second moments -- but putting it on a
+        # high-priority side stream ahead of the statistics GEMM gains nothing: its 1024-thread workgroup needs a whole
+        # CU's registers, the GEMM's workgroups refill every slot as it frees, so the inverse still starts when the GEMM
+        # has drained; 4.88 vs 4.87 ms per EM iteration.  The warm-started inverse made the question moot.)
         if my_N:
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, st)
         need_mu = 'mu' in self.to_learn
@@ -665,18 +641,8 @@ class BSC_ET(DeviceCAModel):
             packed = stats
 
         # the exchange of the step (replaces bsc_et.py:225,258,266,373,374,387,417,426,427)
-        if split:
-            if need_mu:
-                wp_mu = torch.cat([stats[:o_wq], data_sum])
-                comm.allreduce_device(wp_mu)
-                packed[:o_wq] = wp_mu[:o_wq]
-                packed[stats.numel():] = wp_mu[o_wq:]
-            else:
-                comm.allreduce_device(packed[:o_wq])
-            cur.wait_stream(side)
-        else:
-            comm.allreduce_device(packed)
-        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res, pre, anneal)
+        comm.allreduce_device(packed)
+        return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res, None, anneal)
 
     def _scalar_updates(self, host, pies, sigma, E_pi_gamma):
         """pi and sigma updates (bsc_et.py:393-420) from the head of the downloaded statistics, ``host`` =
