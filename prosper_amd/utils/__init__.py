@@ -1,37 +1,35 @@
 """Host-side utilities the hot path touches: communicator, data log, trace points."""
-import errno
+import itertools
 import os
 import sys
-import time as tm
+import time
+
+
+def _job_suffix():
+    """``d<JOBID>`` under a batch scheduler (PBS, SLURM), else the wall-clock minute."""
+    pbs, slurm = os.environ.get('PBS_JOBID'), os.environ.get('SLURM_JOBID')
+    if pbs:
+        return "d" + pbs.split('.')[0]
+    if slurm:
+        return "d" + slurm
+    return time.strftime("%Y-%m-%d+%H:%M")
 
 
 def create_output_path(basename=None, comm=None):
-    """Create ``output/<BASENAME>.<suffix>`` without ever reusing a directory (prosper/utils/__init__.py:17-68): the
-    suffix is ``d<JOBID>`` under PBS / SLURM, else date and time; an existing directory gets ``+N`` appended.  Rank 0
-    creates it, every rank gets the path (with a trailing slash, as upstream)."""
+    """A fresh directory ``output/<basename>.<suffix>[+N]/`` for a run's results (what the reference's
+    ``create_output_path`` provides, prosper/utils/__init__.py:17-68): ``basename`` defaults to the running script, the
+    suffix names the batch job or the time, and ``+N`` is appended until the name is unused, so nothing is ever
+    overwritten.  Rank 0 creates it; every rank gets the same path, with a trailing slash."""
     from .parallel import COMM_WORLD
     comm = COMM_WORLD if comm is None else comm
-    dirname = None
+    path = None
     if comm.rank == 0:
-        if basename is None:
-            basename = sys.argv[0]
-        if 'PBS_JOBID' in os.environ:
-            suffix = "d" + os.environ['PBS_JOBID'].split('.')[0]
-        elif 'SLURM_JOBID' in os.environ:
-            suffix = "d" + os.environ['SLURM_JOBID']
-        else:
-            suffix = tm.strftime("%Y-%m-%d+%H:%M")
-        counter = 0
-        dirname = "output/%s.%s" % (basename, suffix)
-        while True:
+        stem = "output/%s.%s" % (sys.argv[0] if basename is None else basename, _job_suffix())
+        for n in itertools.count():
+            path = stem if n == 0 else "%s+%d" % (stem, n)
             try:
-                os.makedirs(dirname)
-            except OSError as e:
-                if e.errno != errno.EEXIST:
-                    raise
-                counter += 1
-                dirname = "output/%s.%s+%d" % (basename, suffix, counter)
-            else:
+                os.makedirs(path)
                 break
-    dirname = comm.bcast(dirname)
-    return dirname + "/"
+            except FileExistsError:
+                continue
+    return comm.bcast(path) + "/"
