@@ -1,12 +1,59 @@
-"""Soak: 400 EM steps of BSC config 2 through EM.run semantics (step loop), L must not decrease at T=1."""
-import sys, time, numpy as np, torch
-sys.path.insert(0,'.')
-exec(open('scratch/em_loop.py').read().split("for _ in range(3): m.step")[0])
-from prosper_amd.utils.datalog import dlog, StoreInMemory
-h=dlog.set_handler(("L",), StoreInMemory)
-q=dict(p); t=time.perf_counter()
-for i in range(400): q=m.step(an,q,data)
-torch.cuda.synchronize(); dt=time.perf_counter()-t
-L=np.array(h.tables["L"],dtype=float)
-print("400 steps %.2f s (%.2f ms/step); L first %.4f last %.4f; min diff %.3e; finite %s; sigma %.4f pi %.5f"%(dt,dt/400*1e3,L[0],L[-1],np.diff(L).min(),np.isfinite(q["W"]).all(),q["sigma"],q["pi"]))
-print("mem", torch.cuda.max_memory_allocated()/1e9, "GB")
+"""Long EM loops with and without the pipeline features (speculative E-step, warm-started inverse, M-statistics in the
+E-step pass): the trajectories must agree.  BSC at config-2 dimensions (N = 40k), GSC at config-4 dimensions (N = 40k)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+STEPS = int(os.environ.get("STEPS", 200))
+dev = torch.device("cuda", 0)
+class An(dict):
+    crit_params = []
+    def __missing__(self, k): return 0.0
+    def as_dict(self): return dict(self)
+
+def bsc(flags):
+    os.environ["PM_WARM_INVERSE"] = "1" if flags else "0"
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, g, N = 1024, 256, 8, 4, 40000
+    gen = torch.Generator(device=dev).manual_seed(0)
+    W_gt = torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64)
+    S = (torch.rand(N, H, generator=gen, device=dev) < 4.0 / H).to(torch.float64)
+    Y = S @ W_gt.t() + torch.randn(N, D, generator=gen, device=dev, dtype=torch.float64)
+    p = {"W": (W_gt + 0.3 * torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64)).cpu().numpy(), "pi": 2.0 / H, "sigma": 2.0}
+    m = BSC_ET(D, H, Hp, g)
+    m.speculate_estep = m.fuse_mstats = flags
+    t = time.perf_counter()
+    for it in range(STEPS):
+        T = 1.5 if it < 20 else (1.5 - 0.5 * (it - 20) / 30 if it < 50 else 1.0)
+        p = m.step(An(T=T, Ncut_factor=0.5 if 60 <= it < 70 else 0.0), p, {"y": Y})
+    torch.cuda.synchronize()
+    return p, getattr(m, "spec_hits", 0), (time.perf_counter() - t) / STEPS * 1e3
+
+def gsc(flags):
+    os.environ["PM_WARM_INVERSE"] = "1" if flags else "0"
+    from prosper_amd.em.camodels.gsc_et import GSC
+    D, H, Hp, g, N = 256, 128, 6, 3, 40000
+    gen = torch.Generator(device=dev).manual_seed(1)
+    W_gt = torch.randn(D, H, generator=gen, device=dev, dtype=torch.float64)
+    S = (torch.rand(N, H, generator=gen, device=dev) < 2.0 / H).to(torch.float64)
+    Y = (S * (1.5 + torch.randn(N, H, generator=gen, device=dev, dtype=torch.float64))) @ W_gt.t() + torch.randn(N, D, generator=gen, device=dev, dtype=torch.float64)
+    rng = np.random.RandomState(0)
+    p = {"W": W_gt.cpu().numpy() + 0.2 * rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.0), "psi_sq": np.eye(H), "sigma_sq": 2.0}
+    m = GSC(D, H, Hp, g, 'scalar')
+    m.speculate_estep = flags
+    m.fuse_moment_gemm = flags
+    t = time.perf_counter()
+    for it in range(STEPS):
+        p = m.step(An(T=1.3 if it < 30 else 1.0), p, {"y": Y})
+    torch.cuda.synchronize()
+    return p, m.spec_hits, (time.perf_counter() - t) / STEPS * 1e3
+
+for name, fn, keys in (("BSC", bsc, ("W", "pi", "sigma")), ("GSC", gsc, ("W", "pi", "mu", "psi_sq", "sigma_sq"))):
+    steps, STEPS = STEPS, 5
+    fn(True); fn(False)              # one-time costs (code objects, allocator pools) out of the clocks
+    STEPS = steps
+    a, hits, ms_a = fn(True)
+    b, _, ms_b = fn(False)
+    print(name, "steps", STEPS, "speculative hits", hits, "ms/step %.2f (features on) %.2f (off)" % (ms_a, ms_b))
+    for k in keys:
+        x, y = np.asarray(a[k], dtype=np.float64), np.asarray(b[k], dtype=np.float64)
+        print("   %-9s max rel diff %.2e   finite %s" % (k, np.abs(x - y).max() / max(np.abs(y).max(), 1e-300), np.isfinite(x).all()))
