@@ -602,6 +602,34 @@ def test_em_loop_with_speculative_estep(dev, D, H, Hp, gamma, N):
         np.testing.assert_allclose([pa, sa], [pb, sb], rtol=1e-10)
 
 
+def test_warm_inverse_is_transparent_across_unrelated_problems(dev):
+    """The W solve warm-starts from the model's previous inverse (pm_spd_inverse_warm_f64).  A model that is handed an
+    unrelated problem next (other data, other parameters: the start residual is large, the device falls back to the
+    exact sweep) and one that sees a slightly perturbed problem (refined, sweep skipped) both return what a fresh model
+    returns."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, gamma, N = 64, 40, 5, 3, 3000
+    rng = np.random.RandomState(3)
+
+    def problem(scale, seed):
+        r = np.random.RandomState(seed)
+        W_gt = scale * r.normal(size=(D, H))
+        y = (r.random_sample((N, H)) < 2.5 / H) @ W_gt.T + r.normal(size=(N, D))
+        return {"W": W_gt + 0.1 * r.normal(size=(D, H)), "pi": 2.5 / H, "sigma": 1.1}, y
+
+    pa, ya = problem(1.0, 1)
+    pb, yb = problem(3.0, 2)                     # unrelated
+    pc, yc = dict(pa, W=pa["W"] * (1 + 1e-3 * rng.normal(size=(D, H)))), ya     # close to the first
+    an = _An(T=1.0)
+    m = BSC_ET(D, H, Hp, gamma)
+    m.step(an, dict(pa), {"y": ya})
+    for p, y in ((pb, yb), (pc, yc), (pa, ya)):
+        got = m.step(an, dict(p), {"y": y})
+        ref = BSC_ET(D, H, Hp, gamma).step(an, dict(p), {"y": y})
+        np.testing.assert_allclose(got["W"], ref["W"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose([got["pi"], got["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-12)
+
+
 def test_config2_full_shard_against_oracle(dev):
     """BASELINE config 2 at its real size -- D=1024 H=256 H'=8 gamma=4, N = 200 000 on the bench's generator -- through
     the shipped launches (one fused E-step launch of 3125 tiles; with PM_FUSED=0: 196 608 rows of whole GEMM rounds +
