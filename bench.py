@@ -20,7 +20,8 @@ a bounded sample (rank 0, N=1 only), with the rate of one uncontended process an
 multi-threaded form beside it; `parity` compares the HIP path with the oracle's answer (minted by that same leg) after
 3 EM steps on a seeded sample at the bench's dimensions -- outside every timed region; `per_rank` lists every rank's
 own ms_per_step / em_iter_ms / all-reduce time / data seed; `other_models` adds the EM-iteration wall-clock, kernel
-times and rooflines of GSC (config 4) and MCA (config 5) on this GPU, measured after the headline (N=1 only;
+times and rooflines of GSC (config 4) and MCA (config 5), and the EM-iteration time of DSC and TSC, on this GPU, measured
+after the headline (N=1 only;
 `--no-other-models` skips it).
 """
 import argparse
@@ -158,6 +159,32 @@ def other_models(dev, Anneal, steps=20):
                                       "note": "f64 VALU issue roof of the powers alone (S*D per datapoint at 36 issue slots "
                                               "each, from the 78.6 TFLOP/s f64 vector rate); the kernel is instruction-latency "
                                               "bound at 2 wavefronts per SIMD (DESIGN 4.4); not an HBM or MFMA kernel"}
+        del m, Y
+        # --- the "next" models of SURVEY 8(f2) on the same skeleton: DSC (ternary latents) and TSC, D=256 H=128 H'=6
+        # gamma=3, N=100k (no BASELINE config names them; same shapes as configs 4 / 5)
+        from prosper_amd.em.camodels.dsc_et import DSC_ET
+        from prosper_amd.em.camodels.tsc_et import TSC_ET
+        N = 100_000
+        W_gt = torch.randn(Dm, Hm, generator=g, device=dev, dtype=torch.float64) * 2
+        Y = torch.empty(N, Dm, dtype=torch.float64, device=dev)
+        for lo in range(0, N, 25_000):
+            u = torch.rand(25_000, Hm, generator=g, device=dev)
+            S = (u < 1.0 / Hm).to(torch.float64) - (u > 1 - 1.0 / Hm).to(torch.float64)
+            Y[lo:lo + 25_000] = S @ W_gt.t() + torch.randn(25_000, Dm, generator=g, device=dev, dtype=torch.float64)
+        W0 = (W_gt + 0.1 * torch.randn(Dm, Hm, generator=g, device=dev, dtype=torch.float64)).cpu().numpy()
+        for name, m, p in (("dsc", DSC_ET(Dm, Hm, 6, 3, states=np.array([-1., 0., 1.])),
+                            {"W": W0, "pi": np.array([1.0 / Hm, 1 - 2.0 / Hm, 1.0 / Hm]), "sigma": 1.0}),
+                           ("tsc", TSC_ET(Dm, Hm, 6, 3), {"W": W0, "pi": 2.0 / Hm, "sigma": 1.0})):
+            t_warm = time.perf_counter()
+            while time.perf_counter() - t_warm < 0.3:
+                p = m.step(Anneal(T=1.0), p, {"y": Y})
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                p = m.step(Anneal(T=1.0), p, {"y": Y})
+            torch.cuda.synchronize()
+            out["%s_em_iter_ms" % name] = (time.perf_counter() - t) / steps * 1e3
+            out[name] = "%s D=256 H=128 H'=6 gamma=3, N=%d" % (type(m).__name__, N)
     except Exception as e:   # never lose the headline over the side measurements
         out["error"] = repr(e)
     gc.enable()
