@@ -579,6 +579,7 @@ def test_em_loop_with_speculative_estep(dev, D, H, Hp, gamma, N):
     for spec in (True, False):
         m = BSC_ET(D, H, Hp, gamma)
         m.speculate_estep = spec
+        m.speculate = True                            # (whatever PM_SPECULATE* say in the environment)
         h = dlog.set_handler(("L", "N_use"), StoreInMemory)
         p, trace = dict(params), []
         try:

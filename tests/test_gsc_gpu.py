@@ -254,7 +254,7 @@ def test_gsc_em_loop_speculation_is_transparent():
     runs = []
     for spec in (True, False):
         m = GSC(D, H, Hp, gamma, 'scalar')
-        m.speculate = spec
+        m.speculate = m.speculate_estep = spec        # (whatever PM_SPECULATE* say in the environment)
         p = {k: np.array(v, copy=True) for k, v in p0.items()}
         used = []
         for it in range(8):
