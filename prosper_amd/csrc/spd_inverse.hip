@@ -47,16 +47,42 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const double *__restr
             double r2 = 0.0;
             for (int q = 0; q < NMAX; ++q) r2 += s_g[q];
             s_skip = (r2 < guard_tol2) ? 1 : 0;           // (NaN compares false: the sweep runs)
-            if (s_skip && piv_b) {
-                piv_b[0] = 1.0;
-                piv_b[1] = 1.0;
-            }
         }
         __syncthreads();
         if (s_skip) {       // inv = (X + X^T) / 2: the next step's start and the solve both treat it as symmetric
             for (int e = threadIdx.x; e < n * n; e += 1024) {
                 const int i = e / n, j = e - i * n;
                 inv_b[(int64_t)i * ldo + j] = 0.5 * (refined[(int64_t)i * n + j] + refined[(int64_t)j * n + i]);
+            }
+            // Conditioning without the sweep, so that the caller's singularity test (smallest / largest pivot) still
+            // means something on a warm step: 1 / X_ii is the pivot row i would get if it were eliminated LAST (its
+            // Schur complement against all other rows), a lower bound of the pivot the sweep would report for it;
+            // every pivot is at most the matrix's own diagonal entry.  pivots = [min_i 1 / X_ii, max_i A_ii].
+            if (piv_b) {
+                __shared__ double s_lo[NMAX], s_hi[NMAX];
+                const double *up_b = upper + blockIdx.x * stride_in;
+                const double *da_b = diag_add ? diag_add + (int64_t)blockIdx.x * n : nullptr;
+                if (threadIdx.x < NMAX) {
+                    const int i = threadIdx.x;
+                    double lo = INFINITY, hi = 0.0;
+                    if (i < n) {
+                        const double x = refined[(int64_t)i * n + i];
+                        lo = (x > 0.0) ? 1.0 / x : -1.0;             // (a non-positive diagonal: "not positive definite")
+                        hi = up_b[(int64_t)i * ldu + i] + (da_b ? da_b[i] : 0.0);
+                    }
+                    s_lo[i] = lo;
+                    s_hi[i] = hi;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    double lo = INFINITY, hi = 0.0;
+                    for (int q = 0; q < NMAX; ++q) {
+                        lo = fmin(lo, s_lo[q]);
+                        hi = fmax(hi, s_hi[q]);
+                    }
+                    piv_b[0] = lo;
+                    piv_b[1] = hi;
+                }
             }
             return;
         }

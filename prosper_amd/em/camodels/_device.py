@@ -351,11 +351,12 @@ class DeviceCAModel(CAModel):
         another combination rule override it."""
         return self._mix_linear(s.to(torch.float64), model_params['W'])
 
-    def generate_data_device(self, model_params, my_N, seed=None):
+    def generate_data_device(self, model_params, my_N, seed=None, noise_on=True):
         g = self._gen(seed)
         s = self._draw_latents(model_params, my_N, g)
         y = self._superpose(model_params, s, g)
-        y += float(model_params['sigma']) * torch.randn(y.shape, generator=g, device=self.device, dtype=torch.float64)
+        if noise_on:
+            y += float(model_params['sigma']) * torch.randn(y.shape, generator=g, device=self.device, dtype=torch.float64)
         return {'y': DeviceArray(y), 's': DeviceArray(s)}
 
     def invalidate_data(self):

@@ -384,6 +384,7 @@ class BSC_ET(DeviceCAModel):
     def step(self, anneal, model_params, my_data):
         """CAModel.step (camodels/__init__.py:163-193); E_step knows that M_step follows with the same arguments."""
         self._in_step = True
+        self._par.pop("checked", None)        # the first look at W in every step is a full comparison (_same_W)
         sig = (anneal['T'], bool(anneal['anneal_prior']), anneal['Ncut_factor'], anneal['partial'])
         self._flat_schedule = (sig == self._anneal_sig)      # same annealing point as the previous step
         self._anneal_sig = sig
@@ -690,6 +691,10 @@ class BSC_ET(DeviceCAModel):
             if np.any(mu):   # Wp was accumulated against y, the reference uses y - mu
                 rhs = Wp - torch.outer(mus, torch.from_numpy(mu).to(packed.device))
             rhs = rhs.contiguous()
+            if early is not None and rhs.data_ptr() == Wp.data_ptr():
+                # the speculative E-step enqueued from then() zeroes and refills the statistics workspace `packed` views
+                # BEFORE the host has looked at the pivots: the host-lstsq fallback below must read its own copy
+                rhs = Wp.clone()
             X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, rhs, pre)
             parts += [status, X.reshape(-1)]
             if packed.is_cuda and res is not None:   # next step's W^T and Gram matrix are already here: no upload then
@@ -729,6 +734,7 @@ class BSC_ET(DeviceCAModel):
                     self._par = spec[0]
             else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host
                 self._a0 = None
+                self._winv_prev = None        # never warm-start the next inverse from a rejected one
                 with small_blas():
                     W_new = np.linalg.lstsq(Wq.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0]
             pos += 2 + H * D

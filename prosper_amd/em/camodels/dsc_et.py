@@ -113,7 +113,9 @@ class DSC_ET(DeviceCAModel):
         """Latents drawn per datapoint with ``np.random.choice(states, H, p=pi)``, y = s.W^T (+ noise);
         RNG stream as upstream (dsc_et.py:238-299).  ``device=True``: drawn on the GPU (DeviceCAModel.generate_data)."""
         if device:
-            return self.generate_data_device(model_params, my_N, seed)
+            if gs is not None or gp is not None:
+                raise ValueError("generate_data(device=True) draws its own latents: gs / gp need the host generator")
+            return self.generate_data_device(model_params, my_N, seed, noise_on=noise_on)
         D, H, states = self.D, self.H, self.states
         pi = model_params['pi']
         W = model_params['W'].T
@@ -405,6 +407,7 @@ class DSC_ET(DeviceCAModel):
                     self._seed_rec["W"] = W_new.transpose().copy()   # private snapshot of the W handed back
             else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host
                 self._seed_rec = None
+                self._winv_prev = None        # never warm-start the next inverse from a rejected one
                 with small_blas():
                     W_new = np.linalg.lstsq(Wq.cpu().numpy(), Wp.cpu().numpy(), rcond=None)[0]
             W_out = W_new.transpose()

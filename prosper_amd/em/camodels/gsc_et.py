@@ -568,6 +568,8 @@ class GSC(DeviceCAModel):
                 and piv[2] / piv[3] > 1e-12
             if good:        # well-conditioned SPD: use the device inverses; else LAPACK on the host as upstream
                 inverses = (tail[nHH:2 * nHH].reshape(H, H), tail[:nHH].reshape(H, H))    # (zz^-1, (ss + eps I)^-1)
+        if inverses is None:
+            self._inv_prev = None             # never warm-start the next inverses from rejected ones
         if inverses is None or W_given is None or not np.isfinite(W_given).all():
             W_given, self._seed, dev_params = None, None, None       # host fallback: whatever was speculated is void
         elif self._seed is not None:

@@ -366,6 +366,7 @@ class TSC_ET(DeviceCAModel):
                     self._seed_rec["W"] = W_new.transpose().copy()   # private snapshot of the W handed back
             else:   # singular Wq: the reference's pseudo-inverse (tsc_et.py:488)
                 self._seed_rec = None
+                self._winv_prev = None        # never warm-start the next inverse from a rejected one
                 with small_blas():
                     W_new = np.dot(np.linalg.pinv(Wq.cpu().numpy()), Wp.cpu().numpy())
             W_out = W_new.transpose()

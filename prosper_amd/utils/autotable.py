@@ -15,7 +15,9 @@ the library undoes shuffle + zlib itself) -- the basis of ``resume_params`` and 
 
 Same call surface as upstream for numeric data: ``append``, ``append_all``, ``assign``, ``close``, context manager,
 ``compression_level``.  Strings (upstream: VLArray of VLStringAtom, autotable.py:270-276) are stored as
-variable-length UTF-8 string datasets of the same extendable shape.
+variable-length UTF-8 string datasets of the same extendable shape -- readable by h5py / ``h5dump`` / this module, but
+NOT a PyTables VLArray (that is an H5T_VLEN of uint8 with a PSEUDOATOM attribute), so they carry no PyTables CLASS
+stamp: PyTables lists them as unknown leaves instead of misreading them.  Numeric tables are what upstream logs.
 """
 import ctypes
 import ctypes.util
@@ -93,7 +95,7 @@ class _Lib(object):
             "H5Dcreate2": (hid, [hid, cp, hid, hid, hid, hid, hid]), "H5Dopen2": (hid, [hid, cp, hid]),
             "H5Dclose": (ci, [hid]), "H5Dset_extent": (ci, [hid, hsp]), "H5Dget_space": (hid, [hid]),
             "H5Dget_type": (hid, [hid]), "H5Dwrite": (ci, [hid, hid, hid, hid, hid, vp]),
-            "H5Dread": (ci, [hid, hid, hid, hid, hid, vp]), "H5Dvlen_reclaim": (ci, [hid, hid, hid, vp]),
+            "H5Dread": (ci, [hid, hid, hid, hid, hid, vp]),
             "H5Tcopy": (hid, [hid]), "H5Tset_size": (ci, [hid, ctypes.c_size_t]), "H5Tclose": (ci, [hid]),
             "H5Tget_class": (ci, [hid]), "H5Tget_size": (ctypes.c_size_t, [hid]), "H5Tget_sign": (ci, [hid]),
             "H5Tis_variable_str": (ci, [hid]), "H5Tset_cset": (ci, [hid, ci]),
@@ -107,10 +109,24 @@ class _Lib(object):
         for name, (res, args) in protos.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        # variable-length read buffers are handed back through H5Treclaim (HDF5 >= 1.12) or the deprecated
+        # H5Dvlen_reclaim (absent from builds without deprecated symbols): resolved lazily, whichever exists
+        self.vlen_reclaim = None
+        for name in ("H5Treclaim", "H5Dvlen_reclaim"):
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = ci, [hid, hid, hid, vp]
+                self.vlen_reclaim = fn
+                break
         lib.H5Eset_auto2(0, None, None)             # errors are reported through return codes (-> exceptions below)
 
-    def glob_id(self, symbol):
-        return self.hid.in_dll(self.lib, symbol).value
+    def glob_id(self, symbol, *fallbacks):
+        for name in (symbol,) + fallbacks:
+            try:
+                return self.hid.in_dll(self.lib, name).value
+            except ValueError:
+                continue
+        raise IOError("HDF5: none of %s is exported by this libhdf5" % ", ".join((symbol,) + fallbacks))
 
     def native(self, dtype):
         names = {"float64": "H5T_NATIVE_DOUBLE_g", "float32": "H5T_NATIVE_FLOAT_g", "int64": "H5T_NATIVE_INT64_g",
@@ -221,7 +237,7 @@ class AutoTable(object):
         rank = 1 + len(shape)
         rows_per_chunk = max(1, min(1024, (64 * 1024) // row_bytes))
         space = _check(lib.H5Screate_simple(rank, _dims((0,) + shape), _dims((_UNLIMITED,) + shape)), "H5Screate_simple")
-        plist = _check(lib.H5Pcreate(self._h5.glob_id("H5P_CLS_DATASET_CREATE_ID_g")), "H5Pcreate")
+        plist = _check(lib.H5Pcreate(self._h5.glob_id("H5P_CLS_DATASET_CREATE_ID_g", "H5P_CLS_DATASET_CREATE_g")), "H5Pcreate")
         lib.H5Pset_chunk(plist, rank, _dims((rows_per_chunk,) + shape))
         if self.compression_level and dt is not str:
             lib.H5Pset_shuffle(plist)
@@ -229,9 +245,15 @@ class AutoTable(object):
         ds = _check(lib.H5Dcreate2(self._file, name.encode(), ftype, space, 0, plist, 0), "H5Dcreate2 " + name)
         lib.H5Pclose(plist)
         lib.H5Sclose(space)
-        for k, v in (("CLASS", "EARRAY" if dt is not str else "VLARRAY"), ("VERSION", "1.1"), ("TITLE", "")):
-            self._str_attr(ds, k, v)
-        self._int_attr(ds, "EXTDIM", 0)
+        if dt is not str:
+            for k, v in (("CLASS", "EARRAY"), ("VERSION", "1.1"), ("TITLE", "")):
+                self._str_attr(ds, k, v)
+            self._int_attr(ds, "EXTDIM", 0)
+        else:
+            # strings are a plain extendable dataset of variable-length UTF-8 strings (h5dump / h5py read it as such).
+            # PyTables' own VLArray(VLStringAtom) is an H5T_VLEN of uint8 + PSEUDOATOM, which this is NOT: no PyTables
+            # CLASS stamp, so PyTables sees an unknown node instead of misreading it.
+            self._str_attr(ds, "TITLE", "")
         self.tables[name] = [ds, shape, dt, 0, ftype if own_type else None]
         self.types[name] = str if dt is str else np.ndarray
 
@@ -381,8 +403,8 @@ def read_table(fname, name, rows=None):
             if count:
                 _check(lib.H5Dread(ds, ftype, mspace, fspace, 0, ptrs), "H5Dread " + name)
             out = np.array([(p or b"").decode("utf-8") for p in ptrs[:count]], dtype=object).reshape(out_shape)
-            if count:
-                lib.H5Dvlen_reclaim(ftype, mspace, 0, ptrs)
+            if count and h5.vlen_reclaim is not None:
+                h5.vlen_reclaim(ftype, mspace, 0, ptrs)
         else:
             out = np.empty(out_shape, dtype=dt)
             if out.size:

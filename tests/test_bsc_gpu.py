@@ -603,6 +603,47 @@ def test_em_loop_with_speculative_estep(dev, D, H, Hp, gamma, N):
         np.testing.assert_allclose([pa, sa], [pb, sb], rtol=1e-10)
 
 
+def test_host_lstsq_fallback_under_speculation(dev, monkeypatch):
+    """When the device solve is rejected (numerically singular Wq) the M-step falls back to LAPACK's lstsq on the host
+    -- AFTER the speculative next E-step has been enqueued, which zeroes and refills the statistics workspace the
+    right-hand side Wp lives in.  The fallback must read its own copy (round-2 advisor finding: it read zeros and
+    returned W ~ 0 silently).  The rejection is forced at steps 3 and 4 of a flat-schedule loop (the steps at which
+    the M-step speculates); same W as the loop that never speculates, and as the device solve of the same system."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, gamma, N = 64, 24, 5, 3, 4000
+    rng = np.random.RandomState(11)
+    W_gt = rng.normal(size=(D, H))
+    y = (rng.random_sample((N, H)) < 2.0 / H) @ W_gt.T + rng.normal(size=(N, D))
+    params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 2.0 / H, "sigma": 1.05}
+    an = _An(T=1.0)
+
+    def loop(spec, reject):
+        m = BSC_ET(D, H, Hp, gamma)
+        m.speculate, m.speculate_estep = True, spec
+        calls = {"n": 0}
+        real = BSC_ET._solve_ok
+
+        def solve_ok(*a):
+            calls["n"] += 1
+            return False if calls["n"] in reject else real(*a)
+        monkeypatch.setattr(m, "_solve_ok", solve_ok)
+        p, trace = dict(params), []
+        for _ in range(6):
+            p = m.step(an, p, {"y": y})
+            trace.append(np.array(p["W"]))
+        return trace, m.spec_hits
+
+    a, hits = loop(True, (3, 4))
+    b, _ = loop(False, (3, 4))
+    c, _ = loop(False, ())
+    if BSC_ET(D, H, Hp, gamma)._fused():
+        assert hits >= 1
+    for Wa, Wb, Wc in zip(a, b, c):
+        assert np.abs(Wa).max() > 0.1
+        np.testing.assert_allclose(Wa, Wb, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(Wa, Wc, rtol=1e-6, atol=1e-8)
+
+
 def test_warm_inverse_is_transparent_across_unrelated_problems(dev):
     """The W solve warm-starts from the model's previous inverse (pm_spd_inverse_warm_f64).  A model that is handed an
     unrelated problem next (other data, other parameters: the start residual is large, the device falls back to the
