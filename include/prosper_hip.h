@@ -238,6 +238,20 @@ int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double *Wt, int64
                            int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
                            double *expect, int64_t lde, double *stats, int64_t D_stats, void *stream);
 
+/* The same pass with the 8-wavefront tile (csrc/bsc_fused8.hip): a workgroup still owns 64 datapoints x all latents, but
+ * a wavefront accumulates 16 datapoints x 128 latents (<= 128 registers: four wavefronts per SIMD instead of two), wavefront
+ * pairs merge their top-H' lists and exchange partial maxima / sums through LDS.  Same arguments, outputs and reference
+ * lines (bsc_et.py:98-115, :119-192) as pm_bsc_estep_fused_f64.  Needs pm_bsc_fused8_supported(H, D, Hprime, S):
+ * 128 < H <= 256, Hprime <= 8, D a multiple of 8. */
+int pm_bsc_fused8_supported(int64_t H, int64_t D, int64_t Hprime, int64_t S);
+int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
+                            const double *ynorm2, const double *wmu, const double *ymu,
+                            const uint16_t *state_masks, const uint16_t *state_parents,
+                            const int32_t *size_offsets_host, int64_t S, int64_t gamma,
+                            const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
+                            int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
+                            double *expect, int64_t lde, double *stats, int64_t D_stats, void *stream);
+
 /* Fast-path twin of pm_bsc_mstep_rows_f64 (same outputs, same `stats` layout). */
 int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
                             const int32_t *cand, const uint16_t *state_masks, int64_t S,

@@ -57,6 +57,7 @@ class BSC_ET(DeviceCAModel):
         self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
         self.fuse_mstats = os.environ.get('PM_FUSE_MSTATS', '1') == '1'   # M-step row statistics inside the fused E-step
         self.use_fused = os.environ.get('PM_FUSED', '1') == '1'   # scores GEMM + select + E-step as ONE kernel (bsc_fused.hip)
+        self.fused_tile = os.environ.get('PM_FUSED_TILE', 'auto')     # '4' | '8' | 'auto': wavefronts per workgroup of the fused kernel
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
         self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
         self.max_chunk_rows = 1 << 20
@@ -220,7 +221,10 @@ class BSC_ET(DeviceCAModel):
             self._call("select_estep_rest", "pm_bsc_select_estep_f64", _ptr(A), H, _ptr(par["G"]), off(res["ynorm2"]),
                        _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S, self.gamma,
                        Pref, N - main, H, Hp, mode, off(cand, Hp), off(logpj, ldl), ldl, off(lse), st)
-        self._call("estep_fused", "pm_bsc_estep_fused_f64", _ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
+        D8 = Y8.shape[1]
+        tile8 = (self.fused_tile != '4' and mstats is None
+                 and bool(_lib.load().pm_bsc_fused8_supported(H, D8, Hp, S)))
+        self._call("estep_fused", "pm_bsc_estep_fused8_f64" if tile8 else "pm_bsc_estep_fused_f64", _ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
                    _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
                    S, self.gamma, Pref, main, Y8.shape[1], H, Hp, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse),
                    _ptr(mstats[0]) if mstats else None, H, _ptr(mstats[1]) if mstats else None, self.D, self._stream())

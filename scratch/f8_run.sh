@@ -1,0 +1,12 @@
+#!/bin/bash
+# run the harness over the variants present in scratch/libs (on the GPU box)
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/f8_run.log
+: > $OUT
+B=scratch/libs/f8_bench
+for v in "$@"; do
+  name=${v%%:*}; tile=${v#*:}; st=0
+  [ "$name" = "stamps" ] && st=1
+  timeout 120 $B scratch/libs/libpm_$name.so $tile 196608 20 $st 2>&1 | grep -v amdgpu.ids >> $OUT
+done
+cat $OUT

@@ -167,7 +167,11 @@ def test_spd_inverse_warm(dev, n, rel):
     np.testing.assert_array_equal(got, got.T)
     r0 = np.linalg.norm(np.eye(n) - Af @ prev.cpu().numpy())
     if r0 < 0.0999:
-        np.testing.assert_array_equal(pv, [1.0, 1.0])                 # refined, sweep skipped
+        # refined, sweep skipped: conditioning from the inverse's diagonal -- 1 / X_ii is row i's pivot if eliminated
+        # last (a lower bound of the sweep's smallest pivot), the largest pivot is at most the largest diagonal entry
+        d2 = np.diag(np.linalg.cholesky(Af)) ** 2
+        np.testing.assert_allclose(pv, [1.0 / np.diag(np.linalg.inv(Af)).max(), np.diag(Af).max()], rtol=1e-7)
+        assert pv[0] <= d2.min() * (1 + 1e-7) and pv[1] >= d2.max() * (1 - 1e-12)
         assert np.linalg.norm(np.eye(n) - Af @ got) < max(2.0 * r0 ** 8, 1e-11 * np.linalg.cond(Af))
     elif r0 > 0.1001:
         d2 = np.diag(np.linalg.cholesky(Af)) ** 2                     # the exact sweep ran
@@ -207,7 +211,8 @@ def test_spd_inverse_warm_batch(dev):
         got = inv[b].view(n, n).cpu().numpy()
         np.testing.assert_array_equal(got, got.T)
         assert np.linalg.norm(np.eye(n) - Af @ got) < 1e-9 * np.linalg.cond(Af)
-    np.testing.assert_array_equal(pv[:2], [1.0, 1.0])                  # refined
+    A0f = mats[0] + np.diag(dadd[0])                                    # refined: [min_i 1 / X_ii, max_i A_ii]
+    np.testing.assert_allclose(pv[:2], [1.0 / np.diag(np.linalg.inv(A0f)).max(), np.diag(A0f).max()], rtol=1e-7)
     d2 = np.diag(np.linalg.cholesky(mats[1] + np.diag(dadd[1]))) ** 2  # swept
     np.testing.assert_allclose(pv[2:], [d2.min(), d2.max()], rtol=1e-9)
 
