@@ -57,6 +57,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 #ifndef PM_F8_ABL
 #define PM_F8_ABL 0
 #endif
+//   -DPM_F8_SKIP=mask  timing-only ablations of the lean row passes (wrong results): 1 no ranking (keys, sort, pop
+//               rounds), 2 no multi-cause states, 4 no log-joint stores, 8 no log-sum-exp, 16 no barriers in the passes
+#ifndef PM_F8_SKIP
+#define PM_F8_SKIP 0
+#endif
 #ifdef PM_F8_STAMPS
 __device__ unsigned long long pm_f8_stamps[8192][8];
 #define F8_STAMP(slot)                                                                  \
@@ -671,10 +676,32 @@ struct StateSet {
 // LDS map of the lean passes (bytes from the workgroup's LDS base; aliases the ring)
 constexpr int T_SW = 0, T_EW = 2048, T_MUS = 4096, T_ST = 6144;
 constexpr int S_MAX8 = 160;                                   // states the tables are sized for
-constexpr int T_TAB = T_ST + 16 * S_MAX8, T_AREAS = T_TAB + 4 * S_MAX8;      // 8704, 9344
+constexpr int T_TAB = T_ST + 16 * S_MAX8, T_EXP = T_TAB + 4 * S_MAX8;        // 8704, 9344
+constexpr int T_EXPC = T_EXP + 1024, T_AREAS = T_EXPC + 64;                  // 10368, 10432
 constexpr int A_ROW = 0, A_P = 2048, A_WIN = 4096, A_MISC = 4160, AREA_BYTES = 4288;
-constexpr int LEAN_LDS_BYTES = T_AREAS + 16 * AREA_BYTES;     // 77952
+constexpr int LEAN_LDS_BYTES = T_AREAS + 16 * AREA_BYTES;     // 79040
 static_assert(LEAN_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+
+// e^x for x in [-708, 0] from LDS tables: E[j] = 2^(j/128) (128 doubles) and C = {128/ln2, 1.5 2^52, -ln2/128 hi, lo,
+// 1/120, 1/24, 1/6}.  x = k ln2/128 + r, e^r by a degree-5 polynomial, 2^(k/128) = 2^N E_j (pm_exp_tab of pm_common.h
+// with every constant read from LDS: 14 VALU instructions -- a literal f64 operand costs two v_mov each, and in the
+// fused kernel VALU instructions are the currency).  Relative error <= 2.3e-16.
+__device__ __forceinline__ double exp_lds(double x, const double *E, const double *C) {
+    const double c1 = C[1];
+    const double sh = fma(x, C[0], c1);
+    const int k = __double2loint(sh);
+    const double kf = sh - c1;
+    double r = fma(kf, C[2], x);
+    r = fma(kf, C[3], r);
+    double q = C[4];
+    q = fma(q, r, C[5]);
+    q = fma(q, r, C[6]);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    const double Ej = E[k & 127];
+    const double v = fma(Ej, r * q, Ej);
+    return __hiloint2double(__double2hiint(v) + ((k >> 7) << 20), __double2loint(v));
+}
 
 template <int STAGES, int HP, int GAMMA, bool FULL, bool MSTATS>
 __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
@@ -756,6 +783,17 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
         dst[2] = e4;
         dst[3] = 0;
     }
+    if (tid >= 384) {
+        const int j = tid - 384;                                      // 128 threads: the exponential's tables
+        reinterpret_cast<double *>(smem + T_EXP)[j] = pm_powtab_dev[256 + j];
+        if (j < 7) {
+            const double c = j == 0 ? 184.6649652337873 : j == 1 ? 6755399441055744.0 : j == 2 ? -0.00541521234663378
+                           : j == 3 ? -1.4907929134926466e-12 : j == 4 ? 1.0 / 120.0 : j == 5 ? 1.0 / 24.0 : 1.0 / 6.0;
+            reinterpret_cast<double *>(smem + T_EXPC)[j] = c;
+        }
+    }
+    const double *expE = reinterpret_cast<const double *>(smem + T_EXP);
+    const double *expC = reinterpret_cast<const double *>(smem + T_EXPC);
 
     // ---- roles ----
     // accumulating role (MFMA layout): row fk of this wavefront = datapoint 16 rg + fk + 4 r in element r; its scores go
@@ -779,6 +817,16 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
     const double *swA = reinterpret_cast<const double *>(smem + T_SW) + j32;
     const double *ewA = reinterpret_cast<const double *>(smem + T_EW) + j32;
 
+    // Global addresses: a wave-uniform base per output (the tile's first row) + a 32-bit byte offset per lane.  Rows
+    // beyond N shadow the shard's last row: they recompute and rewrite exactly its values.
+    const int rows_left = (int)(N - m0 < AROWS ? N - m0 : AROWS);        // >= 1
+    const char *yn_t = reinterpret_cast<const char *>(ynorm2 + m0);
+    const char *ymu_t = ymu ? reinterpret_cast<const char *>(ymu + m0) : nullptr;
+    char *cand_t = reinterpret_cast<char *>(cand + m0 * HP);
+    char *out_t = reinterpret_cast<char *>(logpj + m0 * ldl);
+    const char *gram_b = reinterpret_cast<const char *>(gram);
+    const uint32_t ldl8 = (uint32_t)ldl * 8u, H8 = (uint32_t)H * 8u;
+
     // scores of pass 0 -> LDS
 #pragma unroll
     for (int i = 0; i < NJ; ++i) rowW[16 * i] = acc[i][0];
@@ -786,21 +834,23 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int64_t n = m0 + 16 * rg + fkM + 4 * r;
-        const bool live = n < N;
-        const int64_t nn = live ? n : N - 1;
-        double yn = ynorm2[nn];
-        if (ymu) yn = yn - 2.0 * ymu[nn] + P.mu_sqnorm;
-        lds_barrier();                           // the scores of pass r (and, r = 0, the tables) are in LDS
+        int lrow = 16 * rg + fkM + 4 * r;
+        const bool live = lrow < rows_left;
+        lrow = live ? lrow : rows_left - 1;
+        double yn = *reinterpret_cast<const double *>(yn_t + (uint32_t)lrow * 8u);
+        if (ymu_t) yn = yn - 2.0 * *reinterpret_cast<const double *>(ymu_t + (uint32_t)lrow * 8u) + P.mu_sqnorm;
+        if (!(PM_F8_SKIP & 16) || r == 0) lds_barrier();      // the scores of pass r (and, r = 0, the tables) are in LDS
         double a[NJ];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) a[i] = rowR[32 * i];
 
         // ---------------- select_Hprimes (bsc_et.py:98-115) ---------------------------------------------------------
         int myc = 0;
-        if (sel) {
+        if (PM_F8_SKIP & 1) {
+            myc = (j32 * 29 + (int)a[0]) & 255;
+        } else if (sel) {
             double key[NJ];
-            // scores are finite unless the datapoint or W is not: one test on |y|^2 (the tables' 1/|W_h| carry W's)
+            // scores are finite unless the datapoint or W is not
             bool odd = !(yn < 1.0e150);
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
@@ -843,10 +893,10 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
                 const uint64_t mb = (uint64_t)__double_as_longlong(win[HP - 1 - j32]);    // ascending: best last
                 const int code = (int)(mb & 0x3FFull);
                 myc = (mb >> 63) ? 0x3FF - code : code;
-                if (live) cand[n * HP + j32] = myc;
+                *reinterpret_cast<int32_t *>(cand_t + (uint32_t)(lrow * HP + j32) * 4u) = myc;
             }
         } else if (j32 < HP) {
-            myc = cand[nn * HP + j32];
+            myc = *reinterpret_cast<const int32_t *>(cand_t + (uint32_t)(lrow * HP + j32) * 4u);
         }
         // the candidates' scores, then the row areas are free for the next pass's scores
         double ac = 0.0;
@@ -854,7 +904,7 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
             ac = reinterpret_cast<const double *>(area + A_ROW)[myc];
             cl[j32] = myc;
         }
-        lds_barrier();
+        if (!(PM_F8_SKIP & 16)) lds_barrier();
         if (r + 1 < 4) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i) rowW[16 * i] = acc[i][r + 1 < 4 ? r + 1 : 3];
@@ -863,26 +913,30 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
 
         // ---------------- E_step (bsc_et.py:119-192) -----------------------------------------------------------------
         // Gram block of the candidates: lane j32 fetches G[c_i, c_k] and G[c_(i+4), c_k], i = j32 >> 3, k = j32 & 7
-        const int ck = cl[j32 & 7], ci0 = cl[j32 >> 3], ci1 = cl[4 + (j32 >> 3)];
-        const double G0 = gram[(unsigned)(ci0 * H + ck)], G1 = gram[(unsigned)(ci1 * H + ck)];
+        const uint32_t ck8 = (uint32_t)cl[j32 & 7] * 8u;
+        const uint32_t ci0 = (uint32_t)cl[j32 >> 3], ci1 = (uint32_t)cl[4 + (j32 >> 3)];
+        const double G0 = *reinterpret_cast<const double *>(gram_b + (ci0 * H8 + ck8));
+        const double G1 = *reinterpret_cast<const double *>(gram_b + (ci1 * H8 + ck8));
         double wmuc = 0.0;
         if (wmu && j32 < HP) wmuc = wmu[myc];
         // singleton log-joints meanwhile: f_h = prior + ecoef (|W_h|^2 - 2 a_h + |y|^2)
-        double *out = logpj + nn * ldl;
+        char *out = out_t + ((uint32_t)lrow * ldl8 + (uint32_t)j32 * 8u);        // &logpj[n, j32]
         const double f0 = ecoef * yn;
         double mx = f0;
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
             const int h = j32 + 32 * i;
             double f = -1.0e300;     // no latent: never the maximum, never counted
-            if (FULL || h < H) {
-                f = fma(m2e, a[i], ewA[32 * i]) + f0;
-                if (live) out[1 + h] = f;
-            }
+            if (FULL || h < H) f = fma(m2e, a[i], ewA[32 * i]) + f0;
             a[i] = f;
             mx = vmax64(mx, f);
         }
-        if (j32 == 0 && live) out[0] = f0;
+        if (!(PM_F8_SKIP & 4)) {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+                if (FULL || j32 + 32 * i < H) *reinterpret_cast<double *>(out + 8 * (1 + 32 * i)) = a[i];
+            if (j32 == 0) *reinterpret_cast<double *>(out) = f0;
+        }
         Pm[9 + j32] = G0;
         Pm[9 + 32 + j32] = G1;
         wave_lds_sync16();
@@ -890,16 +944,17 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
         if (j32 == 0) Pm[0] = 0.0;
         wave_lds_sync16();
         // multi-cause states by size: e(s) = e(parent) + d_k + 2 (G terms)
-        double *outS = out + 1 + H + j32;
+        char *outS = out + 8 * (1 + H);
+        double fs[SS::iters(2) + SS::iters(3) + (GAMMA >= 4 ? SS::iters(4) : 0)];
+        int nf = 0;
 #pragma unroll
         for (int g = 2; g <= GAMMA; ++g) {
             const double pg = ppil * (double)g;
 #pragma unroll
             for (int k = 0; k < SS::iters(g); ++k) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int s0 = SS::off(g) + 32 * k;                     // + j32 = this lane's state
-                if (32 * (k + 1) <= SS::cnt(g) || j32 < SS::cnt(g) - 32 * k) {
+                double f = -1.0e300;
+                if (!(PM_F8_SKIP & 2) && (32 * (k + 1) <= SS::cnt(g) || j32 < SS::cnt(g) - 32 * k)) {
                     const uint32_t *t = stA + 4 * s0;
                     const uint32_t t01 = t[0], t23 = t[1], t4 = t[2];
                     const double e = (*reinterpret_cast<const double *>(Pb + (t01 & 0xFFFFu)) +
@@ -908,45 +963,36 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
                                              *reinterpret_cast<const double *>(Pb + (t23 >> 16))) +
                                             *reinterpret_cast<const double *>(Pb + t4));
                     PeA[s0] = e;
-                    const double f = fma(ecoef, yn + e, pg);
-                    if (live) outS[s0] = f;
-                    mx = vmax64(mx, f);
+                    f = fma(ecoef, yn + e, pg);
+                    if (!(PM_F8_SKIP & 4)) *reinterpret_cast<double *>(outS + 8 * s0) = f;
                 }
+                fs[nf++] = f;
+                mx = vmax64(mx, f);
             }
             wave_lds_sync16();
         }
         if (!lse) continue;
+        if (PM_F8_SKIP & 8) {
+            if (mx == 1.2345e300) lse[0] = mx;
+            continue;
+        }
         // ---------------- log-sum-exp: only terms within exp(-37) of the largest are evaluated ----------------------
         mx = half_max_f64(mx);
         const double thr = mx + NEGLIGIBLE;
         double sum = 0.0;
         {
             const bool need = (j32 == 0) && f0 > thr;
-            if (__any(need)) sum = need ? exp_neg(f0 - mx) : 0.0;
+            if (__any(need)) sum = need ? exp_lds(f0 - mx, expE, expC) : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
             const bool need = a[i] > thr;
-            if (__any(need)) sum += need ? exp_neg(a[i] - mx) : 0.0;
+            if (__any(need)) sum += need ? exp_lds(a[i] - mx, expE, expC) : 0.0;
         }
-        {
-            const double inv_ecoef = 1.0 / ecoef;
 #pragma unroll
-            for (int g = 2; g <= GAMMA; ++g) {
-                const double pg = ppil * (double)g;
-                const double te = (thr - pg) * inv_ecoef - yn;
-#pragma unroll
-                for (int k = 0; k < SS::iters(g); ++k) {
-                    const int s0 = SS::off(g) + 32 * k;
-                    const bool mine = 32 * (k + 1) <= SS::cnt(g) || j32 < SS::cnt(g) - 32 * k;
-                    const double e = PeA[mine ? s0 : SS::off(g)];
-                    const bool need = mine && (ecoef < 0.0 ? e < te : e > te);
-                    if (__any(need)) {
-                        const double f = fma(ecoef, yn + e, pg);
-                        sum += (need && f > thr) ? exp_neg(f - mx) : 0.0;
-                    }
-                }
-            }
+        for (int q = 0; q < nf; ++q) {
+            const bool need = fs[q] > thr;
+            if (__any(need)) sum += need ? exp_lds(fs[q] - mx, expE, expC) : 0.0;
         }
         sum = half_sum_f64(sum);
         if (j32 == 0) {
@@ -959,8 +1005,8 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
         wave_lds_sync16();
         const int rr = j32 & 3;
         const double lse_n = mxs[rr] + log_ge1(sms[rr]);
-        const int64_t n = m0 + 16 * rg + fkM + 4 * rr;
-        if (j32 < 4 && n < N) lse[n] = lse_n;
+        const int lrow = 16 * rg + fkM + 4 * rr;
+        if (j32 < 4 && lrow < rows_left) lse[m0 + lrow] = lse_n;
     }
     F8_STAMP(3);
     F8_STAMP(4);
@@ -968,6 +1014,7 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
     (void)lde;
     (void)stats;
     (void)Dstats;
+    (void)PeA;
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
