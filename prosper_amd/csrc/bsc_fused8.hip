@@ -677,9 +677,9 @@ struct StateSet {
 constexpr int T_SW = 0, T_EW = 2048, T_MUS = 4096, T_ST = 6144;
 constexpr int S_MAX8 = 160;                                   // states the tables are sized for
 constexpr int T_TAB = T_ST + 16 * S_MAX8, T_EXP = T_TAB + 4 * S_MAX8;        // 8704, 9344
-constexpr int T_EXPC = T_EXP + 1024, T_AREAS = T_EXPC + 64;                  // 10368, 10432
+constexpr int T_EXPC = T_EXP + 1024, T_AREAS = T_EXPC + 192;                 // 10368, 10560 (EXPC: 7 constants; 24 doubles at the end)
 constexpr int A_ROW = 0, A_P = 2048, A_WIN = 4096, A_MISC = 4160, AREA_BYTES = 4288;
-constexpr int LEAN_LDS_BYTES = T_AREAS + 16 * AREA_BYTES;     // 79040
+constexpr int LEAN_LDS_BYTES = T_AREAS + 16 * AREA_BYTES;     // 79168
 static_assert(LEAN_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 
 // e^x for x in [-708, 0] from LDS tables: E[j] = 2^(j/128) (128 doubles) and C = {128/ln2, 1.5 2^52, -ln2/128 hi, lo,
@@ -826,6 +826,12 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
     char *out_t = reinterpret_cast<char *>(logpj + m0 * ldl);
     const char *gram_b = reinterpret_cast<const char *>(gram);
     const uint32_t ldl8 = (uint32_t)ldl * 8u, H8 = (uint32_t)H * 8u;
+    // M-step statistics (MSTATS): E[s] rows, the candidates' second-moment block -> Wq, column sums, scalars
+    char *exp_t = MSTATS ? reinterpret_cast<char *>(expect + m0 * lde) : nullptr;
+    double *wq = MSTATS ? stats + pm_bsc_stats_offset_wq_dev(H, Dstats) : nullptr;
+    double *t_mus = reinterpret_cast<double *>(smem + T_MUS);
+    const uint32_t *t_tab = reinterpret_cast<const uint32_t *>(smem + T_TAB);
+    double m_sig = 0.0, m_fs = 0.0, m_cnt = 0.0;        // per-lane partial sums of the scalar statistics
 
     // scores of pass 0 -> LDS
 #pragma unroll
@@ -979,25 +985,105 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
         // ---------------- log-sum-exp: only terms within exp(-37) of the largest are evaluated ----------------------
         mx = half_max_f64(mx);
         const double thr = mx + NEGLIGIBLE;
-        double sum = 0.0;
+        double sum = 0.0, qe = 0.0;       // qe: sum of exp(f - mx) (f - prior) = ecoef sum of exp(.) e   (MSTATS)
         {
             const bool need = (j32 == 0) && f0 > thr;
-            if (__any(need)) sum = need ? exp_lds(f0 - mx, expE, expC) : 0.0;
+            if (__any(need)) {
+                sum = need ? exp_lds(f0 - mx, expE, expC) : 0.0;
+                if (MSTATS) qe = sum * f0;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) {
+        for (int i = 0; i < NJ; ++i) {      // MSTATS: a[i] becomes exp(f - mx) of a term that counts, else 0
             const bool need = a[i] > thr;
-            if (__any(need)) sum += need ? exp_lds(a[i] - mx, expE, expC) : 0.0;
+            double ex = 0.0;
+            if (__any(need)) {
+                ex = need ? exp_lds(a[i] - mx, expE, expC) : 0.0;
+                sum += ex;
+                if (MSTATS) qe = need ? fma(ex, a[i] - ppil, qe) : qe;
+            }
+            if (MSTATS) a[i] = ex;
         }
+        {
+            int q = 0;
 #pragma unroll
-        for (int q = 0; q < nf; ++q) {
-            const bool need = fs[q] > thr;
-            if (__any(need)) sum += need ? exp_lds(fs[q] - mx, expE, expC) : 0.0;
+            for (int g = 2; g <= GAMMA; ++g) {
+#pragma unroll
+                for (int k = 0; k < SS::iters(g); ++k, ++q) {
+                    const bool need = fs[q] > thr;
+                    double ex = 0.0;
+                    if (__any(need)) {
+                        ex = need ? exp_lds(fs[q] - mx, expE, expC) : 0.0;
+                        sum += ex;
+                        if (MSTATS) qe = need ? fma(ex, fs[q] - ppil * (double)g, qe) : qe;
+                    }
+                    if (MSTATS) fs[q] = ex;
+                }
+            }
         }
         sum = half_sum_f64(sum);
         if (j32 == 0) {
             mxs[r] = mx;
             sms[r] = sum;
+        }
+        if (MSTATS) {
+            // posterior weights q = exp(f - mx) / sum (bsc_et.py:271-272) and what the M-step takes from them
+            // (bsc_et.py:334-366, 395-415); rows beyond N (shadows of the last row) contribute nothing
+            double inv = __builtin_amdgcn_rcp(sum);
+            inv = fma(fma(-sum, inv, 1.0), inv, inv);
+            inv = fma(fma(-sum, inv, 1.0), inv, inv);
+            if (live) m_sig += qe * inv;
+            // add[h]: the multi-cause states' share of E[s_h], gathered per candidate in LDS (P is free by now)
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) Pm[j32 + 32 * i] = 0.0;
+            wave_lds_sync16();
+            {
+                int q = 0;
+#pragma unroll
+                for (int g = 2; g <= GAMMA; ++g) {
+#pragma unroll
+                    for (int k = 0; k < SS::iters(g); ++k, ++q) {
+                        const double ex = fs[q];
+                        if (__any(ex != 0.0)) {
+                            if (ex != 0.0) {
+                                const double w = ex * inv;
+                                unsigned mi = t_tab[SS::off(g) + 32 * k + j32] & 0xFFFFu;
+                                while (mi) {     // E[s_i s_k] += weight for every pair i <= k of the state
+                                    const int i = __builtin_ctz(mi);
+                                    mi &= mi - 1;
+                                    const int ci = cl[i];
+                                    atomicAdd(&Pm[ci], ex);
+                                    if (live) {
+                                        pm_atomic_add(wq + (int64_t)ci * H + ci, w);
+                                        unsigned mk = mi;
+                                        while (mk) {
+                                            const int kk = __builtin_ctz(mk);
+                                            mk &= mk - 1;
+                                            const int ck = cl[kk];
+                                            const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
+                                            pm_atomic_add(wq + (int64_t)lo * H + hi, w);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            wave_lds_sync16();
+            char *erow = exp_t + ((uint32_t)lrow * (uint32_t)lde * 8u + (uint32_t)j32 * 8u);
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const int h = j32 + 32 * i;
+                if (FULL || h < H) {
+                    const double v = (a[i] + Pm[h]) * inv;
+                    *reinterpret_cast<double *>(erow + 256 * i) = v;
+                    if (live && __any(v != 0.0)) {
+                        if (v != 0.0) atomicAdd(&t_mus[h], v);
+                    }
+                }
+            }
+            wave_lds_sync16();       // P is the next pass's list area
         }
     }
     if (est && lse) {
@@ -1006,15 +1092,42 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
         const int rr = j32 & 3;
         const double lse_n = mxs[rr] + log_ge1(sms[rr]);
         const int lrow = 16 * rg + fkM + 4 * rr;
-        if (j32 < 4 && lrow < rows_left) lse[m0 + lrow] = lse_n;
+        if (j32 < 4 && lrow < rows_left) {
+            lse[m0 + lrow] = lse_n;
+            m_fs += lse_n;
+            m_cnt += 1.0;
+        }
+    }
+    if (MSTATS) {
+        // column sums of E[s] and the scalar statistics of this tile -> packed statistics buffer
+        const double sig = pm_wave_sum(m_sig) / ecoef, fsum = pm_wave_sum(m_fs), cnt = pm_wave_sum(m_cnt);
+        double *red = reinterpret_cast<double *>(smem + T_EXPC) ;     // (the exponential's constants are done with)
+        lds_barrier();                       // every wavefront's LDS atomics into mus are done; nobody needs expC
+        if (lane == 0) {
+            red[wave] = sig;
+            red[8 + wave] = fsum;
+            red[16 + wave] = cnt;
+        }
+        lds_barrier();
+        double *sc = stats + pm_bsc_stats_offset_scalars_dev(H, Dstats);
+        if (tid < 3) {
+            double v = 0.0;
+            for (int w = 0; w < 8; ++w) v += red[8 * tid + w];
+            if (v != 0.0) pm_atomic_add(sc + tid, v);
+        }
+        double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, Dstats);
+        if (tid < H) {
+            const double v = t_mus[tid];
+            if (v != 0.0) pm_atomic_add(g_mus + tid, v);
+        }
     }
     F8_STAMP(3);
     F8_STAMP(4);
-    (void)expect;
-    (void)lde;
-    (void)stats;
-    (void)Dstats;
     (void)PeA;
+    (void)t_tab;
+    (void)t_mus;
+    (void)exp_t;
+    (void)wq;
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1064,7 +1177,7 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
                        (S > 0 && (!state_masks || !state_parents || !size_offsets_host))))
         return PM_EINVAL;
     if (!pm_bsc_fused8_supported(H, D, Hprime, S) || (mode & ~3)) return PM_ERANGE;
-    if (stats) return PM_ERANGE;                        // (M-statistics: the 4-wavefront tile)
+    if (stats && (!expect || lde < H || !lse || !(mode & 2) || D_stats <= 0)) return PM_EINVAL;
     if (!aligned16(Y) || !aligned16(Wt) || (ldy % 2) || (ldw % 2)) return PM_EINVAL;
     if (N == 0) return PM_OK;
     SizeOffsets so;
@@ -1086,14 +1199,22 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
                            gram, ynorm2, wmu, ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H,  \
                            (int)Hprime, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats);                \
     } while (0)
-#define PM_LAUNCH8S(G, F)                                                                                              \
+#define PM_LAUNCH8SM(G, F, M)                                                                                          \
     do {                                                                                                               \
-        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8s_kernel<4, 8, G, F, false>), \
+        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8s_kernel<4, 8, G, F, M>), \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_s))                \
             return e;                                                                                                  \
-        hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, false>), grid, block, shmem_s, s, Y, ldy, Wt, ldw,    \
+        hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, M>), grid, block, shmem_s, s, Y, ldy, Wt, ldw,        \
                            (int)D, gram, ynorm2, wmu, ymu, state_masks, state_parents, P, N, (int)H, mode, cand,      \
                            logpj, ldl, lse, expect, lde, stats, (int)D_stats);                                         \
+    } while (0)
+#define PM_LAUNCH8S(G, F)             \
+    do {                              \
+        if (stats) {                  \
+            PM_LAUNCH8SM(G, F, true); \
+        } else {                      \
+            PM_LAUNCH8SM(G, F, false);\
+        }                             \
     } while (0)
     // the lean passes: H' = 8 and the complete state set of sizes 2 .. gamma (what generate_state_matrix builds)
     const size_t shmem_s = sizeof(double) * 4 * STAGE > (size_t)LEAN_LDS_BYTES ? sizeof(double) * 4 * STAGE
@@ -1108,9 +1229,12 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
     } else if (lean_ok) {
         if (H == 256) PM_LAUNCH8S(3, true);
         else PM_LAUNCH8S(3, false);
+    } else if (stats) {
+        return PM_ERANGE;                               // (M-statistics ride on the lean passes only)
     } else if (H == 256) PM_LAUNCH8(true);
     else PM_LAUNCH8(false);
 #undef PM_LAUNCH8S
+#undef PM_LAUNCH8SM
 #undef PM_LAUNCH8
     return (int)hipGetLastError();
 }

@@ -222,8 +222,9 @@ class BSC_ET(DeviceCAModel):
                        _ptr(wmu), off(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"], S, self.gamma,
                        Pref, N - main, H, Hp, mode, off(cand, Hp), off(logpj, ldl), ldl, off(lse), st)
         D8 = Y8.shape[1]
-        tile8 = (self.fused_tile != '4' and mstats is None
-                 and bool(_lib.load().pm_bsc_fused8_supported(H, D8, Hp, S)))
+        # the 8-wavefront tile (bsc_fused8.hip) where it applies; its M-statistics ride on the lean passes (H' = 8)
+        tile8 = (self.fused_tile != '4' and bool(_lib.load().pm_bsc_fused8_supported(H, D8, Hp, S))
+                 and (mstats is None or (Hp == 8 and self.gamma in (3, 4))))
         self._call("estep_fused", "pm_bsc_estep_fused8_f64" if tile8 else "pm_bsc_estep_fused_f64", _ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
                    _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
                    S, self.gamma, Pref, main, Y8.shape[1], H, Hp, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse),
