@@ -388,7 +388,7 @@ int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse, d
  * Gaussian (spike-and-slab) Sparse Coding, scalar noise (prosper/em/camodels/gsc_et.py, GSC)
  * ------------------------------------------------------------------------------------- */
 
-/* Shapes the GSC kernel covers: H <= 512, gamma <= 4 (g x g systems solved in registers). */
+/* Shapes the GSC kernel covers: H <= 512, gamma <= 8 (g x g systems solved in registers; instantiated for 2, 3, 4, 6, 8). */
 int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma);
 
 /* stats (float64): [ sum_n xpt_ss, upper triangle, multi-cause part (H*H) |
@@ -427,6 +427,21 @@ int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, cons
                      int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
                      int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
                      double *stats, void *stream);
+
+/* The same pass, also writing every state's log-joint -- what GSC.compute_lpj returns (gsc_et.py:811-944): no
+ * annealing, prior odds included -- to logpj (N, ldl >= 1 + H + S): [null state ; singletons h = 0..H-1 ; multi-cause
+ * states in state_masks order], rows in datapoint order (the reference sorts its cluster order back, :942-944). */
+int pm_gsc_estep_lpj_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                         const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                         int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                         int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
+                         double *stats, double *logpj, int64_t ldl, void *stream);
+
+/* GSC.component_scores (gsc_et.py:752-809): singleton log-posteriors without the prior, clamped as the reference
+ * clamps them (NaN / below -DBL_MAX -> -DBL_MAX, +-inf -> 0), out (N, ldo >= H).  `scores`, `ynorm2`, `tables`
+ * (rows c0, c1, gm, il are read), `sigma_sq` (> 0) as for pm_gsc_estep_f64. */
+int pm_gsc_component_scores_f64(const double *scores, int64_t lds, const double *ynorm2, const double *tables,
+                                double sigma_sq, int64_t N, int64_t H, double *out, int64_t ldo, void *stream);
 
 #ifdef __cplusplus
 }

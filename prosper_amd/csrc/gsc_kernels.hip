@@ -129,7 +129,9 @@ struct GscTables {
     const double *lpi;   // log(pi_h) - log(1 - pi_h)
 };
 
-template <int VPL, int GMAX>
+// LPJ: also write every state's log-joint (no annealing, prior included -- what compute_lpj returns,
+// gsc_et.py:811-944) to logpj (N, 1 + H + S): [null ; singletons h = 0..H-1 ; multi-cause states in table order].
+template <int VPL, int GMAX, bool LPJ>
 __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict__ scores, int64_t lds,
                                                          const double *__restrict__ gram,
                                                          const double *__restrict__ psi,
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                                                          double inv_s2_host, int64_t N, int H, int Hp, int do_select,
                                                          int32_t *__restrict__ cand, double *__restrict__ xpt_s,
                                                          double *__restrict__ xpt_sz, int64_t ldx,
-                                                         double *__restrict__ stats) {
+                                                         double *__restrict__ stats, double *__restrict__ logpj,
+                                                         int64_t ldl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // 1 / sigma^2 from the host, or (0 there) from the ninth table row an M-step on the device has left
     const double inv_s2 = (inv_s2_host != 0.0) ? inv_s2_host : T.c0[8 * (int64_t)H];
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
 
         // ---- multi-cause states
         double Z = (j == 0) ? exp(-yn * inv_s2 * beta) : 0.0;       // null state
+        if (LPJ && live && j == 0) logpj[n * ldl] = -yn * inv_s2;
         for (int s0 = 0; s0 < S; s0 += 16) {
             const int s = s0 + j;
             const bool valid = s < S;
@@ -362,6 +366,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                 kap[r] = lb * inv_s2 + muv[r];
             }
             const double lp = -C_det - r2 * inv_s2 + quad * inv_s2 * inv_s2 + prior;
+            if (LPJ && live && valid) logpj[n * ldl + 1 + H + s] = lp;
             double p = exp(lp * beta);
             if (p != p || p < tiny) p = tiny;
             if (valid) Z += p;
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                 ai = arow2[h];
                 const double bb = ai - s_gm[h];
                 const double lp = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h] + s_lpi[h];
+                if (LPJ && live) logpj[n * ldl + 1 + h] = lp;
                 p = exp(lp * beta);
                 if (p != p || p < tiny) p = tiny;
                 Z += p;
@@ -516,7 +522,7 @@ static size_t gsc_shmem(int64_t H, int64_t Hprime, int64_t S) {
 }
 
 extern "C" int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma) {
-    if (H <= 0 || H > 512 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || Hprime > H || gamma < 1 || gamma > 4) return 0;
+    if (H <= 0 || H > 512 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || Hprime > H || gamma < 1 || gamma > 8) return 0;
     int64_t S = 0, c = Hprime;                       // multi-cause states: sum_{g=2..gamma} C(H', g)
     for (int64_t g = 2; g <= gamma && g <= Hprime; ++g) {
         c = c * (Hprime - g + 1) / g;
@@ -615,12 +621,13 @@ extern "C" int pm_gsc_mstep_finish_f64(const double *xs_xsz, const double *xsz_x
     return (int)hipGetLastError();
 }
 
-extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
-                                const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
-                                int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
-                                int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
-                                double *stats, void *stream) {
+static int gsc_estep_launch(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                            const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                            int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                            int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
+                            double *stats, double *logpj, int64_t ldl, void *stream) {
     if (N == 0) return PM_OK;
+    if (logpj && ldl < 1 + H + S) return PM_EINVAL;
     if (!scores || !gram || !psi_sq || !ynorm2 || !tables || !cand || !xpt_s || !xpt_sz || !stats || N < 0 || H <= 0 ||
         Hprime <= 0 || S < 0 || lds < H || ldx < H || (S > 0 && !state_masks) || !(sigma_sq >= 0.0))
         return PM_EINVAL;
@@ -634,18 +641,28 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
     dim3 grid((unsigned)groups), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double inv_s2 = sigma_sq > 0.0 ? 1.0 / sigma_sq : 0.0;   // 0: tables[8 H] holds it (pm_gsc_mstep_finish_f64)
-#define PM_LAUNCH(V, G)                                                                                             \
+#define PM_LAUNCH_L(V, G, L)                                                                                        \
     do {                                                                                                            \
-        if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G>), shmem)) return e;          \
-        hipLaunchKernelGGL((gsc_estep_kernel<V, G>), grid, block, shmem, s, scores, lds, gram, psi_sq, ynorm2, T,   \
+        if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, L>), shmem)) return e;       \
+        hipLaunchKernelGGL((gsc_estep_kernel<V, G, L>), grid, block, shmem, s, scores, lds, gram, psi_sq, ynorm2, T, \
                            state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select, cand, xpt_s, xpt_sz, \
-                           ldx, stats);                                                                             \
+                           ldx, stats, logpj, ldl);                                                                 \
+    } while (0)
+#define PM_LAUNCH(V, G)                 \
+    do {                                \
+        if (logpj) {                    \
+            PM_LAUNCH_L(V, G, true);    \
+        } else {                        \
+            PM_LAUNCH_L(V, G, false);   \
+        }                               \
     } while (0)
 #define PM_BY_G(V)                            \
     do {                                      \
         if (gamma <= 2) PM_LAUNCH(V, 2);      \
         else if (gamma == 3) PM_LAUNCH(V, 3); \
-        else PM_LAUNCH(V, 4);                 \
+        else if (gamma == 4) PM_LAUNCH(V, 4); \
+        else if (gamma <= 6) PM_LAUNCH(V, 6); \
+        else PM_LAUNCH(V, 8);                 \
     } while (0)
     if (H <= 16) PM_BY_G(1);
     else if (H <= 32) PM_BY_G(2);
@@ -655,6 +672,7 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
     else PM_BY_G(32);
 #undef PM_BY_G
 #undef PM_LAUNCH
+#undef PM_LAUNCH_L
     {
         const int64_t rows_per_block = 256;
         const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
@@ -665,5 +683,59 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
         hipLaunchKernelGGL(gsc_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xpt_s, xpt_sz, ldx, N, (int)H,
                            rows_per_block, g_cs, g_cs + H);
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                                const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                                int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                                int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
+                                double *stats, void *stream) {
+    return gsc_estep_launch(scores, lds, gram, psi_sq, ynorm2, tables, state_masks, S, gamma, beta, sigma_sq, N, H, Hprime,
+                            do_select, cand, xpt_s, xpt_sz, ldx, stats, nullptr, 0, stream);
+}
+
+extern "C" int pm_gsc_estep_lpj_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                                    const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                                    int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                                    int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
+                                    double *stats, double *logpj, int64_t ldl, void *stream) {
+    if (!logpj) return PM_EINVAL;
+    return gsc_estep_launch(scores, lds, gram, psi_sq, ynorm2, tables, state_masks, S, gamma, beta, sigma_sq, N, H, Hprime,
+                            do_select, cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, stream);
+}
+
+// component_scores (gsc_et.py:752-809): the singleton log-posterior of every latent WITHOUT the prior, with the
+// reference's clamps (NaN and values below the smallest double -> that double, +-inf -> 0), from the scores a = W^T y
+// (or (Sigma^-1 W)^T y for diagonal / full noise, as pm_gsc_estep_f64 takes them).
+namespace {
+__global__ __launch_bounds__(256) void gsc_component_scores_kernel(const double *__restrict__ scores, int64_t lds,
+                                                                    const double *__restrict__ ynorm2,
+                                                                    const double *__restrict__ tables, double inv_s2,
+                                                                    int64_t N, int H, double *__restrict__ out,
+                                                                    int64_t ldo) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= N * H) return;
+    const int64_t n = e / H;
+    const int h = (int)(e - n * H);
+    const double fmin_ = -1.7976931348623157e308;
+    const double ai = scores[n * lds + h];
+    const double bb = ai - tables[2 * (int64_t)H + h];
+    double v = tables[h] - ynorm2[n] * inv_s2 + tables[(int64_t)H + h] * ai + bb * bb * tables[3 * (int64_t)H + h];
+    if (v != v || v < fmin_) v = fmin_;
+    if (isinf(v)) v = 0.0;
+    out[n * ldo + h] = v;
+}
+}  // namespace
+
+extern "C" int pm_gsc_component_scores_f64(const double *scores, int64_t lds, const double *ynorm2, const double *tables,
+                                           double sigma_sq, int64_t N, int64_t H, double *out, int64_t ldo,
+                                           void *stream) {
+    if (N == 0) return PM_OK;
+    if (!scores || !ynorm2 || !tables || !out || N < 0 || H <= 0 || lds < H || ldo < H || !(sigma_sq > 0.0)) return PM_EINVAL;
+    const int64_t blocks = (N * H + 255) / 256;
+    if (blocks > INT32_MAX) return PM_ERANGE;
+    hipLaunchKernelGGL(gsc_component_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       scores, lds, ynorm2, tables, 1.0 / sigma_sq, N, (int)H, out, ldo);
     return (int)hipGetLastError();
 }

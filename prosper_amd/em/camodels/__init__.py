@@ -82,7 +82,8 @@ class CAModel(Model):
             return my_data
         sel = np.random.permutation(my_N)[:my_pN]
         sel.sort()
-        return {key: _take_rows(val, sel) for key, val in my_data.items()}
+        # (per-row entries only: a cluster dict left behind by an earlier GSC.select_Hprimes describes other rows)
+        return {key: _take_rows(val, sel) for key, val in my_data.items() if not isinstance(val, dict)}
 
     def check_params(self, model_params):
         return model_params

@@ -46,6 +46,55 @@ class SummedMoments(object):
         return self._total
 
 
+class LazyClusters(dict):
+    """``my_data['data_clusters']`` as the reference's ``select_Hprimes`` leaves it (gsc_et.py:731-747): one entry per
+    distinct sorted candidate set, keyed by ``str(candidates)``, holding ``'hprimes'`` (the set), ``'data'`` (its
+    datapoints, rows of y) and ``'ind'`` (their indices), in order of first appearance.  The kernels never need the
+    bucketing (they walk datapoints, not clusters), so it is built only when somebody looks: the first access runs the
+    selection pass and groups the rows on the host."""
+
+    def __init__(self, model, model_params, my_data):
+        dict.__init__(self)
+        self._build = (model, model_params, my_data)
+
+    def _fill(self):
+        if self._build is None:
+            return
+        (model, model_params, my_data), self._build = self._build, None
+        y = my_data['y']
+        y_host = np.asarray(y)
+        cands = np.asarray(model.candidates(model_params, {'y': y})).astype(np.int64)
+        for ind in range(cands.shape[0]):
+            key = str(cands[ind, :])
+            c = dict.get(self, key)
+            if c is None:
+                c = {'hprimes': cands[ind, :], 'data': [], 'ind': []}
+                dict.__setitem__(self, key, c)
+            c['data'].append(y_host[ind])
+            c['ind'].append(ind)
+        for c in dict.values(self):
+            c['data'] = np.array(c['data']).reshape((len(c['ind']), y_host.shape[1]))
+
+    def order(self):
+        """Datapoint indices in the reference's cluster order (the row order of its E_step outputs)."""
+        self._fill()
+        return np.concatenate([np.asarray(c['ind'], dtype=np.int64) for c in dict.values(self)]) if len(self) else \
+            np.zeros(0, dtype=np.int64)
+
+
+def _lazy(name):
+    def method(self, *a, **k):
+        self._fill()
+        return getattr(dict, name)(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _name in ('__getitem__', '__iter__', '__len__', '__contains__', 'keys', 'values', 'items', 'get', '__repr__',
+              '__eq__', 'copy'):
+    setattr(LazyClusters, _name, _lazy(_name))
+
+
 class GSC(DeviceCAModel):
     def __init__(self, D, H, Hprime=0, gamma=0, sigma_sq_type='scalar',
                  to_learn=['W', 'pi', 'mu', 'sigma_sq', 'psi_sq'], comm=parallel.COMM_WORLD, device=None):
@@ -78,6 +127,9 @@ class GSC(DeviceCAModel):
         self._in_step = False
         self._anneal_sig = None
         self._flat_schedule = False
+        # True: E_step returns its statistics and leaves my_data['y'] / ['candidates'] in the reference's cluster order
+        # (gsc_et.py:572-573) instead of datapoint order -- for callers that walk my_data['data_clusters'] alongside them
+        self.reference_order = False
 
     # ------------------------------------------------------------------ host-side mirror
     @tracing.traced
@@ -208,7 +260,7 @@ class GSC(DeviceCAModel):
         if self.sigma_sq_type not in ('scalar', 'diagonal', 'full'):
             raise _lib.HipError("GSC: unknown sigma_sq_type %r" % (self.sigma_sq_type,))
         if not _lib.load().pm_gsc_supported(self.H, self.Hprime, self.gamma):
-            raise _lib.HipError("GSC kernel range: H <= 512, gamma <= 4 (got H=%d Hprime=%d gamma=%d)"
+            raise _lib.HipError("GSC kernel range: H <= 512, gamma <= 8 (got H=%d Hprime=%d gamma=%d)"
                                 % (self.H, self.Hprime, self.gamma))
 
     def _masks(self):
@@ -299,7 +351,7 @@ class GSC(DeviceCAModel):
         self._seed = {"ykey": res["key"], "Wt": Wt, "G": G, "A": A, "W_host": None}
 
     # ------------------------------------------------------------------ hot path
-    def _run(self, anneal_T, model_params, res, cand_in):
+    def _run(self, anneal_T, model_params, res, cand_in, logpj=None):
         """Scores GEMM + the fused select / E-step kernel; returns (cand, xpt_s, xpt_sz, stats)."""
         self._require_scalar()
         Y = res["Y"]
@@ -312,9 +364,10 @@ class GSC(DeviceCAModel):
             par["scores"] = None
             if A is None:
                 A = self._gemm_nt(Y, par["Wst"], self._buf("scores", (N, H)), "scores_gemm")
-        return self._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], par["tables"], par["s2"], anneal_T, cand_in)
+        return self._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], par["tables"], par["s2"], anneal_T, cand_in,
+                                  logpj)
 
-    def _launch_estep(self, res, A, G, psi_d, yn, tables, s2, anneal_T, cand_in):
+    def _launch_estep(self, res, A, G, psi_d, yn, tables, s2, anneal_T, cand_in, logpj=None):
         """The fused select / E-step kernel on scores ``A``; ``s2 == 0.0``: 1/sigma_sq sits in the ninth row of
         ``tables`` (an M-step that finished on the device).  Returns (cand, xpt_s, xpt_sz, stats)."""
         N = res["Y"].shape[0]
@@ -343,7 +396,12 @@ class GSC(DeviceCAModel):
             do_select = 1
         else:
             cand, do_select = cand_in, 0
-        if N:
+        if N and logpj is not None:      # compute_lpj: the same pass also writes every state's log-joint
+            self._call("estep", "pm_gsc_estep_lpj_f64", _ptr(A), H, _ptr(G), _ptr(psi_d), _ptr(yn),
+                       _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
+                       ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
+                       _ptr(stats), _ptr(logpj), logpj.stride(0), self._stream())
+        elif N:
             self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(G), _ptr(psi_d), _ptr(yn),
                        _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
                        ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
@@ -375,14 +433,42 @@ class GSC(DeviceCAModel):
     @tracing.traced
     def select_Hprimes(self, model_params, my_data):
         """Candidates = the Hprime latents with the best singleton log-posterior, sorted by index
-        (gsc_et.py:721-728).  The selection itself is fused into the E-step kernel; this records the
-        request (the reference's ``data_clusters`` bucketing has no counterpart: datapoints keep
-        their order)."""
+        (gsc_et.py:721-728).  The selection itself is fused into the E-step kernel; ``data_clusters`` -- the reference's
+        bucketing of the datapoints by candidate set (gsc_et.py:731-747) -- is a ``LazyClusters`` that is filled when
+        somebody looks at it.  Statistics stay in datapoint order unless ``self.reference_order`` is set."""
         self._require_scalar()
         res = self._resident(my_data['y'])
-        my_data['data_clusters'] = {'deferred': True}
+        my_data['data_clusters'] = LazyClusters(self, dict(model_params), my_data)     # (shallow: nothing is copied)
         my_data.pop('candidates', None)
         return my_data
+
+    @tracing.traced
+    def component_scores(self, model_params, my_data):
+        """Singleton log-posterior of every latent without the prior, (N, H), clamped as upstream clamps it
+        (gsc_et.py:752-809): what ``select_Hprimes`` ranks.  Scores GEMM + one element-wise HIP kernel."""
+        self._require_scalar()
+        res = self._resident(my_data['y'])
+        N, H = res["Y"].shape[0], self.H
+        par = self._tables_for(model_params, res)
+        out = torch.empty((N, H), dtype=torch.float64, device=self.device)
+        if N:
+            A = self._gemm_nt(res["Y"], par["Wst"], self._buf("scores", (N, H)), "scores_gemm")
+            self._call("component_scores", "pm_gsc_component_scores_f64", _ptr(A), H, _ptr(par["yn"]), _ptr(par["tables"]),
+                       ctypes.c_double(par["s2"]), N, H, _ptr(out), H, self._stream())
+        return DeviceArray(out)
+
+    def compute_lpj(self, anneal, model_params, my_data):
+        """Candidates and log-pseudo-joints of the truncated states (gsc_et.py:811-944): ``(logpj (N, 1+H+S),
+        candidates (N, Hprime))`` in datapoint order -- no annealing, prior odds included; columns [null ; singletons ;
+        multi-cause states in ``state_matrix`` order over the sorted candidates].  ``CAModel.inference`` consumes it."""
+        assert 'y' in my_data, "Key 'y' in test_data dict not defined."
+        self._require_scalar()
+        res = self._resident(my_data['y'])
+        N = res["Y"].shape[0]
+        K = 1 + self.H + self.no_states
+        logpj = torch.empty((N, K), dtype=torch.float64, device=self.device)
+        cand, _, _, _ = self._run(1.0, model_params, res, None, logpj=logpj)
+        return DeviceArray(logpj), DeviceArray(cand, np.int64)
 
     def candidates(self, model_params, my_data):
         """Sorted candidates (N, Hprime) on their own (np.asarray-able)."""
@@ -416,6 +502,14 @@ class GSC(DeviceCAModel):
         sum_ss = off + off.t() + torch.diag(cs)                            # diag(sum xpt_ss) = sum xpt_s
         offz = torch.triu(U_zz, 1)
         sum_zz = offz + offz.t() + torch.diag(torch.diagonal(U_zz) + dzz)
+        if self.reference_order and isinstance(my_data.get('data_clusters'), LazyClusters):
+            # the reference's row order (gsc_et.py:572-573): clusters in order of first appearance
+            order = my_data['data_clusters'].order()
+            idx = torch.from_numpy(order).to(self.device)
+            xs, xsz = xs.index_select(0, idx), xsz.index_select(0, idx)
+            my_data['candidates'] = DeviceArray(cand.index_select(0, idx), np.float64)
+            y = my_data['y']
+            my_data['y'] = DeviceArray(y.tensor.index_select(0, idx)) if isinstance(y, DeviceArray) else np.asarray(y)[order]
         out = {'xpt_s': DeviceArray(xs), 'xpt_sz': DeviceArray(xsz),
                'xpt_ss': SummedMoments(sum_ss, N), 'xpt_szsz': SummedMoments(sum_zz, N)}
         out['_sums'] = (cs, csz)

@@ -159,6 +159,13 @@ class Comm(object):
         """In-place sum-all-reduce of a device (or CPU) torch tensor.  On GPUs this
         is a single ncclAllReduce over xGMI; replaces the eight MPI calls of
         bsc_et.py:225-417."""
+        if not self._solo() and tensor.is_cuda and dist.get_backend(self._group) == "gloo":
+            # gloo moves host memory: stage the device buffer through the host (two ranks sharing one GPU in the
+            # tests -- RCCL refuses two ranks per device; production groups are nccl)
+            host = tensor.detach().cpu()
+            dist.all_reduce(host, group=self._group)
+            tensor.copy_(host)
+            return tensor
         if not self._solo():
             if self._timed is not None and tensor.is_cuda:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

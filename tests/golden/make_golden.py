@@ -127,6 +127,85 @@ def bsc_inference_case():
     print("bsc_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
 
 
+def _inference_runs(model, anneal, params, y, runs):
+    import io, contextlib
+    out = {}
+    for tag, kw in runs:
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = model.inference(anneal, {k: np.array(v, copy=True) for k, v in params.items()}, {"y": y.copy()}, **kw)
+        for k, v in res.items():
+            out["%s_%s" % (tag, k)] = v
+    return out
+
+
+_INFERENCE_RUNS = (("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
+                   ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True)))
+
+
+def mca_inference_case():
+    """CAModel.inference (camodels/__init__.py:256-375) of MCA_ET: compute_lpj = select_Hprimes + E_step
+    (mca_et.py:88-179), top-K states, marginals, adaptive H'/gamma."""
+    D, H, Hp, gamma, N = 25, 10, 4, 2, 60
+    rng = np.random.RandomState(43)
+    W_gt = 10 * generate_bars_dict(H)
+    W = W_gt + 0.5 * np.abs(rng.normal(size=(D, H)))
+    params = {"W": W, "pi": 0.25, "sigma": 1.5}
+    s = rng.random_sample((N, H)) < 0.25
+    y = np.zeros((N, D))
+    for n in range(N):
+        if s[n].any():
+            y[n] = np.maximum(0.0, W_gt.T[s[n]].max(axis=0))
+    y += rng.normal(scale=1.5, size=(N, D))
+    model = MCA_ET(D, H, Hp, gamma)
+    anneal = FixedAnneal(T=1.0)
+    out = _inference_runs(model, anneal, params, y, _INFERENCE_RUNS)
+    assert (model.Hprime, model.gamma) == (Hp, gamma)
+    np.savez_compressed(os.path.join(HERE, "mca_inference.npz"), D=D, H=H, Hprime=Hp, gamma=gamma, y=y, W=W,
+                        pi=params["pi"], sigma=params["sigma"], **out)
+    print("mca_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
+
+
+def mmca_inference_case():
+    """CAModel.inference of MMCA_ET (signed max-magnitude causes, mmca_et.py:96-199)."""
+    D, H, Hp, gamma, N = 20, 10, 4, 2, 60
+    rng = np.random.RandomState(44)
+    W_gt = rng.normal(size=(D, H)) * 3.0
+    W = W_gt * (1.0 + 0.2 * rng.uniform(-1, 1, size=(D, H)))
+    params = {"W": W, "pi": 0.2, "sigma": 1.2}
+    model = MMCA_ET(D, H, Hp, gamma)
+    s = rng.random_sample((N, H)) < 0.2
+    y = model.generate_from_hidden({"W": W_gt, "pi": 0.2, "sigma": 0.0}, {"s": s})["y"] + rng.normal(scale=1.0, size=(N, D))
+    anneal = FixedAnneal(T=1.0)
+    out = _inference_runs(model, anneal, params, y, _INFERENCE_RUNS)
+    assert (model.Hprime, model.gamma) == (Hp, gamma)
+    np.savez_compressed(os.path.join(HERE, "mmca_inference.npz"), D=D, H=H, Hprime=Hp, gamma=gamma, y=y, W=W,
+                        pi=params["pi"], sigma=params["sigma"], **out)
+    print("mmca_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
+
+
+def gsc_inference_case():
+    """CAModel.inference of GSC through its own compute_lpj (gsc_et.py:811-944), plus component_scores
+    (gsc_et.py:752-809) of the same parameters."""
+    D, H, Hp, gamma, N = 20, 10, 4, 2, 60
+    rng = np.random.RandomState(45)
+    W_gt = rng.normal(size=(D, H))
+    pi_gt = np.full(H, 0.2)
+    mu_gt = np.ones(H) * 1.5
+    s = rng.random_sample((N, H)) <= pi_gt
+    z = np.where(s, mu_gt[None, :] + rng.normal(size=(N, H)), 0.0)
+    y = z @ W_gt.T + rng.normal(size=(N, D))
+    params = {"W": W_gt + 0.2 * rng.normal(size=(D, H)), "pi": np.clip(pi_gt * rng.uniform(0.7, 1.4, size=H), 0.02, 0.9),
+              "mu": mu_gt + 0.2 * rng.normal(size=H), "psi_sq": np.diag(rng.uniform(0.6, 1.6, size=H)), "sigma_sq": 1.3}
+    model = GSC(D, H, Hp, gamma, "scalar")
+    anneal = FixedAnneal(T=1.0)
+    out = _inference_runs(model, anneal, params, y, _INFERENCE_RUNS)
+    assert (model.Hprime, model.gamma) == (Hp, gamma)
+    scores = model.component_scores({k: np.array(v, copy=True) for k, v in params.items()}, {"y": y.copy()})
+    np.savez_compressed(os.path.join(HERE, "gsc_inference.npz"), D=D, H=H, Hprime=Hp, gamma=gamma, y=y,
+                        component_scores=scores, **params, **out)
+    print("gsc_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
+
+
 def mca_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, bars=False):
     """One check_params -> select_Hprimes -> E_step -> M_step of MCA_ET on seeded data."""
     rng = np.random.RandomState(seed)
@@ -330,7 +409,7 @@ class FixedAnneal(dict):
 
 
 def bsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior, bars=False,
-                  mu=False, to_learn=("W", "pi", "sigma"), sigma_gt=1.0, amp=1.0, big=False):
+                  mu=False, to_learn=("W", "pi", "sigma"), sigma_gt=1.0, amp=1.0, big=False, pi_gt=None):
     """``big`` (config-2 dimensions): the inputs are rounded to float32-representable values and stored as float32
     (the reference runs on their exact float64 upcasts), and the all-reduced statistics Wq / Wp the reference hands
     to ``np.linalg.lstsq`` (bsc_et.py:373-380) are captured: with N < H datapoints Wq is rank-deficient and W_new
@@ -341,7 +420,7 @@ def bsc_step_case(name, D, H, Hp, gamma, N, seed, T, Ncut, anneal_prior, bars=Fa
         pi_gt, sigma_gt = 2. / H, 2.0
     else:
         W_gt = amp * rng.normal(size=(D, H))
-        pi_gt = min(0.45, 2.0 / H)
+        pi_gt = min(0.45, 2.0 / H) if pi_gt is None else pi_gt
     model = BSC_ET(D, H, Hp, gamma, to_learn=list(to_learn))
     s = rng.random_sample((N, H)) < pi_gt
     y = s.astype(float) @ W_gt.T + rng.normal(scale=sigma_gt, size=(N, D))
@@ -457,7 +536,7 @@ def main(only=None, cases=None):
     want = lambda fn: only is None or fn.__name__.startswith(only)
     g = globals()
     for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
-               "bsc_trajectory", "bsc_init", "anneal_tracks"):
+               "mca_inference_case", "mmca_inference_case", "gsc_inference_case", "bsc_trajectory", "bsc_init", "anneal_tracks"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
     if cases:
@@ -478,6 +557,9 @@ def main(only=None, cases=None):
     # un-stabilised exp(logpj) sums above the underflow threshold for every datapoint of the sample
     bsc_step_case("c2_plain", 1024, 256, 8, 4, 128, seed=12, T=1.0, Ncut=0.0, anneal_prior=False, sigma_gt=2.0, big=True)
     bsc_step_case("c2_cut", 1024, 256, 8, 4, 128, seed=13, T=1.2, Ncut=0.7, anneal_prior=False, sigma_gt=2.0, big=True)
+    # ... and with enough datapoints for a full-rank Wq (N = 512 > H and a seed for which every latent is active in at least one datapoint): W_new
+    # itself is pinned at config-2 dimensions
+    bsc_step_case("c2_fullrank", 1024, 256, 8, 4, 512, seed=131, T=1.0, Ncut=0.0, anneal_prior=False, sigma_gt=2.0, big=True)
     gsc_step_case("small", 16, 8, 4, 3, 200, seed=31, T=1.0)
     gsc_step_case("small_T", 16, 8, 4, 3, 151, seed=32, T=1.5, full_psi=True)
     gsc_step_case("h24", 40, 24, 5, 3, 120, seed=33, T=1.0, full_psi=True)
@@ -502,6 +584,9 @@ def main(only=None, cases=None):
     tsc_inference_case()
     bsc_inference_case()
     dsc_inference_case()
+    mca_inference_case()
+    mmca_inference_case()
+    gsc_inference_case()
     bsc_trajectory()
     bsc_init()
     anneal_tracks()

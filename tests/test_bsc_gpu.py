@@ -677,25 +677,82 @@ def test_warm_inverse_is_transparent_across_unrelated_problems(dev):
         np.testing.assert_allclose([got["pi"], got["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-12)
 
 
+def test_config2_fullrank_w_through_cold_and_warm_inverse(dev):
+    """bsc_step_c2_fullrank.npz: config-2 dimensions with N = 512 > H datapoints and a full-rank Wq (smin / smax =
+    4e-6), so the reference's W_new = lstsq(Wq, Wp) is well posed and is compared itself -- through the exact sweep (a
+    fresh model), through the warm-started inverse (the same model called again: Newton-Schulz from its previous inverse,
+    sweep skipped) and on the two-kernel path."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    g = golden("bsc_step_c2_fullrank.npz")
+    assert not rank_deficient(g)
+    an = _An(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
+    params = {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])}
+    for path in ("fused", "rows16"):
+        m = _set_path(BSC_ET(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"])), path)
+        for call in ("cold", "warm", "warm again"):
+            p = dict(params)
+            data = m.select_Hprimes(p, {"y": g["y"]})
+            ss = m.E_step(an, p, data)                        # (inserts p['mu'], as upstream)
+            new = m.M_step(an, p, ss, data)
+            assert (getattr(m, "_winv_prev", None) is not None), call
+            Wp, Wq = _device_stats(m)
+            np.testing.assert_allclose(Wq, g["Wq"], rtol=1e-9, atol=1e-12 * np.abs(g["Wq"]).max(), err_msg=call)
+            np.testing.assert_allclose(Wp, g["Wp"], rtol=1e-9, atol=1e-11 * np.abs(g["Wp"]).max(), err_msg=call)
+            np.testing.assert_allclose(new["W"], g["W_new"], rtol=1e-8, atol=1e-8 * np.abs(g["W_new"]).max(),
+                                       err_msg="%s / %s" % (path, call))
+            np.testing.assert_allclose([new["pi"], new["sigma"]], [float(g["pi_new"]), float(g["sigma_new"])], rtol=1e-10)
+
+
+def test_constant_partial_never_reuses_a_stale_shard(dev):
+    """Regression (round 1): with a constant ``anneal['partial'] = 0.9`` every step draws a NEW random subset of the rows
+    (camodels/__init__.py:125-152) of the same shape as the previous one; the resident-shard cache must key on the
+    rows' content, not on their shape.  Each step is compared with the oracle on exactly the subset the step drew."""
+    from oracle import bsc_oracle as O
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, gamma, N = 48, 20, 5, 3, 1500
+    rng = np.random.RandomState(23)
+    W_gt = rng.normal(size=(D, H))
+    y, _ = O.generate_bsc_data(W_gt, 2.0 / H, 1.0, N, rng)
+    params = {"W": W_gt + 0.2 * rng.normal(size=(D, H)), "pi": 2.0 / H, "sigma": 1.1}
+    model = O.make_model(D, H, Hp, gamma)
+    m = BSC_ET(D, H, Hp, gamma)
+    an = _An(T=1.0, partial=0.9)
+    p = dict(params)
+    subsets = []
+    for step in range(4):
+        np.random.seed(100 + step)
+        sel = np.sort(np.random.permutation(N)[:int(np.ceil(N * 0.9))])
+        subsets.append(sel)
+        np.random.seed(100 + step)                         # CAModel.step draws the same permutation
+        ref, _ = O.em_step(O.Anneal(T=1.0), model, dict(p), y[sel], stats_fn=O.m_step_stats_vec, vec=True)
+        p = m.step(an, dict(p), {"y": y})
+        np.testing.assert_allclose(p["W"], ref["W"], rtol=1e-7, atol=1e-9, err_msg="step %d" % step)
+        np.testing.assert_allclose([p["pi"], p["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-9, err_msg="step %d" % step)
+    assert not np.array_equal(subsets[0], subsets[1])
+
+
 def test_config2_full_shard_against_oracle(dev):
-    """BASELINE config 2 at its real size -- D=1024 H=256 H'=8 gamma=4, N = 200 000 on the bench's generator -- through
-    the shipped launches (one fused E-step launch of 3125 tiles; with PM_FUSED=0: 196 608 rows of whole GEMM rounds +
-    3 392 rows as fused K-slices).  Datapoints are independent given the parameters, so the vectorised oracle is run
+    """BASELINE config 2 at its real size -- D=1024 H=256 H'=8 gamma=4, N = 200 000 drawn by bench.py's default recipe
+    (np.random.RandomState(0) for W_gt and the start W, RandomState(rank) for the rows, latents then noise)
+    -- through the shipped launches (one fused E-step launch of 3072 workgroups = 196 608 rows of whole rounds + the
+    3 392-row remainder path; with PM_FUSED=0: whole GEMM rounds + fused K-slices).  Datapoints are independent given the parameters, so the vectorised oracle is run
     on ~1000 sampled rows (spread over the shard, dense around the whole-rounds / remainder boundary and at the end):
     candidates exact, log-joints to 1e-10; the M-step statistics of the sample as its own shard against the oracle's,
     and additivity of the full shard's statistics over two halves."""
     from oracle import bsc_oracle as O
     from prosper_amd.em.camodels.bsc_et import BSC_ET
     D, H, Hp, gamma, N = 1024, 256, 8, 4, 200_000
-    g0 = torch.Generator(device=dev).manual_seed(0)
-    W_gt = torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)
-    W0 = (W_gt + 0.1 * torch.randn(D, H, generator=g0, device=dev, dtype=torch.float64)).cpu().numpy()
-    gr = torch.Generator(device=dev).manual_seed(100)
+    rs0 = np.random.RandomState(0)
+    W_gt_h = rs0.randn(D, H)
+    W0 = np.ascontiguousarray((W_gt_h + 0.1 * rs0.randn(D, H)).T).T
+    W_gt = torch.from_numpy(W_gt_h).to(dev)
+    rs = np.random.RandomState(0)                        # rank 0's rows
     Y = torch.empty(N, D, dtype=torch.float64, device=dev)
     for lo in range(0, N, 25_000):
-        S = (torch.rand(25_000, H, generator=gr, device=dev) < 4.0 / H).to(torch.float64)
-        Y[lo:lo + 25_000] = S @ W_gt.t() + torch.randn(25_000, D, generator=gr, device=dev, dtype=torch.float64)
-    del S
+        S = torch.from_numpy((rs.random_sample((25_000, H)) < 4.0 / H).astype(np.float64)).to(dev)
+        noise = torch.from_numpy(rs.normal(size=(25_000, D))).to(dev)
+        Y[lo:lo + 25_000] = torch.addmm(noise, S, W_gt.t())
+    del S, noise
     params = {"W": W0, "pi": 4.0 / H, "sigma": 1.0, "mu": np.zeros(D)}
     an = _An(T=1.0)
     rng = np.random.RandomState(5)

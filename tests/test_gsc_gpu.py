@@ -65,6 +65,77 @@ def test_gsc_step_matches_reference_golden(case):
     np.testing.assert_allclose(np.asarray(suff2["xpt_sz"]), g["xpt_sz"], rtol=1e-8, atol=1e-12)
 
 
+@pytest.mark.parametrize("case", _cases())
+def test_gsc_compute_lpj_matches_reference_golden(case):
+    """GSC.compute_lpj (gsc_et.py:811-944): log-joints of [null ; singletons ; multi-cause states] without annealing,
+    prior odds included, in datapoint order -- against what the reference's own compute_lpj returned (the ``logpj``
+    of the step goldens, scalar / diagonal / full noise, config-4 dimensions)."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    g = golden(case)
+    m = GSC(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]), _kind(g))
+    logpj, cand = m.compute_lpj(_An(T=float(g["T"])), _params(g), {"y": g["y"]})
+    assert np.array_equal(np.asarray(cand), g["candidates"])
+    lp = np.asarray(logpj)
+    assert lp.shape == g["logpj"].shape and lp.dtype == np.float64
+    np.testing.assert_allclose(lp, g["logpj"], rtol=1e-9, atol=1e-8)
+
+
+def test_gsc_data_clusters_and_reference_order():
+    """``my_data['data_clusters']`` after select_Hprimes is the reference's bucketing by candidate set (gsc_et.py:731-747),
+    built on first access; with ``reference_order`` the E-step's rows follow the clusters as upstream (gsc_et.py:572-573)."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    g = golden("gsc_step_small.npz")
+    y, cands = g["y"], g["candidates"]
+    expect = {}
+    for n in range(y.shape[0]):
+        expect.setdefault(str(cands[n]), []).append(n)
+    order = np.concatenate([np.array(v) for v in expect.values()])
+    m = GSC(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    data = m.select_Hprimes(_params(g), {"y": y.copy()})
+    cl = data["data_clusters"]
+    assert list(cl.keys()) == list(expect.keys()) and len(cl) == len(expect)
+    for k, c in cl.items():
+        assert c["ind"] == expect[k] and np.array_equal(c["hprimes"], cands[expect[k][0]])
+        assert np.array_equal(c["data"], y[expect[k]])
+    suff = m.E_step(_An(T=float(g["T"])), _params(g), data)                      # datapoint order (the default)
+    np.testing.assert_allclose(np.asarray(suff["xpt_s"]), g["xpt_s"], rtol=1e-8, atol=1e-12)
+    m2 = GSC(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    m2.reference_order = True
+    d2 = m2.select_Hprimes(_params(g), {"y": y.copy()})
+    s2 = m2.E_step(_An(T=float(g["T"])), _params(g), d2)
+    assert np.array_equal(np.asarray(d2["y"]), y[order])
+    assert np.array_equal(np.asarray(d2["candidates"]).astype(np.int64), cands[order])
+    np.testing.assert_allclose(np.asarray(s2["xpt_s"]), g["xpt_s"][order], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(np.asarray(s2["xpt_sz"]), g["xpt_sz"][order], rtol=1e-8, atol=1e-12)
+    new = m2.M_step(_An(T=float(g["T"])), _params(g), s2, d2)                    # consistent: same update either way
+    np.testing.assert_allclose(new["W"], g["W_new"], rtol=1e-7, atol=1e-9)
+
+
+def test_gsc_component_scores_match_reference():
+    """GSC.component_scores (gsc_et.py:752-809) against the reference's own output."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    g = golden("gsc_inference.npz")
+    m = GSC(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    got = np.asarray(m.component_scores(_params(g), {"y": g["y"]}))
+    np.testing.assert_allclose(got, g["component_scores"], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
+                                    ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True))])
+def test_gsc_inference_matches_reference(tag, kw, capsys):
+    """CAModel.inference (camodels/__init__.py:256-375) through GSC's own compute_lpj: top-K states bit for bit,
+    marginals and probabilities; the adaptive run grows gamma to 5 and H' to 7 (g x g systems up to 5 x 5)."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    g = golden("gsc_inference.npz")
+    m = GSC(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    res = m.inference(_An(T=1.0), _params(g), {"y": g["y"]}, **kw)
+    assert (m.Hprime, m.gamma) == (int(g["Hprime"]), int(g["gamma"]))
+    assert np.array_equal(res["gamma"], g[tag + "_gamma"]) and np.array_equal(res["Hprime"], g[tag + "_Hprime"])
+    assert res["s"].dtype == np.int8 and np.array_equal(res["s"], g[tag + "_s"])
+    np.testing.assert_allclose(res["p"], g[tag + "_p"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(res["m"], g[tag + "_m"], rtol=1e-7, atol=1e-12)
+
+
 @pytest.mark.parametrize("D,H,Hp,gamma,N,T", [(256, 128, 6, 3, 1000, 1.0), (60, 50, 5, 4, 333, 1.3), (20, 10, 3, 2, 70, 1.0),
                                               (64, 200, 4, 2, 101, 1.0), (40, 40, 8, 2, 90, 1.1)])   # 16 latents per lane; H' = 8
 def test_gsc_step_matches_oracle(D, H, Hp, gamma, N, T):

@@ -236,3 +236,21 @@ def test_config5_full_shard_against_oracle():
     got = MCA_ET(D, H, Hp, gamma).step(an, dict(params), {"y": y_s})
     np.testing.assert_allclose(got["W"], ref["W"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose([got["pi"], got["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-9)
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
+                                    ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True))])
+def test_mca_inference_matches_reference(tag, kw, capsys):
+    """CAModel.inference (camodels/__init__.py:256-375) of MCA_ET -- compute_lpj = select_Hprimes + E_step on the HIP
+    path -- against the reference's own output: top-K states bit for bit, probabilities and marginals; the adaptive
+    run regenerates the state table up to the H' / gamma the golden records."""
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    g = golden("mca_inference.npz")
+    m = MCA_ET(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    an = _An(T=1.0)
+    res = m.inference(an, {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])}, {"y": g["y"]}, **kw)
+    assert (m.Hprime, m.gamma) == (int(g["Hprime"]), int(g["gamma"]))
+    assert np.array_equal(res["gamma"], g[tag + "_gamma"]) and np.array_equal(res["Hprime"], g[tag + "_Hprime"])
+    assert res["s"].dtype == np.int8 and np.array_equal(res["s"], g[tag + "_s"])
+    np.testing.assert_allclose(res["p"], g[tag + "_p"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(res["m"], g[tag + "_m"], rtol=1e-7, atol=1e-12)

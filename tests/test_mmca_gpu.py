@@ -133,3 +133,21 @@ def test_mmca_em_improves_likelihood():
         p = m.step(_An(T=1.0), p, {"y": y})
         Q.append(p["Q"])
     assert Q[-1] > Q[0] and np.isfinite(p["W"]).all()
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
+                                    ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True))])
+def test_mmca_inference_matches_reference(tag, kw, capsys):
+    """CAModel.inference (camodels/__init__.py:256-375) of MMCA_ET -- compute_lpj = select_Hprimes + E_step on the HIP
+    path -- against the reference's own output: top-K states bit for bit, probabilities and marginals; the adaptive
+    run regenerates the state table up to the H' / gamma the golden records."""
+    from prosper_amd.em.camodels.mmca_et import MMCA_ET
+    g = golden("mmca_inference.npz")
+    m = MMCA_ET(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    an = _An(T=1.0)
+    res = m.inference(an, {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])}, {"y": g["y"]}, **kw)
+    assert (m.Hprime, m.gamma) == (int(g["Hprime"]), int(g["gamma"]))
+    assert np.array_equal(res["gamma"], g[tag + "_gamma"]) and np.array_equal(res["Hprime"], g[tag + "_Hprime"])
+    assert res["s"].dtype == np.int8 and np.array_equal(res["s"], g[tag + "_s"])
+    np.testing.assert_allclose(res["p"], g[tag + "_p"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(res["m"], g[tag + "_m"], rtol=1e-7, atol=1e-12)
