@@ -16,7 +16,6 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "prosper_hip.h"
 #include "pm_common.h"
@@ -62,8 +61,7 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
     SizeOffsets so, int S, int gamma, pm_bsc_estep_params P, int64_t N, int H, int Hp, int mode,
     int32_t *__restrict__ cand, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse,
-    double *__restrict__ expect, int64_t lde, double *__restrict__ stats, int Dstats, int stagger_lo, int stagger_hi,
-    int stagger_ticks) {
+    double *__restrict__ expect, int64_t lde, double *__restrict__ stats, int Dstats) {
     constexpr int STAGE = (AROWS + 16 * NJ) * DK;   // doubles per stage
     constexpr int L = 1 + NJ / 4;                   // DMA instructions per K-step and wavefront
     constexpr int NG = NJ / 4;                      // groups of four column blocks
@@ -73,13 +71,6 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * AROWS;
-    // Optional (off by default, see the launcher): the workgroups of the SECOND resident set (the dispatcher deals blocks
-    // 0 .. CUs-1 one per CU, then CUs .. 2 CUs-1) start later, so that one workgroup of a CU is in its K-loop while the
-    // other runs its row passes (speed only; any placement is correct).
-    if ((int)blockIdx.x >= stagger_lo && (int)blockIdx.x < stagger_hi) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(32);
-    }
     PM_STAMP(0);
 #ifdef PM_FUSED_STAMPS
     if (tid == 0 && blockIdx.x < 8192)
@@ -316,26 +307,9 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// four ring stages (80 KB at H = 256): the K-loop is unrolled over the ring, every LDS address an immediate;
-// PM_FUSED_STAGES=3 selects the three-stage ring (60 KB, generic loop)
-int fused_stages() {
-    static int v = 0;
-    if (!v) {
-        const char *e = getenv("PM_FUSED_STAGES");
-        v = (e && e[0] == '3') ? 3 : 4;
-    }
-    return v;
-}
-
-double fused_stagger_us() {
-    static double v = -1.0;
-    if (v < 0.0) {
-        const char *e = getenv("PM_FUSED_STAGGER_US");
-        v = e ? atof(e) : 0.0;
-        if (v < 0.0) v = 0.0;
-    }
-    return v;
-}
+// Four ring stages (80 KB at H = 256): the K-loop is unrolled over the ring, every LDS address an immediate.  (A
+// three-stage ring and a start stagger of the second resident workgroup set were measured in round 2 -- -1 % and no gain
+// -- and are gone, and with them the library's only environment look-ups: no mutable state outside the arguments.)
 
 template <int NJ, int ST>
 size_t fused_lds_bytes(int64_t H, int64_t Hp, int64_t S) {
@@ -365,7 +339,6 @@ extern "C" int pm_fused_read_stamps(unsigned long long *host, int n) {
 extern "C" int pm_bsc_fused_occupancy(int64_t H, int64_t D, int64_t Hprime, int64_t S) {
     if (!pm_bsc_fused_supported(H, D, Hprime, S)) return 0;
     int n = 0;
-    const bool three = fused_stages() == 3;
     hipError_t e;
 #define PM_OCC(NJ, ST)                                                                                                 \
     do {                                                                                                               \
@@ -376,13 +349,8 @@ extern "C" int pm_bsc_fused_occupancy(int64_t H, int64_t D, int64_t Hprime, int6
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bsc_estep_fused_kernel<NJ, ST, false, false>, 256,    \
                                                              shmem);                                                   \
     } while (0)
-    if (H <= 128) {
-        if (three) PM_OCC(8, 3);
-        else PM_OCC(8, 4);
-    } else {
-        if (three) PM_OCC(16, 3);
-        else PM_OCC(16, 4);
-    }
+    if (H <= 128) PM_OCC(8, 4);
+    else PM_OCC(16, 4);
 #undef PM_OCC
     return e == hipSuccess ? n : -(int)e;
 }
@@ -422,8 +390,7 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
             return e;                                                                                                  \
         hipLaunchKernelGGL((bsc_estep_fused_kernel<NJ, ST, F, M>), grid, block, shmem, s, Y, ldy, Wt, ldw, (int)D,     \
                            gram, ynorm2, wmu, ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H,  \
-                           (int)Hprime, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, stagger_lo,    \
-                           stagger_hi, stagger_ticks);                                                                 \
+                           (int)Hprime, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats);               \
     } while (0)
 #define PM_LAUNCH_F(NJ, ST, F)              \
     do {                                    \
@@ -441,30 +408,8 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
             PM_LAUNCH_F(NJ, ST, false);    \
         }                                  \
     } while (0)
-    // Optional start stagger of the second resident set of workgroups (PM_FUSED_STAGGER_US=<microseconds>; default off).
-    // Measured: with both workgroups of a CU in phase a tile pair takes 240 us of K-loops (96 % of the matrix pipe at the
-    // sustained clock) + 47 us of row passes; half a tile apart the row passes hide behind the partner's K-loop, but a
-    // K-loop with no second K-loop beside it exposes its per-K-step barrier (137 instead of 115 us): 288 us either way.
-    int stagger_lo = 0, stagger_hi = 0, stagger_ticks = 0;
-    {
-        int dev = 0, cus = 0;
-        const double us = fused_stagger_us();
-        if (us > 0.0 && hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
-            tiles >= 2 * (int64_t)cus) {
-            stagger_lo = cus;
-            stagger_hi = 2 * cus;
-            stagger_ticks = (int)(us * 100.0);
-        }
-    }
-    const bool three = fused_stages() == 3;
-    if (H <= 128) {
-        if (three) PM_LAUNCH(8, 3);
-        else PM_LAUNCH(8, 4);
-    } else {
-        if (three) PM_LAUNCH(16, 3);
-        else PM_LAUNCH(16, 4);
-    }
+    if (H <= 128) PM_LAUNCH(8, 4);
+    else PM_LAUNCH(16, 4);
 #undef PM_LAUNCH
 #undef PM_LAUNCH_F
 #undef PM_LAUNCH_FM

@@ -691,15 +691,9 @@ int resident_slots() {  // workgroups of these kernels resident at once: 2 per C
     return slots;
 }
 
-// PM_GEMM_FUSE_REMAINDER=0 restores the two-launch form (main rounds, then the split-K remainder)
-bool fuse_remainder() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("PM_GEMM_FUSE_REMAINDER");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v != 0;
-}
+// (The two-launch form -- main rounds, then the split-K remainder -- and a forced split factor were environment
+// switches in round 2; measured, settled, removed: the library reads no environment.)
+constexpr bool fuse_remainder() { return true; }
 
 template <int MT>
 void launch_nt_mt(bool al, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int M,
@@ -775,7 +769,6 @@ extern "C" int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int
             // many K-slices of many tiles: the slices' f64 atomics (16 K per workgroup) outweigh the shorter K-loops
             // (3392 x 256 x 1024: 9 slices 67 us, 4 slices 56 us, 2 slices 77 us)
             if (nsplit > 4 && rest_tiles >= 32) nsplit = nsplit / 2 > 4 ? nsplit / 2 : 4;
-            if (const char *e = getenv("PM_GEMM_NSPLIT")) nsplit = atoi(e) > 0 ? atoi(e) : nsplit;   // (experiments)
         }
         if (main_panels > 0 && rest_rows > 0 && nsplit > 1 && fuse_remainder()) {
             launch_nt_dma_fused(A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)main_panels, (int)nsplit, s);

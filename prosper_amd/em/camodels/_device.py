@@ -511,6 +511,14 @@ class DeviceCAModel(CAModel):
         if rhs.is_cuda and H <= 256:
             Wq, Winv, piv = pre if pre is not None else self._invert_normal_matrix(Wq_u, qdiag)
             return self._apply_inverse(Wq, Winv, rhs), piv, Wq
+        if rhs.is_cuda:
+            # H > 256: the one-workgroup inverse on 256-blocks + Schur complements (the library's own GEMMs; no rocSOLVER)
+            Wq = torch.triu(Wq_u, 1)
+            Wq = (Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)).contiguous()
+            Winv, pmin, pmax = self._spd_inverse_blocked(Wq)
+            return self._apply_inverse(Wq, Winv, rhs), torch.stack([pmin, pmax]), Wq
+        # host tensors: the world_size-2 gloo tests feed CPU statistics through the same finalize code (never the
+        # product path, whose statistics live on the device)
         Wq = torch.triu(Wq_u, 1)
         Wq = Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)
         Lc, info = torch.linalg.cholesky_ex(Wq)
@@ -519,6 +527,44 @@ class DeviceCAModel(CAModel):
         piv = torch.stack([torch.where(info.reshape(()) == 0, d.min(), -torch.ones((), dtype=d.dtype, device=d.device)),
                            d.max()])
         return X, piv, Wq
+
+    def _spd_inverse_blocked(self, A):
+        """Inverse of a symmetric positive definite device matrix of any size from pm_spd_inverse_f64 (n <= 256, one
+        workgroup) by recursive 2 x 2 blocking:  with T = A11^-1 A12 and the Schur complement S = A22 - A12^T T,
+            A^-1 = [[A11^-1 + T S^-1 T^T, -T S^-1], [-S^-1 T^T, S^-1]].
+        Returns (inverse, smallest pivot, largest pivot) -- the pivots of the blocks ARE the pivots of the unblocked
+        elimination (first those of A11, then those of S).  Products go through pm_gemm_tn_acc_f64 / pm_gemm_nt_f64."""
+        n = A.shape[0]
+        dev = A.device
+        st = self._stream()
+        if n <= 256:
+            A = A.contiguous()
+            inv = torch.empty((n, n), dtype=torch.float64, device=dev)
+            piv = torch.empty(2, dtype=torch.float64, device=dev)
+            self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(A), n, None, n, None, _ptr(inv), n, _ptr(piv), st)
+            return inv, piv[0], piv[1]
+        n1 = min(256, n // 2 // 16 * 16) if n <= 512 else (n // 2 + 15) // 16 * 16
+        n2 = n - n1
+        A11, A12, A22 = A[:n1, :n1].contiguous(), A[:n1, n1:].contiguous(), A[n1:, n1:].contiguous()
+        I11, p1min, p1max = self._spd_inverse_blocked(A11)
+        T = torch.zeros((n1, n2), dtype=torch.float64, device=dev)
+        self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(I11), n1, _ptr(A12), n2, _ptr(T), n2, n1, n2, n1, st)   # I11^T A12
+        C = torch.zeros((n2, n2), dtype=torch.float64, device=dev)
+        self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(A12), n2, _ptr(T), n2, _ptr(C), n2, n2, n2, n1, st)     # A12^T T
+        S = A22 - C
+        S = (0.5 * (S + S.t())).contiguous()
+        IS, p2min, p2max = self._spd_inverse_blocked(S)
+        B12 = torch.empty((n1, n2), dtype=torch.float64, device=dev)
+        self._gemm_nt(T, IS, B12, "solve_gemm")                  # T S^-1 (S^-1 symmetric)
+        TST = torch.empty((n1, n1), dtype=torch.float64, device=dev)
+        self._gemm_nt(B12, T, TST, "solve_gemm")                 # T S^-1 T^T
+        out = torch.empty((n, n), dtype=torch.float64, device=dev)
+        B11 = I11 + TST
+        out[:n1, :n1] = 0.5 * (B11 + B11.t())
+        out[:n1, n1:] = -B12
+        out[n1:, :n1] = -B12.t()
+        out[n1:, n1:] = IS
+        return out, torch.minimum(p1min, p2min), torch.maximum(p1max, p2max)
 
     @staticmethod
     def _solve_ok(piv_min, piv_max):

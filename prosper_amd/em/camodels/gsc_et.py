@@ -212,7 +212,7 @@ class GSC(DeviceCAModel):
         t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)).to(dev)
         pi, mu, psi = t(model_params['pi']), t(model_params['mu']), t(model_params['psi_sq'])
         s = torch.rand((my_N, H), generator=g, device=dev, dtype=torch.float64) <= pi
-        L = torch.linalg.cholesky(psi)
+        L = t(np.linalg.cholesky(np.asarray(model_params['psi_sq'], dtype=np.float64)))     # (H x H, on the host)
         zfull = mu[None, :] + torch.randn((my_N, H), generator=g, device=dev, dtype=torch.float64) @ L.t()
         live = (s.to(torch.float64) @ torch.arange(H, dtype=torch.float64, device=dev)) != 0
         z = torch.where(s & live[:, None], zfull, torch.zeros((), dtype=torch.float64, device=dev))

@@ -217,6 +217,24 @@ def test_spd_inverse_warm_batch(dev):
     np.testing.assert_allclose(pv[2:], [d2.min(), d2.max()], rtol=1e-9)
 
 
+@pytest.mark.parametrize("n", [257, 300, 512, 700])
+def test_spd_inverse_blocked(dev, n):
+    """H x H systems beyond the one-workgroup inverse (n > 256): recursive 2 x 2 blocking with Schur complements on the
+    library's own kernels (DeviceCAModel._spd_inverse_blocked; no rocSOLVER) -- inverse and pivots against numpy."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    rs = np.random.RandomState(n)
+    B = rs.normal(size=(n, 2 * n))
+    A = B @ B.T + np.diag(rs.uniform(0.5, 2.0, size=n))
+    m = BSC_ET(8, 4, 2, 2)
+    inv, pmin, pmax = m._spd_inverse_blocked(torch.from_numpy(A).to(dev))
+    got = inv.cpu().numpy()
+    ref = np.linalg.inv(A)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * np.linalg.cond(A) * np.abs(ref).max())
+    np.testing.assert_array_equal(got, got.T)
+    d2 = np.diag(np.linalg.cholesky(A)) ** 2           # the pivots of the unblocked elimination
+    np.testing.assert_allclose([float(pmin), float(pmax)], [d2.min(), d2.max()], rtol=1e-8)
+
+
 def test_spd_inverse_rejects_large(dev):
     from prosper_amd import _lib
     t = torch.zeros((300, 300), dtype=torch.float64, device=dev)
@@ -458,7 +476,8 @@ def test_em_run_with_partial_data_and_parameter_noise(dev):
 # ------------------------------------------------------------------------- BSC vs oracle
 @pytest.mark.parametrize("D,H,Hp,gamma,N,T,ncut,ap", [
     (256, 128, 6, 3, 3000, 1.0, 0.0, False),
-    (100, 300, 8, 4, 777, 1.3, 0.7, True),
+    (100, 300, 8, 4, 777, 1.3, 0.7, True),          # H > 256: the blocked device inverse (_spd_inverse_blocked)
+    (48, 600, 5, 3, 4000, 1.0, 0.0, False),         # H > 512: generic row kernels, two levels of blocking
     (64, 64, 3, 2, 500, 1.0, 0.3, False),
     (32, 20, 2, 2, 129, 2.0, 0.0, False),
 ])
