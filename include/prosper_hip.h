@@ -81,9 +81,9 @@ int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add,
                        double *inv, int64_t ldo, double *pivots, void *stream);
 
 /* The same inverse, warm-started: `prev_inv` (n x n, leading dimension n) is the inverse of a nearby matrix -- the
- * previous EM step's second moments.  Three Newton-Schulz steps X <- X + X (I - A X) on the matrix cores refine it into
+ * previous EM step's second moments.  Four Newton-Schulz steps X <- X + X (I - A X) on the matrix cores refine it into
  * `inv` (symmetrised); the Gauss-Jordan sweep is launched behind them and returns at once when the start residual
- * ||I - A prev_inv||_F was below 0.1 (then ||I - A inv|| < 1e-8 and pivots = {min_i 1 / inv_ii, max_i A_ii}: a lower
+ * ||I - A prev_inv||_F was below 0.1 (then ||I - A inv|| < 1e-16 up to rounding and pivots = {min_i 1 / inv_ii, max_i A_ii}: a lower
  * bound of the smallest and an upper bound of the largest pivot of the sweep), else it overwrites `inv` with
  * the exact inverse as pm_spd_inverse_f64 would.  The decision is taken on the device from sums formed in a fixed
  * order.  `work`: pm_spd_inverse_warm_work_len(n) doubles; `full` (required, leading dimension ldo = n) receives the

@@ -58,7 +58,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define PM_F8_ABL 0
 #endif
 //   -DPM_F8_SKIP=mask  timing-only ablations of the lean row passes (wrong results): 1 no ranking (keys, sort, pop
-//               rounds), 2 no multi-cause states, 4 no log-joint stores, 8 no log-sum-exp, 16 no barriers in the passes
+//               rounds), 2 no multi-cause states, 4 no log-joint stores, 8 no log-sum-exp, 16 no barriers in the passes,
+//               32 (M-statistics) no E[s] row stores, 64 no Wq / mus atomics
 #ifndef PM_F8_SKIP
 #define PM_F8_SKIP 0
 #endif
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
                                     mi &= mi - 1;
                                     const int ci = cl[i];
                                     atomicAdd(&Pm[ci], ex);
-                                    if (live) {
+                                    if (!(PM_F8_SKIP & 64) && live) {
                                         pm_atomic_add(wq + (int64_t)ci * H + ci, w);
                                         unsigned mk = mi;
                                         while (mk) {
@@ -1077,8 +1078,8 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
                 const int h = j32 + 32 * i;
                 if (FULL || h < H) {
                     const double v = (a[i] + Pm[h]) * inv;
-                    *reinterpret_cast<double *>(erow + 256 * i) = v;
-                    if (live && __any(v != 0.0)) {
+                    if (!(PM_F8_SKIP & 32)) *reinterpret_cast<double *>(erow + 256 * i) = v;
+                    if (!(PM_F8_SKIP & 64) && live && __any(v != 0.0)) {
                         if (v != 0.0) atomicAdd(&t_mus[h], v);
                     }
                 }

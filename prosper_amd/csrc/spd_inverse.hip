@@ -39,53 +39,19 @@ __global__ __launch_bounds__(1024) void spd_inverse_kernel(const double *__restr
         __shared__ double s_g[NMAX];
         __shared__ int s_skip;
         guard += blockIdx.x * guard_stride;              // (matrix blockIdx.x of a batch)
-        refined += blockIdx.x * guard_stride;
-        double *inv_b = inv + blockIdx.x * stride_out, *piv_b = pivots ? pivots + 2 * blockIdx.x : nullptr;
         if (threadIdx.x < NMAX) s_g[threadIdx.x] = (int)threadIdx.x < guard_n ? guard[threadIdx.x] : 0.0;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double r2 = 0.0;
-            for (int q = 0; q < NMAX; ++q) r2 += s_g[q];
-            s_skip = (r2 < guard_tol2) ? 1 : 0;           // (NaN compares false: the sweep runs)
+        if (threadIdx.x < 64) {
+            // fixed summation order (four consecutive entries per lane, then a butterfly): every rank holding the same
+            // matrices gets the same bits -- and not 256 dependent LDS reads by one thread (11 us of this path)
+            const int l = threadIdx.x;
+            double r2 = ((s_g[4 * l] + s_g[4 * l + 1]) + s_g[4 * l + 2]) + s_g[4 * l + 3];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
+            if (l == 0) s_skip = (r2 < guard_tol2) ? 1 : 0;           // (NaN compares false: the sweep runs)
         }
         __syncthreads();
-        if (s_skip) {       // inv = (X + X^T) / 2: the next step's start and the solve both treat it as symmetric
-            for (int e = threadIdx.x; e < n * n; e += 1024) {
-                const int i = e / n, j = e - i * n;
-                inv_b[(int64_t)i * ldo + j] = 0.5 * (refined[(int64_t)i * n + j] + refined[(int64_t)j * n + i]);
-            }
-            // Conditioning without the sweep, so that the caller's singularity test (smallest / largest pivot) still
-            // means something on a warm step: 1 / X_ii is the pivot row i would get if it were eliminated LAST (its
-            // Schur complement against all other rows), a lower bound of the pivot the sweep would report for it;
-            // every pivot is at most the matrix's own diagonal entry.  pivots = [min_i 1 / X_ii, max_i A_ii].
-            if (piv_b) {
-                __shared__ double s_lo[NMAX], s_hi[NMAX];
-                const double *up_b = upper + blockIdx.x * stride_in;
-                const double *da_b = diag_add ? diag_add + (int64_t)blockIdx.x * n : nullptr;
-                if (threadIdx.x < NMAX) {
-                    const int i = threadIdx.x;
-                    double lo = INFINITY, hi = 0.0;
-                    if (i < n) {
-                        const double x = refined[(int64_t)i * n + i];
-                        lo = (x > 0.0) ? 1.0 / x : -1.0;             // (a non-positive diagonal: "not positive definite")
-                        hi = up_b[(int64_t)i * ldu + i] + (da_b ? da_b[i] : 0.0);
-                    }
-                    s_lo[i] = lo;
-                    s_hi[i] = hi;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    double lo = INFINITY, hi = 0.0;
-                    for (int q = 0; q < NMAX; ++q) {
-                        lo = fmin(lo, s_lo[q]);
-                        hi = fmax(hi, s_hi[q]);
-                    }
-                    piv_b[0] = lo;
-                    piv_b[1] = hi;
-                }
-            }
-            return;
-        }
+        if (s_skip) return;      // (ns_finish_kernel, which took the same decision, has written inv and the pivots)
     }
     // one workgroup per matrix of a batch (blockIdx.x): independent inverses run on different CUs at once
     upper += blockIdx.x * stride_in;
@@ -324,6 +290,63 @@ __global__ __launch_bounds__(256) void ns_step_kernel(const double *__restrict__
     }
 }
 
+// The warm path's last launch before the (guarded) sweep: every workgroup sums the start residual's per-tile squares in the
+// SAME fixed order the sweep kernel uses and, if the refinement is accepted, writes its 16 x 16 tile of
+// inv = (X + X^T) / 2 (the next step's start and the solve both treat it as symmetric); workgroup (0, 0) adds the
+// conditioning estimate: 1 / X_ii is the pivot row i would get if it were eliminated LAST (its Schur complement against
+// all other rows), a lower bound of the pivot the sweep would report for it, and every pivot is at most the matrix's
+// own diagonal entry -- pivots = [min_i 1 / X_ii, max_i A_ii].  (One workgroup doing all of this inside the sweep
+// kernel took 60 us: 64 K transposed reads through one CU.)
+__global__ __launch_bounds__(256) void ns_finish_kernel(const double *__restrict__ X, int n, int64_t stride_x,
+                                                        const double *__restrict__ partial, int n_partial,
+                                                        double tol2, const double *__restrict__ upper, int64_t ldu,
+                                                        int64_t stride_in, const double *__restrict__ diag_add,
+                                                        double *__restrict__ inv, int64_t ldo, int64_t stride_out,
+                                                        double *__restrict__ pivots) {
+    __shared__ double s_g[NMAX], s_lo[NMAX], s_hi[NMAX];
+    __shared__ int s_skip;
+    const int tid = threadIdx.x;
+    X += blockIdx.z * stride_x;
+    partial += blockIdx.z * stride_x;
+    s_g[tid] = tid < n_partial ? partial[tid] : 0.0;
+    __syncthreads();
+    if (tid < 64) {
+        double r2 = ((s_g[4 * tid] + s_g[4 * tid + 1]) + s_g[4 * tid + 2]) + s_g[4 * tid + 3];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
+        if (tid == 0) s_skip = (r2 < tol2) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_skip) return;
+    const int i = blockIdx.y * NS_T + (tid >> 4), j = blockIdx.x * NS_T + (tid & 15);
+    if (i < n && j < n)
+        inv[blockIdx.z * stride_out + (int64_t)i * ldo + j] = 0.5 * (X[(int64_t)i * n + j] + X[(int64_t)j * n + i]);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && pivots) {
+        double lo = INFINITY, hi = 0.0;
+        if (tid < n) {
+            const double x = X[(int64_t)tid * n + tid];
+            lo = (x > 0.0) ? 1.0 / x : -1.0;             // (a non-positive diagonal: "not positive definite")
+            hi = upper[blockIdx.z * stride_in + (int64_t)tid * ldu + tid] + (diag_add ? diag_add[(int64_t)blockIdx.z * n + tid] : 0.0);
+        }
+        s_lo[tid] = lo;
+        s_hi[tid] = hi;
+        __syncthreads();
+        if (tid < 64) {
+            lo = fmin(fmin(s_lo[tid], s_lo[tid + 64]), fmin(s_lo[tid + 128], s_lo[tid + 192]));
+            hi = fmax(fmax(s_hi[tid], s_hi[tid + 64]), fmax(s_hi[tid + 128], s_hi[tid + 192]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo = fmin(lo, __shfl_xor(lo, off));
+                hi = fmax(hi, __shfl_xor(hi, off));
+            }
+            if (tid == 0) {
+                pivots[2 * blockIdx.z] = lo;
+                pivots[2 * blockIdx.z + 1] = hi;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, double *full,
@@ -356,11 +379,17 @@ static int launch_warm(const double *upper, int64_t ldu, int64_t stride_in, cons
                        (int)n, n, X[1], R[1], L[1], stride_prev, wl);
     hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
                        (const double *)L[1], (int)n, n, X[0], R[0], L[0], wl, wl);
-    hipLaunchKernelGGL(ns_step_kernel<true>, grid, dim3(256), 0, s, (const double *)X[0], (const double *)R[0],
-                       (const double *)L[0], (int)n, n, X[1], (double *)nullptr, (double *)nullptr, wl, wl);
+    // a fourth step (residual R0^16 < 1e-16 for every start the guard accepts): the refined inverse is then exact to
+    // rounding and the caller's solve needs no refinement pass of its own (two H x H x D products saved per EM step)
+    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[0], (const double *)R[0],
+                       (const double *)L[0], (int)n, n, X[1], R[1], L[1], wl, wl);
+    hipLaunchKernelGGL(ns_step_kernel<true>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
+                       (const double *)L[1], (int)n, n, X[0], (double *)nullptr, (double *)nullptr, wl, wl);
+    hipLaunchKernelGGL(ns_finish_kernel, grid, dim3(256), 0, s, (const double *)X[0], (int)n, wl, (const double *)partial,
+                       tiles * tiles, 0.01, upper, ldu, stride_in, diag_add, inv, n, stride_out, pivots);
     hipLaunchKernelGGL(spd_inverse_kernel, dim3((unsigned)batch), dim3(1024), 0, s, upper, ldu, diag_add, (int)n,
                        (double *)nullptr, inv, n, pivots, stride_in, stride_out, (const double *)partial, tiles * tiles, 0.01,
-                       (const double *)X[1], wl);
+                       (const double *)X[0], wl);
     return (int)hipGetLastError();
 }
 

@@ -482,16 +482,24 @@ class DeviceCAModel(CAModel):
         else:
             self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
                        H, _ptr(piv), self._stream())
+        self._winv_was_warm = prev is not None and tuple(prev.shape) == (H, H) and prev.device == Wq_u.device \
+            and os.environ.get("PM_WARM_INVERSE", "1") == "1"
         self._winv_prev = Winv
         return Wq, Winv, piv
 
-    def _apply_inverse(self, Wq, Winv, rhs):
-        """X = Winv . rhs with one step of iterative refinement, X += Winv (rhs - Wq X).  Every product is accumulated
+    def _apply_inverse(self, Wq, Winv, rhs, refine=True):
+        """X = Winv . rhs with one step of iterative refinement, X += Winv (rhs - Wq X) -- skipped (``refine=False``) behind
+        the warm-started inverse, whose four Newton-Schulz steps already leave ||I - Wq Winv|| at rounding level (or, if
+        the device fell back to the exact sweep, at cond(Wq) eps, what the sweep gives anyway).  Every product is accumulated
         into a ZEROED buffer and added once: the K-slices of pm_gemm_tn_acc_f64 are summed with f64 atomics, and
         slices added to a non-zero X in run-to-run order would make ranks that solve the same all-reduced system
         differ in the last bit (and drift apart over EM steps)."""
         H, D = rhs.shape
         st = self._stream()
+        if not refine:
+            X0 = torch.zeros((H, D), dtype=torch.float64, device=rhs.device)
+            self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(rhs), D, _ptr(X0), D, H, D, H, st)
+            return X0
         XT = torch.zeros((3, H, D), dtype=torch.float64, device=rhs.device)     # X0, Wq.X0 and the correction: one fill
         X0, T, C = XT[0], XT[1], XT[2]
         self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(rhs), D, _ptr(X0), D, H, D, H, st)
@@ -510,7 +518,7 @@ class DeviceCAModel(CAModel):
         H, D = rhs.shape
         if rhs.is_cuda and H <= 256:
             Wq, Winv, piv = pre if pre is not None else self._invert_normal_matrix(Wq_u, qdiag)
-            return self._apply_inverse(Wq, Winv, rhs), piv, Wq
+            return self._apply_inverse(Wq, Winv, rhs, refine=not getattr(self, "_winv_was_warm", False)), piv, Wq
         if rhs.is_cuda:
             # H > 256: the one-workgroup inverse on 256-blocks + Schur complements (the library's own GEMMs; no rocSOLVER)
             Wq = torch.triu(Wq_u, 1)

@@ -2,7 +2,7 @@
 // of libprosper_hip.so (argv[1]), runs pm_bsc_estep_fused_f64 / pm_bsc_estep_fused8_f64 on synthetic data and prints
 // milliseconds per launch (HIP events).  Used with ablation / stamp builds of the library (scratch/f8_variants.sh);
 // correctness is the job of tests/, not of this program.
-//   f8_bench <lib.so> <tile 4|8> [N=196608] [reps=20] [stamps 0|1]
+//   f8_bench <lib.so> <tile 4|8> [N=196608] [reps=20] [stamps 0|1] [mstats 0|1]
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -78,6 +78,7 @@ int main(int argc, char **argv) {
     const int64_t N = argc > 3 ? atoll(argv[3]) : 196608;
     const int reps = argc > 4 ? atoi(argv[4]) : 20;
     const int want_stamps = argc > 5 ? atoi(argv[5]) : 0;
+    const int want_mstats = argc > 6 ? atoi(argv[6]) : 0;
     const int D = 1024, H = 256, Hp = 8, gamma = 4;
     void *lib = dlopen(libpath, RTLD_NOW);
     if (!lib) {
@@ -134,6 +135,13 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&dlogpj, sizeof(double) * N * Kpad));
     CK(hipMalloc(&dlse, sizeof(double) * N));
     CK(hipMalloc(&dcand, sizeof(int32_t) * N * Hp));
+    double *dexpect = nullptr, *dstats = nullptr;
+    const int64_t nstats = (int64_t)H * D + (int64_t)H * H + 2 * H + 4;
+    if (want_mstats) {
+        CK(hipMalloc(&dexpect, sizeof(double) * N * H));
+        CK(hipMalloc(&dstats, sizeof(double) * nstats));
+        CK(hipMemset(dstats, 0, sizeof(double) * nstats));
+    }
     CK(hipMalloc(&dmasks, 2 * S));
     CK(hipMalloc(&dparents, 2 * S));
     CK(hipMemcpy(dWgt, Wgt.data(), sizeof(double) * H * D, hipMemcpyHostToDevice));
@@ -154,7 +162,7 @@ int main(int argc, char **argv) {
     P.mu_sqnorm = 0.0;
     auto launch = [&]() {
         return fused(dY, D, dW, D, dG, dyn, nullptr, nullptr, dmasks, dparents, size_off.data(), S, gamma, &P, N, D, H, Hp,
-                     3, dcand, dlogpj, Kpad, dlse, nullptr, 0, nullptr, 0, nullptr);
+                     3, dcand, dlogpj, Kpad, dlse, dexpect, H, dstats, D, nullptr);
     };
     for (int i = 0; i < 10; ++i)
         if (int e = launch()) {

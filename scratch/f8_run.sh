@@ -5,8 +5,9 @@ OUT=gpurun_out/f8_run.log
 : > $OUT
 B=scratch/libs/f8_bench
 for v in "$@"; do
-  name=${v%%:*}; tile=${v#*:}; st=0
+  name=${v%%:*}; rest=${v#*:}; tile=${rest%%:*}; ms=0; st=0
+  [ "$rest" != "$tile" ] && ms=${rest#*:}
   [ "$name" = "stamps" ] && st=1
-  timeout 120 $B scratch/libs/libpm_$name.so $tile 196608 20 $st 2>&1 | grep -v amdgpu.ids >> $OUT
+  timeout 120 $B scratch/libs/libpm_$name.so $tile 196608 20 $st $ms 2>&1 | grep -v amdgpu.ids >> $OUT
 done
 cat $OUT
