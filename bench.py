@@ -421,7 +421,7 @@ def main():
     if rank == 0:
         fused = model._fused()
         dom = "estep_fused" if fused else "scores_gemm"
-        chunk = model._fused_rows(N) if fused else model._launch_rows(N)     # datapoints the dominant launch covers
+        chunk = model._dominant_rows(N) if fused else model._launch_rows(N)  # datapoints the dominant launch covers
         # HBM-side bytes of the dominant kernel: NOT measured in this run -- from the committed rocprofv3 --pmc passes
         # (profiles/summarize_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), per launch
         traffic, traffic_source = None, None
@@ -444,7 +444,10 @@ def main():
         estep_bytes = N * (D * 8 + HP * 4 + K_states * 8)   # 11 512 B/datapoint
         mfma_roof_dps = MFMA_F64_PEAK_TFLOPS * 1e12 / (2.0 * D * H)      # 150 M datapoints/s
         if fused:
-            kname = "bsc_estep_fused_kernel (scores GEMM + select_Hprimes + E_step, one launch per pass)"
+            kname = ("bsc_estep_fused8s_kernel (scores GEMM + select_Hprimes + E_step in one kernel; 8-wavefront tiles, whole "
+                     "rounds of the shard; the ragged remainder runs in its TAIL launch, timed apart as estep_fused_tail)"
+                     if model._tile8_whole_shard() else
+                     "bsc_estep_fused_kernel (scores GEMM + select_Hprimes + E_step, one launch per pass)")
             alg_bytes = chunk * (D * 8 + HP * 4 + (K_states + 1) * 8) + H * D * 8
         else:
             kname = "gemm_nt_f64_dma_kernel (scores A = Y.W^T)"

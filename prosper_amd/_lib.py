@@ -69,9 +69,11 @@ SIGNATURES = {
                                          C.POINTER(C.c_int32), i64, i64, C.POINTER(EStepParams), i64, i64, i64, i64,
                                          C.c_int, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp]),
     "pm_bsc_fused8_supported": (C.c_int, [i64, i64, i64, i64]),
+    "pm_bsc_fused8_whole_shard": (C.c_int, [i64, i64, i64, i64]),
+    "pm_bsc_fused8_main_rows": (i64, [i64, i64]),
     "pm_bsc_estep_fused8_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
                                           C.POINTER(C.c_int32), i64, i64, C.POINTER(EStepParams), i64, i64, i64, i64,
-                                          C.c_int, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp]),
+                                          C.c_int, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, C.c_int, c_dp]),
     "pm_bsc_mstep_rows16_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64,
                                           C.POINTER(EStepParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
     "pm_mca_select_scores_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),

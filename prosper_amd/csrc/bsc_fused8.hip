@@ -63,6 +63,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 #ifndef PM_F8_SKIP
 #define PM_F8_SKIP 0
 #endif
+// log-joint stores: plain, or (-DPM_F8_NT) non-temporal
+#ifdef PM_F8_NT
+#define F8_STORE(p, v) __builtin_nontemporal_store((v), reinterpret_cast<double *>(p))
+#else
+#define F8_STORE(p, v) (*reinterpret_cast<double *>(p) = (v))
+#endif
 #ifdef PM_F8_STAMPS
 __device__ unsigned long long pm_f8_stamps[8192][8];
 #define F8_STAMP(slot)                                                                  \
@@ -704,15 +710,74 @@ __device__ __forceinline__ double exp_lds(double x, const double *E, const doubl
     return __hiloint2double(__double2hiint(v) + ((k >> 7) << 20), __double2loint(v));
 }
 
-template <int STAGES, int HP, int GAMMA, bool FULL, bool MSTATS>
-__global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
+// The ragged last round (TAIL kernels): a workgroup owns 16 datapoints x 256 latents and splits K four ways --
+// wavefront (kq, half) = (wave & 3, wave >> 2) accumulates latents 128 half .. over K-steps [kq nk/4, (kq+1) nk/4).  A
+// whole-rounds launch leaves N mod 32768 rows (3392 of 200 000 at config 2) for which 64-row tiles would run 53 workgroups on 53
+// of 256 CUs for a full tile time; 16-row tiles make 212 workgroups of a quarter of the K-loop each.  No operand is
+// shared between wavefronts here, so nothing goes through LDS and nothing synchronises: every lane loads its own MFMA
+// operands from global memory (L2: W is 2 MB), PD K-steps ahead in registers (1 workgroup per CU: 256 registers).
+constexpr int TAIL_ROWS = 16, TAIL_PD = 3, TAIL_DK = 8;
+__device__ __forceinline__ void tail8_scores(d4 (&acc)[NJ], const double *__restrict__ Y, int64_t ldy,
+                                             const double *__restrict__ Wt, int64_t ldw, int D, int64_t N, int H,
+                                             int64_t m0, int lane, int wave) {
+    // (Measured: 16-column steps with one whole 128-byte line per row and request are SLOWER -- 104 vs 74 us for 3392
+    // rows; what bounds this loop is the ~30 GB/s a CU pulls from L2 into registers at this occupancy: every workgroup
+    // reads all of W, 2 MB.)
+    const int kq = wave & 3, half = wave >> 2;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int nk = D / TAIL_DK;
+    const int t0 = (kq * nk) / 4, t1 = ((kq + 1) * nk) / 4;
+    int64_t ra = m0 + frow;
+    ra = ra < N ? ra : N - 1;
+    const char *pa = reinterpret_cast<const char *>(Y + ra * ldy) + 16 * fk;
+    const char *wb = reinterpret_cast<const char *>(Wt) + 16 * fk;
+    uint32_t boff[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        int rb = half * 128 + 16 * i + frow;
+        rb = rb < H ? rb : H - 1;
+        boff[i] = (uint32_t)rb * (uint32_t)ldw * 8u;
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    d2 fa[TAIL_PD], fb[TAIL_PD][NJ];
+    auto load = [&](int t, int u) {
+        const int64_t k0 = (int64_t)t * (TAIL_DK * 8);
+        fa[u] = *reinterpret_cast<const d2 *>(pa + k0);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) fb[u][i] = *reinterpret_cast<const d2 *>(wb + k0 + boff[i]);
+    };
+#pragma unroll
+    for (int u = 0; u < TAIL_PD; ++u)
+        if (t0 + u < t1) load(t0 + u, u);
+    for (int t = t0; t < t1; t += TAIL_PD) {
+#pragma unroll
+        for (int u = 0; u < TAIL_PD; ++u) {
+            if (t + u < t1) {
+                const d2 a = fa[u];
+                d2 b[NJ];
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) b[i] = fb[u][i];
+                if (t + u + TAIL_PD < t1) load(t + u + TAIL_PD, u);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) acc[i] = mfma16(a.x, b[i].x, acc[i]);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) acc[i] = mfma16(a.y, b[i].y, acc[i]);
+            }
+        }
+    }
+}
+
+template <int STAGES, int HP, int GAMMA, bool FULL, bool MSTATS, bool TAIL>
+__global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kernel(
     const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wt, int64_t ldw, int D,
     const double *__restrict__ gram, const double *__restrict__ ynorm2, const double *__restrict__ wmu,
     const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
     pm_bsc_estep_params P, int64_t N, int H, int mode, int32_t *__restrict__ cand, double *__restrict__ logpj,
     int64_t ldl, double *__restrict__ lse, double *__restrict__ expect, int64_t lde, double *__restrict__ stats,
-    int Dstats) {
+    int Dstats, int64_t row0) {
     using SS = StateSet<HP, GAMMA>;
+    constexpr int TILE_ROWS = TAIL ? TAIL_ROWS : AROWS, NPASS = TAIL ? 1 : 4;
     constexpr int S = SS::S;
     constexpr int O_D = 8, O_G = 8 * 9, O_E = 8 * (9 + HP * HP);          // byte offsets inside P = [zero | d | G | e]
     static_assert(9 + HP * HP + S <= 256 && S <= S_MAX8, "P = [zero | d (8) | G | e] must fit the 2 KB list area");
@@ -722,7 +787,7 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave & 3, half = wave >> 2;
-    const int64_t m0 = (int64_t)blockIdx.x * AROWS;
+    const int64_t m0 = row0 + (int64_t)blockIdx.x * TILE_ROWS;
     F8_STAMP(0);
 #ifdef PM_F8_STAMPS
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
@@ -731,7 +796,41 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
                                       __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
 #endif
     d4 acc[NJ];
-    tile8_scores<STAGES>(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
+    if (TAIL) {
+        tail8_scores(acc, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
+        // the four K-quarters of a latent half summed in a fixed order, (q0 + q2) + (q1 + q3), through 64 KB of LDS
+        double *red = sm + (size_t)((wave & 1) + 2 * half) * (NJ * 4 * 64) + lane;      // [slot][i][r][lane]
+        if (rg >= 2) {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(i * 4 + r) * 64] = acc[i][r];
+        }
+        lds_barrier();
+        if (rg < 2) {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] += red[(i * 4 + r) * 64];
+        }
+        lds_barrier();
+        double *red2 = sm + (size_t)(1 + 2 * half) * (NJ * 4 * 64) + lane;
+        if (rg == 1) {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red2[(i * 4 + r) * 64] = acc[i][r];
+        }
+        lds_barrier();
+        if (rg == 0) {
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] += red2[(i * 4 + r) * 64];
+        }
+    } else {
+        tile8_scores<STAGES>(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
+    }
     F8_STAMP(1);
 #ifdef PM_F8_STAMPS
     if (tid == 0 && blockIdx.x < 8192) pm_f8_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memtime() - clk0;
@@ -745,7 +844,7 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
         return;
     }
 #endif
-    __builtin_amdgcn_s_barrier();        // every wavefront is done with the ring
+    lds_barrier();                       // every wavefront is done with the ring (TAIL: with the reduction scratch)
     unsigned char *smem = reinterpret_cast<unsigned char *>(sm);
     const double ppil = P.prior_scale * P.pil_bar, ecoef = P.ecoef;
     const double m2e = -2.0 * ecoef;
@@ -805,7 +904,9 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
     // j32 + 32 i
     const int j32 = lane & 31, dsel = lane >> 5;
     const int fkM = 2 * half + dsel;
-    unsigned char *area = smem + T_AREAS + (rg * 4 + fkM) * AREA_BYTES;
+    // (TAIL: the workgroup's 16 datapoints are the 16 slots, one pass; slot 2 wave + dsel is this half-wavefront's)
+    const int slot = TAIL ? 2 * wave + dsel : rg * 4 + fkM;
+    unsigned char *area = smem + T_AREAS + slot * AREA_BYTES;
     const double *rowR = reinterpret_cast<const double *>(area + A_ROW) + j32;
     double *Pm = reinterpret_cast<double *>(area + A_P);
     unsigned char *Pb = area + A_P;
@@ -820,7 +921,7 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
 
     // Global addresses: a wave-uniform base per output (the tile's first row) + a 32-bit byte offset per lane.  Rows
     // beyond N shadow the shard's last row: they recompute and rewrite exactly its values.
-    const int rows_left = (int)(N - m0 < AROWS ? N - m0 : AROWS);        // >= 1
+    const int rows_left = (int)(N - m0 < TILE_ROWS ? N - m0 : TILE_ROWS);        // >= 1
     const char *yn_t = reinterpret_cast<const char *>(ynorm2 + m0);
     const char *ymu_t = ymu ? reinterpret_cast<const char *>(ymu + m0) : nullptr;
     char *cand_t = reinterpret_cast<char *>(cand + m0 * HP);
@@ -834,14 +935,25 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
     const uint32_t *t_tab = reinterpret_cast<const uint32_t *>(smem + T_TAB);
     double m_sig = 0.0, m_fs = 0.0, m_cnt = 0.0;        // per-lane partial sums of the scalar statistics
 
-    // scores of pass 0 -> LDS
+    // scores of pass 0 -> LDS (TAIL: the wavefronts holding the K-sums write all 16 datapoints' rows)
+    if (TAIL) {
+        if (rg == 0) {
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) rowW[16 * i] = acc[i][0];
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i)
+                    reinterpret_cast<double *>(smem + T_AREAS + (fk + 4 * r) * AREA_BYTES + A_ROW)[half * 128 + j16 + 16 * i] =
+                        acc[i][r];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) rowW[16 * i] = acc[i][0];
+    }
     F8_STAMP(2);
 
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int lrow = 16 * rg + fkM + 4 * r;
+    for (int r = 0; r < NPASS; ++r) {
+        int lrow = TAIL ? slot : 16 * rg + fkM + 4 * r;
         const bool live = lrow < rows_left;
         lrow = live ? lrow : rows_left - 1;
         double yn = *reinterpret_cast<const double *>(yn_t + (uint32_t)lrow * 8u);
@@ -911,8 +1023,8 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
             ac = reinterpret_cast<const double *>(area + A_ROW)[myc];
             cl[j32] = myc;
         }
-        if (!(PM_F8_SKIP & 16)) lds_barrier();
-        if (r + 1 < 4) {
+        if (!TAIL && !(PM_F8_SKIP & 16)) lds_barrier();
+        if (!TAIL && r + 1 < 4) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i) rowW[16 * i] = acc[i][r + 1 < 4 ? r + 1 : 3];
         }
@@ -927,7 +1039,11 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
         double wmuc = 0.0;
         if (wmu && j32 < HP) wmuc = wmu[myc];
         // singleton log-joints meanwhile: f_h = prior + ecoef (|W_h|^2 - 2 a_h + |y|^2)
+#if PM_F8_SKIP & 128
+        char *out = out_t + ((uint32_t)(lrow & 1) * ldl8 + (uint32_t)j32 * 8u);  // (timing only: every row into rows 0/1)
+#else
         char *out = out_t + ((uint32_t)lrow * ldl8 + (uint32_t)j32 * 8u);        // &logpj[n, j32]
+#endif
         const double f0 = ecoef * yn;
         double mx = f0;
 #pragma unroll
@@ -941,8 +1057,8 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
         if (!(PM_F8_SKIP & 4)) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i)
-                if (FULL || j32 + 32 * i < H) *reinterpret_cast<double *>(out + 8 * (1 + 32 * i)) = a[i];
-            if (j32 == 0) *reinterpret_cast<double *>(out) = f0;
+                if (FULL || j32 + 32 * i < H) F8_STORE(out + 8 * (1 + 32 * i), a[i]);
+            if (j32 == 0) F8_STORE(out, f0);
         }
         Pm[9 + j32] = G0;
         Pm[9 + 32 + j32] = G1;
@@ -971,7 +1087,7 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
                                             *reinterpret_cast<const double *>(Pb + t4));
                     PeA[s0] = e;
                     f = fma(ecoef, yn + e, pg);
-                    if (!(PM_F8_SKIP & 4)) *reinterpret_cast<double *>(outS + 8 * s0) = f;
+                    if (!(PM_F8_SKIP & 4)) F8_STORE(outS + 8 * s0, f);
                 }
                 fs[nf++] = f;
                 mx = vmax64(mx, f);
@@ -1090,10 +1206,10 @@ __global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8s_kernel(
     if (est && lse) {
         // the four passes' log-evidences at once: lane r of the half-wavefront takes pass r
         wave_lds_sync16();
-        const int rr = j32 & 3;
+        const int rr = TAIL ? 0 : (j32 & 3);
         const double lse_n = mxs[rr] + log_ge1(sms[rr]);
-        const int lrow = 16 * rg + fkM + 4 * rr;
-        if (j32 < 4 && lrow < rows_left) {
+        const int lrow = TAIL ? slot : 16 * rg + fkM + 4 * rr;
+        if (j32 < NPASS && lrow < rows_left) {
             lse[m0 + lrow] = lse_n;
             m_fs += lse_n;
             m_cnt += 1.0;
@@ -1163,6 +1279,33 @@ static const bool pm_f8_force_generic = true;
 #else
 static const bool pm_f8_force_generic = false;
 #endif
+#ifdef PM_F8_NO_TAIL
+static const bool pm_f8_force_no_tail = true;
+#else
+static const bool pm_f8_force_no_tail = false;
+#endif
+
+// The lean passes apply (H' = 8, the complete state set of sizes 2 .. gamma, gamma in {3, 4}): pm_bsc_estep_fused8_f64
+// then takes a WHOLE shard in one call -- whole rounds of 64-row tiles plus the TAIL kernel for a ragged remainder -- and
+// also produces the M-step statistics when asked.
+// Leading rows of an N-row shard the 64-row-tile launch takes (the TAIL launch takes the rest): whole rounds of resident
+// workgroups; everything when the ragged round is mostly full (>= 70 %) or too large for two rounds of 16-row workgroups.
+extern "C" int64_t pm_bsc_fused8_main_rows(int64_t N, int64_t D) {
+    if (N <= 0) return 0;
+    if (D % TAIL_DK != 0) return N;                   // (the TAIL kernel walks K in steps of 16 columns)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    const int64_t rnd = 2 * (int64_t)cus * AROWS;
+    const int64_t main_rows = N / rnd * rnd, rest = N - main_rows;
+    if (pm_f8_force_no_tail || rest * 10 >= rnd * 7 || rest > 2 * (int64_t)cus * TAIL_ROWS) return N;
+    return main_rows;
+}
+
+extern "C" int pm_bsc_fused8_whole_shard(int64_t H, int64_t Hprime, int64_t gamma, int64_t S) {
+    if (H <= 128 || H > 256 || Hprime != 8) return 0;
+    return ((gamma == 4 && S == StateSet<8, 4>::S) || (gamma == 3 && S == StateSet<8, 3>::S)) ? 1 : 0;
+}
 
 extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
                                        const double *ynorm2, const double *wmu, const double *ymu,
@@ -1170,9 +1313,10 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
                                        const int32_t *size_offsets_host, int64_t S, int64_t gamma,
                                        const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
                                        int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
-                                       double *expect, int64_t lde, double *stats, int64_t D_stats, void *stream) {
+                                       double *expect, int64_t lde, double *stats, int64_t D_stats, int part,
+                                       void *stream) {
     if (!Y || !Wt || !gram || !ynorm2 || !cand || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || ldy < D ||
-        ldw < D || !(mode & 3) || ((wmu == nullptr) != (ymu == nullptr)))
+        ldw < D || !(mode & 3) || ((wmu == nullptr) != (ymu == nullptr)) || part < 0 || part > 2)
         return PM_EINVAL;
     if ((mode & 2) && (!params_host || !logpj || ldl < 1 + H + S || gamma < 1 || gamma > Hprime ||
                        (S > 0 && (!state_masks || !state_parents || !size_offsets_host))))
@@ -1200,42 +1344,58 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
                            gram, ynorm2, wmu, ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H,  \
                            (int)Hprime, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats);                \
     } while (0)
-#define PM_LAUNCH8SM(G, F, M)                                                                                          \
-    do {                                                                                                               \
-        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8s_kernel<4, 8, G, F, M>), \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_s))                \
-            return e;                                                                                                  \
-        hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, M>), grid, block, shmem_s, s, Y, ldy, Wt, ldw,        \
-                           (int)D, gram, ynorm2, wmu, ymu, state_masks, state_parents, P, N, (int)H, mode, cand,      \
-                           logpj, ldl, lse, expect, lde, stats, (int)D_stats);                                         \
-    } while (0)
-#define PM_LAUNCH8S(G, F)             \
-    do {                              \
-        if (stats) {                  \
-            PM_LAUNCH8SM(G, F, true); \
-        } else {                      \
-            PM_LAUNCH8SM(G, F, false);\
-        }                             \
-    } while (0)
     // the lean passes: H' = 8 and the complete state set of sizes 2 .. gamma (what generate_state_matrix builds)
     const size_t shmem_s = sizeof(double) * 4 * STAGE > (size_t)LEAN_LDS_BYTES ? sizeof(double) * 4 * STAGE
                                                                                 : (size_t)LEAN_LDS_BYTES;
-    bool lean_ok = !pm_f8_force_generic && Hprime == 8 &&
-                   ((gamma == 4 && S == StateSet<8, 4>::S) || (gamma == 3 && S == StateSet<8, 3>::S));
-    if (lean_ok && (mode & 2))
-        for (int g = 2; g <= gamma; ++g) lean_ok = lean_ok && size_offsets_host[g - 2] == StateSet<8, 4>::off(g);
-    if (lean_ok && gamma == 4) {
-        if (H == 256) PM_LAUNCH8S(4, true);
-        else PM_LAUNCH8S(4, false);
-    } else if (lean_ok) {
-        if (H == 256) PM_LAUNCH8S(3, true);
-        else PM_LAUNCH8S(3, false);
+    const bool lean_ok = pm_bsc_fused8_whole_shard(H, Hprime, gamma, S) && !pm_f8_force_generic;
+    if (lean_ok && (mode & 2) && S > 0)
+        for (int g = 2; g <= gamma; ++g)
+            if (size_offsets_host[g - 2] != (gamma == 4 ? StateSet<8, 4>::off(g) : StateSet<8, 3>::off(g))) return PM_EINVAL;
+#define PM_LAUNCH8SMT(G, F, M, T, GRID, SH, NN, R0)                                                                    \
+    do {                                                                                                               \
+        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SH)))                   \
+            return e;                                                                                                  \
+        hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), dim3((unsigned)(GRID)), block, (SH), s, Y, ldy, \
+                           Wt, ldw, (int)D, gram, ynorm2, wmu, ymu, state_masks, state_parents, P, (int64_t)(NN),    \
+                           (int)H, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, (int64_t)(R0));     \
+    } while (0)
+#define PM_LAUNCH8ST(G, F, T, GRID, SH, NN, R0)            \
+    do {                                                    \
+        if (stats) {                                        \
+            PM_LAUNCH8SMT(G, F, true, T, GRID, SH, NN, R0); \
+        } else {                                            \
+            PM_LAUNCH8SMT(G, F, false, T, GRID, SH, NN, R0);\
+        }                                                   \
+    } while (0)
+#define PM_LAUNCH8SGF(T, GRID, SH, NN, R0)                             \
+    do {                                                                \
+        if (gamma == 4) {                                               \
+            if (H == 256) PM_LAUNCH8ST(4, true, T, GRID, SH, NN, R0);   \
+            else PM_LAUNCH8ST(4, false, T, GRID, SH, NN, R0);           \
+        } else {                                                        \
+            if (H == 256) PM_LAUNCH8ST(3, true, T, GRID, SH, NN, R0);   \
+            else PM_LAUNCH8ST(3, false, T, GRID, SH, NN, R0);           \
+        }                                                               \
+    } while (0)
+    if (lean_ok) {
+        // Whole rounds of resident workgroups (2 per CU x 64 datapoints) go to the 64-row tiles; a ragged last round that
+        // fills most of a round stays with them; a small remainder (up to two rounds of 16-row workgroups) goes to the
+        // TAIL kernel, whose workgroups split K four ways; anything in between is cheaper as a partial round of tiles.
+        const int64_t main_rows = pm_bsc_fused8_main_rows(N, D);
+        const int64_t rest = N - main_rows;
+        if (main_rows > 0 && part != 2) PM_LAUNCH8SGF(false, (main_rows + AROWS - 1) / AROWS, shmem_s, main_rows, 0);
+        if (rest > 0 && part != 1) PM_LAUNCH8SGF(true, (rest + TAIL_ROWS - 1) / TAIL_ROWS, (size_t)LEAN_LDS_BYTES, N, main_rows);
+    } else if (part == 2) {
+        return PM_OK;                                   // (no TAIL launch outside the lean passes)
     } else if (stats) {
         return PM_ERANGE;                               // (M-statistics ride on the lean passes only)
     } else if (H == 256) PM_LAUNCH8(true);
     else PM_LAUNCH8(false);
-#undef PM_LAUNCH8S
-#undef PM_LAUNCH8SM
+#undef PM_LAUNCH8SGF
+#undef PM_LAUNCH8ST
+#undef PM_LAUNCH8SMT
+
 #undef PM_LAUNCH8
     return (int)hipGetLastError();
 }

@@ -191,11 +191,29 @@ class BSC_ET(DeviceCAModel):
             p = holder[name] = (t, buf)
         return p[1]
 
+    def _tile8_whole_shard(self):
+        """The 8-wavefront tile with its lean passes applies (config 2's shape class): one C call per shard."""
+        if self.fused_tile == '4':
+            return False
+        lib = _lib.load()
+        D8 = (self.D + 7) // 8 * 8
+        return bool(lib.pm_bsc_fused8_supported(self.H, D8, self.Hprime, self.no_states)
+                    and lib.pm_bsc_fused8_whole_shard(self.H, self.Hprime, self.gamma, self.no_states))
+
+    def _dominant_rows(self, N):
+        """Datapoints the launch labelled ``estep_fused`` covers (bench.py's roofline accounting)."""
+        if self._tile8_whole_shard():
+            D8 = (self.D + 7) // 8 * 8
+            return int(_lib.load().pm_bsc_fused8_main_rows(N, D8)) or N
+        return self._fused_rows(N)
+
     def _fused_rows(self, N):
         """Rows of the shard the one-kernel E-step takes: whole rounds of resident workgroups (2 per CU, 64 datapoints
         each).  A ragged last round would run a fraction of the chip for a whole tile time (tiles cannot be split over
         K: the row passes need complete scores), so those rows go through the two-kernel path, whose GEMM does split K
         -- unless they fill most of a round anyway, or the shard is smaller than one round."""
+        if self._tile8_whole_shard():
+            return N          # the 8-wavefront kernels take the whole shard (a TAIL launch for the ragged round)
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         rnd = 2 * cus * 64
         if N < rnd or os.environ.get("PM_FUSED_SPLIT", "1") != "1":
@@ -224,11 +242,20 @@ class BSC_ET(DeviceCAModel):
         D8 = Y8.shape[1]
         # the 8-wavefront tile (bsc_fused8.hip) where it applies; its M-statistics ride on the lean passes (H' = 8)
         tile8 = (self.fused_tile != '4' and bool(_lib.load().pm_bsc_fused8_supported(H, D8, Hp, S))
-                 and (mstats is None or (Hp == 8 and self.gamma in (3, 4))))
-        self._call("estep_fused", "pm_bsc_estep_fused8_f64" if tile8 else "pm_bsc_estep_fused_f64", _ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
-                   _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
-                   S, self.gamma, Pref, main, Y8.shape[1], H, Hp, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse),
-                   _ptr(mstats[0]) if mstats else None, H, _ptr(mstats[1]) if mstats else None, self.D, self._stream())
+                 and (mstats is None or self._tile8_whole_shard()))
+        args = (_ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
+                _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
+                S, self.gamma, Pref, main, Y8.shape[1], H, Hp, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse),
+                _ptr(mstats[0]) if mstats else None, H, _ptr(mstats[1]) if mstats else None, self.D)
+        if tile8:
+            # two launches, labelled apart (timers / traces): whole rounds of 64-row tiles, then the ragged remainder
+            main_rows = int(_lib.load().pm_bsc_fused8_main_rows(main, Y8.shape[1])) if self._tile8_whole_shard() else main
+            if main_rows > 0:
+                self._call("estep_fused", "pm_bsc_estep_fused8_f64", *(args + (1, self._stream())))
+            if main_rows < main:
+                self._call("estep_fused_tail", "pm_bsc_estep_fused8_f64", *(args + (2, self._stream())))
+            return main
+        self._call("estep_fused", "pm_bsc_estep_fused_f64", *(args + (self._stream(),)))
         return main
 
     # ---- scores GEMM, then the fused, chunked select + E-step (two-kernel path) -------------------

@@ -2,7 +2,7 @@
 // of libprosper_hip.so (argv[1]), runs pm_bsc_estep_fused_f64 / pm_bsc_estep_fused8_f64 on synthetic data and prints
 // milliseconds per launch (HIP events).  Used with ablation / stamp builds of the library (scratch/f8_variants.sh);
 // correctness is the job of tests/, not of this program.
-//   f8_bench <lib.so> <tile 4|8> [N=196608] [reps=20] [stamps 0|1] [mstats 0|1]
+//   f8_bench <lib.so> <tile 4|8> [N=196608] [reps=20] [stamps 0|1] [mstats 0|1] [part 0|1|2]
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -28,7 +28,11 @@
 typedef int (*fused_fn)(const double *, int64_t, const double *, int64_t, const double *, const double *, const double *,
                         const double *, const uint16_t *, const uint16_t *, const int32_t *, int64_t, int64_t,
                         const pm_bsc_estep_params *, int64_t, int64_t, int64_t, int64_t, int, int32_t *, double *, int64_t,
-                        double *, double *, int64_t, double *, int64_t, void *);
+                        double *, double *, int64_t, double *, int64_t, int, void *);
+typedef int (*fused4_fn)(const double *, int64_t, const double *, int64_t, const double *, const double *, const double *,
+                         const double *, const uint16_t *, const uint16_t *, const int32_t *, int64_t, int64_t,
+                         const pm_bsc_estep_params *, int64_t, int64_t, int64_t, int64_t, int, int32_t *, double *, int64_t,
+                         double *, double *, int64_t, double *, int64_t, void *);
 typedef int (*gemm_fn)(const double *, int64_t, const double *, int64_t, double *, int64_t, int64_t, int64_t, int64_t, void *);
 typedef int (*stamps_fn)(unsigned long long *, int);
 
@@ -85,7 +89,9 @@ int main(int argc, char **argv) {
         fprintf(stderr, "%s\n", dlerror());
         return 1;
     }
-    fused_fn fused = (fused_fn)dlsym(lib, tile == 8 ? "pm_bsc_estep_fused8_f64" : "pm_bsc_estep_fused_f64");
+    fused_fn fused = (fused_fn)dlsym(lib, "pm_bsc_estep_fused8_f64");
+    fused4_fn fused4 = (fused4_fn)dlsym(lib, "pm_bsc_estep_fused_f64");
+    const int part = argc > 7 ? atoi(argv[7]) : 0;
     gemm_fn gemm = (gemm_fn)dlsym(lib, "pm_gemm_nt_f64");
     if (!fused || !gemm) return 1;
 
@@ -161,8 +167,11 @@ int main(int argc, char **argv) {
     P.prior_scale = 1.0;
     P.mu_sqnorm = 0.0;
     auto launch = [&]() {
+        if (tile != 8)
+            return fused4(dY, D, dW, D, dG, dyn, nullptr, nullptr, dmasks, dparents, size_off.data(), S, gamma, &P, N, D, H,
+                          Hp, 3, dcand, dlogpj, Kpad, dlse, dexpect, H, dstats, D, nullptr);
         return fused(dY, D, dW, D, dG, dyn, nullptr, nullptr, dmasks, dparents, size_off.data(), S, gamma, &P, N, D, H, Hp,
-                     3, dcand, dlogpj, Kpad, dlse, dexpect, H, dstats, D, nullptr);
+                     3, dcand, dlogpj, Kpad, dlse, dexpect, H, dstats, D, part, nullptr);
     };
     for (int i = 0; i < 10; ++i)
         if (int e = launch()) {

@@ -8,6 +8,6 @@ for v in "$@"; do
   name=${v%%:*}; rest=${v#*:}; tile=${rest%%:*}; ms=0; st=0
   [ "$rest" != "$tile" ] && ms=${rest#*:}
   [ "$name" = "stamps" ] && st=1
-  timeout 120 $B scratch/libs/libpm_$name.so $tile 196608 20 $st $ms 2>&1 | grep -v amdgpu.ids >> $OUT
+  timeout 120 $B scratch/libs/libpm_$name.so $tile ${F8_N:-196608} 20 $st $ms ${F8_PART:-0} 2>&1 | grep -v amdgpu.ids >> $OUT
 done
 cat $OUT
