@@ -274,6 +274,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     comm = parallel.Comm()
     comm.time_collectives(True)
+    # self-check of the launch (a SCALE record must be attributable): the process group has as many ranks as --gpus asks
+    # for, every rank sits on its own device
+    assert comm.size == world == max(1, args.gpus), "--gpus %d but WORLD_SIZE / process group say %d / %d" % (
+        args.gpus, world, comm.size)
+    if world > 1:
+        devs = comm.allgather((rank, local_rank, torch.cuda.current_device()))
+        assert len({d[2] for d in devs}) == world and sorted(d[0] for d in devs) == list(range(world)), devs
 
     def barrier():
         torch.cuda.synchronize()
@@ -419,6 +426,9 @@ def main():
     elapsed, em_elapsed = float(per_rank[:, 0].max()), float(per_rank[:, 1].max())   # MAX over ranks
 
     if rank == 0:
+        # ... and every rank drew its own rows (seeds differ) -- a shard read twice would double-count throughput
+        seeds = [int(v) for v in per_rank[:, 3]]
+        assert len(set(seeds)) == world and all(int(v) == N for v in per_rank[:, 4]), (seeds, per_rank[:, 4])
         fused = model._fused()
         dom = "estep_fused" if fused else "scores_gemm"
         chunk = model._dominant_rows(N) if fused else model._launch_rows(N)  # datapoints the dominant launch covers

@@ -451,6 +451,19 @@ int pm_gsc_estep_lpj_f64(const double *scores, int64_t lds, const double *gram, 
 int pm_gsc_component_scores_f64(const double *scores, int64_t lds, const double *ynorm2, const double *tables,
                                 double sigma_sq, int64_t N, int64_t H, double *out, int64_t ldo, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * CAModel.inference (prosper/em/camodels/__init__.py:256-375), after compute_lpj
+ * ------------------------------------------------------------------------------------- */
+
+/* Per datapoint, from its K = 1 + H + S log-joints (logpj (N, ldl), columns [null ; singletons ; multi-cause states over
+ * `cand` (N, Hprime) in state_masks order]): the topK columns of the normalised posterior, descending, ties larger column
+ * first (argsort()[..., ::-1], :302) -> top_idx (N, topK) int32, their normalised log-probabilities top_lpc and their
+ * log-joints relative to the row maximum top_rel (what the reference reports for logprob=False, :309-312), and the
+ * log-marginals log p(s_h = 1 | y) -> marg (N, ldm >= H) (:321-327). */
+int pm_infer_topk_f64(const double *logpj, int64_t ldl, const int32_t *cand, const uint16_t *state_masks, int64_t N,
+                      int64_t H, int64_t Hprime, int64_t S, int64_t topK, int32_t *top_idx, double *top_lpc,
+                      double *top_rel, double *marg, int64_t ldm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

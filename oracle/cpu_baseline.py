@@ -103,6 +103,21 @@ def parity_case(path, D, H, Hp, gamma, N=1536, steps=3):
     np.savez(path, **out)
 
 
+def _physical_cores():
+    """Worker processes = PHYSICAL cores this process may run on (one BLAS-free NumPy loop per core): the logical count
+    (SMT siblings) oversubscribes the cores' memory system and makes the baseline a straw man."""
+    logical = len(os.sched_getaffinity(0))
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or logical
+        total = psutil.cpu_count(logical=True) or logical
+        # the affinity mask may cover a part of the machine: scale the physical count with it
+        phys = max(1, min(logical, int(round(phys * logical / float(total)))))
+        return phys
+    except Exception:
+        return logical
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--D", type=int, default=1024)
@@ -124,7 +139,7 @@ def main():
         return
     if a.parity_out:
         parity_case(a.parity_out, a.D, a.H, a.Hprime, a.gamma)
-    cores = a.cores or len(os.sched_getaffinity(0))
+    cores = a.cores or _physical_cores()
     # one process alone on the box: the per-core rate without the memory-system contention of `cores` workers
     solo = None
     if a.solo_budget > 0:
@@ -160,7 +175,7 @@ def main():
     print(json.dumps({
         "value": e_rate, "unit": "datapoints/s", "cores": cores, "kind": "port",
         "sample": "%d rows of the config-2 generator (D=%d H=%d H'=%d gamma=%d), %d rows/chunk, %.0f s E-step budget "
-                  "per core; faithful per-datapoint NumPy loops, 1 BLAS thread per process" % (
+                  "per core; faithful per-datapoint NumPy loops, one process per PHYSICAL core, 1 BLAS thread each" % (
                       rows, a.D, a.H, a.Hprime, a.gamma, a.chunk, a.budget),
         "per_core_estep": per_core_e, "per_core_mstep": per_core_m, "full_step_value": full,
         "uncontended_per_core": solo, "vectorised": vec,

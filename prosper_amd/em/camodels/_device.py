@@ -676,11 +676,22 @@ class DeviceCAModel(CAModel):
                 cd = cd.long()
                 n_cur, K = lp.shape
                 Hp = self.Hprime
-                lpc = lp - torch.logsumexp(lp, dim=1, keepdim=True)          # normalised log posterior
                 k_eff = min(topK, K)
-                top_val, top_idx = torch.topk(lpc, k_eff, dim=1, largest=True, sorted=True)
-                # upstream quirk (:309-312): logprob=False reports exp(logpj - max), NOT the normalised value
-                top_rel = torch.gather(lp, 1, top_idx) - lp.max(dim=1, keepdim=True).values
+                # top-K columns of the normalised posterior and the log-marginals: one HIP pass over the rows
+                # (csrc/infer_kernels.hip).  Upstream quirk (:309-312): logprob=False reports exp(logpj - max), NOT the
+                # normalised value -- the kernel returns both
+                SMh = self.state_matrix.astype(np.int64)
+                mk = (SMh << np.arange(SMh.shape[1])[None, :]).sum(axis=1).astype(np.uint16) if SMh.size else np.zeros(1, np.uint16)
+                masks_d = torch.from_numpy(mk.view(np.int16).copy()).to(dev)
+                lp = lp.contiguous() if lp.stride(1) != 1 else lp
+                cd32 = cd.to(torch.int32).contiguous()
+                top_idx32 = torch.empty((n_cur, k_eff), dtype=torch.int32, device=dev)
+                top_val = torch.empty((n_cur, k_eff), dtype=torch.float64, device=dev)
+                top_rel = torch.empty((n_cur, k_eff), dtype=torch.float64, device=dev)
+                m_blk = torch.empty((n_cur, H), dtype=torch.float64, device=dev)
+                self._call("infer_topk", "pm_infer_topk_f64", _ptr(lp), lp.stride(0), _ptr(cd32), _ptr(masks_d), n_cur, H, Hp,
+                           self.no_states, k_eff, _ptr(top_idx32), _ptr(top_val), _ptr(top_rel), _ptr(m_blk), H, self._stream())
+                top_idx = top_idx32.long()
                 res_Hprime[ind_n] = float(self.Hprime)
                 res_gamma[ind_n] = float(self.gamma)
                 # top-K states as H-dimensional binary vectors
@@ -701,18 +712,7 @@ class DeviceCAModel(CAModel):
                     s_blk[nn_[:, None].expand(-1, Hp), mm_[:, None].expand(-1, Hp), cd[nn_]] = rows
                 res_s[ind_n, :k_eff] = s_blk
                 res_p[ind_n, :k_eff] = top_val if logprob else torch.exp(top_rel)
-                # marginals: log p(s_h = 1 | y) = logsumexp over the states containing h
-                m_blk = lpc[:, 1:H + 1].clone()
-                if self.no_states:
-                    multi_lp = lpc[:, H + 1:]                                       # (n, S)
-                    SMb = SM.bool()
-                    for j in range(Hp):
-                        lj = torch.logsumexp(torch.where(SMb[:, j][None, :], multi_lp,
-                                                         torch.full_like(multi_lp, float("-inf"))), dim=1)
-                        hj = cd[:, j]
-                        rows_n = torch.arange(n_cur, device=dev)
-                        m_blk[rows_n, hj] = torch.logaddexp(lpc[rows_n, 1 + hj], lj)
-                res_m[ind_n] = m_blk
+                res_m[ind_n] = m_blk        # log p(s_h = 1 | y): log-sum-exp over the states containing h (the kernel)
                 if not adaptive:
                     break
                 which = ((res_s[:, 0, :] != 0).sum(-1) == self.gamma)
