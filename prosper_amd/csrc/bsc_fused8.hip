@@ -71,6 +71,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 #ifdef PM_F8_STAMPS
 __device__ unsigned long long pm_f8_stamps[8192][8];
+__device__ unsigned long long pm_f8_estamps[16][32];       // workgroup 0's wavefronts: phase stamps inside the row passes
+#define F8_ESTAMP(slot)                                                                           \
+    do {                                                                                          \
+        if (blockIdx.x == 300 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 16)              \
+            pm_f8_estamps[threadIdx.x >> 6][slot] = __builtin_amdgcn_s_memrealtime();             \
+    } while (0)
 #define F8_STAMP(slot)                                                                  \
     do {                                                                                \
         if (threadIdx.x == 0 && blockIdx.x < 8192)                                      \
@@ -78,6 +84,7 @@ __device__ unsigned long long pm_f8_stamps[8192][8];
     } while (0)
 #else
 #define F8_STAMP(slot)
+#define F8_ESTAMP(slot)
 #endif
 
 // workgroup barrier that publishes LDS writes but does NOT wait for global stores (a workgroup-scope fence would drain
@@ -92,6 +99,18 @@ __device__ __forceinline__ double half_max_f64(double v) {
     v = vmax64(v, swz_xor_f64<2>(v));
     v = vmax64(v, swz_xor_f64<4>(v));
     v = vmax64(v, swz_xor_f64<8>(v));
+    v = vmax64(v, swz_xor_f64<16>(v));
+    return v;
+}
+// The same maximum with the four levels inside a 16-lane row as DPP moves (register-file latency) and only the level
+// across the two rows through the LDS crossbar: 13 VALU instructions instead of 5, a fifth of the dependent latency --
+// what the pop rounds of the 16-wavefront kernel want (its row passes run with the matrix pipe idle: latency, not the
+// instruction count, is their price).
+__device__ __forceinline__ double half_max_dpp(double v) {
+    v = vmax64(v, pm_dpp_f64<0xB1>(v));
+    v = vmax64(v, pm_dpp_f64<0x4E>(v));
+    v = vmax64(v, pm_dpp_f64<0x141>(v));
+    v = vmax64(v, pm_dpp_f64<0x140>(v));
     v = vmax64(v, swz_xor_f64<16>(v));
     return v;
 }
@@ -271,6 +290,43 @@ __device__ __forceinline__ void tile8_scores(d4 (&acc)[NJ], double *sm, const do
         }
         __builtin_amdgcn_s_barrier();
 
+#ifdef PM_F8_T32
+        // 32 datapoints x 64 latents per wavefront (row half wave & 1, latent quarter wave >> 1): 2 + 4 fragment reads per
+        // 16 MFMAs instead of 1 + 8
+        const int rb2 = wave & 1, cq = wave >> 1;
+        const int a2_off = (rb2 * 32 + frow) * DK + ((fk ^ sw) << 1);
+        const int b2_off = AROWS * DK + (cq * 64 + frow) * DK + ((fk ^ sw) << 1);
+        d2 fa2[2][2], fb2[2][4];
+        auto read_ab = [&](int stage, int p) {
+            const double *sa = sm + stage * STAGE + a2_off;
+            fa2[p][0] = *reinterpret_cast<const d2 *>(sa);
+            fa2[p][1] = *reinterpret_cast<const d2 *>(sa + 16 * DK);
+            const double *sb = sm + stage * STAGE + b2_off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fb2[p][q] = *reinterpret_cast<const d2 *>(sb + q * 16 * DK);
+        };
+        read_ab(0, 0);
+        auto kstep = [&](int t, int stage, int nstage, int par) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1 && t + 1 < nk) {
+                    int ahead = nk - t - 2;
+                    ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ahead >= 2) wait_vmcnt<2 * L>();
+                    else if (ahead == 1) wait_vmcnt<L>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    read_ab(nstage, par ^ 1);
+                    if (t + STAGES < nk) dma(t + STAGES, stage);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa2[par][g].x, fb2[par][q].x, acc[4 * g + q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa2[par][g].y, fb2[par][q].y, acc[4 * g + q]);
+            }
+        };
+#else
         d2 fa[2];
         d2 fb[2][4];
         fa[0] = read_a(0);
@@ -286,25 +342,226 @@ __device__ __forceinline__ void tile8_scores(d4 (&acc)[NJ], double *sm, const do
                     int ahead = nk - t - 2;
                     ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef PM_F8_KNOWAIT
                     if (ahead >= 2) wait_vmcnt<2 * L>();
                     else if (ahead == 1) wait_vmcnt<L>();
                     else wait_vmcnt<0>();
-#if PM_F8_ABL != 3
+#endif
+#if PM_F8_ABL != 3 && !defined(PM_F8_KNOBAR)
                     __builtin_amdgcn_s_barrier();
 #endif
                     const d2 an = read_a(nstage);
                     if (par) fa[0] = an;
                     else fa[1] = an;
                     read_b(nstage, 0, fb[0]);
+#if !defined(PM_F8_KNODMA) && !defined(PM_F8_KDMALATE)
                     if (t + STAGES < nk) dma(t + STAGES, stage);
+#endif
                 }
                 const d2 af = par ? fa[1] : fa[0];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.x, fb[g][q].x, acc[4 * g + q]);
+#if defined(PM_F8_KDMALATE)
+                if (g == 1 && t + 1 < nk && t + STAGES < nk) dma(t + STAGES, stage);
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.y, fb[g][q].y, acc[4 * g + q]);
             }
         };
+#endif
+        int t = 0;
+        if (STAGES % 2 == 0) {
+            for (; t + STAGES <= nk; t += STAGES) {
+#pragma unroll
+                for (int u = 0; u < STAGES; ++u) kstep(t + u, u, (u + 1) % STAGES, u & 1);
+            }
+        }
+        for (int stage = t % STAGES; t < nk; ++t) {
+            const int nstage = (stage + 1 == STAGES) ? 0 : stage + 1;
+            kstep(t, stage, nstage, t & 1);
+            stage = nstage;
+        }
+    };
+#ifdef PM_F8_PRIO
+    __builtin_amdgcn_s_setprio(PM_F8_PRIO);
+#endif
+    if (half == 0) kloop(std::true_type{});
+    else kloop(std::false_type{});
+#ifdef PM_F8_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+
+}
+
+// The same for the 16-wavefront workgroup (128 datapoints x 256 latents; row group wave & 7, latent half wave >> 3):
+// acc[i][r] = <y_n, W_h>, n = m0 + 16 rg + (lane >> 4) + 4 r, h = 128 half + (lane & 15) + 16 i.
+template <int STAGES>
+__device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const double *__restrict__ Y, int64_t ldy,
+                                             const double *__restrict__ Wt, int64_t ldw, int D, int64_t N, int H,
+                                             int64_t m0, int lane, int wave) {
+    const int rg = wave & 7, half = wave >> 3;
+    constexpr int AROWS = 128, STAGE = (AROWS + HT) * DK;       // (shadow the 8-wavefront tile's constants)
+    // ---------------- K-loop: LDS-DMA ring, one barrier per K-step ------------------------------------------------
+    // DMA sources: wavefront `wave` moves latent blocks wave and wave + 8; the first four wavefronts also move the
+    // datapoint rows of their row group (3 resp. 2 DMA instructions per K-step: the counted waits are per wavefront).
+    // A stage is [rows][8 doubles]; pair p (16 B) of row R sits in slot p ^ PI(R >> 2) of its row, PI = {0, 3, 2, 1}:
+    // ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 --
+    // and with this permutation every group's 16 fragment reads fall into 16 different bank quads (the plain
+    // p ^ (R >> 2) of the 4-wavefront kernel is two-way conflicted: SQ_LDS_BANK_CONFLICT = half the LDS cycles).
+#ifdef PM_F8_OLDSWZ
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((lane >> 4) & 3);
+#else
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+#endif
+    const char *sbase[2];
+    uint32_t soff[2];
+    {
+        int64_t r0 = m0 + 16 * rg;
+        r0 = r0 < N ? r0 : N - 1;
+        int64_t ra = r0 + dr;
+        ra = ra < N ? ra : N - 1;
+        sbase[0] = reinterpret_cast<const char *>(Y + r0 * ldy);
+        soff[0] = (uint32_t)((ra - r0) * ldy * 8 + 16 * dj);
+        {
+            int b0 = 16 * wave;
+            b0 = b0 < H ? b0 : H - 1;
+            int rb = b0 + dr;
+            rb = rb < H ? rb : H - 1;
+            sbase[1] = reinterpret_cast<const char *>(Wt + (int64_t)b0 * ldw);
+            soff[1] = (uint32_t)((int64_t)(rb - b0) * ldw * 8 + 16 * dj);
+        }
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) double *)(sm));
+    auto dma1 = [&](unsigned dst, uint32_t voff, const char *base) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(base)
+                     : "memory");
+    };
+
+    // fragment reads: pair p of row R sits at R*8 + ((p ^ ((R>>2)&3)) << 1) (the slot the DMA wrote)
+    const int frow = lane & 15, fk = lane >> 4;
+#ifdef PM_F8_OLDSWZ
+    const int sw = (frow >> 2) & 3;
+#else
+    const int sw = (4 - (frow >> 2)) & 3;
+#endif
+    const int a_off = (rg * 16 + frow) * DK + ((fk ^ sw) << 1);
+    const int b_off = AROWS * DK + (half * 128 + frow) * DK + ((fk ^ sw) << 1);
+    auto read_a = [&](int stage) { return *reinterpret_cast<const d2 *>(sm + stage * STAGE + a_off); };
+    auto read_b = [&](int stage, int g, d2 (&f)[4]) {
+        const double *sb = sm + stage * STAGE + b_off + g * 4 * 16 * DK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const d2 *>(sb + q * 16 * DK);
+    };
+
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+
+#if PM_F8_ABL == 2
+    const int nk = 8;
+#else
+    const int nk = D / DK;   // host guarantees D % DK == 0, D >= DK
+#endif
+    auto kloop = [&](auto withA) {
+        constexpr bool WA = decltype(withA)::value;
+        constexpr int L = WA ? 2 : 1;          // DMA instructions per K-step of this wavefront
+        auto dma = [&](int kt, int stage) {
+            const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8);
+            const int64_t k0 = (int64_t)kt * (DK * 8);
+            if (WA) dma1(dst + (unsigned)rg * 1024u, soff[0], sbase[0] + k0);
+            dma1(dst + (8u + (unsigned)wave) * 1024u, soff[1], sbase[1] + k0);
+        };
+#pragma unroll
+        for (int t = 0; t < STAGES; ++t)
+            if (t < nk) dma(t, t);
+        {
+            const int behind = (nk < STAGES ? nk : STAGES) - 1;   // K-steps issued beyond step 0
+            if (behind >= 3) wait_vmcnt<3 * L>();
+            else if (behind == 2) wait_vmcnt<2 * L>();
+            else if (behind == 1) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+
+#ifdef PM_F8_T32
+        // 32 datapoints x 64 latents per wavefront (row half wave & 1, latent quarter wave >> 1): 2 + 4 fragment reads per
+        // 16 MFMAs instead of 1 + 8
+        const int rb2 = wave & 1, cq = wave >> 1;
+        const int a2_off = (rb2 * 32 + frow) * DK + ((fk ^ sw) << 1);
+        const int b2_off = AROWS * DK + (cq * 64 + frow) * DK + ((fk ^ sw) << 1);
+        d2 fa2[2][2], fb2[2][4];
+        auto read_ab = [&](int stage, int p) {
+            const double *sa = sm + stage * STAGE + a2_off;
+            fa2[p][0] = *reinterpret_cast<const d2 *>(sa);
+            fa2[p][1] = *reinterpret_cast<const d2 *>(sa + 16 * DK);
+            const double *sb = sm + stage * STAGE + b2_off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fb2[p][q] = *reinterpret_cast<const d2 *>(sb + q * 16 * DK);
+        };
+        read_ab(0, 0);
+        auto kstep = [&](int t, int stage, int nstage, int par) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1 && t + 1 < nk) {
+                    int ahead = nk - t - 2;
+                    ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ahead >= 2) wait_vmcnt<2 * L>();
+                    else if (ahead == 1) wait_vmcnt<L>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    read_ab(nstage, par ^ 1);
+                    if (t + STAGES < nk) dma(t + STAGES, stage);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa2[par][g].x, fb2[par][q].x, acc[4 * g + q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa2[par][g].y, fb2[par][q].y, acc[4 * g + q]);
+            }
+        };
+#else
+        d2 fa[2];
+        d2 fb[2][4];
+        fa[0] = read_a(0);
+        read_b(0, 0, fb[0]);
+        auto kstep = [&](int t, int stage, int nstage, int par) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 0) {
+                    read_b(stage, 1, fb[1]);
+                } else if (t + 1 < nk) {
+                    // my reads of this stage are done (lgkmcnt) and my share of K-step t+1 has landed (vmcnt); after the
+                    // barrier that holds for every wavefront: stage t may be refilled, t+1 may be read
+                    int ahead = nk - t - 2;
+                    ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef PM_F8_KNOWAIT
+                    if (ahead >= 2) wait_vmcnt<2 * L>();
+                    else if (ahead == 1) wait_vmcnt<L>();
+                    else wait_vmcnt<0>();
+#endif
+#if PM_F8_ABL != 3 && !defined(PM_F8_KNOBAR)
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    const d2 an = read_a(nstage);
+                    if (par) fa[0] = an;
+                    else fa[1] = an;
+                    read_b(nstage, 0, fb[0]);
+#if !defined(PM_F8_KNODMA) && !defined(PM_F8_KDMALATE)
+                    if (t + STAGES < nk) dma(t + STAGES, stage);
+#endif
+                }
+                const d2 af = par ? fa[1] : fa[0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.x, fb[g][q].x, acc[4 * g + q]);
+#if defined(PM_F8_KDMALATE)
+                if (g == 1 && t + 1 < nk && t + STAGES < nk) dma(t + STAGES, stage);
+#endif
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.y, fb[g][q].y, acc[4 * g + q]);
+            }
+        };
+#endif
         int t = 0;
         if (STAGES % 2 == 0) {
             for (; t + STAGES <= nk; t += STAGES) {
@@ -684,10 +941,12 @@ struct StateSet {
 constexpr int T_SW = 0, T_EW = 2048, T_MUS = 4096, T_ST = 6144;
 constexpr int S_MAX8 = 160;                                   // states the tables are sized for
 constexpr int T_TAB = T_ST + 16 * S_MAX8, T_EXP = T_TAB + 4 * S_MAX8;        // 8704, 9344
-constexpr int T_EXPC = T_EXP + 1024, T_AREAS = T_EXPC + 192;                 // 10368, 10560 (EXPC: 7 constants; 24 doubles at the end)
+constexpr int T_EXPC = T_EXP + 1024, T_AREAS = T_EXPC + 384;                 // 10368, 10752 (EXPC: 7 constants; 48 doubles at the end)
 constexpr int A_ROW = 0, A_P = 2048, A_WIN = 4096, A_MISC = 4160, AREA_BYTES = 4288;
-constexpr int LEAN_LDS_BYTES = T_AREAS + 16 * AREA_BYTES;     // 79168
+constexpr int LEAN_LDS_BYTES = T_AREAS + 16 * AREA_BYTES;     // 79360
 static_assert(LEAN_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+constexpr int LEAN16_LDS_BYTES = T_AREAS + 32 * AREA_BYTES;   // 147968: the 16-wavefront workgroup, one per CU
+static_assert(LEAN16_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 // e^x for x in [-708, 0] from LDS tables: E[j] = 2^(j/128) (128 doubles) and C = {128/ln2, 1.5 2^52, -ln2/128 hi, lo,
 // 1/120, 1/24, 1/6}.  x = k ln2/128 + r, e^r by a degree-5 polynomial, 2^(k/128) = 2^N E_j (pm_exp_tab of pm_common.h
@@ -768,8 +1027,19 @@ __device__ __forceinline__ void tail8_scores(d4 (&acc)[NJ], const double *__rest
     }
 }
 
-template <int STAGES, int HP, int GAMMA, bool FULL, bool MSTATS, bool TAIL>
-__global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kernel(
+// W16 (the shipped main launch): a workgroup of SIXTEEN wavefronts owns 128 datapoints, one per CU (4 wavefronts per
+// SIMD as with two 8-wavefront workgroups).  Measured on the stamps (profiles/r03_*): with two independent workgroups per
+// CU one ends up in its row passes while the other K-loops -- the row passes, throttled to one VALU slot per MFMA, then
+// take 118 us instead of the 21 us they need alone, and the lone K-loop 144 us instead of the 109 us two K-loops take per
+// tile when they share a SIMD.  One workgroup keeps all 16 wavefronts in the same phase: an MFMA-bound K-loop over
+// 128 rows (W fetched once per 128 rows), then row passes at full vector rate.
+#ifdef PM_F8_W8
+constexpr bool W16_DEFAULT = false;
+#else
+constexpr bool W16_DEFAULT = true;
+#endif
+template <int STAGES, int HP, int GAMMA, bool FULL, bool MSTATS, bool TAIL, bool W16 = (W16_DEFAULT && !TAIL)>
+__global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kernel(
     const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wt, int64_t ldw, int D,
     const double *__restrict__ gram, const double *__restrict__ ynorm2, const double *__restrict__ wmu,
     const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
@@ -777,7 +1047,8 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
     int64_t ldl, double *__restrict__ lse, double *__restrict__ expect, int64_t lde, double *__restrict__ stats,
     int Dstats, int64_t row0) {
     using SS = StateSet<HP, GAMMA>;
-    constexpr int TILE_ROWS = TAIL ? TAIL_ROWS : AROWS, NPASS = TAIL ? 1 : 4;
+    constexpr int TILE_ROWS = TAIL ? TAIL_ROWS : (W16 ? 128 : AROWS), NPASS = TAIL ? 1 : 4;
+    constexpr int NWAVES = W16 ? 16 : 8, RGMASK = W16 ? 7 : 3, HSHIFT = W16 ? 3 : 2;
     constexpr int S = SS::S;
     constexpr int O_D = 8, O_G = 8 * 9, O_E = 8 * (9 + HP * HP);          // byte offsets inside P = [zero | d | G | e]
     static_assert(9 + HP * HP + S <= 256 && S <= S_MAX8, "P = [zero | d (8) | G | e] must fit the 2 KB list area");
@@ -786,7 +1057,7 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave & 3, half = wave >> 2;
+    const int rg = wave & RGMASK, half = wave >> HSHIFT;
     const int64_t m0 = row0 + (int64_t)blockIdx.x * TILE_ROWS;
     F8_STAMP(0);
 #ifdef PM_F8_STAMPS
@@ -828,6 +1099,8 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][r] += red2[(i * 4 + r) * 64];
         }
+    } else if (W16) {
+        tile16_scores<STAGES>(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
     } else {
         tile8_scores<STAGES>(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
     }
@@ -883,7 +1156,7 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
         dst[2] = e4;
         dst[3] = 0;
     }
-    if (tid >= 384) {
+    if (tid >= 384 && tid < 512) {
         const int j = tid - 384;                                      // 128 threads: the exponential's tables
         reinterpret_cast<double *>(smem + T_EXP)[j] = pm_powtab_dev[256 + j];
         if (j < 7) {
@@ -958,7 +1231,9 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
         lrow = live ? lrow : rows_left - 1;
         double yn = *reinterpret_cast<const double *>(yn_t + (uint32_t)lrow * 8u);
         if (ymu_t) yn = yn - 2.0 * *reinterpret_cast<const double *>(ymu_t + (uint32_t)lrow * 8u) + P.mu_sqnorm;
+        F8_ESTAMP(r * 8 + 0);
         if (!(PM_F8_SKIP & 16) || r == 0) lds_barrier();      // the scores of pass r (and, r = 0, the tables) are in LDS
+        F8_ESTAMP(r * 8 + 1);
         double a[NJ];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) a[i] = rowR[32 * i];
@@ -1003,7 +1278,9 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
 #pragma unroll
             for (int q = 0; q < HP; ++q) {
                 const double head = *head_p;
-                const double m = half_max_f64(head);
+                // (16-wavefront workgroup: the passes run with the matrix pipe idle -- latency is their price, DPP moves;
+                // beside a K-loop every VALU instruction costs MFMA time -- the LDS crossbar)
+                const double m = W16 ? half_max_dpp(head) : half_max_f64(head);
                 win[q] = m;                          // the same value from all 32 lanes
                 head_p += (head == m) ? 32 : 0;
             }
@@ -1017,13 +1294,25 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
         } else if (j32 < HP) {
             myc = *reinterpret_cast<const int32_t *>(cand_t + (uint32_t)(lrow * HP + j32) * 4u);
         }
+        F8_ESTAMP(r * 8 + 2);
         // the candidates' scores, then the row areas are free for the next pass's scores
         double ac = 0.0;
         if (j32 < HP) {
             ac = reinterpret_cast<const double *>(area + A_ROW)[myc];
             cl[j32] = myc;
         }
+        // Gram block of the candidates, requested NOW (an L2 round trip that the barrier, the next pass's score rows and the
+        // singleton log-joints below cover): lane j32 fetches G[c_i, c_k] and G[c_(i+4), c_k], i = j32 >> 3, k = j32 & 7
+        double G0 = 0.0, G1 = 0.0;
+        if (est) {
+            wave_lds_sync16();
+            const uint32_t ck8 = (uint32_t)cl[j32 & 7] * 8u;
+            const uint32_t ci0 = (uint32_t)cl[j32 >> 3], ci1 = (uint32_t)cl[4 + (j32 >> 3)];
+            G0 = *reinterpret_cast<const double *>(gram_b + (ci0 * H8 + ck8));
+            G1 = *reinterpret_cast<const double *>(gram_b + (ci1 * H8 + ck8));
+        }
         if (!TAIL && !(PM_F8_SKIP & 16)) lds_barrier();
+        F8_ESTAMP(r * 8 + 3);
         if (!TAIL && r + 1 < 4) {
 #pragma unroll
             for (int i = 0; i < NJ; ++i) rowW[16 * i] = acc[i][r + 1 < 4 ? r + 1 : 3];
@@ -1031,11 +1320,6 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
         if (!est) continue;
 
         // ---------------- E_step (bsc_et.py:119-192) -----------------------------------------------------------------
-        // Gram block of the candidates: lane j32 fetches G[c_i, c_k] and G[c_(i+4), c_k], i = j32 >> 3, k = j32 & 7
-        const uint32_t ck8 = (uint32_t)cl[j32 & 7] * 8u;
-        const uint32_t ci0 = (uint32_t)cl[j32 >> 3], ci1 = (uint32_t)cl[4 + (j32 >> 3)];
-        const double G0 = *reinterpret_cast<const double *>(gram_b + (ci0 * H8 + ck8));
-        const double G1 = *reinterpret_cast<const double *>(gram_b + (ci1 * H8 + ck8));
         double wmuc = 0.0;
         if (wmu && j32 < HP) wmuc = wmu[myc];
         // singleton log-joints meanwhile: f_h = prior + ecoef (|W_h|^2 - 2 a_h + |y|^2)
@@ -1066,6 +1350,7 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
         if (j32 < HP) Pm[1 + j32] = Pm[9 + (HP + 1) * j32] - 2.0 * (ac - wmuc);     // d_k = G_kk - 2 a_k
         if (j32 == 0) Pm[0] = 0.0;
         wave_lds_sync16();
+        F8_ESTAMP(r * 8 + 4);
         // multi-cause states by size: e(s) = e(parent) + d_k + 2 (G terms)
         char *outS = out + 8 * (1 + H);
         double fs[SS::iters(2) + SS::iters(3) + (GAMMA >= 4 ? SS::iters(4) : 0)];
@@ -1099,6 +1384,7 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
             if (mx == 1.2345e300) lse[0] = mx;
             continue;
         }
+        F8_ESTAMP(r * 8 + 5);
         // ---------------- log-sum-exp: only terms within exp(-37) of the largest are evaluated ----------------------
         mx = half_max_f64(mx);
         const double thr = mx + NEGLIGIBLE;
@@ -1139,6 +1425,7 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
             }
         }
         sum = half_sum_f64(sum);
+        F8_ESTAMP(r * 8 + 6);
         if (j32 == 0) {
             mxs[r] = mx;
             sms[r] = sum;
@@ -1222,14 +1509,14 @@ __global__ __launch_bounds__(THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kerne
         lds_barrier();                       // every wavefront's LDS atomics into mus are done; nobody needs expC
         if (lane == 0) {
             red[wave] = sig;
-            red[8 + wave] = fsum;
-            red[16 + wave] = cnt;
+            red[16 + wave] = fsum;
+            red[32 + wave] = cnt;
         }
         lds_barrier();
         double *sc = stats + pm_bsc_stats_offset_scalars_dev(H, Dstats);
         if (tid < 3) {
             double v = 0.0;
-            for (int w = 0; w < 8; ++w) v += red[8 * tid + w];
+            for (int w = 0; w < NWAVES; ++w) v += red[16 * tid + w];
             if (v != 0.0) pm_atomic_add(sc + tid, v);
         }
         double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, Dstats);
@@ -1263,6 +1550,9 @@ using namespace pm_fused8;
 #ifdef PM_F8_STAMPS
 extern "C" int pm_f8_read_stamps(unsigned long long *host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pm_f8_stamps), sizeof(unsigned long long) * 8 * n);
+}
+extern "C" int pm_f8_read_estamps(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pm_f8_estamps), sizeof(unsigned long long) * 16 * 32);
 }
 #endif
 
@@ -1345,8 +1635,13 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
                            (int)Hprime, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats);                \
     } while (0)
     // the lean passes: H' = 8 and the complete state set of sizes 2 .. gamma (what generate_state_matrix builds)
-    const size_t shmem_s = sizeof(double) * 4 * STAGE > (size_t)LEAN_LDS_BYTES ? sizeof(double) * 4 * STAGE
-                                                                                : (size_t)LEAN_LDS_BYTES;
+#ifdef PM_F8_ONE_WG   // (diagnostic: one workgroup per CU)
+    const size_t shmem_s = 100 * 1024;
+#else
+    const size_t shmem_s = W16_DEFAULT ? (size_t)LEAN16_LDS_BYTES      // (>= the ring: 4 stages x 24 KB)
+                                       : (sizeof(double) * 4 * STAGE > (size_t)LEAN_LDS_BYTES ? sizeof(double) * 4 * STAGE
+                                                                                                : (size_t)LEAN_LDS_BYTES);
+#endif
     const bool lean_ok = pm_bsc_fused8_whole_shard(H, Hprime, gamma, S) && !pm_f8_force_generic;
     if (lean_ok && (mode & 2) && S > 0)
         for (int g = 2; g <= gamma; ++g)
@@ -1356,7 +1651,8 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
         if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SH)))                   \
             return e;                                                                                                  \
-        hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), dim3((unsigned)(GRID)), block, (SH), s, Y, ldy, \
+        hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), dim3((unsigned)(GRID)),                       \
+                           dim3((!(T) && W16_DEFAULT) ? 1024 : THREADS), (SH), s, Y, ldy,                              \
                            Wt, ldw, (int)D, gram, ynorm2, wmu, ymu, state_masks, state_parents, P, (int64_t)(NN),    \
                            (int)H, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, (int64_t)(R0));     \
     } while (0)
@@ -1384,7 +1680,8 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
         // TAIL kernel, whose workgroups split K four ways; anything in between is cheaper as a partial round of tiles.
         const int64_t main_rows = pm_bsc_fused8_main_rows(N, D);
         const int64_t rest = N - main_rows;
-        if (main_rows > 0 && part != 2) PM_LAUNCH8SGF(false, (main_rows + AROWS - 1) / AROWS, shmem_s, main_rows, 0);
+        constexpr int MROWS = W16_DEFAULT ? 128 : AROWS;
+        if (main_rows > 0 && part != 2) PM_LAUNCH8SGF(false, (main_rows + MROWS - 1) / MROWS, shmem_s, main_rows, 0);
         if (rest > 0 && part != 1) PM_LAUNCH8SGF(true, (rest + TAIL_ROWS - 1) / TAIL_ROWS, (size_t)LEAN_LDS_BYTES, N, main_rows);
     } else if (part == 2) {
         return PM_OK;                                   // (no TAIL launch outside the lean passes)

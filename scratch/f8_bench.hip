@@ -233,6 +233,22 @@ int main(int argc, char **argv) {
         }
         printf("  stamps (mean us per workgroup): K-loop %.1f | tables %.1f | row passes %.1f | tail %.1f ; span %.1f us ; clock %.3f GHz\n",
                sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, span, nclk ? clk / nclk : 0.0);
+        typedef int (*es_fn)(unsigned long long *);
+        es_fn res = (es_fn)dlsym(lib, "pm_f8_read_estamps");
+        if (res) {
+            unsigned long long es[16][32];
+            if (!res(&es[0][0])) {
+                printf("  row-pass phases of workgroup 300 (us since its pass 0 started; slots: start, B1, select, B2, fetch+singles, energies, lse):\n");
+                for (int w = 0; w < 16; ++w) {
+                    printf("   wave %d:", w);
+                    for (int r = 0; r < 4; ++r) {
+                        for (int k = 0; k < 7; ++k) printf(" %5.1f", (double)((long long)es[w][r * 8 + k] - (long long)es[0][0]) / 100.0);
+                        printf(" |");
+                    }
+                    printf("\n");
+                }
+            }
+        }
         // timeline of the first CU's workgroups (same HW_ID)
         const unsigned long long id0 = st[7];
         int shown = 0;

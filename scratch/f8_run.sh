@@ -7,7 +7,7 @@ B=scratch/libs/f8_bench
 for v in "$@"; do
   name=${v%%:*}; rest=${v#*:}; tile=${rest%%:*}; ms=0; st=0
   [ "$rest" != "$tile" ] && ms=${rest#*:}
-  [ "$name" = "stamps" ] && st=1
+  case "$name" in stamps*) st=1;; esac
   timeout 120 $B scratch/libs/libpm_$name.so $tile ${F8_N:-196608} 20 $st $ms ${F8_PART:-0} 2>&1 | grep -v amdgpu.ids >> $OUT
 done
 cat $OUT
