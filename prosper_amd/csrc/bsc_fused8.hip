@@ -1027,6 +1027,68 @@ __device__ __forceinline__ void tail8_scores(d4 (&acc)[NJ], const double *__rest
     }
 }
 
+// The same K-quarter per wavefront, operands through a PRIVATE two-stage LDS ring per wavefront filled by LDS-DMA (a CU
+// pulls ~25-30 GB/s from L2 into registers with vector loads, 2-3 times that into LDS): stage = [A chunk | 8 latent
+// chunks] x 1 KB = 9 KB, 2 stages x 8 wavefronts = 144 KB (one workgroup per CU).  No barrier: nothing is shared.
+constexpr int TAIL_STAGE_BYTES = 9 * 1024, TAIL_RING_BYTES = 8 * 2 * TAIL_STAGE_BYTES;
+__device__ __forceinline__ void tail8_scores_dma(d4 (&acc)[NJ], double *sm, const double *__restrict__ Y, int64_t ldy,
+                                                 const double *__restrict__ Wt, int64_t ldw, int D, int64_t N, int H,
+                                                 int64_t m0, int lane, int wave) {
+    const int kq = wave & 3, half = wave >> 2;
+    const int nk = D / DK;
+    const int t0 = (kq * nk) / 4, t1 = ((kq + 1) * nk) / 4;
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+    int64_t r0 = m0 < N ? m0 : N - 1;
+    int64_t ra = m0 + dr;
+    ra = ra < N ? ra : N - 1;
+    const char *baseA = reinterpret_cast<const char *>(Y + r0 * ldy);
+    const uint32_t voffA = (uint32_t)((ra - r0) * ldy * 8 + 16 * dj);
+    const char *baseB = reinterpret_cast<const char *>(Wt);
+    uint32_t voffB[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        int rb = half * 128 + 16 * i + dr;
+        rb = rb < H ? rb : H - 1;
+        voffB[i] = (uint32_t)rb * (uint32_t)ldw * 8u + 16u * (uint32_t)dj;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) double *)(sm)) + (unsigned)wave * (2u * TAIL_STAGE_BYTES);
+    auto dma1 = [&](unsigned dst, uint32_t voff, const char *base) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(base)
+                     : "memory");
+    };
+    auto dma = [&](int t, int stage) {
+        const unsigned dst = lds0 + (unsigned)stage * TAIL_STAGE_BYTES;
+        const int64_t k0 = (int64_t)t * (DK * 8);
+        dma1(dst, voffA, baseA + k0);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) dma1(dst + (1u + i) * 1024u, voffB[i], baseB + k0);
+    };
+    const int frow = lane & 15, fk = lane >> 4;
+    const int sw = (4 - (frow >> 2)) & 3;
+    const double *mine = sm + (size_t)wave * (2 * TAIL_STAGE_BYTES / 8) + frow * DK + ((fk ^ sw) << 1);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    if (t0 < t1) dma(t0, 0);
+    if (t0 + 1 < t1) dma(t0 + 1, 1);
+    for (int t = t0; t < t1; ++t) {
+        const int stage = (t - t0) & 1;
+        if (t + 1 < t1) wait_vmcnt<9>();        // this step's nine pieces have landed (the next step's may be in flight)
+        else wait_vmcnt<0>();
+        const double *st = mine + stage * (TAIL_STAGE_BYTES / 8);
+        const d2 a = *reinterpret_cast<const d2 *>(st);
+        d2 b[NJ];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) b[i] = *reinterpret_cast<const d2 *>(st + (1 + i) * 128);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 2 < t1) dma(t + 2, stage);      // (my reads of this stage are in registers)
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) acc[i] = mfma16(a.x, b[i].x, acc[i]);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) acc[i] = mfma16(a.y, b[i].y, acc[i]);
+    }
+}
+
 // W16 (the shipped main launch): a workgroup of SIXTEEN wavefronts owns 128 datapoints, one per CU (4 wavefronts per
 // SIMD as with two 8-wavefront workgroups).  Measured on the stamps (profiles/r03_*): with two independent workgroups per
 // CU one ends up in its row passes while the other K-loops -- the row passes, throttled to one VALU slot per MFMA, then
@@ -1068,7 +1130,12 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
 #endif
     d4 acc[NJ];
     if (TAIL) {
+#ifdef PM_F8_TAILREG
         tail8_scores(acc, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
+#else
+        tail8_scores_dma(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
+        lds_barrier();                   // the rings become the reduction scratch
+#endif
         // the four K-quarters of a latent half summed in a fixed order, (q0 + q2) + (q1 + q3), through 64 KB of LDS
         double *red = sm + (size_t)((wave & 1) + 2 * half) * (NJ * 4 * 64) + lane;      // [slot][i][r][lane]
         if (rg >= 2) {
@@ -1682,7 +1749,12 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
         const int64_t rest = N - main_rows;
         constexpr int MROWS = W16_DEFAULT ? 128 : AROWS;
         if (main_rows > 0 && part != 2) PM_LAUNCH8SGF(false, (main_rows + MROWS - 1) / MROWS, shmem_s, main_rows, 0);
-        if (rest > 0 && part != 1) PM_LAUNCH8SGF(true, (rest + TAIL_ROWS - 1) / TAIL_ROWS, (size_t)LEAN_LDS_BYTES, N, main_rows);
+#ifdef PM_F8_TAILREG
+        const size_t shmem_t = (size_t)LEAN_LDS_BYTES;
+#else
+        const size_t shmem_t = (size_t)TAIL_RING_BYTES > (size_t)LEAN_LDS_BYTES ? (size_t)TAIL_RING_BYTES : (size_t)LEAN_LDS_BYTES;
+#endif
+        if (rest > 0 && part != 1) PM_LAUNCH8SGF(true, (rest + TAIL_ROWS - 1) / TAIL_ROWS, shmem_t, N, main_rows);
     } else if (part == 2) {
         return PM_OK;                                   // (no TAIL launch outside the lean passes)
     } else if (stats) {
