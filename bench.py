@@ -435,7 +435,7 @@ def main():
         # HBM-side bytes of the dominant kernel: NOT measured in this run -- from the committed rocprofv3 --pmc passes
         # (profiles/summarize_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), per launch
         traffic, traffic_source = None, None
-        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]
                 cands = [k for k, v in pmc.items() if k.startswith(dom) and v.get("datapoints_per_launch") == chunk]

@@ -20,6 +20,21 @@ import glob
 import json
 import sys
 
+import re
+
+# round 3: the 8-/16-wavefront kernels of bsc_fused8.hip, template arguments <STAGES, H', gamma, FULL, MSTATS, TAIL[, W16]>
+_F8 = re.compile(r"bsc_estep_fused8s_kernel<\d+, \d+, \d+, (?:true|false), (true|false), (true|false)")
+
+
+def _fused8_label(name):
+    m = _F8.search(name)
+    if not m:
+        return None
+    if m.group(2) == "true":
+        return "estep_fused_tail_mstats" if m.group(1) == "true" else "estep_fused_tail"
+    return "estep_fused_mstats" if m.group(1) == "true" else "estep_fused"
+
+
 KERNELS = {
     # (order matters: first match wins)
     "bsc_estep_fused_kernel<16, 4, true, true>": "estep_fused_mstats",   # E-step + M-step statistics (inside EM steps)
@@ -31,6 +46,7 @@ KERNELS = {
     "bsc_mstep_rows16_kernel": "mstep_rows",
 }
 FETCH_FACTOR = {"estep_fused": 2.0, "estep_fused_mstats": 2.0,    # reads are the LDS-DMA stream of Y (16 B per lane)
+                "estep_fused_tail": 2.0, "estep_fused_tail_mstats": 2.0,
                 "scores_gemm": 2.0, "scores_gemm_splitk": 2.0, "stats_gemm": 2.0, "select_estep": 1.0, "mstep_rows": 2.0}
 
 
@@ -38,6 +54,10 @@ def load(d):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
+        lab8 = _fused8_label(r["Kernel_Name"])
+        if lab8:
+            agg[(lab8, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+            continue
         for pat, lab in KERNELS.items():
             if pat in r["Kernel_Name"]:
                 agg[(lab, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
@@ -56,8 +76,10 @@ def main():
                                          "write_bytes": w_b, "hbm_bytes": f_b + w_b}
         if lab == "scores_gemm" and f_b + w_b > 1e9:   # the headline launch: all 200000 datapoints of the shard (whole
             res["%s@grid%d" % (lab, grid)]["datapoints_per_launch"] = 200000   # rounds + the fused ragged round)
-        if lab.startswith("estep_fused"):              # one 256-thread workgroup per 64 datapoints
-            res["%s@grid%d" % (lab, grid)]["datapoints_per_launch"] = grid // 256 * 64
+        if lab.startswith("estep_fused_tail"):         # 512-thread workgroups of 16 datapoints (upper bound: ragged last one)
+            res["%s@grid%d" % (lab, grid)]["datapoints_per_launch"] = grid // 512 * 16
+        elif lab.startswith("estep_fused"):            # 1024-thread workgroups of 128 datapoints (round 3; round 2: 256 / 64)
+            res["%s@grid%d" % (lab, grid)]["datapoints_per_launch"] = grid // 1024 * 128 if grid % 1024 == 0 and grid >= 1024 * 256 else grid // 256 * 64
     json.dump({"note": "per-launch HBM-side bytes (FETCH_SIZE x per-kernel gfx950 factor, see summarize_pmc.py, "
                        "+ WRITE_SIZE), rocprofv3 --pmc, separate passes; bench.py --steps 5 --warmup 2 --em-steps 3 "
                        "--prewarm-ms 0", "kernels": res}, open(out, "w"), indent=1)

@@ -437,6 +437,15 @@ __device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const d
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(base)
                      : "memory");
     };
+    // the datapoint rows are read once: non-temporal, so that they do not push W (2 MB, re-read by every tile) out of L2
+    auto dma1_nt = [&](unsigned dst, uint32_t voff, const char *base) {
+#ifdef PM_F8_NTA
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst), "v"(voff), "s"(base)
+                     : "memory");
+#else
+        dma1(dst, voff, base);
+#endif
+    };
 
     // fragment reads: pair p of row R sits at R*8 + ((p ^ ((R>>2)&3)) << 1) (the slot the DMA wrote)
     const int frow = lane & 15, fk = lane >> 4;
@@ -468,7 +477,7 @@ __device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const d
         auto dma = [&](int kt, int stage) {
             const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8);
             const int64_t k0 = (int64_t)kt * (DK * 8);
-            if (WA) dma1(dst + (unsigned)rg * 1024u, soff[0], sbase[0] + k0);
+            if (WA) dma1_nt(dst + (unsigned)rg * 1024u, soff[0], sbase[0] + k0);
             dma1(dst + (8u + (unsigned)wave) * 1024u, soff[1], sbase[1] + k0);
         };
 #pragma unroll
