@@ -60,6 +60,27 @@ def parse():
     return ap.parse_args()
 
 
+def valu_issue_roofline(kernel_prefix, measured_ms, what):
+    """Roofline of a VALU-bound row kernel against the f64 vector ISSUE roof: the kernel's dynamic wave-instruction count
+    (SQ_INSTS_VALU per launch, profiles/r03_valu_counts.json -- a separate rocprofv3 --pmc pass of this command, not this
+    run) x 4 cycles / (1024 SIMDs x 2.4 GHz) is the time the chip needs just to issue them; `frac` = that floor / the launch
+    duration measured here.  (These kernels move a few hundred MB per launch: the HBM roof is 3-10x further away.)"""
+    try:
+        kern = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_counts.json")))["kernels"]
+        key = [k for k in kern if k.startswith(kernel_prefix)]
+        if not key:
+            return None
+        insts = kern[key[0]]["valu_insts"]
+        floor_ms = insts * 4.0 / (1024 * 2.4e9) * 1e3
+        return {"bound": "valu_issue", "kernel": what, "achieved": insts / (measured_ms * 1e-3) / 1e9,
+                "peak": 1024 * 2.4e9 / 4.0 / 1e9, "unit": "G wave-instructions/s", "frac": floor_ms / measured_ms,
+                "avg_launch_ms": measured_ms, "issue_floor_ms": floor_ms, "valu_insts_per_launch": insts,
+                "counts_source": "profiles/r03_valu_counts.json (%s; separate --pmc pass, not this run)" % key[0],
+                "traffic": None}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def other_models(dev, Anneal, steps=20):
     """EM-iteration wall-clock of the other §8(a) models at BASELINE configs 4 and 5 (one GPU's share), after the
     headline timing: GSC D=256 H=128 H'=6 gamma=3 N=200k, MCA D=256 H=128 H'=8 gamma=3 N=100k.  Informational."""
@@ -104,15 +125,15 @@ def other_models(dev, Anneal, steps=20):
         ks = kt.summary()
         out["gsc_c4_kernels_ms"] = {k: round(v[1], 4) for k, v in sorted(ks.items())}
         if "estep" in ks:
-            # dominant kernel: gsc_estep_kernel.  Algorithmic HBM bytes per launch: the scores row in (H f64), xpt_s | xpt_sz
-            # rows out (2H f64), candidates (H' int32) per datapoint; the (H,H) moment sums stay on chip.
-            nbytes = N * (3 * Hm * 8 + 6 * 4)
-            gbs = nbytes / (ks["estep"][1] * 1e-3) / 1e9
-            out["gsc_c4_roofline"] = {"bound": "hbm", "kernel": "gsc_estep_kernel (select + E-step, one pass over the scores)",
-                                      "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                      "avg_launch_ms": ks["estep"][1], "algorithmic_bytes": nbytes, "traffic": None,
-                                      "note": "latency / f64-VALU bound row kernel (35 multi-cause states with g x g solves in "
-                                              "registers per datapoint): far from the HBM roof by construction, DESIGN section 4"}
+            # dominant kernel: gsc_estep_kernel -- 35 multi-cause states with g x g solves in registers + 128 singletons per
+            # datapoint: f64-VALU bound (not HBM: 3 H doubles per datapoint in and out, 0.6 GB per launch)
+            out["gsc_c4_roofline"] = valu_issue_roofline("gsc_estep_kernel<8, 3, false>", ks["estep"][1],
+                                                         "gsc_estep_kernel (select + E-step, one pass over the scores)")
+            if out["gsc_c4_roofline"] and "frac" in out["gsc_c4_roofline"]:
+                out["gsc_c4_roofline"]["note"] = (
+                    "avg_launch_ms brackets the whole pm_gsc_estep_f64 call with HIP events: gsc_estep_kernel (0.67 ms in "
+                    "rocprofv3's per-kernel view) + pm_fold_copies_kernel + gsc_colsum_kernel and the gaps between the three "
+                    "launches (~0.1 ms) -- the 0.67 vs 0.79 ms of round 2; frac prices the call, i.e. reads low by that share")
         del Y, m
         # --- MCA, config 5 (N = 800k over 8 GPUs)
         N = 100_000
@@ -144,21 +165,10 @@ def other_models(dev, Anneal, steps=20):
         out["mca_c5_kernels_ms"] = {k: round(v[1], 4) for k, v in sorted(ks.items())}
         lab = "estep_mstats" if "estep_mstats" in ks else ("estep" if "estep" in ks else None)
         if lab:
-            # dominant kernel: the fused E-step + M-statistics pass.  Its algorithmic work is one f64 power
-            # Wbar_sd = (sum_j W_jd^rho)^(1/rho) per multi-cause state and observed dimension (mca_et.py:170): S x D per
-            # datapoint, 36 f64-VALU issue slots each (pm_pow_tab).  Peak: the f64 vector issue rate, 78.6 TFLOP/s =
-            # 39.3 T FMA-class lane-instructions/s chip-wide, / 36 per power -- a roof for the powers alone; the state
-            # loop's other ~150 instructions per state and its latency at 2 wavefronts per SIMD are inside `frac`.
-            S_mca = m.no_states
-            npow = float(N) * S_mca * Dm
-            ach = npow / (ks[lab][1] * 1e-3) / 1e9
-            peak = MFMA_F64_PEAK_TFLOPS * 1e12 / 2 / 36 / 1e9
-            out["mca_c5_roofline"] = {"bound": "valu_f64", "kernel": "mca_estep_fused_kernel (E-step + M-step statistics)",
-                                      "achieved": ach, "peak": peak, "unit": "Gpow/s", "frac": ach / peak,
-                                      "avg_launch_ms": ks[lab][1], "algorithmic_pows": npow, "traffic": None,
-                                      "note": "f64 VALU issue roof of the powers alone (S*D per datapoint at 36 issue slots "
-                                              "each, from the 78.6 TFLOP/s f64 vector rate); the kernel is instruction-latency "
-                                              "bound at 2 wavefronts per SIMD (DESIGN 4.4); not an HBM or MFMA kernel"}
+            # dominant kernel: the fused E-step + M-statistics pass: one f64 power per multi-cause state and observed
+            # dimension (S x D per datapoint, 36 VALU issue slots each) + the state loop around it: f64-VALU bound
+            out["mca_c5_roofline"] = valu_issue_roofline("mca_estep_fused_kernel<4, 8, false>", ks[lab][1],
+                                                         "mca_estep_fused_kernel (E-step + M-step statistics)")
         del m, Y
         # --- the "next" models of SURVEY 8(f2) on the same skeleton: DSC (ternary latents) and TSC, D=256 H=128 H'=6
         # gamma=3, N=100k (no BASELINE config names them; same shapes as configs 4 / 5)
@@ -185,6 +195,19 @@ def other_models(dev, Anneal, steps=20):
             torch.cuda.synchronize()
             out["%s_em_iter_ms" % name] = (time.perf_counter() - t) / steps * 1e3
             out[name] = "%s D=256 H=128 H'=6 gamma=3, N=%d" % (type(m).__name__, N)
+            m.timer = kt = KernelTimer()
+            for _ in range(3):
+                p = m.step(Anneal(T=1.0), p, {"y": Y})
+            m.timer = None
+            ks = kt.summary()
+            out["%s_kernels_ms" % name] = {k: round(v[1], 4) for k, v in sorted(ks.items())}
+            if name == "dsc":       # (the two DSC row kernels; TSC runs the same kernels on its own state table)
+                if "estep" in ks:
+                    out["dsc_estep_roofline"] = valu_issue_roofline("dsc_estep_kernel<8>", ks["estep"][1],
+                                                                    "dsc_estep_kernel (log-joints of the K-ary states)")
+                if "mstep_rows" in ks:
+                    out["dsc_mstep_rows_roofline"] = valu_issue_roofline("dsc_mstep_rows_kernel<8>", ks["mstep_rows"][1],
+                                                                         "dsc_mstep_rows_kernel (posterior moments)")
     except Exception as e:   # never lose the headline over the side measurements
         out["error"] = repr(e)
     gc.enable()

@@ -1,0 +1,25 @@
+#!/bin/bash
+# SQ_INSTS_VALU / SQ_WAVES / SQ_INSTS_VALU_MFMA-free counts per launch of every model's row kernels (bench.py's side models):
+# profiles/r03_valu_counts.json feeds the VALU-issue rooflines bench.py reports for them.
+R=$PWD
+cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pv
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES --kernel-trace -d /tmp/pv -o x --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --em-steps 2 --prewarm-ms 0 --no-cpu-baseline > /tmp/pv.log 2>&1 || tail -3 /tmp/pv.log
+python3 - $R/gpurun_out/r03_valu_counts.json <<'PY'
+import glob, csv, collections, json, sys, re
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("/tmp/pv/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = re.sub(r"\(anonymous namespace\)::|void |pm_fused8::", "", r["Kernel_Name"]).split("(")[0]
+        agg[(name, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for (name, grid), c in sorted(agg.items()):
+    v = {k: sum(x) / len(x) for k, x in c.items()}
+    if v.get("SQ_INSTS_VALU", 0) < 1e6:
+        continue
+    out["%s@grid%d" % (name, grid)] = {"launches": len(c["SQ_INSTS_VALU"]), "valu_insts": v.get("SQ_INSTS_VALU"),
+                                        "mfma_insts": v.get("SQ_INSTS_MFMA"), "waves": v.get("SQ_WAVES")}
+json.dump({"note": "wave-instructions per launch (SQ_INSTS_VALU includes MFMAs), rocprofv3 --pmc, bench.py --steps 2 "
+                   "--warmup 1 --em-steps 2 --prewarm-ms 0 --no-cpu-baseline", "kernels": out}, open(sys.argv[1], "w"), indent=1)
+for k, v in out.items():
+    print(k, v)
+PY
