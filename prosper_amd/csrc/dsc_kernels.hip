@@ -105,6 +105,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     double *s_G = s_a + Hp;
     uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_w2 + H + WAVES * (Hp + Hp * Hp));
     __shared__ double s_val[PM_DSC_MAX_K];
+    // 2^(j/128) table of pm_exp_tab (pm_common.h): the log-sum-exp's exponentials were libm exp() calls -- ~45 VALU
+    // instructions each, 340 of the kernel's ~900 per datapoint (round 3, SQ_INSTS_VALU); table-driven they are 14, and
+    // terms below e^-37 of the largest are not evaluated at all
+    __shared__ double s_E[128];
+    if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
+    const double *etab = s_E - 256;                      // pm_exp_tab indexes tab[256 + (k & 127)]
     for (int h = tid; h < H; h += blockDim.x) s_w2[h] = gram[(int64_t)h * H + h];
     for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
     if (tid < PM_DSC_MAX_K) s_val[tid] = (tid < P.K) ? P.values[tid] : 0.0;
@@ -168,14 +174,24 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
         // second pass over this lane's own values
         const double *src = stage ? s_f : out;
         double sum = 0.0;
-        if (!tab && lane == 0) sum += exp(src[0] - m);
+        auto add = [&](double d, bool mine) {           // uniform trip counts: every lane reaches the __any
+            const bool need = mine && d > -37.0;
+            if (__any(need)) sum += need ? pm_exp_tab(d, etab) : 0.0;
+        };
+        if (!tab) add(lane == 0 ? src[0] - m : 0.0, lane == 0);
         c = 0;
         for (int k = 0; k < P.K && !tab; ++k) {
             if (k == P.K0) continue;
-            for (int h = lane; h < H; h += 64) sum += exp(src[1 + c * H + h] - m);
+            for (int h0 = 0; h0 < H; h0 += 64) {
+                const int h = h0 + lane;
+                add(h < H ? src[1 + c * H + h] - m : 0.0, h < H);
+            }
             ++c;
         }
-        for (int s = lane; s < S; s += 64) sum += exp(src[base + s] - m);
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            add(s < S ? src[base + s] - m : 0.0, s < S);
+        }
         sum = pm_wave_sum(sum);
         if (lane == 0) lse[n] = m + log(sum);
         wave_sync_lds_dsc();
@@ -202,6 +218,9 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
     double *s_B = s_m + Hp;
     uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_scal + 4 + WAVES * per_wave);
     __shared__ double s_val[PM_DSC_MAX_K];
+    __shared__ double s_E[128];                          // (pm_exp_tab's table: see dsc_estep_kernel)
+    if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
+    const double *etab = s_E - 256;
     for (int h = tid; h < H + PM_DSC_MAX_K + 4; h += blockDim.x) s_qdiag[h] = 0.0;
     for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
     if (tid < PM_DSC_MAX_K) s_val[tid] = (tid < P.K) ? P.values[tid] : 0.0;
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
         if (lane == 0) {
             if (!tab) {
                 const double f0 = f[0];
-                sig += exp(f0 - l) * ((f0 - P.pscale * prior[0]) * inv_ecoef);
+                sig += (f0 - l > qcut ? pm_exp_tab(f0 - l, etab) : 0.0) * ((f0 - P.pscale * prior[0]) * inv_ecoef);
             }
             fs += l;
             kept += 1.0;
@@ -259,7 +278,8 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
             for (int k = 0; k < PM_DSC_MAX_K; ++k) {
                 if (tab || k >= P.K || k == P.K0) continue;
                 const double fh = f[1 + c * H + h];
-                const double q = exp(fh - l);
+                const double dq = fh - l;
+                const double q = dq > qcut ? pm_exp_tab(dq, etab) : 0.0;   // (below e^-60 of the evidence: nothing in f64)
                 const double v = P.values[k];
                 row += q * v;
                 qd += q * v * v;
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
             const double fsv = f[base + s];
             const double dl = fsv - l;
             if (!(dl > qcut)) continue;
-            const double q = exp(dl);
+            const double q = pm_exp_tab(dl, etab);
             sig += q * ((fsv - P.pscale * prior[base + s]) * inv_ecoef);
             const uint8_t *row = s_tab + s * Hp;
             // the state's value indices and values first (LDS lookups, static register indices), then the scatter
