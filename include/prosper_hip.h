@@ -55,6 +55,10 @@ int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int64_t ldb,
  * bsc_et.py:339-363 (my_Wp). */
 int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B, int64_t ldb,
                        double *C, int64_t ldc, int64_t M, int64_t N, int64_t K, void *stream);
+/* The same product, decided on the device: the kernels return at once unless *gate (a device double) is non-zero.  The
+ * dense half of the pair (pm_bsc_wp_sparse_f64, this) that is enqueued without the host knowing which one applies. */
+int pm_gemm_tn_acc_gated_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
+                             int64_t M, int64_t N, int64_t K, const double *gate, void *stream);
 
 /* out[n] = sum_d Y[n,d]^2 -- np.inner(y, y) of bsc_et.py:111 and (y**2).sum() of :172;
  * computed once per resident data shard. */
@@ -168,7 +172,8 @@ int pm_bsc_estep_f64(const double *scores, int64_t lds, const double *gram, cons
  * scalars: [0] sum_n sum_k q_nk e_nk (sigma statistic, bsc_et.py:395-415)
  *          [1] sum over kept n of log sum_k exp(logpj) (Fs, bsc_et.py:265)
  *          [2] number of kept datapoints (my_N after truncation, bsc_et.py:257)
- *          [3] reserved                                                              */
+ *          [3] number of datapoints whose E[s] row had more than PM_BSC_NZ_MAX non-zeros while the E-step pass wrote
+ *              non-zero lists (pm_bsc_estep_fused8_nz_f64); gates pm_bsc_wp_sparse_f64 / pm_gemm_tn_acc_gated_f64 */
 #define PM_BSC_NSCALARS 4
 int64_t pm_bsc_stats_len(int64_t H, int64_t D);
 int64_t pm_bsc_stats_offset_wq(int64_t H, int64_t D);
@@ -259,6 +264,26 @@ int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const double *Wt, int6
                             const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
                             int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
                             double *expect, int64_t lde, double *stats, int64_t D_stats, int part, void *stream);
+
+/* pm_bsc_estep_fused8_f64 that also leaves every E[s] row as a list of its non-zeros (statistics passes only: `stats`
+ * given): nz_idx (N x PM_BSC_NZ_MAX uint16: latent indices, unused slots 0xFFFF) and nz_val (N x PM_BSC_NZ_MAX).  Past the
+ * annealing phase a posterior of the truncated state set puts weight on a handful of latents (3.7 of 256 per datapoint
+ * on config 2), and the M-step's Wp = E[s]^T Y (bsc_et.py:339-363) needs only those rows of the product.  A row with more
+ * than PM_BSC_NZ_MAX non-zeros is counted in scalars[3]; `expect` is complete either way. */
+#define PM_BSC_NZ_MAX 16
+int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
+                               const double *ynorm2, const double *wmu, const double *ymu,
+                               const uint16_t *state_masks, const uint16_t *state_parents,
+                               const int32_t *size_offsets_host, int64_t S, int64_t gamma,
+                               const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
+                               int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
+                               double *expect, int64_t lde, double *stats, int64_t D_stats, uint16_t *nz_idx,
+                               double *nz_val, int part, void *stream);
+/* Wp (the leading H x D block of `stats`) += sum_n sum_t nz_val[n,t] . Y[n,:] into row nz_idx[n,t]  -- my_Wp of
+ * bsc_et.py:339-363 from the non-zero lists; returns at once on the device when scalars[3] of `stats` is non-zero (some
+ * list overflowed: pm_gemm_tn_acc_gated_f64 on `expect` does the work then).  H <= 256. */
+int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *stats,
+                         int64_t N, int64_t H, int64_t D, void *stream);
 
 /* Fast-path twin of pm_bsc_mstep_rows_f64 (same outputs, same `stats` layout). */
 int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,

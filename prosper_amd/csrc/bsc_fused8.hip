@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
     const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
     pm_bsc_estep_params P, int64_t N, int H, int mode, int32_t *__restrict__ cand, double *__restrict__ logpj,
     int64_t ldl, double *__restrict__ lse, double *__restrict__ expect, int64_t lde, double *__restrict__ stats,
-    int Dstats, int64_t row0) {
+    int Dstats, int64_t row0, uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val) {
     using SS = StateSet<HP, GAMMA>;
     constexpr int TILE_ROWS = TAIL ? TAIL_ROWS : (W16 ? 128 : AROWS), NPASS = TAIL ? 1 : 4;
     constexpr int NWAVES = W16 ? 16 : 8, RGMASK = W16 ? 7 : 3, HSHIFT = W16 ? 3 : 2;
@@ -1552,16 +1552,41 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
             }
             wave_lds_sync16();
             char *erow = exp_t + ((uint32_t)lrow * (uint32_t)lde * 8u + (uint32_t)j32 * 8u);
+            // the row's non-zeros as a list as well (pm_bsc_wp_sparse_f64 multiplies them into the data): up to
+            // PM_BSC_NZ_MAX (index, value) pairs in the order the lanes hold them, unused index slots 0xFFFF; a longer
+            // row counts in the statistics' overflow scalar and the dense product runs instead
+            const bool lists = nz_idx != nullptr;
+            uint16_t *nzi = nz_idx + (m0 + lrow) * PM_BSC_NZ_MAX;
+            double *nzv = nz_val + (m0 + lrow) * PM_BSC_NZ_MAX;
+            uint32_t nzn = 0;
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
                 const int h = j32 + 32 * i;
+                double v = 0.0;
                 if (FULL || h < H) {
-                    const double v = (a[i] + Pm[h]) * inv;
+                    v = (a[i] + Pm[h]) * inv;
                     if (!(PM_F8_SKIP & 32)) *reinterpret_cast<double *>(erow + 256 * i) = v;
                     if (!(PM_F8_SKIP & 64) && live && __any(v != 0.0)) {
                         if (v != 0.0) atomicAdd(&t_mus[h], v);
                     }
                 }
+                if (lists) {
+                    const uint64_t bal = __ballot(v != 0.0);
+                    const uint32_t mine = dsel ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                    if (mine) {
+                        const uint32_t pos = nzn + __popc(mine & ((1u << j32) - 1u));
+                        if (v != 0.0 && pos < PM_BSC_NZ_MAX && live) {
+                            nzi[pos] = (uint16_t)h;
+                            nzv[pos] = v;
+                        }
+                        nzn += __popc(mine);
+                    }
+                }
+            }
+            if (lists && live) {
+                if (j32 < PM_BSC_NZ_MAX && (uint32_t)j32 >= nzn) nzi[j32] = 0xFFFFu;
+                if (j32 == 0 && nzn > PM_BSC_NZ_MAX)
+                    pm_atomic_add(stats + pm_bsc_stats_offset_scalars_dev(H, Dstats) + 3, 1.0);
             }
             wave_lds_sync16();       // P is the next pass's list area
         }
@@ -1681,6 +1706,20 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
                                        int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
                                        double *expect, int64_t lde, double *stats, int64_t D_stats, int part,
                                        void *stream) {
+    return pm_bsc_estep_fused8_nz_f64(Y, ldy, Wt, ldw, gram, ynorm2, wmu, ymu, state_masks, state_parents,
+                                      size_offsets_host, S, gamma, params_host, N, D, H, Hprime, mode, cand, logpj, ldl, lse,
+                                      expect, lde, stats, D_stats, nullptr, nullptr, part, stream);
+}
+
+extern "C" int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw,
+                                          const double *gram, const double *ynorm2, const double *wmu, const double *ymu,
+                                          const uint16_t *state_masks, const uint16_t *state_parents,
+                                          const int32_t *size_offsets_host, int64_t S, int64_t gamma,
+                                          const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
+                                          int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl,
+                                          double *lse, double *expect, int64_t lde, double *stats, int64_t D_stats,
+                                          uint16_t *nz_idx, double *nz_val, int part, void *stream) {
+    if ((nz_idx == nullptr) != (nz_val == nullptr) || (nz_idx && !stats)) return PM_EINVAL;
     if (!Y || !Wt || !gram || !ynorm2 || !cand || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || ldy < D ||
         ldw < D || !(mode & 3) || ((wmu == nullptr) != (ymu == nullptr)) || part < 0 || part > 2)
         return PM_EINVAL;
@@ -1730,7 +1769,8 @@ extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const doubl
         hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), dim3((unsigned)(GRID)),                       \
                            dim3((!(T) && W16_DEFAULT) ? 1024 : THREADS), (SH), s, Y, ldy,                              \
                            Wt, ldw, (int)D, gram, ynorm2, wmu, ymu, state_masks, state_parents, P, (int64_t)(NN),    \
-                           (int)H, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, (int64_t)(R0));     \
+                           (int)H, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, (int64_t)(R0),      \
+                           nz_idx, nz_val);                                                                            \
     } while (0)
 #define PM_LAUNCH8ST(G, F, T, GRID, SH, NN, R0)            \
     do {                                                    \

@@ -1,0 +1,116 @@
+// my_Wp of BSC_ET.M_step (prosper/em/camodels/bsc_et.py:339-363) from the non-zero lists of E[s].
+//
+// The reference adds, per datapoint, np.outer(E[s], y) into the (H, D) accumulator.  Dense, that is the 2 N H D flop GEMM
+// E[s]^T Y (pm_gemm_tn_acc_f64: 1.49 ms of a 3.6 ms EM iteration on config 2, at 90 % of the f64 MFMA peak).  But past the
+// annealing phase the truncated posterior has weight on a handful of latents: 3.7 non-zeros of 256 per row on config 2
+// (max 8; scratch/nnz_hist.py), so 98.5 % of those flops multiply zeros.  With the lists the E-step pass leaves
+// (pm_bsc_estep_fused8_nz_f64) the product is N nnz D multiply-adds -- nothing -- and one read of the data: the kernel
+// is bound by streaming Y once (N D 8 bytes; 1.64 GB on config 2 = 0.2 ms at HBM speed).
+//
+// Layout: a workgroup owns a 64-column chunk of Wp for a group of datapoints and keeps its (H x 64) accumulator in LDS
+// (128 KB at H = 256: one 16-wavefront workgroup per CU).  A wavefront takes one datapoint at a time: lane c holds
+// y[n, c0 + c], lanes 0..15 hold the list; every non-zero is one ds_add_f64 of 64 lanes into the accumulator row of its
+// latent (a row is 512 contiguous bytes: all banks once).  The accumulators are flushed with f64 atomics; all
+// workgroups of a column chunk sit on one XCD, so a Wp line is only ever touched through one L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "prosper_hip.h"
+#include "pm_common.h"
+
+namespace {
+
+constexpr int SP_DC = 64;          // columns per workgroup
+constexpr int SP_WAVES = 16;
+constexpr int SP_UNROLL = 8;       // datapoints in flight per wavefront (8 x 512 B of Y)
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint16_t *__restrict__ nz_idx,
+                                                                      const double *__restrict__ nz_val,
+                                                                      const double *__restrict__ Y, int64_t ldy,
+                                                                      double *__restrict__ Wp, int64_t ldw,
+                                                                      const double *__restrict__ gate, int64_t N, int H,
+                                                                      int D, int nchunks, int64_t rows_per_group) {
+    extern __shared__ __attribute__((aligned(16))) double acc[];          // [H][SP_DC]
+    if (*gate != 0.0) return;                  // some list overflowed: the dense product runs instead
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroups are dealt round-robin over the 8 XCDs: chunk = 8 k + (blockIdx & 7) keeps a chunk on one XCD
+    const int per8 = (nchunks + 7) >> 3;
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int chunk = x + 8 * (q % per8);
+    const int64_t grp = q / per8;
+    if (chunk >= nchunks) return;
+    for (int i = tid; i < H * SP_DC; i += SP_WAVES * 64) acc[i] = 0.0;
+    __syncthreads();
+
+    const int col = chunk * SP_DC + lane;
+    const bool colok = col < D;
+    const int64_t lo = grp * rows_per_group;
+    const int64_t hi = lo + rows_per_group < N ? lo + rows_per_group : N;
+    double *arow = acc + lane;
+    for (int64_t n0 = lo + wave; n0 < hi; n0 += SP_WAVES * SP_UNROLL) {
+        double y[SP_UNROLL], v[SP_UNROLL];
+        int ix[SP_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SP_UNROLL; ++u) {
+            const int64_t n = n0 + (int64_t)u * SP_WAVES;
+            const bool ok = n < hi;
+            y[u] = (ok && colok) ? Y[n * ldy + col] : 0.0;
+            ix[u] = 0xFFFF;
+            v[u] = 0.0;
+            if (ok && lane < PM_BSC_NZ_MAX) {
+                ix[u] = nz_idx[n * PM_BSC_NZ_MAX + lane];
+                v[u] = nz_val[n * PM_BSC_NZ_MAX + lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SP_UNROLL; ++u) {
+            const int cnt = __popcll(__ballot(ix[u] != 0xFFFF));     // (the valid slots are the leading ones)
+            for (int t = 0; t < cnt; ++t) {
+                const int h = __builtin_amdgcn_readlane(ix[u], t);
+                const double w = readlane_f64(v[u], t);
+                atomicAdd(arow + h * SP_DC, w * y[u]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < H * SP_DC; i += SP_WAVES * 64) {
+        const double a = acc[i];
+        const int h = i / SP_DC, c = chunk * SP_DC + (i % SP_DC);
+        if (a != 0.0 && c < D) pm_atomic_add(Wp + (int64_t)h * ldw + c, a);
+    }
+}
+
+}  // namespace
+
+extern "C" int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy,
+                                    double *stats, int64_t N, int64_t H, int64_t D, void *stream) {
+    if (!nz_idx || !nz_val || !Y || !stats || N < 0 || H <= 0 || D <= 0 || ldy < D) return PM_EINVAL;
+    if (H > 256 || D > INT32_MAX) return PM_ERANGE;
+    if (N == 0) return PM_OK;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    const int nchunks = (int)((D + SP_DC - 1) / SP_DC), per8 = (nchunks + 7) / 8;
+    // one workgroup per CU: groups of datapoints so that (8 per8) x groups covers the CUs, whole unroll rounds each
+    int64_t groups = cus / (8 * per8);
+    if (groups < 1) groups = 1;
+    const int64_t round = SP_WAVES * SP_UNROLL;
+    int64_t rpg = (N + groups - 1) / groups;
+    rpg = (rpg + round - 1) / round * round;
+    groups = (N + rpg - 1) / rpg;
+    const size_t shmem = sizeof(double) * (size_t)H * SP_DC;
+    if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_wp_sparse_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+        return e;
+    const double *gate = stats + pm_bsc_stats_offset_scalars_dev(H, D) + 3;
+    hipLaunchKernelGGL(bsc_wp_sparse_kernel, dim3((unsigned)(8 * per8 * groups)), dim3(SP_WAVES * 64), shmem,
+                       static_cast<hipStream_t>(stream), nz_idx, nz_val, Y, ldy, stats, D, gate, N, (int)H, (int)D, nchunks,
+                       rpg);
+    return (int)hipGetLastError();
+}

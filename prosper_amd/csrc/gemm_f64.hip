@@ -492,8 +492,10 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(const double *__restrict__ A, int64_t lda,
                                                               const double *__restrict__ B, int64_t ldb,
                                                               double *__restrict__ C, int64_t ldc, int M, int N,
-                                                              int64_t K, int tiles_n, int64_t k_per_split) {
+                                                              int64_t K, int tiles_n, int64_t k_per_split,
+                                                              const double *__restrict__ gate) {
     __shared__ __attribute__((aligned(16))) double sm[2 * 2 * BK * TN_LD];
+    if (gate && *gate == 0.0) return;      // (pm_gemm_tn_acc_gated_f64: the device decides whether this product runs)
     // All output tiles of one K-split read the same rows of A and B.  Workgroups are dealt round-robin
     // over the 8 XCDs (linear ids L and L+8 share an XCD), so hand XCD r the splits r, r+8, ... with all
     // their tiles back-to-back: each operand slab then crosses the fabric once per split instead of once
@@ -530,8 +532,10 @@ constexpr int TDSTAGE = 2 * DK * TN_LD;  // doubles per stage (18 KB)
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_dma_kernel(const double *__restrict__ A, int64_t lda,
                                                                   const double *__restrict__ B, int64_t ldb,
                                                                   double *__restrict__ C, int64_t ldc, int tiles_n,
-                                                                  int64_t K, int64_t k_per_split) {
+                                                                  int64_t K, int64_t k_per_split,
+                                                                  const double *__restrict__ gate) {
     __shared__ __attribute__((aligned(1024))) double sm[DSTAGES * TDSTAGE];
+    if (gate && *gate == 0.0) return;
     int tile = blockIdx.x, split = blockIdx.y;
     if (gridDim.y % 8 == 0) {   // all tiles of a K-split on one XCD (see gemm_tn_f64_kernel)
         const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
@@ -792,6 +796,12 @@ extern "C" int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int
 
 extern "C" int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                                   int64_t M, int64_t N, int64_t K, void *stream) {
+    return pm_gemm_tn_acc_gated_f64(A, lda, B, ldb, C, ldc, M, N, K, nullptr, stream);
+}
+
+extern "C" int pm_gemm_tn_acc_gated_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C,
+                                        int64_t ldc, int64_t M, int64_t N, int64_t K, const double *gate,
+                                        void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K < 0 || lda < M || ldb < N || ldc < N) return PM_EINVAL;
     if (M > INT32_MAX || N > INT32_MAX) return PM_ERANGE;
     if (K == 0) return PM_OK;
@@ -816,16 +826,16 @@ extern "C" int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B,
         // multiple of 16); the last K % 8 rows go through the register-staged kernel
         const int64_t K8 = K - K % DK;
         dim3 g8((unsigned)tiles, (unsigned)((K8 + kps - 1) / kps));
-        hipLaunchKernelGGL(gemm_tn_f64_dma_kernel, g8, block, 0, s, A, lda, B, ldb, C, ldc, tiles_n, K8, kps);
+        hipLaunchKernelGGL(gemm_tn_f64_dma_kernel, g8, block, 0, s, A, lda, B, ldb, C, ldc, tiles_n, K8, kps, gate);
         if (K8 < K)
             hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, dim3((unsigned)tiles, 1), block, 0, s, A + K8 * lda, lda,
-                               B + K8 * ldb, ldb, C, ldc, (int)M, (int)N, K - K8, tiles_n, (int64_t)BK);
+                               B + K8 * ldb, ldb, C, ldc, (int)M, (int)N, K - K8, tiles_n, (int64_t)BK, gate);
     } else if (al)
         hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K,
-                           tiles_n, kps);
+                           tiles_n, kps, gate);
     else
         hipLaunchKernelGGL(gemm_tn_f64_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K,
-                           tiles_n, kps);
+                           tiles_n, kps, gate);
     return (int)hipGetLastError();
 }
 

@@ -56,6 +56,9 @@ class BSC_ET(DeviceCAModel):
         self.spec_hits = 0
         self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
         self.fuse_mstats = os.environ.get('PM_FUSE_MSTATS', '1') == '1'   # M-step row statistics inside the fused E-step
+        # Wp = E[s]^T Y from the non-zero lists of E[s] the statistics pass leaves (pm_bsc_wp_sparse_f64); the dense
+        # product still runs -- decided on the device -- when a list overflowed
+        self.sparse_wp = os.environ.get('PM_SPARSE_WP', '1') == '1'
         self.use_fused = os.environ.get('PM_FUSED', '1') == '1'   # scores GEMM + select + E-step as ONE kernel (bsc_fused.hip)
         self.fused_tile = os.environ.get('PM_FUSED_TILE', 'auto')     # '4' | '8' | 'auto': wavefronts per workgroup of the fused kernel
         self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
@@ -250,10 +253,18 @@ class BSC_ET(DeviceCAModel):
         if tile8:
             # two launches, labelled apart (timers / traces): whole rounds of 64-row tiles, then the ragged remainder
             main_rows = int(_lib.load().pm_bsc_fused8_main_rows(main, Y8.shape[1])) if self._tile8_whole_shard() else main
+            entry = "pm_bsc_estep_fused8_f64"
+            self._nz = None
+            if mstats and self.sparse_wp and main == N:
+                nz_max = 16                                            # PM_BSC_NZ_MAX
+                nz = (self._buf("nz_idx", (N, nz_max), torch.int16), self._buf("nz_val", (N, nz_max)))
+                args = args + (_ptr(nz[0]), _ptr(nz[1]))
+                entry = "pm_bsc_estep_fused8_nz_f64"
+                self._nz = {"idx": nz[0], "val": nz[1], "stats": mstats[1], "rows": N}
             if main_rows > 0:
-                self._call("estep_fused", "pm_bsc_estep_fused8_f64", *(args + (1, self._stream())))
+                self._call("estep_fused", entry, *(args + (1, self._stream())))
             if main_rows < main:
-                self._call("estep_fused_tail", "pm_bsc_estep_fused8_f64", *(args + (2, self._stream())))
+                self._call("estep_fused_tail", entry, *(args + (2, self._stream())))
             return main
         self._call("estep_fused", "pm_bsc_estep_fused_f64", *(args + (self._stream(),)))
         return main
@@ -491,6 +502,7 @@ class BSC_ET(DeviceCAModel):
             stats = self._buf("stats", (n_stats,))
             stats.zero_()
             mstats = (self._buf("expect", (N, H)), stats)
+        self._nz = None
         if N:
             rows = self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats)
         out = DeviceArray(logpj)
@@ -498,7 +510,8 @@ class BSC_ET(DeviceCAModel):
         out.cand = cand
         if mstats is not None:
             out.mstats = {"expect": mstats[0], "stats": mstats[1], "rows": rows, "res": res, "cand": cand,
-                          "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm)}
+                          "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm), "nz": self._nz}
+        self._nz = None
         return out
 
     def _speculate_estep(self, res, par, anneal, pies, sigma):
@@ -630,11 +643,12 @@ class BSC_ET(DeviceCAModel):
         st = self._stream()
         # statistics the E-step pass has already produced for its first `done` rows (same shard, candidates, scalars)
         ms = getattr(logpj, "mstats", None) if isinstance(logpj, DeviceArray) else None
-        done = 0
+        done, nz = 0, None
         if (ms is not None and ms["res"] is res and ms["stats"] is stats and ms["expect"] is expect and ms["cand"] is cand
                 and ms["P"] == (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm) and lse_cut == float("-inf")
                 and tab["fast"]):
             done = ms["rows"]
+            nz = ms.get("nz")
             logpj.mstats = None
             lib = _lib.load()
             o_wq, o_qd, o_mus = (lib.pm_bsc_stats_offset_wq(H, D), lib.pm_bsc_stats_offset_qdiag(H, D),
@@ -663,7 +677,14 @@ class BSC_ET(DeviceCAModel):
         # high-priority side stream ahead of the statistics GEMM gains nothing: its 1024-thread workgroup needs a whole
         # CU's registers, the GEMM's workgroups refill every slot as it frees, so the inverse still starts when the GEMM
         # has drained; 4.88 vs 4.87 ms per EM iteration.  The warm-started inverse made the question moot.)
-        if my_N:
+        if my_N and done == my_N and nz is not None and nz["stats"] is stats and nz["rows"] == my_N:
+            # the lists of this very pass: sparse product, and the dense one behind the device-side gate (scalars[3])
+            gate = ctypes.c_void_p(stats.data_ptr() + 8 * (_lib.load().pm_bsc_stats_offset_scalars(H, D) + 3))
+            self._call("stats_sparse", "pm_bsc_wp_sparse_f64", _ptr(nz["idx"]), _ptr(nz["val"]), _ptr(Y), Y.stride(0),
+                       _ptr(stats), my_N, H, D, st)
+            self._call("stats_gemm", "pm_gemm_tn_acc_gated_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D,
+                       my_N, gate, st)
+        elif my_N:
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, st)
         need_mu = 'mu' in self.to_learn
         if need_mu:

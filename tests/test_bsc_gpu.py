@@ -583,6 +583,64 @@ def test_step_with_fused_mstep_statistics(dev, D, H, Hp, gamma, N):
         np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("N,T,overflow", [(40000, 1.0, False), (3000, 1.0, False), (40000, 40.0, True), (777, 6.0, None)])
+def test_sparse_wp_from_nonzero_lists(dev, N, T, overflow):
+    """The statistics pass leaves every E[s] row as a list of its non-zeros too (pm_bsc_estep_fused8_nz_f64), and
+    Wp = E[s]^T Y (bsc_et.py:339-363) is accumulated from the lists (pm_bsc_wp_sparse_f64).  The lists hold exactly the
+    non-zeros of the dense rows, bit for bit; the statistics and the new parameters equal those of the dense product;
+    rows with more than PM_BSC_NZ_MAX non-zeros (a hot annealing temperature) are counted and the dense product runs
+    instead, decided on the device."""
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, gamma = 128, 256, 8, 4
+    rng = np.random.RandomState(N + int(T))
+    W_gt = rng.normal(size=(D, H))
+    y = (rng.random_sample((N, H)) < 3.0 / H) @ W_gt.T + rng.normal(size=(N, D))
+    params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 3.0 / H, "sigma": 1.05}
+    out = {}
+    for sparse in (True, False):
+        m = BSC_ET(D, H, Hp, gamma)
+        assert m._tile8_whole_shard()
+        m.sparse_wp = sparse
+        names = []
+        orig = m._call
+        m._call = lambda label, name, *a, _o=orig, _n=names: (_n.append(name), _o(label, name, *a))[1]
+        new = m.step(_An(T=T), dict(params), {"y": y})
+        out[sparse] = (new, m._ws["stats"].cpu().numpy().copy(), m._ws["expect"].cpu().numpy().copy(), names)
+        if sparse:
+            idx = m._ws["nz_idx"].cpu().numpy().view(np.uint16).astype(np.int64)
+            val = m._ws["nz_val"].cpu().numpy()
+    a, b = out[True], out[False]
+    assert "pm_bsc_wp_sparse_f64" in a[3] and "pm_gemm_tn_acc_gated_f64" in a[3]
+    assert "pm_bsc_wp_sparse_f64" not in b[3] and "pm_gemm_tn_acc_f64" in b[3]
+    o_sc = _lib.load().pm_bsc_stats_offset_scalars(H, D)
+    E = a[2]
+    nnz = (E != 0).sum(axis=1)
+    n_over = int(a[1][o_sc + 3])
+    assert n_over == int((nnz > 16).sum())
+    if overflow is not None:
+        assert (n_over > 0) == overflow
+    # the lists: the non-zeros of the dense row, in ascending-lane order of the kernel, 0xFFFF behind them
+    ok = nnz <= 16
+    cnt = (idx != 0xFFFF).sum(axis=1)
+    assert np.array_equal(cnt[ok], nnz[ok])
+    rebuilt = np.zeros_like(E)
+    rows = np.repeat(np.arange(N), 16).reshape(N, 16)
+    sel = (idx != 0xFFFF) & ok[:, None]
+    rebuilt[rows[sel], idx[sel]] = val[sel]
+    assert np.array_equal(rebuilt[ok], E[ok])
+    assert all(len(set(r[r != 0xFFFF])) == (r != 0xFFFF).sum() for r in idx[ok][:500])
+    # statistics and parameters
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-300)
+    sa, sb = a[1].copy(), b[1].copy()
+    sa[o_sc + 3] = sb[o_sc + 3] = 0.0
+    np.testing.assert_allclose(sa, sb, rtol=1e-9, atol=1e-11 * np.abs(sb).max())
+    Wp_ref = E.T @ y
+    np.testing.assert_allclose(a[1][:H * D].reshape(H, D), Wp_ref, rtol=1e-10, atol=1e-11 * np.abs(Wp_ref).max())
+    for k in ("W", "pi", "sigma"):
+        np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-8, atol=1e-10)
+
+
 @pytest.mark.parametrize("D,H,Hp,gamma,N", [(256, 64, 6, 3, 40000), (25, 10, 5, 3, 333)])
 def test_em_loop_with_speculative_estep(dev, D, H, Hp, gamma, N):
     """On a flat annealing schedule the M-step launches the next step's E-step itself, as soon as pi_new / sigma_new
