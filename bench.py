@@ -511,6 +511,14 @@ def main():
                                  "whole-pass fraction of that roof, frac the dominant kernel's"},
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(all_kern.items())},
             "em_kernels_ms": {k: round(v[1], 4) for k, v in sorted(em_kern.items())},
+            # the M-step's Wp = E[s]^T Y from the non-zero lists of E[s] (pm_bsc_wp_sparse_f64): bound by streaming the
+            # data once (N D 8 algorithmic bytes per launch); the dense product it replaces was MFMA-bound at 1.49 ms
+            "em_stats_roofline": ({"bound": "hbm", "kernel": "bsc_wp_sparse_kernel (Wp from the non-zero lists of E[s])",
+                                   "achieved": N * D * 8 / (em_kern["stats_sparse"][1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s",
+                                   "frac": N * D * 8 / (em_kern["stats_sparse"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "avg_launch_ms": em_kern["stats_sparse"][1], "traffic": None}
+                                  if "stats_sparse" in em_kern else None),
             "per_rank": [{"rank": r, "ms_per_step": per_rank[r, 0] / args.steps * 1e3,
                           "em_iter_ms": per_rank[r, 1] / args.em_steps * 1e3, "allreduce_us": per_rank[r, 2],
                           "data_seed": int(per_rank[r, 3]), "rows": int(per_rank[r, 4])} for r in range(world)],

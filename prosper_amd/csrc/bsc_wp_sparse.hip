@@ -5,7 +5,9 @@
 // annealing phase the truncated posterior has weight on a handful of latents: 3.7 non-zeros of 256 per row on config 2
 // (max 8; scratch/nnz_hist.py), so 98.5 % of those flops multiply zeros.  With the lists the E-step pass leaves
 // (pm_bsc_estep_fused8_nz_f64) the product is N nnz D multiply-adds -- nothing -- and one read of the data: the kernel
-// is bound by streaming Y once (N D 8 bytes; 1.64 GB on config 2 = 0.2 ms at HBM speed).
+// is bound by streaming Y once (N D 8 bytes; 1.64 GB on config 2 = 0.2 ms at the HBM peak, 0.27 ms at the 6 TB/s a
+// plain reduction over Y reaches on this chip; measured 0.40 ms = 4.1 TB/s -- each workgroup reads 512-byte pieces of
+// 8 KB rows; with empty lists the same loop streams at 4.8 TB/s, scratch/sparse_bench.py).
 //
 // Layout: a workgroup owns a 64-column chunk of Wp for a group of datapoints and keeps its (H x 64) accumulator in LDS
 // (128 KB at H = 256: one 16-wavefront workgroup per CU).  A wavefront takes one datapoint at a time: lane c holds
@@ -22,7 +24,10 @@ namespace {
 
 constexpr int SP_DC = 64;          // columns per workgroup
 constexpr int SP_WAVES = 16;
-constexpr int SP_UNROLL = 8;       // datapoints in flight per wavefront (8 x 512 B of Y)
+#ifndef PM_SP_UNROLL
+#define PM_SP_UNROLL 8
+#endif
+constexpr int SP_UNROLL = PM_SP_UNROLL;   // datapoints per batch; two batches in flight per wavefront (16 x 512 B of Y)
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -48,35 +53,54 @@ __global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint
     for (int i = tid; i < H * SP_DC; i += SP_WAVES * 64) acc[i] = 0.0;
     __syncthreads();
 
-    const int col = chunk * SP_DC + lane;
-    const bool colok = col < D;
-    const int64_t lo = grp * rows_per_group;
-    const int64_t hi = lo + rows_per_group < N ? lo + rows_per_group : N;
+    // (no predication in the loop: columns past D and datapoints past the group are clamped to valid addresses -- the
+    // former are never flushed, the latter get an empty list)
+    const uint32_t col = chunk * SP_DC + lane < D ? chunk * SP_DC + lane : D - 1;
+    const uint32_t slot = lane & (PM_BSC_NZ_MAX - 1);
+    const int lo = (int)(grp * rows_per_group);                // (N < 2^31: checked by the caller)
+    const int hi = lo + rows_per_group < N ? (int)(lo + rows_per_group) : (int)N;
     double *arow = acc + lane;
-    for (int64_t n0 = lo + wave; n0 < hi; n0 += SP_WAVES * SP_UNROLL) {
+    struct Batch {
         double y[SP_UNROLL], v[SP_UNROLL];
         int ix[SP_UNROLL];
+        bool ok[SP_UNROLL];
+    };
+    auto load = [&](int n0, Batch &b) {
 #pragma unroll
         for (int u = 0; u < SP_UNROLL; ++u) {
-            const int64_t n = n0 + (int64_t)u * SP_WAVES;
-            const bool ok = n < hi;
-            y[u] = (ok && colok) ? Y[n * ldy + col] : 0.0;
-            ix[u] = 0xFFFF;
-            v[u] = 0.0;
-            if (ok && lane < PM_BSC_NZ_MAX) {
-                ix[u] = nz_idx[n * PM_BSC_NZ_MAX + lane];
-                v[u] = nz_val[n * PM_BSC_NZ_MAX + lane];
-            }
+            int n = n0 + u * SP_WAVES;                         // wavefront-uniform: scalar base + 32-bit lane offset
+            b.ok[u] = n < hi;
+            n = b.ok[u] ? n : hi - 1;
+#ifdef PM_SP_NO_NT
+            b.y[u] = (Y + (int64_t)n * ldy)[col];
+#else
+            b.y[u] = __builtin_nontemporal_load((Y + (int64_t)n * ldy) + col);   // read once: leave L2 to the lists
+#endif
+            b.ix[u] = (nz_idx + (int64_t)n * PM_BSC_NZ_MAX)[slot];
+            b.v[u] = (nz_val + (int64_t)n * PM_BSC_NZ_MAX)[slot];
         }
+    };
+    auto accumulate = [&](const Batch &b) {
 #pragma unroll
         for (int u = 0; u < SP_UNROLL; ++u) {
-            const int cnt = __popcll(__ballot(ix[u] != 0xFFFF));     // (the valid slots are the leading ones)
+            // (the valid slots are the leading ones; lanes 16.. repeat lanes 0..15)
+            const int cnt = b.ok[u] ? __popc((uint32_t)__ballot(b.ix[u] != 0xFFFF) & 0xFFFFu) : 0;
             for (int t = 0; t < cnt; ++t) {
-                const int h = __builtin_amdgcn_readlane(ix[u], t);
-                const double w = readlane_f64(v[u], t);
-                atomicAdd(arow + h * SP_DC, w * y[u]);
+                const int h = __builtin_amdgcn_readlane(b.ix[u], t);
+                const double w = readlane_f64(b.v[u], t);
+                atomicAdd(arow + h * SP_DC, w * b.y[u]);
             }
         }
+    };
+    // two batches in flight: the loads of one are issued before the other is accumulated
+    constexpr int STEP = SP_WAVES * SP_UNROLL;
+    Batch b0, b1;
+    load(lo + wave, b0);
+    for (int n0 = lo + wave; n0 < hi; n0 += 2 * STEP) {
+        load(n0 + STEP, b1);
+        accumulate(b0);
+        load(n0 + 2 * STEP, b0);
+        accumulate(b1);
     }
     __syncthreads();
     for (int i = tid; i < H * SP_DC; i += SP_WAVES * 64) {
@@ -91,7 +115,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint
 extern "C" int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy,
                                     double *stats, int64_t N, int64_t H, int64_t D, void *stream) {
     if (!nz_idx || !nz_val || !Y || !stats || N < 0 || H <= 0 || D <= 0 || ldy < D) return PM_EINVAL;
-    if (H > 256 || D > INT32_MAX) return PM_ERANGE;
+    if (H > 256 || D > INT32_MAX || N > INT32_MAX - 4096) return PM_ERANGE;
     if (N == 0) return PM_OK;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
