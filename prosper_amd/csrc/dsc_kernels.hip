@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
     const double *__restrict__ ynorm2, const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S,
     const double *__restrict__ prior_g, pm_dsc_params P, int64_t N, int H, int Hp, double *__restrict__ logpj,
-    int64_t ldl, double *__restrict__ lse, int stage) {
+    int64_t ldl, double *__restrict__ lse, int stage, int fast_off, int NT) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [ w2 (H) | per wave: a (Hp) G (Hp*Hp) | state table (S*Hp bytes, padded to 8) | staged: prior (Kt) | per wave: f (Kt) ]
     // staged (when it fits): the log-prior table is read from LDS instead of global memory for every datapoint, and
@@ -127,6 +127,77 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
         __syncthreads();
     }
     const double *prior = stage ? s_prior : prior_g;
+
+    // Energy terms by table (round 3).  The energy of a state is yn + sum_j v_j (v_j G_jj - 2 a_j) + 2 sum_{k<j} v_j v_k
+    // G_jk over its non-zero positions: with at most three of them (gamma <= 3) it is the sum of three single-position
+    // terms U(j, v) and three pair terms P(j, k, v, v') out of a per-datapoint table of NT = 1 + H'(K-1) + C(H',2)(K-1)^2
+    // entries (73 at H' = 6, K = 3; entry 0 is an exact zero for the unused slots).  The table costs ~10 instructions
+    // per entry and datapoint, a state 6 LDS reads + 6 adds instead of the ~80 instructions of state_energy (which
+    // walks all H' positions with zero factors) -- the states were 60 % of this kernel's instructions.
+    //   fast tables: [ s_off (S x 8 bytes: six entry indices) | s_dj (NT) s_dk (NT) | s_c1 (NT) | s_c2 (NT) | per wave: T (NT) ]
+    //   T[e] = c1[e] G[dj, dk] + c2[e] a[dj]
+    // (Tried on top, not kept: fetching the candidate gather -- two dependent round trips -- one datapoint ahead:
+    // 0.28 vs 0.21 ms; on gfx950 loads and stores share one in-order counter, so waiting for the prefetched values
+    // also waits for the previous datapoint's 477 log-joint stores.)
+    bool fast = NT > 0;
+    uint8_t *s_off = smem + fast_off;
+    const int NTp = (NT + 7) & ~7;
+    uint8_t *s_dj = s_off + (size_t)S * 8, *s_dk = s_dj + NTp;
+    double *s_c1 = reinterpret_cast<double *>(s_dk + NTp), *s_c2 = s_c1 + NT;
+    double *s_T = s_c2 + NT + (size_t)wave * NT;
+    if (fast) {
+        const int Kn = P.K - 1, nU = Hp * Kn;
+        for (int e = tid; e < NT; e += blockDim.x) {
+            int j = 0, k = 0;
+            double c1 = 0.0, c2 = 0.0;
+            if (e >= 1 && e <= nU) {
+                j = k = (e - 1) / Kn;
+                const int c = (e - 1) % Kn;
+                const double v = s_val[c < P.K0 ? c : c + 1];
+                c1 = v * v;
+                c2 = -2.0 * v;
+            } else if (e > nU) {
+                const int r = e - 1 - nU, pair = r / (Kn * Kn), cc = r % (Kn * Kn);
+                k = 1;
+                while ((k + 1) * k / 2 <= pair) ++k;           // pair = k (k - 1) / 2 + j, j < k
+                j = pair - k * (k - 1) / 2;
+                const int ca = cc / Kn, cb = cc % Kn;
+                c1 = 2.0 * s_val[ca < P.K0 ? ca : ca + 1] * s_val[cb < P.K0 ? cb : cb + 1];
+            }
+            s_dj[e] = (uint8_t)j;
+            s_dk[e] = (uint8_t)k;
+            s_c1[e] = c1;
+            s_c2[e] = c2;
+        }
+        int too_many = 0;
+        for (int st = tid; st < S; st += blockDim.x) {
+            int pos[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, g = 0;
+            for (int j = 0; j < Hp; ++j) {
+                const int ki = s_tab[st * Hp + j];
+                if (ki != P.K0) {
+                    if (g < 3) {
+                        pos[g] = j;
+                        cv[g] = ki < P.K0 ? ki : ki - 1;
+                    }
+                    ++g;
+                }
+            }
+            too_many |= g > 3;
+            auto U = [&](int a) { return a < g ? 1 + pos[a] * Kn + cv[a] : 0; };
+            auto PP = [&](int a, int b) {       // a < b: positions ascend
+                return b < g ? 1 + nU + (pos[b] * (pos[b] - 1) / 2 + pos[a]) * Kn * Kn + cv[a] * Kn + cv[b] : 0;
+            };
+            uint8_t *o = s_off + (size_t)st * 8;
+            o[0] = (uint8_t)U(0);
+            o[1] = (uint8_t)U(1);
+            o[2] = (uint8_t)U(2);
+            o[3] = (uint8_t)PP(0, 1);
+            o[4] = (uint8_t)PP(0, 2);
+            o[5] = (uint8_t)PP(1, 2);
+            o[6] = o[7] = 0;
+        }
+        fast = !__syncthreads_or(too_many);      // (a state with more than three non-zeros: the generic walk for all)
+    }
     for (int64_t n = (int64_t)blockIdx.x * WAVES + wave; n < N; n += (int64_t)gridDim.x * WAVES) {
         const double *arow = scores + n * lds;
         const int32_t *cn = cand + n * Hp;
@@ -140,6 +211,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
             if (ok) s_G[p] = gram[(int64_t)ci * H + ck];
         }
         wave_sync_lds_dsc();
+        if (fast) {
+            for (int e = lane; e < NT; e += 64) {
+                const int j = s_dj[e];
+                s_T[e] = fma(s_c1[e], s_G[j * Hp + s_dk[e]], s_c2[e] * s_a[j]);
+            }
+        }
 
         double *out = logpj + n * ldl;
         double m = -INFINITY;
@@ -163,8 +240,16 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
             }
             ++c;
         }
+        if (fast) wave_sync_lds_dsc();
         for (int s = lane; s < S; s += 64) {
-            const double e = state_energy<MAXHP>(s_tab + s * Hp, Hp, s_val, s_a, s_G, yn);
+            double e;
+            if (fast) {
+                const uint2 o = *reinterpret_cast<const uint2 *>(s_off + (size_t)s * 8);
+                e = yn + s_T[o.x & 255u] + s_T[(o.x >> 8) & 255u] + s_T[(o.x >> 16) & 255u] + s_T[o.x >> 24] +
+                    s_T[o.y & 255u] + s_T[(o.y >> 8) & 255u];
+            } else {
+                e = state_energy<MAXHP>(s_tab + s * Hp, Hp, s_val, s_a, s_G, yn);
+            }
             const double f = P.ecoef * e + P.pscale * prior[base + s];
             out[base + s] = f;
             if (stage) s_f[base + s] = f;
@@ -411,12 +496,19 @@ extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double 
     const size_t staged = shmem + sizeof(double) * (size_t)(WAVES + 1) * (size_t)Kt;
     const int stage = staged <= 30 * 1024 ? 1 : 0;       // keep five workgroups per CU
     if (stage) shmem = staged;
+    // the energy-term tables (see the kernel): where they fit beside the rest
+    const int64_t Kn = params_host->K - 1;
+    int64_t NT = 1 + Hprime * Kn + Hprime * (Hprime - 1) / 2 * Kn * Kn;
+    const size_t fast_off = align8(shmem);
+    const size_t fast_bytes = (size_t)S * 8 + 2 * (size_t)((NT + 7) & ~7) + sizeof(double) * (size_t)NT * (2 + WAVES);
+    if (NT > 256 || S == 0 || fast_off + fast_bytes > 40 * 1024) NT = 0;
+    else shmem = fast_off + fast_bytes;
 #define PM_LAUNCH(M)                                                                                                 \
     do {                                                                                                             \
         if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_estep_kernel<M>), shmem)) return e;             \
         hipLaunchKernelGGL(dsc_estep_kernel<M>, dim3(row_grid(N, M <= 8 ? 5 : 4)), dim3(64 * WAVES), shmem,            \
                            static_cast<hipStream_t>(stream), scores, lds, gram, ynorm2, cand, state_idx, (int)S, prior, \
-                           *params_host, N, (int)H, (int)Hprime, logpj, ldl, lse, stage);                            \
+                           *params_host, N, (int)H, (int)Hprime, logpj, ldl, lse, stage, (int)fast_off, (int)NT);   \
     } while (0)
     if (Hprime <= 8) PM_LAUNCH(8);
     else PM_LAUNCH(PM_MAX_HPRIME);
