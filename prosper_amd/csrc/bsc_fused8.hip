@@ -954,7 +954,10 @@ constexpr int T_EXPC = T_EXP + 1024, T_AREAS = T_EXPC + 384;                 // 
 constexpr int A_ROW = 0, A_P = 2048, A_WIN = 4096, A_MISC = 4160, AREA_BYTES = 4288;
 constexpr int LEAN_LDS_BYTES = T_AREAS + 16 * AREA_BYTES;     // 79360
 static_assert(LEAN_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
-constexpr int LEAN16_LDS_BYTES = T_AREAS + 32 * AREA_BYTES;   // 147968: the 16-wavefront workgroup, one per CU
+// (16-wavefront workgroup only: behind the areas, a 36-entry block per datapoint slot where the statistics pass gathers
+// E[s_i s_k] of the candidate pairs before they go to Wq -- see PAIRLDS in the kernel)
+constexpr int T_PAIRS16 = T_AREAS + 32 * AREA_BYTES, PAIR_ENTRIES = 36;
+constexpr int LEAN16_LDS_BYTES = T_PAIRS16 + 32 * PAIR_ENTRIES * 8;   // 157184: the 16-wavefront workgroup, one per CU
 static_assert(LEAN16_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 // e^x for x in [-708, 0] from LDS tables: E[j] = 2^(j/128) (128 doubles) and C = {128/ln2, 1.5 2^52, -ln2/128 hi, lo,
@@ -1109,6 +1112,9 @@ constexpr bool W16_DEFAULT = false;
 #else
 constexpr bool W16_DEFAULT = true;
 #endif
+#ifdef PM_F8_WQX
+__device__ double pm_f8_wqx[7 * 65536];
+#endif
 template <int STAGES, int HP, int GAMMA, bool FULL, bool MSTATS, bool TAIL, bool W16 = (W16_DEFAULT && !TAIL)>
 __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kernel(
     const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wt, int64_t ldw, int D,
@@ -1262,6 +1268,11 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
     double *listA = Pm + j32;
     double *win = reinterpret_cast<double *>(area + A_WIN);
     int *cl = reinterpret_cast<int *>(area + A_MISC);
+    constexpr bool PAIRLDS = W16 && MSTATS;
+    double *Bp = reinterpret_cast<double *>(smem + T_PAIRS16) + (PAIRLDS ? slot : 0) * PAIR_ENTRIES;
+    // lane j32 flushes pair entry j32 = k (k + 1) / 2 + i (entries 32..35 = (4..7, 7) go with lanes 0..3)
+    const int pair_k = (j32 >= 1) + (j32 >= 3) + (j32 >= 6) + (j32 >= 10) + (j32 >= 15) + (j32 >= 21) + (j32 >= 28);
+    const int pair_i = j32 - pair_k * (pair_k + 1) / 2;
     double *mxs = reinterpret_cast<double *>(area + A_MISC) + 8, *sms = mxs + 4;
     const uint32_t *stA = reinterpret_cast<const uint32_t *>(smem + T_ST) + 4 * j32;
     double *PeA = reinterpret_cast<double *>(Pb + O_E) + j32;
@@ -1280,6 +1291,9 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
     // M-step statistics (MSTATS): E[s] rows, the candidates' second-moment block -> Wq, column sums, scalars
     char *exp_t = MSTATS ? reinterpret_cast<char *>(expect + m0 * lde) : nullptr;
     double *wq = MSTATS ? stats + pm_bsc_stats_offset_wq_dev(H, Dstats) : nullptr;
+#ifdef PM_F8_WQX   // (timing experiment: every XCD adds into its own copy of Wq; the copies are not folded)
+    if (MSTATS && pm_xcc_id()) wq = pm_f8_wqx + (size_t)(pm_xcc_id() - 1) * 65536;
+#endif
     double *t_mus = reinterpret_cast<double *>(smem + T_MUS);
     const uint32_t *t_tab = reinterpret_cast<const uint32_t *>(smem + T_TAB);
     double m_sig = 0.0, m_fs = 0.0, m_cnt = 0.0;        // per-lane partial sums of the scalar statistics
@@ -1516,6 +1530,15 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
             // add[h]: the multi-cause states' share of E[s_h], gathered per candidate in LDS (P is free by now)
 #pragma unroll
             for (int i = 0; i < NJ; ++i) Pm[j32 + 32 * i] = 0.0;
+            // PAIRLDS: the second moments of the candidate pairs are gathered in LDS as well -- entry k (k + 1) / 2 + i
+            // for positions i <= k -- and go to Wq as ONE predicated atomic instruction per datapoint.  Every
+            // multi-cause state that carries weight used to issue its 3 / 6 / 10 global atomics itself (a cl[] lookup,
+            // a min / max and a 64-bit address each): 0.084 ms of the 1.77 ms pass on the parameters of a running EM
+            // loop (scratch/em_estep_time.py; per-XCD copies of Wq changed nothing, so it was the issue cost).
+            if (PAIRLDS) {
+                Bp[j32] = 0.0;
+                if (j32 < PAIR_ENTRIES - 32) Bp[32 + j32] = 0.0;
+            }
             wave_lds_sync16();
             {
                 int q = 0;
@@ -1533,7 +1556,15 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
                                     mi &= mi - 1;
                                     const int ci = cl[i];
                                     atomicAdd(&Pm[ci], ex);
-                                    if (!(PM_F8_SKIP & 64) && live) {
+                                    if (PAIRLDS) {
+                                        atomicAdd(&Bp[i * (i + 1) / 2 + i], w);
+                                        unsigned mk = mi;
+                                        while (mk) {
+                                            const int kk = __builtin_ctz(mk);      // kk > i
+                                            mk &= mk - 1;
+                                            atomicAdd(&Bp[kk * (kk + 1) / 2 + i], w);
+                                        }
+                                    } else if (!(PM_F8_SKIP & (64 | 256)) && live) {
                                         pm_atomic_add(wq + (int64_t)ci * H + ci, w);
                                         unsigned mk = mi;
                                         while (mk) {
@@ -1551,6 +1582,19 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
                 }
             }
             wave_lds_sync16();
+            if (PAIRLDS) {
+                // lane j32 flushes entry j32 = (pair_i, pair_k) and, lanes 0..3, entry 32 + j32 = (4 + j32, 7)
+                const double v = Bp[j32];
+                const int ci = cl[pair_i], ck = cl[pair_k];
+                const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
+                if (!(PM_F8_SKIP & (64 | 256)) && live && v != 0.0) pm_atomic_add(wq + (int64_t)lo * H + hi, v);
+                if (j32 < PAIR_ENTRIES - 32) {
+                    const double v2 = Bp[32 + j32];
+                    const int c2 = cl[4 + j32], c7 = cl[7];
+                    const int lo2 = c2 < c7 ? c2 : c7, hi2 = c2 < c7 ? c7 : c2;
+                    if (!(PM_F8_SKIP & (64 | 256)) && live && v2 != 0.0) pm_atomic_add(wq + (int64_t)lo2 * H + hi2, v2);
+                }
+            }
             char *erow = exp_t + ((uint32_t)lrow * (uint32_t)lde * 8u + (uint32_t)j32 * 8u);
             // the row's non-zeros as a list as well (pm_bsc_wp_sparse_f64 multiplies them into the data): up to
             // PM_BSC_NZ_MAX (index, value) pairs in the order the lanes hold them, unused index slots 0xFFFF; a longer
@@ -1633,6 +1677,9 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
     (void)t_mus;
     (void)exp_t;
     (void)wq;
+    (void)Bp;
+    (void)pair_i;
+    (void)pair_k;
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     //   fast tables: [ s_off (S x 8 bytes: six entry indices) | s_dj (NT) s_dk (NT) | s_c1 (NT) | s_c2 (NT) | per wave: T (NT) ]
     //   T[e] = c1[e] G[dj, dk] + c2[e] a[dj]
     // (Tried on top, not kept: fetching the candidate gather -- two dependent round trips -- one datapoint ahead:
-    // 0.28 vs 0.21 ms; on gfx950 loads and stores share one in-order counter, so waiting for the prefetched values
-    // also waits for the previous datapoint's 477 log-joint stores.)
+    // 0.28 vs 0.21 ms -- not investigated further; loads and stores share the vmcnt counter on gfx950, so the wait for
+    // the prefetched values may well have become a wait for the previous datapoint's 477 log-joint stores.)
     bool fast = NT > 0;
     uint8_t *s_off = smem + fast_off;
     const int NTp = (NT + 7) & ~7;
