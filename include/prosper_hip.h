@@ -269,7 +269,10 @@ int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const double *Wt, int6
  * given): nz_idx (N x PM_BSC_NZ_MAX uint16: latent indices, unused slots 0xFFFF) and nz_val (N x PM_BSC_NZ_MAX).  Past the
  * annealing phase a posterior of the truncated state set puts weight on a handful of latents (3.7 of 256 per datapoint
  * on config 2), and the M-step's Wp = E[s]^T Y (bsc_et.py:339-363) needs only those rows of the product.  A row with more
- * than PM_BSC_NZ_MAX non-zeros is counted in scalars[3]; `expect` is complete either way. */
+ * than PM_BSC_NZ_MAX non-zeros is counted in scalars[3]; `expect` is complete either way.
+ * Statistics of the whole-shard passes (pm_bsc_fused8_whole_shard; both entries): the diagonal of the second moments is
+ * left in `qdiag` in full (= mus: E[s_h^2] = E[s_h]) and the diagonal of the Wq block stays zero -- the assembled matrix
+ * upper + upper^T - diag(upper) + diag(qdiag) is the same, no fix-up pass is needed. */
 #define PM_BSC_NZ_MAX 16
 int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
                                const double *ynorm2, const double *wmu, const double *ymu,

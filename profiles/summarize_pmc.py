@@ -42,12 +42,16 @@ KERNELS = {
     "gemm_nt_f64_dma_kernel<false>": "scores_gemm",
     "gemm_nt_f64_dma_kernel<true>": "scores_gemm_splitk",
     "gemm_tn_f64": "stats_gemm",
+    "bsc_wp_sparse_kernel": "stats_sparse",                              # Wp from the non-zero lists of E[s] (round 3)
     "bsc_select_estep16_kernel": "select_estep",
     "bsc_mstep_rows16_kernel": "mstep_rows",
 }
 FETCH_FACTOR = {"estep_fused": 2.0, "estep_fused_mstats": 2.0,    # reads are the LDS-DMA stream of Y (16 B per lane)
                 "estep_fused_tail": 2.0, "estep_fused_tail_mstats": 2.0,
-                "scores_gemm": 2.0, "scores_gemm_splitk": 2.0, "stats_gemm": 2.0, "select_estep": 1.0, "mstep_rows": 2.0}
+                "scores_gemm": 2.0, "scores_gemm_splitk": 2.0, "stats_gemm": 2.0, "select_estep": 1.0, "mstep_rows": 2.0,
+                # 8 B/lane loads of 512-byte aligned row segments, like bsc_select_estep16 (factor 1); check: the kernel
+                # must read N D 8 bytes of Y (1.638 GB at N = 200000) + the lists
+                "stats_sparse": 1.0}
 
 
 def load(d):

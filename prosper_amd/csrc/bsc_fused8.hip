@@ -1556,8 +1556,9 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
                                     mi &= mi - 1;
                                     const int ci = cl[i];
                                     atomicAdd(&Pm[ci], ex);
+                                    // (the diagonal of the second moments is not accumulated: E[s_h^2] = E[s_h], the
+                                    // kernel leaves qdiag = mus and a zero diagonal in the Wq block)
                                     if (PAIRLDS) {
-                                        atomicAdd(&Bp[i * (i + 1) / 2 + i], w);
                                         unsigned mk = mi;
                                         while (mk) {
                                             const int kk = __builtin_ctz(mk);      // kk > i
@@ -1565,7 +1566,6 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
                                             atomicAdd(&Bp[kk * (kk + 1) / 2 + i], w);
                                         }
                                     } else if (!(PM_F8_SKIP & (64 | 256)) && live) {
-                                        pm_atomic_add(wq + (int64_t)ci * H + ci, w);
                                         unsigned mk = mi;
                                         while (mk) {
                                             const int kk = __builtin_ctz(mk);
@@ -1665,9 +1665,13 @@ __global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_
             if (v != 0.0) pm_atomic_add(sc + tid, v);
         }
         double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, Dstats);
+        double *g_qd = stats + pm_bsc_stats_offset_qdiag_dev(H, Dstats);
         if (tid < H) {
             const double v = t_mus[tid];
-            if (v != 0.0) pm_atomic_add(g_mus + tid, v);
+            if (v != 0.0) {
+                pm_atomic_add(g_mus + tid, v);
+                pm_atomic_add(g_qd + tid, v);      // diag(Wq) in full: see the state loop
+            }
         }
     }
     F8_STAMP(3);

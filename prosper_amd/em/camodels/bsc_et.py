@@ -255,6 +255,7 @@ class BSC_ET(DeviceCAModel):
             main_rows = int(_lib.load().pm_bsc_fused8_main_rows(main, Y8.shape[1])) if self._tile8_whole_shard() else main
             entry = "pm_bsc_estep_fused8_f64"
             self._nz = None
+            self._qd_done = bool(mstats) and self._tile8_whole_shard()    # these passes leave qdiag complete (= mus)
             if mstats and self.sparse_wp and main == N:
                 nz_max = 16                                            # PM_BSC_NZ_MAX
                 nz = (self._buf("nz_idx", (N, nz_max), torch.int16), self._buf("nz_val", (N, nz_max)))
@@ -503,6 +504,7 @@ class BSC_ET(DeviceCAModel):
             stats.zero_()
             mstats = (self._buf("expect", (N, H)), stats)
         self._nz = None
+        self._qd_done = False
         if N:
             rows = self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats)
         out = DeviceArray(logpj)
@@ -510,7 +512,7 @@ class BSC_ET(DeviceCAModel):
         out.cand = cand
         if mstats is not None:
             out.mstats = {"expect": mstats[0], "stats": mstats[1], "rows": rows, "res": res, "cand": cand,
-                          "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm), "nz": self._nz}
+                          "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm), "nz": self._nz, "qd_done": self._qd_done}
         self._nz = None
         return out
 
@@ -653,9 +655,11 @@ class BSC_ET(DeviceCAModel):
             lib = _lib.load()
             o_wq, o_qd, o_mus = (lib.pm_bsc_stats_offset_wq(H, D), lib.pm_bsc_stats_offset_qdiag(H, D),
                                  lib.pm_bsc_stats_offset_mus(H, D))
-            # the pass leaves mus = sum E[s] and the multi-cause block of Wq incl. its diagonal; qdiag (the singletons'
-            # share of the diagonal, s_h^2 = s_h) is the difference
-            stats[o_qd:o_mus] = stats[o_mus:o_mus + H] - torch.diagonal(stats[o_wq:o_qd].view(H, H))
+            # the 4-wavefront pass leaves mus = sum E[s] and the multi-cause block of Wq incl. its diagonal; qdiag (the
+            # singletons' share of the diagonal, s_h^2 = s_h) is the difference.  The whole-shard passes leave the full
+            # diagonal in qdiag themselves (one small launch less per step).
+            if not ms.get("qd_done"):
+                stats[o_qd:o_mus] = stats[o_mus:o_mus + H] - torch.diagonal(stats[o_wq:o_qd].view(H, H))
         else:
             stats.zero_()
         if done:
