@@ -595,8 +595,13 @@ def test_step_with_fused_mstep_statistics(dev, D, H, Hp, gamma, N):
         np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize("N,T,overflow", [(40000, 1.0, False), (3000, 1.0, False), (40000, 40.0, True), (777, 6.0, None)])
-def test_sparse_wp_from_nonzero_lists(dev, N, T, overflow):
+@pytest.mark.parametrize("N,T,overflow,D,H,gamma", [
+    (40000, 1.0, False, 128, 256, 4), (3000, 1.0, False, 128, 256, 4), (40000, 40.0, True, 128, 256, 4),
+    (777, 6.0, None, 128, 256, 4),
+    (35000, 1.0, False, 200, 200, 3),     # H < 256 (guarded latent slots), D not a multiple of the 64-column chunks
+    (5000, 1.0, None, 72, 200, 3),        # ... and a broad posterior: some lists overflow, the dense product runs
+])
+def test_sparse_wp_from_nonzero_lists(dev, N, T, overflow, D, H, gamma):
     """The statistics pass leaves every E[s] row as a list of its non-zeros too (pm_bsc_estep_fused8_nz_f64), and
     Wp = E[s]^T Y (bsc_et.py:339-363) is accumulated from the lists (pm_bsc_wp_sparse_f64).  The lists hold exactly the
     non-zeros of the dense rows, bit for bit; the statistics and the new parameters equal those of the dense product;
@@ -604,7 +609,7 @@ def test_sparse_wp_from_nonzero_lists(dev, N, T, overflow):
     instead, decided on the device."""
     from prosper_amd import _lib
     from prosper_amd.em.camodels.bsc_et import BSC_ET
-    D, H, Hp, gamma = 128, 256, 8, 4
+    Hp = 8
     rng = np.random.RandomState(N + int(T))
     W_gt = rng.normal(size=(D, H))
     y = (rng.random_sample((N, H)) < 3.0 / H) @ W_gt.T + rng.normal(size=(N, D))
