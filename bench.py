@@ -468,6 +468,13 @@ def main():
                     break
             except Exception:
                 pass
+        sparse_traffic = None
+        try:
+            if N == N_PER_GPU and traffic_source:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", traffic_source.split()[0].split("/")[-1])))["kernels"]
+                sparse_traffic = next((v["hbm_bytes"] for k, v in pmc.items() if k.startswith("stats_sparse")), None)
+        except Exception:
+            pass
         ms_step = elapsed / args.steps * 1e3
         value = world * N * args.steps / elapsed
         dom_ms = kern[dom][1]
@@ -517,7 +524,8 @@ def main():
                                    "achieved": N * D * 8 / (em_kern["stats_sparse"][1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s",
                                    "frac": N * D * 8 / (em_kern["stats_sparse"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "avg_launch_ms": em_kern["stats_sparse"][1], "traffic": None}
+                                   "avg_launch_ms": em_kern["stats_sparse"][1], "traffic": sparse_traffic,
+                                   "traffic_source": traffic_source if sparse_traffic else None}
                                   if "stats_sparse" in em_kern else None),
             "per_rank": [{"rank": r, "ms_per_step": per_rank[r, 0] / args.steps * 1e3,
                           "em_iter_ms": per_rank[r, 1] / args.em_steps * 1e3, "allreduce_us": per_rank[r, 2],
