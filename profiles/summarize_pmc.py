@@ -49,9 +49,9 @@ KERNELS = {
 FETCH_FACTOR = {"estep_fused": 2.0, "estep_fused_mstats": 2.0,    # reads are the LDS-DMA stream of Y (16 B per lane)
                 "estep_fused_tail": 2.0, "estep_fused_tail_mstats": 2.0,
                 "scores_gemm": 2.0, "scores_gemm_splitk": 2.0, "stats_gemm": 2.0, "select_estep": 1.0, "mstep_rows": 2.0,
-                # 8 B/lane loads of 512-byte aligned row segments, like bsc_select_estep16 (factor 1); check: the kernel
-                # must read N D 8 bytes of Y (1.638 GB at N = 200000) + the lists
-                "stats_sparse": 1.0}
+                # 8 B/lane non-temporal loads of 512-byte row segments: calibrated on the bytes the kernel must read -- N D 8 =
+                # 1.638 GB of Y at N = 200000 against a raw counter of 0.948 GB -> factor 2 (1.90 GB: Y + the lists' L2 misses)
+                "stats_sparse": 2.0}
 
 
 def load(d):
