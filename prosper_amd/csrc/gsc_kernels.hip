@@ -170,17 +170,6 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     __syncthreads();
 
     const double tiny = 2.2250738585072014e-308, fmin_ = -1.7976931348623157e308;
-    // e^x of the un-stabilised weights: table-driven inside [-700, 700] (pm_exp_tab: 14 instructions against libm's ~45,
-    // 11 exponentials per lane and datapoint), libm outside and for NaN, where the reference's underflow / overflow /
-    // clamp behaviour is what counts -- decided per wavefront
-    __shared__ double s_E[128];
-    if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
-    __syncthreads();
-    const double *etab = s_E - 256;
-    auto wexp = [&](double x) {
-        const bool plain = (x <= 700.0) && (x >= -700.0);
-        return __all(plain) ? pm_exp_tab(x, etab) : exp(x);
-    };
     // The block sums are accumulated per XCD (pm_common.h: f64 atomics from eight XCDs on the same few thousand
     // lines bounce those lines between the L2s -- measured: a third of this kernel's time).  Copy 0 is the
     // caller-visible slot, copies 1..7 sit behind the documented layout; the launcher folds them.
@@ -378,7 +367,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
             }
             const double lp = -C_det - r2 * inv_s2 + quad * inv_s2 * inv_s2 + prior;
             if (LPJ && live && valid) logpj[n * ldl + 1 + H + s] = lp;
-            double p = wexp(lp * beta);
+            double p = exp(lp * beta);
             if (p != p || p < tiny) p = tiny;
             if (valid) Z += p;
 #pragma unroll
@@ -413,7 +402,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                 const double bb = ai - s_gm[h];
                 const double lp = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h] + s_lpi[h];
                 if (LPJ && live) logpj[n * ldl + 1 + h] = lp;
-                p = wexp(h < H ? lp * beta : 0.0);
+                p = exp(lp * beta);
                 if (p != p || p < tiny) p = tiny;
                 Z += p;
             }
