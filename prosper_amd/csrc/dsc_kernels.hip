@@ -88,6 +88,66 @@ __device__ __forceinline__ double state_energy(const uint8_t *row, int Hp, const
     return e;
 }
 
+// Builds the energy-term tables of a workgroup (see dsc_estep_kernel): decode tables s_dj / s_dk / s_c1 / s_c2 of the NT
+// entries, the six entry indices of every state in s_off.  Returns (to every thread) whether some state has more than
+// three non-zero positions -- the tables do not apply then.  Every thread of the workgroup calls this.
+__device__ __forceinline__ bool dsc_build_energy_tables(const pm_dsc_params &P, int Hp, int S, int NT, const uint8_t *s_tab,
+                                                        const double *s_val, uint8_t *s_off, uint8_t *s_dj, uint8_t *s_dk,
+                                                        double *s_c1, double *s_c2) {
+    const int tid = threadIdx.x;
+    const int Kn = P.K - 1, nU = Hp * Kn;
+    for (int e = tid; e < NT; e += blockDim.x) {
+        int j = 0, k = 0;
+        double c1 = 0.0, c2 = 0.0;
+        if (e >= 1 && e <= nU) {
+            j = k = (e - 1) / Kn;
+            const int c = (e - 1) % Kn;
+            const double v = s_val[c < P.K0 ? c : c + 1];
+            c1 = v * v;
+            c2 = -2.0 * v;
+        } else if (e > nU) {
+            const int r = e - 1 - nU, pair = r / (Kn * Kn), cc = r % (Kn * Kn);
+            k = 1;
+            while ((k + 1) * k / 2 <= pair) ++k;           // pair = k (k - 1) / 2 + j, j < k
+            j = pair - k * (k - 1) / 2;
+            const int ca = cc / Kn, cb = cc % Kn;
+            c1 = 2.0 * s_val[ca < P.K0 ? ca : ca + 1] * s_val[cb < P.K0 ? cb : cb + 1];
+        }
+        s_dj[e] = (uint8_t)j;
+        s_dk[e] = (uint8_t)k;
+        s_c1[e] = c1;
+        s_c2[e] = c2;
+    }
+    int too_many = 0;
+    for (int st = tid; st < S; st += blockDim.x) {
+        int pos[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, g = 0;
+        for (int j = 0; j < Hp; ++j) {
+            const int ki = s_tab[st * Hp + j];
+            if (ki != P.K0) {
+                if (g < 3) {
+                    pos[g] = j;
+                    cv[g] = ki < P.K0 ? ki : ki - 1;
+                }
+                ++g;
+            }
+        }
+        too_many |= g > 3;
+        auto U = [&](int a) { return a < g ? 1 + pos[a] * Kn + cv[a] : 0; };
+        auto PP = [&](int a, int b) {       // a < b: positions ascend
+            return b < g ? 1 + nU + (pos[b] * (pos[b] - 1) / 2 + pos[a]) * Kn * Kn + cv[a] * Kn + cv[b] : 0;
+        };
+        uint8_t *o = s_off + (size_t)st * 8;
+        o[0] = (uint8_t)U(0);
+        o[1] = (uint8_t)U(1);
+        o[2] = (uint8_t)U(2);
+        o[3] = (uint8_t)PP(0, 1);
+        o[4] = (uint8_t)PP(0, 2);
+        o[5] = (uint8_t)PP(1, 2);
+        o[6] = o[7] = 0;
+    }
+    return __syncthreads_or(too_many);
+}
+
 template <int MAXHP>
 __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
@@ -145,59 +205,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
     uint8_t *s_dj = s_off + (size_t)S * 8, *s_dk = s_dj + NTp;
     double *s_c1 = reinterpret_cast<double *>(s_dk + NTp), *s_c2 = s_c1 + NT;
     double *s_T = s_c2 + NT + (size_t)wave * NT;
-    if (fast) {
-        const int Kn = P.K - 1, nU = Hp * Kn;
-        for (int e = tid; e < NT; e += blockDim.x) {
-            int j = 0, k = 0;
-            double c1 = 0.0, c2 = 0.0;
-            if (e >= 1 && e <= nU) {
-                j = k = (e - 1) / Kn;
-                const int c = (e - 1) % Kn;
-                const double v = s_val[c < P.K0 ? c : c + 1];
-                c1 = v * v;
-                c2 = -2.0 * v;
-            } else if (e > nU) {
-                const int r = e - 1 - nU, pair = r / (Kn * Kn), cc = r % (Kn * Kn);
-                k = 1;
-                while ((k + 1) * k / 2 <= pair) ++k;           // pair = k (k - 1) / 2 + j, j < k
-                j = pair - k * (k - 1) / 2;
-                const int ca = cc / Kn, cb = cc % Kn;
-                c1 = 2.0 * s_val[ca < P.K0 ? ca : ca + 1] * s_val[cb < P.K0 ? cb : cb + 1];
-            }
-            s_dj[e] = (uint8_t)j;
-            s_dk[e] = (uint8_t)k;
-            s_c1[e] = c1;
-            s_c2[e] = c2;
-        }
-        int too_many = 0;
-        for (int st = tid; st < S; st += blockDim.x) {
-            int pos[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, g = 0;
-            for (int j = 0; j < Hp; ++j) {
-                const int ki = s_tab[st * Hp + j];
-                if (ki != P.K0) {
-                    if (g < 3) {
-                        pos[g] = j;
-                        cv[g] = ki < P.K0 ? ki : ki - 1;
-                    }
-                    ++g;
-                }
-            }
-            too_many |= g > 3;
-            auto U = [&](int a) { return a < g ? 1 + pos[a] * Kn + cv[a] : 0; };
-            auto PP = [&](int a, int b) {       // a < b: positions ascend
-                return b < g ? 1 + nU + (pos[b] * (pos[b] - 1) / 2 + pos[a]) * Kn * Kn + cv[a] * Kn + cv[b] : 0;
-            };
-            uint8_t *o = s_off + (size_t)st * 8;
-            o[0] = (uint8_t)U(0);
-            o[1] = (uint8_t)U(1);
-            o[2] = (uint8_t)U(2);
-            o[3] = (uint8_t)PP(0, 1);
-            o[4] = (uint8_t)PP(0, 2);
-            o[5] = (uint8_t)PP(1, 2);
-            o[6] = o[7] = 0;
-        }
-        fast = !__syncthreads_or(too_many);      // (a state with more than three non-zeros: the generic walk for all)
-    }
+    if (fast)
+        fast = !dsc_build_energy_tables(P, Hp, S, NT, s_tab, s_val, s_off, s_dj, s_dk, s_c1, s_c2);   // (> 3 non-zeros: generic walk)
     for (int64_t n = (int64_t)blockIdx.x * WAVES + wave; n < N; n += (int64_t)gridDim.x * WAVES) {
         const double *arow = scores + n * lds;
         const int32_t *cn = cand + n * Hp;
@@ -279,6 +288,157 @@ __global__ __launch_bounds__(64 * WAVES, 4) void dsc_estep_kernel(
         }
         sum = pm_wave_sum(sum);
         if (lane == 0) lse[n] = m + log(sum);
+        wave_sync_lds_dsc();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dsc_estep_kernel with SIXTEEN lanes per datapoint (four datapoints per wavefront, 16 per workgroup).  The one-
+// wavefront form is latency-bound -- per datapoint two dependent memory round trips (candidates, then their scores and
+// Gram entries) in front of ~500 instructions, and the wave-wide reductions, the gather and the syncs are paid per
+// datapoint.  Here four datapoints share every wavefront instruction and four gathers are in flight per wavefront;
+// reductions are four DPP steps inside a 16-lane row.  Lane j of a row takes the singleton columns h = j + 16 i and
+// the states s = j + 16 i.  The log-joints are not parked in LDS between the two passes of the log-sum-exp (16 rows of
+// K doubles would not fit): the second pass recomputes them (6-12 instructions each) and evaluates the exponential.
+// LDS: [ w2 (H) | state table | prior (K, when staged) | energy-term tables | per row: a (H') G (H'^2) T (NT) ]
+// ---------------------------------------------------------------------------------------------------------------
+struct Lay16 {
+    int tab, prior, off, dj, dk, c1, c2, rows, row_stride, bytes;
+};
+__host__ __device__ inline Lay16 dsc_lay16(int H, int Hp, int S, int Kt, int NT, int stage) {
+    Lay16 L;
+    int o = 8 * H;
+    L.tab = o;
+    o += (S * Hp + 7) & ~7;
+    L.prior = o;
+    o += stage ? 8 * Kt : 0;
+    L.off = o;
+    o += NT ? S * 8 : 0;
+    const int NTp = (NT + 7) & ~7;
+    L.dj = o;
+    L.dk = o + NTp;
+    o += 2 * NTp;
+    L.c1 = o;
+    L.c2 = o + 8 * NT;
+    o += 16 * NT;
+    L.rows = o;
+    L.row_stride = 8 * (Hp + Hp * Hp + NT);
+    L.bytes = o + 16 * L.row_stride;
+    return L;
+}
+
+template <int MAXHP, int VPL>      // VPL: latents per lane, H <= 16 VPL (the scores row of a datapoint is held in registers)
+__global__ __launch_bounds__(256, 4) void dsc_estep16_kernel(
+    const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
+    const double *__restrict__ ynorm2, const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S,
+    const double *__restrict__ prior_g, pm_dsc_params P, int64_t N, int H, int Hp, double *__restrict__ logpj,
+    int64_t ldl, double *__restrict__ lse, int stage, int NT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nss = (P.K - 1) * H;
+    const bool tab = P.flags & PM_DSC_TABLE_ONLY;        // TSC: columns = rows of the state table, nothing else
+    const int base = tab ? 0 : 1 + nss;
+    const int Kt = base + S;
+    const Lay16 L = dsc_lay16(H, Hp, S, Kt, NT, stage);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, row = lane >> 4, rowbase = lane & 48;
+    double *s_w2 = reinterpret_cast<double *>(smem);
+    uint8_t *s_tab = smem + L.tab;
+    double *s_prior = reinterpret_cast<double *>(smem + L.prior);
+    uint8_t *s_off = smem + L.off, *s_dj = smem + L.dj, *s_dk = smem + L.dk;
+    double *s_c1 = reinterpret_cast<double *>(smem + L.c1), *s_c2 = reinterpret_cast<double *>(smem + L.c2);
+    double *s_a = reinterpret_cast<double *>(smem + L.rows + (wave * 4 + row) * L.row_stride);
+    double *s_G = s_a + Hp, *s_T = s_G + Hp * Hp;
+    __shared__ double s_val[PM_DSC_MAX_K];
+    __shared__ double s_E[128];
+    if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
+    const double *etab = s_E - 256;
+    for (int h = tid; h < H; h += blockDim.x) s_w2[h] = gram[(int64_t)h * H + h];
+    for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
+    if (tid < PM_DSC_MAX_K) s_val[tid] = (tid < P.K) ? P.values[tid] : 0.0;
+    if (stage)
+        for (int i = tid; i < Kt; i += blockDim.x) s_prior[i] = prior_g[i];
+    __syncthreads();
+    const double *prior = stage ? s_prior : prior_g;
+    bool fast = NT > 0;
+    if (fast) fast = !dsc_build_energy_tables(P, Hp, S, NT, s_tab, s_val, s_off, s_dj, s_dk, s_c1, s_c2);
+
+    for (int64_t n0 = (int64_t)blockIdx.x * 16; n0 < N; n0 += (int64_t)gridDim.x * 16) {
+        const int64_t n = n0 + wave * 4 + row;
+        const bool live = n < N;
+        const int64_t nn = live ? n : N - 1;              // rows past N shadow the last datapoint and store nothing
+        const double *arow = scores + nn * lds;
+        const double yn = ynorm2[nn];
+        const int myc = j < Hp ? cand[nn * Hp + j] : 0;
+        // the scores row, requested at once (the singleton loops below would otherwise wait for one load per trip)
+        double ar[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) ar[i] = (!tab && j + 16 * i < H) ? arow[j + 16 * i] : 0.0;
+        if (j < Hp) s_a[j] = arow[myc];
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {        // uniform trip count: every lane feeds the permutes
+            const int p = p0 + j;
+            const bool ok = p < Hp * Hp;
+            const int pi = ok ? p / Hp : 0, pk = ok ? p - pi * Hp : 0;
+            const int ci = __builtin_amdgcn_ds_bpermute((rowbase + pi) << 2, myc);
+            const int ck = __builtin_amdgcn_ds_bpermute((rowbase + pk) << 2, myc);
+            if (ok) s_G[p] = gram[(int64_t)ci * H + ck];
+        }
+        wave_sync_lds_dsc();
+        if (fast) {
+            for (int e = j; e < NT; e += 16) {
+                const int dj = s_dj[e];
+                s_T[e] = fma(s_c1[e], s_G[dj * Hp + s_dk[e]], s_c2[e] * s_a[dj]);
+            }
+            wave_sync_lds_dsc();
+        }
+        double *out = logpj + nn * ldl;
+        // every column of this lane, in a fixed order: fn(column, log-joint)
+        auto visit = [&](auto &&fn) {
+            if (!tab && j == 0) fn(0, P.ecoef * yn + P.pscale * prior[0]);
+            int c = 0;
+            for (int k = 0; k < P.K && !tab; ++k) {
+                if (k == P.K0) continue;
+                const double v = s_val[k];
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const int h = j + 16 * i;
+                    if (h < H) {
+                        const double e = v * v * s_w2[h] - 2.0 * v * ar[i] + yn;
+                        fn(1 + c * H + h, P.ecoef * e + P.pscale * prior[1 + c * H + h]);
+                    }
+                }
+                ++c;
+            }
+            for (int st = j; st < S; st += 16) {
+                double e;
+                if (fast) {
+                    const uint2 o = *reinterpret_cast<const uint2 *>(s_off + (size_t)st * 8);
+                    e = yn + s_T[o.x & 255u] + s_T[(o.x >> 8) & 255u] + s_T[(o.x >> 16) & 255u] + s_T[o.x >> 24] +
+                        s_T[o.y & 255u] + s_T[(o.y >> 8) & 255u];
+                } else {
+                    e = state_energy<MAXHP>(s_tab + st * Hp, Hp, s_val, s_a, s_G, yn);
+                }
+                fn(base + st, P.ecoef * e + P.pscale * prior[base + st]);
+            }
+        };
+        double m = -INFINITY;
+        visit([&](int col, double f) {
+            if (live) out[col] = f;
+            m = fmax(m, f);
+        });
+        m = fmax(m, pm_dpp_f64<0xB1>(m));
+        m = fmax(m, pm_dpp_f64<0x4E>(m));
+        m = fmax(m, pm_dpp_f64<0x141>(m));
+        m = fmax(m, pm_dpp_f64<0x140>(m));
+        double sum = 0.0;
+        visit([&](int, double f) {
+            const double d = f - m;
+            sum += d > -37.0 ? pm_exp_tab(d, etab) : 0.0;
+        });
+        sum += pm_dpp_f64<0xB1>(sum);
+        sum += pm_dpp_f64<0x4E>(sum);
+        sum += pm_dpp_f64<0x141>(sum);
+        sum += pm_dpp_f64<0x140>(sum);
+        if (j == 0 && live) lse[n] = m + log(sum);
         wave_sync_lds_dsc();
     }
 }
@@ -490,9 +650,42 @@ extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double 
         return PM_EINVAL;
     if (ldl < ((params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S)) return PM_EINVAL;
     if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
+    const int64_t Kt = (params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S;
+#ifndef PM_DSC_WAVE64
+    {
+        // sixteen lanes per datapoint where its LDS layout fits four workgroups per CU
+        const int64_t Kn16 = params_host->K - 1;
+        int64_t NT16 = 1 + Hprime * Kn16 + Hprime * (Hprime - 1) / 2 * Kn16 * Kn16;
+        if (NT16 > 256 || S == 0) NT16 = 0;
+        if (S * Hprime < (1 << 20) && Kt < (1 << 20)) {
+            int stage16 = 1;
+            Lay16 L = dsc_lay16((int)H, (int)Hprime, (int)S, (int)Kt, (int)NT16, stage16);
+            if (L.bytes > 40 * 1024) {
+                stage16 = 0;
+                L = dsc_lay16((int)H, (int)Hprime, (int)S, (int)Kt, (int)NT16, stage16);
+            }
+            if (L.bytes <= 40 * 1024 && H <= 256) {
+                const int64_t blocks16 = (N + 15) / 16;
+                const unsigned grid16 = (unsigned)(blocks16 < 256 * 4 ? blocks16 : 256 * 4);
+#define PM_LAUNCH16(M, V)                                                                                              \
+    do {                                                                                                               \
+        if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_estep16_kernel<M, V>), (size_t)L.bytes)) return e; \
+        hipLaunchKernelGGL((dsc_estep16_kernel<M, V>), dim3(grid16), dim3(256), (size_t)L.bytes,                       \
+                           static_cast<hipStream_t>(stream), scores, lds, gram, ynorm2, cand, state_idx, (int)S, prior, \
+                           *params_host, N, (int)H, (int)Hprime, logpj, ldl, lse, stage16, (int)NT16);                 \
+    } while (0)
+                if (Hprime <= 8 && H <= 128) PM_LAUNCH16(8, 8);
+                else if (Hprime <= 8) PM_LAUNCH16(8, 16);
+                else if (H <= 128) PM_LAUNCH16(PM_MAX_HPRIME, 8);
+                else PM_LAUNCH16(PM_MAX_HPRIME, 16);
+#undef PM_LAUNCH16
+                return (int)hipGetLastError();
+            }
+        }
+    }
+#endif
     size_t shmem = sizeof(double) * (H + WAVES * (Hprime + Hprime * Hprime)) + align8((size_t)S * Hprime);
     if (shmem > 150 * 1024) return PM_ERANGE;
-    const int64_t Kt = (params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S;
     const size_t staged = shmem + sizeof(double) * (size_t)(WAVES + 1) * (size_t)Kt;
     const int stage = staged <= 30 * 1024 ? 1 : 0;       // keep five workgroups per CU
     if (stage) shmem = staged;
