@@ -604,6 +604,200 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// dsc_mstep_rows_kernel with sixteen lanes per datapoint (see dsc_estep16_kernel): the log-joints of a datapoint are
+// requested in batches (VPL singleton columns per value, eight state columns at a time) instead of one load per loop
+// trip, the candidate bookkeeping and the reductions are per 16-lane row.
+// LDS: [ qdiag (H) cnt (8) scal (4) | state table | prior (K, when staged) | per row: E[s] row (H) m (H') B (H'^2) ]
+// ---------------------------------------------------------------------------------------------------------------
+template <int MAXHP, int VPL>
+__global__ __launch_bounds__(256, 4) void dsc_mstep_rows16_kernel(
+    const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
+    const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior_g,
+    pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ expect, int64_t lde,
+    double *__restrict__ stats, int stage) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *s_qdiag = reinterpret_cast<double *>(smem);
+    double *s_cnt = s_qdiag + H;
+    double *s_scal = s_cnt + PM_DSC_MAX_K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, row = lane >> 4, rowbase = lane & 48;
+    const int nss = (P.K - 1) * H;
+    const bool tab = P.flags & PM_DSC_TABLE_ONLY;
+    const int base = tab ? 0 : 1 + nss;
+    const int Kt = base + S;
+    uint8_t *s_tab = reinterpret_cast<uint8_t *>(s_scal + 4);
+    double *s_prior = reinterpret_cast<double *>(s_tab + (((size_t)S * Hp + 7) & ~size_t(7)));
+    const int per_row = H + Hp + Hp * Hp;
+    double *s_row = s_prior + (stage ? Kt : 0) + (size_t)(wave * 4 + row) * per_row;
+    double *s_m = s_row + H;
+    double *s_B = s_m + Hp;
+    __shared__ double s_val[PM_DSC_MAX_K];
+    __shared__ double s_E[128];
+    if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
+    const double *etab = s_E - 256;
+    for (int h = tid; h < H + PM_DSC_MAX_K + 4; h += blockDim.x) s_qdiag[h] = 0.0;
+    for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
+    if (tid < PM_DSC_MAX_K) s_val[tid] = (tid < P.K) ? P.values[tid] : 0.0;
+    if (stage)
+        for (int i = tid; i < Kt; i += blockDim.x) s_prior[i] = prior_g[i];
+    __syncthreads();
+    const double *prior = stage ? s_prior : prior_g;
+    const double inv_ecoef = 1.0 / P.ecoef;
+    const double qcut = -60.0;     // weights below e^-60 of the evidence add nothing in f64
+    double sig = 0.0, fs = 0.0, kept = 0.0;
+    double cnt[PM_DSC_MAX_K];
+#pragma unroll
+    for (int k = 0; k < PM_DSC_MAX_K; ++k) cnt[k] = 0.0;
+    double *Wq = stats + (int64_t)H * D;
+
+    for (int64_t n0 = (int64_t)blockIdx.x * 16; n0 < N; n0 += (int64_t)gridDim.x * 16) {
+        const int64_t n = n0 + wave * 4 + row;
+        const bool live = n < N;
+        const int64_t nn = live ? n : N - 1;
+        const double l_n = lse[nn];
+        const bool use = live && (l_n > lse_cut);             // truncated: strictly-greater rule of dsc_et.py:832
+        const double l = use ? l_n : INFINITY;                  // (every weight of a dropped / shadow row is exp(-inf) = 0)
+        const double *f = logpj + nn * ldl;
+        const int myc = j < Hp ? cand[nn * Hp + j] : -1;
+        if (j < Hp) s_m[j] = 0.0;
+        for (int p = j; p < Hp * Hp; p += 16) s_B[p] = 0.0;
+        // positions that are the last occurrence of their latent (all of them unless candidates repeat)
+        bool mine_last = j < Hp;
+        for (int k = 1; k < Hp; ++k) {                          // uniform trip count
+            const int other = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc);
+            if (k > j && other == myc) mine_last = false;
+        }
+        const unsigned lastmask = (P.flags & PM_DSC_LAST_POSITION)
+                                      ? (unsigned)((__ballot(mine_last) >> rowbase) & 0xFFFFull)
+                                      : ((1u << Hp) - 1u);
+        if (j == 0 && use) {
+            if (!tab) {
+                const double f0 = f[0];
+                sig += (f0 - l > qcut ? pm_exp_tab(f0 - l, etab) : 0.0) * ((f0 - P.pscale * prior[0]) * inv_ecoef);
+            }
+            fs += l;
+            kept += 1.0;
+        }
+        // singletons: E[s_h] and its second moment over the values (dsc_et.py:660-700)
+        {
+            double rowv[VPL], qd[VPL];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) rowv[i] = qd[i] = 0.0;
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < PM_DSC_MAX_K; ++k) {
+                if (tab || k >= P.K || k == P.K0) continue;
+                const double v = s_val[k];
+                double fv[VPL];
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) fv[i] = (j + 16 * i < H) ? f[1 + c * H + j + 16 * i] : -INFINITY;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const int h = j + 16 * i;
+                    if (h < H) {
+                        const double dq = fv[i] - l;
+                        const double q = dq > qcut ? pm_exp_tab(dq, etab) : 0.0;
+                        rowv[i] += q * v;
+                        qd[i] += q * v * v;
+                        cnt[k] += q;
+                        sig += q * ((fv[i] - P.pscale * prior[1 + c * H + h]) * inv_ecoef);
+                    }
+                }
+                ++c;
+            }
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int h = j + 16 * i;
+                if (h < H) {
+                    s_row[h] = rowv[i];
+                    if (qd[i] != 0.0) atomicAdd(&s_qdiag[h], qd[i]);
+                }
+            }
+        }
+        wave_sync_lds_dsc();
+        // multi-cause states, eight columns per lane at a time
+        for (int s0 = 0; s0 < S; s0 += 128) {
+            double fv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int st = s0 + j + 16 * u;
+                fv[u] = st < S ? f[base + st] : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int st = s0 + j + 16 * u;
+                const double dl = fv[u] - l;
+                if (!(dl > qcut)) continue;
+                const double q = pm_exp_tab(dl, etab);
+                sig += q * ((fv[u] - P.pscale * prior[base + st]) * inv_ecoef);
+                const uint8_t *srow = s_tab + st * Hp;
+                int ki[MAXHP];
+                double vv[MAXHP];
+#pragma unroll
+                for (int a = 0; a < MAXHP; ++a) {
+                    ki[a] = (a < Hp) ? (int)srow[a] : P.K0;
+                    vv[a] = (a < Hp) ? s_val[ki[a]] : 0.0;
+                }
+#pragma unroll
+                for (int a = 0; a < MAXHP; ++a) {
+                    if (a < Hp && ki[a] != P.K0) {
+#pragma unroll
+                        for (int k = 0; k < PM_DSC_MAX_K; ++k)
+                            if (k == ki[a]) cnt[k] += q;
+                        atomicAdd(&s_m[a], q * vv[a]);
+#pragma unroll
+                        for (int k2 = a; k2 < MAXHP; ++k2)
+                            if (k2 < Hp && ki[k2] != P.K0) atomicAdd(&s_B[a * Hp + k2], q * vv[a] * vv[k2]);
+                    }
+                }
+            }
+        }
+        wave_sync_lds_dsc();
+        if (j < Hp && ((lastmask >> j) & 1u)) s_row[myc] += s_m[j];   // distinct latents
+        wave_sync_lds_dsc();
+        if (live) {
+            double *erow = expect + n * lde;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (j + 16 * i < H) erow[j + 16 * i] = s_row[j + 16 * i];
+        }
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {              // uniform trip count: every lane feeds the permutes
+            const int p = p0 + j;
+            const bool ok = p < Hp * Hp;
+            const int a = ok ? p / Hp : 0, k2 = ok ? p - a * Hp : 0;
+            const int cj = __builtin_amdgcn_ds_bpermute((rowbase + a) << 2, myc);
+            const int ck = __builtin_amdgcn_ds_bpermute((rowbase + k2) << 2, myc);
+            if (!ok || k2 < a || !((lastmask >> a) & 1u) || !((lastmask >> k2) & 1u)) continue;
+            const double v = s_B[p];
+            if (v == 0.0) continue;
+            const int r = cj < ck ? cj : ck, cc = cj < ck ? ck : cj;
+            pm_atomic_add(Wq + (int64_t)r * H + cc, v);          // upper triangle (pm_spd_inverse_f64 layout)
+        }
+        wave_sync_lds_dsc();
+    }
+
+    sig = pm_wave_sum(sig);
+    fs = pm_wave_sum(fs);
+    kept = pm_wave_sum(kept);
+#pragma unroll
+    for (int k = 0; k < PM_DSC_MAX_K; ++k) cnt[k] = pm_wave_sum(cnt[k]);
+    if (lane == 0) {
+        atomicAdd(&s_scal[0], sig);
+        atomicAdd(&s_scal[1], fs);
+        atomicAdd(&s_scal[2], kept);
+#pragma unroll
+        for (int k = 0; k < PM_DSC_MAX_K; ++k)
+            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], cnt[k]);
+    }
+    __syncthreads();
+    double *g_qdiag = stats + (int64_t)H * D + (int64_t)H * H;
+    for (int h = tid; h < H + PM_DSC_MAX_K + 4; h += blockDim.x) {
+        const double v = s_qdiag[h];
+        if (v != 0.0) pm_atomic_add(g_qdiag + h, v);
+    }
+}
+
 inline size_t align8(size_t x) { return (x + 7) & ~size_t(7); }
 
 inline int allow_lds_dsc(const void *kernel, size_t bytes) {
@@ -721,10 +915,40 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
         params_host->ecoef == 0.0)
         return PM_EINVAL;
     if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
+    const int64_t Kt = (params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S;
+#ifndef PM_DSC_WAVE64
+    if (H <= 256 && S * Hprime < (1 << 20) && Kt < (1 << 20)) {
+        // sixteen lanes per datapoint where the layout fits four workgroups per CU
+        const size_t fixed = sizeof(double) * (H + PM_DSC_MAX_K + 4) + align8((size_t)S * Hprime);
+        const size_t rows16 = sizeof(double) * 16 * (size_t)(H + Hprime + Hprime * Hprime);
+        int stage16 = 1;
+        size_t sh16 = fixed + sizeof(double) * (size_t)Kt + rows16;
+        if (sh16 > 40 * 1024) {
+            stage16 = 0;
+            sh16 = fixed + rows16;
+        }
+        if (sh16 <= 40 * 1024) {
+            const int64_t blocks16 = (N + 15) / 16;
+            const unsigned grid16 = (unsigned)(blocks16 < 256 * 4 ? blocks16 : 256 * 4);
+#define PM_LAUNCH16(M, V)                                                                                              \
+    do {                                                                                                               \
+        if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows16_kernel<M, V>), sh16)) return e;      \
+        hipLaunchKernelGGL((dsc_mstep_rows16_kernel<M, V>), dim3(grid16), dim3(256), sh16,                             \
+                           static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior, \
+                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, stage16);                 \
+    } while (0)
+            if (Hprime <= 8 && H <= 128) PM_LAUNCH16(8, 8);
+            else if (Hprime <= 8) PM_LAUNCH16(8, 16);
+            else if (H <= 128) PM_LAUNCH16(PM_MAX_HPRIME, 8);
+            else PM_LAUNCH16(PM_MAX_HPRIME, 16);
+#undef PM_LAUNCH16
+            return (int)hipGetLastError();
+        }
+    }
+#endif
     size_t shmem = sizeof(double) * (H + PM_DSC_MAX_K + 4 + WAVES * (H + Hprime + Hprime * Hprime)) +
                    align8((size_t)S * Hprime);
     if (shmem > 150 * 1024) return PM_ERANGE;
-    const int64_t Kt = (params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S;
     const int stage = shmem + sizeof(double) * (size_t)Kt <= 36 * 1024 ? 1 : 0;     // four workgroups per CU stay
     if (stage) shmem += sizeof(double) * (size_t)Kt;
 #define PM_LAUNCH(M)                                                                                                 \
