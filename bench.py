@@ -203,11 +203,11 @@ def other_models(dev, Anneal, steps=20):
             out["%s_kernels_ms" % name] = {k: round(v[1], 4) for k, v in sorted(ks.items())}
             if name == "dsc":       # (the two DSC row kernels; TSC runs the same kernels on its own state table)
                 if "estep" in ks:
-                    out["dsc_estep_roofline"] = valu_issue_roofline("dsc_estep_kernel<8>", ks["estep"][1],
-                                                                    "dsc_estep_kernel (log-joints of the K-ary states)")
+                    out["dsc_estep_roofline"] = valu_issue_roofline("dsc_only:dsc_estep16_kernel", ks["estep"][1],
+                                                                    "dsc_estep16_kernel (log-joints of the K-ary states)")
                 if "mstep_rows" in ks:
-                    out["dsc_mstep_rows_roofline"] = valu_issue_roofline("dsc_mstep_rows_kernel<8>", ks["mstep_rows"][1],
-                                                                         "dsc_mstep_rows_kernel (posterior moments)")
+                    out["dsc_mstep_rows_roofline"] = valu_issue_roofline("dsc_only:dsc_mstep_rows16_kernel", ks["mstep_rows"][1],
+                                                                         "dsc_mstep_rows16_kernel (posterior moments)")
     except Exception as e:   # never lose the headline over the side measurements
         out["error"] = repr(e)
     gc.enable()
