@@ -25,6 +25,10 @@
 namespace {
 
 constexpr int WAVES = 4;
+#ifndef PM_DSC_M16_WPE
+#define PM_DSC_M16_WPE 4     // wavefronts per SIMD dsc_mstep_rows16_kernel<8, 8> is compiled for: 4 costs 28 spilled registers and
+                             // still wins (0.170 ms; 3 per SIMD, no spill: 0.200; scratch/dsc_ab.sh)
+#endif
 
 __device__ __forceinline__ void wave_sync_lds_dsc() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -328,7 +332,7 @@ __host__ __device__ inline Lay16 dsc_lay16(int H, int Hp, int S, int Kt, int NT,
 }
 
 template <int MAXHP, int VPL>      // VPL: latents per lane, H <= 16 VPL (the scores row of a datapoint is held in registers)
-__global__ __launch_bounds__(256, 4) void dsc_estep16_kernel(
+__global__ __launch_bounds__(256, MAXHP <= 8 ? 4 : 2) void dsc_estep16_kernel(
     const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
     const double *__restrict__ ynorm2, const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S,
     const double *__restrict__ prior_g, pm_dsc_params P, int64_t N, int H, int Hp, double *__restrict__ logpj,
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
 // LDS: [ qdiag (H) cnt (8) scal (4) | state table | prior (K, when staged) | per row: E[s] row (H) m (H') B (H'^2) ]
 // ---------------------------------------------------------------------------------------------------------------
 template <int MAXHP, int VPL>
-__global__ __launch_bounds__(256, 4) void dsc_mstep_rows16_kernel(
+__global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_M16_WPE : 2) void dsc_mstep_rows16_kernel(
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior_g,
     pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ expect, int64_t lde,

@@ -408,17 +408,20 @@ def test_shipped_hot_kernels_do_not_spill(tmp_path):
     build = os.path.join(ROOT, "prosper_amd", "csrc", "build")
     seen = {}
     for obj, patterns in (("bsc_fused8.o", ("bsc_estep_fused8s_kernel",)), ("gemm_f64.o", ("gemm_nt_f64_dma_kernel", "gemm_tn_f64_dma_kernel")),
-                          ("bsc_rows16.o", ("bsc_select_estep16_kernel", "bsc_mstep_rows16_kernel"))):
+                          ("bsc_rows16.o", ("bsc_select_estep16_kernel", "bsc_mstep_rows16_kernel")),
+                          ("bsc_wp_sparse.o", ("bsc_wp_sparse_kernel",)),
+                          ("dsc_kernels.o", ("dsc_estep16_kernel", "dsc_mstep_rows16_kernel"))):
         path = os.path.join(build, obj)
         if not os.path.exists(path):
             pytest.skip("no object files (library built elsewhere)")
         for name, md in _kernel_metadata(path, str(tmp_path)):
             if any(p in name for p in patterns):
                 seen[name] = md
-    assert len(seen) >= 16, sorted(seen)
+    assert len(seen) >= 25, sorted(seen)
     # (bsc_mstep_rows16_kernel -- the M-step's own pass after a data-truncation step -- was deliberately capped at 128
     # registers for four wavefronts per SIMD at the price of 12 spilled registers: 0.48 -> 0.42 ms)
-    limit = lambda n: 16 if "bsc_mstep_rows16_kernel" in n else 4
+    # (dsc_mstep_rows16_kernel<8, 8> likewise: 28 spilled registers at four wavefronts per SIMD, 0.170 vs 0.200 ms at three)
+    limit = lambda n: 16 if "bsc_mstep_rows16_kernel" in n else 32 if "dsc_mstep_rows16_kernelILi8ELi8E" in n else 4
     bad = {n: md for n, md in seen.items() if md.get(".vgpr_spill_count", 0) > limit(n)}
     assert not bad, bad
     # <STAGES, H', gamma, FULL, MSTATS, TAIL = false, W16 = true>: <= 128 registers (4 wavefronts per SIMD)
