@@ -487,11 +487,25 @@ __global__ __launch_bounds__(256) void gsc_colsum_kernel(const double *__restric
     for (int h0 = 0; h0 < H; h0 += cols) {
         const int h = h0 + c;
         double a = 0.0, b = 0.0;
-        if (h < H && rr < lanes_r)
-            for (int64_t r = r0 + rr; r < r1; r += lanes_r) {
+        if (h < H && rr < lanes_r) {
+            // four rows per trip: eight independent loads in flight per thread (one per trip ran at 3.3 TB/s)
+            double a1 = 0.0, a2 = 0.0, a3 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+            int64_t r = r0 + rr;
+            for (; r + 3 * lanes_r < r1; r += 4 * lanes_r) {
+                const double *ps = xpt_s + r * ldx + h, *pz = xpt_sz + r * ldx + h;
+                const int64_t st = (int64_t)lanes_r * ldx;
+                const double x0 = ps[0], x1 = ps[st], x2 = ps[2 * st], x3 = ps[3 * st];
+                const double z0 = pz[0], z1 = pz[st], z2 = pz[2 * st], z3 = pz[3 * st];
+                a += x0; a1 += x1; a2 += x2; a3 += x3;
+                b += z0; b1 += z1; b2 += z2; b3 += z3;
+            }
+            for (; r < r1; r += lanes_r) {
                 a += xpt_s[r * ldx + h];
                 b += xpt_sz[r * ldx + h];
             }
+            a = (a + a1) + (a2 + a3);
+            b = (b + b1) + (b2 + b3);
+        }
         s_part[0][tid] = a;
         s_part[1][tid] = b;
         __syncthreads();
@@ -674,7 +688,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
 #undef PM_LAUNCH
 #undef PM_LAUNCH_L
     {
-        const int64_t rows_per_block = 256;
+        const int64_t rows_per_block = 512;
         const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
         double *g_cs = stats + 2 * H * H;
         const int64_t HH2 = 2 * H * H;
