@@ -287,6 +287,10 @@ int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const double *Wt, i
  * list overflowed: pm_gemm_tn_acc_gated_f64 on `expect` does the work then).  H <= 256. */
 int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *stats,
                          int64_t N, int64_t H, int64_t D, void *stream);
+/* The same accumulation for any model whose statistics start with Wp = E[s]^T Y (DSC / TSC, dsc_et.py:703-735): Wp (H x D,
+ * leading dimension ldw) and the device-side gate (a double: non-zero = skip) are given explicitly. */
+int pm_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp, int64_t ldw,
+                     const double *gate, int64_t N, int64_t H, int64_t D, void *stream);
 
 /* Fast-path twin of pm_bsc_mstep_rows_f64 (same outputs, same `stats` layout). */
 int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
@@ -409,7 +413,7 @@ int pm_dsc_estep_f64(const double *scores, int64_t lds, const double *gram, cons
 /* Packed DSC statistics (float64): [ Wp = E[s]^T.Y (H*D, filled by pm_gemm_tn_acc_f64) |
  * Wq upper triangle, multi-cause part (H*H) | Wq diagonal, singleton part (H) |
  * expected counts of every non-zero value (PM_DSC_MAX_K, entry K0 unused) |
- * sum_nk q e, sum lse, kept datapoints, unused ]. */
+ * sum_nk q e, sum lse, kept datapoints, rows whose non-zero list overflowed (pm_dsc_mstep_rows_nz_f64) ]. */
 int64_t pm_dsc_stats_len(int64_t H, int64_t D);
 
 /* Per-datapoint part of M_step, dsc_et.py:660-735, for datapoints with lse[n] > lse_cut (strict,
@@ -419,6 +423,15 @@ int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse, d
                           const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
                           const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
                           double *expect, int64_t lde, double *stats, void *stream);
+/* The same pass that also leaves every E[s] row as a list of its non-zeros (format of pm_bsc_estep_fused8_nz_f64:
+ * N x PM_BSC_NZ_MAX indices / values, unused index slots 0xFFFF; a longer row counts in the last scalar of `stats`), for
+ * pm_wp_sparse_f64.  Only where pm_dsc_rows16_supported(...) holds (the sixteen-lanes-per-datapoint kernel). */
+int pm_dsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S, int64_t K, int flags);
+int pm_dsc_mstep_rows_nz_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                          const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
+                          const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
+                          double *expect, int64_t lde, double *stats, uint16_t *nz_idx, double *nz_val,
+                             void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Gaussian (spike-and-slab) Sparse Coding, scalar noise (prosper/em/camodels/gsc_et.py, GSC)

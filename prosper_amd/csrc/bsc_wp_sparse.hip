@@ -44,11 +44,19 @@ __global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint
     extern __shared__ __attribute__((aligned(16))) double acc[];          // [H][SP_DC]
     if (*gate != 0.0) return;                  // some list overflowed: the dense product runs instead
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroups are dealt round-robin over the 8 XCDs: chunk = 8 k + (blockIdx & 7) keeps a chunk on one XCD
-    const int per8 = (nchunks + 7) >> 3;
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int chunk = x + 8 * (q % per8);
-    const int64_t grp = q / per8;
+    // workgroups are dealt round-robin over the 8 XCDs: chunk = 8 k + (blockIdx & 7) keeps a chunk on one XCD (fewer
+    // than 8 chunks -- D <= 448 -- : plain enumeration, every workgroup has work)
+    int chunk;
+    int64_t grp;
+    if (nchunks >= 8) {
+        const int per8 = (nchunks + 7) >> 3;
+        const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        chunk = x + 8 * (q % per8);
+        grp = q / per8;
+    } else {
+        chunk = blockIdx.x % nchunks;
+        grp = blockIdx.x / nchunks;
+    }
     if (chunk >= nchunks) return;
     for (int i = tid; i < H * SP_DC; i += SP_WAVES * 64) acc[i] = 0.0;
     __syncthreads();
@@ -114,15 +122,23 @@ __global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint
 
 extern "C" int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy,
                                     double *stats, int64_t N, int64_t H, int64_t D, void *stream) {
-    if (!nz_idx || !nz_val || !Y || !stats || N < 0 || H <= 0 || D <= 0 || ldy < D) return PM_EINVAL;
+    if (!stats) return PM_EINVAL;
+    return pm_wp_sparse_f64(nz_idx, nz_val, Y, ldy, stats, D, stats + pm_bsc_stats_offset_scalars_dev(H, D) + 3, N, H, D,
+                            stream);
+}
+
+extern "C" int pm_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp,
+                                int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, void *stream) {
+    if (!nz_idx || !nz_val || !Y || !Wp || !gate || N < 0 || H <= 0 || D <= 0 || ldy < D || ldw < D) return PM_EINVAL;
     if (H > 256 || D > INT32_MAX || N > INT32_MAX - 4096) return PM_ERANGE;
     if (N == 0) return PM_OK;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
     const int nchunks = (int)((D + SP_DC - 1) / SP_DC), per8 = (nchunks + 7) / 8;
-    // one workgroup per CU: groups of datapoints so that (8 per8) x groups covers the CUs, whole unroll rounds each
-    int64_t groups = cus / (8 * per8);
+    const int slots = nchunks >= 8 ? 8 * per8 : nchunks;       // workgroups per group of datapoints (see the kernel)
+    // one workgroup per CU: groups of datapoints so that slots x groups covers the CUs, whole unroll rounds each
+    int64_t groups = cus / slots;      // (H <= 128, 64 KB accumulators, two workgroups per CU: slower -- twice the flush)
     if (groups < 1) groups = 1;
     const int64_t round = SP_WAVES * SP_UNROLL;
     int64_t rpg = (N + groups - 1) / groups;
@@ -132,9 +148,8 @@ extern "C" int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val
     if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_wp_sparse_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
         return e;
-    const double *gate = stats + pm_bsc_stats_offset_scalars_dev(H, D) + 3;
-    hipLaunchKernelGGL(bsc_wp_sparse_kernel, dim3((unsigned)(8 * per8 * groups)), dim3(SP_WAVES * 64), shmem,
-                       static_cast<hipStream_t>(stream), nz_idx, nz_val, Y, ldy, stats, D, gate, N, (int)H, (int)D, nchunks,
+    hipLaunchKernelGGL(bsc_wp_sparse_kernel, dim3((unsigned)(slots * groups)), dim3(SP_WAVES * 64), shmem,
+                       static_cast<hipStream_t>(stream), nz_idx, nz_val, Y, ldy, Wp, ldw, gate, N, (int)H, (int)D, nchunks,
                        rpg);
     return (int)hipGetLastError();
 }

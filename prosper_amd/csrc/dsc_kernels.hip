@@ -619,13 +619,14 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_M16_WPE : 2)
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior_g,
     pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ expect, int64_t lde,
-    double *__restrict__ stats, int stage) {
+    double *__restrict__ stats, int stage, uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *s_qdiag = reinterpret_cast<double *>(smem);
     double *s_cnt = s_qdiag + H;
     double *s_scal = s_cnt + PM_DSC_MAX_K;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, row = lane >> 4, rowbase = lane & 48;
+    double overflow = 0.0;
     const int nss = (P.K - 1) * H;
     const bool tab = P.flags & PM_DSC_TABLE_ONLY;
     const int base = tab ? 0 : 1 + nss;
@@ -766,6 +767,27 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_M16_WPE : 2)
             for (int i = 0; i < VPL; ++i)
                 if (j + 16 * i < H) erow[j + 16 * i] = s_row[j + 16 * i];
         }
+        if (nz_idx) {      // the row's non-zeros as a list too (pm_wp_sparse_f64; format of the BSC statistics pass)
+            uint16_t *nzi = nz_idx + nn * PM_BSC_NZ_MAX;
+            double *nzv = nz_val + nn * PM_BSC_NZ_MAX;
+            uint32_t nzn = 0;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int h = j + 16 * i;
+                const double v = h < H ? s_row[h] : 0.0;
+                const uint32_t mine = (uint32_t)((__ballot(v != 0.0) >> rowbase) & 0xFFFFull);
+                const uint32_t pos = nzn + __builtin_popcount(mine & ((1u << j) - 1u));
+                if (v != 0.0 && pos < PM_BSC_NZ_MAX && live) {
+                    nzi[pos] = (uint16_t)h;
+                    nzv[pos] = v;
+                }
+                nzn += __builtin_popcount(mine);
+            }
+            if (live) {
+                if ((uint32_t)j >= nzn) nzi[j] = 0xFFFFu;               // (16 lanes = PM_BSC_NZ_MAX slots)
+                if (j == 0 && nzn > PM_BSC_NZ_MAX) overflow += 1.0;
+            }
+        }
         for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {              // uniform trip count: every lane feeds the permutes
             const int p = p0 + j;
             const bool ok = p < Hp * Hp;
@@ -784,12 +806,14 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_M16_WPE : 2)
     sig = pm_wave_sum(sig);
     fs = pm_wave_sum(fs);
     kept = pm_wave_sum(kept);
+    overflow = pm_wave_sum(overflow);
 #pragma unroll
     for (int k = 0; k < PM_DSC_MAX_K; ++k) cnt[k] = pm_wave_sum(cnt[k]);
     if (lane == 0) {
         atomicAdd(&s_scal[0], sig);
         atomicAdd(&s_scal[1], fs);
         atomicAdd(&s_scal[2], kept);
+        if (overflow != 0.0) atomicAdd(&s_scal[3], overflow);
 #pragma unroll
         for (int k = 0; k < PM_DSC_MAX_K; ++k)
             if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], cnt[k]);
@@ -907,10 +931,44 @@ extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double 
     return (int)hipGetLastError();
 }
 
+// the launch geometry of dsc_mstep_rows16_kernel, or 0 bytes where it does not apply
+static size_t dsc_rows16_lds(int64_t H, int64_t Hprime, int64_t S, int64_t Kt, int *stage16) {
+#ifdef PM_DSC_WAVE64
+    return 0;
+#else
+    if (!(H <= 256 && S * Hprime < (1 << 20) && Kt < (1 << 20))) return 0;
+    const size_t fixed = sizeof(double) * (H + PM_DSC_MAX_K + 4) + align8((size_t)S * Hprime);
+    const size_t rows16 = sizeof(double) * 16 * (size_t)(H + Hprime + Hprime * Hprime);
+    *stage16 = 1;
+    size_t sh16 = fixed + sizeof(double) * (size_t)Kt + rows16;
+    if (sh16 > 40 * 1024) {
+        *stage16 = 0;
+        sh16 = fixed + rows16;
+    }
+    return sh16 <= 40 * 1024 ? sh16 : 0;
+#endif
+}
+
+extern "C" int pm_dsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S, int64_t K, int flags) {
+    if (H <= 0 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || S < 0 || K < 2 || K > PM_DSC_MAX_K) return 0;
+    int st = 0;
+    return dsc_rows16_lds(H, Hprime, S, (flags & PM_DSC_TABLE_ONLY) ? S : 1 + (K - 1) * H + S, &st) ? 1 : 0;
+}
+
 extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
                                      const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
                                      const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
                                      double *expect, int64_t lde, double *stats, void *stream) {
+    return pm_dsc_mstep_rows_nz_f64(logpj, ldl, lse, lse_cut, cand, state_idx, S, prior, params_host, N, H, D, Hprime,
+                                    expect, lde, stats, nullptr, nullptr, stream);
+}
+
+extern "C" int pm_dsc_mstep_rows_nz_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                                        const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
+                                        const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D,
+                                        int64_t Hprime, double *expect, int64_t lde, double *stats, uint16_t *nz_idx,
+                                        double *nz_val, void *stream) {
+    if ((nz_idx == nullptr) != (nz_val == nullptr)) return PM_EINVAL;
     if (N == 0) return PM_OK;
     if (!logpj || !lse || !cand || !prior || !expect || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 ||
         lde < H || bad_params(params_host) || (S > 0 && !state_idx))
@@ -920,18 +978,11 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
         return PM_EINVAL;
     if (Hprime > PM_MAX_HPRIME || Hprime > H || H > 65536) return PM_ERANGE;
     const int64_t Kt = (params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S;
-#ifndef PM_DSC_WAVE64
-    if (H <= 256 && S * Hprime < (1 << 20) && Kt < (1 << 20)) {
+    {
         // sixteen lanes per datapoint where the layout fits four workgroups per CU
-        const size_t fixed = sizeof(double) * (H + PM_DSC_MAX_K + 4) + align8((size_t)S * Hprime);
-        const size_t rows16 = sizeof(double) * 16 * (size_t)(H + Hprime + Hprime * Hprime);
-        int stage16 = 1;
-        size_t sh16 = fixed + sizeof(double) * (size_t)Kt + rows16;
-        if (sh16 > 40 * 1024) {
-            stage16 = 0;
-            sh16 = fixed + rows16;
-        }
-        if (sh16 <= 40 * 1024) {
+        int stage16 = 0;
+        const size_t sh16 = dsc_rows16_lds(H, Hprime, S, Kt, &stage16);
+        if (sh16) {
             const int64_t blocks16 = (N + 15) / 16;
             const unsigned grid16 = (unsigned)(blocks16 < 256 * 4 ? blocks16 : 256 * 4);
 #define PM_LAUNCH16(M, V)                                                                                              \
@@ -939,7 +990,7 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
         if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows16_kernel<M, V>), sh16)) return e;      \
         hipLaunchKernelGGL((dsc_mstep_rows16_kernel<M, V>), dim3(grid16), dim3(256), sh16,                             \
                            static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior, \
-                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, stage16);                 \
+                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, stage16, nz_idx, nz_val); \
     } while (0)
             if (Hprime <= 8 && H <= 128) PM_LAUNCH16(8, 8);
             else if (Hprime <= 8) PM_LAUNCH16(8, 16);
@@ -949,7 +1000,7 @@ extern "C" int pm_dsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
             return (int)hipGetLastError();
         }
     }
-#endif
+    if (nz_idx) return PM_ERANGE;       // (lists come from the sixteen-lane kernel only: pm_dsc_rows16_supported)
     size_t shmem = sizeof(double) * (H + PM_DSC_MAX_K + 4 + WAVES * (H + Hprime + Hprime * Hprime)) +
                    align8((size_t)S * Hprime);
     if (shmem > 150 * 1024) return PM_ERANGE;

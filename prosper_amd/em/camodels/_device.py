@@ -227,6 +227,28 @@ class DeviceCAModel(CAModel):
         else:
             self.timer.launch(label, lambda: _lib.call(entry, *args))
 
+    def _rows_and_wp(self, rows_args, lp_ld, expect, Y, stats, my_N, K, flags, Hp, S):
+        """DSC / TSC M-step: the per-datapoint pass (pm_dsc_mstep_rows[_nz]_f64) and Wp = E[s]^T Y.  Where the
+        sixteen-lane kernel applies the pass also leaves the non-zero lists of E[s] and Wp is accumulated from them
+        (pm_wp_sparse_f64); the dense product follows behind the device-side gate (last scalar of `stats`: rows whose
+        list overflowed) and only does work then."""
+        H, D = self.H, self.D
+        lib = _lib.load()
+        st = self._stream()
+        sparse = (os.environ.get('PM_SPARSE_WP', '1') == '1' and Y.is_cuda and H <= 256
+                  and bool(lib.pm_dsc_rows16_supported(H, Hp, S, K, flags)))
+        if sparse:
+            nz_idx, nz_val = self._buf("nz_idx", (my_N, 16), torch.int16), self._buf("nz_val", (my_N, 16))
+            self._call("mstep_rows", "pm_dsc_mstep_rows_nz_f64", *(rows_args + (_ptr(nz_idx), _ptr(nz_val), st)))
+            gate = ctypes.c_void_p(stats.data_ptr() + 8 * (lib.pm_dsc_stats_len(H, D) - 1))
+            self._call("stats_sparse", "pm_wp_sparse_f64", _ptr(nz_idx), _ptr(nz_val), _ptr(Y), Y.stride(0), _ptr(stats),
+                       D, gate, my_N, H, D, st)
+            self._call("stats_gemm", "pm_gemm_tn_acc_gated_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D,
+                       my_N, gate, st)
+        else:
+            self._call("mstep_rows", "pm_dsc_mstep_rows_f64", *(rows_args + (st,)))
+            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, st)
+
     def _buf(self, name, shape, dtype=None):
         """Reusable device workspace (no allocation inside the EM loop once warm)."""
         dtype = dtype or torch.float64

@@ -359,11 +359,9 @@ class DSC_ET(DeviceCAModel):
         P = self._params(anneal, pi, sigma)
         prior = self._upload("dsc_prior", self._prior(pi))
         if my_N:
-            self._call("mstep_rows", "pm_dsc_mstep_rows_f64", _ptr(lp), Kt, _ptr(lse), ctypes.c_double(lse_cut),
-                       _ptr(cand), _ptr(tab), S, _ptr(prior), ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,
-                       _ptr(stats), self._stream())
-            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N,
-                       self._stream())
+            self._rows_and_wp((_ptr(lp), Kt, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S, _ptr(prior),
+                               ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats)),
+                              Kt, expect, Y, stats, my_N, self.K, int(P.flags), Hp, S)
         comm.allreduce_device(stats)      # replaces dsc_et.py:648,738,739,747,769 and the allreduce in get_likelihood
         self._mstep_res = res
         return self._finalize(stats, model_params)

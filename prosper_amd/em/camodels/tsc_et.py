@@ -320,11 +320,9 @@ class TSC_ET(DeviceCAModel):
         P = self._params(anneal, sigma)
         prior = self._upload("tsc_prior", self._prior(pi))
         if my_N:
-            self._call("mstep_rows", "pm_dsc_mstep_rows_f64", _ptr(lp), S, _ptr(lse), ctypes.c_double(lse_cut),
-                       _ptr(cand), _ptr(tab), S, _ptr(prior), ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,
-                       _ptr(stats), self._stream())
-            self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N,
-                       self._stream())
+            self._rows_and_wp((_ptr(lp), S, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S, _ptr(prior),
+                               ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats)),
+                              S, expect, Y, stats, my_N, int(P.K), int(P.flags), Hp, S)
         comm.allreduce_device(stats)      # replaces tsc_et.py:412,446,453,486,487,497,527
         self._mstep_res = res
         return self._finalize(stats, model_params, A_pi_gamma, E_pi_gamma)

@@ -420,8 +420,8 @@ def test_shipped_hot_kernels_do_not_spill(tmp_path):
     assert len(seen) >= 25, sorted(seen)
     # (bsc_mstep_rows16_kernel -- the M-step's own pass after a data-truncation step -- was deliberately capped at 128
     # registers for four wavefronts per SIMD at the price of 12 spilled registers: 0.48 -> 0.42 ms)
-    # (dsc_mstep_rows16_kernel<8, 8> likewise: 28 spilled registers at four wavefronts per SIMD, 0.170 vs 0.200 ms at three)
-    limit = lambda n: 16 if "bsc_mstep_rows16_kernel" in n else 32 if "dsc_mstep_rows16_kernelILi8ELi8E" in n else 4
+    # (dsc_mstep_rows16_kernel<8, 8> likewise: 34 spilled registers at four wavefronts per SIMD, 0.19 vs 0.215 ms at three)
+    limit = lambda n: 16 if "bsc_mstep_rows16_kernel" in n else 40 if "dsc_mstep_rows16_kernelILi8ELi8E" in n else 4
     bad = {n: md for n, md in seen.items() if md.get(".vgpr_spill_count", 0) > limit(n)}
     assert not bad, bad
     # <STAGES, H', gamma, FULL, MSTATS, TAIL = false, W16 = true>: <= 128 registers (4 wavefronts per SIMD)

@@ -203,3 +203,58 @@ def test_em_loop_speculation_is_transparent(model):
         runs.append(p)
     for k in ("W", "pi", "sigma"):
         np.testing.assert_allclose(runs[0][k], runs[1][k], rtol=1e-8, atol=1e-11, err_msg=k)
+
+
+@pytest.mark.parametrize("model,T", [("dsc", 1.0), ("tsc", 1.0), ("dsc", 60.0)])
+def test_sparse_wp_from_nonzero_lists(model, T, monkeypatch):
+    """DSC / TSC M-step: the per-datapoint pass leaves the non-zeros of every E[s] row as a list as well and
+    Wp = E[s]^T Y (dsc_et.py:703-735) is accumulated from the lists (pm_wp_sparse_f64); rows with more than 16 non-zeros
+    (hot temperature) are counted and the dense product runs instead, decided on the device.  Same statistics and
+    parameters as the dense product; the lists hold exactly the non-zeros of the dense rows."""
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    from prosper_amd.em.camodels.tsc_et import TSC_ET
+    D, H, Hp, gamma, N = 96, 128, 6, 3, 5000
+    rng = np.random.RandomState(11)
+    W_gt = 2.0 * rng.normal(size=(D, H))
+    u = rng.random_sample((N, H))
+    y = ((u < 1.5 / H).astype(float) - (u > 1 - 1.5 / H)) @ W_gt.T + rng.normal(size=(N, D))
+    W0 = W_gt + 0.1 * rng.normal(size=(D, H))
+    out = {}
+    for sparse in ("1", "0"):
+        monkeypatch.setenv("PM_SPARSE_WP", sparse)
+        if model == "dsc":
+            m = DSC_ET(D, H, Hp, gamma, states=np.array([-1., 0., 1.]))
+            p = {"W": W0, "pi": np.array([1.5 / H, 1 - 3.0 / H, 1.5 / H]), "sigma": 1.0}
+        else:
+            m = TSC_ET(D, H, Hp, gamma)
+            p = {"W": W0, "pi": 3.0 / H, "sigma": 1.0}
+        names = []
+        orig = m._call
+        m._call = lambda label, name, *a, _o=orig, _n=names: (_n.append(name), _o(label, name, *a))[1]
+        new = m.step(_An(T=T), dict(p), {"y": y})
+        st = m._ws["dsc_stats" if model == "dsc" else "tsc_stats"].cpu().numpy().copy()
+        out[sparse] = (new, st, m._ws["expect"].cpu().numpy().copy(), names)
+        if sparse == "1":
+            idx = m._ws["nz_idx"].cpu().numpy().view(np.uint16).astype(np.int64)
+            val = m._ws["nz_val"].cpu().numpy()
+    a, b = out["1"], out["0"]
+    assert "pm_wp_sparse_f64" in a[3] and "pm_gemm_tn_acc_gated_f64" in a[3] and "pm_wp_sparse_f64" not in b[3]
+    E = a[2]
+    nnz = (E != 0).sum(axis=1)
+    assert int(a[1][-1]) == int((nnz > 16).sum())
+    assert (int(a[1][-1]) > 0) == (T > 10)
+    ok = nnz <= 16
+    assert np.array_equal((idx != 0xFFFF).sum(axis=1)[ok], nnz[ok])
+    rebuilt = np.zeros_like(E)
+    rows = np.repeat(np.arange(N), 16).reshape(N, 16)
+    sel = (idx != 0xFFFF) & ok[:, None]
+    rebuilt[rows[sel], idx[sel]] = val[sel]
+    assert np.array_equal(rebuilt[ok], E[ok])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-300)
+    sa, sb = a[1].copy(), b[1].copy()
+    sa[-1] = sb[-1] = 0.0
+    np.testing.assert_allclose(sa, sb, rtol=1e-9, atol=1e-11 * np.abs(sb).max())
+    Wp_ref = E.T @ y
+    np.testing.assert_allclose(a[1][:H * D].reshape(H, D), Wp_ref, rtol=1e-10, atol=1e-11 * np.abs(Wp_ref).max())
+    np.testing.assert_allclose(a[0]["W"], b[0]["W"], rtol=1e-8, atol=1e-10)
