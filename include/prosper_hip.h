@@ -297,6 +297,13 @@ int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse,
                             const int32_t *cand, const uint16_t *state_masks, int64_t S,
                             const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D,
                             int64_t Hprime, double *expect, int64_t lde, double *stats, void *stream);
+/* ... that also leaves the non-zeros of every E[s] row as a list (format of pm_bsc_estep_fused8_nz_f64; rows with more
+ * than PM_BSC_NZ_MAX non-zeros count in scalars[3]).  The M-step after a data-truncation step. */
+int pm_bsc_mstep_rows16_nz_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                               const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                               const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D,
+                               int64_t Hprime, double *expect, int64_t lde, double *stats, uint16_t *nz_idx,
+                               double *nz_val, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Maximal Causes Analysis (prosper/em/camodels/mca_et.py)

@@ -82,6 +82,9 @@ SIGNATURES = {
     "pm_gemm_tn_acc_gated_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp, c_dp]),
     "pm_bsc_mstep_rows16_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64,
                                           C.POINTER(EStepParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
+    "pm_bsc_mstep_rows16_nz_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64,
+                                             C.POINTER(EStepParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp, c_dp,
+                                             c_dp]),
     "pm_mca_select_scores_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
     "pm_mca_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, i64,
                                    C.POINTER(McaParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp, c_dp]),

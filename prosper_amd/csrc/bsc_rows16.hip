@@ -76,11 +76,12 @@ __global__ __launch_bounds__(256, ESTEP ? (VPL <= 4 ? 4 : VPL <= 8 ? 3 : VPL <= 
 // ---------------------------------------------------------------------------------------------
 // M_step, per-datapoint part
 // ---------------------------------------------------------------------------------------------
-template <int VPL>
-__global__ __launch_bounds__(256, VPL <= 16 ? 4 : 1) void bsc_mstep_rows16_kernel(
+template <int VPL, bool NZ>      // NZ: list mode (nz_idx / nz_val given): E[s] rows merged through LDS, non-zeros listed
+__global__ __launch_bounds__(256, VPL <= 16 ? (NZ && VPL == 16 ? 3 : 4) : 1) void bsc_mstep_rows16_kernel(
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint16_t *__restrict__ masks, int S, pm_bsc_estep_params P, int64_t N,
-    int H, int D, int Hp, double *__restrict__ expect, int64_t lde, double *__restrict__ stats) {
+    int H, int D, int Hp, double *__restrict__ expect, int64_t lde, double *__restrict__ stats,
+    uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [ qdiag (H) | mus (H) | per datapoint: m2 (Hp*Hp) | red (3*4) | masks (S) ]
     double *s_qdiag = reinterpret_cast<double *>(smem);
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 1) void bsc_mstep_rows16_kerne
     double *s_m2all = s_mus + H;
     double *s_red = s_m2all + ROWS * Hp * Hp;
     uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_red + 12);
+    double *s_rows = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(s_masks) + (((size_t)S * 2 + 7) & ~size_t(7)));   // list mode only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int j = lane & 15, row = lane >> 4;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 1) void bsc_mstep_rows16_kerne
     double qd[VPL];  // column sums of q1 over this lane's datapoints (mus = these + the candidate terms)
 #pragma unroll
     for (int i = 0; i < VPL; ++i) qd[i] = 0.0;
-    double sig = 0.0, fs = 0.0, cnt = 0.0;
+    double sig = 0.0, fs = 0.0, cnt = 0.0, overflow = 0.0;
 
     const int64_t groups = (N + ROWS - 1) / ROWS;
     for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
@@ -193,15 +195,53 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 1) void bsc_mstep_rows16_kerne
         // lanes that own them once those stores have completed (8 f64 atomics per datapoint instead of a
         // 16 x VPL select chain into the register row)
         const double m1c = (j < Hp) ? s_m2[j * Hp + j] : 0.0;
+        if (NZ) {
+            // list mode: the candidates' multi-cause terms are merged into the row through LDS (one row of H doubles per
+            // datapoint slot, behind the masks), so that the row is stored complete and its non-zeros can be listed
+            double *srow = s_rows + (size_t)(wave * 4 + row) * H;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (j + 16 * i < H) srow[j + 16 * i] = es[i];
+            wave_lds_sync16();
+            if (keep && j < Hp && m1c != 0.0) srow[myc] += m1c;       // (candidates are distinct latents)
+            wave_lds_sync16();
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) es[i] = (j + 16 * i < H) ? srow[j + 16 * i] : 0.0;
+        }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
             if (live && h < H) erow[h] = es[i];
         }
+        if (NZ) {
+            // the row's non-zeros as a list for pm_bsc_wp_sparse_f64 (format of pm_bsc_estep_fused8_nz_f64)
+            uint16_t *nzi = nz_idx + nn * PM_BSC_NZ_MAX;
+            double *nzv = nz_val + nn * PM_BSC_NZ_MAX;
+            const int rb = lane & 48;
+            uint32_t nzn = 0;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const double v = es[i];
+                const int h = j + 16 * i;
+                const uint32_t mine = (uint32_t)((__ballot(v != 0.0) >> rb) & 0xFFFFull);
+                const uint32_t pos = nzn + __builtin_popcount(mine & ((1u << j) - 1u));
+                if (v != 0.0 && pos < PM_BSC_NZ_MAX && live) {
+                    nzi[pos] = (uint16_t)h;
+                    nzv[pos] = v;
+                }
+                nzn += __builtin_popcount(mine);
+            }
+            if (live) {
+                if ((uint32_t)j >= nzn) nzi[j] = 0xFFFFu;               // (16 lanes = PM_BSC_NZ_MAX slots)
+                if (j == 0 && nzn > PM_BSC_NZ_MAX) overflow += 1.0;
+            }
+        }
         wave_lds_sync16();
         for (int p = j; p < Hp * Hp; p += 16) s_m2[p] = 0.0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (keep && j < Hp && m1c != 0.0) pm_atomic_add(erow + myc, m1c);
+        if (!NZ) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (keep && j < Hp && m1c != 0.0) pm_atomic_add(erow + myc, m1c);
+        }
         wave_lds_sync16();
     }
 
@@ -217,6 +257,8 @@ __global__ __launch_bounds__(256, VPL <= 16 ? 4 : 1) void bsc_mstep_rows16_kerne
     sig = pm_wave_sum(sig);
     fs = pm_wave_sum(fs);
     cnt = pm_wave_sum(cnt);
+    overflow = pm_wave_sum(overflow);
+    if (lane == 0 && overflow != 0.0) pm_atomic_add(stats + pm_bsc_stats_offset_scalars_dev(H, D) + 3, overflow);
     if (lane == 0) {
         s_red[wave * 3 + 0] = sig;
         s_red[wave * 3 + 1] = fs;
@@ -309,19 +351,39 @@ extern "C" int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const d
                                        const int32_t *cand, const uint16_t *state_masks, int64_t S,
                                        const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D,
                                        int64_t Hprime, double *expect, int64_t lde, double *stats, void *stream) {
+    return pm_bsc_mstep_rows16_nz_f64(logpj, ldl, lse, lse_cut, cand, state_masks, S, params_host, N, H, D, Hprime, expect,
+                                      lde, stats, nullptr, nullptr, stream);
+}
+
+extern "C" int pm_bsc_mstep_rows16_nz_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                                          const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                                          const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D,
+                                          int64_t Hprime, double *expect, int64_t lde, double *stats, uint16_t *nz_idx,
+                                          double *nz_val, void *stream) {
+    if ((nz_idx == nullptr) != (nz_val == nullptr)) return PM_EINVAL;
     if (!logpj || !lse || !cand || !params_host || !expect || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 ||
         S < 0 || ldl < 1 + H + S || lde < H || (S > 0 && !state_masks))
         return PM_EINVAL;
     if (!pm_bsc_rows16_supported(H, Hprime, S)) return PM_ERANGE;
     if (N == 0) return PM_OK;
-    const size_t shmem = sizeof(double) * (2 * H + ROWS * Hprime * Hprime + 12) + sizeof(uint16_t) * S;
+    size_t shmem = sizeof(double) * (2 * H + ROWS * Hprime * Hprime + 12) + sizeof(uint16_t) * S;
+    if (nz_idx) shmem = ((shmem + 7) & ~size_t(7)) + sizeof(double) * ROWS * (size_t)H;     // + one row per datapoint slot
+    if (shmem > 64 * 1024) return PM_ERANGE;
     dim3 grid((unsigned)grid_groups(N)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PM_LAUNCH(V)                                                                                               \
     do {                                                                                                           \
-        if (int e = allow_lds16(reinterpret_cast<const void *>(bsc_mstep_rows16_kernel<V>), shmem)) return e;      \
-        hipLaunchKernelGGL(bsc_mstep_rows16_kernel<V>, grid, block, shmem, s, logpj, ldl, lse, lse_cut, cand,      \
-                           state_masks, (int)S, *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats); \
+        if (nz_idx) {                                                                                              \
+            if (int e = allow_lds16(reinterpret_cast<const void *>(bsc_mstep_rows16_kernel<V, true>), shmem)) return e; \
+            hipLaunchKernelGGL((bsc_mstep_rows16_kernel<V, true>), grid, block, shmem, s, logpj, ldl, lse, lse_cut, cand, \
+                               state_masks, (int)S, *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, \
+                               nz_idx, nz_val);                                                                    \
+        } else {                                                                                                   \
+            if (int e = allow_lds16(reinterpret_cast<const void *>(bsc_mstep_rows16_kernel<V, false>), shmem)) return e; \
+            hipLaunchKernelGGL((bsc_mstep_rows16_kernel<V, false>), grid, block, shmem, s, logpj, ldl, lse, lse_cut, cand, \
+                               state_masks, (int)S, *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, \
+                               nz_idx, nz_val);                                                                    \
+        }                                                                                                          \
     } while (0)
     if (H <= 16) PM_LAUNCH(1);
     else if (H <= 32) PM_LAUNCH(2);

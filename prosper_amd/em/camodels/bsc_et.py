@@ -669,6 +669,14 @@ class BSC_ET(DeviceCAModel):
                 self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", off(lp, ldl), ldl, off(lse), ctypes.c_double(lse_cut),
                            off(cand, Hp), _ptr(tab["masks"]), S, ctypes.byref(P), r, H, D, Hp, off(expect, H), H,
                            _ptr(stats), st)
+        elif my_N and tab["fast"] and self.sparse_wp and H <= 256 and expect.is_cuda:
+            # (the M-step's own pass -- after a data-truncation step, or on log-joints from outside: lists as well)
+            nzb = (self._buf("nz_idx", (my_N, 16), torch.int16), self._buf("nz_val", (my_N, 16)))
+            self._call("mstep_rows", "pm_bsc_mstep_rows16_nz_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut),
+                       _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,
+                       _ptr(stats), _ptr(nzb[0]), _ptr(nzb[1]), st)
+            done = my_N
+            nz = {"idx": nzb[0], "val": nzb[1], "stats": stats, "rows": my_N}
         elif my_N and tab["fast"]:
             self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut),
                        _ptr(cand), _ptr(tab["masks"]), S, ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H,

@@ -586,6 +586,7 @@ def test_step_with_fused_mstep_statistics(dev, D, H, Hp, gamma, N):
 
     def assembled(st):
         st = st.copy()
+        st[lib.pm_bsc_stats_offset_scalars(H, D) + 3] = 0.0     # (count of overflowing non-zero lists: only where lists are made)
         Wq = st[o_wq:o_qd].reshape(H, H)
         st[o_qd:o_mus] += np.diagonal(Wq)
         Wq[np.arange(H), np.arange(H)] = 0.0
@@ -654,6 +655,54 @@ def test_sparse_wp_from_nonzero_lists(dev, N, T, overflow, D, H, gamma):
     np.testing.assert_allclose(sa, sb, rtol=1e-9, atol=1e-11 * np.abs(sb).max())
     Wp_ref = E.T @ y
     np.testing.assert_allclose(a[1][:H * D].reshape(H, D), Wp_ref, rtol=1e-10, atol=1e-11 * np.abs(Wp_ref).max())
+    for k in ("W", "pi", "sigma"):
+        np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("D,H,Hp,gamma,N,T", [(128, 256, 8, 4, 20000, 1.0), (512, 256, 8, 4, 6000, 1.0), (64, 100, 6, 3, 3000, 1.0),
+                                              (64, 100, 6, 3, 3000, 50.0)])
+def test_sparse_wp_after_data_truncation(dev, D, H, Hp, gamma, N, T):
+    """With data truncation ahead the statistics need the global cut first, so the M-step runs its own per-datapoint pass
+    (pm_bsc_mstep_rows16_nz_f64): it leaves the non-zeros of E[s] as lists too and Wp comes from them.  Same statistics
+    and parameters as the dense product; the lists hold exactly the non-zeros of the dense rows."""
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    rng = np.random.RandomState(N + H)
+    W_gt = rng.normal(size=(D, H))
+    y = (rng.random_sample((N, H)) < 3.0 / H) @ W_gt.T + rng.normal(size=(N, D))
+    params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 3.0 / H, "sigma": 1.05}
+    out = {}
+    for sparse in (True, False):
+        m = BSC_ET(D, H, Hp, gamma)
+        m.sparse_wp = sparse
+        names = []
+        orig = m._call
+        m._call = lambda label, name, *a, _o=orig, _n=names: (_n.append(name), _o(label, name, *a))[1]
+        new = m.step(_An(T=T, Ncut_factor=0.6), dict(params), {"y": y})
+        out[sparse] = (new, m._ws["stats"].cpu().numpy().copy(), m._ws["expect"].cpu().numpy().copy(), names)
+        if sparse:
+            idx = m._ws["nz_idx"].cpu().numpy().view(np.uint16).astype(np.int64)
+            val = m._ws["nz_val"].cpu().numpy()
+    a, b = out[True], out[False]
+    assert "pm_bsc_mstep_rows16_nz_f64" in a[3] and "pm_bsc_wp_sparse_f64" in a[3] and "pm_bsc_wp_sparse_f64" not in b[3]
+    o_sc = _lib.load().pm_bsc_stats_offset_scalars(H, D)
+    E = a[2]
+    assert (E == 0).all(axis=1).sum() > N // 10                 # the cut datapoints: empty rows, empty lists
+    nnz = (E != 0).sum(axis=1)
+    n_over = int(a[1][o_sc + 3])
+    assert n_over == int((nnz > 16).sum())                      # (some rows do overflow at these small D, all at T = 50)
+    assert T < 10 or n_over > N // 4
+    ok = nnz <= 16
+    assert np.array_equal((idx != 0xFFFF).sum(axis=1)[ok], nnz[ok])
+    rebuilt = np.zeros_like(E)
+    rows = np.repeat(np.arange(N), 16).reshape(N, 16)
+    sel = (idx != 0xFFFF) & ok[:, None]
+    rebuilt[rows[sel], idx[sel]] = val[sel]
+    assert np.array_equal(rebuilt[ok], E[ok])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-300)
+    sa, sb = a[1].copy(), b[1].copy()
+    sa[o_sc + 3] = sb[o_sc + 3] = 0.0
+    np.testing.assert_allclose(sa, sb, rtol=1e-9, atol=1e-11 * np.abs(sb).max())
     for k in ("W", "pi", "sigma"):
         np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-8, atol=1e-10)
 
