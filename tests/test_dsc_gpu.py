@@ -258,3 +258,63 @@ def test_sparse_wp_from_nonzero_lists(model, T, monkeypatch):
     Wp_ref = E.T @ y
     np.testing.assert_allclose(a[1][:H * D].reshape(H, D), Wp_ref, rtol=1e-10, atol=1e-11 * np.abs(Wp_ref).max())
     np.testing.assert_allclose(a[0]["W"], b[0]["W"], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("model", ["dsc", "tsc"])
+def test_full_shard_against_oracle_rows(model):
+    """DSC / TSC at the bench's dimensions (D=256, H=128, H'=6, gamma=3) on a shard large enough that every workgroup of
+    the sixteen-lane row kernels walks several groups of datapoints (N = 70000 > 16 x the resident grid): candidates,
+    log-joints and E[s] rows of 400 sampled datapoints against the oracle on those rows alone, and the M-step's
+    statistics against the dense product of the device's own E[s]."""
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    from prosper_amd.em.camodels.tsc_et import TSC_ET
+    D, H, Hp, gamma, N = 256, 128, 6, 3, 70000
+    rng = np.random.RandomState(5)
+    W_gt = 2.0 * rng.normal(size=(D, H))
+    u = rng.random_sample((N, H))
+    y = ((u < 1.0 / H).astype(float) - (u > 1 - 1.0 / H)) @ W_gt.T + rng.normal(size=(N, D))
+    W0 = W_gt + 0.1 * rng.normal(size=(D, H))
+    states = np.array([-1., 0., 1.])
+    if model == "dsc":
+        from oracle import dsc_oracle as M
+        m = DSC_ET(D, H, Hp, gamma, states=states)
+        pi = np.array([1.0 / H, 1 - 2.0 / H, 1.0 / H])
+        om = M.make_model(D, H, Hp, gamma, states)
+    else:
+        from oracle import tsc_oracle as M
+        m = TSC_ET(D, H, Hp, gamma)
+        pi = 2.0 / H
+        om = M.make_model(D, H, Hp, gamma)
+    params = {"W": W0, "pi": pi, "sigma": 1.0}
+    an = _An(T=1.0)
+    data = m.select_Hprimes(params, {"y": y})
+    ss = m.E_step(an, params, data)
+    idx = np.sort(rng.choice(N, 400, replace=False))
+    idx[-1] = N - 1                                             # the last datapoint of the last (ragged) group too
+    cand = np.asarray(data["candidates"][idx])
+    oan = M.Anneal(T=1.0, Ncut_factor=0.0, anneal_prior=False)
+    ref_cand = M.select_hprimes_vec(om, W0, pi, 1.0, y[idx])
+    if model == "dsc":
+        _check_candidates(cand, ref_cand, M.select_scores_vec(om, W0, pi, 1.0, y[idx]))
+    else:
+        best = M.select_scores_vec(om, W0, y[idx])
+        for r in range(len(idx)):       # (TSC candidates may repeat a latent; equal scores may swap)
+            np.testing.assert_allclose(np.sort(best[r, cand[r]]), np.sort(best[r, ref_cand[r]]), rtol=1e-9)
+    logpj = M.e_step_vec(oan, om, W0, pi, 1.0, y[idx], cand)
+    got = np.asarray(ss["logpj"][idx])
+    np.testing.assert_allclose(got, logpj, rtol=1e-10, atol=1e-9)
+    new = m.M_step(an, params, ss, data)
+    E = m._ws["expect"].cpu().numpy()
+    q = np.exp(logpj - np.logaddexp.reduce(logpj, axis=1, keepdims=True))
+    stats = m._ws["dsc_stats" if model == "dsc" else "tsc_stats"].cpu().numpy()
+    Wp_ref = E.T @ y
+    np.testing.assert_allclose(stats[:H * D].reshape(H, D), Wp_ref, rtol=1e-10, atol=1e-11 * np.abs(Wp_ref).max())
+    assert np.isfinite(new["W"]).all() and E.shape == (N, H) and q.shape[0] == 400
+    # E[s] rows of the sampled datapoints: the same kernels on those rows alone (one group per workgroup; that case is
+    # held to the oracle by test_*_step_matches_oracle)
+    m2 = type(m)(D, H, Hp, gamma, states=states) if model == "dsc" else type(m)(D, H, Hp, gamma)
+    d2 = {"y": y[idx], "candidates": cand}
+    ss2 = m2.E_step(an, params, d2)
+    np.testing.assert_allclose(np.asarray(ss2["logpj"]), got, rtol=1e-12, atol=1e-12)
+    m2.M_step(an, params, ss2, d2)
+    np.testing.assert_allclose(E[idx], m2._ws["expect"].cpu().numpy(), rtol=1e-10, atol=1e-14)
