@@ -7,7 +7,8 @@
 // (pm_bsc_estep_fused8_nz_f64) the product is N nnz D multiply-adds -- nothing -- and one read of the data: the kernel
 // is bound by streaming Y once (N D 8 bytes; 1.64 GB on config 2 = 0.2 ms at the HBM peak, 0.27 ms at the 6 TB/s a
 // plain reduction over Y reaches on this chip; measured 0.40 ms = 4.1 TB/s -- each workgroup reads 512-byte pieces of
-// 8 KB rows; with empty lists the same loop streams at 4.8 TB/s, scratch/sparse_bench.py).
+// 8 KB rows; with empty lists the same loop streams at 4.8 TB/s, scratch/sparse_bench.py; reading a chunk-major copy of
+// Y instead -- one contiguous stream per workgroup -- changes nothing, 0.393 vs 0.392 ms: the access pattern is not it).
 //
 // Layout: a workgroup owns a 64-column chunk of Wp for a group of datapoints and keeps its (H x 64) accumulator in LDS
 // (128 KB at H = 256: one 16-wavefront workgroup per CU).  A wavefront takes one datapoint at a time: lane c holds
