@@ -427,3 +427,28 @@ def test_shipped_hot_kernels_do_not_spill(tmp_path):
     # <STAGES, H', gamma, FULL, MSTATS, TAIL = false, W16 = true>: <= 128 registers (4 wavefronts per SIMD)
     main = {n: md for n, md in seen.items() if "bsc_estep_fused8s_kernel" in n and n.split("EEEv")[0].endswith("Lb0ELb1")}
     assert main and all(md[".vgpr_count"] <= 128 for md in main.values()), main
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The newest committed bench line (profiles/r03_*_bench.json, written by `python bench.py` on the GPU box) carries
+    every key of the driver's contract, the roofline and cpu_baseline objects, and figures that are consistent with each
+    other (value = datapoints / time; frac = achieved / peak)."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_v*_bench.json")))
+    assert files
+    d = json.load(open(files[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    n = d["config"]["global_datapoints"]
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    flops = 2.0 * r["datapoints_per_launch"] * 1024 * 256
+    assert abs(r["achieved"] - flops / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] > 0.9 * 2.2e9
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
