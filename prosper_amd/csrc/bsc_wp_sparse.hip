@@ -65,51 +65,82 @@ __global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint
     // (no predication in the loop: columns past D and datapoints past the group are clamped to valid addresses -- the
     // former are never flushed, the latter get an empty list)
     const uint32_t col = chunk * SP_DC + lane < D ? chunk * SP_DC + lane : D - 1;
-    const uint32_t slot = lane & (PM_BSC_NZ_MAX - 1);
     const int lo = (int)(grp * rows_per_group);                // (N < 2^31: checked by the caller)
     const int hi = lo + rows_per_group < N ? (int)(lo + rows_per_group) : (int)N;
     double *arow = acc + lane;
+    // A wavefront takes EIGHT CONSECUTIVE datapoints per batch: their lists are 128 contiguous uint16 / doubles, so the
+    // whole batch's lists are FOUR coalesced loads (lane l: slot l & 15 of datapoint l >> 4, and of datapoint 4 + (l >> 4))
+    // instead of sixteen -- with a load per datapoint and array the list traffic cost a third of the data stream
+    // (0.34 ms with empty lists against 0.24 ms for the loads of Y alone).  (Packing them further -- index pairs in a
+    // dword, value pairs in 16 bytes: two loads -- made the per-non-zero extraction scalar-heavy and the loop
+    // issue-bound: 0.46 ms.)
+    static_assert(SP_UNROLL == 8 && PM_BSC_NZ_MAX == 16, "64 lanes = the lists of four datapoints");
     struct Batch {
-        double y[SP_UNROLL], v[SP_UNROLL];
-        int ix[SP_UNROLL];
-        bool ok[SP_UNROLL];
+        double y[SP_UNROLL];
+        double v[2];
+        int ix[2];
+        int n0;
     };
-    auto load = [&](int n0, Batch &b) {
+    // (batches that lie wholly inside the group -- all but possibly the group's last one, which is walked one list at a
+    // time behind the loop: no predication and no second kind of load inside the pipelined loop)
+    auto load = [&](int n0, Batch &b) {                        // n0: wavefront-uniform first datapoint of the batch
+        const bool in = n0 + SP_UNROLL <= hi;
+        const int nb = in ? n0 : lo;                           // (past the end: any valid batch, its lists are not used)
+        b.n0 = in ? n0 : -1;
 #pragma unroll
         for (int u = 0; u < SP_UNROLL; ++u) {
-            int n = n0 + u * SP_WAVES;                         // wavefront-uniform: scalar base + 32-bit lane offset
-            b.ok[u] = n < hi;
-            n = b.ok[u] ? n : hi - 1;
 #ifdef PM_SP_NO_NT
-            b.y[u] = (Y + (int64_t)n * ldy)[col];
+            b.y[u] = (Y + (int64_t)(nb + u) * ldy)[col];
 #else
-            b.y[u] = __builtin_nontemporal_load((Y + (int64_t)n * ldy) + col);   // read once: leave L2 to the lists
+            b.y[u] = __builtin_nontemporal_load((Y + (int64_t)(nb + u) * ldy) + col);   // read once: leave L2 to the lists
 #endif
-            b.ix[u] = (nz_idx + (int64_t)n * PM_BSC_NZ_MAX)[slot];
-            b.v[u] = (nz_val + (int64_t)n * PM_BSC_NZ_MAX)[slot];
         }
+        const uint16_t *pi = nz_idx + (int64_t)nb * PM_BSC_NZ_MAX;
+        const double *pv = nz_val + (int64_t)nb * PM_BSC_NZ_MAX;
+        b.ix[0] = pi[lane];
+        b.ix[1] = pi[64 + lane];
+        b.v[0] = pv[lane];
+        b.v[1] = pv[64 + lane];
     };
     auto accumulate = [&](const Batch &b) {
+        if (b.n0 < 0) return;                                   // uniform
+        const uint64_t valid[2] = {__ballot(b.ix[0] != 0xFFFF), __ballot(b.ix[1] != 0xFFFF)};
 #pragma unroll
         for (int u = 0; u < SP_UNROLL; ++u) {
-            // (the valid slots are the leading ones; lanes 16.. repeat lanes 0..15)
-            const int cnt = b.ok[u] ? __popc((uint32_t)__ballot(b.ix[u] != 0xFFFF) & 0xFFFFu) : 0;
+            // the valid slots of a list are the leading ones
+            const int cnt = __popc((uint32_t)(valid[u >> 2] >> (16 * (u & 3))) & 0xFFFFu);
             for (int t = 0; t < cnt; ++t) {
-                const int h = __builtin_amdgcn_readlane(b.ix[u], t);
-                const double w = readlane_f64(b.v[u], t);
-                atomicAdd(arow + h * SP_DC, w * b.y[u]);
+                const int src = 16 * (u & 3) + t;
+                const int h = __builtin_amdgcn_readlane(b.ix[u >> 2], src);
+                atomicAdd(arow + h * SP_DC, readlane_f64(b.v[u >> 2], src) * b.y[u]);
             }
         }
     };
-    // two batches in flight: the loads of one are issued before the other is accumulated
+    // three batches in flight: two are loading while one is accumulated
     constexpr int STEP = SP_WAVES * SP_UNROLL;
-    Batch b0, b1;
-    load(lo + wave, b0);
-    for (int n0 = lo + wave; n0 < hi; n0 += 2 * STEP) {
-        load(n0 + STEP, b1);
-        accumulate(b0);
-        load(n0 + 2 * STEP, b0);
-        accumulate(b1);
+    if (hi - lo >= SP_UNROLL) {
+        Batch b0, b1, b2;
+        load(lo + SP_UNROLL * wave, b0);
+        load(lo + SP_UNROLL * wave + STEP, b1);
+        for (int n0 = lo + SP_UNROLL * wave; n0 + SP_UNROLL <= hi; n0 += 3 * STEP) {
+            load(n0 + 2 * STEP, b2);
+            accumulate(b0);
+            load(n0 + 3 * STEP, b0);
+            accumulate(b1);
+            load(n0 + 4 * STEP, b1);
+            accumulate(b2);
+        }
+    }
+    // the group's ragged end (fewer than eight datapoints: the shard's last rows), one list at a time, by wavefront 0
+    if (wave == 0) {
+        for (int n = lo + (hi - lo) / SP_UNROLL * SP_UNROLL; n < hi; ++n) {
+            const double yv = (Y + (int64_t)n * ldy)[col];
+            const int ixs = lane < PM_BSC_NZ_MAX ? (int)nz_idx[(int64_t)n * PM_BSC_NZ_MAX + lane] : 0xFFFF;
+            const double vs = lane < PM_BSC_NZ_MAX ? nz_val[(int64_t)n * PM_BSC_NZ_MAX + lane] : 0.0;
+            const int cnt = __popc((uint32_t)__ballot(ixs != 0xFFFF) & 0xFFFFu);
+            for (int t = 0; t < cnt; ++t)
+                atomicAdd(arow + __builtin_amdgcn_readlane(ixs, t) * SP_DC, readlane_f64(vs, t) * yv);
+        }
     }
     __syncthreads();
     for (int i = tid; i < H * SP_DC; i += SP_WAVES * 64) {
