@@ -6,15 +6,17 @@
 // (max 8; scratch/nnz_hist.py), so 98.5 % of those flops multiply zeros.  With the lists the E-step pass leaves
 // (pm_bsc_estep_fused8_nz_f64) the product is N nnz D multiply-adds -- nothing -- and one read of the data: the kernel
 // is bound by streaming Y once (N D 8 bytes; 1.64 GB on config 2 = 0.2 ms at the HBM peak, 0.27 ms at the 6 TB/s a
-// plain reduction over Y reaches on this chip; measured 0.40 ms = 4.1 TB/s -- each workgroup reads 512-byte pieces of
-// 8 KB rows; with empty lists the same loop streams at 4.8 TB/s, scratch/sparse_bench.py; reading a chunk-major copy of
-// Y instead -- one contiguous stream per workgroup -- changes nothing, 0.393 vs 0.392 ms: the access pattern is not it).
+// plain reduction over Y reaches on this chip; measured 0.32-0.33 ms = 5.0 TB/s, with empty lists 0.27 ms = 6.1 TB/s;
+// scratch/sparse_bench.py).  The first version ran 0.40 ms: it loaded every datapoint's list with two small loads of its
+// own (see the loop).  Reading a chunk-major copy of Y -- one contiguous stream per workgroup instead of 512-byte pieces
+// of 8 KB rows -- changed nothing (0.393 vs 0.392 ms): the access pattern was not it.
 //
 // Layout: a workgroup owns a 64-column chunk of Wp for a group of datapoints and keeps its (H x 64) accumulator in LDS
-// (128 KB at H = 256: one 16-wavefront workgroup per CU).  A wavefront takes one datapoint at a time: lane c holds
-// y[n, c0 + c], lanes 0..15 hold the list; every non-zero is one ds_add_f64 of 64 lanes into the accumulator row of its
-// latent (a row is 512 contiguous bytes: all banks once).  The accumulators are flushed with f64 atomics; all
-// workgroups of a column chunk sit on one XCD, so a Wp line is only ever touched through one L2.
+// (128 KB at H = 256: one 16-wavefront workgroup per CU).  A wavefront takes eight consecutive datapoints per batch:
+// lane c holds y[n, c0 + c] of each, the lanes together hold the eight lists; every non-zero is one ds_add_f64 of 64
+// lanes into the accumulator row of its latent (a row is 512 contiguous bytes: all banks once).  The accumulators are
+// flushed with f64 atomics; all workgroups of a column chunk sit on one XCD, so a Wp line is only ever touched through
+// one L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
