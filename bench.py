@@ -55,6 +55,11 @@ def parse():
     ap.add_argument("--no-other-models", action="store_true", help="skip the GSC / MCA EM-iteration side measurements")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed E-step passes by wall time before the warm-up")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend for --gpus > 1.  nccl (= RCCL over xGMI) is the product path; gloo is a "
+                         "debugging switch that lets N ranks share whatever devices the box has (LOCAL_RANK modulo the "
+                         "device count; RCCL refuses two ranks per device) -- tests/test_nccl_gpu.py runs the multi-rank "
+                         "branch of this script end to end on the one-GPU box with it; never a SCALE measurement")
     ap.add_argument("--data", choices=("numpy", "device"), default="numpy",
                     help="numpy: SURVEY 8d's np.random.RandomState recipe (host draws, ~5 s); device: torch.Generator on the GPU")
     return ap.parse_args()
@@ -276,7 +281,7 @@ def main():
         port = os.environ.get("MASTER_PORT", "29531")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.run(cmd).returncode)
+        sys.exit(subprocess.run(cmd).returncode)         # (children start fresh: this process never touched the GPU)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -290,11 +295,17 @@ def main():
     from prosper_amd.em.camodels.bsc_et import BSC_ET, KernelTimer
     from prosper_amd.utils import parallel
 
+    shared_devices = world > 1 and args.backend == "gloo"
+    if shared_devices:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     comm = parallel.Comm()
     comm.time_collectives(True)
     # self-check of the launch (a SCALE record must be attributable): the process group has as many ranks as --gpus asks
@@ -303,7 +314,8 @@ def main():
         args.gpus, world, comm.size)
     if world > 1:
         devs = comm.allgather((rank, local_rank, torch.cuda.current_device()))
-        assert len({d[2] for d in devs}) == world and sorted(d[0] for d in devs) == list(range(world)), devs
+        assert sorted(d[0] for d in devs) == list(range(world)), devs
+        assert shared_devices or len({d[2] for d in devs}) == world, devs
 
     def barrier():
         torch.cuda.synchronize()
@@ -441,9 +453,12 @@ def main():
     # per-rank record: what every rank generated and measured (a SCALE record stays attributable)
     mine = torch.tensor([elapsed, em_elapsed, allreduce_us, float(data_seed), float(N)], dtype=torch.float64, device=dev)
     if world > 1:
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = torch.stack(allr).cpu().numpy()
+        if args.backend == "nccl":
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = torch.stack(allr).cpu().numpy()
+        else:
+            per_rank = np.stack(comm.allgather(mine.cpu().numpy()))
     else:
         per_rank = mine.cpu().numpy()[None, :]
     elapsed, em_elapsed = float(per_rank[:, 0].max()), float(per_rank[:, 1].max())   # MAX over ranks
@@ -500,7 +515,9 @@ def main():
             "dtype": "f64", "data": "synthetic" if args.data == "device" else "synthetic (np.random.RandomState recipe of SURVEY 8d: W_gt seed 0, rows of rank r seed r)",
             "config": {"workload": "BSC_ET synthetic Gaussian D=1024 H=256 H'=8 gamma=4 (K=411 states), "
                                    "N=%d datapoints per GPU, select_Hprimes+E_step per step" % N,
-                       "global_datapoints": world * N, "parallelism": "dp%d" % world},
+                       "global_datapoints": world * N, "parallelism": "dp%d" % world,
+                       "backend": ("rccl" if args.backend == "nccl" else "gloo (debug: ranks may share a device)")
+                                  if world > 1 else None},
             "em_iter_ms": em_elapsed / args.em_steps * 1e3,
             "em_iter_datapoints_per_s": world * N * args.em_steps / em_elapsed,
             "roofline": {"bound": "mfma", "kernel": kname,

@@ -202,6 +202,10 @@ int pm_bsc_mstep_rows_f64(const double *logpj, int64_t ldl, const double *lse, d
  * the per-datapoint state areas fit LDS).
  * ------------------------------------------------------------------------------------- */
 int pm_bsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S);
+/* ... and whether the list-writing form of the M-step row pass (pm_bsc_mstep_rows16_nz_f64: it keeps one more score row
+ * per datapoint slot in LDS) fits as well; when it does not, callers run pm_bsc_mstep_rows16_f64 and the dense
+ * pm_gemm_tn_acc_f64 (same statistics, bsc_et.py:334-366). */
+int pm_bsc_rows16_nz_supported(int64_t H, int64_t Hprime, int64_t S);
 
 /* select_Hprimes (bsc_et.py:98-115) and/or E_step (bsc_et.py:119-192) in one pass over the
  * scores: mode bit 0 = select (write `cand`; otherwise `cand` is an input), bit 1 = E-step

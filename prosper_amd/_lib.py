@@ -60,6 +60,7 @@ SIGNATURES = {
     "pm_bsc_mstep_rows_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64, c_dp, c_dp, i64,
                                         C.POINTER(EStepParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
     "pm_bsc_rows16_supported": (C.c_int, [i64, i64, i64]),
+    "pm_bsc_rows16_nz_supported": (C.c_int, [i64, i64, i64]),
     "pm_bsc_select_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
                                           C.POINTER(C.c_int32), i64, i64, C.POINTER(EStepParams), i64, i64, i64,
                                           C.c_int, c_dp, c_dp, i64, c_dp, c_dp]),

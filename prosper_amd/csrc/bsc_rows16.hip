@@ -299,6 +299,18 @@ extern "C" int pm_bsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S) {
     return make_layout((int)H, (int)Hprime, (int)S, 0).bytes <= 64 * 1024 ? 1 : 0;
 }
 
+// The list-writing M-step pass needs one more score row per datapoint slot (ROWS * H doubles) than the plain one.
+static size_t mstep_rows16_lds(int64_t H, int64_t Hprime, int64_t S, bool lists) {
+    size_t shmem = sizeof(double) * (2 * H + ROWS * Hprime * Hprime + 12) + sizeof(uint16_t) * S;
+    if (lists) shmem = ((shmem + 7) & ~size_t(7)) + sizeof(double) * ROWS * (size_t)H;
+    return shmem;
+}
+
+extern "C" int pm_bsc_rows16_nz_supported(int64_t H, int64_t Hprime, int64_t S) {
+    if (!pm_bsc_rows16_supported(H, Hprime, S) || H > 256) return 0;       // (list indices are uint16 slots of <= 256 latents)
+    return mstep_rows16_lds(H, Hprime, S, true) <= 64 * 1024 ? 1 : 0;
+}
+
 extern "C" int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
                                        const double *wmu, const double *ymu, const uint16_t *state_masks,
                                        const uint16_t *state_parents, const int32_t *size_offsets_host, int64_t S,
@@ -366,8 +378,8 @@ extern "C" int pm_bsc_mstep_rows16_nz_f64(const double *logpj, int64_t ldl, cons
         return PM_EINVAL;
     if (!pm_bsc_rows16_supported(H, Hprime, S)) return PM_ERANGE;
     if (N == 0) return PM_OK;
-    size_t shmem = sizeof(double) * (2 * H + ROWS * Hprime * Hprime + 12) + sizeof(uint16_t) * S;
-    if (nz_idx) shmem = ((shmem + 7) & ~size_t(7)) + sizeof(double) * ROWS * (size_t)H;     // + one row per datapoint slot
+    if (nz_idx && !pm_bsc_rows16_nz_supported(H, Hprime, S)) return PM_ERANGE;
+    const size_t shmem = mstep_rows16_lds(H, Hprime, S, nz_idx != nullptr);
     if (shmem > 64 * 1024) return PM_ERANGE;
     dim3 grid((unsigned)grid_groups(N)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -102,6 +102,8 @@ class BSC_ET(DeviceCAModel):
             if parents.size else torch.zeros(1, dtype=torch.int16, device=dev),
             "size_off": (ctypes.c_int32 * len(size_off))(*size_off),
             "fast": bool(_lib.load().pm_bsc_rows16_supported(self.H, Hp, len(mlist))) and self.use_rows16,
+            # (the list-writing M-step pass needs 16 H more doubles of LDS: H = 256, H' = 16 does not fit)
+            "fast_nz": bool(_lib.load().pm_bsc_rows16_nz_supported(self.H, Hp, len(mlist))) and self.use_rows16,
             # uint16 payloads travel as int16 tensors (same bytes)
             "masks": torch.from_numpy(np.ascontiguousarray(masks).view(np.int16).copy()).to(dev)
             if masks.size else torch.zeros(1, dtype=torch.int16, device=dev),
@@ -669,7 +671,7 @@ class BSC_ET(DeviceCAModel):
                 self._call("mstep_rows", "pm_bsc_mstep_rows16_f64", off(lp, ldl), ldl, off(lse), ctypes.c_double(lse_cut),
                            off(cand, Hp), _ptr(tab["masks"]), S, ctypes.byref(P), r, H, D, Hp, off(expect, H), H,
                            _ptr(stats), st)
-        elif my_N and tab["fast"] and self.sparse_wp and H <= 256 and expect.is_cuda:
+        elif my_N and tab["fast_nz"] and self.sparse_wp and expect.is_cuda:
             # (the M-step's own pass -- after a data-truncation step, or on log-joints from outside: lists as well)
             nzb = (self._buf("nz_idx", (my_N, 16), torch.int16), self._buf("nz_val", (my_N, 16)))
             self._call("mstep_rows", "pm_bsc_mstep_rows16_nz_f64", _ptr(lp), ldl, _ptr(lse), ctypes.c_double(lse_cut),

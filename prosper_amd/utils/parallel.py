@@ -162,9 +162,13 @@ class Comm(object):
         if not self._solo() and tensor.is_cuda and dist.get_backend(self._group) == "gloo":
             # gloo moves host memory: stage the device buffer through the host (two ranks sharing one GPU in the
             # tests -- RCCL refuses two ranks per device; production groups are nccl)
+            import time
+            t0 = time.perf_counter()
             host = tensor.detach().cpu()
             dist.all_reduce(host, group=self._group)
             tensor.copy_(host)
+            if self._timed is not None:
+                self._timed.append((time.perf_counter() - t0) * 1e3)     # (host wall time incl. the staging copies)
             return tensor
         if not self._solo():
             if self._timed is not None and tensor.is_cuda:
@@ -186,7 +190,7 @@ class Comm(object):
         if not self._timed:
             return []
         torch.cuda.synchronize()
-        out = [a.elapsed_time(b) for a, b in self._timed]
+        out = [t if isinstance(t, float) else t[0].elapsed_time(t[1]) for t in self._timed]
         self._timed = []
         return out
 

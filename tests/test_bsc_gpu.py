@@ -343,6 +343,33 @@ def test_bsc_step_matches_reference_golden(dev, case, path):
     assert new["W"].shape == (int(g["D"]), int(g["H"]))
 
 
+@pytest.mark.parametrize("case", ["bsc_step_c2_plain.npz", "bsc_step_c2_fullrank.npz", "bsc_step_h256.npz", "bsc_step_c1_plain.npz"])
+def test_install_parameters_entry_of_the_bench(dev, case):
+    """bench.py's timed region drives `install_parameters` -> `select_Hprimes` -> `E_step` (W^T already on the device, as
+    an M-step leaves it; bench.py:estep_pass): the same three calls against the reference's golden -- incl. a second
+    install of a DIFFERENT W^T in between, whose Gram matrix / scores must not survive."""
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    g = golden(case)
+    m = BSC_ET(int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]))
+    an = _An(T=float(g["T"]), Ncut_factor=float(g["Ncut_factor"]), anneal_prior=bool(g["anneal_prior"]))
+    params = {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])}
+    if bool(g["has_mu"]):
+        params["mu"] = g["mu"].copy()
+    data = {"y": g["y"]}
+    Wt_host = np.ascontiguousarray(g["W"].T)
+    Wt_dev = torch.from_numpy(Wt_host).to(dev)
+    other_host = np.ascontiguousarray(Wt_host[::-1] * 1.5)
+    other_dev = torch.from_numpy(other_host).to(dev)
+    for _ in range(2):
+        m.install_parameters(data, other_dev, other_host)
+        m.E_step(an, dict(params, W=np.ascontiguousarray(other_host.T)), m.select_Hprimes(dict(params, W=np.ascontiguousarray(other_host.T)), data))
+        m.install_parameters(data, Wt_dev, Wt_host)
+        d = m.select_Hprimes(params, data)
+        ss = m.E_step(an, params, d)
+        assert np.array_equal(np.asarray(d["candidates"]), g["candidates"])
+        np.testing.assert_allclose(np.asarray(ss["logpj"]), g["logpj"], rtol=1e-10, atol=1e-9)
+
+
 def test_m_step_accepts_foreign_numpy_inputs(dev):
     """candidates / logpj handed in as plain NumPy arrays (not our device handles)."""
     from prosper_amd.em.camodels.bsc_et import BSC_ET
@@ -480,6 +507,8 @@ def test_em_run_with_partial_data_and_parameter_noise(dev):
     (48, 600, 5, 3, 4000, 1.0, 0.0, False),         # H > 512: generic row kernels, two levels of blocking
     (64, 64, 3, 2, 500, 1.0, 0.3, False),
     (32, 20, 2, 2, 129, 2.0, 0.0, False),
+    (64, 256, 16, 2, 4000, 1.2, 0.6, False),        # rows16 fits, its list-writing M-step pass does not (66 KB of LDS):
+    (64, 240, 16, 2, 4000, 1.2, 0.0, False),        # ... the plain pass + the dense statistics GEMM run (round-3 advisor finding)
 ])
 def test_bsc_step_matches_oracle(dev, D, H, Hp, gamma, N, T, ncut, ap):
     from oracle import bsc_oracle as O
@@ -495,6 +524,8 @@ def test_bsc_step_matches_oracle(dev, D, H, Hp, gamma, N, T, ncut, ap):
     ref, rlog = O.em_step(an, om, dict(params), y, stats_fn=O.m_step_stats_vec, vec=True)
 
     m = BSC_ET(D, H, Hp, gamma)
+    if Hp == 16:
+        assert m._state_tables()["fast"] and not m._state_tables()["fast_nz"]
     h = dlog.set_handler(("L", "N_use"), StoreInMemory)
     try:
         new = m.step(_An(T=T, Ncut_factor=ncut, anneal_prior=ap), dict(params), {"y": y})

@@ -59,6 +59,40 @@ def test_two_ranks_share_the_gpu_over_gloo(dev):
         assert p.returncode == 0 and ("ok %d" % rank) in out.split("\n"), "rank %d\n%s\n%s" % (rank, out[-2000:], err[-4000:])
 
 
+@pytest.mark.timeout(900)
+def test_bench_multi_rank_branch_over_gloo(dev):
+    """`bench.py --gpus 2`'s multi-rank branch end to end on the one-GPU box: the self-launch through
+    torch.distributed.run, process-group init, the device / seed self-checks, per-rank records and their gather -- with
+    `--backend gloo` (two ranks share the device; RCCL would refuse).  One JSON line, n_gpus = 2, two `per_rank`
+    entries with distinct data seeds, a timed statistics all-reduce."""
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--n-per-gpu", "33000", "--steps", "2", "--warmup", "1", "--em-steps", "2", "--prewarm-ms", "5",
+                        "--no-cpu-baseline", "--no-other-models"], env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["unit"] == "datapoints/s"
+    assert out["config"]["global_datapoints"] == 66000 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["backend"].startswith("gloo")
+    pr = out["per_rank"]
+    assert [e["rank"] for e in pr] == [0, 1] and len({e["data_seed"] for e in pr}) == 2
+    assert all(e["rows"] == 33000 and e["ms_per_step"] > 0 and e["em_iter_ms"] > 0 and e["allreduce_us"] > 0 for e in pr)
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["cpu_baseline"] is None
+    # value = all ranks' datapoints / the slowest rank's time
+    slow = max(e["ms_per_step"] for e in pr)
+    assert abs(out["value"] - 66000 / (slow * 1e-3)) <= 1e-6 * out["value"]
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
