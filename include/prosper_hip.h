@@ -49,6 +49,13 @@ const char *pm_error_string(int code);
 int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int64_t ldb,
                    double *C, int64_t ldc, int64_t M, int64_t N, int64_t K, void *stream);
 
+/* The same product for SMALL outputs (M, N <= 1024), deterministic: one workgroup per 16 x 16 tile, the K range split over
+ * its eight wavefronts and summed in a fixed order -- no atomics, so every rank holding the same operands gets the same
+ * bits (pm_gemm_nt_f64 splits such shapes over K with f64 atomics).  A == B: the Gram matrix W W^T of the models' energy
+ * algebra (bsc_et.py:177-183 in Gram form), stored symmetric bit for bit. */
+int pm_gemm_nt_small_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
+                         int64_t M, int64_t N, int64_t K, void *stream);
+
 /* C[M,N] += A[K,M]^T . B[K,N]   (reduction over the leading/row index, split over
  * workgroups, f64 atomics into C; C must be initialised by the caller).
  * Wp = E[s]^T . Y  -- replaces the per-datapoint np.outer accumulation of
@@ -90,9 +97,10 @@ int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add,
  * ||I - A prev_inv||_F was below 0.1 (then ||I - A inv|| < 1e-16 up to rounding and pivots = {min_i 1 / inv_ii, max_i A_ii}: a lower
  * bound of the smallest and an upper bound of the largest pivot of the sweep), else it overwrites `inv` with
  * the exact inverse as pm_spd_inverse_f64 would.  The decision is taken on the device from sums formed in a fixed
- * order.  `work`: pm_spd_inverse_warm_work_len(n) doubles; `full` (required, leading dimension ldo = n) receives the
- * assembled matrix.  Same role as pm_spd_inverse_f64 (np.linalg.lstsq(Wq, Wp), bsc_et.py:380); callers follow it with
- * a step of iterative refinement of the solve. */
+ * order and left for the caller in the LAST word of `work`: 1.0 = the refinement stands, 0.0 = the sweep ran (`inv` is
+ * then exact to cond(A) eps only: a caller that skipped the iterative refinement of its solve repeats it with one).
+ * `work`: pm_spd_inverse_warm_work_len(n) doubles; `full` (required, leading dimension ldo = n) receives the
+ * assembled matrix.  Same role as pm_spd_inverse_f64 (np.linalg.lstsq(Wq, Wp), bsc_et.py:380). */
 int64_t pm_spd_inverse_warm_work_len(int64_t n);
 int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, const double *prev_inv,
                             int64_t ldp, double *work, double *full, double *inv, int64_t ldo, double *pivots,
@@ -101,10 +109,23 @@ int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag
 /* `batch` warm-started inverses at once (every kernel of pm_spd_inverse_warm_f64 gets a batch dimension): matrix b is
  * read at upper + b*stride_in (diag_add + b*n), its previous inverse at prev_inv + b*stride_prev (dense n x n), its
  * result written at inv + b*stride_out (dense n x n), pivots 2 doubles per matrix; `work`: batch *
- * pm_spd_inverse_warm_work_len(n) doubles.  GSC's M-step: (sum xpt_szsz)^-1 and (sum xpt_ss + eps I)^-1. */
+ * pm_spd_inverse_warm_work_len(n) doubles (matrix b's accepted flag in the last word of its share).  GSC's M-step: (sum xpt_szsz)^-1 and (sum xpt_ss + eps I)^-1. */
 int pm_spd_inverse_warm_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
                                   const double *prev_inv, int64_t stride_prev, double *work, double *inv,
                                   int64_t stride_out, double *pivots, int64_t batch, void *stream);
+
+/* The same launches with GENERAL (non-symmetric) matrices among the batch: bit b of `general_mask` says matrix b is given in
+ * full (row-major, both triangles; diag_add still added) and is refined by the left-sided Newton-Schulz iteration
+ * X <- X + (I - X A^T) X from prev_inv + b*stride_prev -- its result is the inverse of the TRANSPOSE, (A^T)^-1 = (A^-1)^T,
+ * not symmetrised.  GSC from its second EM step on: psi_sq leaves the M-step non-symmetric (gsc_et.py:660-675), with it
+ * Lambda^-1 and sum xpt_szsz, which gsc_et.py:625 inverts as it is; W_new^T = (A^-1)^T Wp^T is then one pm_gemm_nt_f64.
+ * `accepted` (batch doubles): 1.0 = the refinement of matrix b stands, 0.0 = its start was too far off and the guarded
+ * sweep ran -- which for a general matrix inverts only its upper-mirrored stand-in: the caller then inverts on the host,
+ * as the reference does.  A cold start is pm_spd_inverse_batch_f64 on the same buffer (upper-mirrored: a start within
+ * ~1e-6) followed by this entry. */
+int pm_inverse_warm_batch_f64(const double *mats, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
+                              const double *prev_inv, int64_t stride_prev, double *work, double *inv, int64_t stride_out,
+                              double *pivots, double *accepted, int64_t batch, uint32_t general_mask, void *stream);
 
 /* `batch` independent inverses in one launch, one workgroup each (they run on different CUs at once): matrix b is
  * read at upper + b*stride_in, written at inv (and full, if given) + b*stride_out; diag_add (optional) holds n

@@ -37,6 +37,7 @@ SIGNATURES = {
     "pm_version": (C.c_int, []),
     "pm_error_string": (C.c_char_p, [C.c_int]),
     "pm_gemm_nt_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
+    "pm_gemm_nt_small_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
     "pm_gemm_tn_acc_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
     "pm_row_sqnorm_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp]),
     "pm_col_moments_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp, c_dp]),
@@ -45,6 +46,8 @@ SIGNATURES = {
     "pm_spd_inverse_warm_work_len": (i64, [i64]),
     "pm_spd_inverse_warm_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp]),
     "pm_spd_inverse_warm_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp]),
+    "pm_inverse_warm_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp, i64, C.c_uint32,
+                                            c_dp]),
     "pm_spd_inverse_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, c_dp, i64, i64, c_dp, i64, c_dp]),
     "pm_kth_hist_f64": (C.c_int, [c_dp, i64, c_dp, C.c_int, C.c_int, c_dp, c_dp]),
     "pm_kth_scan": (C.c_int, [c_dp, c_dp, C.c_int, C.c_int, c_dp]),

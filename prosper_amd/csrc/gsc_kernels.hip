@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     double nf_prev = 0.0;
     bool pend = false;
 
-    // previous datapoint's blocks -> global sums (upper triangle, mirrored by the host; candidates are sorted by
+    // previous datapoint's blocks -> global sums (xpt_ss: upper triangle, mirrored by the host; candidates are sorted by
     // index, so ci <= ck for i <= k); accumulators cleared for the next one
     auto flush_pairs = [&](bool clear) {
         for (int p0 = 0; p0 < HH; p0 += 16) {
@@ -201,8 +201,10 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
             const int ci = __builtin_amdgcn_ds_bpermute((rowbase + i) << 2, myc_prev);
             const int ck = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc_prev);
             if (ok) {
-                if (pend && k >= i) {
-                    pm_atomic_add(g_ss + (int64_t)ci * H + ck, s_ass[p] * nf_prev);
+                if (pend) {
+                    // xpt_ss is symmetric: upper triangle only; xpt_szsz = kappa kappa^T + Lambda^-1 is NOT once psi_sq has
+                    // been through an M-step (gsc_et.py:660-675 leaves it non-symmetric): both triangles, as they are
+                    if (k >= i) pm_atomic_add(g_ss + (int64_t)ci * H + ck, s_ass[p] * nf_prev);
                     pm_atomic_add(g_szsz + (int64_t)ci * H + ck, s_aszsz[p] * nf_prev);
                 }
                 if (clear) {

@@ -189,6 +189,41 @@ __device__ __forceinline__ void ns_tile(const double *__restrict__ Pt0, const do
     }
 }
 
+// GENERAL (non-symmetric) matrices -- GSC's sum xpt_szsz from the second EM step on (gsc_et.py:625 inverts it as it is;
+// psi_sq stops being symmetric at gsc_et.py:660-675) -- take the LEFT-sided iteration, whose products need no transposed
+// copy of X:  R' = I - X B,  X <- X + R' X,  R' <- R' R'  (with L' = R'^T kept beside R' as in the symmetric form).
+// The tile below is acc0 += sum_k P[k][i] Q0[k][j] (and acc1 with Q1): one left operand, two right ones; PT / QT read the
+// operand through transposed indices (P[k][i] := Pm[i][k], Q0[k][j] := Q0m[j][k] + [j == k] qdiag[j]): the residual kernel
+// forms X0 B for B = A^T out of the row-major X0 and A themselves, i.e. the iteration converges to (A^T)^-1 = (A^-1)^T --
+// the left operand GSC's W_new^T = (A^-1)^T Wp^T wants.
+template <bool TWOQ, bool PT, bool QT>
+__device__ __forceinline__ void ns_tile_g(const double *__restrict__ Pm, const double *__restrict__ Q0,
+                                          const double *__restrict__ Q1, const double *__restrict__ qdiag, int i0, int j0,
+                                          int n, int64_t ldp, int64_t ldq, int lane, int wave, d4 &acc0, d4 &acc1) {
+    constexpr int KSTEPS = NMAX / 4 / 4;
+    const int i = i0 + (lane & 15), j = j0 + (lane & 15), kq = lane >> 4;
+    const int ic = min(i, n - 1), jc = min(j, n - 1);
+    double a[KSTEPS], b0[KSTEPS], b1[KSTEPS];
+#pragma unroll
+    for (int u = 0; u < KSTEPS; ++u) {
+        const int k = (wave * KSTEPS + u) * 4 + kq;
+        const int kc = min(k, n - 1);
+        a[u] = PT ? Pm[(int64_t)ic * ldp + kc] : Pm[(int64_t)kc * ldp + ic];
+        b0[u] = QT ? Q0[(int64_t)jc * ldq + kc] : Q0[(int64_t)kc * ldq + jc];
+        if (QT && qdiag && kc == jc) b0[u] += qdiag[jc];
+        if (TWOQ) b1[u] = Q1[(int64_t)kc * ldq + jc];
+        const bool kv = k < n;
+        a[u] = (kv && i < n) ? a[u] : 0.0;
+        b0[u] = (kv && j < n) ? b0[u] : 0.0;
+        if (TWOQ) b1[u] = (kv && j < n) ? b1[u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < KSTEPS; ++u) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b0[u], acc0, 0, 0, 0);
+        if (TWOQ) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b1[u], acc1, 0, 0, 0);
+    }
+}
+
 // the four wavefronts' partial tiles summed in a fixed order; every wavefront returns the total
 __device__ __forceinline__ d4 ns_reduce(d4 acc, double (*s_t)[4][64], int lane, int wave) {
 #pragma unroll
@@ -208,10 +243,11 @@ __global__ __launch_bounds__(256) void ns_residual_kernel(const double *__restri
                                                           double *__restrict__ full, double *__restrict__ R,
                                                           double *__restrict__ L, double *__restrict__ partial,
                                                           int64_t stride_in, int64_t stride_x, int64_t stride_full,
-                                                          int64_t stride_work) {
+                                                          int64_t stride_work, unsigned general_mask) {
     __shared__ double s_t[4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.y * NS_T, j0 = blockIdx.x * NS_T;
+    const bool gen = (general_mask >> blockIdx.z) & 1u;  // this matrix is a general one, given in full: see ns_tile_g
     upper += blockIdx.z * stride_in;                     // matrix blockIdx.z of a batch
     if (diag_add) diag_add += (int64_t)blockIdx.z * n;
     X += blockIdx.z * stride_x;
@@ -222,13 +258,16 @@ __global__ __launch_bounds__(256) void ns_residual_kernel(const double *__restri
     if (full) {   // this tile of the assembled matrix: one element per thread
         const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
         if (i < n && j < n) {
-            double v = (i <= j) ? upper[(int64_t)i * ldu + j] : upper[(int64_t)j * ldu + i];
+            double v = (i <= j || gen) ? upper[(int64_t)i * ldu + j] : upper[(int64_t)j * ldu + i];
             if (i == j && diag_add) v += diag_add[i];
             full[(int64_t)i * ld + j] = v;
         }
     }
     d4 t = {0, 0, 0, 0}, unused = {0, 0, 0, 0};
-    ns_tile<false, true>(upper, nullptr, X, diag_add, i0, j0, n, ldu, ld, lane, wave, t, unused);
+    if (gen)     // t = X0 A^T: the left residual of the transposed problem
+        ns_tile_g<false, true, true>(X, upper, nullptr, diag_add, i0, j0, n, ld, ldu, lane, wave, t, unused);
+    else
+        ns_tile<false, true>(upper, nullptr, X, diag_add, i0, j0, n, ldu, ld, lane, wave, t, unused);
     t = ns_reduce(t, s_t, lane, wave);
     if (wave != 0) return;
     const int j = j0 + (lane & 15);
@@ -253,10 +292,12 @@ template <bool LAST>
 __global__ __launch_bounds__(256) void ns_step_kernel(const double *__restrict__ X, const double *__restrict__ R,
                                                       const double *__restrict__ L, int n, int64_t ld,
                                                       double *__restrict__ Xn, double *__restrict__ Rn,
-                                                      double *__restrict__ Ln, int64_t stride_x, int64_t stride_work) {
+                                                      double *__restrict__ Ln, int64_t stride_x, int64_t stride_work,
+                                                      unsigned general_mask) {
     __shared__ double s_t[2][4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.y * NS_T, j0 = blockIdx.x * NS_T;
+    const bool gen = (general_mask >> blockIdx.z) & 1u;
     X += blockIdx.z * stride_x;                          // matrix blockIdx.z of a batch
     R += blockIdx.z * stride_work;
     L += blockIdx.z * stride_work;
@@ -266,7 +307,10 @@ __global__ __launch_bounds__(256) void ns_step_kernel(const double *__restrict__
         Ln += blockIdx.z * stride_work;
     }
     d4 xr = {0, 0, 0, 0}, rr = {0, 0, 0, 0};
-    ns_tile<!LAST, false>(X, L, R, nullptr, i0, j0, n, ld, ld, lane, wave, xr, rr);
+    if (gen)     // left-sided: R' X = L'^T X and R' R' = L'^T R'
+        ns_tile_g<!LAST, false, false>(L, X, R, nullptr, i0, j0, n, ld, ld, lane, wave, xr, rr);
+    else
+        ns_tile<!LAST, false>(X, L, R, nullptr, i0, j0, n, ld, ld, lane, wave, xr, rr);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         s_t[0][wave][r][lane] = xr[r];
@@ -302,7 +346,8 @@ __global__ __launch_bounds__(256) void ns_finish_kernel(const double *__restrict
                                                         double tol2, const double *__restrict__ upper, int64_t ldu,
                                                         int64_t stride_in, const double *__restrict__ diag_add,
                                                         double *__restrict__ inv, int64_t ldo, int64_t stride_out,
-                                                        double *__restrict__ pivots) {
+                                                        double *__restrict__ pivots, double *__restrict__ accepted,
+                                                        int64_t accepted_stride, unsigned general_mask) {
     __shared__ double s_g[NMAX], s_lo[NMAX], s_hi[NMAX];
     __shared__ int s_skip;
     const int tid = threadIdx.x;
@@ -317,10 +362,15 @@ __global__ __launch_bounds__(256) void ns_finish_kernel(const double *__restrict
         if (tid == 0) s_skip = (r2 < tol2) ? 1 : 0;
     }
     __syncthreads();
+    // the decision itself, for the caller (the last word of this matrix's `work`): 1 = the refinement stands (inv is exact
+    // to rounding), 0 = the sweep behind this kernel computes inv (exact to cond(A) eps, as pm_spd_inverse_f64)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && accepted) accepted[blockIdx.z * accepted_stride] = s_skip ? 1.0 : 0.0;
     if (!s_skip) return;
     const int i = blockIdx.y * NS_T + (tid >> 4), j = blockIdx.x * NS_T + (tid & 15);
+    const bool gen = (general_mask >> blockIdx.z) & 1u;      // (a general matrix: X = (A^T)^-1 as it stands)
     if (i < n && j < n)
-        inv[blockIdx.z * stride_out + (int64_t)i * ldo + j] = 0.5 * (X[(int64_t)i * n + j] + X[(int64_t)j * n + i]);
+        inv[blockIdx.z * stride_out + (int64_t)i * ldo + j] =
+            gen ? X[(int64_t)i * n + j] : 0.5 * (X[(int64_t)i * n + j] + X[(int64_t)j * n + i]);
     if (blockIdx.x == 0 && blockIdx.y == 0 && pivots) {
         double lo = INFINITY, hi = 0.0;
         if (tid < n) {
@@ -361,12 +411,13 @@ extern "C" int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double
 
 extern "C" int64_t pm_spd_inverse_warm_work_len(int64_t n) {
     const int64_t tiles = (n + NS_T - 1) / NS_T;
-    return n > 0 ? 6 * n * n + tiles * tiles : 0;
+    return n > 0 ? 6 * n * n + tiles * tiles + 1 : 0;       // (+ 1: the accepted flag)
 }
 
 static int launch_warm(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
                        const double *prev_inv, int64_t stride_prev, double *work, double *full, double *inv,
-                       int64_t stride_out, double *pivots, int64_t batch, hipStream_t s) {
+                       int64_t stride_out, double *pivots, int64_t batch, hipStream_t s, unsigned general_mask = 0u,
+                       double *accepted = nullptr) {
     const int tiles = (int)((n + NS_T - 1) / NS_T);
     const int64_t nn = n * n, wl = pm_spd_inverse_warm_work_len(n);
     // work, per matrix: two (X, R, L) triples, then the residual's per-tile sums of squares
@@ -374,19 +425,20 @@ static int launch_warm(const double *upper, int64_t ldu, int64_t stride_in, cons
     double *partial = work + 6 * nn;
     const dim3 grid((unsigned)tiles, (unsigned)tiles, (unsigned)batch);
     hipLaunchKernelGGL(ns_residual_kernel, grid, dim3(256), 0, s, upper, ldu, diag_add, prev_inv, (int)n, n, full, R[0], L[0],
-                       partial, stride_in, stride_prev, stride_out, wl);
+                       partial, stride_in, stride_prev, stride_out, wl, general_mask);
     hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, prev_inv, (const double *)R[0], (const double *)L[0],
-                       (int)n, n, X[1], R[1], L[1], stride_prev, wl);
+                       (int)n, n, X[1], R[1], L[1], stride_prev, wl, general_mask);
     hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
-                       (const double *)L[1], (int)n, n, X[0], R[0], L[0], wl, wl);
+                       (const double *)L[1], (int)n, n, X[0], R[0], L[0], wl, wl, general_mask);
     // a fourth step (residual R0^16 < 1e-16 for every start the guard accepts): the refined inverse is then exact to
     // rounding and the caller's solve needs no refinement pass of its own (two H x H x D products saved per EM step)
     hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[0], (const double *)R[0],
-                       (const double *)L[0], (int)n, n, X[1], R[1], L[1], wl, wl);
+                       (const double *)L[0], (int)n, n, X[1], R[1], L[1], wl, wl, general_mask);
     hipLaunchKernelGGL(ns_step_kernel<true>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
-                       (const double *)L[1], (int)n, n, X[0], (double *)nullptr, (double *)nullptr, wl, wl);
+                       (const double *)L[1], (int)n, n, X[0], (double *)nullptr, (double *)nullptr, wl, wl, general_mask);
     hipLaunchKernelGGL(ns_finish_kernel, grid, dim3(256), 0, s, (const double *)X[0], (int)n, wl, (const double *)partial,
-                       tiles * tiles, 0.01, upper, ldu, stride_in, diag_add, inv, n, stride_out, pivots);
+                       tiles * tiles, 0.01, upper, ldu, stride_in, diag_add, inv, n, stride_out, pivots,
+                       accepted ? accepted : work + wl - 1, accepted ? (int64_t)1 : wl, general_mask);
     hipLaunchKernelGGL(spd_inverse_kernel, dim3((unsigned)batch), dim3(1024), 0, s, upper, ldu, diag_add, (int)n,
                        (double *)nullptr, inv, n, pivots, stride_in, stride_out, (const double *)partial, tiles * tiles, 0.01,
                        (const double *)X[0], wl);
@@ -412,6 +464,19 @@ extern "C" int pm_spd_inverse_warm_batch_f64(const double *upper, int64_t ldu, i
     if (n > NMAX || batch > 65535) return PM_ERANGE;
     return launch_warm(upper, ldu, stride_in, diag_add, n, prev_inv, stride_prev, work, nullptr, inv, stride_out, pivots, batch,
                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pm_inverse_warm_batch_f64(const double *mats, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
+                                         const double *prev_inv, int64_t stride_prev, double *work, double *inv,
+                                         int64_t stride_out, double *pivots, double *accepted, int64_t batch,
+                                         uint32_t general_mask, void *stream) {
+    if (batch == 0) return PM_OK;
+    if (!mats || !inv || !prev_inv || !work || !pivots || !accepted || n <= 0 || ldu < n || batch < 0 ||
+        stride_in < ldu * (n - 1) + n || stride_out < n * n || stride_prev < n * n)
+        return PM_EINVAL;
+    if (n > NMAX || batch > 32) return PM_ERANGE;
+    return launch_warm(mats, ldu, stride_in, diag_add, n, prev_inv, stride_prev, work, nullptr, inv, stride_out, pivots, batch,
+                       static_cast<hipStream_t>(stream), general_mask, accepted);
 }
 
 extern "C" int pm_spd_inverse_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add,

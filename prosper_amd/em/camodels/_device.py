@@ -389,8 +389,10 @@ class DeviceCAModel(CAModel):
     def _gemm_nt(self, A, B, out, label="gemm_nt"):
         M, K = A.shape
         N = B.shape[0]
-        self._call(label, "pm_gemm_nt_f64", _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0),
-                  M, N, K, self._stream())
+        # small outputs (Gram matrices, the H x H x D solve products): the deterministic one-workgroup-per-tile kernel --
+        # every rank holding the same operands gets the same bits, and no zero fill + K-slice atomics
+        fn = "pm_gemm_nt_small_f64" if (M <= 512 and N <= 512) else "pm_gemm_nt_f64"
+        self._call(label, fn, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), M, N, K, self._stream())
         return out
 
     def _upload(self, name, host, keep=False):
@@ -496,18 +498,28 @@ class DeviceCAModel(CAModel):
         Winv = torch.empty((H, H), dtype=torch.float64, device=Wq_u.device)
         piv = torch.empty(2, dtype=torch.float64, device=Wq_u.device)
         prev = getattr(self, "_winv_prev", None)
-        if (prev is not None and tuple(prev.shape) == (H, H) and prev.device == Wq_u.device
-                and os.environ.get("PM_WARM_INVERSE", "1") == "1"):
+        warm = (prev is not None and tuple(prev.shape) == (H, H) and prev.device == Wq_u.device
+                and os.environ.get("PM_WARM_INVERSE", "1") == "1")
+        if warm:
             work = self._buf("spd_warm_work", (int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
             self._call("spd_inverse", "pm_spd_inverse_warm_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(prev), H, _ptr(work),
                        _ptr(Wq), _ptr(Winv), H, _ptr(piv), self._stream())
+            # the device's own verdict on the warm start (1 = refinement accepted, 0 = the sweep ran): travels to the
+            # host with the pivots, see _solve_normal_eq / _solve_accurate
+            self._winv_flag = work[-1:]
         else:
             self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
                        H, _ptr(piv), self._stream())
-        self._winv_was_warm = prev is not None and tuple(prev.shape) == (H, H) and prev.device == Wq_u.device \
-            and os.environ.get("PM_WARM_INVERSE", "1") == "1"
+            self._winv_flag = None
+        self._winv_was_warm = warm
         self._winv_prev = Winv
         return Wq, Winv, piv
+
+    def _one(self, device):
+        one = getattr(self, "_one_dev", None)
+        if one is None or one.device != device:
+            one = self._one_dev = torch.ones(1, dtype=torch.float64, device=device)
+        return one
 
     def _apply_inverse(self, Wq, Winv, rhs, refine=True):
         """X = Winv . rhs with one step of iterative refinement, X += Winv (rhs - Wq X) -- skipped (``refine=False``) behind
@@ -538,15 +550,24 @@ class DeviceCAModel(CAModel):
         one download (``_solve_ok``) and falls back to LAPACK's lstsq on the host when they say "singular".
         ``pre``: the result of ``_invert_normal_matrix`` when the caller has already run it."""
         H, D = rhs.shape
+        self._last_solve = None
         if rhs.is_cuda and H <= 256:
             Wq, Winv, piv = pre if pre is not None else self._invert_normal_matrix(Wq_u, qdiag)
-            return self._apply_inverse(Wq, Winv, rhs, refine=not getattr(self, "_winv_was_warm", False)), piv, Wq
+            warm = getattr(self, "_winv_was_warm", False)
+            X = self._apply_inverse(Wq, Winv, rhs, refine=not warm)
+            if warm:
+                # The refinement pass of the solve was skipped on the HOST's guess that the device would accept the warm
+                # start.  The device's verdict rides behind the pivots; a caller that reads "sweep ran" there repeats the
+                # solve with the refinement (_solve_accurate): the accuracy of W no longer depends on the call history.
+                self._last_solve = (Wq, Winv, rhs)
+                return X, [piv, self._winv_flag], Wq
+            return X, [piv, self._one(rhs.device)], Wq
         if rhs.is_cuda:
             # H > 256: the one-workgroup inverse on 256-blocks + Schur complements (the library's own GEMMs; no rocSOLVER)
             Wq = torch.triu(Wq_u, 1)
             Wq = (Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)).contiguous()
             Winv, pmin, pmax = self._spd_inverse_blocked(Wq)
-            return self._apply_inverse(Wq, Winv, rhs), torch.stack([pmin, pmax]), Wq
+            return self._apply_inverse(Wq, Winv, rhs), [torch.stack([pmin, pmax]), self._one(rhs.device)], Wq
         # host tensors: the world_size-2 gloo tests feed CPU statistics through the same finalize code (never the
         # product path, whose statistics live on the device)
         Wq = torch.triu(Wq_u, 1)
@@ -556,7 +577,18 @@ class DeviceCAModel(CAModel):
         X = torch.cholesky_solve(rhs, Lc).contiguous()    # garbage if the factorisation failed
         piv = torch.stack([torch.where(info.reshape(()) == 0, d.min(), -torch.ones((), dtype=d.dtype, device=d.device)),
                            d.max()])
-        return X, piv, Wq
+        return X, [piv, self._one(rhs.device)], Wq
+
+    def _solve_accurate(self, flag):
+        """``None`` if the solution `_solve_normal_eq` returned is at full accuracy -- the refined cold solve, or the warm
+        start the device accepted (``flag`` = the word behind the pivots in the download: 1) -- else (the device rejected the
+        warm start and ran the sweep, but the host had skipped the refinement pass) the refined solution X (H,D) as a
+        host array, computed now from the sweep's inverse: X0 + Winv (rhs - Wq X0), exactly what the cold path returns."""
+        last, self._last_solve = getattr(self, "_last_solve", None), None
+        if flag != 0.0 or last is None:
+            return None
+        Wq, Winv, rhs = last
+        return self._apply_inverse(Wq, Winv, rhs, refine=True).cpu().numpy()
 
     def _spd_inverse_blocked(self, A):
         """Inverse of a symmetric positive definite device matrix of any size from pm_spd_inverse_f64 (n <= 256, one

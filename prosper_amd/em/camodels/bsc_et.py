@@ -763,7 +763,7 @@ class BSC_ET(DeviceCAModel):
                 # BEFORE the host has looked at the pivots: the host-lstsq fallback below must read its own copy
                 rhs = Wp.clone()
             X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, rhs, pre)
-            parts += [status, X.reshape(-1)]
+            parts += status + [X.reshape(-1)]
             if packed.is_cuda and res is not None:   # next step's W^T and Gram matrix are already here: no upload then
                 seed = (X, self._gemm_nt(X, X, self._buf("gram", (H, H)), "gram_gemm"))
         if learn_mu:
@@ -793,7 +793,14 @@ class BSC_ET(DeviceCAModel):
         pos = H + 4
         if learn_W:
             ok = self._solve_ok(float(host[pos]), float(host[pos + 1]))
-            if ok:
+            redo = self._solve_accurate(float(host[pos + 2])) if ok else None
+            pos += 1
+            if redo is not None:
+                # the device rejected the warm start of the inverse and the solve behind it had skipped its refinement
+                # pass: W from the refined solve; whatever was seeded / speculated from the unrefined one is void
+                self._a0 = None
+                W_new = redo
+            elif ok:
                 Wt_host = host[pos + 2:pos + 2 + H * D].reshape(H, D)
                 W_new = Wt_host.copy()
                 if seed is not None:

@@ -382,7 +382,7 @@ class DSC_ET(DeviceCAModel):
         if learn_W:
             tracing.tracepoint("M_step:update W")
             X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, Wp.contiguous())
-            parts += [status, X.reshape(-1)]
+            parts += status + [X.reshape(-1)]
         flat = torch.cat(parts)
         self._seed_rec = None
         res = getattr(self, "_mstep_res", None)
@@ -399,8 +399,12 @@ class DSC_ET(DeviceCAModel):
         W = np.asarray(model_params['W'])
         if learn_W:
             ok = self._solve_ok(float(host[12]), float(host[13]))
-            if ok:
-                W_new = host[14:14 + H * D].reshape(H, D).copy()
+            redo = self._solve_accurate(float(host[14])) if ok else None
+            if redo is not None:    # the device rejected the inverse's warm start: W from the refined solve, seed void
+                self._seed_rec = None
+                W_new = redo
+            elif ok:
+                W_new = host[15:15 + H * D].reshape(H, D).copy()
                 if self._seed_rec is not None:
                     self._seed_rec["W"] = W_new.transpose().copy()   # private snapshot of the W handed back
             else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host

@@ -500,8 +500,9 @@ class GSC(DeviceCAModel):
         cs, csz, dzz = (st[2 * H * H + i * H:2 * H * H + (i + 1) * H] for i in range(3))   # per-XCD scratch follows
         off = torch.triu(U_ss, 1)
         sum_ss = off + off.t() + torch.diag(cs)                            # diag(sum xpt_ss) = sum xpt_s
-        offz = torch.triu(U_zz, 1)
-        sum_zz = offz + offz.t() + torch.diag(torch.diagonal(U_zz) + dzz)
+        # xpt_szsz = kappa kappa^T + Lambda^-1 is symmetric only while psi_sq is (gsc_et.py:660-675 returns a non-symmetric
+        # one): the kernel accumulates both triangles as they are
+        sum_zz = U_zz + torch.diag(dzz)
         if self.reference_order and isinstance(my_data.get('data_clusters'), LazyClusters):
             # the reference's row order (gsc_et.py:572-573): clusters in order of first appearance
             order = my_data['data_clusters'].order()
@@ -552,7 +553,7 @@ class GSC(DeviceCAModel):
         nWp, nHH = D * H, H * H
         n_stat = nWp + 4 * nHH + 2 * H + 1
         # one buffer, one download: [statistics (all-reduced) | 2 inverses + 4 pivots | W_new^T | pi mu psi_sq sigma_sq]
-        n_inv, n_par = 2 * nHH + 4, 2 * H + nHH + 1
+        n_inv, n_par = 2 * nHH + 4 + 2, 2 * H + nHH + 1          # (+ 2: the warm starts' accepted flags)
         o_inv = n_stat + (n_stat & 1)               # (16-byte alignment for the GEMM's vector loads)
         whole = torch.zeros(o_inv + n_inv + nWp + n_par, dtype=torch.float64, device=self.device)
         packed = whole[:n_stat]
@@ -591,24 +592,26 @@ class GSC(DeviceCAModel):
             # the two H x H inverses of the update (gsc_et.py:625, 673) on the device, ahead of the download: a
             # 128 x 128 LAPACK inverse costs 0.4 ms of host time each while the GPU idles.  [sum_ss ; sum_zz] sit back
             # to back in the statistics; inverses are stored in that order: [(sum_ss + eps I)^-1 ; sum_zz^-1 ; 4 pivots]
+            # sum_zz is a GENERAL matrix from the second EM step on (psi_sq is not symmetric any more: gsc_et.py:660-675) and
+            # the reference inverts it as it is (:625): the left-sided Newton-Schulz refinement of pm_inverse_warm_batch_f64
+            # (its result is the inverse of the transpose -- what W_new^T = (A^-1)^T Wp^T needs), started from the previous
+            # EM step's inverses or, cold, from the sweep's inverses of the upper-mirrored matrices (within ~1e-6).
             dadd = self._eps_diag(H, eps)
             prev = getattr(self, "_inv_prev", None)
-            if prev is not None and tuple(prev.shape) == (2, H, H) and os.environ.get("PM_WARM_INVERSE", "1") == "1":
-                # warm start from the previous EM step's inverses (Newton-Schulz on the matrix cores, the sweep as the
-                # device-side fallback): both matrices in every launch
-                work = self._buf("spd_warm_work", (2 * int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
-                self._call("spd_inverse", "pm_spd_inverse_warm_batch_f64", at(o), H, nHH, _ptr(dadd), H, _ptr(prev), nHH,
-                           _ptr(work), at(o_inv), nHH, at(o_inv + 2 * nHH), 2, st)
-            else:
-                # ONE launch, one workgroup per matrix: the two inverses run side by side on two CUs
+            if not (prev is not None and tuple(prev.shape) == (2, H, H) and os.environ.get("PM_WARM_INVERSE", "1") == "1"):
+                # ONE launch, one workgroup per matrix: the two sweeps run side by side on two CUs
                 self._call("spd_inverse", "pm_spd_inverse_batch_f64", at(o), H, nHH, _ptr(dadd), H, None, at(o_inv), H, nHH,
                            at(o_inv + 2 * nHH), 2, st)
+                prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H).clone()
+            work = self._buf("spd_warm_work", (2 * int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
+            self._call("spd_inverse", "pm_inverse_warm_batch_f64", at(o), H, nHH, _ptr(dadd), H, _ptr(prev), nHH,
+                       _ptr(work), at(o_inv), nHH, at(o_inv + 2 * nHH), at(o_inv + 2 * nHH + 4), 2, 2, st)
             self._inv_prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H).clone()
         Wt_next = None
         self._seed = None
         if have_inv and 'W' in self.to_learn and self.sigma_sq_type == 'scalar' and self.speculate:
-            # W_new^T = (sum xpt_szsz)^-1 . Wp^T on the device too (gsc_et.py:625): the next step's scores GEMM can
-            # then start before the host has even seen this step's result
+            # W_new^T = (sum xpt_szsz)^-T . Wp^T on the device too (gsc_et.py:625; the inverse sits there transposed): the
+            # next step's scores GEMM can then start before the host has even seen this step's result
             Wt_next = whole[o_wt:o_wt + nWp].view(H, D)
             self._gemm_nt(whole[o_inv + nHH:o_inv + 2 * nHH].view(H, H), whole[:nWp].view(D, H), Wt_next, "solve_gemm")
         # The rest of the update is H- and H x H-sized (gsc_et.py:640-713): done on the device as well
@@ -657,11 +660,12 @@ class GSC(DeviceCAModel):
         inverses = None
         if have_inv:
             tail = host[o_inv:o_inv + n_inv]
-            piv = tail[2 * nHH:]
+            piv, acc = tail[2 * nHH:2 * nHH + 4], tail[2 * nHH + 4:]
+            # (a rejected start of the general matrix leaves only the inverse of its upper-mirrored stand-in: host then)
             good = np.isfinite(tail).all() and piv[0] > 0 and piv[2] > 0 and piv[0] / piv[1] > 1e-12 \
-                and piv[2] / piv[3] > 1e-12
-            if good:        # well-conditioned SPD: use the device inverses; else LAPACK on the host as upstream
-                inverses = (tail[nHH:2 * nHH].reshape(H, H), tail[:nHH].reshape(H, H))    # (zz^-1, (ss + eps I)^-1)
+                and piv[2] / piv[3] > 1e-12 and acc[1] == 1.0
+            if good:        # well-conditioned: use the device inverses; else LAPACK on the host as upstream
+                inverses = (tail[nHH:2 * nHH].reshape(H, H).T, tail[:nHH].reshape(H, H))    # (zz^-1, (ss + eps I)^-1)
         if inverses is None:
             self._inv_prev = None             # never warm-start the next inverses from rejected ones
         if inverses is None or W_given is None or not np.isfinite(W_given).all():

@@ -10,7 +10,8 @@ the host), each running the real HIP kernels on its `stride_data` shard of the d
   * MCA at config-5 dimensions (D=256 H=128 H'=8 gamma=3, N = 1001: the fused E-step + M-statistics pass and its f64
     atomics on both ranks, then truncation steps through the distributed radix select) and GSC at config-4 dimensions
     (D=256 H=128 H'=6 gamma=3, N = 1001: per-XCD statistics scratch, the batched warm inverse, the device-side M-step
-    tail), three EM steps each against the oracle's single-process trajectory, bitwise rank identity after every step.
+    tail), three EM steps each against the oracle's single-process steps (MCA: its free-running trajectory; GSC: the oracle's
+    step from the same parameters), bitwise rank identity after every step.
 Rank 0 holds the oracle; its verdict is shared after every step (`agree`), so a failed comparison ends BOTH ranks at
 once with the assertion's text instead of leaving rank 1 in the next collective until the parent's timeout.
 Prints "ok <rank>" on success."""
@@ -162,19 +163,21 @@ def main():
         gmodel = GO.make_model(D, H, Hp, gamma)
         gkeys = ("W", "pi", "mu", "psi_sq", "sigma_sq")
         p = {k: np.array(v, copy=True) for k, v in p0.items()}
-        ref = [{k: np.array(v, copy=True) for k, v in p0.items()}]
         shard = {"y": yg[lo:hi].copy()}
         for step, T in enumerate([1.1, 1.0, 1.0]):
+            # (every step against the oracle's step FROM THE SAME PARAMETERS: with ~16 active datapoints per latent the W
+            # solve is ill-conditioned enough that free-running trajectories drift apart by more than one step's tolerance)
+            start = {k: np.array(v, copy=True) for k, v in p.items()}
             p = mg.step(An(T=T), p, shard)
             same_on_all_ranks(p, "config-4 step %d" % step, keys=gkeys)
 
             def check_gsc():
-                ref[0], log = GO.em_step(GO.Anneal(T=T), gmodel, ref[0], yg)
+                ref, log = GO.em_step(GO.Anneal(T=T), gmodel, start, yg)
                 cond = np.linalg.cond(log["suff"]["xpt_szsz"].sum(0))
-                tol = max(1e-8, 50 * cond * np.finfo(float).eps) * (step + 1)
+                tol = max(1e-8, 50 * cond * np.finfo(float).eps)
                 for k in gkeys:
-                    np.testing.assert_allclose(p[k], ref[0][k], rtol=10 * tol, atol=tol * max(1.0, np.abs(ref[0][k]).max()),
-                                               err_msg=k)
+                    np.testing.assert_allclose(p[k], ref[k], rtol=10 * tol, atol=tol * max(1.0, np.abs(ref[k]).max()),
+                                               err_msg="%s (step %d, cond %.2e)" % (k, step, cond))
             agree(check_gsc, "config-4 step %d" % step)
             p = {k: np.array(p[k], copy=True) for k in gkeys}
         comm.Barrier()

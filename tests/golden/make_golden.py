@@ -53,9 +53,12 @@ class Capture(DataHandler):
 dlog.set_handler(("L", "N", "N_use", "prior_mass"), Capture)
 
 
-def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False, sigma_type="scalar"):
+def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False, sigma_type="scalar", presteps=0):
     """select_Hprimes -> E_step -> M_step (+ compute_lpj) of GSC with scalar sigma_sq.  The reference
-    returns its statistics in candidate-bucket order; they are mapped back to datapoint order here."""
+    returns its statistics in candidate-bucket order; they are mapped back to datapoint order here.
+    ``presteps``: the fixture's INPUT parameters are what that many reference EM steps leave behind -- from the first
+    M-step on psi_sq is NOT symmetric (gsc_et.py:660-675: the term -2 outer(mu * xpt_s, xpt_sz)), and with it Lambda,
+    its inverse and sum xpt_szsz (which gsc_et.py:625 inverts as it is)."""
     rng = np.random.RandomState(seed)
     W_gt = rng.normal(size=(D, H))
     pi_gt = np.full(H, min(0.4, 2.0 / H))
@@ -75,9 +78,15 @@ def gsc_step_case(name, D, H, Hp, gamma, N, seed, T, full_psi=False, sigma_type=
     elif sigma_type == "full":
         Qs = 0.15 * rng.normal(size=(D, D))
         params["sigma_sq"] = np.diag(rng.uniform(0.8, 1.8, size=D)) + Qs @ Qs.T
-    inp = {k: np.array(v, copy=True) for k, v in params.items()}
     model = GSC(D, H, Hp, gamma, sigma_type)
     anneal = FixedAnneal(T=T)
+    for _ in range(presteps):
+        d0 = model.select_Hprimes(params, {"y": y.copy()})
+        params = model.M_step(anneal, params, model.E_step(anneal, params, d0), d0)
+        params = {k: np.array(params[k], copy=True) for k in ("W", "pi", "mu", "psi_sq", "sigma_sq")}
+    if presteps:
+        assert np.abs(params["psi_sq"] - params["psi_sq"].T).max() > 0
+    inp = {k: np.array(v, copy=True) for k, v in params.items()}
     logpj, cands = model.compute_lpj(anneal, {k: np.array(v, copy=True) for k, v in inp.items()}, {"y": y.copy()})
     data = model.select_Hprimes(params, {"y": y.copy()})
     order = np.concatenate([np.array(c["ind"]) for c in data["data_clusters"].values()])
@@ -570,6 +579,12 @@ def main(only=None, cases=None):
     gsc_step_case("diag_T", 40, 24, 5, 3, 120, seed=37, T=1.4, full_psi=True, sigma_type="diagonal")
     gsc_step_case("full", 16, 8, 4, 3, 200, seed=38, T=1.0, sigma_type="full")
     gsc_step_case("full_T", 40, 24, 5, 3, 120, seed=39, T=1.3, full_psi=True, sigma_type="full")
+    # second / third EM step: non-symmetric psi_sq in, non-symmetric sum xpt_szsz inverted (round 4)
+    gsc_step_case("step2", 40, 24, 5, 3, 150, seed=41, T=1.0, presteps=1)
+    gsc_step_case("step3_T", 30, 12, 5, 4, 120, seed=42, T=1.2, full_psi=True, presteps=2)
+    gsc_step_case("step2_c4", 256, 128, 6, 3, 160, seed=43, T=1.0, presteps=1)           # BASELINE config-4 dims
+    gsc_step_case("step2_diag", 40, 24, 5, 3, 150, seed=44, T=1.0, sigma_type="diagonal", presteps=1)
+    gsc_step_case("step2_full", 40, 24, 5, 3, 150, seed=45, T=1.1, sigma_type="full", presteps=1)
     mca_step_case("small", 16, 8, 4, 3, 300, seed=21, T=1.0, Ncut=0.0)
     mca_step_case("small_cut", 16, 8, 4, 3, 257, seed=22, T=1.4, Ncut=0.5)
     mca_step_case("bars", 25, 10, 5, 3, 300, seed=23, T=1.0, Ncut=1.0, bars=True)

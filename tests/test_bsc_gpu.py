@@ -50,6 +50,32 @@ def test_gemm_nt_matches_numpy(dev, M, N, K):
     np.testing.assert_allclose(c.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (128, 128, 256), (100, 37, 25), (1, 1, 1), (130, 129, 18), (17, 512, 1030),
+                                   (300, 300, 64), (512, 256, 128)])
+def test_gemm_nt_small_matches_numpy_and_is_deterministic(dev, M, N, K):
+    """pm_gemm_nt_small_f64 (Gram matrices, H x H x D solve products): against NumPy; bit-identical from launch to launch
+    (fixed summation order, no atomics -- what keeps ranks with the same W on the same bits); A == B gives a Gram matrix
+    that is symmetric bit for bit."""
+    from prosper_amd import _lib
+    rng = np.random.RandomState(M + 7 * N + K)
+    A, B = rng.normal(size=(M, K)), rng.normal(size=(N, K))
+    a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    outs = []
+    for _ in range(3):
+        c = torch.full((M, N), float("nan"), dtype=torch.float64, device=dev)
+        _lib.call("pm_gemm_nt_small_f64", _p(a), K, _p(b), K, _p(c), N, M, N, K, _stream())
+        outs.append(c.cpu().numpy())
+    ref = A @ B.T
+    np.testing.assert_allclose(outs[0], ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    if M == N:
+        g = torch.full((M, M), float("nan"), dtype=torch.float64, device=dev)
+        _lib.call("pm_gemm_nt_small_f64", _p(a), K, _p(a), K, _p(g), M, M, M, K, _stream())
+        G = g.cpu().numpy()
+        assert np.array_equal(G, G.T)
+        np.testing.assert_allclose(G, A @ A.T, rtol=1e-12, atol=1e-12 * np.abs(A @ A.T).max())
+
+
 def test_gemm_nt_layout_asymmetric(dev):
     """A = I against an asymmetric B catches a swapped row/column map of the MFMA tile."""
     from prosper_amd import _lib
@@ -215,6 +241,56 @@ def test_spd_inverse_warm_batch(dev):
     np.testing.assert_allclose(pv[:2], [1.0 / np.diag(np.linalg.inv(A0f)).max(), np.diag(A0f).max()], rtol=1e-7)
     d2 = np.diag(np.linalg.cholesky(mats[1] + np.diag(dadd[1]))) ** 2  # swept
     np.testing.assert_allclose(pv[2:], [d2.min(), d2.max()], rtol=1e-9)
+
+
+@pytest.mark.parametrize("n,asym", [(24, 1e-6), (128, 1e-6), (128, 1e-4), (256, 1e-5)])
+def test_inverse_warm_batch_general(dev, n, asym):
+    """pm_inverse_warm_batch_f64: [an SPD matrix given by its upper triangle + diag_add ; a GENERAL matrix given in full]
+    -- GSC's (sum xpt_ss + eps I, sum xpt_szsz) from the second EM step on.  Cold start as the model does it (sweep of
+    the upper-mirrored matrices, then the refinement): the general matrix comes back as the inverse of its TRANSPOSE,
+    exact to rounding like LAPACK's general inverse, not symmetrised; a far-off start is reported as not accepted."""
+    from prosper_amd import _lib
+    rs = np.random.RandomState(n)
+    B = rs.normal(size=(n, 3 * n))
+    S0, S1 = B @ B.T / n, None
+    C = rs.normal(size=(n, 3 * n))
+    S1 = C @ C.T / n
+    E = rs.normal(size=(n, n))
+    A1 = S1 + asym * np.abs(S1).max() * (E - E.T)                   # non-symmetric, as sum xpt_szsz is
+    dadd = np.concatenate([np.full(n, 1e-5), np.zeros(n)])
+    mats = torch.from_numpy(np.stack([np.triu(S0), A1])).to(dev)
+    da = torch.from_numpy(dadd).to(dev)
+    inv = torch.zeros((2, n, n), dtype=torch.float64, device=dev)
+    piv = torch.zeros(4, dtype=torch.float64, device=dev)
+    acc = torch.full((2,), -1.0, dtype=torch.float64, device=dev)
+    work = torch.zeros(2 * int(_lib.load().pm_spd_inverse_warm_work_len(n)), dtype=torch.float64, device=dev)
+    _lib.call("pm_spd_inverse_batch_f64", _p(mats), n, n * n, _p(da), n, None, _p(inv), n, n * n, _p(piv), 2, _stream())
+    prev = inv.clone()
+    _lib.call("pm_inverse_warm_batch_f64", _p(mats), n, n * n, _p(da), n, _p(prev), n * n, _p(work), _p(inv), n * n, _p(piv),
+              _p(acc), 2, 2, _stream())
+    assert acc.cpu().tolist() == [1.0, 1.0]
+    got = inv.cpu().numpy()
+    ref0, ref1 = np.linalg.inv(S0 + 1e-5 * np.eye(n)), np.linalg.inv(A1)
+    c0, c1 = np.linalg.cond(S0), np.linalg.cond(A1)
+    np.testing.assert_allclose(got[0], ref0, rtol=0, atol=1e-14 * c0 * np.abs(ref0).max())
+    np.testing.assert_allclose(got[1], ref1.T, rtol=0, atol=1e-14 * c1 * np.abs(ref1).max())
+    assert np.abs(got[1] - got[1].T).max() > 0.1 * np.abs(ref1 - ref1.T).max()            # not symmetrised
+    assert np.abs(A1 @ got[1].T - np.eye(n)).max() < 1e-13 * c1
+    # warm: a nearby pair refined from these inverses
+    mats2 = torch.from_numpy(np.stack([np.triu(S0 * 1.001), A1 * 0.999 + 1e-4 * asym * E])).to(dev)
+    prev = inv.clone()
+    _lib.call("pm_inverse_warm_batch_f64", _p(mats2), n, n * n, _p(da), n, _p(prev), n * n, _p(work), _p(inv), n * n, _p(piv),
+              _p(acc), 2, 2, _stream())
+    assert acc.cpu().tolist() == [1.0, 1.0]
+    ref1b = np.linalg.inv(A1 * 0.999 + 1e-4 * asym * E)
+    np.testing.assert_allclose(inv[1].cpu().numpy(), ref1b.T, rtol=0, atol=1e-14 * c1 * np.abs(ref1b).max())
+    # a start that is far off: the general matrix is reported as NOT accepted (the caller inverts on the host)
+    prev = (inv * 3.0).clone()
+    _lib.call("pm_inverse_warm_batch_f64", _p(mats2), n, n * n, _p(da), n, _p(prev), n * n, _p(work), _p(inv), n * n, _p(piv),
+              _p(acc), 2, 2, _stream())
+    assert acc.cpu().tolist() == [0.0, 0.0]
+    ref0b = np.linalg.inv(S0 * 1.001 + 1e-5 * np.eye(n))
+    np.testing.assert_allclose(inv[0].cpu().numpy(), ref0b, rtol=0, atol=1e-13 * c0 * np.abs(ref0b).max())   # (the sweep's)
 
 
 @pytest.mark.parametrize("n", [257, 300, 512, 700])
@@ -849,6 +925,50 @@ def test_warm_inverse_is_transparent_across_unrelated_problems(dev):
         ref = BSC_ET(D, H, Hp, gamma).step(an, dict(p), {"y": y})
         np.testing.assert_allclose(got["W"], ref["W"], rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose([got["pi"], got["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-12)
+
+
+@pytest.mark.parametrize("cond", [1e3, 1e9])
+def test_solve_after_a_rejected_warm_start_is_refined(dev, cond):
+    """Round-3 advisor finding: the solve's refinement pass was skipped on the host's guess that the device would accept
+    the inverse's warm start; when the device rejected it (start residual >= 0.1) the sweep's inverse was applied
+    UNREFINED, i.e. the accuracy of W depended on the call history.  Now the device's verdict travels with the pivots and a
+    rejected start repeats the solve with the refinement: the result equals, bit for bit, what a model without history
+    (cold sweep + refinement) returns, and solves Wq X = Wp like LAPACK's lstsq -- also for cond(Wq) = 1e9."""
+    from prosper_amd.em.camodels._device import DeviceCAModel
+    H, D = 96, 80
+    rs = np.random.RandomState(int(np.log10(cond)))
+
+    def spd(c):
+        Q, _ = np.linalg.qr(rs.normal(size=(H, H)))
+        return (Q * np.logspace(0, -np.log10(c), H)) @ Q.T
+
+    def run(model, A, B):
+        Wq_u = torch.from_numpy(np.triu(A) - np.diag(np.diag(A)) * 0.5).to(dev)       # upper triangle, half the diagonal ...
+        qd = torch.from_numpy(np.diag(A) * 0.5).to(dev)                              # ... the other half as diag_add
+        X, status, _ = model._solve_normal_eq(Wq_u, qd, torch.from_numpy(B).to(dev))
+        host = torch.cat(status + [X.reshape(-1)]).cpu().numpy()
+        assert DeviceCAModel._solve_ok(host[0], host[1])
+        redo = model._solve_accurate(float(host[2]))
+        return (redo if redo is not None else host[3:].reshape(H, D)), float(host[2]), redo is not None
+
+    A1, A2 = spd(10.0), spd(cond)
+    A1, A2 = 0.5 * (A1 + A1.T), 0.5 * (A2 + A2.T)
+    B = rs.normal(size=(H, D))
+    warm = DeviceCAModel(D, H, 4, 2)
+    _, flag, redone = run(warm, A1, B)
+    assert flag == 1.0 and not redone                           # first call: cold sweep, refined
+    X_w, flag, redone = run(warm, A2, B)                        # unrelated matrix: the device rejects the warm start
+    assert flag == 0.0 and redone
+    X_c, flag, redone = run(DeviceCAModel(D, H, 4, 2), A2, B)   # no history
+    assert flag == 1.0 and not redone
+    assert np.array_equal(X_w, X_c)
+    ref = np.linalg.lstsq(A2, B, rcond=None)[0]
+    resid = lambda X: np.abs(A2 @ X - B).max() / (np.abs(A2).max() * np.abs(X).max())
+    assert resid(X_w) < 50 * np.finfo(float).eps * H            # backward error at rounding level, whatever cond is
+    np.testing.assert_allclose(X_w, ref, rtol=0, atol=1e-13 * cond * np.abs(ref).max())
+    X_n, flag, redone = run(warm, A2 * (1 + 1e-4), B)           # a nearby matrix next: accepted, nothing repeated
+    assert flag == 1.0 and not redone
+    np.testing.assert_allclose(X_n * (1 + 1e-4), X_c, rtol=0, atol=1e-13 * cond * np.abs(ref).max())
 
 
 def test_config2_fullrank_w_through_cold_and_warm_inverse(dev):

@@ -237,8 +237,10 @@ def test_config4_properties():
     torch.testing.assert_close(ss["_sums"][1], xsz.sum(0), rtol=1e-11, atol=1e-9)
     # (2) second moments: symmetric, positive semi-definite, off-diagonal mass only between co-candidates
     torch.testing.assert_close(sum_ss, sum_ss.t(), rtol=0, atol=0)
-    torch.testing.assert_close(sum_zz, sum_zz.t(), rtol=0, atol=0)
-    assert torch.linalg.eigvalsh(sum_zz).min().item() > -1e-8 * sum_zz.abs().max().item()
+    # (sum xpt_szsz is accumulated with both triangles as they are -- from the second EM step on psi_sq, and with it this
+    # matrix, is not symmetric, gsc_et.py:660-675; with the symmetric psi_sq of this test it is, up to rounding)
+    torch.testing.assert_close(sum_zz, sum_zz.t(), rtol=1e-10, atol=1e-10)
+    assert torch.linalg.eigvalsh(0.5 * (sum_zz + sum_zz.t())).min().item() > -1e-8 * sum_zz.abs().max().item()
     co = torch.zeros(H, H, dtype=torch.bool, device=dev)
     co[cand[:, :, None].expand(N, Hp, Hp).reshape(-1), cand[:, None, :].expand(N, Hp, Hp).reshape(-1)] = True
     assert (sum_ss[~co] == 0).all() and (sum_zz[~co] == 0).all()
@@ -340,7 +342,10 @@ def test_gsc_em_loop_speculation_is_transparent():
             assert m._seed is not None and m._seed["W_host"] is not p["W"] and np.array_equal(m._seed["W_host"], p["W"])
             # the M-step also finishes on the device and launches the next E-step itself: adopted at steps 2, 5, 6, 7
             # (step 1 follows the first step: no flat schedule yet; 3 and 4 follow an edit)
-            assert m.spec_hits == 4, m.spec_hits
+            # (... unless the device rejected the warm start of the general matrix sum xpt_szsz at one of them -- early EM
+            # steps move it a lot --: that step's inverse then comes from the host, as upstream, and nothing is launched
+            # from the device's result)
+            assert 3 <= m.spec_hits <= 4, m.spec_hits
         else:
             assert m.spec_hits == 0
     for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
