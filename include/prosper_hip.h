@@ -55,6 +55,10 @@ int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int64_t ldb,
  * algebra (bsc_et.py:177-183 in Gram form), stored symmetric bit for bit. */
 int pm_gemm_nt_small_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                          int64_t M, int64_t N, int64_t K, void *stream);
+/* C = A . B (A: M x K, B: K x N, row-major; M <= 1024), same scheme: the W solve X = Wq^-1 . Wp behind the device inverse
+ * (np.linalg.lstsq(Wq, Wp) at bsc_et.py:380, dsc_et.py:741) in one launch -- no zero fill, no K-slice atomics. */
+int pm_gemm_nn_small_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
+                         int64_t M, int64_t N, int64_t K, void *stream);
 
 /* C[M,N] += A[K,M]^T . B[K,N]   (reduction over the leading/row index, split over
  * workgroups, f64 atomics into C; C must be initialised by the caller).
@@ -97,9 +101,9 @@ int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add,
  * ||I - A prev_inv||_F was below 0.1 (then ||I - A inv|| < 1e-16 up to rounding and pivots = {min_i 1 / inv_ii, max_i A_ii}: a lower
  * bound of the smallest and an upper bound of the largest pivot of the sweep), else it overwrites `inv` with
  * the exact inverse as pm_spd_inverse_f64 would.  The decision is taken on the device from sums formed in a fixed
- * order and left for the caller in the LAST word of `work`: 1.0 = the refinement stands, 0.0 = the sweep ran (`inv` is
- * then exact to cond(A) eps only: a caller that skipped the iterative refinement of its solve repeats it with one).
- * `work`: pm_spd_inverse_warm_work_len(n) doubles; `full` (required, leading dimension ldo = n) receives the
+ * order and left for the caller in pivots[2] (`pivots`: THREE doubles here): 1.0 = the refinement stands, 0.0 = the sweep
+ * ran (`inv` is then exact to cond(A) eps only: a caller that skipped the iterative refinement of its solve repeats it
+ * with one).  `work`: pm_spd_inverse_warm_work_len(n) doubles; `full` (required, leading dimension ldo = n) receives the
  * assembled matrix.  Same role as pm_spd_inverse_f64 (np.linalg.lstsq(Wq, Wp), bsc_et.py:380). */
 int64_t pm_spd_inverse_warm_work_len(int64_t n);
 int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, const double *prev_inv,
@@ -109,7 +113,7 @@ int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag
 /* `batch` warm-started inverses at once (every kernel of pm_spd_inverse_warm_f64 gets a batch dimension): matrix b is
  * read at upper + b*stride_in (diag_add + b*n), its previous inverse at prev_inv + b*stride_prev (dense n x n), its
  * result written at inv + b*stride_out (dense n x n), pivots 2 doubles per matrix; `work`: batch *
- * pm_spd_inverse_warm_work_len(n) doubles (matrix b's accepted flag in the last word of its share).  GSC's M-step: (sum xpt_szsz)^-1 and (sum xpt_ss + eps I)^-1. */
+ * pm_spd_inverse_warm_work_len(n) doubles (matrix b's accepted flag -- see above -- in the last word of its share).  GSC's M-step: (sum xpt_szsz)^-1 and (sum xpt_ss + eps I)^-1. */
 int pm_spd_inverse_warm_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
                                   const double *prev_inv, int64_t stride_prev, double *work, double *inv,
                                   int64_t stride_out, double *pivots, int64_t batch, void *stream);

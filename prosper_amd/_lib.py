@@ -37,6 +37,7 @@ SIGNATURES = {
     "pm_version": (C.c_int, []),
     "pm_error_string": (C.c_char_p, [C.c_int]),
     "pm_gemm_nt_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
+    "pm_gemm_nn_small_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
     "pm_gemm_nt_small_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
     "pm_gemm_tn_acc_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
     "pm_row_sqnorm_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, c_dp]),

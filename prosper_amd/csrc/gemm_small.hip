@@ -24,7 +24,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int SW = 8;          // wavefronts per workgroup
 constexpr int CH = 16;         // K columns per chunk: lane (r, kq) holds columns 4 kq .. 4 kq + 3 of row r
-constexpr int UNR = 8;         // chunks a wavefront keeps in flight
+// (UNR, template parameter: chunks a wavefront keeps in flight -- 8 for K >= 1024, fewer for shorter products)
 
 // columns k .. k + 3 of `row` (zeros beyond kend); ALIGNED: rows start 16-byte aligned and K % 4 == 0
 template <bool ALIGNED>
@@ -42,7 +42,7 @@ __device__ __forceinline__ void load4(const double *__restrict__ row, int64_t k,
     }
 }
 
-template <bool ALIGNED>
+template <bool ALIGNED, int UNR>
 __global__ __launch_bounds__(64 * SW) void gemm_nt_small_kernel(const double *__restrict__ A, int64_t lda,
                                                                  const double *__restrict__ B, int64_t ldb,
                                                                  double *__restrict__ C, int64_t ldc, int M, int N,
@@ -91,6 +91,55 @@ __global__ __launch_bounds__(64 * SW) void gemm_nt_small_kernel(const double *__
     }
 }
 
+
+// C = A . B (A: M x K, B: K x N, both row-major) for small M: the W solve X = Wq^-1 . Wp of the M-step (bsc_et.py:380 via the
+// device inverse) and its relatives.  Same scheme: the A fragment is 32 contiguous bytes per lane and chunk, the B fragment
+// four 8-byte loads that sixteen lanes make contiguous (128 bytes per K row of the tile).
+template <int UNR>
+__global__ __launch_bounds__(64 * SW) void gemm_nn_small_kernel(const double *__restrict__ A, int64_t lda,
+                                                                 const double *__restrict__ B, int64_t ldb,
+                                                                 double *__restrict__ C, int64_t ldc, int M, int N,
+                                                                 int64_t K, int aligned) {
+    __shared__ double s_t[SW][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const int ia = (i0 + r < M) ? i0 + r : M - 1, jb = (j0 + r < N) ? j0 + r : N - 1;
+    const double *pa = A + (int64_t)ia * lda + 4 * kq, *pb = B + (int64_t)(4 * kq) * ldb + jb;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int64_t nch = (K + CH - 1) / CH;
+    for (int64_t c0 = wave; c0 < nch; c0 += (int64_t)SW * UNR) {
+        double a[UNR][4], b[UNR][4];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t c = c0 + (int64_t)u * SW;
+            const int64_t k = (c < nch ? c : nch - 1) * CH;
+            const int64_t kend = (c < nch) ? K - 4 * kq : 0;
+            if (aligned) load4<true>(pa, k, kend, a[u]);
+            else load4<false>(pa, k, kend, a[u]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[u][e] = (k + e < kend) ? pb[(k + e) * ldb] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][e], b[u][e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_t[wave][q][lane] = acc[q];
+    __syncthreads();
+    if (wave != 0) return;
+    const int j = j0 + r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = i0 + kq + 4 * q;
+        double v = s_t[0][q][lane];
+#pragma unroll
+        for (int w = 1; w < SW; ++w) v += s_t[w][q][lane];                 // fixed order
+        if (i < M && j < N) C[(int64_t)i * ldc + j] = v;
+    }
+}
+
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -103,9 +152,36 @@ extern "C" int pm_gemm_nt_small_f64(const double *A, int64_t lda, const double *
     const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16)), block(64 * SW);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool al = al16(A) && al16(B) && lda % 2 == 0 && ldb % 2 == 0 && K % 4 == 0;
-    if (al)
-        hipLaunchKernelGGL(gemm_nt_small_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K, gram);
-    else
-        hipLaunchKernelGGL(gemm_nt_small_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K, gram);
+    const int64_t per_wave = ((K + CH - 1) / CH + SW - 1) / SW;          // chunks per wavefront
+#define PM_NT_SMALL(AL, U) \
+    hipLaunchKernelGGL((gemm_nt_small_kernel<AL, U>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K, gram)
+    if (al) {
+        if (per_wave <= 1) PM_NT_SMALL(true, 1);
+        else if (per_wave <= 2) PM_NT_SMALL(true, 2);
+        else if (per_wave <= 4) PM_NT_SMALL(true, 4);
+        else PM_NT_SMALL(true, 8);
+    } else {
+        if (per_wave <= 2) PM_NT_SMALL(false, 2);
+        else PM_NT_SMALL(false, 8);
+    }
+#undef PM_NT_SMALL
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_gemm_nn_small_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
+                                    int64_t M, int64_t N, int64_t K, void *stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldb < N || ldc < N) return PM_EINVAL;
+    if (M > 1024 || N > 65536) return PM_ERANGE;
+    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16)), block(64 * SW);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int al = (al16(A) && lda % 2 == 0 && K % 4 == 0) ? 1 : 0;
+    const int64_t per_wave = ((K + CH - 1) / CH + SW - 1) / SW;
+#define PM_NN_SMALL(U) \
+    hipLaunchKernelGGL((gemm_nn_small_kernel<U>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K, al)
+    if (per_wave <= 1) PM_NN_SMALL(1);
+    else if (per_wave <= 2) PM_NN_SMALL(2);
+    else if (per_wave <= 4) PM_NN_SMALL(4);
+    else PM_NN_SMALL(8);
+#undef PM_NN_SMALL
     return (int)hipGetLastError();
 }

@@ -451,7 +451,8 @@ extern "C" int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const d
     if (!upper || !inv || !prev_inv || !work || !full || !pivots || n <= 0 || ldu < n || ldo < n || ldp < n) return PM_EINVAL;
     if (n > NMAX) return PM_ERANGE;
     if (ldp != n || ldo != n) return PM_EINVAL;          // the work matrices share one leading dimension with them
-    return launch_warm(upper, ldu, 0, diag_add, n, prev_inv, 0, work, full, inv, 0, pivots, 1, static_cast<hipStream_t>(stream));
+    return launch_warm(upper, ldu, 0, diag_add, n, prev_inv, 0, work, full, inv, 0, pivots, 1, static_cast<hipStream_t>(stream),
+                       0u, pivots + 2);
 }
 
 extern "C" int pm_spd_inverse_warm_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add,

@@ -485,32 +485,34 @@ class DeviceCAModel(CAModel):
             return None
         return {"ykey": res["key"], "W": seed["W"], "Wt": seed["Wt"], "G": seed["G"], "A": seed["A"]}
 
-    def _invert_normal_matrix(self, Wq_u, qdiag):
+    def _invert_normal_matrix(self, Wq_u, qdiag, status=None):
         """Wq = triu(Wq_u) + triu(Wq_u, 1)^T + diag(qdiag) and its inverse, enqueued on the CURRENT stream:
-        ``(Wq, Winv, pivots)`` -- one-workgroup SPD inverse (csrc/spd_inverse.hip) instead of ~40 rocSOLVER launches.
-        Only for device tensors with H <= 256.  It needs nothing but the (all-reduced) second moments, so a caller can
-        run it on a side stream beside the statistics GEMM, which needs nothing but E[s] (BSC_ET.M_step).
+        ``(Wq, Winv, status)`` -- one-workgroup SPD inverse (csrc/spd_inverse.hip) instead of ~40 rocSOLVER launches.
+        Only for device tensors with H <= 256.  ``status`` (3 doubles; ``status``: where to put them, e.g. a slice of the
+        caller's download buffer) = [smallest pivot, largest pivot, accurate]: see ``_solve_normal_eq``.
         From the second call on the previous call's inverse warm-starts a Newton-Schulz refinement
         (pm_spd_inverse_warm_f64: ~40 us instead of the sweep's 0.3 ms when the matrix has moved little -- an EM loop;
-        the device falls back to the sweep by itself otherwise).  ``PM_WARM_INVERSE=0`` disables it."""
+        the device falls back to the sweep by itself otherwise and says so in status[2]).  ``PM_WARM_INVERSE=0`` disables it."""
         H = qdiag.shape[0]
         Wq = torch.empty((H, H), dtype=torch.float64, device=Wq_u.device)
         Winv = torch.empty((H, H), dtype=torch.float64, device=Wq_u.device)
-        piv = torch.empty(2, dtype=torch.float64, device=Wq_u.device)
         prev = getattr(self, "_winv_prev", None)
         warm = (prev is not None and tuple(prev.shape) == (H, H) and prev.device == Wq_u.device
                 and os.environ.get("PM_WARM_INVERSE", "1") == "1")
         if warm:
+            piv = status if status is not None else torch.empty(3, dtype=torch.float64, device=Wq_u.device)
             work = self._buf("spd_warm_work", (int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
+            # (pivots[2] <- the device's own verdict on the warm start: 1 = refinement accepted, 0 = the sweep ran)
             self._call("spd_inverse", "pm_spd_inverse_warm_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(prev), H, _ptr(work),
                        _ptr(Wq), _ptr(Winv), H, _ptr(piv), self._stream())
-            # the device's own verdict on the warm start (1 = refinement accepted, 0 = the sweep ran): travels to the
-            # host with the pivots, see _solve_normal_eq / _solve_accurate
-            self._winv_flag = work[-1:]
         else:
+            if status is not None:
+                piv = status
+                piv[2:] = 1.0
+            else:
+                piv = torch.ones(3, dtype=torch.float64, device=Wq_u.device)
             self._call("spd_inverse", "pm_spd_inverse_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(Wq), _ptr(Winv),
                        H, _ptr(piv), self._stream())
-            self._winv_flag = None
         self._winv_was_warm = warm
         self._winv_prev = Winv
         return Wq, Winv, piv
@@ -521,53 +523,57 @@ class DeviceCAModel(CAModel):
             one = self._one_dev = torch.ones(1, dtype=torch.float64, device=device)
         return one
 
-    def _apply_inverse(self, Wq, Winv, rhs, refine=True):
+    def _apply_inverse(self, Wq, Winv, rhs, refine=True, out=None):
         """X = Winv . rhs with one step of iterative refinement, X += Winv (rhs - Wq X) -- skipped (``refine=False``) behind
-        the warm-started inverse, whose four Newton-Schulz steps already leave ||I - Wq Winv|| at rounding level (or, if
-        the device fell back to the exact sweep, at cond(Wq) eps, what the sweep gives anyway).  Every product is accumulated
-        into a ZEROED buffer and added once: the K-slices of pm_gemm_tn_acc_f64 are summed with f64 atomics, and
-        slices added to a non-zero X in run-to-run order would make ranks that solve the same all-reduced system
-        differ in the last bit (and drift apart over EM steps)."""
+        the warm-started inverse, whose four Newton-Schulz steps already leave ||I - Wq Winv|| at rounding level.  Products
+        run on the deterministic small-GEMM kernel (pm_gemm_nn_small_f64: fixed summation order, no zero fill, no
+        K-slice atomics), so ranks that solve the same all-reduced system stay bitwise identical.  ``out``: where X goes."""
         H, D = rhs.shape
         st = self._stream()
+        X = out if out is not None else torch.empty((H, D), dtype=torch.float64, device=rhs.device)
+        nn = lambda A, B, C: self._call("solve_gemm", "pm_gemm_nn_small_f64", _ptr(A), A.stride(0), _ptr(B), B.stride(0),
+                                        _ptr(C), C.stride(0), A.shape[0], B.shape[1], A.shape[1], st)
         if not refine:
-            X0 = torch.zeros((H, D), dtype=torch.float64, device=rhs.device)
-            self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(rhs), D, _ptr(X0), D, H, D, H, st)
-            return X0
-        XT = torch.zeros((3, H, D), dtype=torch.float64, device=rhs.device)     # X0, Wq.X0 and the correction: one fill
-        X0, T, C = XT[0], XT[1], XT[2]
-        self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(rhs), D, _ptr(X0), D, H, D, H, st)
-        self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Wq), H, _ptr(X0), D, _ptr(T), D, H, D, H, st)
+            nn(Winv, rhs, X)                 # (Winv is symmetric)
+            return X
+        X0 = torch.empty((H, D), dtype=torch.float64, device=rhs.device)
+        T = torch.empty((H, D), dtype=torch.float64, device=rhs.device)
+        nn(Winv, rhs, X0)
+        nn(Wq, X0, T)
         R = rhs - T
-        self._call("solve_gemm", "pm_gemm_tn_acc_f64", _ptr(Winv), H, _ptr(R), D, _ptr(C), D, H, D, H, st)
-        return X0 + C
+        nn(Winv, R, T)
+        torch.add(X0, T, out=X)
+        return X
 
-    def _solve_normal_eq(self, Wq_u, qdiag, rhs, pre=None):
+    def _solve_normal_eq(self, Wq_u, qdiag, rhs, pre=None, out=None, status=None):
         """X = Wq^-1 . rhs, enqueued on the device, for the symmetric second-moment matrix
         Wq = triu(Wq_u) + triu(Wq_u, 1)^T + diag(qdiag) -- the models' ``np.linalg.lstsq(Wq, Wp)``
-        (bsc_et.py:380, dsc_et.py:741).  Returns (X (H,D), pivots (2,) = [smallest, largest pivot of the
-        elimination; smallest <= 0 marks a failed factorisation], Wq (H,H)); the caller fetches the pivots with its
-        one download (``_solve_ok``) and falls back to LAPACK's lstsq on the host when they say "singular".
-        ``pre``: the result of ``_invert_normal_matrix`` when the caller has already run it."""
+        (bsc_et.py:380, dsc_et.py:741).  Returns (X (H,D), status (3,) = [smallest, largest pivot of the elimination --
+        smallest <= 0 marks a failed factorisation --, accurate], Wq (H,H)); the caller fetches the status with its one
+        download, checks the pivots (``_solve_ok``: "singular" -> LAPACK's lstsq on the host) and hands status[2] to
+        ``_solve_accurate``.  ``pre``: the result of ``_invert_normal_matrix`` when the caller has already run it;
+        ``out`` / ``status``: device tensors to write X / the status into (slices of the caller's download buffer)."""
         H, D = rhs.shape
         self._last_solve = None
         if rhs.is_cuda and H <= 256:
-            Wq, Winv, piv = pre if pre is not None else self._invert_normal_matrix(Wq_u, qdiag)
+            Wq, Winv, piv = pre if pre is not None else self._invert_normal_matrix(Wq_u, qdiag, status)
             warm = getattr(self, "_winv_was_warm", False)
-            X = self._apply_inverse(Wq, Winv, rhs, refine=not warm)
+            X = self._apply_inverse(Wq, Winv, rhs, refine=not warm, out=out)
             if warm:
                 # The refinement pass of the solve was skipped on the HOST's guess that the device would accept the warm
                 # start.  The device's verdict rides behind the pivots; a caller that reads "sweep ran" there repeats the
                 # solve with the refinement (_solve_accurate): the accuracy of W no longer depends on the call history.
                 self._last_solve = (Wq, Winv, rhs)
-                return X, [piv, self._winv_flag], Wq
-            return X, [piv, self._one(rhs.device)], Wq
+            return X, piv, Wq
         if rhs.is_cuda:
             # H > 256: the one-workgroup inverse on 256-blocks + Schur complements (the library's own GEMMs; no rocSOLVER)
             Wq = torch.triu(Wq_u, 1)
             Wq = (Wq + Wq.t() + torch.diag(torch.diagonal(Wq_u) + qdiag)).contiguous()
             Winv, pmin, pmax = self._spd_inverse_blocked(Wq)
-            return self._apply_inverse(Wq, Winv, rhs), [torch.stack([pmin, pmax]), self._one(rhs.device)], Wq
+            piv = torch.stack([pmin, pmax, self._one(rhs.device)[0]])
+            if status is not None:
+                status.copy_(piv)
+            return self._apply_inverse(Wq, Winv, rhs, out=out), piv, Wq
         # host tensors: the world_size-2 gloo tests feed CPU statistics through the same finalize code (never the
         # product path, whose statistics live on the device)
         Wq = torch.triu(Wq_u, 1)
@@ -576,14 +582,19 @@ class DeviceCAModel(CAModel):
         d = torch.diagonal(Lc) ** 2                       # squared Cholesky diagonal = the elimination's pivots
         X = torch.cholesky_solve(rhs, Lc).contiguous()    # garbage if the factorisation failed
         piv = torch.stack([torch.where(info.reshape(()) == 0, d.min(), -torch.ones((), dtype=d.dtype, device=d.device)),
-                           d.max()])
-        return X, [piv, self._one(rhs.device)], Wq
+                           d.max(), torch.ones((), dtype=d.dtype, device=d.device)])
+        if out is not None:
+            out.copy_(X)
+            X = out
+        if status is not None:
+            status.copy_(piv)
+        return X, piv, Wq
 
     def _solve_accurate(self, flag):
         """``None`` if the solution `_solve_normal_eq` returned is at full accuracy -- the refined cold solve, or the warm
-        start the device accepted (``flag`` = the word behind the pivots in the download: 1) -- else (the device rejected the
-        warm start and ran the sweep, but the host had skipped the refinement pass) the refined solution X (H,D) as a
-        host array, computed now from the sweep's inverse: X0 + Winv (rhs - Wq X0), exactly what the cold path returns."""
+        start the device accepted (``flag`` = status[2] from the download: 1) -- else (the device rejected the warm start and
+        ran the sweep, but the host had skipped the refinement pass) the refined solution X (H,D) as a host array, computed
+        now from the sweep's inverse: X0 + Winv (rhs - Wq X0), exactly what the cold path returns."""
         last, self._last_solve = getattr(self, "_last_solve", None), None
         if flag != 0.0 or last is None:
             return None

@@ -502,7 +502,10 @@ class BSC_ET(DeviceCAModel):
         mstats, rows = None, 0
         if N and want_ms and self.fuse_mstats and self._fused() and Hp <= 8 and 'mu' not in self.to_learn:
             n_stats = _lib.load().pm_bsc_stats_len(H, D)
-            stats = self._buf("stats", (n_stats,))
+            # two statistics workspaces alternate: the M-step that launches the NEXT E-step (speculation) still reads its
+            # own Wp -- the right-hand side of the W solve, and of the host fallback -- from the other one
+            self._stats_flip = 1 - getattr(self, "_stats_flip", 0)
+            stats = self._buf("stats%d" % self._stats_flip, (n_stats,))
             stats.zero_()
             mstats = (self._buf("expect", (N, H)), stats)
         self._nz = None
@@ -641,12 +644,17 @@ class BSC_ET(DeviceCAModel):
         tracing.tracepoint("M_step:iterating")
         _lib.load()
         n_stats = _lib.load().pm_bsc_stats_len(H, D)
-        stats = self._buf("stats", (n_stats,))
         expect = self._buf("expect", (my_N, H))
         P = self._estep_params(anneal, pies, sigma, mu)
         st = self._stream()
         # statistics the E-step pass has already produced for its first `done` rows (same shard, candidates, scalars)
         ms = getattr(logpj, "mstats", None) if isinstance(logpj, DeviceArray) else None
+        if ms is not None and any(ms["stats"] is self._ws.get("stats%d" % k) for k in (0, 1)):
+            stats = ms["stats"]                       # (the workspace that pass accumulated into: see _launch_estep)
+        else:
+            self._stats_flip = 1 - getattr(self, "_stats_flip", 0)
+            stats = self._buf("stats%d" % self._stats_flip, (n_stats,))
+        self._ws["stats"] = stats                     # (the workspace of THIS M-step, for tools and tests)
         done, nz = 0, None
         if (ms is not None and ms["res"] is res and ms["stats"] is stats and ms["expect"] is expect and ms["cand"] is cand
                 and ms["P"] == (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm) and lse_cut == float("-inf")
@@ -742,7 +750,7 @@ class BSC_ET(DeviceCAModel):
         mus = packed[o_mus:o_sc]
         learn_W, learn_mu = 'W' in self.to_learn, 'mu' in self.to_learn
 
-        parts = [packed[o_mus:o_sc + 4]]          # [mus (H) | 4 scalars], contiguous in the packed buffer; summed on the host
+        head = packed[o_mus:o_sc + 4]             # [mus (H) | 4 scalars], contiguous in the packed buffer; summed on the host
         Wq = rhs = seed = None
         # A plain EM loop on a flat annealing schedule: the scalar statistics travel to the host AHEAD of the W solve, so
         # pi_new / sigma_new are known while the device still inverts Wq, and the next step's E-step is enqueued right
@@ -751,24 +759,33 @@ class BSC_ET(DeviceCAModel):
         if (packed.is_cuda and res is not None and anneal is not None and learn_W and not learn_mu and not np.any(mu)
                 and self._in_step and self._flat_schedule and self._spec_ok and self.speculate and self.speculate_estep
                 and self._state_tables()["fast"] and self._fused()):
-            early = self._download_async(parts[0], slot="mstep_early")
+            early = self._download_async(head, slot="mstep_early")
+        # The download buffer [mus | scalars | status (3) + pad | X (H,D) | data sums (D)]: the inverse writes its status and
+        # the solve its solution straight into it (no torch.cat of 2 MB), on the device.  A fresh tensor every step (the caching
+        # allocator recycles the memory once nothing refers to it): parameter records of earlier steps -- a LazyCandidates
+        # ticket someone still holds -- keep pointing at THEIR W^T.
+        n_head = H + 4
+        o_st, o_x = n_head, n_head + 4
+        n_flat = o_x + (H * D if learn_W else 0) + (D if learn_mu else 0)
+        flat = torch.empty(n_flat, dtype=torch.float64, device=packed.device)
+        if early is None:
+            flat[:n_head] = head
         if learn_W:
             tracing.tracepoint("M_step:update W")
             rhs = Wp
             if np.any(mu):   # Wp was accumulated against y, the reference uses y - mu
                 rhs = Wp - torch.outer(mus, torch.from_numpy(mu).to(packed.device))
             rhs = rhs.contiguous()
-            if early is not None and rhs.data_ptr() == Wp.data_ptr():
-                # the speculative E-step enqueued from then() zeroes and refills the statistics workspace `packed` views
-                # BEFORE the host has looked at the pivots: the host-lstsq fallback below must read its own copy
-                rhs = Wp.clone()
-            X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, rhs, pre)
-            parts += status + [X.reshape(-1)]
+            # (under speculation the next E-step accumulates into the OTHER statistics workspace: Wp stays intact for the
+            # host-lstsq fallback and the repeated solve below)
+            X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, rhs, pre, out=flat[o_x:o_x + H * D].view(H, D),
+                                                  status=flat[o_st:o_st + 3])
+            if pre is not None:
+                flat[o_st:o_st + 3] = status
             if packed.is_cuda and res is not None:   # next step's W^T and Gram matrix are already here: no upload then
-                seed = (X, self._gemm_nt(X, X, self._buf("gram", (H, H)), "gram_gemm"))
+                seed = (X, self._gemm_nt(X, X, torch.empty((H, H), dtype=torch.float64, device=X.device), "gram_gemm"))
         if learn_mu:
-            parts += [packed[n_stats:]]
-        flat = torch.cat(parts)
+            flat[n_flat - D:] = packed[n_stats:]
         if flat.is_cuda:                                        # the one synchronisation of the EM step
             spec = []
             if learn_W:
@@ -780,9 +797,14 @@ class BSC_ET(DeviceCAModel):
                     early[1].synchronize()
                     _, _, _, _, pi_e, sigma_e = self._scalar_updates(early[0], pies, sigma, E_pi_gamma)
                     self._speculate_estep(res, spec[0], anneal, pi_e, sigma_e)
-            host = self._download(flat, slot="mstep", then=then if seed else None)
+            # (under speculation the head has already travelled: `body` then starts behind it)
+            body = self._download(flat if early is None else flat[n_head:], slot="mstep", then=then if seed else None)
+            base = 0 if early is None else n_head
+            host = body if early is None else early[0]
         else:
-            host = flat.numpy()
+            host = body = flat.numpy()
+            base = 0
+        o_st, o_x = o_st - base, o_x - base                     # offsets into `body`
 
         mus_h, my_sigma, Fs, N_use, pi_new, sigma_new = self._scalar_updates(host, pies, sigma, E_pi_gamma)
         dlog.append('N', N_use)
@@ -790,18 +812,17 @@ class BSC_ET(DeviceCAModel):
         L += Fs / N_use
         dlog.append('L', L)
 
-        pos = H + 4
+        pos = o_x
         if learn_W:
-            ok = self._solve_ok(float(host[pos]), float(host[pos + 1]))
-            redo = self._solve_accurate(float(host[pos + 2])) if ok else None
-            pos += 1
+            ok = self._solve_ok(float(body[o_st]), float(body[o_st + 1]))
+            redo = self._solve_accurate(float(body[o_st + 2])) if ok else None
             if redo is not None:
                 # the device rejected the warm start of the inverse and the solve behind it had skipped its refinement
                 # pass: W from the refined solve; whatever was seeded / speculated from the unrefined one is void
                 self._a0 = None
                 W_new = redo
             elif ok:
-                Wt_host = host[pos + 2:pos + 2 + H * D].reshape(H, D)
+                Wt_host = body[o_x:o_x + H * D].reshape(H, D)
                 W_new = Wt_host.copy()
                 if seed is not None:
                     spec[0]["Whost"] = Wt_host
@@ -811,7 +832,7 @@ class BSC_ET(DeviceCAModel):
                 self._winv_prev = None        # never warm-start the next inverse from a rejected one
                 with small_blas():
                     W_new = np.linalg.lstsq(Wq.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0]
-            pos += 2 + H * D
+            pos += H * D
         else:
             W_new = W_DH.T
 
@@ -824,7 +845,7 @@ class BSC_ET(DeviceCAModel):
             tracing.tracepoint("M_step:update mu")
             # the reference divides by the rank-local kept count (bsc_et.py:428), which is only
             # meaningful on one rank; with several ranks the global count is used
-            dsum = host[pos:pos + D]
+            dsum = body[pos:pos + D]
             mu_new = dsum / N_use - np.inner(W_new.T / N_use, mus_h)
         else:
             mu_new = mu

@@ -382,7 +382,7 @@ class DSC_ET(DeviceCAModel):
         if learn_W:
             tracing.tracepoint("M_step:update W")
             X, status, Wq = self._solve_normal_eq(Wq_u, qdiag, Wp.contiguous())
-            parts += status + [X.reshape(-1)]
+            parts += [status, X.reshape(-1)]
         flat = torch.cat(parts)
         self._seed_rec = None
         res = getattr(self, "_mstep_res", None)

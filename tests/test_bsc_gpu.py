@@ -186,7 +186,7 @@ def test_spd_inverse_warm(dev, n, rel):
     work = torch.zeros(int(_lib.load().pm_spd_inverse_warm_work_len(n)), dtype=torch.float64, device=dev)
     full = torch.zeros((n, n), dtype=torch.float64, device=dev)
     inv = torch.zeros((n, n), dtype=torch.float64, device=dev)
-    piv = torch.zeros(2, dtype=torch.float64, device=dev)
+    piv = torch.zeros(3, dtype=torch.float64, device=dev)
     _lib.call("pm_spd_inverse_warm_f64", _p(u), n, _p(da), n, _p(prev), n, _p(work), _p(full), _p(inv), n, _p(piv), _stream())
     np.testing.assert_array_equal(full.cpu().numpy(), Af)
     got, pv = inv.cpu().numpy(), piv.cpu().numpy()
@@ -196,12 +196,14 @@ def test_spd_inverse_warm(dev, n, rel):
         # refined, sweep skipped: conditioning from the inverse's diagonal -- 1 / X_ii is row i's pivot if eliminated
         # last (a lower bound of the sweep's smallest pivot), the largest pivot is at most the largest diagonal entry
         d2 = np.diag(np.linalg.cholesky(Af)) ** 2
-        np.testing.assert_allclose(pv, [1.0 / np.diag(np.linalg.inv(Af)).max(), np.diag(Af).max()], rtol=1e-7)
+        np.testing.assert_allclose(pv[:2], [1.0 / np.diag(np.linalg.inv(Af)).max(), np.diag(Af).max()], rtol=1e-7)
         assert pv[0] <= d2.min() * (1 + 1e-7) and pv[1] >= d2.max() * (1 - 1e-12)
+        assert pv[2] == 1.0                                           # the device's verdict: refinement accepted
         assert np.linalg.norm(np.eye(n) - Af @ got) < max(2.0 * r0 ** 16, 1e-11 * np.linalg.cond(Af))
     elif r0 > 0.1001:
         d2 = np.diag(np.linalg.cholesky(Af)) ** 2                     # the exact sweep ran
-        np.testing.assert_allclose(pv, [d2.min(), d2.max()], rtol=1e-9)
+        np.testing.assert_allclose(pv[:2], [d2.min(), d2.max()], rtol=1e-9)
+        assert pv[2] == 0.0                                           # ... rejected: the caller refines its solve
         ref = np.linalg.inv(Af)
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-14 * np.linalg.cond(Af) * np.abs(ref).max())
     assert rel != 0.5 or r0 > 0.1001 or n == 1
@@ -946,7 +948,7 @@ def test_solve_after_a_rejected_warm_start_is_refined(dev, cond):
         Wq_u = torch.from_numpy(np.triu(A) - np.diag(np.diag(A)) * 0.5).to(dev)       # upper triangle, half the diagonal ...
         qd = torch.from_numpy(np.diag(A) * 0.5).to(dev)                              # ... the other half as diag_add
         X, status, _ = model._solve_normal_eq(Wq_u, qd, torch.from_numpy(B).to(dev))
-        host = torch.cat(status + [X.reshape(-1)]).cpu().numpy()
+        host = torch.cat([status, X.reshape(-1)]).cpu().numpy()
         assert DeviceCAModel._solve_ok(host[0], host[1])
         redo = model._solve_accurate(float(host[2]))
         return (redo if redo is not None else host[3:].reshape(H, D)), float(host[2]), redo is not None
