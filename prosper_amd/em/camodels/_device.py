@@ -558,8 +558,11 @@ class DeviceCAModel(CAModel):
         if rhs.is_cuda and H <= 256:
             Wq, Winv, piv = pre if pre is not None else self._invert_normal_matrix(Wq_u, qdiag, status)
             warm = getattr(self, "_winv_was_warm", False)
-            X = self._apply_inverse(Wq, Winv, rhs, refine=not warm, out=out)
-            if warm:
+            # (after a rejected warm start the next one is likely to be rejected too -- the first EM steps, a jump in the
+            # annealing schedule --: refine right away then instead of finding out from the download and repeating the solve)
+            refine = (not warm) or getattr(self, "_refine_next", False)
+            X = self._apply_inverse(Wq, Winv, rhs, refine=refine, out=out)
+            if not refine:
                 # The refinement pass of the solve was skipped on the HOST's guess that the device would accept the warm
                 # start.  The device's verdict rides behind the pivots; a caller that reads "sweep ran" there repeats the
                 # solve with the refinement (_solve_accurate): the accuracy of W no longer depends on the call history.
@@ -596,10 +599,12 @@ class DeviceCAModel(CAModel):
         ran the sweep, but the host had skipped the refinement pass) the refined solution X (H,D) as a host array, computed
         now from the sweep's inverse: X0 + Winv (rhs - Wq X0), exactly what the cold path returns."""
         last, self._last_solve = getattr(self, "_last_solve", None), None
+        self._refine_next = (flag == 0.0)
         if flag != 0.0 or last is None:
             return None
         Wq, Winv, rhs = last
-        return self._apply_inverse(Wq, Winv, rhs, refine=True).cpu().numpy()
+        self._redo_dev = self._apply_inverse(Wq, Winv, rhs, refine=True)      # (kept: callers seed the next step from it)
+        return self._redo_dev.cpu().numpy()
 
     def _spd_inverse_blocked(self, A):
         """Inverse of a symmetric positive definite device matrix of any size from pm_spd_inverse_f64 (n <= 256, one

@@ -782,8 +782,8 @@ class BSC_ET(DeviceCAModel):
                                                   status=flat[o_st:o_st + 3])
             if pre is not None:
                 flat[o_st:o_st + 3] = status
-            if packed.is_cuda and res is not None:   # next step's W^T and Gram matrix are already here: no upload then
-                seed = (X, self._gemm_nt(X, X, torch.empty((H, H), dtype=torch.float64, device=X.device), "gram_gemm"))
+            if packed.is_cuda and res is not None:   # next step's W^T is already here (its Gram matrix: `then` below)
+                seed = X
         if learn_mu:
             flat[n_flat - D:] = packed[n_stats:]
         if flat.is_cuda:                                        # the one synchronisation of the EM step
@@ -792,13 +792,18 @@ class BSC_ET(DeviceCAModel):
                 self._par = {}                                  # its host snapshot may live in the buffer reused now
                 self._a0 = None
             def then():
-                spec.append(self._seed_params(res, seed[0], seed[1], self._spec_ok and self.speculate))
+                # (The download is on its way -- on the copy stream, a blit kernel of 2 MB that needs CUs: it must get going
+                # BEFORE the next E-step's 1024-thread workgroups fill the chip, or it crawls between them for 0.3 ms and
+                # costs that launch its whole-round tiling.  The Gram matrix and the workspace fill enqueued from here give
+                # it that head start.)
+                G = self._gemm_nt(seed, seed, torch.empty((H, H), dtype=torch.float64, device=seed.device), "gram_gemm")
+                spec.append(self._seed_params(res, seed, G, self._spec_ok and self.speculate))
                 if early is not None:
                     early[1].synchronize()
                     _, _, _, _, pi_e, sigma_e = self._scalar_updates(early[0], pies, sigma, E_pi_gamma)
                     self._speculate_estep(res, spec[0], anneal, pi_e, sigma_e)
             # (under speculation the head has already travelled: `body` then starts behind it)
-            body = self._download(flat if early is None else flat[n_head:], slot="mstep", then=then if seed else None)
+            body = self._download(flat if early is None else flat[n_head:], slot="mstep", then=then if seed is not None else None)
             base = 0 if early is None else n_head
             host = body if early is None else early[0]
         else:
@@ -821,6 +826,13 @@ class BSC_ET(DeviceCAModel):
                 # pass: W from the refined solve; whatever was seeded / speculated from the unrefined one is void
                 self._a0 = None
                 W_new = redo
+                if seed is not None:      # the next step still finds its W^T and Gram matrix on the device
+                    Xr = self._redo_dev
+                    G = self._gemm_nt(Xr, Xr, torch.empty((H, H), dtype=torch.float64, device=Xr.device), "gram_gemm")
+                    par = self._seed_params(res, Xr, G, False)
+                    par["Whost"] = W_new
+                    self._par = par
+                self._spec_estep = None
             elif ok:
                 Wt_host = body[o_x:o_x + H * D].reshape(H, D)
                 W_new = Wt_host.copy()
