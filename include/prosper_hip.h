@@ -485,6 +485,12 @@ int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma);
  * whole buffer once; the documented entries accumulate across calls as before. */
 int64_t pm_gsc_stats_len(int64_t H);
 
+/* The statistics pm_gsc_estep_f64 leaves in `stats` -> [sum xpt_ss (H,H) | sum xpt_szsz (H,H) | sum xpt_s (H) | sum xpt_sz (H)
+ * | sum |y|^2] as the M-step all-reduces them (gsc_et.py:603-610, 662-671): xpt_ss mirrored from its upper triangle with
+ * sum xpt_s on the diagonal, xpt_szsz as accumulated (it is not symmetric once psi_sq is not) plus the singletons' diagonal.
+ * `sum_ynorm2`: device pointer to sum_n |y_n|^2 of the shard.  One launch. */
+int pm_gsc_pack_stats_f64(const double *stats, int64_t H, const double *sum_ynorm2, double *out, void *stream);
+
 /* The H- and H x H-sized tail of GSC's M-step for scalar sigma_sq (gsc_et.py:640-713) and the tables of the next
  * E-step, on the device (one workgroup): pi clip, mu, psi_sq (with (sum_ss + eps I)^-1 from pm_spd_inverse_batch_f64),
  * sigma_sq = (sum |y|^2 - trace(xsz_xsz . gram)) / N / D + eps, gram = W_new^T W_new.  `old` / `params`:

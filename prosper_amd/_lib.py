@@ -112,6 +112,7 @@ SIGNATURES = {
     "pm_wp_sparse_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp]),
     "pm_gsc_supported": (C.c_int, [i64, i64, i64]),
     "pm_gsc_stats_len": (i64, [i64]),
+    "pm_gsc_pack_stats_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp]),
     "pm_gsc_mstep_finish_f64": (C.c_int, [c_dp] * 10 + [C.c_double, i64, i64, C.c_int, c_dp, c_dp, c_dp]),
     "pm_gsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
                                    i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp]),

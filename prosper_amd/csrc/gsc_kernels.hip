@@ -131,7 +131,10 @@ struct GscTables {
 
 // LPJ: also write every state's log-joint (no annealing, prior included -- what compute_lpj returns,
 // gsc_et.py:811-944) to logpj (N, 1 + H + S): [null ; singletons h = 0..H-1 ; multi-cause states in table order].
-template <int VPL, int GMAX, bool LPJ>
+// LACC: the column sums of xpt_s / xpt_sz are accumulated in LDS, one private slot per (datapoint row of the workgroup,
+// latent) -- plain read-add-write, no atomics, no conflicts -- and folded over the rows at the end: no second pass over the
+// N x H moments (gsc_colsum_kernel read 410 MB again at config 4: 0.09 ms).
+template <int VPL, int GMAX, bool LPJ, bool LACC>
 __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict__ scores, int64_t lds,
                                                          const double *__restrict__ gram,
                                                          const double *__restrict__ psi,
@@ -163,6 +166,11 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     // vector-memory operation at all (see the deferred pair atomics below)
     uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_dp + ROWS * dp_stride);
     for (int s = tid; s < S; s += 256) s_masks[s] = masks[s];
+    // LACC: [2][ROWS][H] private accumulators behind the masks (8-byte aligned)
+    double *s_acc = reinterpret_cast<double *>(smem + ((8 * (size_t)(8 * H + ROWS * dp_stride) + 2 * (size_t)S + 7) & ~(size_t)7));
+    if (LACC)
+        for (int e = tid; e < 2 * ROWS * H; e += 256) s_acc[e] = 0.0;
+    double *acc_mine = s_acc + (size_t)(wave * 4 + row) * H + j;        // + 16 i: latent j + 16 i; + ROWS * H: next quantity
     double *s_ac = s_dp + (wave * 4 + row) * dp_stride;   // a at the candidates
     double *s_Gc = s_ac + 16, *s_Pc = s_Gc + HH;
     double *s_ass = s_Pc + HH, *s_aszsz = s_ass + HH;
@@ -445,8 +453,13 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
             if (live && h < H) {
-                xpt_s[n * ldx + h] = xs[i] * nf;
-                xpt_sz[n * ldx + h] = xsz[i] * nf;
+                const double vs = xs[i] * nf, vz = xsz[i] * nf;
+                xpt_s[n * ldx + h] = vs;
+                xpt_sz[n * ldx + h] = vz;
+                if (LACC) {
+                    acc_mine[16 * i] += vs;
+                    acc_mine[ROWS * H + 16 * i] += vz;
+                }
             }
         }
         myc_prev = myc;
@@ -456,10 +469,21 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     }
     flush_pairs(false);
 
-    // flush the singleton diagonal of sum xpt_szsz: lanes of different rows / waves own the same latent, so fold
-    // them in LDS first (the parameter tables are dead by now) and send ONE global atomic per latent and block --
-    // a per-lane flush puts 256 * VPL atomics per block on H addresses and serialises the grid's tail on them.
+    // flush the per-latent sums: lanes of different rows / waves own the same latent, so fold them in LDS first and send ONE
+    // global atomic per latent and block -- a per-lane flush puts 256 * VPL atomics per block on H addresses and serialises
+    // the grid's tail on them.
     __syncthreads();
+    double *g_cs = stats + 2 * (int64_t)H * H;          // [column sums of xpt_s | of xpt_sz | singleton diagonal of sum xpt_szsz]
+    if (LACC) {
+        for (int e = tid; e < 2 * H; e += 256) {
+            const int q = e / H, h = e - q * H;
+            const double *src = s_acc + (size_t)q * ROWS * H + h;
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) v += src[(size_t)r * H];            // fixed order
+            if (v != 0.0) pm_atomic_add(g_cs + e, v);
+        }
+    }
     for (int h = tid; h < H; h += 256) s_c0[h] = 0.0;
     __syncthreads();
 #pragma unroll
@@ -469,7 +493,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         if (row == 0 && h < H) atomicAdd(&s_c0[h], c_d);
     }
     __syncthreads();
-    double *g_dszsz = stats + 2 * (int64_t)H * H + 2 * H;
+    double *g_dszsz = g_cs + 2 * H;
     for (int h = tid; h < H; h += 256)
         if (s_c0[h] != 0.0) pm_atomic_add(g_dszsz + h, s_c0[h]);
 }
@@ -535,6 +559,11 @@ extern "C" int64_t pm_gsc_stats_len(int64_t H) { return 2 * H * H + 3 * H + (PM_
 
 static size_t gsc_shmem(int64_t H, int64_t Hprime, int64_t S) {
     return sizeof(double) * (8 * H + ROWS * (48 + 4 * Hprime * Hprime) + (S + 3) / 4);
+}
+// ... with the per-row accumulators of the column sums behind it (LACC); used when two workgroups still fit a CU (80 KB:
+// the kernel's 244 registers allow two wavefronts per SIMD anyway) -- H <= 128 at H' = 6
+static size_t gsc_shmem_lacc(int64_t H, int64_t Hprime, int64_t S) {
+    return gsc_shmem(H, Hprime, S) + sizeof(double) * (2 * ROWS * H + 1);
 }
 
 extern "C" int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma) {
@@ -650,27 +679,30 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
     if (!pm_gsc_supported(H, Hprime, gamma)) return PM_ERANGE;
     GscTables T{tables, tables + H, tables + 2 * H, tables + 3 * H, tables + 4 * H, tables + 5 * H, tables + 6 * H,
                 tables + 7 * H};
-    const size_t shmem = gsc_shmem(H, Hprime, S);
-    if (shmem > 64 * 1024) return PM_ERANGE;
+    const bool lacc = gsc_shmem_lacc(H, Hprime, S) <= 80 * 1024;
+    const size_t shmem = lacc ? gsc_shmem_lacc(H, Hprime, S) : gsc_shmem(H, Hprime, S);
+    if (gsc_shmem(H, Hprime, S) > 64 * 1024) return PM_ERANGE;
     int64_t groups = (N + ROWS - 1) / ROWS;
     if (groups > 2048) groups = 2048;
     dim3 grid((unsigned)groups), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double inv_s2 = sigma_sq > 0.0 ? 1.0 / sigma_sq : 0.0;   // 0: tables[8 H] holds it (pm_gsc_mstep_finish_f64)
-#define PM_LAUNCH_L(V, G, L)                                                                                        \
-    do {                                                                                                            \
-        if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, L>), shmem)) return e;       \
-        hipLaunchKernelGGL((gsc_estep_kernel<V, G, L>), grid, block, shmem, s, scores, lds, gram, psi_sq, ynorm2, T, \
-                           state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select, cand, xpt_s, xpt_sz, \
-                           ldx, stats, logpj, ldl);                                                                 \
+#define PM_LAUNCH_LA(V, G, L, A)                                                                                        \
+    do {                                                                                                               \
+        if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, L, A>), shmem)) return e;       \
+        hipLaunchKernelGGL((gsc_estep_kernel<V, G, L, A>), grid, block, shmem, s, scores, lds, gram, psi_sq, ynorm2, T, \
+                           state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select, cand, xpt_s, xpt_sz,  \
+                           ldx, stats, logpj, ldl);                                                                    \
     } while (0)
-#define PM_LAUNCH(V, G)                 \
-    do {                                \
-        if (logpj) {                    \
-            PM_LAUNCH_L(V, G, true);    \
-        } else {                        \
-            PM_LAUNCH_L(V, G, false);   \
-        }                               \
+#define PM_LAUNCH(V, G)                         \
+    do {                                        \
+        if (logpj) {                            \
+            PM_LAUNCH_LA(V, G, true, false);    \
+        } else if (lacc) {                      \
+            PM_LAUNCH_LA(V, G, false, true);    \
+        } else {                                \
+            PM_LAUNCH_LA(V, G, false, false);   \
+        }                                       \
     } while (0)
 #define PM_BY_G(V)                            \
     do {                                      \
@@ -688,7 +720,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
     else PM_BY_G(32);
 #undef PM_BY_G
 #undef PM_LAUNCH
-#undef PM_LAUNCH_L
+#undef PM_LAUNCH_LA
     {
         const int64_t rows_per_block = 512;
         const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
@@ -696,9 +728,42 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         const int64_t HH2 = 2 * H * H;
         hipLaunchKernelGGL(pm_fold_copies_kernel, dim3((unsigned)((HH2 + 255) / 256)), dim3(256), 0, s, stats,
                            stats + HH2 + 3 * H, HH2);
-        hipLaunchKernelGGL(gsc_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xpt_s, xpt_sz, ldx, N, (int)H,
-                           rows_per_block, g_cs, g_cs + H);
+        if (!lacc || logpj)
+            hipLaunchKernelGGL(gsc_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xpt_s, xpt_sz, ldx, N, (int)H,
+                               rows_per_block, g_cs, g_cs + H);
     }
+    return (int)hipGetLastError();
+}
+
+// The E-step kernel's statistics buffer [U_ss | U_zz | cs | csz | dzz] -> the M-step's packed layout
+// [sum xpt_ss (H,H) | sum xpt_szsz (H,H) | sum xpt_s (H) | sum xpt_sz (H) | sum |y|^2]: xpt_ss mirrored from its upper
+// triangle with the column sums of xpt_s on the diagonal (s_h^2 = s_h), xpt_szsz as accumulated (both triangles) plus the
+// singletons' diagonal -- one launch instead of eight small tensor operations per EM step (gsc_et.py:603-610, 662-671).
+namespace {
+__global__ __launch_bounds__(256) void gsc_pack_kernel(const double *__restrict__ stats, int H,
+                                                       const double *__restrict__ yy, double *__restrict__ out) {
+    const int64_t HH = (int64_t)H * H;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const double *U_ss = stats, *U_zz = stats + HH, *cs = stats + 2 * HH, *csz = cs + H, *dzz = csz + H;
+    if (e < HH) {
+        const int i = (int)(e / H), j = (int)(e - (int64_t)i * H);
+        out[e] = i < j ? U_ss[e] : (i > j ? U_ss[(int64_t)j * H + i] : cs[i]);
+        out[HH + e] = U_zz[e] + (i == j ? dzz[i] : 0.0);
+    }
+    if (e < H) {
+        out[2 * HH + e] = cs[e];
+        out[2 * HH + H + e] = csz[e];
+    }
+    if (e == 0) out[2 * HH + 2 * H] = yy[0];
+}
+}  // namespace
+
+extern "C" int pm_gsc_pack_stats_f64(const double *stats, int64_t H, const double *sum_ynorm2, double *out, void *stream) {
+    if (!stats || !sum_ynorm2 || !out || H <= 0) return PM_EINVAL;
+    if (H > 512) return PM_ERANGE;
+    const int64_t HH = H * H;
+    hipLaunchKernelGGL(gsc_pack_kernel, dim3((unsigned)((HH + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       stats, (int)H, sum_ynorm2, out);
     return (int)hipGetLastError();
 }
 

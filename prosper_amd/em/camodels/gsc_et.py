@@ -37,12 +37,14 @@ class SummedMoments(object):
     """sum over datapoints of a per-datapoint (H,H) moment (what the M-step consumes of
     ``xpt_ss`` / ``xpt_szsz``).  ``.sum(axis=0)`` returns the (H,H) ndarray."""
 
-    def __init__(self, total, N):
-        self._total = total
-        self.shape = (N,) + tuple(total.shape)
+    def __init__(self, total, N, shape=None):
+        self._total = total                 # the (H,H) tensor, or a function that assembles it on first use
+        self.shape = (N,) + tuple(shape if shape is not None else total.shape)
 
     def sum(self, axis=0):
         assert axis == 0, "only the sum over datapoints exists"
+        if callable(self._total):
+            self._total = self._total()
         return self._total
 
 
@@ -498,11 +500,12 @@ class GSC(DeviceCAModel):
         U_ss = st[:H * H].view(H, H)
         U_zz = st[H * H:2 * H * H].view(H, H)
         cs, csz, dzz = (st[2 * H * H + i * H:2 * H * H + (i + 1) * H] for i in range(3))   # per-XCD scratch follows
-        off = torch.triu(U_ss, 1)
-        sum_ss = off + off.t() + torch.diag(cs)                            # diag(sum xpt_ss) = sum xpt_s
+        def sum_ss():        # (assembled only for a caller that asks: M_step packs both straight from `stats`)
+            off = torch.triu(U_ss, 1)
+            return off + off.t() + torch.diag(cs)                           # diag(sum xpt_ss) = sum xpt_s
         # xpt_szsz = kappa kappa^T + Lambda^-1 is symmetric only while psi_sq is (gsc_et.py:660-675 returns a non-symmetric
         # one): the kernel accumulates both triangles as they are
-        sum_zz = U_zz + torch.diag(dzz)
+        sum_zz = lambda: U_zz + torch.diag(dzz)
         if self.reference_order and isinstance(my_data.get('data_clusters'), LazyClusters):
             # the reference's row order (gsc_et.py:572-573): clusters in order of first appearance
             order = my_data['data_clusters'].order()
@@ -512,8 +515,9 @@ class GSC(DeviceCAModel):
             y = my_data['y']
             my_data['y'] = DeviceArray(y.tensor.index_select(0, idx)) if isinstance(y, DeviceArray) else np.asarray(y)[order]
         out = {'xpt_s': DeviceArray(xs), 'xpt_sz': DeviceArray(xsz),
-               'xpt_ss': SummedMoments(sum_ss, N), 'xpt_szsz': SummedMoments(sum_zz, N)}
+               'xpt_ss': SummedMoments(sum_ss, N, (H, H)), 'xpt_szsz': SummedMoments(sum_zz, N, (H, H))}
         out['_sums'] = (cs, csz)
+        out['_stats'] = (stats, out['xpt_ss'], out['xpt_szsz'])      # M_step: pack from the kernel's buffer in one launch
         return out
 
     @tracing.traced
@@ -547,8 +551,12 @@ class GSC(DeviceCAModel):
         if not paired:
             xs, xsz = xs.contiguous(), xsz.contiguous()
         ldx = xs.stride(0) if my_N else H
-        sum_ss = dev(suff_stats['xpt_ss'].sum(axis=0))
-        sum_zz = dev(suff_stats['xpt_szsz'].sum(axis=0))
+        raw = suff_stats.get('_stats')
+        if not (raw is not None and raw[1] is suff_stats['xpt_ss'] and raw[2] is suff_stats['xpt_szsz'] and my_N
+                and suff_stats.get('_sums') is not None):
+            raw = None                      # moments from outside (or replaced by the caller): the general path
+            sum_ss = dev(suff_stats['xpt_ss'].sum(axis=0))
+            sum_zz = dev(suff_stats['xpt_szsz'].sum(axis=0))
         # packed: [Wp (D,H) | xs^T xsz (H,H) | xsz^T xsz (H,H) | sum_ss | sum_zz | sum_s | sum_sz | sum |y|^2]
         nWp, nHH = D * H, H * H
         n_stat = nWp + 4 * nHH + 2 * H + 1
@@ -575,13 +583,20 @@ class GSC(DeviceCAModel):
                 self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xsz), H, _ptr(xsz), H,
                            ctypes.c_void_p(packed.data_ptr() + 8 * (nWp + nHH)), H, H, H, my_N, s)
         o = nWp + 2 * nHH
-        packed[o:o + nHH] = sum_ss.reshape(-1)
-        packed[o + nHH:o + 2 * nHH] = sum_zz.reshape(-1)
         o2 = o + 2 * nHH
-        sums = suff_stats.get('_sums')               # column sums from the E-step kernel, when it made suff_stats
-        packed[o2:o2 + H] = sums[0] if sums is not None else xs.sum(dim=0)
-        packed[o2 + H:o2 + 2 * H] = sums[1] if sums is not None else xsz.sum(dim=0)
-        packed[o2 + 2 * H] = res["ynorm2"].sum()
+        yy = res.get("ynorm2_sum")                   # sum_n |y_n|^2: a constant of the resident shard
+        if yy is None:
+            yy = res["ynorm2_sum"] = res["ynorm2"].sum().reshape(1)
+        if raw is not None:      # [sum_ss | sum_zz | sum_s | sum_sz | sum |y|^2] straight from the E-step kernel's buffer
+            self._call("pack_stats", "pm_gsc_pack_stats_f64", _ptr(raw[0]), H, _ptr(yy),
+                       ctypes.c_void_p(packed.data_ptr() + 8 * o), self._stream())
+        else:
+            packed[o:o + nHH] = sum_ss.reshape(-1)
+            packed[o + nHH:o + 2 * nHH] = sum_zz.reshape(-1)
+            sums = suff_stats.get('_sums')               # column sums from the E-step kernel, when it made suff_stats
+            packed[o2:o2 + H] = sums[0] if sums is not None else xs.sum(dim=0)
+            packed[o2 + H:o2 + 2 * H] = sums[1] if sums is not None else xsz.sum(dim=0)
+            packed[o2 + 2 * H] = yy[0]
         comm.allreduce_device(packed)      # replaces gsc_et.py:608-610,620,668,671,713
         data_sq = self._data_second_moment(res) if 'sigma_sq' in self.to_learn else None
         st = self._stream()
@@ -606,7 +621,7 @@ class GSC(DeviceCAModel):
             work = self._buf("spd_warm_work", (2 * int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
             self._call("spd_inverse", "pm_inverse_warm_batch_f64", at(o), H, nHH, _ptr(dadd), H, _ptr(prev), nHH,
                        _ptr(work), at(o_inv), nHH, at(o_inv + 2 * nHH), at(o_inv + 2 * nHH + 4), 2, 2, st)
-            self._inv_prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H).clone()
+            self._inv_prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H)     # (`whole` is this step's own tensor: no copy)
         Wt_next = None
         self._seed = None
         if have_inv and 'W' in self.to_learn and self.sigma_sq_type == 'scalar' and self.speculate:
