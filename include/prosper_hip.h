@@ -272,17 +272,16 @@ int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double *Wt, int64
                            int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
                            double *expect, int64_t lde, double *stats, int64_t D_stats, void *stream);
 
-/* The same pass with the 8-wavefront tile (csrc/bsc_fused8.hip): a workgroup still owns 64 datapoints x all latents, but
- * a wavefront accumulates 16 datapoints x 128 latents (<= 128 registers: four wavefronts per SIMD instead of two), wavefront
- * pairs merge their top-H' lists and exchange partial maxima / sums through LDS.  Same arguments, outputs and reference
- * lines (bsc_et.py:98-115, :119-192) as pm_bsc_estep_fused_f64.  Needs pm_bsc_fused8_supported(H, D, Hprime, S):
- * 128 < H <= 256, Hprime <= 8, D a multiple of 8.
- * Where pm_bsc_fused8_whole_shard(H, Hprime, gamma, S) holds (Hprime = 8 and the complete state set of sizes 2 .. gamma,
- * gamma 3 or 4 -- config 2) the call takes a WHOLE shard: whole rounds of resident workgroups run 64-row tiles, a ragged
- * remainder of up to two rounds of 16-row workgroups that split K four ways runs in a second launch (no scores buffer,
- * no separate row kernel), and `stats` / `expect` (the M-step statistics of pm_bsc_estep_fused_f64) are accepted.
- * pm_bsc_fused8_main_rows(N, D): the leading rows the 64-row-tile launch takes.  `part`: 0 both launches, 1 only the
- * 64-row tiles, 2 only the remainder (callers that time or trace the two kernels separately). */
+/* The same pass for config 2's shape class as a 16-wavefront kernel (csrc/bsc_fused8.hip): a workgroup of 1024 threads
+ * owns 128 datapoints x all latents, one per CU; a wavefront accumulates 16 datapoints x 128 latents (<= 128 registers:
+ * four wavefronts per SIMD), the row passes run one half-wavefront per datapoint.  Same arguments, outputs and reference
+ * lines (bsc_et.py:98-115, :119-192) as pm_bsc_estep_fused_f64.  Needs pm_bsc_fused8_supported(H, D, Hprime, S) --
+ * 128 < H <= 256, Hprime = 8, S = 84 or 154, D a multiple of 8 -- and pm_bsc_fused8_whole_shard(H, Hprime, gamma, S): the
+ * complete state set of sizes 2 .. gamma, gamma 3 or 4.  The call takes a WHOLE shard: whole rounds of resident
+ * workgroups run 128-row tiles, a ragged remainder of up to two rounds of 16-row workgroups that split K four ways runs in
+ * a second launch (no scores buffer, no separate row kernel), and `stats` / `expect` (the M-step statistics of
+ * pm_bsc_estep_fused_f64) are accepted.  pm_bsc_fused8_main_rows(N, D): the leading rows the main launch takes.
+ * `part`: 0 both launches, 1 only the main one, 2 only the remainder (callers that time or trace them separately). */
 int pm_bsc_fused8_supported(int64_t H, int64_t D, int64_t Hprime, int64_t S);
 int pm_bsc_fused8_whole_shard(int64_t H, int64_t Hprime, int64_t gamma, int64_t S);
 int64_t pm_bsc_fused8_main_rows(int64_t N, int64_t D);

@@ -117,6 +117,18 @@ __device__ __forceinline__ void sym_inverse(double (&M)[G][G], LogDet &ld) {
 }
 
 
+// The un-stabilised posterior weight exp(x) of the reference (gsc_et.py:354-356: NaN and everything below the smallest
+// normal double become `tiny`) from the 2^(j/128) table (pm_exp_tab: 14 instructions, relative error 2.3e-16; libm's exp
+// is ~45, and a datapoint evaluates 11-12 of them per lane: a tenth of the kernel's instructions).  exp(x) < tiny exactly
+// when x < log(tiny): decided on the argument; arguments above 700 (never seen: a log-joint) take libm.
+__device__ __forceinline__ double gsc_weight(double x, const double *etab) {
+    const double tiny = 2.2250738585072014e-308;
+    if (__builtin_expect(x > 700.0, 0)) return exp(x);
+    double p = pm_exp_tab(x, etab);
+    if (!(x >= -708.3964185322641)) p = tiny;            // (NaN included)
+    return p;
+}
+
 // per-latent tables (H doubles each), prepared on the host per EM step
 struct GscTables {
     const double *c0;    // nc_h - mu_h^2 G_hh / s2,  nc_h = -(log psi_hh + log lam_h)
@@ -171,6 +183,9 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     if (LACC)
         for (int e = tid; e < 2 * ROWS * H; e += 256) s_acc[e] = 0.0;
     double *acc_mine = s_acc + (size_t)(wave * 4 + row) * H + j;        // + 16 i: latent j + 16 i; + ROWS * H: next quantity
+    __shared__ double s_E[128];                           // 2^(j/128): pm_exp_tab's table
+    if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
+    const double *etab = s_E - 256;
     double *s_ac = s_dp + (wave * 4 + row) * dp_stride;   // a at the candidates
     double *s_Gc = s_ac + 16, *s_Pc = s_Gc + HH;
     double *s_ass = s_Pc + HH, *s_aszsz = s_ass + HH;
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         g_sync();
 
         // ---- multi-cause states
-        double Z = (j == 0) ? exp(-yn * inv_s2 * beta) : 0.0;       // null state
+        double Z = (j == 0) ? exp(-yn * inv_s2 * beta) : 0.0;       // null state (not clamped upstream: libm)
         if (LPJ && live && j == 0) logpj[n * ldl] = -yn * inv_s2;
         for (int s0 = 0; s0 < S; s0 += 16) {
             const int s = s0 + j;
@@ -377,8 +392,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
             }
             const double lp = -C_det - r2 * inv_s2 + quad * inv_s2 * inv_s2 + prior;
             if (LPJ && live && valid) logpj[n * ldl + 1 + H + s] = lp;
-            double p = exp(lp * beta);
-            if (p != p || p < tiny) p = tiny;
+            const double p = gsc_weight(lp * beta, etab);
             if (valid) Z += p;
 #pragma unroll
             for (int r = 0; r < GMAX; ++r) {
@@ -412,8 +426,7 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                 const double bb = ai - s_gm[h];
                 const double lp = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h] + s_lpi[h];
                 if (LPJ && live) logpj[n * ldl + 1 + h] = lp;
-                p = exp(lp * beta);
-                if (p != p || p < tiny) p = tiny;
+                p = gsc_weight(lp * beta, etab);
                 Z += p;
             }
             av1[i] = ai;

@@ -235,7 +235,7 @@ class DeviceCAModel(CAModel):
         H, D = self.H, self.D
         lib = _lib.load()
         st = self._stream()
-        sparse = (os.environ.get('PM_SPARSE_WP', '1') == '1' and Y.is_cuda and H <= 256
+        sparse = (getattr(self, "sparse_wp", True) and Y.is_cuda and H <= 256
                   and bool(lib.pm_dsc_rows16_supported(H, Hp, S, K, flags)))
         if sparse:
             nz_idx, nz_val = self._buf("nz_idx", (my_N, 16), torch.int16), self._buf("nz_val", (my_N, 16))

@@ -48,21 +48,19 @@ class BSC_ET(DeviceCAModel):
         self._a0 = None          # (par, data key, rows): whose first-chunk scores the scores_c0 buffer holds
         self._spec_ok = False    # the last M-step's seeded parameters were used as they were
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
-        self.fused_remainder = os.environ.get('PM_GEMM_FUSE_REMAINDER', '1') == '1'   # ragged last round inside the main launch
         self._in_step = False
         self._spec_estep = None  # next step's E-step, launched by the M-step (_speculate_estep)
         self._anneal_sig = None  # annealing point of the previous step() (speculate only on a flat schedule)
         self._flat_schedule = False
         self.spec_hits = 0
         self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
-        self.fuse_mstats = os.environ.get('PM_FUSE_MSTATS', '1') == '1'   # M-step row statistics inside the fused E-step
-        # Wp = E[s]^T Y from the non-zero lists of E[s] the statistics pass leaves (pm_bsc_wp_sparse_f64); the dense
-        # product still runs -- decided on the device -- when a list overflowed
-        self.sparse_wp = os.environ.get('PM_SPARSE_WP', '1') == '1'
-        self.use_fused = os.environ.get('PM_FUSED', '1') == '1'   # scores GEMM + select + E-step as ONE kernel (bsc_fused.hip)
-        self.fused_tile = os.environ.get('PM_FUSED_TILE', 'auto')     # '4' | '8' | 'auto': wavefronts per workgroup of the fused kernel
-        self.overlap_streams = os.environ.get('PM_OVERLAP', '0') == '1'   # GEMM(c+1) beside the row kernel of chunk c
-        self.chunk_rounds = int(os.environ.get("PM_CHUNK_ROUNDS", "0"))   # GEMM rounds per chunk (0 = whole shard)
+        # plain attributes (the tests flip them to compare code paths; no environment switches):
+        self.fuse_mstats = True      # M-step row statistics inside the fused E-step pass
+        self.sparse_wp = True        # Wp = E[s]^T Y from the non-zero lists of E[s] (pm_bsc_wp_sparse_f64); the dense product
+                                     # still runs -- decided on the device -- when a list overflowed
+        self.use_fused = True        # scores GEMM + select + E-step as ONE kernel (bsc_fused8.hip / bsc_fused.hip)
+        self.overlap_streams = False  # two-kernel path: GEMM(c+1) beside the row kernel of chunk c
+        self.chunk_rounds = 0        # two-kernel path: GEMM rounds per chunk (0 = whole shard)
         self.max_chunk_rows = 1 << 20
 
     # ------------------------------------------------------------------ plumbing
@@ -198,8 +196,6 @@ class BSC_ET(DeviceCAModel):
 
     def _tile8_whole_shard(self):
         """The 8-wavefront tile with its lean passes applies (config 2's shape class): one C call per shard."""
-        if self.fused_tile == '4':
-            return False
         lib = _lib.load()
         D8 = (self.D + 7) // 8 * 8
         return bool(lib.pm_bsc_fused8_supported(self.H, D8, self.Hprime, self.no_states)
@@ -221,7 +217,7 @@ class BSC_ET(DeviceCAModel):
             return N          # the 8-wavefront kernels take the whole shard (a TAIL launch for the ragged round)
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         rnd = 2 * cus * 64
-        if N < rnd or os.environ.get("PM_FUSED_SPLIT", "1") != "1":
+        if N < rnd:
             return N
         main = N // rnd * rnd
         return N if (N - main) * 10 >= rnd * 7 else main
@@ -246,18 +242,17 @@ class BSC_ET(DeviceCAModel):
                        Pref, N - main, H, Hp, mode, off(cand, Hp), off(logpj, ldl), ldl, off(lse), st)
         D8 = Y8.shape[1]
         # the 8-wavefront tile (bsc_fused8.hip) where it applies; its M-statistics ride on the lean passes (H' = 8)
-        tile8 = (self.fused_tile != '4' and bool(_lib.load().pm_bsc_fused8_supported(H, D8, Hp, S))
-                 and (mstats is None or self._tile8_whole_shard()))
+        tile8 = self._tile8_whole_shard()
         args = (_ptr(Y8), Y8.stride(0), _ptr(W8), W8.stride(0), _ptr(par["G"]),
                 _ptr(res["ynorm2"]), _ptr(wmu), _ptr(ymu), _ptr(tab["masks"]), _ptr(tab["parents"]), tab["size_off"],
                 S, self.gamma, Pref, main, Y8.shape[1], H, Hp, mode, _ptr(cand), _ptr(logpj), ldl, _ptr(lse),
                 _ptr(mstats[0]) if mstats else None, H, _ptr(mstats[1]) if mstats else None, self.D)
         if tile8:
             # two launches, labelled apart (timers / traces): whole rounds of 64-row tiles, then the ragged remainder
-            main_rows = int(_lib.load().pm_bsc_fused8_main_rows(main, Y8.shape[1])) if self._tile8_whole_shard() else main
+            main_rows = int(_lib.load().pm_bsc_fused8_main_rows(main, Y8.shape[1]))
             entry = "pm_bsc_estep_fused8_f64"
             self._nz = None
-            self._qd_done = bool(mstats) and self._tile8_whole_shard()    # these passes leave qdiag complete (= mus)
+            self._qd_done = bool(mstats)                                  # these passes leave qdiag complete (= mus)
             if mstats and self.sparse_wp and main == N:
                 nz_max = 16                                            # PM_BSC_NZ_MAX
                 nz = (self._buf("nz_idx", (N, nz_max), torch.int16), self._buf("nz_val", (N, nz_max)))
@@ -303,20 +298,14 @@ class BSC_ET(DeviceCAModel):
         if self._a0 is not None and self._a0[0] is par and self._a0[1:] == tag[1:]:
             return A
         stream = torch.cuda.current_stream(self.device)
-        if self.fused_remainder:
-            # one call: pm_gemm_nt_f64 runs whole rounds of tiles and K-slices of the ragged last round in ONE launch
-            self._scores_chunk(res, par, A, 0, N, N, 1, stream)
-        else:
-            rows = min(N, self._chunk_rows(N))
-            self._scores_chunk(res, par, A[:rows], 0, rows, rows, 2 if rows < N else 1, stream)
-            if rows < N:
-                self._scores_chunk(res, par, A[rows:], rows, N, rows, 2, stream)
+        # one call: pm_gemm_nt_f64 runs whole rounds of tiles and K-slices of the ragged last round in ONE launch
+        self._scores_chunk(res, par, A, 0, N, N, 1, stream)
         self._a0 = tag
         return A
 
     def _launch_rows(self, N):
         """Datapoints one ``scores_gemm`` launch covers (bench.py's roofline accounting)."""
-        return N if (self._whole_shard(N) and self.fused_remainder) else min(N, self._chunk_rows(N))
+        return N if self._whole_shard(N) else min(N, self._chunk_rows(N))
 
     def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None, mstats=None):
         """Scores GEMM + fused select/E-step kernel.  Whole-shard mode: the scores of all rows, then ONE pass of

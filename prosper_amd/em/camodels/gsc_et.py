@@ -122,7 +122,7 @@ class GSC(DeviceCAModel):
         self._masks_dev = None
         self._seed = None        # next step's W^T / Gram / scores left on the device by M_step (_speculate)
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
-        self.fuse_moment_gemm = os.environ.get('PM_GSC_FUSE_GEMM', '1') == '1'   # [Y | xs | xsz]^T xsz as one GEMM
+        self.fuse_moment_gemm = True      # [Y | xs | xsz]^T xsz as one GEMM (a plain attribute: tests flip it)
         self._spec = None        # next step's whole E-step, launched by M_step from device-side parameters
         self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
         self.spec_hits = 0

@@ -1,14 +1,21 @@
-// Binary Sparse Coding: scores GEMM + select_Hprimes + E_step (+ the M-step's row statistics) in ONE kernel
-// (bsc_et.py:98-192, 334-366, 395-415), config 2's shape class: H in (128, 256], H' = 8, gamma in {3, 4}.
+// Binary Sparse Coding: scores GEMM + select_Hprimes + E_step in ONE kernel (bsc_et.py:98-192), 8-wavefront tile.
 //
-// A workgroup of SIXTEEN wavefronts owns 128 datapoints x 256 latents (one workgroup per CU): wavefront (rg, half) =
-// (wave & 7, wave >> 3) accumulates datapoints 16 rg .. 16 rg + 15 against latents 128 half .. 128 half + 127 -- 64
-// accumulator registers, <= 128 in total, four wavefronts per SIMD.  K-loop: an LDS-DMA ring (tile16_scores); then four
-// "lean" row passes, each over 32 datapoints: the scores cross from the MFMA layout to one half-wavefront per datapoint
-// through LDS, which owns it from ranking to log-evidence.  A ragged last round of the shard runs in the TAIL
-// instantiation (16-row workgroups of 8 wavefronts that split K four ways).  DESIGN.md section 4.1 has the measurements
-// that shaped this; the variants that lost them (8-wavefront tiles with and without lean passes, 32 x 64 blocks per
-// wavefront, the old LDS swizzle, register-staged TAIL loads, ...) are kept in scratch/bsc_fused8_r03_variants.hip.
+// Same contract as bsc_estep_fused_kernel (bsc_fused.hip); what differs is how a workgroup's 64 datapoints x 256
+// latents are cut.  There a wavefront owns 16 datapoints x ALL latents: 128 accumulator registers, 256 in total, two
+// wavefronts per SIMD -- whenever one of the two is in its row passes the other K-loops alone and every one of its
+// stalls (the hand-over barrier, LDS latency) idles the SIMD.  Here a workgroup has EIGHT wavefronts, wavefront
+// (rg, half) = (wave & 3, wave >> 2) owns datapoints 16 rg .. 16 rg + 15 x latents 128 half .. 128 half + 127:
+// 64 accumulator registers, <= 128 in total, FOUR wavefronts per SIMD (two workgroups of 80 KB LDS per CU as before).
+// The matrix pipe and the vector ALU of a SIMD exclude each other for f64 (scratch/coissue*.hip), so the work per
+// SIMD is the same sum; what the deeper occupancy buys is that a stalled wavefront no longer stalls the SIMD.
+//
+// Row passes.  A datapoint's scores now sit in two wavefronts (the pair (rg,0), (rg,1) -- on the same SIMD).  Work that
+// needs the accumulators stays in the MFMA layout (16 lanes per datapoint, lane j holds latents 128 half + j + 16 i):
+// ranking keys, the per-lane sort, the pop rounds for the half's own top-H', the singleton log-joints.  Everything
+// after it needs only LDS and is dealt by DATAPOINT with 32 lanes each: wavefront (rg, half) merges the two half
+// lists, fetches the Gram block and runs the multi-cause states for datapoint rows 2 half, 2 half + 1 of the pass.
+// Per pass (4 datapoints per pair) three workgroup barriers separate: [keys, sort, pop, singletons] | [merge, fetch,
+// state energies] | [exponentials] | -- the partial maxima / sums cross the pair through LDS.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -27,9 +34,11 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int DK = 8;          // K columns per ring stage
+constexpr int AROWS = 64;      // datapoints per workgroup: 4 row groups x 16
 constexpr int HT = 256;        // latent rows of a stage (H in (128, 256], rows beyond H shadow row H - 1)
 constexpr int NJ = 8;          // 16-latent column blocks per wavefront
-constexpr int THREADS = 512;   // the TAIL workgroup (the main one has 1024)
+constexpr int STAGE = (AROWS + HT) * DK;   // doubles per ring stage (20 KB)
+constexpr int THREADS = 512;
 
 __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -41,7 +50,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Diagnostic builds only (scratch/f8_bench.hip, scratch/f8_variants.sh), never in the shipped library:
+// Diagnostic builds only (scratch/f8_variants.sh), never in the shipped library:
 //   -DPM_F8_STAMPS   per-workgroup timeline (s_memrealtime, 100 MHz) and shader clock over the K-loop
 //   -DPM_F8_ABL=1    K-loop only (no row passes)          =2  row passes behind a K-loop of 8 steps
 //               =3   K-loop without its hand-over barrier (wrong results; what the barrier costs)
@@ -54,7 +63,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 #ifndef PM_F8_SKIP
 #define PM_F8_SKIP 0
 #endif
+// log-joint stores: plain, or (-DPM_F8_NT) non-temporal
+#ifdef PM_F8_NT
+#define F8_STORE(p, v) __builtin_nontemporal_store((v), reinterpret_cast<double *>(p))
+#else
 #define F8_STORE(p, v) (*reinterpret_cast<double *>(p) = (v))
+#endif
 #ifdef PM_F8_STAMPS
 __device__ unsigned long long pm_f8_stamps[8192][8];
 __device__ unsigned long long pm_f8_estamps[16][32];       // workgroup 0's wavefronts: phase stamps inside the row passes
@@ -109,22 +123,296 @@ __device__ __forceinline__ double half_sum_f64(double v) {
     return v;
 }
 
-// The scores block of one wavefront of the 16-wavefront workgroup (128 datapoints x 256 latents; row group wave & 7,
-// latent half wave >> 3): acc[i][r] = <y_n, W_h>, n = m0 + 16 rg + (lane >> 4) + 4 r, h = 128 half + (lane & 15) + 16 i.
+// ---- LDS layout of the row passes (aliases the ring) --------------------------------------------------------------
+//   [ w2 (HT) | sw (HT) | ew (HT) | mus (HT) | 16 datapoint areas | tab (S u32) | st (S x 8 u16) | ik (Hp*Hp u16) ]
+// A datapoint area (one per (row group, row of 16 lanes): the four datapoints a wavefront pair works on per pass):
+//   P    (p_len)  [ zero | d (16) | G (Hp*Hp) | e (S) ], byte-addressed by the state table; during selection the same
+//                 bytes hold the two halves' sorted key lists (2 x 8 x 16 doubles: no sentinel row -- a lane's pointer
+//                 is read at most Hp <= 8 times), after the merge e[0..8) holds the merged winners
+//   win  (16)     the two halves' winners, 8 each, descending
+//   misc (16)     [0..5] partial maxima (3 per pass parity) [6..8] partial sums [9] |y|^2 [12..15] 8 candidates (int32)
+//   row  (HT)     the datapoint's scores as an indexable row
+struct Layout8 {
+    int area, p_len;               // doubles
+    int off_dp, off_tab, off_st, off_ik, bytes;
+};
+__host__ __device__ inline Layout8 make_layout8(int Hp, int S) {
+    Layout8 L;
+    const int p = 17 + Hp * Hp + (S > 8 ? S : 8);
+    L.p_len = p > 256 ? p : 256;
+    L.area = L.p_len + 16 + 16 + HT;
+    L.off_dp = 4 * HT * 8;
+    L.off_tab = L.off_dp + 16 * L.area * 8;
+    L.off_st = (L.off_tab + 4 * S + 15) / 16 * 16;
+    L.off_ik = L.off_st + 16 * S;
+    L.bytes = (L.off_ik + 2 * Hp * Hp + 15) / 16 * 16;
+    return L;
+}
+
+__device__ __forceinline__ void build_tables8(unsigned char *smem, const Layout8 &L, int tid, double ecoef, double ppil,
+                                              const double *__restrict__ gram, const double *__restrict__ wmu, int H,
+                                              const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
+                                              int S, int Hp) {
+    double *w2 = reinterpret_cast<double *>(smem);
+    double *sw = w2 + HT, *ew = w2 + 2 * HT, *mus = w2 + 3 * HT;
+    if (tid < HT) {
+        const int hc = tid < H ? tid : H - 1;
+        const double g = gram[(int64_t)hc * H + hc];
+        const double w = g + (wmu ? 2.0 * wmu[hc] : 0.0);
+        w2[tid] = w;
+        sw[tid] = 1.0 / sqrt(g);   // ranking uses a * (1/|W_h|): keys keep 42 mantissa bits anyway
+        ew[tid] = fma(ecoef, w, ppil);
+        mus[tid] = 0.0;
+    }
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem + L.off_tab);
+    uint16_t *st = reinterpret_cast<uint16_t *>(smem + L.off_st);
+    const int o_d = 8, o_G = 8 * 17, o_e = 8 * (17 + Hp * Hp);
+    for (int s = tid; s < S; s += THREADS) {
+        const uint32_t t = (uint32_t)masks[s] | ((uint32_t)parents[s] << 16);
+        const unsigned mask = t & 0xFFFFu, par = t >> 16;
+        tab[s] = t;
+        const int k = 31 - __builtin_clz(mask);
+        unsigned rest = mask & ~(1u << k);
+        const int g = __builtin_popcount(mask);
+        unsigned e0 = 0, e2 = 0, e3 = 0, e4 = 0;
+        const unsigned e1 = o_d + 8 * k;
+        if (g <= 4) {
+            const int b0 = __builtin_ctz(rest);
+            e0 = (g == 2) ? (unsigned)(o_d + 8 * b0) : (unsigned)(o_e + 8 * par);
+            e2 = o_G + 8 * (b0 * Hp + k);
+            rest &= rest - 1;
+            if (rest) {
+                e3 = o_G + 8 * (__builtin_ctz(rest) * Hp + k);
+                rest &= rest - 1;
+            }
+            if (rest) e4 = o_G + 8 * (__builtin_ctz(rest) * Hp + k);
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(st + s * 8);
+        dst[0] = e0 | (e1 << 16);
+        dst[1] = e2 | (e3 << 16);
+        dst[2] = e4;
+        dst[3] = 0;
+    }
+    uint16_t *ik = reinterpret_cast<uint16_t *>(smem + L.off_ik);
+    for (int p = tid; p < Hp * Hp; p += THREADS) {
+        const int i = p / Hp;
+        ik[p] = (uint16_t)(i | ((p - i * Hp) << 8));
+    }
+}
+
+// The scores block of one wavefront: acc[i][r] = <y_n, W_h>, n = m0 + 16 rg + (lane >> 4) + 4 r, h = 128 half + (lane & 15) + 16 i.
+template <int STAGES>
+__device__ __forceinline__ void tile8_scores(d4 (&acc)[NJ], double *sm, const double *__restrict__ Y, int64_t ldy,
+                                             const double *__restrict__ Wt, int64_t ldw, int D, int64_t N, int H,
+                                             int64_t m0, int lane, int wave) {
+    const int rg = wave & 3, half = wave >> 2;
+    // ---------------- K-loop: LDS-DMA ring, one barrier per K-step ------------------------------------------------
+    // DMA sources: wavefront `wave` moves latent blocks wave and wave + 8; the first four wavefronts also move the
+    // datapoint rows of their row group (3 resp. 2 DMA instructions per K-step: the counted waits are per wavefront).
+    // A stage is [rows][8 doubles]; pair p (16 B) of row R sits in slot p ^ PI(R >> 2) of its row, PI = {0, 3, 2, 1}:
+    // ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 --
+    // and with this permutation every group's 16 fragment reads fall into 16 different bank quads (the plain
+    // p ^ (R >> 2) of the 4-wavefront kernel is two-way conflicted: SQ_LDS_BANK_CONFLICT = half the LDS cycles).
+#ifdef PM_F8_OLDSWZ
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((lane >> 4) & 3);
+#else
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+#endif
+    const char *sbase[3];
+    uint32_t soff[3];
+    {
+        int64_t r0 = m0 + 16 * rg;
+        r0 = r0 < N ? r0 : N - 1;
+        int64_t ra = r0 + dr;
+        ra = ra < N ? ra : N - 1;
+        sbase[0] = reinterpret_cast<const char *>(Y + r0 * ldy);
+        soff[0] = (uint32_t)((ra - r0) * ldy * 8 + 16 * dj);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int b0 = 16 * (wave + 8 * q);
+            b0 = b0 < H ? b0 : H - 1;
+            int rb = b0 + dr;
+            rb = rb < H ? rb : H - 1;
+            sbase[1 + q] = reinterpret_cast<const char *>(Wt + (int64_t)b0 * ldw);
+            soff[1 + q] = (uint32_t)((int64_t)(rb - b0) * ldw * 8 + 16 * dj);
+        }
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) double *)(sm));
+    auto dma1 = [&](unsigned dst, uint32_t voff, const char *base) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(base)
+                     : "memory");
+    };
+
+    // fragment reads: pair p of row R sits at R*8 + ((p ^ ((R>>2)&3)) << 1) (the slot the DMA wrote)
+    const int frow = lane & 15, fk = lane >> 4;
+#ifdef PM_F8_OLDSWZ
+    const int sw = (frow >> 2) & 3;
+#else
+    const int sw = (4 - (frow >> 2)) & 3;
+#endif
+    const int a_off = (rg * 16 + frow) * DK + ((fk ^ sw) << 1);
+    const int b_off = AROWS * DK + (half * 128 + frow) * DK + ((fk ^ sw) << 1);
+    auto read_a = [&](int stage) { return *reinterpret_cast<const d2 *>(sm + stage * STAGE + a_off); };
+    auto read_b = [&](int stage, int g, d2 (&f)[4]) {
+        const double *sb = sm + stage * STAGE + b_off + g * 4 * 16 * DK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const d2 *>(sb + q * 16 * DK);
+    };
+
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+
+#if PM_F8_ABL == 2
+    const int nk = 8;
+#else
+    const int nk = D / DK;   // host guarantees D % DK == 0, D >= DK
+#endif
+    auto kloop = [&](auto withA) {
+        constexpr bool WA = decltype(withA)::value;
+        constexpr int L = WA ? 3 : 2;          // DMA instructions per K-step of this wavefront
+        auto dma = [&](int kt, int stage) {
+            const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8);
+            const int64_t k0 = (int64_t)kt * (DK * 8);
+            if (WA) dma1(dst + (unsigned)rg * 1024u, soff[0], sbase[0] + k0);
+            dma1(dst + (4u + (unsigned)wave) * 1024u, soff[1], sbase[1] + k0);
+            dma1(dst + (12u + (unsigned)wave) * 1024u, soff[2], sbase[2] + k0);
+        };
+#pragma unroll
+        for (int t = 0; t < STAGES; ++t)
+            if (t < nk) dma(t, t);
+        {
+            const int behind = (nk < STAGES ? nk : STAGES) - 1;   // K-steps issued beyond step 0
+            if (behind >= 3) wait_vmcnt<3 * L>();
+            else if (behind == 2) wait_vmcnt<2 * L>();
+            else if (behind == 1) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+
+#ifdef PM_F8_T32
+        // 32 datapoints x 64 latents per wavefront (row half wave & 1, latent quarter wave >> 1): 2 + 4 fragment reads per
+        // 16 MFMAs instead of 1 + 8
+        const int rb2 = wave & 1, cq = wave >> 1;
+        const int a2_off = (rb2 * 32 + frow) * DK + ((fk ^ sw) << 1);
+        const int b2_off = AROWS * DK + (cq * 64 + frow) * DK + ((fk ^ sw) << 1);
+        d2 fa2[2][2], fb2[2][4];
+        auto read_ab = [&](int stage, int p) {
+            const double *sa = sm + stage * STAGE + a2_off;
+            fa2[p][0] = *reinterpret_cast<const d2 *>(sa);
+            fa2[p][1] = *reinterpret_cast<const d2 *>(sa + 16 * DK);
+            const double *sb = sm + stage * STAGE + b2_off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fb2[p][q] = *reinterpret_cast<const d2 *>(sb + q * 16 * DK);
+        };
+        read_ab(0, 0);
+        auto kstep = [&](int t, int stage, int nstage, int par) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1 && t + 1 < nk) {
+                    int ahead = nk - t - 2;
+                    ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ahead >= 2) wait_vmcnt<2 * L>();
+                    else if (ahead == 1) wait_vmcnt<L>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    read_ab(nstage, par ^ 1);
+                    if (t + STAGES < nk) dma(t + STAGES, stage);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa2[par][g].x, fb2[par][q].x, acc[4 * g + q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa2[par][g].y, fb2[par][q].y, acc[4 * g + q]);
+            }
+        };
+#else
+        d2 fa[2];
+        d2 fb[2][4];
+        fa[0] = read_a(0);
+        read_b(0, 0, fb[0]);
+        auto kstep = [&](int t, int stage, int nstage, int par) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 0) {
+                    read_b(stage, 1, fb[1]);
+                } else if (t + 1 < nk) {
+                    // my reads of this stage are done (lgkmcnt) and my share of K-step t+1 has landed (vmcnt); after the
+                    // barrier that holds for every wavefront: stage t may be refilled, t+1 may be read
+                    int ahead = nk - t - 2;
+                    ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef PM_F8_KNOWAIT
+                    if (ahead >= 2) wait_vmcnt<2 * L>();
+                    else if (ahead == 1) wait_vmcnt<L>();
+                    else wait_vmcnt<0>();
+#endif
+#if PM_F8_ABL != 3 && !defined(PM_F8_KNOBAR)
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    const d2 an = read_a(nstage);
+                    if (par) fa[0] = an;
+                    else fa[1] = an;
+                    read_b(nstage, 0, fb[0]);
+#if !defined(PM_F8_KNODMA) && !defined(PM_F8_KDMALATE)
+                    if (t + STAGES < nk) dma(t + STAGES, stage);
+#endif
+                }
+                const d2 af = par ? fa[1] : fa[0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.x, fb[g][q].x, acc[4 * g + q]);
+#if defined(PM_F8_KDMALATE)
+                if (g == 1 && t + 1 < nk && t + STAGES < nk) dma(t + STAGES, stage);
+#endif
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.y, fb[g][q].y, acc[4 * g + q]);
+            }
+        };
+#endif
+        int t = 0;
+        if (STAGES % 2 == 0) {
+            for (; t + STAGES <= nk; t += STAGES) {
+#pragma unroll
+                for (int u = 0; u < STAGES; ++u) kstep(t + u, u, (u + 1) % STAGES, u & 1);
+            }
+        }
+        for (int stage = t % STAGES; t < nk; ++t) {
+            const int nstage = (stage + 1 == STAGES) ? 0 : stage + 1;
+            kstep(t, stage, nstage, t & 1);
+            stage = nstage;
+        }
+    };
+#ifdef PM_F8_PRIO
+    __builtin_amdgcn_s_setprio(PM_F8_PRIO);
+#endif
+    if (half == 0) kloop(std::true_type{});
+    else kloop(std::false_type{});
+#ifdef PM_F8_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+
+}
+
+// The same for the 16-wavefront workgroup (128 datapoints x 256 latents; row group wave & 7, latent half wave >> 3):
+// acc[i][r] = <y_n, W_h>, n = m0 + 16 rg + (lane >> 4) + 4 r, h = 128 half + (lane & 15) + 16 i.
 template <int STAGES>
 __device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const double *__restrict__ Y, int64_t ldy,
                                              const double *__restrict__ Wt, int64_t ldw, int D, int64_t N, int H,
                                              int64_t m0, int lane, int wave) {
     const int rg = wave & 7, half = wave >> 3;
-    constexpr int AROWS = 128, STAGE = (AROWS + HT) * DK;       // doubles per ring stage (24 KB)
+    constexpr int AROWS = 128, STAGE = (AROWS + HT) * DK;       // (shadow the 8-wavefront tile's constants)
     // ---------------- K-loop: LDS-DMA ring, one barrier per K-step ------------------------------------------------
-    // DMA sources: wavefront `wave` moves latent block `wave`; the first eight wavefronts also move the datapoint rows of
-    // their row group (2 resp. 1 DMA instructions per K-step: the counted waits are per wavefront).
+    // DMA sources: wavefront `wave` moves latent blocks wave and wave + 8; the first four wavefronts also move the
+    // datapoint rows of their row group (3 resp. 2 DMA instructions per K-step: the counted waits are per wavefront).
     // A stage is [rows][8 doubles]; pair p (16 B) of row R sits in slot p ^ PI(R >> 2) of its row, PI = {0, 3, 2, 1}:
     // ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 --
     // and with this permutation every group's 16 fragment reads fall into 16 different bank quads (the plain
     // p ^ (R >> 2) of the 4-wavefront kernel is two-way conflicted: SQ_LDS_BANK_CONFLICT = half the LDS cycles).
+#ifdef PM_F8_OLDSWZ
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((lane >> 4) & 3);
+#else
     const int dr = lane >> 2, dj = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+#endif
     const char *sbase[2];
     uint32_t soff[2];
     {
@@ -149,11 +437,23 @@ __device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const d
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(base)
                      : "memory");
     };
-    // (non-temporal loads of the datapoint rows, which are read once, measured +3 % time: DESIGN.md 4.1)
+    // the datapoint rows are read once: non-temporal, so that they do not push W (2 MB, re-read by every tile) out of L2
+    auto dma1_nt = [&](unsigned dst, uint32_t voff, const char *base) {
+#ifdef PM_F8_NTA
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst), "v"(voff), "s"(base)
+                     : "memory");
+#else
+        dma1(dst, voff, base);
+#endif
+    };
 
     // fragment reads: pair p of row R sits at R*8 + ((p ^ ((R>>2)&3)) << 1) (the slot the DMA wrote)
     const int frow = lane & 15, fk = lane >> 4;
+#ifdef PM_F8_OLDSWZ
+    const int sw = (frow >> 2) & 3;
+#else
     const int sw = (4 - (frow >> 2)) & 3;
+#endif
     const int a_off = (rg * 16 + frow) * DK + ((fk ^ sw) << 1);
     const int b_off = AROWS * DK + (half * 128 + frow) * DK + ((fk ^ sw) << 1);
     auto read_a = [&](int stage) { return *reinterpret_cast<const d2 *>(sm + stage * STAGE + a_off); };
@@ -177,7 +477,7 @@ __device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const d
         auto dma = [&](int kt, int stage) {
             const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8);
             const int64_t k0 = (int64_t)kt * (DK * 8);
-            if (WA) dma1(dst + (unsigned)rg * 1024u, soff[0], sbase[0] + k0);
+            if (WA) dma1_nt(dst + (unsigned)rg * 1024u, soff[0], sbase[0] + k0);
             dma1(dst + (8u + (unsigned)wave) * 1024u, soff[1], sbase[1] + k0);
         };
 #pragma unroll
@@ -192,6 +492,43 @@ __device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const d
         }
         __builtin_amdgcn_s_barrier();
 
+#ifdef PM_F8_T32
+        // 32 datapoints x 64 latents per wavefront (row half wave & 1, latent quarter wave >> 1): 2 + 4 fragment reads per
+        // 16 MFMAs instead of 1 + 8
+        const int rb2 = wave & 1, cq = wave >> 1;
+        const int a2_off = (rb2 * 32 + frow) * DK + ((fk ^ sw) << 1);
+        const int b2_off = AROWS * DK + (cq * 64 + frow) * DK + ((fk ^ sw) << 1);
+        d2 fa2[2][2], fb2[2][4];
+        auto read_ab = [&](int stage, int p) {
+            const double *sa = sm + stage * STAGE + a2_off;
+            fa2[p][0] = *reinterpret_cast<const d2 *>(sa);
+            fa2[p][1] = *reinterpret_cast<const d2 *>(sa + 16 * DK);
+            const double *sb = sm + stage * STAGE + b2_off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fb2[p][q] = *reinterpret_cast<const d2 *>(sb + q * 16 * DK);
+        };
+        read_ab(0, 0);
+        auto kstep = [&](int t, int stage, int nstage, int par) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1 && t + 1 < nk) {
+                    int ahead = nk - t - 2;
+                    ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (ahead >= 2) wait_vmcnt<2 * L>();
+                    else if (ahead == 1) wait_vmcnt<L>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    read_ab(nstage, par ^ 1);
+                    if (t + STAGES < nk) dma(t + STAGES, stage);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa2[par][g].x, fb2[par][q].x, acc[4 * g + q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(fa2[par][g].y, fb2[par][q].y, acc[4 * g + q]);
+            }
+        };
+#else
         d2 fa[2];
         d2 fb[2][4];
         fa[0] = read_a(0);
@@ -207,25 +544,33 @@ __device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const d
                     int ahead = nk - t - 2;
                     ahead = ahead < STAGES - 2 ? ahead : STAGES - 2;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef PM_F8_KNOWAIT
                     if (ahead >= 2) wait_vmcnt<2 * L>();
                     else if (ahead == 1) wait_vmcnt<L>();
                     else wait_vmcnt<0>();
-#if PM_F8_ABL != 3
+#endif
+#if PM_F8_ABL != 3 && !defined(PM_F8_KNOBAR)
                     __builtin_amdgcn_s_barrier();
 #endif
                     const d2 an = read_a(nstage);
                     if (par) fa[0] = an;
                     else fa[1] = an;
                     read_b(nstage, 0, fb[0]);
+#if !defined(PM_F8_KNODMA) && !defined(PM_F8_KDMALATE)
                     if (t + STAGES < nk) dma(t + STAGES, stage);
+#endif
                 }
                 const d2 af = par ? fa[1] : fa[0];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.x, fb[g][q].x, acc[4 * g + q]);
+#if defined(PM_F8_KDMALATE)
+                if (g == 1 && t + 1 < nk && t + STAGES < nk) dma(t + STAGES, stage);
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[4 * g + q] = mfma16(af.y, fb[g][q].y, acc[4 * g + q]);
             }
         };
+#endif
         int t = 0;
         if (STAGES % 2 == 0) {
             for (; t + STAGES <= nk; t += STAGES) {
@@ -239,9 +584,336 @@ __device__ __forceinline__ void tile16_scores(d4 (&acc)[NJ], double *sm, const d
             stage = nstage;
         }
     };
+#ifdef PM_F8_PRIO
+    __builtin_amdgcn_s_setprio(PM_F8_PRIO);
+#endif
     if (half == 0) kloop(std::true_type{});
     else kloop(std::false_type{});
+#ifdef PM_F8_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
+}
+
+// FULL: H == 256, no latent-index guards.  MSTATS: the row passes also produce the per-datapoint part of the M-step.
+template <int STAGES, bool FULL, bool MSTATS>
+__global__ __launch_bounds__(THREADS, 4) void bsc_estep_fused8_kernel(
+    const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wt, int64_t ldw, int D,
+    const double *__restrict__ gram, const double *__restrict__ ynorm2, const double *__restrict__ wmu,
+    const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
+    SizeOffsets so, int S, int gamma, pm_bsc_estep_params P, int64_t N, int H, int Hp, int mode,
+    int32_t *__restrict__ cand, double *__restrict__ logpj, int64_t ldl, double *__restrict__ lse,
+    double *__restrict__ expect, int64_t lde, double *__restrict__ stats, int Dstats) {
+    extern __shared__ __attribute__((aligned(1024))) double sm[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave & 3, half = wave >> 2;
+    const int64_t m0 = (int64_t)blockIdx.x * AROWS;
+    F8_STAMP(0);
+#ifdef PM_F8_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && blockIdx.x < 8192)
+        pm_f8_stamps[blockIdx.x][7] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                                      __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+#endif
+
+    d4 acc[NJ];
+    tile8_scores<STAGES>(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
+    const int frow = lane & 15, fk = lane >> 4;
+    F8_STAMP(1);
+#ifdef PM_F8_STAMPS
+    if (tid == 0 && blockIdx.x < 8192) pm_f8_stamps[blockIdx.x][6] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
+#if PM_F8_ABL == 1
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) s += (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
+        if (s == 1.2345e300) lse[0] = s;
+        return;
+    }
+#endif
+    // ---------------- epilogue: the row passes -----------------------------------------------------------------------
+    __builtin_amdgcn_s_barrier();        // every wavefront is done with the ring
+    unsigned char *smem = reinterpret_cast<unsigned char *>(sm);
+    const Layout8 lay = make_layout8(Hp, S);
+    const double ppil = P.prior_scale * P.pil_bar, ecoef = P.ecoef;
+    build_tables8(smem, lay, tid, ecoef, ppil, gram, wmu, H, masks, parents, S, Hp);
+    lds_barrier();
+
+    F8_STAMP(2);
+    const double *t_w2 = reinterpret_cast<const double *>(smem);
+    const double *t_sw = t_w2 + HT, *t_ew = t_w2 + 2 * HT;
+    double *t_mus = reinterpret_cast<double *>(smem) + 3 * HT;
+    const uint32_t *t_tab = reinterpret_cast<const uint32_t *>(smem + lay.off_tab);
+    const uint16_t *t_st = reinterpret_cast<const uint16_t *>(smem + lay.off_st);
+    const uint16_t *t_ik = reinterpret_cast<const uint16_t *>(smem + lay.off_ik);
+    double *areas = reinterpret_cast<double *>(smem + lay.off_dp);
+
+    // MFMA-layout view: row fk (16 lanes) of this wavefront holds datapoint m0 + 16 rg + fk + 4 r in element r of every
+    // accumulator; lane j16 of the row holds latents 128 half + j16 + 16 i.
+    const int j16 = frow;
+    double *aS = areas + (rg * 4 + fk) * lay.area;
+    double *winS = aS + lay.p_len, *miscS = winS + 16, *rowS = miscS + 16;
+    // by-datapoint view: lanes 32 dsel .. 32 dsel + 31 of this wavefront work on datapoint row 2 half + dsel of the pass
+    const int j32 = lane & 31, dsel = lane >> 5;
+    const int mrow = 2 * half + dsel;
+    double *aM = areas + (rg * 4 + mrow) * lay.area;
+    double *winM = aM + lay.p_len, *miscM = winM + 16, *rowM = miscM + 16;
+    double *Pd = aM + 1, *PG = aM + 17, *Pe = aM + 17 + Hp * Hp;
+    const unsigned char *Pb = reinterpret_cast<const unsigned char *>(aM);
+    int *clM = reinterpret_cast<int *>(miscM + 12);
+
+    const double m2e = -2.0 * ecoef;
+    const double inv_ecoef = 1.0 / ecoef;
+    const bool sel = mode & 1, est = mode & 2;
+
+    // |y|^2 of the four datapoints of this lane's row, fetched now
+    double yns[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int64_t n = m0 + 16 * rg + fk + 4 * r;
+        n = n < N ? n : N - 1;
+        double v = ynorm2[n];
+        if (ymu) v = v - 2.0 * ymu[n] + P.mu_sqnorm;
+        yns[r] = v;
+    }
+
+    double mx_prev = 0.0;          // finalizer lanes: the maximum of the previous pass
+    int64_t n_prev = 0;
+    MAcc macc{0.0, 0.0, 0.0};
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int par3 = 3 * (r & 1);
+        // ================= phase 1 (MFMA layout): scores row, keys, sort, pop rounds, singleton log-joints ===========
+        const int64_t nS = m0 + 16 * rg + fk + 4 * r;
+        const bool liveS = nS < N;
+        const int64_t nnS = liveS ? nS : N - 1;
+        const double yn = yns[r];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) rowS[half * 128 + j16 + 16 * i] = acc[i][r];
+        if (sel) {
+            double key[NJ];
+            bool odd = false;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const int h = half * 128 + j16 + 16 * i;
+                const double x = acc[i][r] * t_sw[h];
+                odd |= __builtin_amdgcn_class(x, 0x207);         // NaN, -inf, +inf
+                const uint64_t b = (uint64_t)__double_as_longlong(x);
+                const uint32_t flip = (uint32_t)((int32_t)(b >> 32) >> 31) & 0x3FFu;
+                const uint32_t code = (uint32_t)h ^ flip;
+                const uint64_t kb = (b & ~0x3FFull) | code;
+                key[i] = (FULL || h < H) ? __longlong_as_double((long long)kb) : -INFINITY;
+            }
+            if (__any(odd)) {   // rare: redo the keys of non-finite scores (see row_select)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    const int h = half * 128 + j16 + 16 * i;
+                    const double x = acc[i][r] * t_sw[h];
+                    uint64_t b = (uint64_t)__double_as_longlong(x);
+                    if (x != x) b = 0xFFEFFFFFFFFFFC00ull;
+                    else if ((b & 0x7FF0000000000000ull) == 0x7FF0000000000000ull)
+                        b = (b & 0x8000000000000000ull) | 0x7FEFFFFFFFFFF800ull;
+                    const uint64_t code = (uint64_t)h;
+                    b = (b & ~0x3FFull) | ((b >> 63) ? 0x3FFull - code : code);
+                    if (FULL || h < H) key[i] = __longlong_as_double((long long)b);
+                }
+            }
+            sort_desc<NJ>(key);
+            double *list = aS + half * 128 + j16;
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) list[t * 16] = key[t];
+            wave_lds_sync16();
+            int ptr = 0;
+            for (int q = 0; q < Hp; ++q) {
+                const double head = list[ptr * 16];
+                const double m = row_max_f64(head);
+                winS[half * 8 + q] = m;              // the same value from all 16 lanes
+                ptr += (head == m) ? 1 : 0;
+            }
+        }
+        double mxs = -INFINITY;
+        const double f0 = ecoef * yn;
+        if (est) {
+            double *out = logpj + nnS * ldl;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {   // the accumulator element becomes the singleton log-joint of latent h
+                const int h = half * 128 + j16 + 16 * i;
+                double f = -1.0e300;     // no latent: never the maximum, never counted
+                if (FULL || h < H) {
+                    f = fma(m2e, acc[i][r], t_ew[h]) + f0;
+                    if (liveS) out[1 + h] = f;
+                }
+                acc[i][r] = f;
+                mxs = vmax64(mxs, f);
+            }
+            if (half == 0 && j16 == 0) {
+                if (liveS) out[0] = f0;
+                mxs = vmax64(mxs, f0);
+                miscS[9] = yn;
+            }
+            mxs = row_max_f64(mxs);
+            if (j16 == 0) miscS[par3 + half] = mxs;
+        }
+        lds_barrier();                                                                                // ---- B1
+        // the previous pass's log-evidence (its partial sums were published before the barrier that ended it)
+        // ================= phase 2 (by datapoint): merge, candidates, Gram block, state energies ====================
+        const int64_t nM = m0 + 16 * rg + mrow + 4 * r;
+        const bool liveM = nM < N;
+        const int64_t nnM = liveM ? nM : N - 1;
+        int myc = 0;
+        if (sel) {
+            // ranks in the union of the two descending lists: position in the own list + entries of the other list
+            // that are larger (keys are distinct: they carry the latent index)
+            const int hl = (j32 >> 3) & 1, t = j32 & 7;
+            const bool valid = j32 < 16 && t < Hp;
+            const double key = winM[hl * 8 + (t < Hp ? t : 0)];
+            int cnt = 0;
+            for (int u = 0; u < Hp; ++u) cnt += (winM[(1 - hl) * 8 + u] > key) ? 1 : 0;
+            const int rank = t + cnt;
+            if (valid && rank < Hp) Pe[rank] = key;
+            wave_lds_sync16();
+            if (j32 < Hp) {
+                const uint64_t mb = (uint64_t)__double_as_longlong(Pe[Hp - 1 - j32]);    // ascending: best last
+                const int code = (int)(mb & 0x3FFull);
+                myc = (mb >> 63) ? 0x3FF - code : code;
+                if (liveM) cand[nM * Hp + j32] = myc;
+            }
+        } else if (j32 < Hp) {
+            myc = cand[nnM * Hp + j32];
+        }
+        double mxm = -INFINITY;
+        double ynM = 0.0;
+        if (est) {
+            if (j32 < Hp) clM[j32] = myc;
+            wave_lds_sync16();
+            const int c = (j32 < Hp) ? myc : 0;
+            const double gdiag = gram[(int64_t)c * H + c];
+            const double wmuc = wmu ? wmu[c] : 0.0;
+            const double ac = rowM[c];
+            double Gv[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int p = 32 * it + j32;
+                const bool valid = p < Hp * Hp;
+                const unsigned ik = valid ? t_ik[p] : 0u;
+                const int ci = clM[ik & 0xFF], ck = clM[ik >> 8];
+                Gv[it] = (32 * it < Hp * Hp) ? gram[(int64_t)ci * H + ck] : 0.0;
+            }
+            ynM = miscM[9];
+            if (j32 == 0) aM[0] = 0.0;
+            if (j32 < Hp) Pd[j32] = gdiag - 2.0 * (ac - wmuc);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int p = 32 * it + j32;
+                if (p < Hp * Hp) PG[p] = Gv[it];
+            }
+            wave_lds_sync16();
+            double *out = logpj + nnM * ldl;
+            for (int g = 2; g <= gamma; ++g) {
+                const double pg = ppil * (double)g;
+                const int s1 = so.off[g - 1];
+                if (g <= 4) {
+                    for (int s = so.off[g - 2] + j32; s < s1; s += 32) {
+                        const uint16_t *t = t_st + s * 8;
+                        const double e = (*reinterpret_cast<const double *>(Pb + t[0]) +
+                                          *reinterpret_cast<const double *>(Pb + t[1])) +
+                                         2.0 * ((*reinterpret_cast<const double *>(Pb + t[2]) +
+                                                 *reinterpret_cast<const double *>(Pb + t[3])) +
+                                                *reinterpret_cast<const double *>(Pb + t[4]));
+                        Pe[s] = e;
+                        const double f = fma(ecoef, ynM + e, pg);
+                        if (liveM) out[1 + H + s] = f;
+                        mxm = vmax64(mxm, f);
+                    }
+                } else {
+                    for (int s = so.off[g - 2] + j32; s < s1; s += 32) {
+                        const uint32_t t = t_tab[s];
+                        const unsigned mask = t & 0xFFFFu;
+                        const int k = 31 - __builtin_clz(mask);  // highest candidate position of the state
+                        unsigned rest = mask & ~(1u << k);
+                        double off = 0.0;
+                        while (rest) {
+                            const int i = __builtin_ctz(rest);
+                            rest &= rest - 1;
+                            off += PG[i * Hp + k];
+                        }
+                        const double e = (Pe[t >> 16] + Pd[k]) + 2.0 * off;
+                        Pe[s] = e;
+                        const double f = fma(ecoef, ynM + e, pg);
+                        if (liveM) out[1 + H + s] = f;
+                        mxm = vmax64(mxm, f);
+                    }
+                }
+                wave_lds_sync16();
+            }
+            mxm = half_max_f64(mxm);
+            if (j32 == 0) miscM[par3 + 2] = mxm;
+        }
+        if (!est || !lse) {
+            lds_barrier();       // (the areas are rewritten by the next pass)
+            continue;
+        }
+        lds_barrier();                                                                                // ---- B3
+        // ================= phase 3: exponentials of the terms within exp(-37) of the maximum =======================
+        {
+            const double mx = vmax64(vmax64(miscS[par3], miscS[par3 + 1]), miscS[par3 + 2]);
+            const double thr = mx + NEGLIGIBLE;
+            double sum = 0.0;
+            if (half == 0) {
+                const bool need = (j16 == 0) && f0 > thr;
+                if (__any(need)) sum = need ? exp_neg(f0 - mx) : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const bool need = acc[i][r] > thr;
+                if (__any(need)) sum += need ? exp_neg(acc[i][r] - mx) : 0.0;
+            }
+            sum = row_sum_f64(sum);
+            if (j16 == 0) miscS[6 + half] = sum;
+            mx_prev = mx;
+            n_prev = nS;
+        }
+        {
+            const double mx = vmax64(vmax64(miscM[par3], miscM[par3 + 1]), miscM[par3 + 2]);
+            const double thr = mx + NEGLIGIBLE;
+            double sum = 0.0;
+            for (int g = 2; g <= gamma; ++g) {
+                const double pg = ppil * (double)g;
+                const double te = (thr - pg) * inv_ecoef - ynM;
+                const int s0 = so.off[g - 2], s1 = so.off[g - 1];
+                for (int sb = s0; sb < s1; sb += 32) {  // uniform trip count
+                    const int s = sb + j32;
+                    const double e = Pe[s < s1 ? s : s1 - 1];
+                    const bool need = (s < s1) && (ecoef < 0.0 ? e < te : e > te);
+                    if (__any(need)) {
+                        const double f = fma(ecoef, ynM + e, pg);
+                        sum += (need && f > thr) ? exp_neg(f - mx) : 0.0;
+                    }
+                }
+            }
+            sum = half_sum_f64(sum);
+            if (j32 == 0) miscM[8] = sum;
+        }
+        lds_barrier();                                                                                // ---- B4
+        if (half == 0) {
+            const double total = (miscS[6] + miscS[7]) + miscS[8];
+            const double lse_n = mx_prev + log_ge1(total);
+            if (j16 == 0 && n_prev < N) lse[n_prev] = lse_n;
+        }
+    }
+    F8_STAMP(3);
+    F8_STAMP(4);
+    (void)macc;
+    (void)t_w2;
+    (void)t_mus;
+    (void)expect;
+    (void)lde;
+    (void)stats;
+    (void)Dstats;
 }
 
 // =====================================================================================================================
@@ -311,13 +983,65 @@ __device__ __forceinline__ double exp_lds(double x, const double *E, const doubl
 
 // The ragged last round (TAIL kernels): a workgroup owns 16 datapoints x 256 latents and splits K four ways --
 // wavefront (kq, half) = (wave & 3, wave >> 2) accumulates latents 128 half .. over K-steps [kq nk/4, (kq+1) nk/4).  A
-// whole-rounds launch leaves N mod 32768 rows (3392 of 200 000 at config 2), for which 128-row tiles would run 27
-// workgroups on 27 of 256 CUs for a full tile time; 16-row tiles make 212 workgroups of a quarter of the K-loop each.
-constexpr int TAIL_ROWS = 16, TAIL_DK = 8;
-// No operand is shared between wavefronts, so every wavefront streams its own through a PRIVATE two-stage LDS ring
-// filled by LDS-DMA (a CU pulls ~25-30 GB/s from L2 into registers with vector loads -- the first version, 0.082 ms --,
-// 2-3 times that into LDS): stage = [A chunk | 8 latent chunks] x 1 KB = 9 KB, 2 stages x 8 wavefronts = 144 KB (one
-// workgroup per CU).  No barrier in the loop: nothing is shared.
+// whole-rounds launch leaves N mod 32768 rows (3392 of 200 000 at config 2) for which 64-row tiles would run 53 workgroups on 53
+// of 256 CUs for a full tile time; 16-row tiles make 212 workgroups of a quarter of the K-loop each.  No operand is
+// shared between wavefronts here, so nothing goes through LDS and nothing synchronises: every lane loads its own MFMA
+// operands from global memory (L2: W is 2 MB), PD K-steps ahead in registers (1 workgroup per CU: 256 registers).
+constexpr int TAIL_ROWS = 16, TAIL_PD = 3, TAIL_DK = 8;
+__device__ __forceinline__ void tail8_scores(d4 (&acc)[NJ], const double *__restrict__ Y, int64_t ldy,
+                                             const double *__restrict__ Wt, int64_t ldw, int D, int64_t N, int H,
+                                             int64_t m0, int lane, int wave) {
+    // (Measured: 16-column steps with one whole 128-byte line per row and request are SLOWER -- 104 vs 74 us for 3392
+    // rows; what bounds this loop is the ~30 GB/s a CU pulls from L2 into registers at this occupancy: every workgroup
+    // reads all of W, 2 MB.)
+    const int kq = wave & 3, half = wave >> 2;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int nk = D / TAIL_DK;
+    const int t0 = (kq * nk) / 4, t1 = ((kq + 1) * nk) / 4;
+    int64_t ra = m0 + frow;
+    ra = ra < N ? ra : N - 1;
+    const char *pa = reinterpret_cast<const char *>(Y + ra * ldy) + 16 * fk;
+    const char *wb = reinterpret_cast<const char *>(Wt) + 16 * fk;
+    uint32_t boff[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        int rb = half * 128 + 16 * i + frow;
+        rb = rb < H ? rb : H - 1;
+        boff[i] = (uint32_t)rb * (uint32_t)ldw * 8u;
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    d2 fa[TAIL_PD], fb[TAIL_PD][NJ];
+    auto load = [&](int t, int u) {
+        const int64_t k0 = (int64_t)t * (TAIL_DK * 8);
+        fa[u] = *reinterpret_cast<const d2 *>(pa + k0);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) fb[u][i] = *reinterpret_cast<const d2 *>(wb + k0 + boff[i]);
+    };
+#pragma unroll
+    for (int u = 0; u < TAIL_PD; ++u)
+        if (t0 + u < t1) load(t0 + u, u);
+    for (int t = t0; t < t1; t += TAIL_PD) {
+#pragma unroll
+        for (int u = 0; u < TAIL_PD; ++u) {
+            if (t + u < t1) {
+                const d2 a = fa[u];
+                d2 b[NJ];
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) b[i] = fb[u][i];
+                if (t + u + TAIL_PD < t1) load(t + u + TAIL_PD, u);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) acc[i] = mfma16(a.x, b[i].x, acc[i]);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) acc[i] = mfma16(a.y, b[i].y, acc[i]);
+            }
+        }
+    }
+}
+
+// The same K-quarter per wavefront, operands through a PRIVATE two-stage LDS ring per wavefront filled by LDS-DMA (a CU
+// pulls ~25-30 GB/s from L2 into registers with vector loads, 2-3 times that into LDS): stage = [A chunk | 8 latent
+// chunks] x 1 KB = 9 KB, 2 stages x 8 wavefronts = 144 KB (one workgroup per CU).  No barrier: nothing is shared.
 constexpr int TAIL_STAGE_BYTES = 9 * 1024, TAIL_RING_BYTES = 8 * 2 * TAIL_STAGE_BYTES;
 __device__ __forceinline__ void tail8_scores_dma(d4 (&acc)[NJ], double *sm, const double *__restrict__ Y, int64_t ldy,
                                                  const double *__restrict__ Wt, int64_t ldw, int D, int64_t N, int H,
@@ -383,8 +1107,16 @@ __device__ __forceinline__ void tail8_scores_dma(d4 (&acc)[NJ], double *sm, cons
 // take 118 us instead of the 21 us they need alone, and the lone K-loop 144 us instead of the 109 us two K-loops take per
 // tile when they share a SIMD.  One workgroup keeps all 16 wavefronts in the same phase: an MFMA-bound K-loop over
 // 128 rows (W fetched once per 128 rows), then row passes at full vector rate.
-template <int STAGES, int HP, int GAMMA, bool FULL, bool MSTATS, bool TAIL>
-__global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep_fused8s_kernel(
+#ifdef PM_F8_W8
+constexpr bool W16_DEFAULT = false;
+#else
+constexpr bool W16_DEFAULT = true;
+#endif
+#ifdef PM_F8_WQX
+__device__ double pm_f8_wqx[7 * 65536];
+#endif
+template <int STAGES, int HP, int GAMMA, bool FULL, bool MSTATS, bool TAIL, bool W16 = (W16_DEFAULT && !TAIL)>
+__global__ __launch_bounds__(W16 ? 1024 : THREADS, TAIL ? 2 : 4) void bsc_estep_fused8s_kernel(
     const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wt, int64_t ldw, int D,
     const double *__restrict__ gram, const double *__restrict__ ynorm2, const double *__restrict__ wmu,
     const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
@@ -392,8 +1124,7 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
     int64_t ldl, double *__restrict__ lse, double *__restrict__ expect, int64_t lde, double *__restrict__ stats,
     int Dstats, int64_t row0, uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val) {
     using SS = StateSet<HP, GAMMA>;
-    constexpr bool W16 = !TAIL;                       // the main launch: sixteen wavefronts, 128 datapoints
-    constexpr int TILE_ROWS = TAIL ? TAIL_ROWS : 128, NPASS = TAIL ? 1 : 4;
+    constexpr int TILE_ROWS = TAIL ? TAIL_ROWS : (W16 ? 128 : AROWS), NPASS = TAIL ? 1 : 4;
     constexpr int NWAVES = W16 ? 16 : 8, RGMASK = W16 ? 7 : 3, HSHIFT = W16 ? 3 : 2;
     constexpr int S = SS::S;
     constexpr int O_D = 8, O_G = 8 * 9, O_E = 8 * (9 + HP * HP);          // byte offsets inside P = [zero | d | G | e]
@@ -414,8 +1145,12 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
 #endif
     d4 acc[NJ];
     if (TAIL) {
+#ifdef PM_F8_TAILREG
+        tail8_scores(acc, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
+#else
         tail8_scores_dma(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
         lds_barrier();                   // the rings become the reduction scratch
+#endif
         // the four K-quarters of a latent half summed in a fixed order, (q0 + q2) + (q1 + q3), through 64 KB of LDS
         double *red = sm + (size_t)((wave & 1) + 2 * half) * (NJ * 4 * 64) + lane;      // [slot][i][r][lane]
         if (rg >= 2) {
@@ -446,8 +1181,10 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][r] += red2[(i * 4 + r) * 64];
         }
-    } else {
+    } else if (W16) {
         tile16_scores<STAGES>(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
+    } else {
+        tile8_scores<STAGES>(acc, sm, Y, ldy, Wt, ldw, D, N, H, m0, lane, wave);
     }
     F8_STAMP(1);
 #ifdef PM_F8_STAMPS
@@ -554,6 +1291,9 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
     // M-step statistics (MSTATS): E[s] rows, the candidates' second-moment block -> Wq, column sums, scalars
     char *exp_t = MSTATS ? reinterpret_cast<char *>(expect + m0 * lde) : nullptr;
     double *wq = MSTATS ? stats + pm_bsc_stats_offset_wq_dev(H, Dstats) : nullptr;
+#ifdef PM_F8_WQX   // (timing experiment: every XCD adds into its own copy of Wq; the copies are not folded)
+    if (MSTATS && pm_xcc_id()) wq = pm_f8_wqx + (size_t)(pm_xcc_id() - 1) * 65536;
+#endif
     double *t_mus = reinterpret_cast<double *>(smem + T_MUS);
     const uint32_t *t_tab = reinterpret_cast<const uint32_t *>(smem + T_TAB);
     double m_sig = 0.0, m_fs = 0.0, m_cnt = 0.0;        // per-lane partial sums of the scalar statistics
@@ -948,6 +1688,13 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <int ST>
+size_t fused8_lds_bytes(int64_t Hp, int64_t S) {
+    const size_t ring = sizeof(double) * ST * STAGE;
+    const size_t epi = (size_t)make_layout8((int)Hp, (int)S).bytes;
+    return ring > epi ? ring : epi;
+}
+
 }  // namespace pm_fused8
 
 using namespace pm_fused8;
@@ -961,28 +1708,39 @@ extern "C" int pm_f8_read_estamps(unsigned long long *host) {
 }
 #endif
 
-// The kernel covers config 2's shape class: 128 < H <= 256 latents, H' = 8 candidates, the complete state set of sizes
-// 2 .. gamma for gamma in {3, 4} (what generate_state_matrix builds: S = 84 / 154), D a multiple of 8.  Everything else
-// takes the 4-wavefront kernel of bsc_fused.hip or the two-kernel path.
+// The 8-wavefront tile covers 128 < H <= 256 latents, H' <= 8 candidates, states that fit the datapoint areas with two
+// workgroups per CU, D a multiple of 8.
 extern "C" int pm_bsc_fused8_supported(int64_t H, int64_t D, int64_t Hprime, int64_t S) {
-    if (H <= 128 || H > 256 || D < DK || D % DK != 0 || Hprime != 8) return 0;
-    return (S == StateSet<8, 4>::S || S == StateSet<8, 3>::S) ? 1 : 0;
+    if (H <= 128 || H > 256 || D < DK || D % DK != 0 || Hprime <= 0 || Hprime > 8 || Hprime > H || S < 0 || S > 4096)
+        return 0;
+    return make_layout8((int)Hprime, (int)S).bytes <= 80 * 1024 ? 1 : 0;
 }
 
-// pm_bsc_estep_fused8_f64 takes a WHOLE shard in one call -- whole rounds of 128-row tiles plus the TAIL kernel for a
-// ragged remainder -- and also produces the M-step statistics when asked.
-// Leading rows of an N-row shard the main launch takes (the TAIL launch takes the rest): whole rounds of resident
-// workgroups (one per CU); everything when the ragged round is mostly full (>= 70 %) or too large for two rounds of 16-row
-// workgroups.
+#ifdef PM_F8_GENERIC
+static const bool pm_f8_force_generic = true;
+#else
+static const bool pm_f8_force_generic = false;
+#endif
+#ifdef PM_F8_NO_TAIL
+static const bool pm_f8_force_no_tail = true;
+#else
+static const bool pm_f8_force_no_tail = false;
+#endif
+
+// The lean passes apply (H' = 8, the complete state set of sizes 2 .. gamma, gamma in {3, 4}): pm_bsc_estep_fused8_f64
+// then takes a WHOLE shard in one call -- whole rounds of 64-row tiles plus the TAIL kernel for a ragged remainder -- and
+// also produces the M-step statistics when asked.
+// Leading rows of an N-row shard the 64-row-tile launch takes (the TAIL launch takes the rest): whole rounds of resident
+// workgroups; everything when the ragged round is mostly full (>= 70 %) or too large for two rounds of 16-row workgroups.
 extern "C" int64_t pm_bsc_fused8_main_rows(int64_t N, int64_t D) {
     if (N <= 0) return 0;
-    if (D % TAIL_DK != 0) return N;
+    if (D % TAIL_DK != 0) return N;                   // (the TAIL kernel walks K in steps of 16 columns)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus <= 0) cus = 256;
-    const int64_t rnd = (int64_t)cus * 128;
+    const int64_t rnd = 2 * (int64_t)cus * AROWS;
     const int64_t main_rows = N / rnd * rnd, rest = N - main_rows;
-    if (rest * 10 >= rnd * 7 || rest > 2 * (int64_t)cus * TAIL_ROWS) return N;
+    if (pm_f8_force_no_tail || rest * 10 >= rnd * 7 || rest > 2 * (int64_t)cus * TAIL_ROWS) return N;
     return main_rows;
 }
 
@@ -1023,21 +1781,44 @@ extern "C" int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const do
     if (stats && (!expect || lde < H || !lse || !(mode & 2) || D_stats <= 0)) return PM_EINVAL;
     if (!aligned16(Y) || !aligned16(Wt) || (ldy % 2) || (ldw % 2)) return PM_EINVAL;
     if (N == 0) return PM_OK;
-    pm_bsc_estep_params P = params_host ? *params_host : pm_bsc_estep_params{0, 0, 0, 0};
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // H' = 8 and the complete state set of sizes 2 .. gamma (what generate_state_matrix builds), in its order
-    if (!pm_bsc_fused8_whole_shard(H, Hprime, gamma, S)) return PM_ERANGE;
+    SizeOffsets so;
+    for (int g = 0; g < PM_MAX_HPRIME; ++g) so.off[g] = (int)S;
     if ((mode & 2) && S > 0)
+        for (int g = 0; g < gamma; ++g) so.off[g] = size_offsets_host[g];  // off[g-2] = first state of size g
+    pm_bsc_estep_params P = params_host ? *params_host : pm_bsc_estep_params{0, 0, 0, 0};
+    const int64_t tiles = (N + AROWS - 1) / AROWS;
+    if (tiles > INT32_MAX) return PM_ERANGE;
+    dim3 grid((unsigned)tiles), block(THREADS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t shmem = fused8_lds_bytes<4>(Hprime, S);
+#define PM_LAUNCH8(F)                                                                                                  \
+    do {                                                                                                               \
+        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8_kernel<4, F, false>),     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))                  \
+            return e;                                                                                                  \
+        hipLaunchKernelGGL((bsc_estep_fused8_kernel<4, F, false>), grid, block, shmem, s, Y, ldy, Wt, ldw, (int)D,     \
+                           gram, ynorm2, wmu, ymu, state_masks, state_parents, so, (int)S, (int)gamma, P, N, (int)H,  \
+                           (int)Hprime, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats);                \
+    } while (0)
+    // the lean passes: H' = 8 and the complete state set of sizes 2 .. gamma (what generate_state_matrix builds)
+#ifdef PM_F8_ONE_WG   // (diagnostic: one workgroup per CU)
+    const size_t shmem_s = 100 * 1024;
+#else
+    const size_t shmem_s = W16_DEFAULT ? (size_t)LEAN16_LDS_BYTES      // (>= the ring: 4 stages x 24 KB)
+                                       : (sizeof(double) * 4 * STAGE > (size_t)LEAN_LDS_BYTES ? sizeof(double) * 4 * STAGE
+                                                                                                : (size_t)LEAN_LDS_BYTES);
+#endif
+    const bool lean_ok = pm_bsc_fused8_whole_shard(H, Hprime, gamma, S) && !pm_f8_force_generic;
+    if (lean_ok && (mode & 2) && S > 0)
         for (int g = 2; g <= gamma; ++g)
             if (size_offsets_host[g - 2] != (gamma == 4 ? StateSet<8, 4>::off(g) : StateSet<8, 3>::off(g))) return PM_EINVAL;
-    const size_t shmem_s = (size_t)LEAN16_LDS_BYTES;      // (>= the ring: 4 stages x 24 KB)
 #define PM_LAUNCH8SMT(G, F, M, T, GRID, SH, NN, R0)                                                                    \
     do {                                                                                                               \
         if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SH)))                   \
             return e;                                                                                                  \
         hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), dim3((unsigned)(GRID)),                       \
-                           dim3((T) ? THREADS : 1024), (SH), s, Y, ldy,                                                \
+                           dim3((!(T) && W16_DEFAULT) ? 1024 : THREADS), (SH), s, Y, ldy,                              \
                            Wt, ldw, (int)D, gram, ynorm2, wmu, ymu, state_masks, state_parents, P, (int64_t)(NN),    \
                            (int)H, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, (int64_t)(R0),      \
                            nz_idx, nz_val);                                                                            \
@@ -1060,18 +1841,30 @@ extern "C" int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const do
             else PM_LAUNCH8ST(3, false, T, GRID, SH, NN, R0);           \
         }                                                               \
     } while (0)
-    {
-        // Whole rounds of resident workgroups (one 128-row tile per CU) go to the main launch; a ragged last round that
-        // fills most of a round stays with it; a small remainder (up to two rounds of 16-row workgroups) goes to the TAIL
-        // kernel, whose workgroups split K four ways; anything in between is cheaper as a partial round of tiles.
+    if (lean_ok) {
+        // Whole rounds of resident workgroups (2 per CU x 64 datapoints) go to the 64-row tiles; a ragged last round that
+        // fills most of a round stays with them; a small remainder (up to two rounds of 16-row workgroups) goes to the
+        // TAIL kernel, whose workgroups split K four ways; anything in between is cheaper as a partial round of tiles.
         const int64_t main_rows = pm_bsc_fused8_main_rows(N, D);
         const int64_t rest = N - main_rows;
-        if (main_rows > 0 && part != 2) PM_LAUNCH8SGF(false, (main_rows + 127) / 128, shmem_s, main_rows, 0);
+        constexpr int MROWS = W16_DEFAULT ? 128 : AROWS;
+        if (main_rows > 0 && part != 2) PM_LAUNCH8SGF(false, (main_rows + MROWS - 1) / MROWS, shmem_s, main_rows, 0);
+#ifdef PM_F8_TAILREG
+        const size_t shmem_t = (size_t)LEAN_LDS_BYTES;
+#else
         const size_t shmem_t = (size_t)TAIL_RING_BYTES > (size_t)LEAN_LDS_BYTES ? (size_t)TAIL_RING_BYTES : (size_t)LEAN_LDS_BYTES;
+#endif
         if (rest > 0 && part != 1) PM_LAUNCH8SGF(true, (rest + TAIL_ROWS - 1) / TAIL_ROWS, shmem_t, N, main_rows);
-    }
+    } else if (part == 2) {
+        return PM_OK;                                   // (no TAIL launch outside the lean passes)
+    } else if (stats) {
+        return PM_ERANGE;                               // (M-statistics ride on the lean passes only)
+    } else if (H == 256) PM_LAUNCH8(true);
+    else PM_LAUNCH8(false);
 #undef PM_LAUNCH8SGF
 #undef PM_LAUNCH8ST
 #undef PM_LAUNCH8SMT
+
+#undef PM_LAUNCH8
     return (int)hipGetLastError();
 }

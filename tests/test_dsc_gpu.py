@@ -225,13 +225,13 @@ def test_sparse_wp_from_nonzero_lists(model, T, monkeypatch):
     W0 = W_gt + 0.1 * rng.normal(size=(D, H))
     out = {}
     for sparse in ("1", "0"):
-        monkeypatch.setenv("PM_SPARSE_WP", sparse)
         if model == "dsc":
             m = DSC_ET(D, H, Hp, gamma, states=np.array([-1., 0., 1.]))
             p = {"W": W0, "pi": np.array([1.5 / H, 1 - 3.0 / H, 1.5 / H]), "sigma": 1.0}
         else:
             m = TSC_ET(D, H, Hp, gamma)
             p = {"W": W0, "pi": 3.0 / H, "sigma": 1.0}
+        m.sparse_wp = sparse == "1"
         names = []
         orig = m._call
         m._call = lambda label, name, *a, _o=orig, _n=names: (_n.append(name), _o(label, name, *a))[1]
