@@ -807,7 +807,7 @@ int launch_mstep_hp(int hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, 
                     const double *Wrho, const double *Wrm1, const int32_t *cand, const uint16_t *masks, int S,
                     pm_mca_params P, int64_t N, int H, int D, int d0, int Dl, double *q1, int64_t ldq, double *stats) {
     const int Hp = hp;
-    hp = hp <= 4 ? 4 : hp <= 8 ? 8 : 12;
+    hp = hp <= 4 ? 4 : hp <= 8 ? 8 : hp <= 12 ? 12 : 16;
 #define PM_CASE(HPV)                                                                                              \
     case HPV: {                                                                                                   \
         if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_mstep_rows_kernel<DPL, HPV, SIGNED>), shmem)) return e; \
@@ -817,6 +817,14 @@ int launch_mstep_hp(int hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, 
     }
     switch (hp) {
         PM_CASE(4) PM_CASE(8) PM_CASE(12)
+        case 16:      // (V[16][DPL <= 2]: slabs of 128 observed dimensions)
+            if (DPL <= 2) {
+                if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_mstep_rows_kernel<(DPL <= 2 ? DPL : 1), 16, SIGNED>), shmem)) return e;
+                hipLaunchKernelGGL((mca_mstep_rows_kernel<(DPL <= 2 ? DPL : 1), 16, SIGNED>), grid, block, shmem, s, logpj, ldl, lse1,
+                                   lseb, lse_cut, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, d0, Dl, Hp, q1, ldq, stats);
+                return (int)hipGetLastError();
+            }
+            return PM_ERANGE;
         default: return PM_ERANGE;
     }
 #undef PM_CASE
@@ -832,10 +840,10 @@ extern "C" int pm_mca_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
     if (!logpj || !lse1 || !lseb || !Y || !Wrho || !Wrm1 || !cand || !params_host || !q1 || !stats || N < 0 ||
         H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || ldl < 1 + H + S || ldy < D || ldq < H || (S > 0 && !state_masks))
         return PM_EINVAL;
-    if (D > (1 << 20) || Hprime > 12 || Hprime > H || S > 65535) return PM_ERANGE;
-    const int hp_tile = Hprime <= 4 ? 4 : Hprime <= 8 ? 8 : 12;
+    if (D > (1 << 20) || Hprime > PM_MAX_HPRIME || Hprime > H || S > 65535) return PM_ERANGE;
+    const int hp_tile = Hprime <= 4 ? 4 : Hprime <= 8 ? 8 : Hprime <= 12 ? 12 : 16;
     // observed dimensions are walked in slabs whose V[HP][DPL] register tile stays within 48 doubles per lane
-    const int dpl_max = hp_tile == 12 ? 4 : 8;
+    const int dpl_max = hp_tile == 16 ? 2 : hp_tile == 12 ? 4 : 8;
     const int slab = 64 * dpl_max;
     const bool sgn = params_host->signed_w != 0.0;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -472,6 +472,82 @@ class GSC(DeviceCAModel):
         cand, _, _, _ = self._run(1.0, model_params, res, None, logpj=logpj)
         return DeviceArray(logpj), DeviceArray(cand, np.int64)
 
+    @tracing.traced
+    def compute_posterior_hprime(self, anneal, model_params, my_data):
+        """gsc_et.py:260-398: for ONE data cluster -- ``my_data['y']`` (n, D), all rows sharing the candidate set
+        ``my_data['candidates']`` (Hprime,) -- the un-normalised sums over the multi-cause states of the truncated space:
+        ``{'pstr_s' (n,H), 'pstr_ss' (n,H,H), 'pstr_sz' (n,H), 'pstr_szsz' (n,H,H), 'post_nfac_n' (n,)}`` as NumPy arrays
+        (the reference's E_step accumulates them per cluster, :550, then adds the null and one-cause states and normalises).
+        The training path never calls it: ``E_step`` produces the normalised moments of every datapoint in one kernel pass
+        and only ever forms the (H,H) SUMS of the second moments -- this method materialises them per datapoint, so it is
+        for cluster-sized inputs.  The state weights exp(beta lp) come from the E-step kernel's log-joint output
+        (pm_gsc_estep_lpj_f64, candidates handed in); kappa and Lambda^-1 of a state depend on the cluster only through
+        its candidates and are small dense algebra on the device."""
+        self._require_scalar()
+        y = np.asarray(my_data['y'], dtype=np.float64)
+        if y.ndim == 1:
+            y = y[None, :] if y.shape[0] == self.D else y[:, None]
+        n, D, H, Hp, S = y.shape[0], self.D, self.H, self.Hprime, self.no_states
+        comps = np.asarray(my_data['candidates']).astype(np.int64).reshape(-1)
+        assert comps.shape == (Hp,) and y.shape[1] == D
+        beta = 1. / anneal['T']
+        tiny = np.finfo(np.float64).tiny
+        dev = self.device
+        out = {'pstr_s': np.zeros((n, H)), 'pstr_ss': np.zeros((n, H, H)), 'pstr_sz': np.zeros((n, H)),
+               'pstr_szsz': np.zeros((n, H, H)), 'post_nfac_n': np.zeros(n)}
+        if n == 0 or S == 0:
+            return out
+        # log-joints of the states over the SORTED candidates (the kernel's enumeration)
+        order = np.argsort(comps, kind="stable")
+        sorted_c = comps[order]
+        res = self._resident(y)
+        cand_in = self._device_candidates(np.tile(sorted_c[None, :], (n, 1)), n)
+        logpj = torch.empty((n, 1 + H + S), dtype=torch.float64, device=dev)
+        self._run(1.0, model_params, res, cand_in, logpj=logpj)
+        lp = logpj[:, 1 + H:]
+        SM = self.state_matrix.astype(bool)
+        rank = np.empty(Hp, dtype=np.int64)
+        rank[order] = np.arange(Hp)                     # position of caller's candidate j among the sorted ones
+        index_of = {tuple(np.nonzero(row)[0]): i for i, row in enumerate(SM)}
+        W = torch.from_numpy(np.asarray(model_params['W'], dtype=np.float64)).to(dev)
+        mu = torch.from_numpy(np.asarray(model_params['mu'], dtype=np.float64)).to(dev)
+        psi = torch.from_numpy(np.asarray(model_params['psi_sq'], dtype=np.float64)).to(dev)
+        sig = np.asarray(model_params['sigma_sq'], dtype=np.float64)
+        Y = res["Y"]
+        P_s = torch.zeros((n, H), dtype=torch.float64, device=dev)
+        P_sz = torch.zeros_like(P_s)
+        P_ss = torch.zeros((n, H, H), dtype=torch.float64, device=dev)
+        P_zz = torch.zeros_like(P_ss)
+        nfac = torch.zeros(n, dtype=torch.float64, device=dev)
+        if sig.ndim == 2:
+            Sinv = torch.linalg.inv(torch.from_numpy(sig).to(dev))
+        for s_i, row in enumerate(SM):
+            a = np.nonzero(row)[0]                       # active positions in the CALLER's candidate order
+            lat = torch.from_numpy(comps[a]).to(dev)
+            k_i = index_of[tuple(sorted(rank[a]))]       # the same set of latents in the kernel's enumeration
+            post = torch.exp(lp[:, k_i] * beta)
+            post = torch.where(torch.isnan(post) | (post < tiny), torch.full_like(post, tiny), post)
+            W_s, mu_s = W[:, lat], mu[lat]
+            psi_s = psi[lat][:, lat]
+            if sig.ndim == 0:
+                sW = W_s / float(sig)
+            elif sig.ndim == 1:
+                sW = W_s / torch.from_numpy(sig).to(dev)[:, None]
+            else:
+                sW = Sinv @ W_s
+            lam_inv = torch.linalg.inv(sW.t() @ W_s + torch.linalg.inv(psi_s))
+            kappa = (Y - (W_s @ mu_s)[None, :]) @ (lam_inv @ sW.t()).t() + mu_s[None, :]
+            ksq = kappa[:, :, None] * kappa[:, None, :] + lam_inv[None, :, :]
+            nfac += post
+            P_s[:, lat] += post[:, None]
+            P_sz[:, lat] += kappa * post[:, None]
+            ii, jj = torch.meshgrid(lat, lat, indexing="ij")
+            P_ss[:, ii, jj] += post[:, None, None]
+            P_zz[:, ii, jj] += ksq * post[:, None, None]
+        out = {'pstr_s': P_s.cpu().numpy(), 'pstr_ss': P_ss.cpu().numpy(), 'pstr_sz': P_sz.cpu().numpy(),
+               'pstr_szsz': P_zz.cpu().numpy(), 'post_nfac_n': nfac.cpu().numpy()}
+        return out
+
     def candidates(self, model_params, my_data):
         """Sorted candidates (N, Hprime) on their own (np.asarray-able)."""
         res = self._resident(my_data['y'])

@@ -192,6 +192,45 @@ def mmca_inference_case():
     print("mmca_inference: adaptive gamma max %d, Hprime max %d" % (out["adaptive_gamma"].max(), out["adaptive_Hprime"].max()))
 
 
+def gsc_posterior_hprime_case():
+    """GSC.compute_posterior_hprime (gsc_et.py:260-398) on one data cluster -- the un-normalised sums over the multi-cause
+    states E_step accumulates per cluster (:550) -- for a scalar and a full noise model, with a psi_sq that has been
+    through an M-step (non-symmetric), T != 1."""
+    out = {}
+    for tag, sigma_type, seed in (("scalar", "scalar", 71), ("full", "full", 72)):
+        D, H, Hp, gamma, N, T = 20, 10, 4, 3, 60, 1.3
+        rng = np.random.RandomState(seed)
+        W_gt = rng.normal(size=(D, H))
+        s = rng.random_sample((N, H)) <= 0.2
+        y = np.where(s, 1.5 + rng.normal(size=(N, H)), 0.0) @ W_gt.T + rng.normal(size=(N, D))
+        params = {"W": W_gt + 0.2 * rng.normal(size=(D, H)), "pi": np.full(H, 0.2), "mu": 1.5 + 0.2 * rng.normal(size=H),
+                  "psi_sq": np.diag(rng.uniform(0.6, 1.6, size=H)), "sigma_sq": 1.3}
+        if sigma_type == "full":
+            Qs = 0.15 * rng.normal(size=(D, D))
+            params["sigma_sq"] = np.diag(rng.uniform(0.8, 1.8, size=D)) + Qs @ Qs.T
+        model = GSC(D, H, Hp, gamma, sigma_type)
+        anneal = FixedAnneal(T=T)
+        d0 = model.select_Hprimes(params, {"y": y.copy()})
+        params = model.M_step(anneal, params, model.E_step(anneal, params, d0), d0)      # -> non-symmetric psi_sq
+        params = {k: np.array(params[k], copy=True) for k in ("W", "pi", "mu", "psi_sq", "sigma_sq")}
+        data = model.select_Hprimes(params, {"y": y.copy()})
+        key = max(data["data_clusters"], key=lambda k: data["data_clusters"][k]["data"].shape[0])
+        cl = data["data_clusters"][key]
+        if sigma_type == "full":
+            sinv = np.linalg.inv(params["sigma_sq"])
+            B = sinv
+        else:
+            sinv = 1. / params["sigma_sq"]
+            B = sinv * np.eye(D)
+        mp = dict(params, sigma_sq_inv=sinv, B=B)
+        res = model.compute_posterior_hprime(anneal, mp, {"y": cl["data"].copy(), "candidates": cl["hprimes"].copy()})
+        out.update({tag + "_" + k: np.asarray(v) for k, v in params.items()})
+        out.update({tag + "_y": cl["data"], tag + "_cand": np.asarray(cl["hprimes"]).astype(np.int64)})
+        out.update({tag + "_" + k: np.asarray(v, dtype=np.float64) for k, v in res.items()})
+        print("gsc_posterior_hprime %s: cluster of %d rows, candidates %s" % (tag, cl["data"].shape[0], cl["hprimes"]))
+    np.savez_compressed(os.path.join(HERE, "gsc_posterior_hprime.npz"), D=20, H=10, Hprime=4, gamma=3, T=1.3, **out)
+
+
 def gsc_inference_case():
     """CAModel.inference of GSC through its own compute_lpj (gsc_et.py:811-944), plus component_scores
     (gsc_et.py:752-809) of the same parameters."""
@@ -545,7 +584,8 @@ def main(only=None, cases=None):
     want = lambda fn: only is None or fn.__name__.startswith(only)
     g = globals()
     for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
-               "mca_inference_case", "mmca_inference_case", "gsc_inference_case", "bsc_trajectory", "bsc_init", "anneal_tracks"):
+               "mca_inference_case", "mmca_inference_case", "gsc_inference_case", "gsc_posterior_hprime_case", "bsc_trajectory",
+               "bsc_init", "anneal_tracks"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
     if cases:
@@ -602,6 +642,7 @@ def main(only=None, cases=None):
     mca_inference_case()
     mmca_inference_case()
     gsc_inference_case()
+    gsc_posterior_hprime_case()
     bsc_trajectory()
     bsc_init()
     anneal_tracks()

@@ -160,6 +160,33 @@ def test_gsc_step_matches_oracle(D, H, Hp, gamma, N, T):
         np.testing.assert_allclose(new[k], ref[k], rtol=10 * tol, atol=tol * max(1.0, np.abs(ref[k]).max()), err_msg=k)
 
 
+@pytest.mark.parametrize("tag", ["scalar", "full"])
+def test_gsc_compute_posterior_hprime_matches_reference(tag):
+    """GSC.compute_posterior_hprime (gsc_et.py:260-398) on one data cluster against the reference's own output: non-symmetric
+    psi_sq (after an M-step), T = 1.3, scalar and full noise; also with the candidates handed over in another order (the
+    columns of the state matrix index positions in THAT order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    from prosper_amd.em.camodels.gsc_et import GSC
+    g = golden("gsc_posterior_hprime.npz")
+    D, H, Hp, gamma, T = int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"]), float(g["T"])
+    sig = g[tag + "_sigma_sq"]
+    params = {"W": g[tag + "_W"], "pi": g[tag + "_pi"], "mu": g[tag + "_mu"], "psi_sq": g[tag + "_psi_sq"],
+              "sigma_sq": float(sig) if sig.ndim == 0 else sig}
+    assert np.abs(params["psi_sq"] - params["psi_sq"].T).max() > 0
+    m = GSC(D, H, Hp, gamma, tag)
+    got = m.compute_posterior_hprime(_An(T=T), params, {"y": g[tag + "_y"], "candidates": g[tag + "_cand"]})
+    for k in ("pstr_s", "pstr_ss", "pstr_sz", "pstr_szsz", "post_nfac_n"):
+        ref = g[tag + "_" + k]
+        assert got[k].shape == ref.shape
+        np.testing.assert_allclose(got[k], ref, rtol=1e-8, atol=1e-12 * np.abs(ref).max(), err_msg=k)
+    # the same set of candidates in reversed order: every state's latents change, the set of states does not
+    rev = g[tag + "_cand"][::-1].copy()
+    got2 = m.compute_posterior_hprime(_An(T=T), params, {"y": g[tag + "_y"], "candidates": rev})
+    np.testing.assert_allclose(got2["post_nfac_n"], g[tag + "_post_nfac_n"], rtol=1e-8)
+    np.testing.assert_allclose(got2["pstr_sz"], g[tag + "_pstr_sz"], rtol=1e-8, atol=1e-12 * np.abs(g[tag + "_pstr_sz"]).max())
+
+
 def test_gsc_unknown_noise_type_raises():
     from prosper_amd import _lib
     from prosper_amd.em.camodels.gsc_et import GSC

@@ -61,7 +61,9 @@ def test_mca_step_matches_reference_golden(case):
 
 @pytest.mark.parametrize("D,H,Hp,gamma,N,T,ncut", [(256, 128, 8, 3, 1500, 1.0, 0.0), (100, 70, 5, 4, 333, 1.6, 0.6),
                                                     (40, 20, 3, 2, 65, 1.0, 1.0), (700, 24, 4, 3, 90, 1.2, 0.0),
-                                                    (1000, 16, 10, 2, 50, 1.0, 0.4)])
+                                                    (1000, 16, 10, 2, 50, 1.0, 0.4),
+                                                    (200, 40, 14, 2, 300, 1.0, 0.0),     # H' > 12: the M-step's V[16][2] tile,
+                                                    (130, 30, 16, 2, 200, 1.3, 0.5)])    # ... slabs of 128 dimensions (round 4)
 def test_mca_step_matches_oracle(D, H, Hp, gamma, N, T, ncut):
     from oracle import mca_oracle as M
     from prosper_amd.em.camodels.mca_et import MCA_ET
