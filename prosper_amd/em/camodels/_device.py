@@ -761,6 +761,12 @@ class DeviceCAModel(CAModel):
                 m_blk = torch.empty((n_cur, H), dtype=torch.float64, device=dev)
                 self._call("infer_topk", "pm_infer_topk_f64", _ptr(lp), lp.stride(0), _ptr(cd32), _ptr(masks_d), n_cur, H, Hp,
                            self.no_states, k_eff, _ptr(top_idx32), _ptr(top_val), _ptr(top_rel), _ptr(m_blk), H, self._stream())
+                if bool((top_idx32 < 0).any()):
+                    # fewer than topK comparable log-joints in some row (NaN: a non-finite datapoint or parameter).  The
+                    # reference's argsort would rank the NaNs somewhere and carry on; indexing with -1 here would silently
+                    # report a wrapped state -- refuse instead
+                    raise _lib.HipError("inference: non-finite log-joints (NaN) in %d datapoint(s)"
+                                        % int((top_idx32 < 0).any(dim=1).sum()))
                 top_idx = top_idx32.long()
                 res_Hprime[ind_n] = float(self.Hprime)
                 res_gamma[ind_n] = float(self.gamma)

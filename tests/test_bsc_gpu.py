@@ -1187,6 +1187,27 @@ def test_inference_matches_reference(dev, tag, kw, capsys):
 
 
 # ------------------------------------------------------------------------- chunked pipeline
+def test_inference_refuses_nan_log_joints(dev):
+    """pm_infer_topk_f64 skips NaN log-joints and reports index -1 when fewer than topK comparable entries exist (round-3
+    advisor finding: the caller indexed with it unchecked).  `inference` raises instead of returning a wrapped state; rows
+    with -inf entries but enough finite ones are fine."""
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, gamma, N = 16, 8, 3, 2, 12
+    rng = np.random.RandomState(4)
+    W = rng.normal(size=(D, H))
+    y = rng.normal(size=(N, D))
+    m = BSC_ET(D, H, Hp, gamma)
+    params = {"W": W, "pi": 0.2, "sigma": 1.0}
+    K = 1 + H + m.no_states
+    res = m.inference(_An(T=1.0), params, {"y": y}, topK=K, adaptive=False)          # k_eff == K: every column is used
+    assert res["s"].shape == (N, K, H) and np.isfinite(res["p"]).all()
+    y_bad = y.copy()
+    y_bad[5, 3] = np.nan
+    with pytest.raises(_lib.HipError):
+        BSC_ET(D, H, Hp, gamma).inference(_An(T=1.0), params, {"y": y_bad}, topK=4, adaptive=False)
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_chunked_pipeline_matches_whole_shard(dev, overlap):
     """Shards beyond ``max_chunk_rows`` (or ``PM_CHUNK_ROUNDS``) go through the E-step in chunks of whole GEMM

@@ -187,6 +187,48 @@ def test_gsc_compute_posterior_hprime_matches_reference(tag):
     np.testing.assert_allclose(got2["pstr_sz"], g[tag + "_pstr_sz"], rtol=1e-8, atol=1e-12 * np.abs(g[tag + "_pstr_sz"]).max())
 
 
+def test_gsc_dead_latent_column_of_clamped_weights():
+    """A latent whose prior odds underflow (pi_h = 1e-300) has nothing but `tiny`-clamped posterior weights, as upstream
+    (gsc_et.py:354-356: exp(beta lp) < tiny -> tiny) -- its one-cause state and every multi-cause state that contains it,
+    whether it is among a datapoint's candidates (selection ignores the prior) or not.  Its column of xpt_s / xpt_sz is a
+    small multiple of tiny * nf for every datapoint: the kernel must reproduce exactly that -- these entries are all the
+    column sums of a dead latent consist of -- and the sums over datapoints must carry them."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    from oracle import gsc_oracle as G
+    from prosper_amd.em.camodels.gsc_et import GSC
+    D, H, Hp, gamma, N = 40, 12, 4, 3, 300
+    rng = np.random.RandomState(77)
+    gt = {"W": rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.5), "psi_sq": np.eye(H), "sigma_sq": 1.0}
+    y, _, _ = G.generate_gsc_data(gt, N, rng)
+    dead = 7
+    params = {"W": gt["W"] + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.4),
+              "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+    params["pi"][dead] = 1e-300                                # log odds -690.8: every state with this latent underflows
+    model = G.make_model(D, H, Hp, gamma)
+    cand_ref = G.select_hprimes(params, y, Hp)
+    assert (cand_ref == dead).any() and not (cand_ref == dead).any(axis=1).all()       # a candidate for some datapoints only
+    suff = G.e_step(G.Anneal(T=1.0), model, params, y, cand_ref)
+    tiny = np.finfo(np.float64).tiny
+    col = suff["xpt_s"][:, dead]
+    # (a few tiny) * nf: ~1e-290 where the datapoint has states that do not underflow; where ALL of them do, every state
+    # weighs `tiny` and the clamped weights are all there is (entries of order 1 / K)
+    assert (col > 0).all() and np.median(col) < 1e-200
+    m = GSC(D, H, Hp, gamma, "scalar")
+    data = m.select_Hprimes({k: np.array(v, copy=True) for k, v in params.items()}, {"y": y})
+    got = m.E_step(_An(T=1.0), {k: np.array(v, copy=True) for k, v in params.items()}, data)
+    assert np.array_equal(np.asarray(data["candidates"]).astype(np.int64), cand_ref)
+    xs, xsz = np.asarray(got["xpt_s"]), np.asarray(got["xpt_sz"])
+    np.testing.assert_allclose(xs, suff["xpt_s"], rtol=1e-8, atol=0)                  # incl. the dead column, RELATIVE
+    np.testing.assert_allclose(xsz, suff["xpt_sz"], rtol=1e-8, atol=0)
+    np.testing.assert_allclose(got["xpt_ss"].sum(axis=0).cpu().numpy(), suff["xpt_ss"].sum(0), rtol=1e-9, atol=0)
+    np.testing.assert_allclose(got["xpt_szsz"].sum(axis=0).cpu().numpy(), suff["xpt_szsz"].sum(0), rtol=1e-8, atol=1e-305)
+    np.testing.assert_allclose(got["_sums"][0].cpu().numpy(), suff["xpt_s"].sum(0), rtol=1e-9, atol=0)
+    # the update runs (the H x H inverse of a matrix with a ~1e-300 pivot is the reference's own LAPACK call on the host)
+    new = m.step(_An(T=1.0), {k: np.array(v, copy=True) for k, v in params.items()}, {"y": y})
+    assert np.isfinite(new["pi"]).all() and new["pi"][dead] == 5e-5          # clipped from below (gsc_et.py:640-645)
+
+
 def test_gsc_unknown_noise_type_raises():
     from prosper_amd import _lib
     from prosper_amd.em.camodels.gsc_et import GSC
