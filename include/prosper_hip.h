@@ -545,6 +545,13 @@ int pm_gsc_component_scores_f64(const double *scores, int64_t lds, const double 
 int pm_infer_topk_f64(const double *logpj, int64_t ldl, const int32_t *cand, const uint16_t *state_masks, int64_t N,
                       int64_t H, int64_t Hprime, int64_t S, int64_t topK, int32_t *top_idx, double *top_lpc,
                       double *top_rel, double *marg, int64_t ldm, void *stream);
+/* The same for logpj rows with `single_cols` >= H one-cause columns in front of the multi-cause ones -- DSC's K-ary latents
+ * (dsc_et.py:927-1059): [null ; (K - 1) H one-cause states, the first non-zero value's block first ; S multi-cause states].
+ * `state_masks` then marks the positions at which a state's latent takes the value 1 (the reference's marginal,
+ * dsc_et.py:1010-1016: the first value's one-cause state + those multi-cause states); top-K runs over all columns. */
+int pm_infer_topk_cols_f64(const double *logpj, int64_t ldl, const int32_t *cand, const uint16_t *state_masks, int64_t N,
+                           int64_t H, int64_t Hprime, int64_t S, int64_t single_cols, int64_t topK, int32_t *top_idx,
+                           double *top_lpc, double *top_rel, double *marg, int64_t ldm, void *stream);
 
 #ifdef __cplusplus
 }

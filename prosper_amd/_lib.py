@@ -119,6 +119,8 @@ SIGNATURES = {
     "pm_gsc_estep_lpj_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
                                        i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp]),
     "pm_infer_topk_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp]),
+    "pm_infer_topk_cols_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, i64, i64, c_dp, c_dp, c_dp, c_dp, i64,
+                                         c_dp]),
     "pm_gsc_component_scores_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_double, i64, i64, c_dp, i64, c_dp]),
 }
 

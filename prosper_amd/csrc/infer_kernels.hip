@@ -23,12 +23,14 @@ namespace {
 __global__ __launch_bounds__(256) void infer_topk_kernel(const double *__restrict__ logpj, int64_t ldl,
                                                           const int32_t *__restrict__ cand,
                                                           const uint16_t *__restrict__ masks, int64_t N, int H, int Hp,
-                                                          int S, int topK, int32_t *__restrict__ top_idx,
+                                                          int S, int single_cols, int topK, int32_t *__restrict__ top_idx,
                                                           double *__restrict__ top_lpc, double *__restrict__ top_rel,
                                                           double *__restrict__ marg, int64_t ldm) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-    const int K = 1 + H + S;
+    // columns: [null ; single_cols one-cause states (binary latents: H; K-ary: (K - 1) H, the first value's block first) ;
+    // S multi-cause states]
+    const int K = 1 + single_cols + S, moff = 1 + single_cols;
     for (int64_t n = wave0; n < N; n += nwaves) {
         const double *row = logpj + n * ldl;
         // ---- maximum, log-sum-exp
@@ -74,11 +76,11 @@ __global__ __launch_bounds__(256) void infer_topk_kernel(const double *__restric
             const double single = row[1 + c];
             double m = -INFINITY;
             for (int s = lane; s < S; s += 64)
-                if ((masks[s] >> j) & 1) m = fmax(m, row[1 + H + s]);
+                if ((masks[s] >> j) & 1) m = fmax(m, row[moff + s]);
             m = fmax(pm_wave_max(m), single);
             double acc = 0.0;
             for (int s = lane; s < S; s += 64)
-                if ((masks[s] >> j) & 1) acc += exp(row[1 + H + s] - m);
+                if ((masks[s] >> j) & 1) acc += exp(row[moff + s] - m);
             acc = pm_wave_sum(acc) + exp(single - m);
             if (lane == 0) mrow[c] = (m == -INFINITY) ? -INFINITY : (m + log(acc)) - lse;
         }
@@ -90,14 +92,23 @@ __global__ __launch_bounds__(256) void infer_topk_kernel(const double *__restric
 extern "C" int pm_infer_topk_f64(const double *logpj, int64_t ldl, const int32_t *cand, const uint16_t *state_masks,
                                  int64_t N, int64_t H, int64_t Hprime, int64_t S, int64_t topK, int32_t *top_idx,
                                  double *top_lpc, double *top_rel, double *marg, int64_t ldm, void *stream) {
+    return pm_infer_topk_cols_f64(logpj, ldl, cand, state_masks, N, H, Hprime, S, H, topK, top_idx, top_lpc, top_rel, marg,
+                                  ldm, stream);
+}
+
+extern "C" int pm_infer_topk_cols_f64(const double *logpj, int64_t ldl, const int32_t *cand, const uint16_t *state_masks,
+                                      int64_t N, int64_t H, int64_t Hprime, int64_t S, int64_t single_cols, int64_t topK,
+                                      int32_t *top_idx, double *top_lpc, double *top_rel, double *marg, int64_t ldm,
+                                      void *stream) {
     if (N == 0) return PM_OK;
     if (!logpj || !cand || !top_idx || !top_lpc || !top_rel || !marg || N < 0 || H <= 0 || Hprime <= 0 || S < 0 ||
-        topK <= 0 || ldl < 1 + H + S || ldm < H || (S > 0 && !state_masks))
+        single_cols < H || topK <= 0 || ldl < 1 + single_cols + S || ldm < H || (S > 0 && !state_masks))
         return PM_EINVAL;
-    if (Hprime > PM_MAX_HPRIME || topK > 1 + H + S) return PM_ERANGE;
+    if (Hprime > PM_MAX_HPRIME || topK > 1 + single_cols + S || single_cols > INT32_MAX / 2) return PM_ERANGE;
     int64_t blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(infer_topk_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), logpj, ldl,
-                       cand, state_masks, N, (int)H, (int)Hprime, (int)S, (int)topK, top_idx, top_lpc, top_rel, marg, ldm);
+                       cand, state_masks, N, (int)H, (int)Hprime, (int)S, (int)single_cols, (int)topK, top_idx, top_lpc,
+                       top_rel, marg, ldm);
     return (int)hipGetLastError();
 }

@@ -489,10 +489,26 @@ class DSC_ET(DeviceCAModel):
                 cd = (cand.tensor if isinstance(cand, DeviceArray) else torch.as_tensor(np.asarray(cand)).to(dev)).long()
                 n_cur, Kt = lp.shape
                 Hp = self.Hprime
-                rel = lp - lp.max(dim=1, keepdim=True).values
-                lpc = rel - torch.log(torch.exp(rel).sum(dim=1, keepdim=True))      # as :983-987
                 k_eff = min(topK, Kt)
-                top_val, top_idx = torch.topk(lpc, k_eff, dim=1, largest=True, sorted=True)
+                # normalisation, top-K columns and the marginals (:983-1016): one HIP pass over the rows
+                # (pm_infer_topk_cols_f64; the marginal of a candidate combines its FIRST non-zero value's one-cause state
+                # with the multi-cause states in which it takes the value 1: the masks mark exactly those)
+                SMh = self.state_matrix if self.no_states else np.zeros((1, Hp))
+                mk = ((SMh == 1).astype(np.int64) << np.arange(SMh.shape[1])[None, :]).sum(axis=1).astype(np.uint16)
+                masks_d = torch.from_numpy(mk.view(np.int16).copy()).to(dev)
+                lp = lp.contiguous() if lp.stride(1) != 1 else lp
+                cd32 = cd.to(torch.int32).contiguous()
+                top_idx32 = torch.empty((n_cur, k_eff), dtype=torch.int32, device=dev)
+                top_val = torch.empty((n_cur, k_eff), dtype=torch.float64, device=dev)
+                top_rel = torch.empty((n_cur, k_eff), dtype=torch.float64, device=dev)
+                m_blk = torch.empty((n_cur, H), dtype=torch.float64, device=dev)
+                self._call("infer_topk", "pm_infer_topk_cols_f64", _ptr(lp), lp.stride(0), _ptr(cd32), _ptr(masks_d), n_cur, H,
+                           Hp, self.no_states, nss, k_eff, _ptr(top_idx32), _ptr(top_val), _ptr(top_rel), _ptr(m_blk), H,
+                           self._stream())
+                if bool((top_idx32 < 0).any()):
+                    raise _lib.HipError("inference: non-finite log-joints (NaN) in %d datapoint(s)"
+                                        % int((top_idx32 < 0).any(dim=1).sum()))
+                top_idx = top_idx32.long()
                 res_Hprime[ind_n] = float(self.Hprime)
                 res_gamma[ind_n] = float(self.gamma)
                 SM = torch.from_numpy(self.state_matrix.astype(np.int8)).to(dev) if self.no_states else \
@@ -509,18 +525,7 @@ class DSC_ET(DeviceCAModel):
                     rows = SM[top_idx[nn_, mm_] - nss - 1]                           # (M, Hp) latent values
                     s_blk[nn_[:, None].expand(-1, Hp), mm_[:, None].expand(-1, Hp), cd[nn_]] = rows
                 res_s[ind_n, :k_eff] = s_blk
-                res_p[ind_n, :k_eff] = top_val if logprob else torch.exp(torch.gather(rel, 1, top_idx))
-                # marginals (:1010-1016)
-                m_blk = lpc[:, 1:H + 1].clone()
-                if self.no_states:
-                    multi_lp = lpc[:, nss + 1:]
-                    is_one = (SM == 1)
-                    rows_n = torch.arange(n_cur, device=dev)
-                    for j in range(Hp):
-                        lj = torch.logsumexp(torch.where(is_one[:, j][None, :], multi_lp,
-                                                         torch.full_like(multi_lp, float("-inf"))), dim=1)
-                        hj = cd[:, j]
-                        m_blk[rows_n, hj] = torch.logaddexp(lpc[rows_n, 1 + hj], lj)
+                res_p[ind_n, :k_eff] = top_val if logprob else torch.exp(top_rel)
                 res_m[ind_n] = m_blk
                 if not adaptive:
                     break
