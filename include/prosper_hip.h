@@ -468,6 +468,18 @@ int pm_dsc_mstep_rows_nz_f64(const double *logpj, int64_t ldl, const double *lse
                           double *expect, int64_t lde, double *stats, uint16_t *nz_idx, double *nz_val,
                              void *stream);
 
+/* pm_dsc_estep_f64 that ALSO produces the M-step's row statistics -- what pm_dsc_mstep_rows_nz_f64 computes from the stored
+ * log-joints (dsc_et.py:587-774: E[s] rows, their non-zero lists, the candidates' second moments -> Wq, qdiag, the value
+ * counts, the sigma / likelihood scalars) -- from the exponentials its log-sum-exp evaluates anyway: no second pass over the
+ * log-joints.  For the E-step of an EM iteration with no data truncation ahead (every datapoint kept); `stats` is
+ * accumulated into (caller zeroes it), `expect` / `nz_*` as in pm_dsc_mstep_rows_nz_f64.  Sixteen lanes per datapoint:
+ * where pm_dsc_estep_mstats_supported(H, Hprime, S, K, flags) holds (else PM_ERANGE: run the two passes). */
+int pm_dsc_estep_mstats_supported(int64_t H, int64_t Hprime, int64_t S, int64_t K, int flags);
+int pm_dsc_estep_mstats_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2, const int32_t *cand,
+                            const uint8_t *state_idx, int64_t S, const double *prior, const pm_dsc_params *params_host,
+                            int64_t N, int64_t H, int64_t D, int64_t Hprime, double *logpj, int64_t ldl, double *lse,
+                            double *expect, int64_t lde, double *stats, uint16_t *nz_idx, double *nz_val, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Gaussian (spike-and-slab) Sparse Coding, scalar noise (prosper/em/camodels/gsc_et.py, GSC)
  * ------------------------------------------------------------------------------------- */

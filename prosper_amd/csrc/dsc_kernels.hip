@@ -447,6 +447,312 @@ __global__ __launch_bounds__(256, MAXHP <= 8 ? 4 : 2) void dsc_estep16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// dsc_estep16_kernel that ALSO produces the M-step's per-datapoint statistics (dsc_et.py:587-774; what
+// dsc_mstep_rows16_kernel computes from the stored log-joints): the posterior weights are the exponentials the
+// log-sum-exp evaluates anyway -- taken relative to the row maximum, scaled by 1 / sum once per datapoint -- so the
+// second pass over 382 MB of log-joints (config-4-sized DSC) and its exponentials go away.  For E_step inside
+// CAModel.step with no data truncation ahead (every datapoint is kept); terms below e^-37 of the largest add nothing.
+// LDS: the layout of dsc_estep16_kernel, then [ qdiag (H) cnt (8) scal (4) | per row: m (H') B (H'^2) ]; the E[s] row of a
+// datapoint stays in its lanes' registers.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef PM_DSC_MS_WPE
+#define PM_DSC_MS_WPE 3        // wavefronts per SIMD the kernel is compiled for (register budget 512 / WPE)
+#endif
+template <int MAXHP, int VPL, int KM>      // KM >= K: latent values the per-lane counters are sized for (4 or 8)
+__global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_MS_WPE : 2) void dsc_estep16_ms_kernel(
+    const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram,
+    const double *__restrict__ ynorm2, const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S,
+    const double *__restrict__ prior_g, pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ logpj,
+    int64_t ldl, double *__restrict__ lse, int stage, int NT, double *__restrict__ expect, int64_t lde,
+    double *__restrict__ stats, uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nss = (P.K - 1) * H;
+    const bool tab = P.flags & PM_DSC_TABLE_ONLY;        // TSC: columns = rows of the state table, nothing else
+    const int base = tab ? 0 : 1 + nss;
+    const int Kt = base + S;
+    const Lay16 L = dsc_lay16(H, Hp, S, Kt, NT, stage);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, row = lane >> 4, rowbase = lane & 48;
+    double *s_w2 = reinterpret_cast<double *>(smem);
+    uint8_t *s_tab = smem + L.tab;
+    double *s_prior = reinterpret_cast<double *>(smem + L.prior);
+    uint8_t *s_off = smem + L.off, *s_dj = smem + L.dj, *s_dk = smem + L.dk;
+    double *s_c1 = reinterpret_cast<double *>(smem + L.c1), *s_c2 = reinterpret_cast<double *>(smem + L.c2);
+    double *s_a = reinterpret_cast<double *>(smem + L.rows + (wave * 4 + row) * L.row_stride);
+    double *s_G = s_a + Hp, *s_T = s_G + Hp * Hp;
+    // the statistics' areas behind the E-step layout
+    double *s_qdiag = reinterpret_cast<double *>(smem + ((L.bytes + 7) & ~7));
+    double *s_cnt = s_qdiag + H, *s_scal = s_cnt + PM_DSC_MAX_K;
+    const int per_row = Hp + Hp * Hp;
+    double *s_m = s_scal + 4 + (size_t)(wave * 4 + row) * per_row;
+    double *s_B = s_m + Hp;
+    __shared__ double s_val[PM_DSC_MAX_K];
+    __shared__ double s_E[128];
+    if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
+    const double *etab = s_E - 256;
+    for (int h = tid; h < H; h += blockDim.x) s_w2[h] = gram[(int64_t)h * H + h];
+    for (int i = tid; i < S * Hp; i += blockDim.x) s_tab[i] = state_idx[i];
+    if (tid < PM_DSC_MAX_K) s_val[tid] = (tid < P.K) ? P.values[tid] : 0.0;
+    for (int h = tid; h < H + PM_DSC_MAX_K + 4; h += blockDim.x) s_qdiag[h] = 0.0;
+    if (stage)
+        for (int i = tid; i < Kt; i += blockDim.x) s_prior[i] = prior_g[i];
+    __syncthreads();
+    const double *prior = stage ? s_prior : prior_g;
+    bool fast = NT > 0;
+    if (fast) fast = !dsc_build_energy_tables(P, Hp, S, NT, s_tab, s_val, s_off, s_dj, s_dk, s_c1, s_c2);
+    double sig = 0.0, fs = 0.0, kept = 0.0, overflow = 0.0;
+    double cnt[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) cnt[k] = 0.0;
+    double *Wq = stats + (int64_t)H * D;
+
+    for (int64_t n0 = (int64_t)blockIdx.x * 16; n0 < N; n0 += (int64_t)gridDim.x * 16) {
+        const int64_t n = n0 + wave * 4 + row;
+        const bool live = n < N;
+        const int64_t nn = live ? n : N - 1;              // rows past N shadow the last datapoint and contribute nothing
+        const double *arow = scores + nn * lds;
+        const double yn = ynorm2[nn];
+        const int myc = j < Hp ? cand[nn * Hp + j] : -1;
+        double ar[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) ar[i] = (!tab && j + 16 * i < H) ? arow[j + 16 * i] : 0.0;
+        if (j < Hp) {
+            s_a[j] = arow[myc];
+            s_m[j] = 0.0;
+        }
+        for (int p = j; p < Hp * Hp; p += 16) s_B[p] = 0.0;
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {        // uniform trip count: every lane feeds the permutes
+            const int p = p0 + j;
+            const bool ok = p < Hp * Hp;
+            const int pi = ok ? p / Hp : 0, pk = ok ? p - pi * Hp : 0;
+            const int ci = __builtin_amdgcn_ds_bpermute((rowbase + pi) << 2, myc);
+            const int ck = __builtin_amdgcn_ds_bpermute((rowbase + pk) << 2, myc);
+            if (ok) s_G[p] = gram[(int64_t)ci * H + ck];
+        }
+        // positions that are the last occurrence of their latent (all of them unless candidates repeat: TSC)
+        bool mine_last = j < Hp;
+        for (int k = 1; k < Hp; ++k) {                          // uniform trip count
+            const int other = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc);
+            if (k > j && other == myc) mine_last = false;
+        }
+        const unsigned lastmask = (P.flags & PM_DSC_LAST_POSITION)
+                                      ? (unsigned)((__ballot(mine_last) >> rowbase) & 0xFFFFull)
+                                      : ((1u << Hp) - 1u);
+        wave_sync_lds_dsc();
+        if (fast) {
+            for (int e = j; e < NT; e += 16) {
+                const int dj = s_dj[e];
+                s_T[e] = fma(s_c1[e], s_G[dj * Hp + s_dk[e]], s_c2[e] * s_a[dj]);
+            }
+            wave_sync_lds_dsc();
+        }
+        double *out = logpj + nn * ldl;
+        auto state_e = [&](int st) -> double {
+            if (fast) {
+                const uint2 o = *reinterpret_cast<const uint2 *>(s_off + (size_t)st * 8);
+                return yn + s_T[o.x & 255u] + s_T[(o.x >> 8) & 255u] + s_T[(o.x >> 16) & 255u] + s_T[o.x >> 24] +
+                       s_T[o.y & 255u] + s_T[(o.y >> 8) & 255u];
+            }
+            return state_energy<MAXHP>(s_tab + st * Hp, Hp, s_val, s_a, s_G, yn);
+        };
+        // ---- pass 1: log-joints out, row maximum
+        double m = -INFINITY;
+        if (!tab && j == 0) {
+            const double f0 = P.ecoef * yn + P.pscale * prior[0];
+            if (live) out[0] = f0;
+            m = f0;
+        }
+        {
+            int c = 0;
+            for (int k = 0; k < P.K && !tab; ++k) {
+                if (k == P.K0) continue;
+                const double v = s_val[k];
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const int h = j + 16 * i;
+                    if (h < H) {
+                        const double e = v * v * s_w2[h] - 2.0 * v * ar[i] + yn;
+                        const double f = P.ecoef * e + P.pscale * prior[1 + c * H + h];
+                        if (live) out[1 + c * H + h] = f;
+                        m = fmax(m, f);
+                    }
+                }
+                ++c;
+            }
+        }
+        for (int st = j; st < S; st += 16) {
+            const double f = P.ecoef * state_e(st) + P.pscale * prior[base + st];
+            if (live) out[base + st] = f;
+            m = fmax(m, f);
+        }
+        m = fmax(m, pm_dpp_f64<0xB1>(m));
+        m = fmax(m, pm_dpp_f64<0x4E>(m));
+        m = fmax(m, pm_dpp_f64<0x141>(m));
+        m = fmax(m, pm_dpp_f64<0x140>(m));
+        // ---- pass 2: exponentials relative to the maximum; the M-step's sums weighted by them (scaled by 1 / sum below)
+        double sum = 0.0, sig_dp = 0.0;
+        double cnt_dp[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) cnt_dp[k] = 0.0;
+        double rowv[VPL], qd[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) rowv[i] = qd[i] = 0.0;
+        if (!tab && j == 0) {
+            const double d = (P.ecoef * yn + P.pscale * prior[0]) - m;
+            const double ex = d > -37.0 ? pm_exp_tab(d, etab) : 0.0;
+            sum += ex;
+            sig_dp += ex * yn;
+        }
+        {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                if (tab || k >= P.K || k == P.K0) continue;
+                const double v = s_val[k];
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const int h = j + 16 * i;
+                    if (h < H) {
+                        const double e = v * v * s_w2[h] - 2.0 * v * ar[i] + yn;
+                        const double d = (P.ecoef * e + P.pscale * prior[1 + c * H + h]) - m;
+                        const double ex = d > -37.0 ? pm_exp_tab(d, etab) : 0.0;
+                        sum += ex;
+                        rowv[i] += ex * v;
+                        qd[i] += ex * v * v;
+                        cnt_dp[k] += ex;
+                        sig_dp += ex * e;
+                    }
+                }
+                ++c;
+            }
+        }
+        for (int st = j; st < S; st += 16) {
+            const double e = state_e(st);
+            const double d = (P.ecoef * e + P.pscale * prior[base + st]) - m;
+            if (!(d > -37.0)) continue;
+            const double ex = pm_exp_tab(d, etab);
+            sum += ex;
+            sig_dp += ex * e;
+            const uint8_t *srow = s_tab + st * Hp;
+            int ki[MAXHP];
+            double vv[MAXHP];
+#pragma unroll
+            for (int a = 0; a < MAXHP; ++a) {
+                ki[a] = (a < Hp) ? (int)srow[a] : P.K0;
+                vv[a] = (a < Hp) ? s_val[ki[a]] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < MAXHP; ++a) {
+                if (a < Hp && ki[a] != P.K0) {
+#pragma unroll
+                    for (int k = 0; k < KM; ++k)
+                        if (k == ki[a]) cnt_dp[k] += ex;
+                    atomicAdd(&s_m[a], ex * vv[a]);
+#pragma unroll
+                    for (int k2 = a; k2 < MAXHP; ++k2)
+                        if (k2 < Hp && ki[k2] != P.K0) atomicAdd(&s_B[a * Hp + k2], ex * vv[a] * vv[k2]);
+                }
+            }
+        }
+        sum += pm_dpp_f64<0xB1>(sum);
+        sum += pm_dpp_f64<0x4E>(sum);
+        sum += pm_dpp_f64<0x141>(sum);
+        sum += pm_dpp_f64<0x140>(sum);
+        const double lse_n = m + log(sum);
+        const double inv = live ? 1.0 / sum : 0.0;               // (shadow rows: every weight 0)
+        if (j == 0 && live) {
+            lse[n] = lse_n;
+            fs += lse_n;
+            kept += 1.0;
+        }
+        sig += sig_dp * inv;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) cnt[k] += cnt_dp[k] * inv;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            rowv[i] *= inv;
+            if (h < H) {
+                const double q2 = qd[i] * inv;
+                if (q2 != 0.0) atomicAdd(&s_qdiag[h], q2);
+            }
+        }
+        wave_sync_lds_dsc();
+        // the candidates' multi-cause share of E[s]: the lane that holds latent c_a takes s_m[a] (distinct latents)
+        for (int a = 0; a < Hp; ++a) {                           // uniform trip count
+            const int c = __builtin_amdgcn_ds_bpermute((rowbase + a) << 2, myc);
+            const double add = s_m[a] * inv;
+            const bool mine = ((lastmask >> a) & 1u) && (c & 15) == j;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (mine && (c >> 4) == i) rowv[i] += add;
+        }
+        if (live) {
+            double *erow = expect + n * lde;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (j + 16 * i < H) erow[j + 16 * i] = rowv[i];
+        }
+        if (nz_idx) {      // the row's non-zeros as a list too (pm_wp_sparse_f64; format of the BSC statistics pass)
+            uint16_t *nzi = nz_idx + nn * PM_BSC_NZ_MAX;
+            double *nzv = nz_val + nn * PM_BSC_NZ_MAX;
+            uint32_t nzn = 0;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int h = j + 16 * i;
+                const double v = h < H ? rowv[i] : 0.0;
+                const uint32_t mine = (uint32_t)((__ballot(v != 0.0) >> rowbase) & 0xFFFFull);
+                const uint32_t pos = nzn + __builtin_popcount(mine & ((1u << j) - 1u));
+                if (v != 0.0 && pos < PM_BSC_NZ_MAX && live) {
+                    nzi[pos] = (uint16_t)h;
+                    nzv[pos] = v;
+                }
+                nzn += __builtin_popcount(mine);
+            }
+            if (live) {
+                if ((uint32_t)j >= nzn) nzi[j] = 0xFFFFu;               // (16 lanes = PM_BSC_NZ_MAX slots)
+                if (j == 0 && nzn > PM_BSC_NZ_MAX) overflow += 1.0;
+            }
+        }
+        for (int p0 = 0; p0 < Hp * Hp; p0 += 16) {              // uniform trip count: every lane feeds the permutes
+            const int p = p0 + j;
+            const bool ok = p < Hp * Hp;
+            const int a = ok ? p / Hp : 0, k2 = ok ? p - a * Hp : 0;
+            const int cj = __builtin_amdgcn_ds_bpermute((rowbase + a) << 2, myc);
+            const int ck = __builtin_amdgcn_ds_bpermute((rowbase + k2) << 2, myc);
+            if (!ok || k2 < a || !((lastmask >> a) & 1u) || !((lastmask >> k2) & 1u)) continue;
+            const double v = s_B[p] * inv;
+            if (v == 0.0) continue;
+            const int r = cj < ck ? cj : ck, cc = cj < ck ? ck : cj;
+            pm_atomic_add(Wq + (int64_t)r * H + cc, v);          // upper triangle (pm_spd_inverse_f64 layout)
+        }
+        wave_sync_lds_dsc();
+    }
+
+    sig = pm_wave_sum(sig);
+    fs = pm_wave_sum(fs);
+    kept = pm_wave_sum(kept);
+    overflow = pm_wave_sum(overflow);
+#pragma unroll
+    for (int k = 0; k < KM; ++k) cnt[k] = pm_wave_sum(cnt[k]);
+    if (lane == 0) {
+        atomicAdd(&s_scal[0], sig);
+        atomicAdd(&s_scal[1], fs);
+        atomicAdd(&s_scal[2], kept);
+        if (overflow != 0.0) atomicAdd(&s_scal[3], overflow);
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], cnt[k]);
+    }
+    __syncthreads();
+    double *g_qdiag = stats + (int64_t)H * D + (int64_t)H * H;
+    for (int h = tid; h < H + PM_DSC_MAX_K + 4; h += blockDim.x) {
+        const double v = s_qdiag[h];
+        if (v != 0.0) pm_atomic_add(g_qdiag + h, v);
+    }
+}
+
 // one wave per datapoint and several dependent memory round trips per datapoint: latency-bound, so waves per SIMD
 // are what counts (4 for H' <= 8)
 template <int MAXHP>
@@ -928,6 +1234,79 @@ extern "C" int pm_dsc_estep_f64(const double *scores, int64_t lds, const double 
     if (Hprime <= 8) PM_LAUNCH(8);
     else PM_LAUNCH(PM_MAX_HPRIME);
 #undef PM_LAUNCH
+    return (int)hipGetLastError();
+}
+
+// E-step + M-step row statistics in one pass (dsc_estep16_ms_kernel): its LDS layout, or 0 where it does not apply
+static size_t dsc_estep_ms_lds(int64_t H, int64_t Hprime, int64_t S, int64_t Kt, int64_t Kn, int *stage16, int *nt16) {
+#ifdef PM_DSC_WAVE64
+    return 0;
+#else
+    if (!(H <= 256 && S * Hprime < (1 << 20) && Kt < (1 << 20))) return 0;
+    int64_t NT16 = 1 + Hprime * Kn + Hprime * (Hprime - 1) / 2 * Kn * Kn;
+    if (NT16 > 256 || S == 0) NT16 = 0;
+    *stage16 = 1;
+    Lay16 L = dsc_lay16((int)H, (int)Hprime, (int)S, (int)Kt, (int)NT16, 1);
+    if (L.bytes > 40 * 1024) {
+        *stage16 = 0;
+        L = dsc_lay16((int)H, (int)Hprime, (int)S, (int)Kt, (int)NT16, 0);
+    }
+    if (L.bytes > 40 * 1024) return 0;
+    *nt16 = (int)NT16;
+    const size_t total = (size_t)((L.bytes + 7) & ~7) + sizeof(double) * (size_t)(H + PM_DSC_MAX_K + 4) +
+                         sizeof(double) * 16 * (size_t)(Hprime + Hprime * Hprime);
+    return total <= 64 * 1024 ? total : 0;
+#endif
+}
+
+extern "C" int pm_dsc_estep_mstats_supported(int64_t H, int64_t Hprime, int64_t S, int64_t K, int flags) {
+    if (H <= 0 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || Hprime > H || S < 0 || K < 2 || K > PM_DSC_MAX_K) return 0;
+    int st = 0, nt = 0;
+    return dsc_estep_ms_lds(H, Hprime, S, (flags & PM_DSC_TABLE_ONLY) ? S : 1 + (K - 1) * H + S, K - 1, &st, &nt) ? 1 : 0;
+}
+
+extern "C" int pm_dsc_estep_mstats_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
+                                       const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
+                                       const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
+                                       double *logpj, int64_t ldl, double *lse, double *expect, int64_t lde,
+                                       double *stats, uint16_t *nz_idx, double *nz_val, void *stream) {
+    if ((nz_idx == nullptr) != (nz_val == nullptr)) return PM_EINVAL;
+    if (N == 0) return PM_OK;
+    if (!scores || !gram || !ynorm2 || !cand || !prior || !logpj || !lse || !expect || !stats || N < 0 || H <= 0 || D <= 0 ||
+        Hprime <= 0 || S < 0 || lds < H || lde < H || bad_params(params_host) || (S > 0 && !state_idx) ||
+        params_host->ecoef == 0.0)
+        return PM_EINVAL;
+    const int64_t Kt = (params_host->flags & PM_DSC_TABLE_ONLY) ? S : 1 + (params_host->K - 1) * H + S;
+    if (ldl < Kt) return PM_EINVAL;
+    if (Hprime > PM_MAX_HPRIME || Hprime > H) return PM_ERANGE;
+    int stage16 = 0, NT16 = 0;
+    const size_t shmem = dsc_estep_ms_lds(H, Hprime, S, Kt, params_host->K - 1, &stage16, &NT16);
+    if (!shmem) return PM_ERANGE;
+    const int64_t blocks16 = (N + 15) / 16;
+    const int per_cu = (Hprime <= 8 && H <= 128) ? PM_DSC_MS_WPE : 2;
+    const unsigned grid16 = (unsigned)(blocks16 < 256 * per_cu ? blocks16 : 256 * per_cu);
+#define PM_LAUNCH16K(M, V, KMV)                                                                                        \
+    do {                                                                                                               \
+        if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_estep16_ms_kernel<M, V, KMV>), shmem)) return e;  \
+        hipLaunchKernelGGL((dsc_estep16_ms_kernel<M, V, KMV>), dim3(grid16), dim3(256), shmem,                         \
+                           static_cast<hipStream_t>(stream), scores, lds, gram, ynorm2, cand, state_idx, (int)S, prior, \
+                           *params_host, N, (int)H, (int)D, (int)Hprime, logpj, ldl, lse, stage16, NT16, expect, lde,   \
+                           stats, nz_idx, nz_val);                                                                     \
+    } while (0)
+#define PM_LAUNCH16(M, V)                        \
+    do {                                         \
+        if (params_host->K <= 4) {               \
+            PM_LAUNCH16K(M, V, 4);               \
+        } else {                                 \
+            PM_LAUNCH16K(M, V, PM_DSC_MAX_K);    \
+        }                                        \
+    } while (0)
+    if (Hprime <= 8 && H <= 128) PM_LAUNCH16(8, 8);
+    else if (Hprime <= 8) PM_LAUNCH16(8, 16);
+    else if (H <= 128) PM_LAUNCH16(PM_MAX_HPRIME, 8);
+    else PM_LAUNCH16(PM_MAX_HPRIME, 16);
+#undef PM_LAUNCH16
+#undef PM_LAUNCH16K
     return (int)hipGetLastError();
 }
 

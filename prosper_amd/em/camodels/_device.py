@@ -227,20 +227,86 @@ class DeviceCAModel(CAModel):
         else:
             self.timer.launch(label, lambda: _lib.call(entry, *args))
 
-    def _rows_and_wp(self, rows_args, lp_ld, expect, Y, stats, my_N, K, flags, Hp, S):
+    def step(self, anneal, model_params, my_data):
+        """CAModel.step (camodels/__init__.py:163-193); the E-step knows that the M-step follows with the same arguments."""
+        was, self._in_step = getattr(self, "_in_step", False), True
+        try:
+            return CAModel.step(self, anneal, model_params, my_data)
+        finally:
+            self._in_step = was
+
+    def _dsc_estep(self, anneal, stats_name, par, res, cand, tab, S, prior, P, Kt, pi_key):
+        """DSC / TSC E-step launch.  Inside ``step`` with no data truncation ahead the sixteen-lane kernel also produces the
+        M-step's row statistics (pm_dsc_estep_mstats_f64: E[s] rows and their non-zero lists, Wq, qdiag, value counts,
+        scalars) from the exponentials its log-sum-exp evaluates anyway -- ``M_step`` then skips its pass over the
+        log-joints.  Returns the DeviceArray of log-joints with ``.lse`` and, fused, ``.mstats``."""
+        N = res["Y"].shape[0]
+        H, D, Hp = self.H, self.D, self.Hprime
+        lib = _lib.load()
+        logpj = torch.empty((N, Kt), dtype=torch.float64, device=self.device)
+        lse = torch.empty((N,), dtype=torch.float64, device=self.device)
+        out = DeviceArray(logpj)
+        out.lse = lse
+        out.mstats = None
+        if not N:
+            return out
+        st = self._stream()
+        fuse = (getattr(self, "_in_step", False) and getattr(self, "fuse_mstats", True) and anneal['Ncut_factor'] <= 0.0
+                and bool(lib.pm_dsc_estep_mstats_supported(H, Hp, S, int(P.K), int(P.flags))))
+        if fuse:
+            stats = self._buf(stats_name, (lib.pm_dsc_stats_len(H, D),))
+            stats.zero_()
+            expect = self._buf("expect", (N, H))
+            nz = None
+            if getattr(self, "sparse_wp", True):
+                nz = (self._buf("nz_idx", (N, 16), torch.int16), self._buf("nz_val", (N, 16)))
+            self._call("estep_mstats", "pm_dsc_estep_mstats_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]),
+                       _ptr(cand), _ptr(tab), S, _ptr(prior), ctypes.byref(P), N, H, D, Hp, _ptr(logpj), Kt, _ptr(lse),
+                       _ptr(expect), H, _ptr(stats), _ptr(nz[0]) if nz else None, _ptr(nz[1]) if nz else None, st)
+            out.mstats = {"stats": stats, "expect": expect, "nz": nz, "res": res, "cand": cand,
+                          "P": (float(P.ecoef), float(P.pscale), int(P.flags)), "pi": np.array(pi_key, dtype=np.float64, copy=True)}
+        else:
+            self._call("estep", "pm_dsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]), _ptr(cand),
+                       _ptr(tab), S, _ptr(prior), ctypes.byref(P), N, H, Hp, _ptr(logpj), Kt, _ptr(lse), st)
+        return out
+
+    def _dsc_fused_stats(self, logpj, res, cand, P, pi_key, lse_cut):
+        """The statistics workspace the E-step pass has already filled for exactly this M-step, or None."""
+        ms = getattr(logpj, "mstats", None) if isinstance(logpj, DeviceArray) else None
+        if ms is None:
+            return None
+        logpj.mstats = None
+        if (ms["res"] is res and ms["cand"] is cand and lse_cut == float("-inf")
+                and ms["P"] == (float(P.ecoef), float(P.pscale), int(P.flags))
+                and np.array_equal(ms["pi"], np.asarray(pi_key, dtype=np.float64))):
+            return ms
+        return None
+
+    def _rows_and_wp(self, rows_args, lp_ld, expect, Y, stats, my_N, K, flags, Hp, S, fused=None):
         """DSC / TSC M-step: the per-datapoint pass (pm_dsc_mstep_rows[_nz]_f64) and Wp = E[s]^T Y.  Where the
         sixteen-lane kernel applies the pass also leaves the non-zero lists of E[s] and Wp is accumulated from them
         (pm_wp_sparse_f64); the dense product follows behind the device-side gate (last scalar of `stats`: rows whose
-        list overflowed) and only does work then."""
+        list overflowed) and only does work then.  ``fused``: the record of an E-step pass that has already produced the
+        row statistics (``_dsc_estep``): only the product is left."""
         H, D = self.H, self.D
         lib = _lib.load()
         st = self._stream()
+        gate = ctypes.c_void_p(stats.data_ptr() + 8 * (lib.pm_dsc_stats_len(H, D) - 1))
+        if fused is not None:
+            nz = fused["nz"]
+            if nz is not None:
+                self._call("stats_sparse", "pm_wp_sparse_f64", _ptr(nz[0]), _ptr(nz[1]), _ptr(Y), Y.stride(0), _ptr(stats),
+                           D, gate, my_N, H, D, st)
+                self._call("stats_gemm", "pm_gemm_tn_acc_gated_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D,
+                           my_N, gate, st)
+            else:
+                self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, st)
+            return
         sparse = (getattr(self, "sparse_wp", True) and Y.is_cuda and H <= 256
                   and bool(lib.pm_dsc_rows16_supported(H, Hp, S, K, flags)))
         if sparse:
             nz_idx, nz_val = self._buf("nz_idx", (my_N, 16), torch.int16), self._buf("nz_val", (my_N, 16))
             self._call("mstep_rows", "pm_dsc_mstep_rows_nz_f64", *(rows_args + (_ptr(nz_idx), _ptr(nz_val), st)))
-            gate = ctypes.c_void_p(stats.data_ptr() + 8 * (lib.pm_dsc_stats_len(H, D) - 1))
             self._call("stats_sparse", "pm_wp_sparse_f64", _ptr(nz_idx), _ptr(nz_val), _ptr(Y), Y.stride(0), _ptr(stats),
                        D, gate, my_N, H, D, st)
             self._call("stats_gemm", "pm_gemm_tn_acc_gated_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D,

@@ -303,16 +303,8 @@ class DSC_ET(DeviceCAModel):
         P = self._params(anneal, model_params['pi'], model_params['sigma'])
         prior = self._upload("dsc_prior", self._prior(np.asarray(model_params['pi'], dtype=np.float64)))
         Kt = 1 + (self.K - 1) * H + S
-        logpj = torch.empty((N, Kt), dtype=torch.float64, device=self.device)
-        lse = torch.empty((N,), dtype=torch.float64, device=self.device)
         tracing.tracepoint("E_step:iterating")
-        if N:
-            self._call("estep", "pm_dsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]), _ptr(cand),
-                       _ptr(tab), S, _ptr(prior), ctypes.byref(P), N, H, Hp, _ptr(logpj), Kt, _ptr(lse),
-                       self._stream())
-        out = DeviceArray(logpj)
-        out.lse = lse
-        return {'logpj': out}
+        return {'logpj': self._dsc_estep(anneal, "dsc_stats", par, res, cand, tab, S, prior, P, Kt, model_params['pi'])}
 
     @tracing.traced
     def M_step(self, anneal, model_params, my_suff_stat, my_data):
@@ -353,15 +345,17 @@ class DSC_ET(DeviceCAModel):
         tracing.tracepoint("M_step:iterating")
         lib = _lib.load()
         n_stats = lib.pm_dsc_stats_len(H, D)
-        stats = self._buf("dsc_stats", (n_stats,))
-        stats.zero_()
-        expect = self._buf("expect", (my_N, H))
         P = self._params(anneal, pi, sigma)
+        fused = self._dsc_fused_stats(logpj, res, cand, P, pi, lse_cut) if my_N else None
+        stats = fused["stats"] if fused else self._buf("dsc_stats", (n_stats,))
+        if not fused:
+            stats.zero_()
+        expect = self._buf("expect", (my_N, H))
         prior = self._upload("dsc_prior", self._prior(pi))
         if my_N:
             self._rows_and_wp((_ptr(lp), Kt, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S, _ptr(prior),
                                ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats)),
-                              Kt, expect, Y, stats, my_N, self.K, int(P.flags), Hp, S)
+                              Kt, expect, Y, stats, my_N, self.K, int(P.flags), Hp, S, fused=fused)
         comm.allreduce_device(stats)      # replaces dsc_et.py:648,738,739,747,769 and the allreduce in get_likelihood
         self._mstep_res = res
         return self._finalize(stats, model_params)

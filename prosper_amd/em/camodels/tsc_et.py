@@ -258,15 +258,8 @@ class TSC_ET(DeviceCAModel):
         cand = self._device_candidates(my_data['candidates'], N)
         P = self._params(anneal, model_params['sigma'])
         prior = self._upload("tsc_prior", self._prior(model_params['pi']))
-        logpj = torch.empty((N, S), dtype=torch.float64, device=self.device)
-        lse = torch.empty((N,), dtype=torch.float64, device=self.device)
         tracing.tracepoint("E_step:iterating")
-        if N:
-            self._call("estep", "pm_dsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]), _ptr(cand),
-                       _ptr(tab), S, _ptr(prior), ctypes.byref(P), N, H, Hp, _ptr(logpj), S, _ptr(lse), self._stream())
-        out = DeviceArray(logpj)
-        out.lse = lse
-        return {'logpj': out}
+        return {'logpj': self._dsc_estep(anneal, "tsc_stats", par, res, cand, tab, S, prior, P, S, [model_params['pi']])}
 
     @tracing.traced
     def M_step(self, anneal, model_params, my_suff_stat, my_data):
@@ -314,15 +307,17 @@ class TSC_ET(DeviceCAModel):
 
         tracing.tracepoint("M_step:iterating")
         lib = _lib.load()
-        stats = self._buf("tsc_stats", (lib.pm_dsc_stats_len(H, D),))
-        stats.zero_()
-        expect = self._buf("expect", (my_N, H))
         P = self._params(anneal, sigma)
+        fused = self._dsc_fused_stats(logpj, res, cand, P, [pi], lse_cut) if my_N else None
+        stats = fused["stats"] if fused else self._buf("tsc_stats", (lib.pm_dsc_stats_len(H, D),))
+        if not fused:
+            stats.zero_()
+        expect = self._buf("expect", (my_N, H))
         prior = self._upload("tsc_prior", self._prior(pi))
         if my_N:
             self._rows_and_wp((_ptr(lp), S, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S, _ptr(prior),
                                ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats)),
-                              S, expect, Y, stats, my_N, int(P.K), int(P.flags), Hp, S)
+                              S, expect, Y, stats, my_N, int(P.K), int(P.flags), Hp, S, fused=fused)
         comm.allreduce_device(stats)      # replaces tsc_et.py:412,446,453,486,487,497,527
         self._mstep_res = res
         return self._finalize(stats, model_params, A_pi_gamma, E_pi_gamma)

@@ -167,6 +167,57 @@ def test_dsc_inference_matches_reference(tag, kw, capsys):
     np.testing.assert_allclose(res["m"], g[tag + "_m"], rtol=1e-8, atol=1e-12)
 
 
+@pytest.mark.parametrize("model,T,D,H,Hp,gamma,N", [("dsc", 1.0, 96, 128, 6, 3, 5003), ("tsc", 1.0, 96, 128, 6, 3, 5003),
+                                                  ("dsc", 3.0, 40, 20, 4, 3, 333), ("tsc", 2.0, 40, 50, 5, 2, 1000),
+                                                  ("dsc", 1.0, 64, 200, 9, 2, 777)])
+def test_estep_pass_with_mstep_statistics_matches_two_passes(model, T, D, H, Hp, gamma, N):
+    """Inside `step` with no data truncation ahead the E-step kernel also produces the M-step's row statistics
+    (pm_dsc_estep_mstats_f64: posterior weights from the exponentials of its log-sum-exp).  Same statistics buffer, E[s]
+    rows and parameters as the two-pass form (pm_dsc_estep_f64 + pm_dsc_mstep_rows_nz_f64), which the goldens pin."""
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    from prosper_amd.em.camodels.tsc_et import TSC_ET
+    rng = np.random.RandomState(D + H + N)
+    W_gt = 2.0 * rng.normal(size=(D, H))
+    u = rng.random_sample((N, H))
+    y = ((u < 1.5 / H).astype(float) - (u > 1 - 1.5 / H)) @ W_gt.T + rng.normal(size=(N, D))
+    W0 = W_gt + 0.1 * rng.normal(size=(D, H))
+    out = {}
+    for fuse in (True, False):
+        if model == "dsc":
+            m = DSC_ET(D, H, Hp, gamma, states=np.array([-1., 0., 1.]))
+            p = {"W": W0, "pi": np.array([1.5 / H, 1 - 3.0 / H, 1.5 / H]), "sigma": 1.0}
+        else:
+            m = TSC_ET(D, H, Hp, gamma)
+            p = {"W": W0, "pi": 3.0 / H, "sigma": 1.0}
+        m.fuse_mstats = fuse
+        names = []
+        orig = m._call
+        m._call = lambda label, name, *a, _o=orig, _n=names: (_n.append(name), _o(label, name, *a))[1]
+        new = m.step(_An(T=T), dict(p), {"y": y})
+        st = m._ws["dsc_stats" if model == "dsc" else "tsc_stats"].cpu().numpy().copy()
+        out[fuse] = (new, st, m._ws["expect"].cpu().numpy().copy(), names)
+    a, b = out[True], out[False]
+    from prosper_amd import _lib
+    K, flags = (3, 0) if model == "dsc" else (3, 3)
+    can = bool(_lib.load().pm_dsc_estep_mstats_supported(H, Hp, m.no_states if model == "dsc" else m.state_matrix.shape[0], K, flags))
+    assert can                                # (every shape of this test fits; where the layout does not: two passes, silently)
+    if can:
+        assert "pm_dsc_estep_mstats_f64" in a[3] and "pm_dsc_mstep_rows_nz_f64" not in a[3] and "pm_dsc_estep_f64" not in a[3]
+    else:
+        assert "pm_dsc_estep_mstats_f64" not in a[3] and "pm_dsc_estep_f64" in a[3]
+    assert "pm_dsc_estep_mstats_f64" not in b[3] and "pm_dsc_estep_f64" in b[3]
+    # E[s] rows: weights below e^-37 of the row maximum (fused) / e^-60 of the evidence (two passes) are dropped
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-10, atol=1e-15)
+    np.testing.assert_allclose(a[1][:-1], b[1][:-1], rtol=1e-9, atol=1e-11 * np.abs(b[1]).max())
+    for k in ("W", "pi", "sigma"):
+        np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-9, atol=1e-12)
+    # ... and a truncation step takes the two-pass form on its own
+    m.fuse_mstats = True
+    names.clear()
+    m.step(_An(T=T, Ncut_factor=0.5), dict(p), {"y": y})
+    assert "pm_dsc_estep_f64" in names and "pm_dsc_estep_mstats_f64" not in names
+
+
 @pytest.mark.parametrize("model", ["dsc", "tsc"])
 def test_em_loop_speculation_is_transparent(model):
     """The M-step leaves the next step's W^T, Gram matrix and scores on the device (DeviceCAModel._seed_next).  A
