@@ -169,7 +169,7 @@ def test_dsc_inference_matches_reference(tag, kw, capsys):
 
 @pytest.mark.parametrize("model,T,D,H,Hp,gamma,N", [("dsc", 1.0, 96, 128, 6, 3, 5003), ("tsc", 1.0, 96, 128, 6, 3, 5003),
                                                   ("dsc", 3.0, 40, 20, 4, 3, 333), ("tsc", 2.0, 40, 50, 5, 2, 1000),
-                                                  ("dsc", 1.0, 64, 200, 9, 2, 777)])
+                                                  ("dsc", 1.0, 64, 200, 9, 2, 9000)])
 def test_estep_pass_with_mstep_statistics_matches_two_passes(model, T, D, H, Hp, gamma, N):
     """Inside `step` with no data truncation ahead the E-step kernel also produces the M-step's row statistics
     (pm_dsc_estep_mstats_f64: posterior weights from the exponentials of its log-sum-exp).  Same statistics buffer, E[s]
