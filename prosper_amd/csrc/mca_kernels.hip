@@ -114,6 +114,10 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
     double *s_wr = s_tab + PM_POWTAB_LEN + (size_t)wave * (Hp * DS + S);
     double *s_e = s_wr + Hp * DS;
     pm_load_powtab(s_tab, tid, blockDim.x);
+    // rho = 21 (every temperature T <= 1.05), unsigned W: the log / exp-free power (pm_pow_m20_21)
+    __shared__ __attribute__((aligned(16))) double s_rt[PM_ROOT21_LEN + 1];
+    const bool r21 = P.signed_w == 0.0 && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
+    if (r21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
     __syncthreads();
 
     const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
@@ -161,7 +165,9 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
             for (int i = 0; i < DPL; ++i) {
                 // MMCA: T may be negative or 0 (mmca_et.py:191: sign(t) exp(log|t| / rho)); for MCA T > 0
                 const double aT = fabs(T[i]);
-                const double wbar = (aT > 0.0) ? copysign(pm_pow_tab(aT, P.inv_rho, s_tab), T[i]) : 0.0;
+                const double wbar = (aT > 0.0) ? (r21 ? aT * pm_pow_m20_21(aT, s_rt)
+                                                      : copysign(pm_pow_tab(aT, P.inv_rho, s_tab), T[i]))
+                                               : 0.0;
                 const double df = wbar - y[i];
                 part = fma(df, df, part);
             }
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
 // smaller than its final value, so nothing underflows that would survive in the two-pass form.
 // ---------------------------------------------------------------------------------------------
 
-template <int DPL, int HP, bool SIGNED>
+// RHO21: rho = 21 (every temperature T <= 1.05, unsigned W): the states' power through pm_pow_m20_21 (no log / exp)
+template <int DPL, int HP, bool SIGNED, bool RHO21>
 __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
                                        const double *__restrict__ wnorm2, const double *__restrict__ ynorm2,
                                        const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
@@ -241,13 +248,16 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                                        double *__restrict__ lse1, double *__restrict__ lseb,
                                        double *__restrict__ q1, int64_t ldq, double *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [ power tables (PM_POWTAB_LEN) | q1sum (H) | red (4 * waves) | per wave: wr (HP*DS) [wm (HP*DS)] e (S) ]
+    // [ power tables (PM_POWTAB_LEN) | root table (PM_ROOT21_LEN) | q1sum (H) | red (4 * waves) | per wave: wr (HP*DS)
+    //   [wm (HP*DS)] e (S) ]
     constexpr int DS = 64 * DPL;
     const int waves = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *s_tab = reinterpret_cast<double *>(smem);
-    double *s_q1sum = s_tab + PM_POWTAB_LEN;
+    double *s_rt = s_tab + PM_POWTAB_LEN;
+    double *s_q1sum = s_rt + PM_ROOT21_LEN + 1;          // (+ 1: 16-byte alignment of what follows stays as it was)
     pm_load_powtab(s_tab, tid, blockDim.x);
+    if (RHO21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
     double *s_red = s_q1sum + H;
     const size_t per_wave = (size_t)(SIGNED ? 2 : 1) * HP * DS + S;
     double *s_wr = s_red + 4 * waves + (size_t)wave * per_wave;
@@ -319,7 +329,8 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
 #pragma unroll
             for (int i = 0; i < DPL; ++i) {
                 const double aT = SIGNED ? fabs(T[i]) : T[i];      // (unsigned W: T is a sum of W^rho >= 0)
-                const double r = (PM_MCA_ABL == 2) ? aT * 0.37 : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab);
+                const double r = (PM_MCA_ABL == 2) ? aT * 0.37
+                                 : (RHO21 ? pm_pow_m20_21(aT, s_rt) : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
                 const double wb = (aT > 0.0) ? aT * r : 0.0;
                 const double df = (SIGNED ? copysign(wb, T[i]) : wb) - y[i];
                 partP = fma(df, df, partP);
@@ -345,7 +356,8 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                 // ONE power per element: r = |T|^(1/rho - 1) gives |Wbar| = |T| r here and Wbar / T = r for the
                 // M-step weights (no division).  Padding dimensions have T = 0: Wbar = 0, never scattered.
                 const double aT = SIGNED ? fabs(T[i]) : T[i];      // (unsigned W: T is a sum of W^rho >= 0)
-                const double r = (PM_MCA_ABL == 2) ? aT * 0.37 : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab);
+                const double r = (PM_MCA_ABL == 2) ? aT * 0.37
+                                 : (RHO21 ? pm_pow_m20_21(aT, s_rt) : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
                 const double wb = (aT > 0.0) ? aT * r : 0.0;
                 const double df = (SIGNED ? copysign(wb, T[i]) : wb) - y[i];
                 partN = fma(df, df, partN);
@@ -554,6 +566,9 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
     double *s_wr = s_red + 4 * waves + (size_t)wave * ((SIGNED ? 2 : 1) * HP * DS);
     double *s_wm = s_wr + HP * DS;   // SIGNED only: |W|^(rho-1)[cand]
     for (int h = tid; h < H; h += blockDim.x) s_q1sum[h] = 0.0;
+    __shared__ __attribute__((aligned(16))) double s_rt[PM_ROOT21_LEN + 1];       // (see mca_estep_kernel)
+    const bool r21 = !SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
+    if (r21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
     __syncthreads();
 
     // multi-cause numerator / denominator (stats[0 .. H*D) = Q1^T Y by the GEMM): this XCD's copy, folded by
@@ -660,7 +675,8 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
 #pragma unroll
                 for (int i = 0; i < DPL; ++i) {
                     if (!SIGNED) {
-                        v[i] = (T[i] > 0.0) ? q * pm_pow_tab(T[i], P.inv_rho - 1.0, s_tab) : 0.0;  // q_s Wbar_sd / T_sd = q_s T^(1/rho - 1); padding: T = 0
+                        // q_s Wbar_sd / T_sd = q_s T^(1/rho - 1); padding: T = 0
+                        v[i] = (T[i] > 0.0) ? q * (r21 ? pm_pow_m20_21(T[i], s_rt) : pm_pow_tab(T[i], P.inv_rho - 1.0, s_tab)) : 0.0;
                     } else {
                         // q_s min(1, (|W_jd| / |Wbar_sd|)^(rho-1)), (.)^(rho-1) = |W_jd|^(rho-1) |Wbar_sd| / |t_sd|;
                         // t = 0 gives Wbar = 0 and the factor 1 (mmca_et.py:316-324: max(-inf - Wl, 0) = 0)
@@ -880,11 +896,25 @@ int launch_fused_hp(int Hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, 
                     int H, int D, double *logpj, int64_t ldl, double *lse1, double *lseb, double *q1, int64_t ldq,
                     double *stats) {
     const int hp = Hp <= 4 ? 4 : Hp <= 8 ? 8 : 12;
+    // rho = 21 (T <= 1.05: mca_et.py:142 clamps the temperature there), unsigned W: the log / exp-free power
+#ifdef PM_MCA_NO_ROOT21
+    const bool rho21 = false;
+#else
+    const bool rho21 = !SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
+#endif
 #define PM_CASE(HPV)                                                                                                  \
     case HPV: {                                                                                                       \
-        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, SIGNED>), shmem))   \
+        if (rho21) {                                                                                                  \
+            if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, false, true>), shmem)) \
+                return e;                                                                                             \
+            hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, false, true>), grid, block, shmem, s, scores, lds, wnorm2, \
+                               ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, \
+                               ldq, stats);                                                                           \
+            return (int)hipGetLastError();                                                                            \
+        }                                                                                                             \
+        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, SIGNED, false>), shmem)) \
             return e;                                                                                                 \
-        hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, SIGNED>), grid, block, shmem, s, scores, lds, wnorm2,    \
+        hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, SIGNED, false>), grid, block, shmem, s, scores, lds, wnorm2, \
                            ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, ldq, \
                            stats);                                                                                    \
         return (int)hipGetLastError();                                                                                \
@@ -915,7 +945,7 @@ extern "C" int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const 
     const bool sgn = params_host->signed_w != 0.0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl * (sgn ? 2 : 1) + S);
-    const size_t shared = sizeof(double) * (PM_POWTAB_LEN + H + 16);
+    const size_t shared = sizeof(double) * (PM_POWTAB_LEN + PM_ROOT21_LEN + 1 + H + 16);
     const int waves = pick_waves(per_wave, shared);
     const size_t shmem = shared + per_wave * waves;
     if (shmem > 150 * 1024) return PM_ERANGE;

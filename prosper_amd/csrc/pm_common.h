@@ -191,6 +191,47 @@ __device__ __forceinline__ double pm_pow_tab(double x, double c, const double *t
     return __hiloint2double(__double2hiint(r) + ((k >> 7) << 20), __double2loint(r));
 }
 
+// x^(1/21 - 1) = x^(-20/21) for NORMAL x > 0 -- the power of MCA's multi-cause states at rho = 21, i.e. at every annealing
+// temperature T <= 1.05 (mca_et.py:142-175: rho = 1 / (1 - 1 / max(T, 1.05))), the steady state of a run -- without a
+// logarithm or an exponential:  x = 2^(21 q + r) m,  x' = 2^r m,  y = x'^(-1/21) from a table seed
+//   y0 = 2^(-r/21) r_i^(1/21) (1 - d / 21),  d = m r_i - 1 < 2^-7   (r_i: pm_pow_tab's reciprocal table; error 1.5e-6)
+// then  x'^(-20/21) = y0^20 (1 - res)^(-20/21),  res = 1 - x' y0^21  (|res| < 4e-5: three series terms, the fourth is 1e-18)
+// with y0^20, y0^21 by repeated squaring: 15 f64 + 11 integer instructions and two LDS lookups against pm_pow_tab's 36 + 2,
+// and a dependent chain of 14 instead of ~20.  The rounding errors of the power chain cancel between y0^20 and the
+// residual: relative error <= 3e-16 against an 80-bit reference over [e^-190, e^40] (pm_pow_tab: 2.3e-16).
+// `rt`: the workgroup's LDS table from pm_load_root21 -- 128 pairs (r_i, r_i^(1/21)), then 2^(-r/21), r = 0 .. 20.
+#define PM_ROOT21_LEN (256 + 21)
+__device__ __forceinline__ void pm_load_root21(double *rt, const double *powtab, int tid, int nthreads) {
+    for (int i = tid; i < 128; i += nthreads) {
+        const double ri = powtab[2 * i];
+        rt[2 * i] = ri;
+        rt[2 * i + 1] = pow(ri, 1.0 / 21.0);
+    }
+    for (int r = tid; r < 21; r += nthreads) rt[256 + r] = exp2(-(double)r / 21.0);
+}
+__device__ __forceinline__ double pm_pow_m20_21(double x, const double *rt) {
+    typedef double pm_d2 __attribute__((ext_vector_type(2)));
+    const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
+    const unsigned idx = (hi >> 13) & 127u;
+    const pm_d2 rs = reinterpret_cast<const pm_d2 *>(rt)[idx];
+    const unsigned eu = (hi >> 20) + 27u;                    // biased exponent - 1023 + 1050 in [28, 2073]
+    const unsigned q = (eu * 3121u) >> 16;                   // eu / 21 (exact on that range)
+    const unsigned r = eu - 21u * q;
+    const unsigned mant = hi & 0x000FFFFFu;
+    const double m = __hiloint2double((int)(mant | 0x3FF00000u), (int)lo);             // [1, 2)
+    const double xp = __hiloint2double((int)(mant | ((1023u + r) << 20)), (int)lo);    // 2^r m
+    const double d = fma(m, rs.x, -1.0);
+    const double y0 = (rs.y * rt[256 + r]) * fma(d, -1.0 / 21.0, 1.0);
+    const double y2 = y0 * y0, y4 = y2 * y2, y8 = y4 * y4, y16 = y8 * y8;
+    const double y20 = y16 * y4;
+    const double res = fma(-xp, y20 * y0, 1.0);
+    double t = fma(res, 20.0 * 41.0 * 62.0 / (6.0 * 9261.0), 20.0 * 41.0 / (2.0 * 441.0));
+    t = fma(t, res, 20.0 / 21.0);
+    const double v = fma(y20, t * res, y20);
+    // * 2^(-20 (q - 50))
+    return __hiloint2double(__double2hiint(v) + (int)((1000u - 20u * q) << 20), __double2loint(v));
+}
+
 // e^x for x <= ~700 from the same tables: x = k ln2/128 + r (two-part ln2/128, |r| <= ln2/256), e^r by a degree-5
 // polynomial, 2^(k/128) = 2^N E_j.  Arguments below -708 return ~1e-308 (callers only scale by it).  14 VALU slots and one
 // LDS lookup; relative error <= 2.3e-16.
