@@ -146,8 +146,11 @@ struct GscTables {
 // LACC: the column sums of xpt_s / xpt_sz are accumulated in LDS, one private slot per (datapoint row of the workgroup,
 // latent) -- plain read-add-write, no atomics, no conflicts -- and folded over the rows at the end: no second pass over the
 // N x H moments (gsc_colsum_kernel read 410 MB again at config 4: 0.09 ms).
+#ifndef PM_GSC_WPE
+#define PM_GSC_WPE 3        // wavefronts per SIMD the common instantiations are compiled for (register budget 512 / WPE)
+#endif
 template <int VPL, int GMAX, bool LPJ, bool LACC>
-__global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict__ scores, int64_t lds,
+__global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void gsc_estep_kernel(const double *__restrict__ scores, int64_t lds,
                                                          const double *__restrict__ gram,
                                                          const double *__restrict__ psi,
                                                          const double *__restrict__ ynorm2, GscTables T,
@@ -178,11 +181,13 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     // vector-memory operation at all (see the deferred pair atomics below)
     uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_dp + ROWS * dp_stride);
     for (int s = tid; s < S; s += 256) s_masks[s] = masks[s];
-    // LACC: [2][ROWS][H] private accumulators behind the masks (8-byte aligned)
+    // LACC: [3][4 wavefronts][H] accumulators (column sums of xpt_s, of xpt_sz, the singletons' diagonal of sum xpt_szsz) behind the masks (8-byte aligned); the four datapoint rows of a wavefront add
+    // into the same slots (LDS atomics, 4-way same-address: 16 instructions per four datapoints, nothing beside the
+    // ~3300 the rest of them costs) -- per-row private slots cost 32 KB and the third workgroup per CU
     double *s_acc = reinterpret_cast<double *>(smem + ((8 * (size_t)(8 * H + ROWS * dp_stride) + 2 * (size_t)S + 7) & ~(size_t)7));
     if (LACC)
-        for (int e = tid; e < 2 * ROWS * H; e += 256) s_acc[e] = 0.0;
-    double *acc_mine = s_acc + (size_t)(wave * 4 + row) * H + j;        // + 16 i: latent j + 16 i; + ROWS * H: next quantity
+        for (int e = tid; e < 3 * 4 * H; e += 256) s_acc[e] = 0.0;
+    double *acc_mine = s_acc + (size_t)wave * H + j;                    // + 16 i: latent j + 16 i; + 4 * H: next quantity
     __shared__ double s_E[128];                           // 2^(j/128): pm_exp_tab's table
     if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
     const double *etab = s_E - 256;
@@ -202,9 +207,9 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     // sum xpt_ss = column sum of xpt_s; the column sums of xpt_s / xpt_sz come from gsc_colsum_kernel.)  Phases
     // are ordered so that nothing per-latent is live across the multi-cause loop: the kernel's occupancy is set
     // by that loop's g x g algebra (two waves per SIMD) and not by VPL.
-    double dszsz[VPL];
+    double dszsz[LACC ? 1 : VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) dszsz[i] = 0.0;
+    for (int i = 0; i < (LACC ? 1 : VPL); ++i) dszsz[i] = 0.0;
     const int rowbase = lane & 48;
     // The block sums of xpt_ss / xpt_szsz go to global memory as f64 atomics whose round trip is microseconds; any
     // vector-memory wait after them (vmcnt counts in issue order) exposes it.  So a datapoint's atomics are
@@ -415,21 +420,20 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         int64_t row_off = nn * lds;
         asm volatile("" : "+v"(row_off));
         const double *arow2 = scores + row_off;
-        double av1[VPL], xs[VPL];
+        double xs[VPL];
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
-            double p = 0.0, ai = 0.0;
+            double p = 0.0;
             if (h < H) {
                 // the un-clamped singleton log-posterior (the score clamps are selection-only)
-                ai = arow2[h];
+                const double ai = arow2[h];
                 const double bb = ai - s_gm[h];
                 const double lp = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h] + s_lpi[h];
                 if (LPJ && live) logpj[n * ldl + 1 + h] = lp;
                 p = gsc_weight(lp * beta, etab);
                 Z += p;
             }
-            av1[i] = ai;
             xs[i] = p;
         }
         Z = g_row_sum(Z);
@@ -442,14 +446,18 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
             double kap = 0.0, il = 0.0;
-            if (h < H) {
-                kap = (av1[i] - s_gm[h]) * s_kl[h] + s_mu[h];
+            if (h < H) {      // (the score once more from the vector cache: eight registers less across the phase)
+                kap = (arow2[h] - s_gm[h]) * s_kl[h] + s_mu[h];
                 il = s_ilam[h];
             }
             xsz[i] = xs[i] * kap;
             // singles contribute to the diagonals of sum xpt_ss / xpt_szsz (multi-cause diagonal terms went
             // through the block atomics above)
-            if (live) dszsz[i] += xs[i] * (kap * kap + il) * nf;
+            if (LACC) {
+                if (live && h < H) atomicAdd(&acc_mine[8 * H + 16 * i], xs[i] * (kap * kap + il) * nf);
+            } else if (live) {
+                dszsz[i] += xs[i] * (kap * kap + il) * nf;
+            }
         }
         for (int k = 0; k < Hp; ++k) {
             const int c = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc);
@@ -470,8 +478,8 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
                 xpt_s[n * ldx + h] = vs;
                 xpt_sz[n * ldx + h] = vz;
                 if (LACC) {
-                    acc_mine[16 * i] += vs;
-                    acc_mine[ROWS * H + 16 * i] += vz;
+                    atomicAdd(&acc_mine[16 * i], vs);
+                    atomicAdd(&acc_mine[4 * H + 16 * i], vz);
                 }
             }
         }
@@ -487,20 +495,19 @@ __global__ __launch_bounds__(256) void gsc_estep_kernel(const double *__restrict
     // the grid's tail on them.
     __syncthreads();
     double *g_cs = stats + 2 * (int64_t)H * H;          // [column sums of xpt_s | of xpt_sz | singleton diagonal of sum xpt_szsz]
-    if (LACC) {
-        for (int e = tid; e < 2 * H; e += 256) {
+    if (LACC) {       // [column sums of xpt_s | of xpt_sz | singleton diagonal]: the four wavefronts' slots, then one atomic each
+        for (int e = tid; e < 3 * H; e += 256) {
             const int q = e / H, h = e - q * H;
-            const double *src = s_acc + (size_t)q * ROWS * H + h;
-            double v = 0.0;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) v += src[(size_t)r * H];            // fixed order
+            const double *src = s_acc + (size_t)q * 4 * H + h;
+            const double v = (src[0] + src[H]) + (src[2 * (size_t)H] + src[3 * (size_t)H]);
             if (v != 0.0) pm_atomic_add(g_cs + e, v);
         }
+        return;
     }
     for (int h = tid; h < H; h += 256) s_c0[h] = 0.0;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
+    for (int i = 0; i < (LACC ? 1 : VPL); ++i) {
         const int h = j + 16 * i;
         const double c_d = g_col_sum(dszsz[i]);             // rows of the wave first
         if (row == 0 && h < H) atomicAdd(&s_c0[h], c_d);
@@ -573,10 +580,9 @@ extern "C" int64_t pm_gsc_stats_len(int64_t H) { return 2 * H * H + 3 * H + (PM_
 static size_t gsc_shmem(int64_t H, int64_t Hprime, int64_t S) {
     return sizeof(double) * (8 * H + ROWS * (48 + 4 * Hprime * Hprime) + (S + 3) / 4);
 }
-// ... with the per-row accumulators of the column sums behind it (LACC); used when two workgroups still fit a CU (80 KB:
-// the kernel's 244 registers allow two wavefronts per SIMD anyway) -- H <= 128 at H' = 6
+// ... with the per-wavefront accumulators of the column sums behind it (LACC); used when three workgroups still fit a CU
 static size_t gsc_shmem_lacc(int64_t H, int64_t Hprime, int64_t S) {
-    return gsc_shmem(H, Hprime, S) + sizeof(double) * (2 * ROWS * H + 1);
+    return gsc_shmem(H, Hprime, S) + sizeof(double) * (3 * 4 * H + 1);
 }
 
 extern "C" int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma) {
@@ -692,7 +698,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
     if (!pm_gsc_supported(H, Hprime, gamma)) return PM_ERANGE;
     GscTables T{tables, tables + H, tables + 2 * H, tables + 3 * H, tables + 4 * H, tables + 5 * H, tables + 6 * H,
                 tables + 7 * H};
-    const bool lacc = gsc_shmem_lacc(H, Hprime, S) <= 80 * 1024;
+    const bool lacc = gsc_shmem_lacc(H, Hprime, S) <= 53 * 1024;
     const size_t shmem = lacc ? gsc_shmem_lacc(H, Hprime, S) : gsc_shmem(H, Hprime, S);
     if (gsc_shmem(H, Hprime, S) > 64 * 1024) return PM_ERANGE;
     int64_t groups = (N + ROWS - 1) / ROWS;
