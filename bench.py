@@ -14,7 +14,8 @@ second region and reported as `em_iter_ms`.
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- bsc_estep_fused_kernel: scores GEMM,
 selection and E-step of 196 608 datapoints in one launch -- by its algorithmic flops / its average launch duration
 measured with HIP events on its stream inside the timed region, and reports the whole pass against the MFMA and HBM
-roofs beside it (`estep_mfma_frac`, `estep_hbm_frac`); `traffic` comes from committed PMC passes (`traffic_source`).
+roofs beside it (`estep_mfma_frac`, `estep_hbm_frac`); `traffic` comes from committed PMC passes (`traffic_source`), the wave-instruction counts of the VALU-issue rooflines
+likewise (`counts_source`, with `stale` = "taken on another build of the library").
 `cpu_baseline` is the oracle's faithful per-datapoint restatement of the reference timed on this box's host cores on
 a bounded sample (rank 0, N=1 only), with the rate of one uncontended process and of the oracle's vectorised
 multi-threaded form beside it; `parity` compares the HIP path with the oracle's answer (minted by that same leg) after
@@ -65,22 +66,45 @@ def parse():
     return ap.parse_args()
 
 
-def valu_issue_roofline(kernel_prefix, measured_ms, what):
-    """Roofline of a VALU-bound row kernel against the f64 vector ISSUE roof: the kernel's dynamic wave-instruction count
-    (SQ_INSTS_VALU per launch, profiles/r03_valu_counts.json -- a separate rocprofv3 --pmc pass of this command, not this
-    run) x 4 cycles / (1024 SIMDs x 2.4 GHz) is the time the chip needs just to issue them; `frac` = that floor / the launch
-    duration measured here.  (These kernels move a few hundred MB per launch: the HBM roof is 3-10x further away.)"""
+VALU_COUNTS = "r04_valu_counts.json"
+PMC_TRAFFIC = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
+def _library_sha16():
+    import hashlib
     try:
-        kern = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_counts.json")))["kernels"]
+        return hashlib.sha256(open(os.path.join(ROOT, "prosper_amd", "libprosper_hip.so"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def valu_issue_roofline(kernel_prefix, measured_ms, what, grid=None):
+    """Roofline of a VALU-bound row kernel against the f64 vector ISSUE roof: the kernel's dynamic wave-instruction count
+    (SQ_INSTS_VALU per launch) x 4 cycles / (1024 SIMDs x 2.4 GHz) is the time the chip needs just to issue them; `frac` =
+    that floor / the launch duration measured here.  The count is EXTERNAL evidence -- a separate rocprofv3 --pmc pass
+    (profiles/r04_valu_counts.json, scratch/profile_r04.sh), not this run: `counts_library_sha16` is the build it was taken
+    on and `stale` says whether that is the build running now (a kernel change moves the count: then the fraction is only
+    indicative).  `grid`: the launch geometry to match when the file holds the kernel at several.
+    (These kernels move a few hundred MB per launch: the HBM roof is 3-10x further away.)"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", VALU_COUNTS)))
+        kern = rec["kernels"]
         key = [k for k in kern if k.startswith(kernel_prefix)]
+        if grid is not None and any(k.endswith("@grid%d" % grid) for k in key):
+            key = [k for k in key if k.endswith("@grid%d" % grid)]
         if not key:
             return None
-        insts = kern[key[0]]["valu_insts"]
+        key = max(key, key=lambda k: kern[k]["valu_insts"])          # (the full-size launch, not a warm-up shape)
+        insts = kern[key]["valu_insts"]
         floor_ms = insts * 4.0 / (1024 * 2.4e9) * 1e3
+        sha = _library_sha16()
         return {"bound": "valu_issue", "kernel": what, "achieved": insts / (measured_ms * 1e-3) / 1e9,
                 "peak": 1024 * 2.4e9 / 4.0 / 1e9, "unit": "G wave-instructions/s", "frac": floor_ms / measured_ms,
                 "avg_launch_ms": measured_ms, "issue_floor_ms": floor_ms, "valu_insts_per_launch": insts,
-                "counts_source": "profiles/r03_valu_counts.json (%s; separate --pmc pass, not this run)" % key[0],
+                "waves_per_launch": kern[key].get("waves"), "busy_cycles_per_launch": kern[key].get("busy_cycles"),
+                "counts_source": "profiles/%s (%s; separate --pmc pass, not this run)" % (VALU_COUNTS, key),
+                "counts_from_this_run": False, "counts_library_sha16": rec.get("library_sha16"),
+                "stale": (rec.get("library_sha16") != sha) if (sha and rec.get("library_sha16")) else None,
                 "traffic": None}
     except Exception as e:
         return {"error": repr(e)}
@@ -136,9 +160,9 @@ def other_models(dev, Anneal, steps=20):
                                                          "gsc_estep_kernel (select + E-step, one pass over the scores)")
             if out["gsc_c4_roofline"] and "frac" in out["gsc_c4_roofline"]:
                 out["gsc_c4_roofline"]["note"] = (
-                    "avg_launch_ms brackets the whole pm_gsc_estep_f64 call with HIP events: gsc_estep_kernel (0.67 ms in "
-                    "rocprofv3's per-kernel view) + pm_fold_copies_kernel + gsc_colsum_kernel and the gaps between the three "
-                    "launches (~0.1 ms) -- the 0.67 vs 0.79 ms of round 2; frac prices the call, i.e. reads low by that share")
+                    "avg_launch_ms brackets the whole pm_gsc_estep_f64 call with HIP events: gsc_estep_kernel + "
+                    "pm_fold_copies_kernel and the gap between the two launches; frac prices the call, i.e. reads a few "
+                    "per cent low (the column-sum kernel of rounds 1-3 is gone: the sums are accumulated in the pass)")
         del Y, m
         # --- MCA, config 5 (N = 800k over 8 GPUs)
         N = 100_000
@@ -206,13 +230,11 @@ def other_models(dev, Anneal, steps=20):
             m.timer = None
             ks = kt.summary()
             out["%s_kernels_ms" % name] = {k: round(v[1], 4) for k, v in sorted(ks.items())}
-            if name == "dsc":       # (the two DSC row kernels; TSC runs the same kernels on its own state table)
-                if "estep" in ks:
-                    out["dsc_estep_roofline"] = valu_issue_roofline("dsc_only:dsc_estep16_kernel", ks["estep"][1],
-                                                                    "dsc_estep16_kernel (log-joints of the K-ary states)")
-                if "mstep_rows" in ks:
-                    out["dsc_mstep_rows_roofline"] = valu_issue_roofline("dsc_only:dsc_mstep_rows16_kernel", ks["mstep_rows"][1],
-                                                                         "dsc_mstep_rows16_kernel (posterior moments)")
+            if name == "dsc":       # (the DSC row kernel; TSC runs the same kernel on its own state table)
+                if "estep_mstats" in ks:
+                    out["dsc_estep_mstats_roofline"] = valu_issue_roofline(
+                        "dsc_only:dsc_estep16_ms_kernel", ks["estep_mstats"][1],
+                        "dsc_estep16_ms_kernel (log-joints of the K-ary states + the M-step's row statistics, one pass)")
     except Exception as e:   # never lose the headline over the side measurements
         out["error"] = repr(e)
     gc.enable()
@@ -489,7 +511,7 @@ def main():
         # HBM-side bytes of the dominant kernel: NOT measured in this run -- from the committed rocprofv3 --pmc passes
         # (profiles/summarize_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), per launch
         traffic, traffic_source = None, None
-        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in PMC_TRAFFIC:
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"]
                 cands = [k for k, v in pmc.items() if k.startswith(dom) and v.get("datapoints_per_launch") == chunk]
