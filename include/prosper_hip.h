@@ -70,6 +70,13 @@ int pm_gemm_tn_acc_f64(const double *A, int64_t lda, const double *B, int64_t ld
  * dense half of the pair (pm_bsc_wp_sparse_f64, this) that is enqueued without the host knowing which one applies. */
 int pm_gemm_tn_acc_gated_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                              int64_t M, int64_t N, int64_t K, const double *gate, void *stream);
+/* C[M,N] += sum over the rows r = rows[0 .. *count) of A[r,:M]^T . B[r,:N]: the same product over a device-side list of
+ * rows with a device-side length (count <= max_rows) -- the dense datapoints of GSC's moment contraction
+ * (gsc_et.py:592-625; pm_gsc_estep_lists_f64 leaves the list).  `zero_row`: a row of zeros in A and in B (the ragged end of
+ * the list reads it).  M % 128 == 0, N % 128 == 0, 16-byte aligned operands, else PM_ERANGE. */
+int pm_gemm_tn_acc_rows_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M,
+                            int64_t N, const int32_t *rows, const int32_t *count, int64_t max_rows, int64_t zero_row,
+                            void *stream);
 
 /* out[n] = sum_d Y[n,d]^2 -- np.inner(y, y) of bsc_et.py:111 and (y**2).sum() of :172;
  * computed once per resident data shard. */
@@ -319,6 +326,11 @@ int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const dou
  * leading dimension ldw) and the device-side gate (a double: non-zero = skip) are given explicitly. */
 int pm_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp, int64_t ldw,
                      const double *gate, int64_t N, int64_t H, int64_t D, void *stream);
+/* The transposed output, no gate: C (D x H, leading dimension ldc) += Y^T . V with the rows of V (N x H) given as lists --
+ * the listed rows of GSC's contraction [Y | xpt_s | xpt_sz]^T . xpt_sz (gsc_et.py:592-625); rows with an empty list
+ * contribute nothing here (pm_gemm_tn_acc_rows_f64 takes them). */
+int pm_wp_sparse_t_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *C, int64_t ldc,
+                       int64_t N, int64_t H, int64_t D, void *stream);
 
 /* Fast-path twin of pm_bsc_mstep_rows_f64 (same outputs, same `stats` layout). */
 int pm_bsc_mstep_rows16_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
@@ -529,6 +541,21 @@ int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, cons
                      int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
                      int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
                      double *stats, void *stream);
+
+/* The same pass, also splitting the rows of xpt_sz for the M-step's contraction over the datapoints
+ * [Y | xpt_s | xpt_sz]^T . xpt_sz (gsc_et.py:592-625: my_Wp, the two H x H moment products): a row with at most
+ * PM_BSC_NZ_MAX entries above the threshold tables[8 H + 1] leaves them as a list (nz_idx / nz_val, N x PM_BSC_NZ_MAX,
+ * format of pm_bsc_estep_fused8_nz_f64; for pm_wp_sparse_t_f64), any other row an empty list and its index in
+ * dense_rows[0 .. *dense_count) (for pm_gemm_tn_acc_rows_f64; *dense_count = 0 at launch; order as the workgroups finish).
+ * The threshold is written by pm_gsc_mstep_finish_f64 (2^-75 of the smallest |column sum| of xpt_sz over all ranks: what
+ * the lists drop is below the rounding of the sums); 0 keeps every row dense.  Where pm_gsc_lists_supported(H, Hprime,
+ * gamma, D), else PM_ERANGE. */
+int pm_gsc_lists_supported(int64_t H, int64_t Hprime, int64_t gamma, int64_t D);
+int pm_gsc_estep_lists_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                           const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                           int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                           int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx, double *stats,
+                           uint16_t *nz_idx, double *nz_val, int32_t *dense_rows, int32_t *dense_count, void *stream);
 
 /* The same pass, also writing every state's log-joint -- what GSC.compute_lpj returns (gsc_et.py:811-944): no
  * annealing, prior odds included -- to logpj (N, ldl >= 1 + H + S): [null state ; singletons h = 0..H-1 ; multi-cause

@@ -85,6 +85,7 @@ SIGNATURES = {
                                              c_dp]),
     "pm_bsc_wp_sparse_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, i64, i64, i64, c_dp]),
     "pm_gemm_tn_acc_gated_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp, c_dp]),
+    "pm_gemm_tn_acc_rows_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp, c_dp, i64, i64, c_dp]),
     "pm_bsc_mstep_rows16_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64,
                                           C.POINTER(EStepParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
     "pm_bsc_mstep_rows16_nz_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64,
@@ -113,12 +114,16 @@ SIGNATURES = {
     "pm_dsc_estep_mstats_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp, C.POINTER(DscParams), i64, i64, i64,
                                           i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp, c_dp, c_dp]),
     "pm_wp_sparse_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp]),
+    "pm_wp_sparse_t_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
     "pm_gsc_supported": (C.c_int, [i64, i64, i64]),
     "pm_gsc_stats_len": (i64, [i64]),
     "pm_gsc_pack_stats_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp]),
     "pm_gsc_mstep_finish_f64": (C.c_int, [c_dp] * 10 + [C.c_double, i64, i64, C.c_int, c_dp, c_dp, c_dp]),
     "pm_gsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
                                    i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp]),
+    "pm_gsc_lists_supported": (C.c_int, [i64, i64, i64, i64]),
+    "pm_gsc_estep_lists_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
+                                         i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "pm_gsc_estep_lpj_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
                                        i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp]),
     "pm_infer_topk_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp]),

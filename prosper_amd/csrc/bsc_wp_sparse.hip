@@ -43,9 +43,10 @@ __global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint
                                                                       const double *__restrict__ Y, int64_t ldy,
                                                                       double *__restrict__ Wp, int64_t ldw,
                                                                       const double *__restrict__ gate, int64_t N, int H,
-                                                                      int D, int nchunks, int64_t rows_per_group) {
+                                                                      int D, int nchunks, int64_t rows_per_group,
+                                                                      int transposed) {
     extern __shared__ __attribute__((aligned(16))) double acc[];          // [H][SP_DC]
-    if (*gate != 0.0) return;                  // some list overflowed: the dense product runs instead
+    if (gate && *gate != 0.0) return;          // some list overflowed: the dense product runs instead
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroups are dealt round-robin over the 8 XCDs: chunk = 8 k + (blockIdx & 7) keeps a chunk on one XCD (fewer
     // than 8 chunks -- D <= 448 -- : plain enumeration, every workgroup has work)
@@ -146,9 +147,11 @@ __global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint
     }
     __syncthreads();
     for (int i = tid; i < H * SP_DC; i += SP_WAVES * 64) {
-        const double a = acc[i];
-        const int h = i / SP_DC, c = chunk * SP_DC + (i % SP_DC);
-        if (a != 0.0 && c < D) pm_atomic_add(Wp + (int64_t)h * ldw + c, a);
+        // (transposed output: consecutive threads take consecutive latents of one column, so the atomics of a wavefront
+        // still land in whole lines; the strided LDS read behind it is 8 K elements per workgroup)
+        const int h = transposed ? i % H : i / SP_DC, cc = transposed ? i / H : i % SP_DC, c = chunk * SP_DC + cc;
+        const double a = acc[h * SP_DC + cc];
+        if (a != 0.0 && c < D) pm_atomic_add(transposed ? Wp + (int64_t)c * ldw + h : Wp + (int64_t)h * ldw + c, a);
     }
 }
 
@@ -161,9 +164,27 @@ extern "C" int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val
                             stream);
 }
 
+static int wp_sparse_launch(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp,
+                            int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, int transposed, void *stream);
+
 extern "C" int pm_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp,
                                 int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, void *stream) {
-    if (!nz_idx || !nz_val || !Y || !Wp || !gate || N < 0 || H <= 0 || D <= 0 || ldy < D || ldw < D) return PM_EINVAL;
+    if (!gate || ldw < D) return PM_EINVAL;
+    return wp_sparse_launch(nz_idx, nz_val, Y, ldy, Wp, ldw, gate, N, H, D, 0, stream);
+}
+
+// C (D x H, leading dimension ldc) += Y^T . V with V given by its rows' lists: the transposed output, no gate -- the
+// sparse rows of GSC's moment contraction [Y | xpt_s | xpt_sz]^T . xpt_sz (gsc_et.py:592-625), whose dense rows
+// (empty lists here) go through pm_gemm_tn_acc_rows_f64.
+extern "C" int pm_wp_sparse_t_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *C,
+                                  int64_t ldc, int64_t N, int64_t H, int64_t D, void *stream) {
+    if (ldc < H) return PM_EINVAL;
+    return wp_sparse_launch(nz_idx, nz_val, Y, ldy, C, ldc, nullptr, N, H, D, 1, stream);
+}
+
+static int wp_sparse_launch(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp,
+                            int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, int transposed, void *stream) {
+    if (!nz_idx || !nz_val || !Y || !Wp || N < 0 || H <= 0 || D <= 0 || ldy < D) return PM_EINVAL;
     if (H > 256 || D > INT32_MAX || N > INT32_MAX - 4096) return PM_ERANGE;
     if (N == 0) return PM_OK;
     int dev = 0, cus = 256;
@@ -184,6 +205,6 @@ extern "C" int pm_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, co
         return e;
     hipLaunchKernelGGL(bsc_wp_sparse_kernel, dim3((unsigned)(slots * groups)), dim3(SP_WAVES * 64), shmem,
                        static_cast<hipStream_t>(stream), nz_idx, nz_val, Y, ldy, Wp, ldw, gate, N, (int)H, (int)D, nchunks,
-                       rpg);
+                       rpg, transposed);
     return (int)hipGetLastError();
 }

@@ -529,13 +529,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(const double *__res
 // ---------------------------------------------------------------------------------------------
 constexpr int TDSTAGE = 2 * DK * TN_LD;  // doubles per stage (18 KB)
 
+// GATHER: the K rows are rows[0 .. *count) of A and B (a device-side list with a device-side length: GSC's dense datapoints,
+// gsc_kernels.hip) -- the row index of a DMA instruction is wavefront-uniform anyway, it now comes from a scalar load a
+// K-step ahead; positions past the list read `zero_row` (a row of zeros the caller keeps in both operands), so the ragged
+// end needs no second kernel; the K-split is derived from *count here (the grid was sized without knowing it).
+template <bool GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_dma_kernel(const double *__restrict__ A, int64_t lda,
                                                                   const double *__restrict__ B, int64_t ldb,
                                                                   double *__restrict__ C, int64_t ldc, int tiles_n,
                                                                   int64_t K, int64_t k_per_split,
-                                                                  const double *__restrict__ gate) {
+                                                                  const double *__restrict__ gate,
+                                                                  const int32_t *__restrict__ rows,
+                                                                  const int32_t *__restrict__ count, int zero_row) {
     __shared__ __attribute__((aligned(1024))) double sm[DSTAGES * TDSTAGE];
     if (gate && *gate == 0.0) return;
+    int cnt = 0;
+    if (GATHER) {
+        cnt = *count;
+        if (cnt > (int)K) cnt = (int)K;                  // (K: capacity of the list)
+        const int64_t steps = ((int64_t)cnt + DK - 1) / DK;
+        K = steps * DK;
+        k_per_split = (steps + gridDim.y - 1) / gridDim.y * DK;
+        if (K == 0) return;
+    }
     int tile = blockIdx.x, split = blockIdx.y;
     if (gridDim.y % 8 == 0) {   // all tiles of a K-split on one XCD (see gemm_tn_f64_kernel)
         const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
@@ -554,15 +570,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_dma_kernel(const double *_
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int wm = wave >> 1, wn = wave & 1;
     // this wavefront moves rows {wave, wave + 4} of the A slab and of the B slab of every K-step
-    const double *srca = A + (kbeg + wave) * lda + m0 + 2 * lane;
-    const double *srcb = B + (kbeg + wave) * ldb + n0 + 2 * lane;
+    const double *srca = A + (GATHER ? 0 : (kbeg + wave) * lda) + m0 + 2 * lane;
+    const double *srcb = B + (GATHER ? 0 : (kbeg + wave) * ldb) + n0 + 2 * lane;
+    auto row_of = [&](int64_t k) -> int64_t {           // (uniform: a scalar load)
+        return (k < cnt) ? (int64_t)rows[k] : (int64_t)zero_row;
+    };
     auto dma = [&](int kt, int stage) {
         double *dst = sm + stage * TDSTAGE + wave * TN_LD;
         const int64_t k0 = (int64_t)kt * DK;
-        __builtin_amdgcn_global_load_lds(srca + k0 * lda, dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(srca + (k0 + 4) * lda, dst + 4 * TN_LD, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(srcb + k0 * ldb, dst + DK * TN_LD, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(srcb + (k0 + 4) * ldb, dst + (DK + 4) * TN_LD, 16, 0, 0);
+        const int64_t r0 = GATHER ? row_of(kbeg + k0 + wave) : k0, r1 = GATHER ? row_of(kbeg + k0 + wave + 4) : k0 + 4;
+        __builtin_amdgcn_global_load_lds(srca + r0 * lda, dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srca + r1 * lda, dst + 4 * TN_LD, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srcb + r0 * ldb, dst + DK * TN_LD, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(srcb + r1 * ldb, dst + (DK + 4) * TN_LD, 16, 0, 0);
     };
     const int fcol = lane & 15, fk = lane >> 4;
     const int a_off = fk * TN_LD + wm * 64 + fcol;
@@ -826,7 +846,8 @@ extern "C" int pm_gemm_tn_acc_gated_f64(const double *A, int64_t lda, const doub
         // multiple of 16); the last K % 8 rows go through the register-staged kernel
         const int64_t K8 = K - K % DK;
         dim3 g8((unsigned)tiles, (unsigned)((K8 + kps - 1) / kps));
-        hipLaunchKernelGGL(gemm_tn_f64_dma_kernel, g8, block, 0, s, A, lda, B, ldb, C, ldc, tiles_n, K8, kps, gate);
+        hipLaunchKernelGGL(gemm_tn_f64_dma_kernel<false>, g8, block, 0, s, A, lda, B, ldb, C, ldc, tiles_n, K8, kps, gate,
+                           nullptr, nullptr, 0);
         if (K8 < K)
             hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, dim3((unsigned)tiles, 1), block, 0, s, A + K8 * lda, lda,
                                B + K8 * ldb, ldb, C, ldc, (int)M, (int)N, K - K8, tiles_n, (int64_t)BK, gate);
@@ -836,6 +857,34 @@ extern "C" int pm_gemm_tn_acc_gated_f64(const double *A, int64_t lda, const doub
     else
         hipLaunchKernelGGL(gemm_tn_f64_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K,
                            tiles_n, kps, gate);
+    return (int)hipGetLastError();
+}
+
+// C += A[rows]^T . B[rows] over a device-side row list (see gemm_tn_f64_dma_kernel<true>): `rows` holds *count row
+// indices (count <= max_rows, both on the device); `zero_row` is a row of zeros in A and in B.
+extern "C" int pm_gemm_tn_acc_rows_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
+                                       int64_t M, int64_t N, const int32_t *rows, const int32_t *count, int64_t max_rows,
+                                       int64_t zero_row, void *stream) {
+    if (!A || !B || !C || !rows || !count || M <= 0 || N <= 0 || max_rows < 0 || lda < M || ldb < N || ldc < N || zero_row < 0)
+        return PM_EINVAL;
+    if (M > INT32_MAX || N > INT32_MAX || max_rows > INT32_MAX - 64 || zero_row > INT32_MAX) return PM_ERANGE;
+    const bool al = aligned16(A) && aligned16(B) && (lda % 2 == 0) && (ldb % 2 == 0);
+    if (!al || M % TN_BM != 0 || N % BN != 0) return PM_ERANGE;
+    if (max_rows == 0) return PM_OK;
+    const int tiles_m = (int)(M / TN_BM), tiles_n = (int)(N / BN);
+    const int64_t tiles = (int64_t)tiles_m * tiles_n;
+    const int slots = resident_slots();
+#ifndef PM_TN_ROWS_DIV
+#define PM_TN_ROWS_DIV 1
+#endif
+    int64_t nsplit = slots / tiles / PM_TN_ROWS_DIV;    // ONE round of resident workgroups, whatever *count turns out to be
+    const int64_t max_split = (max_rows + 8 * DK - 1) / (8 * DK);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 65535) nsplit = 65535;
+    hipLaunchKernelGGL(gemm_tn_f64_dma_kernel<true>, dim3((unsigned)tiles, (unsigned)nsplit), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), A, lda, B, ldb, C, ldc, tiles_n, max_rows, (int64_t)0, nullptr, rows,
+                       count, (int)zero_row);
     return (int)hipGetLastError();
 }
 

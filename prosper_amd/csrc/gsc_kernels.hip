@@ -149,7 +149,16 @@ struct GscTables {
 #ifndef PM_GSC_WPE
 #define PM_GSC_WPE 3        // wavefronts per SIMD the common instantiations are compiled for (register budget 512 / WPE)
 #endif
-template <int VPL, int GMAX, bool LPJ, bool LACC>
+// LIST (with LACC): the M-step's contraction [Y | xpt_s | xpt_sz]^T . xpt_sz (gsc_et.py:592-625) as a sparse + a dense part.
+// A row of xpt_sz whose entries above `thr` number at most PM_BSC_NZ_MAX leaves them as a list (format of the BSC / DSC
+// statistics passes: nz_idx uint16 x 16 with 0xFFFF behind the last, nz_val f64 x 16) for pm_wp_sparse_t_f64; any other row
+// gets an empty list and its index appended to `dense_rows` (gathered by the workgroup in LDS, ONE global atomic on
+// *dense_count per workgroup) for pm_gemm_tn_acc_rows_f64.  thr = tables[8 H + 1]: 2^-75 of the smallest |column sum| of
+// xpt_sz of the previous EM step (pm_gsc_mstep_finish_f64) -- what a list drops from a column of the product is below
+// N thr max|left operand| <= 2^-57 of that column's own scale for N <= 2^18 (2^-52: N = 8 M), under the rounding of the sums
+// themselves; thr = 0 (first step, a dead latent's column) keeps everything: every row is dense then, correct and slow.
+constexpr int GSC_DENSE_CAP = 512;          // datapoints per workgroup in LIST mode at most (the launcher sizes the grid)
+template <int VPL, int GMAX, bool LPJ, bool LACC, bool LIST = false>
 __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void gsc_estep_kernel(const double *__restrict__ scores, int64_t lds,
                                                          const double *__restrict__ gram,
                                                          const double *__restrict__ psi,
@@ -159,8 +168,15 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                                                          int32_t *__restrict__ cand, double *__restrict__ xpt_s,
                                                          double *__restrict__ xpt_sz, int64_t ldx,
                                                          double *__restrict__ stats, double *__restrict__ logpj,
-                                                         int64_t ldl) {
+                                                         int64_t ldl, uint16_t *__restrict__ nz_idx,
+                                                         double *__restrict__ nz_val, int32_t *__restrict__ dense_rows,
+                                                         int32_t *__restrict__ dense_count) {
+    static_assert(!LIST || (LACC && !LPJ), "lists ride on the statistics form of the kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_ndense, s_dbase;
+    __shared__ int32_t s_dense[LIST ? GSC_DENSE_CAP : 1];
+    const double thr = LIST ? T.c0[8 * (int64_t)H + 1] : 0.0;
+    if (LIST && threadIdx.x == 0) s_ndense = 0;
     // 1 / sigma^2 from the host, or (0 there) from the ninth table row an M-step on the device has left
     const double inv_s2 = (inv_s2_host != 0.0) ? inv_s2_host : T.c0[8 * (int64_t)H];
     // [ 8 tables (H) | per datapoint: ac (16) Gc Pc ass aszsz as (16) asz (16) | state masks (S x u16) ]
@@ -470,9 +486,12 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                     xsz[i] += asz;
                 }
         }
+        unsigned long long sigb[LIST ? VPL : 1];            // ballots of "significant" per slot (scalar registers)
+        int nsig = 0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int h = j + 16 * i;
+            bool sig = false;
             if (live && h < H) {
                 const double vs = xs[i] * nf, vz = xsz[i] * nf;
                 xpt_s[n * ldx + h] = vs;
@@ -481,6 +500,33 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                     atomicAdd(&acc_mine[16 * i], vs);
                     atomicAdd(&acc_mine[4 * H + 16 * i], vz);
                 }
+                sig = LIST && (__builtin_fabs(vz) > thr || vs > thr);
+            }
+            if (LIST) {
+                sigb[i] = __ballot(sig);
+                nsig += __builtin_popcount((unsigned)((sigb[i] >> (row * 16)) & 0xFFFFull));
+            }
+        }
+        if (LIST && live) {
+            const bool sparse = nsig <= PM_BSC_NZ_MAX;
+            uint16_t *li = nz_idx + n * PM_BSC_NZ_MAX;
+            if (sparse) {
+                double *lv = nz_val + n * PM_BSC_NZ_MAX;
+                int before = 0;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const unsigned rowbits = (unsigned)((sigb[i] >> (row * 16)) & 0xFFFFull);
+                    if ((rowbits >> j) & 1u) {
+                        const int slot = before + __builtin_popcount(rowbits & ((1u << j) - 1u));
+                        li[slot] = (uint16_t)(j + 16 * i);
+                        lv[slot] = xsz[i] * nf;
+                    }
+                    before += __builtin_popcount(rowbits);
+                }
+                if (j >= nsig) li[j] = 0xFFFF;
+            } else {
+                li[j] = 0xFFFF;
+                if (j == 0) s_dense[atomicAdd(&s_ndense, 1)] = (int32_t)n;
             }
         }
         myc_prev = myc;
@@ -495,6 +541,12 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     // the grid's tail on them.
     __syncthreads();
     double *g_cs = stats + 2 * (int64_t)H * H;          // [column sums of xpt_s | of xpt_sz | singleton diagonal of sum xpt_szsz]
+    if (LIST) {       // the workgroup's dense datapoints -> the global list (order among workgroups: as the atomics land)
+        const int nd = s_ndense;
+        if (tid == 0) s_dbase = nd ? atomicAdd(dense_count, nd) : 0;
+        __syncthreads();
+        for (int e = tid; e < nd; e += 256) dense_rows[s_dbase + e] = s_dense[e];
+    }
     if (LACC) {       // [column sums of xpt_s | of xpt_sz | singleton diagonal]: the four wavefronts' slots, then one atomic each
         for (int e = tid; e < 3 * H; e += 256) {
             const int q = e / H, h = e - q * H;
@@ -668,6 +720,15 @@ __global__ __launch_bounds__(1024) void gsc_mstep_finish_kernel(
         tables[7 * H + tid] = log(pi) - log(1.0 - pi);
         tables[8 * H + tid] = 1.0 / s2;
     }
+    // tables[8 H + 1]: the list threshold of the next E-step (gsc_estep_kernel, LIST) from THIS step's all-reduced column sums
+    __syncthreads();
+    s_red[tid] = tid < H ? fabs(sum_sz[tid]) : INFINITY;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) s_red[tid] = fmin(s_red[tid], s_red[tid + w]);
+        __syncthreads();
+    }
+    if (tid == 0 && H > 1) tables[8 * H + 1] = ldexp(s_red[0], -75);
 }
 }  // namespace
 
@@ -689,7 +750,8 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
                             const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
                             int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
                             int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
-                            double *stats, double *logpj, int64_t ldl, void *stream) {
+                            double *stats, double *logpj, int64_t ldl, void *stream, uint16_t *nz_idx = nullptr,
+                            double *nz_val = nullptr, int32_t *dense_rows = nullptr, int32_t *dense_count = nullptr) {
     if (N == 0) return PM_OK;
     if (logpj && ldl < 1 + H + S) return PM_EINVAL;
     if (!scores || !gram || !psi_sq || !ynorm2 || !tables || !cand || !xpt_s || !xpt_sz || !stats || N < 0 || H <= 0 ||
@@ -703,6 +765,12 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
     if (gsc_shmem(H, Hprime, S) > 64 * 1024) return PM_ERANGE;
     int64_t groups = (N + ROWS - 1) / ROWS;
     if (groups > 2048) groups = 2048;
+    if (nz_idx) {      // LIST: a workgroup's dense rows wait in GSC_DENSE_CAP slots of LDS
+        if (!lacc || logpj || gamma > 3 || H <= 64 || H > 256 || !nz_val || !dense_rows || !dense_count) return PM_ERANGE;
+        const int64_t per_wg = GSC_DENSE_CAP / ROWS, need = ((N + ROWS - 1) / ROWS + per_wg - 1) / per_wg;
+        if (groups < need) groups = need;
+        if (groups > INT32_MAX) return PM_ERANGE;
+    }
     dim3 grid((unsigned)groups), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double inv_s2 = sigma_sq > 0.0 ? 1.0 / sigma_sq : 0.0;   // 0: tables[8 H] holds it (pm_gsc_mstep_finish_f64)
@@ -711,7 +779,15 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, L, A>), shmem)) return e;       \
         hipLaunchKernelGGL((gsc_estep_kernel<V, G, L, A>), grid, block, shmem, s, scores, lds, gram, psi_sq, ynorm2, T, \
                            state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select, cand, xpt_s, xpt_sz,  \
-                           ldx, stats, logpj, ldl);                                                                    \
+                           ldx, stats, logpj, ldl, nullptr, nullptr, nullptr, nullptr);                                \
+    } while (0)
+#define PM_LAUNCH_LIST(V, G)                                                                                           \
+    do {                                                                                                               \
+        if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, false, true, true>), shmem))   \
+            return e;                                                                                                  \
+        hipLaunchKernelGGL((gsc_estep_kernel<V, G, false, true, true>), grid, block, shmem, s, scores, lds, gram,      \
+                           psi_sq, ynorm2, T, state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select,    \
+                           cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, nz_idx, nz_val, dense_rows, dense_count);      \
     } while (0)
 #define PM_LAUNCH(V, G)                         \
     do {                                        \
@@ -731,7 +807,15 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         else if (gamma <= 6) PM_LAUNCH(V, 6); \
         else PM_LAUNCH(V, 8);                 \
     } while (0)
-    if (H <= 16) PM_BY_G(1);
+    if (nz_idx) {
+        if (H <= 128) {
+            if (gamma <= 2) PM_LAUNCH_LIST(8, 2);
+            else PM_LAUNCH_LIST(8, 3);
+        } else {
+            if (gamma <= 2) PM_LAUNCH_LIST(16, 2);
+            else PM_LAUNCH_LIST(16, 3);
+        }
+    } else if (H <= 16) PM_BY_G(1);
     else if (H <= 32) PM_BY_G(2);
     else if (H <= 64) PM_BY_G(4);
     else if (H <= 128) PM_BY_G(8);
@@ -740,6 +824,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
 #undef PM_BY_G
 #undef PM_LAUNCH
 #undef PM_LAUNCH_LA
+#undef PM_LAUNCH_LIST
     {
         const int64_t rows_per_block = 512;
         const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
@@ -793,6 +878,32 @@ extern "C" int pm_gsc_estep_f64(const double *scores, int64_t lds, const double 
                                 double *stats, void *stream) {
     return gsc_estep_launch(scores, lds, gram, psi_sq, ynorm2, tables, state_masks, S, gamma, beta, sigma_sq, N, H, Hprime,
                             do_select, cand, xpt_s, xpt_sz, ldx, stats, nullptr, 0, stream);
+}
+
+// pm_gsc_estep_f64 that also splits the rows of xpt_sz into listed (sparse) and dense ones for the M-step's contraction
+// (gsc_estep_kernel, LIST).  `tables` must carry the threshold in tables[8 H + 1] (pm_gsc_mstep_finish_f64 writes it; 0 =
+// every row dense); *dense_count must be 0 at launch; nz_idx / nz_val (N x PM_BSC_NZ_MAX), dense_rows (N).
+extern "C" int pm_gsc_lists_supported(int64_t H, int64_t Hprime, int64_t gamma, int64_t D) {
+    if (!pm_gsc_supported(H, Hprime, gamma) || gamma > 3 || H <= 64 || H > 256) return 0;
+    int64_t S = 0, c = Hprime;
+    for (int64_t g = 2; g <= gamma && g <= Hprime; ++g) {
+        c = c * (Hprime - g + 1) / g;
+        S += c;
+    }
+    // (the sparse product needs H <= 256, the gathered GEMM whole 128 x 128 tiles of the (D + 2 H) x H output)
+    return (gsc_shmem_lacc(H, Hprime, S) <= 53 * 1024 && (D + 2 * H) % 128 == 0 && H % 128 == 0) ? 1 : 0;
+}
+
+extern "C" int pm_gsc_estep_lists_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                                      const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                                      int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                                      int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
+                                      double *stats, uint16_t *nz_idx, double *nz_val, int32_t *dense_rows,
+                                      int32_t *dense_count, void *stream) {
+    if (!nz_idx || !nz_val || !dense_rows || !dense_count) return PM_EINVAL;
+    return gsc_estep_launch(scores, lds, gram, psi_sq, ynorm2, tables, state_masks, S, gamma, beta, sigma_sq, N, H, Hprime,
+                            do_select, cand, xpt_s, xpt_sz, ldx, stats, nullptr, 0, stream, nz_idx, nz_val, dense_rows,
+                            dense_count);
 }
 
 extern "C" int pm_gsc_estep_lpj_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,

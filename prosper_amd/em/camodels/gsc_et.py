@@ -123,6 +123,8 @@ class GSC(DeviceCAModel):
         self._seed = None        # next step's W^T / Gram / scores left on the device by M_step (_speculate)
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.fuse_moment_gemm = True      # [Y | xs | xsz]^T xsz as one GEMM (a plain attribute: tests flip it)
+        self.sparse_moments = True        # ... split into listed rows (sparse product) + gathered dense rows, when the
+                                          # M-step itself launched the E-step (pm_gsc_estep_lists_f64)
         self._spec = None        # next step's whole E-step, launched by M_step from device-side parameters
         self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
         self.spec_hits = 0
@@ -369,7 +371,7 @@ class GSC(DeviceCAModel):
         return self._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], par["tables"], par["s2"], anneal_T, cand_in,
                                   logpj)
 
-    def _launch_estep(self, res, A, G, psi_d, yn, tables, s2, anneal_T, cand_in, logpj=None):
+    def _launch_estep(self, res, A, G, psi_d, yn, tables, s2, anneal_T, cand_in, logpj=None, lists=False):
         """The fused select / E-step kernel on scores ``A``; ``s2 == 0.0``: 1/sigma_sq sits in the ninth row of
         ``tables`` (an M-step that finished on the device).  Returns (cand, xpt_s, xpt_sz, stats)."""
         N = res["Y"].shape[0]
@@ -386,10 +388,11 @@ class GSC(DeviceCAModel):
         if N and self.fuse_moment_gemm:
             bufs = res.setdefault("gsc_big", [None, None])
             k = res["gsc_flip"] = 1 - res.get("gsc_flip", 1)
-            if bufs[k] is None:
-                bufs[k] = torch.empty((N, D + 2 * H), dtype=torch.float64, device=self.device)
-                bufs[k][:, :D] = res["Y"]
-            both = bufs[k][:, D:]
+            if bufs[k] is None:      # (+ a row of zeros: what the gathered GEMM reads past the end of its row list)
+                bufs[k] = torch.empty((N + 1, D + 2 * H), dtype=torch.float64, device=self.device)
+                bufs[k][:N, :D] = res["Y"]
+                bufs[k][N].zero_()
+            both = bufs[k][:N, D:]
         else:
             both = torch.empty((N, 2 * H), dtype=torch.float64, device=self.device)
         xs, xsz = both[:, :H], both[:, H:]
@@ -403,6 +406,21 @@ class GSC(DeviceCAModel):
                        _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
                        ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
                        _ptr(stats), _ptr(logpj), logpj.stride(0), self._stream())
+        elif N and lists and self.fuse_moment_gemm and self.sparse_moments and cand_in is None and \
+                _lib.load().pm_gsc_lists_supported(H, Hp, self.gamma, D):
+            # (`tables` comes from pm_gsc_mstep_finish_f64 here: its slot 8 H + 1 holds the list threshold)
+            lb = res.setdefault("gsc_lists", [None, None])
+            if lb[k] is None:
+                lb[k] = (torch.empty((N, 16), dtype=torch.int16, device=self.device),
+                         torch.empty((N, 16), dtype=torch.float64, device=self.device),
+                         torch.empty(N, dtype=torch.int32, device=self.device))
+            nz_idx, nz_val, dense_rows = lb[k]
+            dense_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._call("estep", "pm_gsc_estep_lists_f64", _ptr(A), H, _ptr(G), _ptr(psi_d), _ptr(yn),
+                       _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
+                       ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
+                       _ptr(stats), _ptr(nz_idx), _ptr(nz_val), _ptr(dense_rows), _ptr(dense_count), self._stream())
+            stats._pm_lists = (nz_idx, nz_val, dense_rows, dense_count, bufs[k])
         elif N:
             self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(G), _ptr(psi_d), _ptr(yn),
                        _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
@@ -622,7 +640,7 @@ class GSC(DeviceCAModel):
         big = None                                                   # ... which sits behind a copy of Y
         if paired and ld == D + 2 * H:
             for b in res.get("gsc_big", ()):
-                if b is not None and b.shape[0] == my_N and xs.data_ptr() == b.data_ptr() + 8 * D:
+                if b is not None and b.shape[0] == my_N + 1 and xs.data_ptr() == b.data_ptr() + 8 * D:
                     big = b
         if not paired:
             xs, xsz = xs.contiguous(), xsz.contiguous()
@@ -643,7 +661,19 @@ class GSC(DeviceCAModel):
         packed = whole[:n_stat]
         if my_N:
             s = self._stream()
-            if big is not None:      # [Y | xs | xsz]^T . xsz -> [Wp ; xs^T xsz ; xsz^T xsz]: the head of the packed buffer
+            lists = getattr(raw[0], "_pm_lists", None) if (raw is not None and big is not None and self._in_step) else None
+            if lists is not None and lists[4] is big:
+                # the same product in two parts (pm_gsc_estep_lists_f64): rows of xsz with a handful of entries above the
+                # threshold from their lists (one stream over [Y | xs | xsz]), the others -- a fifth of the datapoints at
+                # config 4: those no selected state explains spread their weight over every singleton -- gathered into the
+                # MFMA GEMM by a device-side row list
+                # (the outer products of the lists for the two H x H blocks + a stream over the Y columns only was measured:
+                # same EM iteration -- scratch/gsc_list_pairs_r04.hip)
+                self._call("stats_sparse", "pm_wp_sparse_t_f64", _ptr(lists[0]), _ptr(lists[1]), _ptr(big), ldx, _ptr(packed),
+                           H, my_N, H, D + 2 * H, s)
+                self._call("stats_gemm", "pm_gemm_tn_acc_rows_f64", _ptr(big), ldx, _ptr(xsz), ldx, _ptr(packed), H,
+                           D + 2 * H, H, _ptr(lists[2]), _ptr(lists[3]), my_N, my_N, s)
+            elif big is not None:      # [Y | xs | xsz]^T . xsz -> [Wp ; xs^T xsz ; xsz^T xsz]: the head of the packed buffer
                 self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(big), ldx, _ptr(xsz), ldx, _ptr(packed), H,
                            D + 2 * H, H, my_N, s)
             else:
@@ -730,7 +760,7 @@ class GSC(DeviceCAModel):
             self._seed = {"ykey": res["key"], "Wt": Wt_next, "G": fin["G"], "A": A, "W_host": None}
             if self._in_step and self._flat_schedule:
                 fin["out"] = self._launch_estep(res, A, fin["G"], fin["psi"], res["ynorm2"], fin["tdev"], 0.0,
-                                                anneal['T'], None)
+                                                anneal['T'], None, lists=True)
 
         if packed.is_cuda:
             n_down = o_par + n_par if fin is not None else (o_par if Wt_next is not None else

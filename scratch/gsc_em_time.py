@@ -2,6 +2,9 @@
 import sys, os, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from prosper_amd import _lib
+if os.environ.get('PM_LIB_PATH'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['PM_LIB_PATH'])
 from prosper_amd.em.camodels.gsc_et import GSC
 from prosper_amd.em.camodels._device import KernelTimer
 class An(dict):
@@ -21,6 +24,7 @@ for lo in range(0, N, 50_000):
 p = {"W": W_gt.cpu().numpy() + 0.1 * rng.normal(size=(Dm, Hm)), "pi": np.full(Hm, 2.0 / Hm), "mu": np.full(Hm, 1.4),
      "psi_sq": np.eye(Hm) * 1.1, "sigma_sq": 1.2}
 m = GSC(Dm, Hm, 6, 3, 'scalar')
+m.sparse_moments = os.environ.get('SPM', '1') == '1'
 t = time.perf_counter()
 while time.perf_counter() - t < 0.5:
     p = m.step(An(T=1.0), p, {"y": Y})

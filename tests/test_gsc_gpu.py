@@ -377,6 +377,9 @@ def test_gsc_mstep_finish_kernel(H, D, learn):
     lam = Gd / s2 + 1. / psid
     want = np.stack([-(np.log(psid) + np.log(lam)) - mu * mu * Gd / s2, 2. * mu / s2, Gd * mu, 1. / (lam * s2 * s2),
                      1. / (lam * s2), 1. / lam, mu, np.log(pi) - np.log(1 - pi), np.full(H, 1. / s2)])
+    want[8, 1] = float(np.abs(sum_sz).min()) * 2.0 ** -75     # the list threshold of the next E-step (pm_gsc_estep_lists_f64)
+    thr_got, tab[8, 1] = tab[8, 1], want[8, 1]
+    np.testing.assert_allclose(thr_got, want[8, 1], rtol=1e-14)
     np.testing.assert_allclose(tab, want, rtol=1e-10, atol=1e-12)
 
 
@@ -419,6 +422,154 @@ def test_gsc_em_loop_speculation_is_transparent():
             assert m.spec_hits == 0
     for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
         np.testing.assert_allclose(runs[0][k], runs[1][k], rtol=1e-8, atol=1e-11, err_msg=k)
+
+
+def _ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("M,Nc,K,count", [(512, 128, 3000, 2999), (512, 128, 3000, 0), (256, 256, 700, 13), (128, 128, 64, 64)])
+def test_gemm_tn_acc_rows_matches_numpy(M, Nc, K, count):
+    """pm_gemm_tn_acc_rows_f64: C += A[rows]^T B[rows] over a device-side row list with a device-side length (ragged ends
+    read the zero row), A and B views of one buffer as in GSC's M-step."""
+    import ctypes
+    from prosper_amd import _lib
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(M + K + count)
+    big = rng.normal(size=(K + 1, M + 64))
+    big[K] = 0.0
+    rows = rng.permutation(K)[:max(count, 1)].astype(np.int32)
+    C0 = rng.normal(size=(M, Nc))
+    b = torch.from_numpy(big).to(dev)
+    c = torch.from_numpy(C0.copy()).to(dev)
+    r = torch.from_numpy(np.concatenate([rows, np.full(K - len(rows), -7, np.int32)])).to(dev)   # (garbage behind the list)
+    cnt = torch.tensor([count], dtype=torch.int32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    Bv = b[:, M - Nc:M] if M > Nc else b[:, :Nc]                # B: the last Nc columns of A's block (GSC: xsz inside [Y|xs|xsz])
+    _lib.call("pm_gemm_tn_acc_rows_f64", _ptr(b), b.stride(0), _ptr(Bv), b.stride(0), _ptr(c), Nc, M, Nc, _ptr(r), _ptr(cnt),
+              K, K, st)
+    sel = rows[:count]
+    A_np = big[sel][:, :M]
+    B_np = big[sel][:, M - Nc:M] if M > Nc else big[sel][:, :Nc]
+    want = C0 + A_np.T @ B_np
+    np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(want).max()))
+
+
+def test_wp_sparse_transposed_matches_numpy():
+    """pm_wp_sparse_t_f64: C (D x H) += Y^T V with V's rows as lists; rows with an empty list contribute nothing."""
+    import ctypes
+    from prosper_amd import _lib
+    dev = torch.device("cuda", 0)
+    N, D, H = 3001, 512, 128
+    rng = np.random.RandomState(5)
+    Y = rng.normal(size=(N + 1, D))
+    idx = np.full((N, 16), 0xFFFF, dtype=np.uint16)
+    val = rng.normal(size=(N, 16))
+    V = np.zeros((N, H))
+    for n in range(N):
+        k = 0 if n % 5 == 0 else rng.randint(1, 17)
+        hs = rng.permutation(H)[:k]
+        idx[n, :k] = hs
+        V[n, hs] = val[n, :k]
+    C0 = rng.normal(size=(D, H))
+    c = torch.from_numpy(C0.copy()).to(dev)
+    y, i_d, v_d = torch.from_numpy(Y).to(dev), torch.from_numpy(idx.view(np.int16)).to(dev), torch.from_numpy(val).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.call("pm_wp_sparse_t_f64", _ptr(i_d), _ptr(v_d), _ptr(y), D, _ptr(c), H, N, H, D, st)
+    want = C0 + Y[:N].T @ V
+    np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("dead", [False, True])
+def test_gsc_sparse_moments_equal_the_dense_contraction(dead):
+    """Inside an EM loop the M-step launches the next E-step with lists (pm_gsc_estep_lists_f64) and contracts
+    [Y | xs | xsz]^T xsz as sparse product + gathered dense GEMM.  Same trajectory as the one dense GEMM, to rounding;
+    the split really happens (some rows listed, some dense); a latent whose every weight is the `tiny` clamp pulls the
+    threshold to nothing -- every row dense -- and the result still agrees."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    from prosper_amd.em.camodels._device import KernelTimer
+    D, H, Hp, gamma, N = 256, 128, 6, 3, 6000
+    rng = np.random.RandomState(41)
+    W_gt = rng.normal(size=(D, H))
+    S = rng.random_sample((N, H)) < 2.0 / H
+    y = (S * (1.5 + rng.normal(size=(N, H)))) @ W_gt.T + rng.normal(size=(N, D))
+    p0 = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.4),
+          "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+    learn = ('W', 'pi', 'mu', 'psi_sq', 'sigma_sq')
+    if dead:
+        p0["pi"][7] = 1e-300
+        learn = ('W', 'mu', 'psi_sq', 'sigma_sq')        # pi stays: latent 7 stays dead through the loop
+    an = _An(T=1.0)
+    runs, counts = [], None
+    for sparse in (True, False):
+        m = GSC(D, H, Hp, gamma, 'scalar', to_learn=list(learn))
+        m.sparse_moments = sparse
+        p = {k: np.array(v, copy=True) for k, v in p0.items()}
+        traj = []
+        for it in range(7):
+            if sparse and it == 6:
+                m.timer = KernelTimer()
+            p = m.step(an, p, {"y": y})
+            traj.append({k: np.array(p[k], copy=True) for k in p0})
+        runs.append(traj)
+        if sparse:
+            names = set(m.timer.summary())
+            m.timer = None
+            assert m.spec_hits >= 3
+            res = m._resident(y)
+            lists = [l for l in res.get("gsc_lists", []) if l is not None]
+            assert lists, "the list form of the E-step never ran"
+            assert "stats_sparse" in names, names
+            empty = (lists[0][0][:, 0].cpu().numpy().view(np.uint16) == 0xFFFF)
+            counts = (int(empty.sum()), N)
+    for a, b in zip(*runs):
+        for k in p0:
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(b[k]).max()), err_msg=k)
+    # (the "dead" latent still collects 1 / (H + S) of every datapoint whose weights are ALL the clamp, so its column sum --
+    # and with it the threshold -- stays ordinary: its 1e-243 entries elsewhere are dropped, as they should be)
+    n_dense, n_all = counts
+    assert 0.05 * n_all < n_dense < 0.5 * n_all, counts
+
+
+def test_gsc_lists_with_zero_threshold_keep_every_row_dense():
+    """Threshold 0 (what a vanishing column sum of xpt_sz gives): every weight is at least the `tiny` clamp, so every row has
+    H entries above it -- all rows land in the dense list, all lists are empty, and the gathered GEMM alone reproduces the
+    dense contraction."""
+    import ctypes
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels.gsc_et import GSC
+    D, H, Hp, gamma, N = 256, 128, 6, 3, 1500
+    rng = np.random.RandomState(43)
+    W_gt = rng.normal(size=(D, H))
+    S = rng.random_sample((N, H)) < 2.0 / H
+    y = (S * (1.5 + rng.normal(size=(N, H)))) @ W_gt.T + rng.normal(size=(N, D))
+    p = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.4),
+         "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+    m = GSC(D, H, Hp, gamma, 'scalar')
+    res = m._resident(y)
+    par = m._tables_for(p, res)
+    A = m._gemm_nt(res["Y"], par["Wst"], m._buf("scores", (N, H)), "scores_gemm")
+    for thr, all_dense in ((0.0, True), (1e-20, False)):
+        tdev = torch.zeros(9 * H, dtype=torch.float64, device=m.device)
+        tdev[:8 * H] = par["tables"].reshape(-1)[:8 * H]
+        tdev[8 * H] = 1.0 / par["s2"]
+        tdev[8 * H + 1] = thr
+        cand, xs, xsz, stats = m._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], tdev, 0.0, 1.0, None, lists=True)
+        nz_idx, nz_val, rows, cnt, big = stats._pm_lists
+        n_dense = int(cnt.item())
+        listed = nz_idx[:, 0].cpu().numpy().view(np.uint16) != 0xFFFF
+        assert n_dense + int(listed.sum()) == N and sorted(rows[:n_dense].cpu().numpy().tolist()) == np.nonzero(~listed)[0].tolist()
+        assert (n_dense == N) if all_dense else (0 < n_dense < N // 2)
+        want = (big[:N].t() @ xsz).cpu().numpy()
+        got = torch.zeros((D + 2 * H, H), dtype=torch.float64, device=m.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.call("pm_wp_sparse_t_f64", _ptr(nz_idx), _ptr(nz_val), _ptr(big), big.stride(0), _ptr(got), H, N, H, D + 2 * H, st)
+        if all_dense:
+            assert float(got.abs().max()) == 0.0
+        _lib.call("pm_gemm_tn_acc_rows_f64", _ptr(big), big.stride(0), _ptr(xsz), big.stride(0), _ptr(got), H, D + 2 * H, H,
+                  _ptr(rows), _ptr(cnt), N, N, st)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-11, atol=1e-13 * np.abs(want).max())
 
 
 def test_config4_full_shard_against_oracle():
