@@ -763,8 +763,14 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
     const bool lacc = gsc_shmem_lacc(H, Hprime, S) <= 53 * 1024;
     const size_t shmem = lacc ? gsc_shmem_lacc(H, Hprime, S) : gsc_shmem(H, Hprime, S);
     if (gsc_shmem(H, Hprime, S) > 64 * 1024) return PM_ERANGE;
+    // ONE resident round of workgroups (three per CU for the tuned instantiations), each walking its share of the
+    // datapoints: 2048 workgroups -- 2.7 rounds, the last one two thirds full, and 2048 table loads / accumulator flushes --
+    // ran 0.717 ms at config 4, 768 run 0.677 (1536: 0.70, 3072: 0.71)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
     int64_t groups = (N + ROWS - 1) / ROWS;
-    if (groups > 2048) groups = 2048;
+    if (groups > 3 * (int64_t)cus) groups = 3 * (int64_t)cus;
     if (nz_idx) {      // LIST: a workgroup's dense rows wait in GSC_DENSE_CAP slots of LDS
         if (!lacc || logpj || gamma > 3 || H <= 64 || H > 256 || !nz_val || !dense_rows || !dense_count) return PM_ERANGE;
         const int64_t per_wg = GSC_DENSE_CAP / ROWS, need = ((N + ROWS - 1) / ROWS + per_wg - 1) / per_wg;
