@@ -146,6 +146,9 @@ struct GscTables {
 // LACC: the column sums of xpt_s / xpt_sz are accumulated in LDS, one private slot per (datapoint row of the workgroup,
 // latent) -- plain read-add-write, no atomics, no conflicts -- and folded over the rows at the end: no second pass over the
 // N x H moments (gsc_colsum_kernel read 410 MB again at config 4: 0.09 ms).
+#ifndef PM_GSC_ABL
+#define PM_GSC_ABL 0      // timing-only ablation builds (scratch/gsc_abl.sh): bits switch phases off, results are wrong
+#endif
 #ifndef PM_GSC_WPE
 #define PM_GSC_WPE 3        // wavefronts per SIMD the common instantiations are compiled for (register budget 512 / WPE)
 #endif
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             const int ci = __builtin_amdgcn_ds_bpermute((rowbase + i) << 2, myc_prev);
             const int ck = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc_prev);
             if (ok) {
-                if (pend) {
+                if (pend && !(PM_GSC_ABL & 16)) {
                     // xpt_ss is symmetric: upper triangle only; xpt_szsz = kappa kappa^T + Lambda^-1 is NOT once psi_sq has
                     // been through an M-step (gsc_et.py:660-675 leaves it non-symmetric): both triangles, as they are
                     if (k >= i) pm_atomic_add(g_ss + (int64_t)ci * H + ck, s_ass[p] * nf_prev);
@@ -260,12 +263,27 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     };
 
     const int64_t groups = (N + ROWS - 1) / ROWS;
+    // The scores row of the NEXT datapoint is requested before this one's outputs are stored (`apre`): vector-memory
+    // operations complete in issue order as far as s_waitcnt can tell, so a row requested BEHIND the sixteen stores of the
+    // previous datapoint cannot be waited for without waiting for those stores' acknowledgements too (SQ_WAIT_ANY: 65 % of the
+    // wave cycles; a build without the stores ran 0.07 ms faster).
+    double apre[VPL];
+    double yn_pre = 0.0;
+    auto prefetch = [&](int64_t g) {
+        const int64_t n = g * ROWS + wave * 4 + row;
+        const int64_t nn = (g < groups && n < N) ? n : N - 1;
+        const double *ar = scores + nn * lds;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) apre[i] = (j + 16 * i < H) ? ar[j + 16 * i] : 0.0;
+        yn_pre = ynorm2[nn];
+    };
+    prefetch(blockIdx.x);
     for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int64_t n = grp * ROWS + wave * 4 + row;
         const bool live = n < N;
         const int64_t nn = live ? n : N - 1;
         const double *arow = scores + nn * lds;
-        const double yn = ynorm2[nn];
+        const double yn = yn_pre;
 
         // ---- candidates: top-H' scores, then sorted by latent index (gsc_et.py:726-728)
         int myc = 0;
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 const int h = j + 16 * i;
                 double kx = -INFINITY;
                 if (h < H) {  // singleton log-posterior without prior (gsc_et.py:795-805)
-                    const double ai = arow[h];
+                    const double ai = apre[i];
                     const double bb = ai - s_gm[h];
                     double v = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h];
                     if (v != v || v < fmin_) v = fmin_;
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 key[i] = kx;
             }
             uint64_t mine = 0;                                // this lane's own selected latents, bit i
-            for (int r = 0; r < Hp; ++r) {
+            for (int r = 0; r < ((PM_GSC_ABL & 32) ? 1 : Hp); ++r) {
                 double m = key[0];
 #pragma unroll
                 for (int i = 1; i < VPL; ++i) m = __builtin_fmax(m, key[i]);
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
         // ---- multi-cause states
         double Z = (j == 0) ? exp(-yn * inv_s2 * beta) : 0.0;       // null state (not clamped upstream: libm)
         if (LPJ && live && j == 0) logpj[n * ldl] = -yn * inv_s2;
-        for (int s0 = 0; s0 < S; s0 += 16) {
+        for (int s0 = 0; s0 < ((PM_GSC_ABL & 1) ? 0 : S); s0 += 16) {
             const int s = s0 + j;
             const bool valid = s < S;
             const unsigned mask = valid ? s_masks[s] : 0u;
@@ -447,7 +465,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 const double bb = ai - s_gm[h];
                 const double lp = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h] + s_lpi[h];
                 if (LPJ && live) logpj[n * ldl + 1 + h] = lp;
-                p = gsc_weight(lp * beta, etab);
+                p = (PM_GSC_ABL & 2) ? lp : gsc_weight(lp * beta, etab);
                 Z += p;
             }
             xs[i] = p;
@@ -486,6 +504,8 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                     xsz[i] += asz;
                 }
         }
+        prefetch(grp + gridDim.x);                          // (ahead of the stores below: see `apre`; unconditional, so
+                                                            // that the row is not carried across the loop when unused)
         unsigned long long sigb[LIST ? VPL : 1];            // ballots of "significant" per slot (scalar registers)
         int nsig = 0;
 #pragma unroll
@@ -494,9 +514,11 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             bool sig = false;
             if (live && h < H) {
                 const double vs = xs[i] * nf, vz = xsz[i] * nf;
-                xpt_s[n * ldx + h] = vs;
-                xpt_sz[n * ldx + h] = vz;
-                if (LACC) {
+                if (!(PM_GSC_ABL & 4)) {
+                    xpt_s[n * ldx + h] = vs;
+                    xpt_sz[n * ldx + h] = vz;
+                }
+                if (LACC && !(PM_GSC_ABL & 8)) {
                     atomicAdd(&acc_mine[16 * i], vs);
                     atomicAdd(&acc_mine[4 * H + 16 * i], vz);
                 }
@@ -507,7 +529,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 nsig += __builtin_popcount((unsigned)((sigb[i] >> (row * 16)) & 0xFFFFull));
             }
         }
-        if (LIST && live) {
+        if (LIST && live && !(PM_GSC_ABL & 64)) {
             const bool sparse = nsig <= PM_BSC_NZ_MAX;
             uint16_t *li = nz_idx + n * PM_BSC_NZ_MAX;
             if (sparse) {
