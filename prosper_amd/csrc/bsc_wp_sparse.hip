@@ -38,7 +38,11 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(SP_WAVES * 64) void bsc_wp_sparse_kernel(const uint16_t *__restrict__ nz_idx,
+// (amdgpu_waves_per_eu(6, 6): 80 registers instead of 82 -- two spilled dwords -- so that four of these wavefronts per SIMD
+// leave room for ONE workgroup of the gathered f64 GEMM (176 registers a wavefront) on the same CU: GSC's M-step runs the two
+// on two streams, an HBM stream beside an MFMA kernel, 1.29 -> 1.24 ms per EM iteration at config 4; at 82 registers the GEMM's
+// workgroups wait for a free CU and nothing overlaps)
+__global__ __launch_bounds__(SP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void bsc_wp_sparse_kernel(const uint16_t *__restrict__ nz_idx,
                                                                       const double *__restrict__ nz_val,
                                                                       const double *__restrict__ Y, int64_t ldy,
                                                                       double *__restrict__ Wp, int64_t ldw,

@@ -123,6 +123,7 @@ class GSC(DeviceCAModel):
         self._seed = None        # next step's W^T / Gram / scores left on the device by M_step (_speculate)
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.fuse_moment_gemm = True      # [Y | xs | xsz]^T xsz as one GEMM (a plain attribute: tests flip it)
+        self.overlap_moments = True       # ... the two parts on two streams (an HBM stream beside an MFMA GEMM)
         self.sparse_moments = True        # ... split into listed rows (sparse product) + gathered dense rows, when the
                                           # M-step itself launched the E-step (pm_gsc_estep_lists_f64)
         self._spec = None        # next step's whole E-step, launched by M_step from device-side parameters
@@ -669,10 +670,26 @@ class GSC(DeviceCAModel):
                 # MFMA GEMM by a device-side row list
                 # (the outer products of the lists for the two H x H blocks + a stream over the Y columns only was measured:
                 # same EM iteration -- scratch/gsc_list_pairs_r04.hip)
+                side = None
+                if self.overlap_moments and self.timer is None:
+                    # the gathered GEMM (MFMA-bound, one of its workgroups fits beside a sparse-product workgroup on a CU) on a
+                    # second stream: both add into `packed` with atomics, the main stream joins before anything reads it
+                    side = getattr(self, "_side_stream", None)
+                    if side is None:
+                        side = self._side_stream = torch.cuda.Stream(device=self.device)
+                    fork = torch.cuda.Event()
+                    fork.record()
                 self._call("stats_sparse", "pm_wp_sparse_t_f64", _ptr(lists[0]), _ptr(lists[1]), _ptr(big), ldx, _ptr(packed),
                            H, my_N, H, D + 2 * H, s)
+                if side is not None:
+                    side.wait_event(fork)
+                    s = ctypes.c_void_p(side.cuda_stream)
                 self._call("stats_gemm", "pm_gemm_tn_acc_rows_f64", _ptr(big), ldx, _ptr(xsz), ldx, _ptr(packed), H,
                            D + 2 * H, H, _ptr(lists[2]), _ptr(lists[3]), my_N, my_N, s)
+                if side is not None:
+                    join = torch.cuda.Event()
+                    join.record(side)
+                    torch.cuda.current_stream().wait_event(join)
             elif big is not None:      # [Y | xs | xsz]^T . xsz -> [Wp ; xs^T xsz ; xsz^T xsz]: the head of the packed buffer
                 self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(big), ldx, _ptr(xsz), ldx, _ptr(packed), H,
                            D + 2 * H, H, my_N, s)
