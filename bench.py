@@ -156,7 +156,7 @@ def other_models(dev, Anneal, steps=20):
         if "estep" in ks:
             # dominant kernel: gsc_estep_kernel -- 35 multi-cause states with g x g solves in registers + 128 singletons per
             # datapoint: f64-VALU bound (not HBM: 3 H doubles per datapoint in and out, 0.6 GB per launch)
-            out["gsc_c4_roofline"] = valu_issue_roofline("gsc_estep_kernel<8, 3, false>", ks["estep"][1],
+            out["gsc_c4_roofline"] = valu_issue_roofline("gsc_estep_kernel<8, 3, false,", ks["estep"][1],
                                                          "gsc_estep_kernel (select + E-step, one pass over the scores)")
             if out["gsc_c4_roofline"] and "frac" in out["gsc_c4_roofline"]:
                 out["gsc_c4_roofline"]["note"] = (
@@ -196,7 +196,7 @@ def other_models(dev, Anneal, steps=20):
         if lab:
             # dominant kernel: the fused E-step + M-statistics pass: one f64 power per multi-cause state and observed
             # dimension (S x D per datapoint, 36 VALU issue slots each) + the state loop around it: f64-VALU bound
-            out["mca_c5_roofline"] = valu_issue_roofline("mca_estep_fused_kernel<4, 8, false>", ks[lab][1],
+            out["mca_c5_roofline"] = valu_issue_roofline("mca_estep_fused_kernel<4, 8, false,", ks[lab][1],
                                                          "mca_estep_fused_kernel (E-step + M-step statistics)")
         del m, Y
         # --- the "next" models of SURVEY 8(f2) on the same skeleton: DSC (ternary latents) and TSC, D=256 H=128 H'=6

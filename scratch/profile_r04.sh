@@ -8,6 +8,7 @@ mkdir -p $R/gpurun_out
 SHA=$(sha256sum $R/prosper_amd/libprosper_hip.so | cut -c1-16)
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG /tmp/pmc_fetch /tmp/pmc_write /tmp/pv /tmp/pvd
+if [ -z "$SKIP_PMC" ]; then
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --em-steps 3 --prewarm-ms 0 --data device --no-cpu-baseline --no-other-models > /tmp/pmc_f.log 2>&1 || tail -3 /tmp/pmc_f.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --em-steps 3 --prewarm-ms 0 --data device --no-cpu-baseline --no-other-models > /tmp/pmc_w.log 2>&1 || tail -3 /tmp/pmc_w.log
 python3 $R/profiles/summarize_pmc.py /tmp/pmc_fetch /tmp/pmc_write $R/gpurun_out/${TAG}_pmc_traffic.json > /dev/null
@@ -38,9 +39,12 @@ json.dump({"note": "wave-instructions per launch (SQ_INSTS_VALU includes MFMAs),
 for k, v in out.items():
     print(k, v)
 PY
+fi
 # the counts of THIS build are what the bench lines below quote (roofline.traffic, the *_roofline objects of other_models)
+if [ -z "$SKIP_PMC" ]; then
 cp $R/gpurun_out/${TAG}_pmc_traffic.json $R/profiles/r04_pmc_traffic.json
 cp $R/gpurun_out/${TAG}_valu_counts.json $R/profiles/r04_valu_counts.json
+fi
 cd $R
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $R/gpurun_out/${TAG}_bench.json
 cd /tmp
