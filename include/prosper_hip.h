@@ -426,6 +426,14 @@ typedef struct pm_dsc_params {
     int32_t reserved;
 } pm_dsc_params;
 
+/* select_Hprimes of DSC (dsc_et.py:347-410; `params_host` given) or TSC (tsc_et.py:142-213; `params_host` NULL) in ONE pass
+ * over the scores: the ranking values of pm_dsc_select_scores_f64 / pm_tsc_select_scores_f64 are formed in registers and
+ * ranked there (same values, same tie rules as the two-launch form); TSC candidates come out as latents (state % H).
+ * Where pm_xsc_select_supported(H, Hprime, tsc) (TSC: H in {16, 32, 64, 128, 256}), else PM_ERANGE. */
+int pm_xsc_select_supported(int64_t H, int64_t Hprime, int tsc);
+int pm_xsc_select_f64(const double *scores, int64_t lds, const double *gram, const pm_dsc_params *params_host, int64_t N,
+                      int64_t H, int64_t Hprime, int32_t *cand, void *stream);
+
 /* Ternary Sparse Coding (prosper/em/camodels/tsc_et.py) runs on the DSC kernels with two flags:
  * PM_DSC_TABLE_ONLY     logpj has one column per row of the state table and nothing else (tsc_et.py:340-349:
  *                       the table holds the null and one-cause states too; no global singleton block);

@@ -74,6 +74,79 @@ __global__ __launch_bounds__(256, ESTEP ? (VPL <= 4 ? 4 : VPL <= 8 ? 3 : VPL <= 
 }
 
 // ---------------------------------------------------------------------------------------------
+// select_Hprimes of Discrete / Ternary Sparse Coding (dsc_et.py:347-410, tsc_et.py:142-213) in ONE pass over the scores:
+// the ranking values -- DSC: R[h] = -max_k (pre1 (v_k^2 G_hh - 2 v_k a_h) + log pi_k), the H' smallest, best first; TSC:
+// R[h] = -(G_hh + 2 a_h), R[H + h] = -(G_hh - 2 a_h) over the 2 H one-cause states, the H' largest, best last, stored as
+// latents (state % H) -- are formed in registers from the scores row and ranked by row_select.  Rounds 1-3 wrote them to an
+// (N, H) / (N, 2H) buffer with one kernel and ranked that with a second (+ a modulo launch for TSC): 0.08 / 0.135 ms of a
+// 0.70 / 0.65 ms EM iteration.  TSC needs H == 16 VPL (the second half of the keys continues the lane layout).
+// ---------------------------------------------------------------------------------------------
+template <int VPL, bool TSC>
+__global__ __launch_bounds__(256, (TSC ? 2 * VPL : VPL) <= 8 ? 4 : (TSC ? 2 * VPL : VPL) <= 16 ? 3 : 1) void xsc_select16_kernel(
+    const double *__restrict__ scores, int64_t lds, const double *__restrict__ gram, pm_dsc_params P, int64_t N, int H,
+    int Hp, int32_t *__restrict__ cand) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int VK = TSC ? 2 * VPL : VPL;              // keys per lane
+    const int HK = TSC ? 2 * H : H;
+    const Layout lay = make_layout(HK, Hp, 0, 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, row = lane >> 4;
+    double *s_w2 = reinterpret_cast<double *>(smem);     // (the w2 table of the layout: |W_h|^2; the other tables stay unused)
+    __shared__ double s_v[PM_DSC_MAX_K], s_lp[PM_DSC_MAX_K];
+    if (tid < PM_DSC_MAX_K) {
+        s_v[tid] = P.values[tid];
+        s_lp[tid] = P.logpi[tid];
+    }
+    for (int h = tid; h < H; h += 256) s_w2[h] = gram[(int64_t)h * H + h];
+    __syncthreads();
+    RowParams A{};
+    A.N = N;
+    A.H = HK;
+    A.Hp = Hp;
+    A.mode = 1;
+    A.cand = cand;
+    A.cand_mod = TSC ? H : 0;
+    const RowLds L = row_lds(smem, lay, wave * 4 + row);
+    const int64_t groups = (N + ROWS - 1) / ROWS;
+    for (int64_t g0 = blockIdx.x; g0 < groups; g0 += gridDim.x) {
+        const int64_t grp = groups - 1 - g0;             // (last rows first: see bsc_select_estep16_kernel)
+        const int64_t n = grp * ROWS + wave * 4 + row;
+        const int64_t nn = n < N ? n : N - 1;
+        const double *arow = scores + nn * lds;
+        double r[VK], a[VPL], w2[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int h = j + 16 * i;
+            const int hc = h < H ? h : H - 1;
+            a[i] = arow[hc];
+            w2[i] = s_w2[hc];
+        }
+        if (TSC) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const double a2 = 2.0 * a[i];
+                r[i] = -(w2[i] + a2);
+                r[VPL + i] = -(w2[i] - a2);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) r[i] = -INFINITY;
+            for (int k = 0; k < P.K; ++k) {              // (uniform; the values sit in LDS: indexing the kernel-argument
+                if (k == P.K0) continue;                 // struct with a loop variable is a dependent scalar load per use)
+                const double v = s_v[k], lp = s_lp[k];
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) r[i] = fmax(r[i], P.pre1 * (v * v * w2[i] - 2.0 * v * a[i]) + lp);
+            }
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) r[i] = -r[i];
+        }
+        // DSC: smallest first, values as they are (ranking flags 1 | 2); TSC: largest, as they are (2)
+        if (TSC) (void)row_select<VK, 2, true>(r, A, L, lane, n);
+        else (void)row_select<VK, 3, false>(r, A, L, lane, n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // M_step, per-datapoint part
 // ---------------------------------------------------------------------------------------------
 template <int VPL, bool NZ>      // NZ: list mode (nz_idx / nz_val given): E[s] rows merged through LDS, non-zeros listed
@@ -356,6 +429,53 @@ extern "C" int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const 
     else PM_LAUNCH(32);
 #undef PM_LAUNCH
 #undef PM_LAUNCH_E
+    return (int)hipGetLastError();
+}
+
+// select_Hprimes of DSC (params given) / TSC (params NULL) in one pass: see xsc_select16_kernel.  PM_ERANGE where it does
+// not apply (then: pm_dsc_select_scores_f64 / pm_tsc_select_scores_f64 + pm_bsc_select_estep_f64).
+extern "C" int pm_xsc_select_supported(int64_t H, int64_t Hprime, int tsc) {
+    const int64_t HK = tsc ? 2 * H : H;
+    if (!pm_bsc_rows16_supported(HK, Hprime, 0)) return 0;
+    if (tsc && !(H == 16 || H == 32 || H == 64 || H == 128 || H == 256)) return 0;
+    return 1;
+}
+
+extern "C" int pm_xsc_select_f64(const double *scores, int64_t lds, const double *gram, const pm_dsc_params *params_host,
+                                 int64_t N, int64_t H, int64_t Hprime, int32_t *cand, void *stream) {
+    if (!scores || !gram || !cand || N < 0 || H <= 0 || Hprime <= 0 || lds < H) return PM_EINVAL;
+    const bool tsc = params_host == nullptr;
+    if (!tsc && (params_host->K < 2 || params_host->K > PM_DSC_MAX_K || params_host->K0 < 0 || params_host->K0 >= params_host->K))
+        return PM_EINVAL;
+    if (!pm_xsc_select_supported(H, Hprime, tsc ? 1 : 0)) return PM_ERANGE;
+    if (N == 0) return PM_OK;
+    const int64_t HK = tsc ? 2 * H : H;
+    const size_t shmem = (size_t)make_layout((int)HK, (int)Hprime, 0, 0).bytes;
+    dim3 grid((unsigned)grid_groups(N)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    pm_dsc_params P{};
+    if (!tsc) P = *params_host;
+#define PM_LAUNCH_X(V, T)                                                                                    \
+    do {                                                                                                     \
+        if (int e = allow_lds16(reinterpret_cast<const void *>(xsc_select16_kernel<V, T>), shmem)) return e; \
+        hipLaunchKernelGGL((xsc_select16_kernel<V, T>), grid, block, shmem, s, scores, lds, gram, P, N, (int)H, \
+                           (int)Hprime, cand);                                                               \
+    } while (0)
+    if (tsc) {
+        if (H == 16) PM_LAUNCH_X(1, true);
+        else if (H == 32) PM_LAUNCH_X(2, true);
+        else if (H == 64) PM_LAUNCH_X(4, true);
+        else if (H == 128) PM_LAUNCH_X(8, true);
+        else PM_LAUNCH_X(16, true);
+    } else {
+        if (H <= 16) PM_LAUNCH_X(1, false);
+        else if (H <= 32) PM_LAUNCH_X(2, false);
+        else if (H <= 64) PM_LAUNCH_X(4, false);
+        else if (H <= 128) PM_LAUNCH_X(8, false);
+        else if (H <= 256) PM_LAUNCH_X(16, false);
+        else PM_LAUNCH_X(32, false);
+    }
+#undef PM_LAUNCH_X
     return (int)hipGetLastError();
 }
 

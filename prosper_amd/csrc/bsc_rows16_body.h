@@ -166,6 +166,7 @@ struct RowParams {
     double *expect;
     int64_t lde;
     double *wq;
+    int cand_mod;      // != 0: candidates are stored modulo this (TSC: one-cause state 0 .. 2H-1 -> its latent, tsc_et.py:210)
 };
 
 // per-lane partial sums of the scalar M-step statistics over the passes of a wavefront
@@ -388,6 +389,7 @@ __device__ __forceinline__ int row_select(const double (&a)[VPL], const RowParam
         const int code = (int)(mb & 0x3FFull);
         const int win = (mb >> 63) ? 0x3FF - code : code;
         myc = smallest ? 0x3FF - win : win;
+        if (A.cand_mod) myc = myc % A.cand_mod;
         if (live) A.cand[n * Hp + j] = myc;
     }
     wave_lds_sync16();   // the lists' bytes become P

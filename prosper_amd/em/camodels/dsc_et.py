@@ -281,7 +281,11 @@ class DSC_ET(DeviceCAModel):
         par = self._params_dev(model_params['W'], res)
         P = self._params(FixedT(), model_params['pi'], model_params['sigma'])
         cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
-        if N:
+        if N and _lib.load().pm_xsc_select_supported(H, Hp, 0):
+            # ranking values formed and ranked in one pass over the scores (no (N, H) buffer, one launch)
+            self._call("select", "pm_xsc_select_f64", _ptr(par["A"]), H, _ptr(par["G"]), ctypes.byref(P), N, H, Hp,
+                       _ptr(cand), self._stream())
+        elif N:
             R = self._buf("dsc_sel", (N, H))
             self._call("select_scores", "pm_dsc_select_scores_f64", _ptr(par["A"]), H, _ptr(par["G"]),
                        ctypes.byref(P), N, H, _ptr(R), H, self._stream())

@@ -234,7 +234,11 @@ class TSC_ET(DeviceCAModel):
         self._tables()
         par = self._params_dev(model_params['W'], res)
         cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
-        if N:
+        if N and _lib.load().pm_xsc_select_supported(H, Hp, 1):
+            # the 2 H one-cause values formed and ranked in one pass over the scores; candidates come out as latents
+            self._call("select", "pm_xsc_select_f64", _ptr(par["A"]), H, _ptr(par["G"]), None, N, H, Hp, _ptr(cand),
+                       self._stream())
+        elif N:
             R = self._buf("tsc_sel", (N, 2 * H))
             self._call("select_scores", "pm_tsc_select_scores_f64", _ptr(par["A"]), H, _ptr(par["G"]), N, H, _ptr(R),
                        2 * H, self._stream())

@@ -42,4 +42,4 @@ for fuse in (True, False):
             p = m.step(An(T=1.0), p, {"y": Y})
         m.timer = None
         ks = {k: round(v[1], 4) for k, v in sorted(kt.summary().items())}
-        print("%s fuse=%s: %.4f ms/iter  %s" % (name, fuse, best, {k: ks[k] for k in ks if k in ("estep", "estep_mstats", "mstep_rows", "stats_sparse")}), flush=True)
+        print("%s fuse=%s: %.4f ms/iter  %s" % (name, fuse, best, ks), flush=True)

@@ -372,3 +372,56 @@ def test_full_shard_against_oracle_rows(model):
     np.testing.assert_allclose(np.asarray(ss2["logpj"]), got, rtol=1e-12, atol=1e-12)
     m2.M_step(an, params, ss2, d2)
     np.testing.assert_allclose(E[idx], m2._ws["expect"].cpu().numpy(), rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.parametrize("tsc,H,Hp,K,N", [(0, 128, 6, 3, 5001), (0, 50, 5, 5, 777), (0, 300, 4, 3, 403), (0, 10, 3, 2, 70),
+                                          (1, 128, 6, 0, 5001), (1, 32, 4, 0, 333), (1, 256, 8, 0, 150)])
+def test_fused_selection_matches_the_two_launch_form(tsc, H, Hp, K, N):
+    """pm_xsc_select_f64 (ranking values formed in registers and ranked in one pass) against pm_dsc_select_scores_f64 /
+    pm_tsc_select_scores_f64 + pm_bsc_select_estep_f64 (+ the modulo of tsc_et.py:210): the same candidates in the same
+    order; a row may differ only where two ranking values agree to rounding (the two kernels may round a fused multiply-add
+    differently)."""
+    import ctypes
+    from prosper_amd import _lib
+    dev = torch.device("cuda", 0)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.RandomState(H + 3 * Hp + K)
+    A = torch.from_numpy(rng.normal(size=(N, H)) * 30).to(dev)
+    W = rng.normal(size=(H, 40))
+    G = torch.from_numpy(W @ W.T).to(dev)
+    yn = torch.zeros(N, dtype=torch.float64, device=dev)
+    assert _lib.load().pm_xsc_select_supported(H, Hp, tsc)
+    new = torch.full((N, Hp), -1, dtype=torch.int32, device=dev)
+    if tsc:
+        R = torch.empty((N, 2 * H), dtype=torch.float64, device=dev)
+        _lib.call("pm_tsc_select_scores_f64", p(A), H, p(G), N, H, p(R), 2 * H, st)
+        gd = torch.zeros((2 * H, 2 * H), dtype=torch.float64, device=dev)
+        old = torch.empty((N, Hp), dtype=torch.int32, device=dev)
+        _lib.call("pm_bsc_select_estep_f64", p(R), 2 * H, p(gd), p(yn), None, None, None, None, None, 0, 3, None, N, 2 * H,
+                  Hp, 1 | 8, p(old), None, 0, None, st)
+        old = torch.remainder(old, H)
+        _lib.call("pm_xsc_select_f64", p(A), H, p(G), None, N, H, Hp, p(new), st)
+    else:
+        P = _lib.DscParams()
+        vals = np.concatenate([[0.0], rng.permutation(np.arange(1, K))[:K - 1] * rng.choice([-1.0, 1.0], size=K - 1)])
+        P.K, P.K0 = K, 0
+        pi = rng.dirichlet(np.ones(K))
+        for k in range(K):
+            P.values[k] = float(vals[k])
+            P.logpi[k] = float(np.log(pi[k]))
+        P.pre1 = -0.37
+        R = torch.empty((N, H), dtype=torch.float64, device=dev)
+        _lib.call("pm_dsc_select_scores_f64", p(A), H, p(G), ctypes.byref(P), N, H, p(R), H, st)
+        old = torch.empty((N, Hp), dtype=torch.int32, device=dev)
+        _lib.call("pm_bsc_select_estep_f64", p(R), H, p(G), p(yn), None, None, None, None, None, 0, 3, None, N, H, Hp,
+                  1 | 4 | 8, p(old), None, 0, None, st)
+        _lib.call("pm_xsc_select_f64", p(A), H, p(G), ctypes.byref(P), N, H, Hp, p(new), st)
+    old, new, Rh = old.cpu().numpy(), new.cpu().numpy(), R.cpu().numpy()
+    assert new.min() >= 0 and new.max() < H
+    bad = np.nonzero((old != new).any(axis=1))[0]
+    assert len(bad) <= max(1, N // 1000), (len(bad), N)
+    for n in bad:          # only where ranking values tie to rounding
+        r = np.sort(Rh[n])
+        gaps = np.abs(np.diff(r)) / np.maximum(np.abs(r[1:]), 1e-300)
+        assert gaps.min() < 1e-12, (n, old[n], new[n])
