@@ -230,6 +230,7 @@ class DeviceCAModel(CAModel):
     def step(self, anneal, model_params, my_data):
         """CAModel.step (camodels/__init__.py:163-193); the E-step knows that the M-step follows with the same arguments."""
         was, self._in_step = getattr(self, "_in_step", False), True
+        self._step_id = getattr(self, "_step_id", 0) + 1
         try:
             return CAModel.step(self, anneal, model_params, my_data)
         finally:
@@ -541,6 +542,36 @@ class DeviceCAModel(CAModel):
         if N:
             self._gemm_nt(Y, Wt, A, "scores_gemm")
         self._seed_rec = {"ykey": res["key"], "Wt": Wt, "G": G, "A": A, "W": None}
+
+    def _scores_params(self, W, res):
+        """DSC / TSC: device copy of W^T (H,D), the Gram matrix and the scores for the current W and data.  In an EM loop
+        the last M-step has left all three on the device (``_seed_next``): W is compared with ITS snapshot first, and once
+        per ``step`` -- select_Hprimes, E_step and M_step see the same array object there, and a 256 x 128 comparison costs
+        27 us of host time that sits on the loop's critical path (three of them per step until round 4: the device idled
+        ~0.1 ms per 0.7 ms iteration waiting for the E-step launch)."""
+        W = np.asarray(W, dtype=np.float64)
+        par = self._par
+        tag = (getattr(self, "_step_id", 0), id(W)) if getattr(self, "_in_step", False) else None
+        if tag is not None and par.get("checked") == tag and par.get("ykey") == res["key"]:
+            return par
+        if getattr(self, "_seed_rec", None) is not None:
+            seeded = self._take_seed(W, res)
+            if seeded is not None:           # W^T, Gram matrix and scores left on the device by the last M-step
+                seeded["checked"] = tag
+                self._par = seeded
+                return seeded
+        if par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape \
+                and np.array_equal(par["W"], W):
+            par["checked"] = tag
+            return par
+        Wt = self._upload("W", W).t().contiguous()
+        G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
+        Y = res["Y"]
+        A = self._buf("scores", (Y.shape[0], self.H))
+        if Y.shape[0]:
+            self._gemm_nt(Y, Wt, A, "scores_gemm")
+        self._par = {"ykey": res["key"], "W": W.copy(), "Wt": Wt, "G": G, "A": A, "checked": tag}
+        return self._par
 
     def _take_seed(self, W, res):
         """The seeded parameter record if ``W`` (D,H) is what the last M-step returned (compared with a private

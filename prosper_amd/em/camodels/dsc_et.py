@@ -251,23 +251,7 @@ class DSC_ET(DeviceCAModel):
 
     def _params_dev(self, W, res):
         """Device copy of W^T (H,D), the Gram matrix and the scores for the current W and data."""
-        W = np.asarray(W, dtype=np.float64)
-        par = self._par
-        if par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape \
-                and np.array_equal(par["W"], W):
-            return par
-        seeded = self._take_seed(W, res)
-        if seeded is not None:               # W^T, Gram matrix and scores left on the device by the last M-step
-            self._par = seeded
-            return seeded
-        Wt = self._upload("W", W).t().contiguous()
-        G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
-        Y = res["Y"]
-        A = self._buf("scores", (Y.shape[0], self.H))
-        if Y.shape[0]:
-            self._gemm_nt(Y, Wt, A, "scores_gemm")
-        self._par = {"ykey": res["key"], "W": W.copy(), "Wt": Wt, "G": G, "A": A}
-        return self._par
+        return self._scores_params(W, res)
 
     # ------------------------------------------------------------------ hot path
     @tracing.traced
@@ -404,7 +388,8 @@ class DSC_ET(DeviceCAModel):
             elif ok:
                 W_new = host[15:15 + H * D].reshape(H, D).copy()
                 if self._seed_rec is not None:
-                    self._seed_rec["W"] = W_new.transpose().copy()   # private snapshot of the W handed back
+                    self._seed_rec["W"] = W_new.copy().transpose()   # private snapshot of the W handed back (same memory order: a
+                                                                     # contiguous copy and a contiguous comparison)
             else:   # numerically singular Wq: the reference's own LAPACK lstsq on the host
                 self._seed_rec = None
                 self._winv_prev = None        # never warm-start the next inverse from a rejected one

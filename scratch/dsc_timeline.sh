@@ -10,7 +10,7 @@ for f in glob.glob("/tmp/tld/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
 ev.sort()
-idx = [i for i, e in enumerate(ev) if "dsc_estep_kernel" in e[2]]
+idx = [i for i, e in enumerate(ev) if "dsc_estep16_ms_kernel" in e[2]]
 lo, hi = idx[-2], idx[-1]
 t0 = ev[lo][0]; prev = None; small = 0; gaps = 0.0
 for s, e, n in ev[lo:hi]:

@@ -243,16 +243,18 @@ def test_em_loop_speculation_is_transparent(model):
         taken = []
         take = m._take_seed
         m._take_seed = lambda W, res: taken.append(take(W, res)) or taken[-1]
+        hit = []
         for it in range(5):
             if it == 3:
                 p["W"] = p["W"] * (1.0 + 1e-3 * np.cos(np.arange(D * H).reshape(D, H)))
             if it == 4:
                 p["W"][0, 0] += 0.01
+            before = len(taken)
             p = m.step(_An(T=1.0), p, {"y": y})
+            hit.append(any(t is not None for t in taken[before:]))      # (the seed is only looked at when there is one)
         # steps 1 and 2 ran on the seeded parameters, 0 (nothing seeded yet), 3 and 4 (W edited) must not.  (Step 2's
         # seed is void when the device rejected the warm start of step 1's inverse: W then comes from the repeated,
         # refined solve -- DeviceCAModel._solve_accurate -- not from the solution the seed was computed from.)
-        hit = [t is not None for t in taken]
         assert hit[:2] + hit[3:] == ([False, True, False, False] if spec else [False] * 4) and (spec or not hit[2])
         runs.append(p)
     for k in ("W", "pi", "sigma"):
