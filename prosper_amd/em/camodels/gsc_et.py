@@ -634,6 +634,13 @@ class GSC(DeviceCAModel):
                 return x.to(self.device)
             return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float64)).to(self.device)
 
+        old_dev = None
+        if self.speculate and self.speculate_estep and self.sigma_sq_type == 'scalar' and my_N and 'W' in self.to_learn:
+            # the old parameters for pm_gsc_mstep_finish_f64, uploaded NOW: enqueued in front of the contraction they are on
+            # the device long before the finish kernel wants them (uploaded next to it, the copy and its latency sat in the
+            # middle of the M-step's chain of small launches: ~30 us of idle device per step)
+            old_dev = self._upload("gsc_old", np.concatenate([np.asarray(model_params[k], dtype=np.float64).reshape(-1)
+                                                               for k in ('pi', 'mu', 'psi_sq', 'sigma_sq')]))
         xs, xsz = dev(suff_stats['xpt_s']), dev(suff_stats['xpt_sz'])
         ld = xs.stride(0) if xs.dim() == 2 else 0
         paired = (xs.dim() == 2 and xs.stride(1) == 1 and xsz.stride() == (ld, 1) and H % 2 == 0 and ld % 2 == 0
@@ -757,15 +764,13 @@ class GSC(DeviceCAModel):
         # an EM loop on a flat annealing schedule that E-step is launched right here (E_step adopts it iff it is called
         # with exactly the parameters this M-step returns).  The host still receives everything with the one download.
         fin = None
-        if Wt_next is not None and self.speculate_estep and my_N:
+        if Wt_next is not None and self.speculate_estep and my_N and old_dev is not None:
             G_next = self._gemm_nt(Wt_next, Wt_next, torch.empty((H, H), dtype=torch.float64, device=self.device),
                                    "gram_gemm")
-            old = np.concatenate([np.asarray(model_params[k], dtype=np.float64).reshape(-1)
-                                  for k in ('pi', 'mu', 'psi_sq', 'sigma_sq')])
             learn = sum(bit for bit, k in ((1, 'pi'), (2, 'mu'), (4, 'psi_sq'), (8, 'sigma_sq')) if k in self.to_learn)
             tdev = torch.empty(9 * H, dtype=torch.float64, device=self.device)
             self._call("mstep_finish", "pm_gsc_mstep_finish_f64", at(nWp), at(nWp + nHH), at(o), at(o + nHH), at(o_inv),
-                       at(o2), at(o2 + H), at(o2 + 2 * H), _ptr(G_next), _ptr(self._upload("gsc_old", old)),
+                       at(o2), at(o2 + H), at(o2 + 2 * H), _ptr(G_next), _ptr(old_dev),
                        ctypes.c_double(float(N)), D, H, learn, at(o_par), _ptr(tdev), st)
             fin = {"G": G_next, "psi": whole[o_par + 2 * H:o_par + 2 * H + nHH].view(H, H), "tdev": tdev, "out": None}
 
