@@ -103,7 +103,7 @@ class MCA_ET(DeviceCAModel):
         assert np.isfinite(Wl).all() and np.isfinite(host[1]).all() and (host[1] > 1e-86).all()   # mca_et.py:224-227
         dev = self._upload("mca_tabs", host)
         wnorm2 = self._upload("mca_wn", (Wt * Wt).sum(axis=1))
-        self._par = {"ykey": res["key"], "T": T, "W": W.copy(), "Wt": dev[0], "Wrho": dev[1], "Wrm1": dev[2],
+        self._par = {"ykey": res["key"], "T": T, "W": W.copy(order='K'), "Wt": dev[0], "Wrho": dev[1], "Wrm1": dev[2],
                      "wnorm2": wnorm2, "rho": float(rho), "A": None}
         return self._par
 
@@ -121,7 +121,22 @@ class MCA_ET(DeviceCAModel):
         N, D = Y.shape
         H, Hp = self.H, self.Hprime
         self._masks()
-        Wt = self._upload("mca_W", np.ascontiguousarray(np.asarray(model_params['W'], dtype=np.float64).T))
+        W = np.asarray(model_params['W'], dtype=np.float64)
+        seed, self._sel_seed = getattr(self, "_sel_seed", None), None
+        if seed is not None and seed["W"] is not None and seed["ykey"] == res["key"] and seed["W"].shape == W.shape \
+                and np.array_equal(seed["W"], W):
+            # the last M-step ranked the candidates for exactly this W behind its download (``_seed_select``)
+            data['candidates'] = DeviceArray(seed["cand"], np.int64)
+            return data
+        Wt = self._upload("mca_W", np.ascontiguousarray(W.T))
+        data['candidates'] = DeviceArray(self._select_on_device(res, Wt), np.int64)
+        return data
+
+    def _select_on_device(self, res, Wt):
+        """The two selection launches for W^T (H,D) on the device; returns the candidates tensor."""
+        Y = res["Y"]
+        N, D = Y.shape
+        H, Hp = self.H, self.Hprime
         cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
         if N:
             R = self._buf("mca_sim", (N, H))
@@ -132,8 +147,16 @@ class MCA_ET(DeviceCAModel):
             self._call("select", "pm_bsc_select_estep_f64", _ptr(R), H, _ptr(gdummy), _ptr(res["ynorm2"]), None, None,
                        None, None, None, 0, self.gamma, None, N, H, Hp, 1 | 4 | 8, _ptr(cand), None, 0, None,
                        self._stream())
-        data['candidates'] = DeviceArray(cand, np.int64)
-        return data
+        return cand
+
+    def _seed_select(self, res, Wt_new):
+        """Next step's candidates from the W^T the M-step has just formed on the device, enqueued behind its download: the
+        max-plus selection pass (0.45 ms at config 5) runs while the host unpacks the result and prepares the next step's
+        power tables, instead of after both (the device idled ~0.2 ms per 8.4 ms iteration there).  ``select_Hprimes``
+        adopts them iff it is called with the W this M-step returns AFTER ``check_params`` -- the clamp to W_tol that
+        ``CAModel.step`` applies first (mca_et.py:44-55) is applied here too -- compared with a private snapshot."""
+        Wt = torch.clamp_min(Wt_new, float(self.W_tol))
+        self._sel_seed = {"ykey": res["key"], "cand": self._select_on_device(res, Wt), "W": None, "Wt": Wt}
 
     @tracing.traced
     def E_step(self, anneal, model_params, my_data):
@@ -244,6 +267,7 @@ class MCA_ET(DeviceCAModel):
                        self._stream())
         stats = stats[:3 * H * D + H + 4]   # the per-XCD scratch tail is already folded in (and zero)
         comm.allreduce_device(stats)      # replaces mca_et.py:208,253,340,341,357,366,371
+        self._mstep_res = res
         return self._finalize(stats, model_params, par, A_pi_gamma, B_pi_gamma)
 
     def _finalize(self, stats, model_params, par, A_pi_gamma, B_pi_gamma):
@@ -267,13 +291,28 @@ class MCA_ET(DeviceCAModel):
             small = Wq < tiny                       # make sure we do not divide by zero (mca_et.py:343-346)
             Wp = torch.where(small, torch.zeros_like(Wp), Wp)
             Wq = torch.where(small, torch.full_like(Wq, tiny), Wq)
-            parts.append((Wp / Wq).reshape(-1))
+            Wt_new = Wp / Wq
+            parts.append(Wt_new.reshape(-1))
         flat = torch.cat(parts)
-        host = self._download(flat) if flat.is_cuda else flat.numpy()
+        self._sel_seed = None
+        res = getattr(self, "_mstep_res", None)
+        seedable = (flat.is_cuda and learn_W and self.speculate and res is not None and res["Y"].shape[0] > 0
+                    and type(self).select_Hprimes is MCA_ET.select_Hprimes)
+        if seedable:
+            host = self._download(flat, then=lambda: self._seed_select(res, Wt_new))
+        else:
+            host = self._download(flat) if flat.is_cuda else flat.numpy()
         my_pi, my_sigma, ldenom_sum, N_use = float(host[0]), float(host[1]), float(host[2]), int(round(host[3]))
         dlog.append('N_use', N_use)
 
-        W_new = host[4:4 + HD].reshape(H, D).T.copy() if learn_W else np.asarray(model_params['W'])
+        if learn_W:
+            # (D, H) as a transposed view of a contiguous (H, D) copy: no strided copy here, none when the next step takes
+            # W^T again; the seed's snapshot is a second copy in the same memory order
+            W_new = host[4:4 + HD].reshape(H, D).copy().T
+            if self._sel_seed is not None:
+                self._sel_seed["W"] = np.maximum(host[4:4 + HD].reshape(H, D), self.W_tol).T
+        else:
+            W_new = np.asarray(model_params['W'])
         if 'pi' in self.to_learn:
             tracing.tracepoint("M_step:update pi")
             pi_new = A_pi_gamma / B_pi_gamma * pies * my_pi / N_use

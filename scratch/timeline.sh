@@ -2,7 +2,7 @@
 # device timeline (kernels + copies, gaps) of the LAST steady EM iteration of a script:  bash scratch/timeline.sh <script.py> <marker kernel substring>
 R=$PWD; S=$1; K=$2
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/tlx
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tlx -o tl -- python3 $R/$S > /tmp/tlx.log 2>&1 || tail -3 /tmp/tlx.log
+PYTHONPATH=$R rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tlx -o tl -- python3 $R/$S > /tmp/tlx.log 2>&1 || tail -3 /tmp/tlx.log
 python3 - "$K" <<'PY'
 import csv, glob, sys
 ev = []

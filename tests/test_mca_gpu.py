@@ -256,3 +256,41 @@ def test_mca_inference_matches_reference(tag, kw, capsys):
     assert res["s"].dtype == np.int8 and np.array_equal(res["s"], g[tag + "_s"])
     np.testing.assert_allclose(res["p"], g[tag + "_p"], rtol=1e-7, atol=1e-12)
     np.testing.assert_allclose(res["m"], g[tag + "_m"], rtol=1e-7, atol=1e-12)
+
+
+def test_mca_em_loop_seeded_selection_is_transparent():
+    """The M-step ranks the next step's candidates on the device behind its download (MCA_ET._seed_select); the next
+    select_Hprimes adopts them iff it gets the W that M-step returned.  Same trajectory as the loop that never seeds,
+    whether the caller feeds W straight back, replaces it, or edits it in place."""
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    from oracle import mca_oracle as MO
+    D, H, Hp, gamma, N = 64, 32, 5, 3, 900
+    rng = np.random.RandomState(7)
+    Wm = np.abs(rng.normal(size=(D, H))) * 2 + 0.1
+    y, _ = MO.generate_mca_data(Wm, 2.0 / H, 1.0, N, rng)
+    p0 = {"W": Wm * (1 + 0.1 * rng.uniform(-1, 1, size=(D, H))), "pi": 2.0 / H, "sigma": 1.0}
+    runs = []
+    for spec in (True, False):
+        m = MCA_ET(D, H, Hp, gamma)
+        m.speculate = spec
+        launched = []
+        sel = m._select_on_device
+        m._select_on_device = lambda res, Wt: launched.append(1) or sel(res, Wt)
+        p = {k: np.array(v, copy=True) for k, v in p0.items()}
+        per_step = []
+        for it in range(6):
+            if it == 3:
+                p["W"] = p["W"] * (1.0 + 1e-3 * np.cos(np.arange(D * H).reshape(D, H)))
+            if it == 4:
+                p["W"][0, 0] *= 1.01
+            before = len(launched)
+            p = m.step(_An(T=1.0), p, {"y": y})
+            p = {k: p[k] for k in ("W", "pi", "sigma")}
+            per_step.append(len(launched) - before)
+        runs.append(p)
+        # seeding: one selection per step (the M-step's, for the next step) wherever the seed was adopted, two where
+        # select_Hprimes had to rank for itself (step 0, the replaced W, the in-place edit)
+        assert per_step == ([2, 1, 1, 2, 2, 1] if spec else [1] * 6), per_step
+    for k in ("W", "pi", "sigma"):
+        # (the statistics are sums of f64 atomics: two runs of the same loop agree to ~1e-12, not bit for bit)
+        np.testing.assert_allclose(runs[0][k], runs[1][k], rtol=1e-9, err_msg=k)
