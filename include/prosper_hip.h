@@ -407,6 +407,12 @@ int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const double *wno
                             const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
                             int64_t Hprime, double *logpj, int64_t ldl, double *lse1, double *lseb,
                             double *q1, int64_t ldq, double *stats, void *stream);
+/* The element-wise W update of MCA_ET.M_step (mca_et.py:333-348) from the all-reduced `stats`
+ * [G1 (H,D) | Wp_m (H,D) | Wq_m (H,D) | q1sum (H) | ...] and the current W^T (H,D): wt_new = (G1 W^2 + Wp_m) / (q1sum W^2 + Wq_m),
+ * 0 / tiny where the denominator is below the smallest normal double; wt_clamped (or NULL) = max(wt_new, w_tol), what
+ * check_params (mca_et.py:44-55) makes of it at the top of the next step. */
+int pm_mca_w_update_f64(const double *stats, const double *wt, int64_t H, int64_t D, double w_tol, double *wt_new,
+                        double *wt_clamped, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Discrete Sparse Coding (prosper/em/camodels/dsc_et.py, DSC_ET): K-ary latents

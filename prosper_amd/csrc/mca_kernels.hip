@@ -964,3 +964,39 @@ extern "C" int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const 
     mca_fold(stats, H, D, s);
     return (int)hipGetLastError();
 }
+
+// The element-wise W update of MCA_ET.M_step (mca_et.py:333-348) from the all-reduced statistics
+// [G1 (H,D) | Wp_m (H,D) | Wq_m (H,D) | q1sum (H)]:  Wp = G1 W^2 + Wp_m,  Wq = q1sum_h W^2 + Wq_m,  W_new = Wp / Wq with
+// Wq < tiny -> 0 / tiny (the reference's guard against a division by zero) -- one launch instead of eleven tensor operations;
+// `wt_clamped` (optional): max(W_new, w_tol), what check_params makes of it at the top of the next step (the selection
+// seeded behind the download ranks that).
+namespace {
+__global__ __launch_bounds__(256) void mca_wupdate_kernel(const double *__restrict__ stats, const double *__restrict__ wt,
+                                                          int H, int D, double w_tol, double *__restrict__ wt_new,
+                                                          double *__restrict__ wt_clamped) {
+    const int64_t HD = (int64_t)H * D;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= HD) return;
+    const double tiny = 2.2250738585072014e-308;
+    const double w = wt[e], wsq = w * w;
+    double wp = stats[e] * wsq + stats[HD + e];
+    double wq = stats[3 * HD + e / D] * wsq + stats[2 * HD + e];
+    if (wq < tiny) {
+        wp = 0.0;
+        wq = tiny;
+    }
+    const double r = wp / wq;
+    wt_new[e] = r;
+    if (wt_clamped) wt_clamped[e] = fmax(r, w_tol);
+}
+}  // namespace
+
+extern "C" int pm_mca_w_update_f64(const double *stats, const double *wt, int64_t H, int64_t D, double w_tol, double *wt_new,
+                                   double *wt_clamped, void *stream) {
+    if (!stats || !wt || !wt_new || H <= 0 || D <= 0) return PM_EINVAL;
+    const int64_t HD = H * D;
+    if (HD > (int64_t)INT32_MAX * 256) return PM_ERANGE;
+    hipLaunchKernelGGL(mca_wupdate_kernel, dim3((unsigned)((HD + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       stats, wt, (int)H, (int)D, w_tol, wt_new, wt_clamped);
+    return (int)hipGetLastError();
+}

@@ -149,14 +149,13 @@ class MCA_ET(DeviceCAModel):
                        self._stream())
         return cand
 
-    def _seed_select(self, res, Wt_new):
+    def _seed_select(self, res, Wt_new):      # Wt_new: max(W_new^T, W_tol)
         """Next step's candidates from the W^T the M-step has just formed on the device, enqueued behind its download: the
         max-plus selection pass (0.45 ms at config 5) runs while the host unpacks the result and prepares the next step's
         power tables, instead of after both (the device idled ~0.2 ms per 8.4 ms iteration there).  ``select_Hprimes``
         adopts them iff it is called with the W this M-step returns AFTER ``check_params`` -- the clamp to W_tol that
         ``CAModel.step`` applies first (mca_et.py:44-55) is applied here too -- compared with a private snapshot."""
-        Wt = torch.clamp_min(Wt_new, float(self.W_tol))
-        self._sel_seed = {"ykey": res["key"], "cand": self._select_on_device(res, Wt), "W": None, "Wt": Wt}
+        self._sel_seed = {"ykey": res["key"], "cand": self._select_on_device(res, Wt_new), "W": None, "Wt": Wt_new}
 
     @tracing.traced
     def E_step(self, anneal, model_params, my_data):
@@ -275,23 +274,19 @@ class MCA_ET(DeviceCAModel):
         H, D = self.H, self.D
         pies, sigma = model_params['pi'], model_params['sigma']
         HD = H * D
-        G1 = stats[:HD].view(H, D)
-        Wp_m = stats[HD:2 * HD].view(H, D)
-        Wq_m = stats[2 * HD:3 * HD].view(H, D)
-        q1sum = stats[3 * HD:3 * HD + H]
-        scal = stats[3 * HD + H:3 * HD + H + 4]
+        scal = stats[3 * HD + H:3 * HD + H + 4]          # behind [G1 | Wp_m | Wq_m] (H,D each) and q1sum (H)
         parts = [scal]
         learn_W = 'W' in self.to_learn
         if learn_W:
             tracing.tracepoint("M_step:update W")
-            Wsq = par["Wt"] * par["Wt"]
-            Wp = G1 * Wsq + Wp_m
-            Wq = q1sum[:, None] * Wsq + Wq_m
-            tiny = float(np.finfo(np.float64).tiny)
-            small = Wq < tiny                       # make sure we do not divide by zero (mca_et.py:343-346)
-            Wp = torch.where(small, torch.zeros_like(Wp), Wp)
-            Wq = torch.where(small, torch.full_like(Wq, tiny), Wq)
-            Wt_new = Wp / Wq
+            # one launch (pm_mca_w_update_f64) instead of eleven tensor operations; the clamped copy is what the next step's
+            # check_params will make of W: the seeded selection ranks that
+            Wt_new = torch.empty((H, D), dtype=torch.float64, device=stats.device)
+            Wt_cl = torch.empty_like(Wt_new)
+            if not stats.is_cuda:
+                raise _lib.HipError("MCA_ET.M_step: the statistics must be a device tensor (no CPU path)")
+            self._call("w_update", "pm_mca_w_update_f64", _ptr(stats), _ptr(par["Wt"]), H, D, ctypes.c_double(self.W_tol),
+                       _ptr(Wt_new), _ptr(Wt_cl), self._stream())
             parts.append(Wt_new.reshape(-1))
         flat = torch.cat(parts)
         self._sel_seed = None
@@ -299,7 +294,7 @@ class MCA_ET(DeviceCAModel):
         seedable = (flat.is_cuda and learn_W and self.speculate and res is not None and res["Y"].shape[0] > 0
                     and type(self).select_Hprimes is MCA_ET.select_Hprimes)
         if seedable:
-            host = self._download(flat, then=lambda: self._seed_select(res, Wt_new))
+            host = self._download(flat, then=lambda: self._seed_select(res, Wt_cl))
         else:
             host = self._download(flat) if flat.is_cuda else flat.numpy()
         my_pi, my_sigma, ldenom_sum, N_use = float(host[0]), float(host[1]), float(host[2]), int(round(host[3]))
