@@ -174,16 +174,25 @@ class DSC_ET(DeviceCAModel):
         return model_params
 
     def get_scaling_factors(self, pi):
-        """Prior mass of the states with at most gamma non-zero latents (dsc_et.py:798-823)."""
+        """Prior mass of the states with at most gamma non-zero latents (dsc_et.py:798-823).  The count vectors and their
+        multinomial coefficients do not depend on pi: enumerated once (the loop and its summation order are upstream's)."""
+        key = (self.gamma, self.H, self._K_0, len(self.states))
+        cached = getattr(self, "_scaling_terms", None)
+        terms = cached[1] if cached is not None and cached[0] == key else None
+        if terms is None:
+            terms = []
+            for gp in itls.product(np.arange(self.gamma + 1), repeat=len(self.states) - 1):
+                ngp = np.array(gp)
+                if ngp.sum() > self.gamma:
+                    continue
+                abs_array = np.insert(ngp, self._K_0, self.H - ngp.sum())
+                if not abs_array.sum() == self.H:
+                    raise Exception("wrong number of elements counted")
+                terms.append((multinom2(abs_array.sum(), abs_array), abs_array))
+            self._scaling_terms = (key, terms)
         A_pi_gamma = 0.0
-        for gp in itls.product(np.arange(self.gamma + 1), repeat=len(self.states) - 1):
-            ngp = np.array(gp)
-            if ngp.sum() > self.gamma:
-                continue
-            abs_array = np.insert(ngp, self._K_0, self.H - ngp.sum())
-            if not abs_array.sum() == self.H:
-                raise Exception("wrong number of elements counted")
-            A_pi_gamma += multinom2(abs_array.sum(), abs_array) * np.prod(pi ** abs_array)
+        for coef, abs_array in terms:
+            A_pi_gamma += coef * np.prod(pi ** abs_array)
         return A_pi_gamma
 
     def standard_init(self, data):
@@ -339,9 +348,11 @@ class DSC_ET(DeviceCAModel):
         if not fused:
             stats.zero_()
         expect = self._buf("expect", (my_N, H))
-        prior = self._upload("dsc_prior", self._prior(pi))
+        # (the fused pass has used the prior already; only the M-step's own row pass needs it again)
+        prior = None if fused else self._upload("dsc_prior", self._prior(pi))
         if my_N:
-            self._rows_and_wp((_ptr(lp), Kt, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S, _ptr(prior),
+            self._rows_and_wp((_ptr(lp), Kt, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S,
+                               _ptr(prior) if prior is not None else None,
                                ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats)),
                               Kt, expect, Y, stats, my_N, self.K, int(P.flags), Hp, S, fused=fused)
         comm.allreduce_device(stats)      # replaces dsc_et.py:648,738,739,747,769 and the allreduce in get_likelihood

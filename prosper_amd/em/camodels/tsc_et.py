@@ -302,9 +302,10 @@ class TSC_ET(DeviceCAModel):
         if not fused:
             stats.zero_()
         expect = self._buf("expect", (my_N, H))
-        prior = self._upload("tsc_prior", self._prior(pi))
+        prior = None if fused else self._upload("tsc_prior", self._prior(pi))
         if my_N:
-            self._rows_and_wp((_ptr(lp), S, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S, _ptr(prior),
+            self._rows_and_wp((_ptr(lp), S, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S,
+                               _ptr(prior) if prior is not None else None,
                                ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats)),
                               S, expect, Y, stats, my_N, int(P.K), int(P.flags), Hp, S, fused=fused)
         comm.allreduce_device(stats)      # replaces tsc_et.py:412,446,453,486,487,497,527

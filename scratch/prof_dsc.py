@@ -36,4 +36,4 @@ torch.cuda.synchronize()
 el=(time.perf_counter()-t)/300*1e3
 pr.disable()
 print("EM iter ms (under cProfile)", el)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(32)
