@@ -687,7 +687,8 @@ class BSC_ET(DeviceCAModel):
         # (Everything but Wp is final here, and the H x H inverse needs only the second moments -- but putting it on a
         # high-priority side stream ahead of the statistics GEMM gains nothing: its 1024-thread workgroup needs a whole
         # CU's registers, the GEMM's workgroups refill every slot as it frees, so the inverse still starts when the GEMM
-        # has drained; 4.88 vs 4.87 ms per EM iteration.  The warm-started inverse made the question moot.)
+        # has drained; 4.88 vs 4.87 ms per EM iteration.  Round 4, with the warm start's small launches beside the SPARSE
+        # product on one rank: 2.27 against 2.21 ms -- slower; the chain stays in stream order.)
         if my_N and done == my_N and nz is not None and nz["stats"] is stats and nz["rows"] == my_N:
             # the lists of this very pass: sparse product, and the dense one behind the device-side gate (scalars[3])
             gate = ctypes.c_void_p(stats.data_ptr() + 8 * (_lib.load().pm_bsc_stats_offset_scalars(H, D) + 3))
