@@ -143,9 +143,9 @@ struct GscTables {
 
 // LPJ: also write every state's log-joint (no annealing, prior included -- what compute_lpj returns,
 // gsc_et.py:811-944) to logpj (N, 1 + H + S): [null ; singletons h = 0..H-1 ; multi-cause states in table order].
-// LACC: the column sums of xpt_s / xpt_sz are accumulated in LDS, one private slot per (datapoint row of the workgroup,
-// latent) -- plain read-add-write, no atomics, no conflicts -- and folded over the rows at the end: no second pass over the
-// N x H moments (gsc_colsum_kernel read 410 MB again at config 4: 0.09 ms).
+// LACC: the column sums of xpt_s / xpt_sz and the singletons' diagonal of sum xpt_szsz are accumulated in LDS -- [3][4
+// wavefronts][H] accumulators, ds_add_f64 per lane and datapoint row, a copy per wavefront so that the four never contend --
+// and folded at the end: no second pass over the N x H moments (gsc_colsum_kernel read 410 MB again at config 4: 0.09 ms).
 #ifndef PM_GSC_ABL
 #define PM_GSC_ABL 0      // timing-only ablation builds (scratch/gsc_abl.sh): bits switch phases off, results are wrong
 #endif
