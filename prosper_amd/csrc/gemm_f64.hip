@@ -210,11 +210,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *__res
 // before the last 16 MFMAs (their operands are already in registers), counted s_waitcnt vmcnt.
 // Rows/columns past M/N are clamped on load (garbage accumulators that are never stored).
 // ---------------------------------------------------------------------------------------------
-constexpr int DK = 8, DSTAGES = 4, DSTAGE = (128 + 128) * DK;  // doubles per stage (16 KB)
+constexpr int DK = 8, DSTAGES = 4;   // K columns per stage, ring stages (a stage: (BM + 128) x 8 doubles)
 
 #define PM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <bool SPLITK>  // SPLITK: grid.y K-slices added to a zeroed C with atomics (own kernel name in profiles)
+// BM: rows of A per tile -- 128, or 64 for the ragged last round of a tall product whose tiles would fill between a quarter
+// and 70 % of the resident slots (K too short to split): twice as many workgroups of half the work fill that round (DSC /
+// TSC / MCA scores at N = 100k: 782 tiles on 512 slots ran two rounds for 1.53 rounds of work).  A 64-row tile does 16 MFMAs
+// per K-step and wavefront on 6 fragment reads instead of 32 on 8.
+template <int Q>
+__device__ __forceinline__ void nt_wait_vmcnt() {
+    if (Q == 12) PM_WAIT_VMCNT(12);
+    else if (Q == 9) PM_WAIT_VMCNT(9);
+    else if (Q == 8) PM_WAIT_VMCNT(8);
+    else if (Q == 6) PM_WAIT_VMCNT(6);
+    else if (Q == 4) PM_WAIT_VMCNT(4);
+    else if (Q == 3) PM_WAIT_VMCNT(3);
+    else PM_WAIT_VMCNT(0);
+}
+
+template <bool SPLITK, int BM = 128>  // SPLITK: grid.y K-slices added to a zeroed C with atomics (own kernel name in profiles)
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *__restrict__ A, int64_t lda,
                                                                   const double *__restrict__ B, int64_t ldb,
                                                                   double *__restrict__ C, int64_t ldc, int M, int N,
@@ -225,7 +240,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     // Fused remainder (SPLITK == false, main_tiles < all tiles): workgroups [0, main_tiles) are whole rounds of
     // un-split tiles; the ones behind them are K-slices of the ragged last round's tiles (rows zeroed by the
     // launcher, atomics), dispatched as the last main round drains instead of in a launch of their own.
-    __shared__ __attribute__((aligned(1024))) double sm[DSTAGES * DSTAGE];
+    static_assert(BM == 128 || BM == 64, "tile rows");
+    constexpr int QA = BM / 64;                    // A chunks (16 rows) this wavefront moves per K-step
+    constexpr int AI = BM / 32;                    // 16-row blocks of A per wavefront
+    constexpr int ACH = BM / 16;                   // A chunks per stage
+    constexpr int DSTAGE_T = (BM + 128) * DK;      // doubles per stage
+    constexpr int L = QA + 2;                      // DMA instructions per K-step and wavefront
+    __shared__ __attribute__((aligned(1024))) double sm[DSTAGES * DSTAGE_T];
 
     const int tid = threadIdx.x;
     // the wavefront index is uniform: say so, and the LDS-DMA destinations (M0) become scalar arithmetic
@@ -239,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     int kt0 = blockIdx.y * kps;
     bool slice = SPLITK;
     if (!SPLITK && tile >= main_tiles) {                       // K-slice of a remainder tile
-        const int rest_tiles = ((M + 127) / 128) * tiles_n - main_tiles;
+        const int rest_tiles = ((M + BM - 1) / BM) * tiles_n - main_tiles;
         const int u = tile - main_tiles;
         tile = main_tiles + u % rest_tiles;
         kt0 = (u / rest_tiles) * rest_kps;
@@ -249,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
         tile = (tile & ~15) + ((tile & 7) << 1) + ((tile >> 3) & 1);
     }
     const int bn = tile % tiles_n, bm = tile / tiles_n;
-    const int m0 = bm * 128, n0 = bn * 128;
+    const int m0 = bm * BM, n0 = bn * 128;
 
-    // DMA sources: this wavefront moves chunks {wave, wave+4} of A and of B
+    // DMA sources: this wavefront moves chunks {wave, wave+4} of A (BM = 64: chunk `wave`) and of B
     const int dr = lane >> 2, dj = (lane & 3) ^ ((lane >> 4) & 3);
     const double *src[4];
 #pragma unroll
@@ -263,12 +284,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
         src[2 + q] = B + (int64_t)rb * ldb + 2 * dj;
     }
     auto dma = [&](int kt, int stage) {
-        double *dst = sm + stage * DSTAGE + wave * 128;  // chunk = 128 doubles
+        double *dst = sm + stage * DSTAGE_T + wave * 128;  // chunk = 128 doubles
         const int k0 = (kt0 + kt) * DK;
         __builtin_amdgcn_global_load_lds(src[0] + k0, dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(src[1] + k0, dst + 4 * 128, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(src[2] + k0, dst + 8 * 128, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(src[3] + k0, dst + 12 * 128, 16, 0, 0);
+        if (QA == 2) __builtin_amdgcn_global_load_lds(src[1] + k0, dst + 4 * 128, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src[2] + k0, dst + ACH * 128, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src[3] + k0, dst + (ACH + 4) * 128, 16, 0, 0);
     };
 
     // fragment reads.  The two MFMAs of a K-step may take the 8 K-columns in any order as long as A and B agree:
@@ -277,24 +298,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     // and wavefront instead of 16).  Pair p of row R sits at R*8 + ((p ^ ((R>>2)&3)) << 1).
     const int frow = lane & 15, fk = lane >> 4;
     const int sw = (frow >> 2) & 3;
-    const int a_off = (wm * 64 + frow) * DK + ((fk ^ sw) << 1);
-    const int b_off = 128 * DK + (wn * 64 + frow) * DK + ((fk ^ sw) << 1);
+    const int a_off = (wm * (BM / 2) + frow) * DK + ((fk ^ sw) << 1);
+    const int b_off = BM * DK + (wn * 64 + frow) * DK + ((fk ^ sw) << 1);
     typedef double d2 __attribute__((ext_vector_type(2)));
     struct Frag {
-        d2 a[4], b[4];
+        d2 a[AI], b[4];
     };
     auto fread = [&](int stage, Frag &f) {
-        const double *sa = sm + stage * DSTAGE + a_off;
-        const double *sb = sm + stage * DSTAGE + b_off;
+        const double *sa = sm + stage * DSTAGE_T + a_off;
+        const double *sb = sm + stage * DSTAGE_T + b_off;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const d2 *>(sa + i * 16 * DK);
+        for (int i = 0; i < AI; ++i) f.a[i] = *reinterpret_cast<const d2 *>(sa + i * 16 * DK);
 #pragma unroll
         for (int j = 0; j < 4; ++j) f.b[j] = *reinterpret_cast<const d2 *>(sb + j * 16 * DK);
     };
 
-    d4 acc[4][4];
+    d4 acc[AI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < AI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
@@ -305,10 +326,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     for (int t = 0; t < DSTAGES; ++t)
         if (t < nk) dma(t, t);
     // this wavefront's part of K-step 0 has landed
-    if (nk >= 4) PM_WAIT_VMCNT(12);
-    else if (nk == 3) PM_WAIT_VMCNT(8);
-    else if (nk == 2) PM_WAIT_VMCNT(4);
-    else PM_WAIT_VMCNT(0);
+    if (nk >= 4) nt_wait_vmcnt<3 * L>();
+    else if (nk == 3) nt_wait_vmcnt<2 * L>();
+    else if (nk == 2) nt_wait_vmcnt<L>();
+    else nt_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     Frag f0, f1;
     fread(0, f0);
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     auto kstep = [&](int t, const Frag &cur, Frag &nxt) {
         const int stage = t & (DSTAGES - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < AI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(cur.a[i].x, cur.b[j].x, acc[i][j]);
         if (t + 1 < nk) {
@@ -326,15 +347,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
             // after the barrier that holds for every wavefront: stage t may be refilled, t+1 may be read
             const int ahead = nk - t - 2;  // K-steps issued beyond t+1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (ahead >= 2) PM_WAIT_VMCNT(8);
-            else if (ahead == 1) PM_WAIT_VMCNT(4);
-            else PM_WAIT_VMCNT(0);
+            if (ahead >= 2) nt_wait_vmcnt<2 * L>();
+            else if (ahead == 1) nt_wait_vmcnt<L>();
+            else nt_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             fread((t + 1) & (DSTAGES - 1), nxt);
             if (t + DSTAGES < nk) dma(t + DSTAGES, stage);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < AI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(cur.a[i].y, cur.b[j].y, acc[i][j]);
     };
@@ -344,11 +365,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
     }
 
     const bool split = slice;
-    const bool interior = (m0 + 128 <= M) && (n0 + 128 <= N);
-    double *cbase = C + (int64_t)(m0 + wm * 64 + fk) * ldc + n0 + wn * 64 + frow;
+    const bool interior = (m0 + BM <= M) && (n0 + 128 <= N);
+    double *cbase = C + (int64_t)(m0 + wm * (BM / 2) + fk) * ldc + n0 + wn * 64 + frow;
     if (!split && interior) {  // the common case: plain stores, no guards
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < AI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -356,10 +377,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AI; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * 64 + i * 16 + fk + 4 * r;
+            const int row = m0 + wm * (BM / 2) + i * 16 + fk + 4 * r;
             if (row >= M) continue;
             double *crow = cbase + (int64_t)(i * 16 + 4 * r) * ldc;
 #pragma unroll
@@ -748,6 +769,15 @@ void launch_nt_dma(const double *A, int64_t lda, const double *B, int64_t ldb, d
                            kps, (int)grid.x, 0);
 }
 
+// 64-row tiles, un-split (the ragged last round of a tall product with a short K: see the kernel)
+void launch_nt_dma64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int M, int N,
+                     int K, hipStream_t s) {
+    const int tiles_m = (M + 63) / 64, tiles_n = (N + BN - 1) / BN;
+    dim3 grid((unsigned)((int64_t)tiles_m * tiles_n), 1), block(256);
+    hipLaunchKernelGGL((gemm_nt_f64_dma_kernel<false, 64>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, tiles_n,
+                       K / DK, (int)grid.x, 0);
+}
+
 // whole rounds of un-split tiles + K-slices of the ragged last round's tiles in ONE launch (see the kernel)
 void launch_nt_dma_fused(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int M, int N,
                          int K, int main_panels, int nsplit, hipStream_t s) {
@@ -799,9 +829,15 @@ extern "C" int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int
             return (int)hipGetLastError();
         }
         if (main_panels > 0) launch_nt_dma(A, lda, B, ldb, C, ldc, (int)(main_panels * 128), (int)N, (int)K, 1, s);
-        if (rest_rows > 0)
-            launch_nt_dma(A + main_panels * 128 * lda, lda, B, ldb, C + main_panels * 128 * ldc, ldc, (int)rest_rows,
-                          (int)N, (int)K, (int)nsplit, s);
+        if (rest_rows > 0) {
+            const int64_t rest_tiles = (panels - main_panels) * tiles_n;
+            if (nsplit == 1 && main_panels > 0 && rest_tiles * 4 >= slots && rest_tiles * 10 < (int64_t)slots * 7)
+                launch_nt_dma64(A + main_panels * 128 * lda, lda, B, ldb, C + main_panels * 128 * ldc, ldc, (int)rest_rows,
+                                (int)N, (int)K, s);
+            else
+                launch_nt_dma(A + main_panels * 128 * lda, lda, B, ldb, C + main_panels * 128 * ldc, ldc, (int)rest_rows,
+                              (int)N, (int)K, (int)nsplit, s);
+        }
         return (int)hipGetLastError();
     }
     // register-staged kernels: any alignment, any K; small tiles for small problems

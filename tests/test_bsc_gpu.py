@@ -76,6 +76,22 @@ def test_gemm_nt_small_matches_numpy_and_is_deterministic(dev, M, N, K):
         np.testing.assert_allclose(G, A @ A.T, rtol=1e-12, atol=1e-12 * np.abs(A @ A.T).max())
 
 
+@pytest.mark.parametrize("M,N,K", [(100000, 128, 256), (70000, 256, 64), (65536 + 64 * 150 + 7, 128, 256)])
+def test_gemm_nt_ragged_last_round_in_64_row_tiles(dev, M, N, K):
+    """pm_gemm_nt_f64 on tall products whose last round of 128-row tiles would fill a quarter to 70 % of the resident
+    slots and whose K is too short to split: that round runs in 64-row tiles (gemm_nt_f64_dma_kernel<false, 64>).  Rows
+    across the seam between the two launches and the ragged end against torch."""
+    from prosper_amd import _lib
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    a = torch.randn(M, K, generator=g, device=dev, dtype=torch.float64)
+    b = torch.randn(N, K, generator=g, device=dev, dtype=torch.float64)
+    c = torch.full((M, N), float("nan"), dtype=torch.float64, device=dev)
+    _lib.call("pm_gemm_nt_f64", _p(a), K, _p(b), K, _p(c), N, M, N, K, _stream())
+    ref = a @ b.t()
+    err = float((c - ref).abs().max())
+    assert err <= 1e-11 * float(ref.abs().max()), err
+
+
 def test_gemm_nt_layout_asymmetric(dev):
     """A = I against an asymmetric B catches a swapped row/column map of the MFMA tile."""
     from prosper_amd import _lib
