@@ -41,13 +41,14 @@ __device__ __forceinline__ void wave_sync_lds() {
 // sim[n,h] = sum_d max(W[h,d] - Y[n,d], 0): 64 x 64 output tile per 256-thread workgroup, 4 x 4 per
 // thread, D walked in 16-column slabs through LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int ST = 64, SK = 16, SLD = SK + 1;
+constexpr int ST = 64, SK = 16, SLD = SK + 2;      // rows of 18 doubles: 16-byte aligned pairs, conflict-free ds_read_b128
 
 __global__ __launch_bounds__(256) void mca_select_scores_kernel(const double *__restrict__ Y, int64_t ldy,
                                                                  const double *__restrict__ W, int64_t ldw,
                                                                  double *__restrict__ R, int64_t ldr, int64_t N,
                                                                  int H, int D, int tiles_h) {
-    __shared__ double sy[ST * SLD], sw[ST * SLD];
+    __shared__ __attribute__((aligned(16))) double sy[ST * SLD], sw[ST * SLD];
+    typedef double d2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
     const int64_t n0 = (int64_t)(blockIdx.x / tiles_h) * ST;
     const int h0 = (blockIdx.x % tiles_h) * ST;
@@ -58,28 +59,44 @@ __global__ __launch_bounds__(256) void mca_select_scores_kernel(const double *__
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
 
-    for (int k0 = 0; k0 < D; k0 += SK) {
-        // stage: 64 rows x 16 columns of Y and of W, 4 elements per thread each
+    // slab k0 + SK is requested into registers BEFORE slab k0 is used: with the load -> LDS -> barrier -> compute sequence of
+    // the first version every workgroup sat out a memory round trip per slab (0.41 ms at config 5 whatever the inner loop
+    // issued: two instructions per (n, h, d) instead of three, wider LDS reads -- nothing moved it)
+    double ny[4], nw[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + 256 * e, r = idx >> 4, c = idx & 15;
             const int64_t n = n0 + r;
-            sy[r * SLD + c] = (n < N && k0 + c < D) ? Y[n * ldy + k0 + c] : 0.0;
-            // padding columns: W = -inf side (contributes max(.,0) = 0) -> use y = 0, w = 0
-            sw[r * SLD + c] = (h0 + r < H && k0 + c < D) ? W[(int64_t)(h0 + r) * ldw + k0 + c] : 0.0;
+            ny[e] = (n < N && k0 + c < D) ? Y[n * ldy + k0 + c] : 0.0;
+            // padding columns: y = 0, w = 0 contribute max(0 - 0, 0) = 0
+            nw[e] = (h0 + r < H && k0 + c < D) ? W[(int64_t)(h0 + r) * ldw + k0 + c] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < D; k0 += SK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e, r = idx >> 4, c = idx & 15;
+            sy[r * SLD + c] = ny[e];
+            sw[r * SLD + c] = nw[e];
         }
         __syncthreads();
+        if (k0 + SK < D) fetch(k0 + SK);
 #pragma unroll
-        for (int k = 0; k < SK; ++k) {
-            double yv[4], wv[4];
+        for (int k = 0; k < SK; k += 2) {
+            d2 yv[4], wv[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) yv[a] = sy[(tr + 16 * a) * SLD + k];
+            for (int a = 0; a < 4; ++a) yv[a] = *reinterpret_cast<const d2 *>(&sy[(tr + 16 * a) * SLD + k]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) wv[b] = sw[(tc + 16 * b) * SLD + k];
+            for (int b = 0; b < 4; ++b) wv[b] = *reinterpret_cast<const d2 *>(&sw[(tc + 16 * b) * SLD + k]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] += fmax(wv[b] - yv[a], 0.0);
+                for (int b = 0; b < 4; ++b) {
+                    acc[a][b] += fmax(wv[b].x - yv[a].x, 0.0);
+                    acc[a][b] += fmax(wv[b].y - yv[a].y, 0.0);
+                }
         }
         __syncthreads();
     }
