@@ -2,7 +2,7 @@
 //
 //   mca_select_scores_kernel   sim[n,h] = sum_d max(W_hd - y_d, 0)        (mca_et.py:104-106)
 //                              a register-tiled N x H x D max-plus contraction: no MFMA form exists,
-//                              the bound is the f64 VALU (3 ops per (n,h,d))
+//                              the bound is the f64 VALU (2 ops per (n,h,d) as sum max(W, y) - sum y)
 //   mca_estep_kernel           log-pseudo-joints (mca_et.py:142-175): singletons from the scores GEMM
 //                              (Gram identity), multi-cause states from
 //                              Wbar_sd = (sum_{j in s} W_{c_j d}^rho)^(1/rho) -- one f64 log+exp per
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void mca_select_scores_kernel(const double *__
     const int64_t n0 = (int64_t)(blockIdx.x / tiles_h) * ST;
     const int h0 = (blockIdx.x % tiles_h) * ST;
     const int tr = tid >> 4, tc = tid & 15;  // thread tile: rows tr + 16 a, cols tc + 16 b
-    double acc[4][4];
+    double acc[4][4], ysum[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -94,9 +94,27 @@ __global__ __launch_bounds__(256) void mca_select_scores_kernel(const double *__
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
+#ifndef PM_MCA_SEL3
+                    // sum_d max(W - y, 0) = sum_d max(W, y) - sum_d y: two f64 instructions per (n, h, d) instead of three
+                    // (one raw v_max_f64 -- fmax() canonicalises operands it cannot prove quiet -- and one add; the row
+                    // sums of y ride along, one add per datapoint and d): 0.343 -> 0.283 ms at config 5 once the slabs are
+                    // prefetched (before that the pass was latency-bound and this form measured no faster).  The difference
+                    // of two sums of ~500 rounds at ~1e-13 absolute; the ranking it feeds separates candidates by O(1).
+                    // -DPM_MCA_SEL3 builds the three-instruction form.
+                    double m0, m1;
+                    asm("v_max_f64 %0, %1, %2" : "=v"(m0) : "v"(wv[b].x), "v"(yv[a].x));
+                    asm("v_max_f64 %0, %1, %2" : "=v"(m1) : "v"(wv[b].y), "v"(yv[a].y));
+                    acc[a][b] += m0;
+                    acc[a][b] += m1;
+#else
                     acc[a][b] += fmax(wv[b].x - yv[a].x, 0.0);
                     acc[a][b] += fmax(wv[b].y - yv[a].y, 0.0);
+#endif
                 }
+#ifndef PM_MCA_SEL3
+#pragma unroll
+            for (int a = 0; a < 4; ++a) ysum[a] += yv[a].x + yv[a].y;
+#endif
         }
         __syncthreads();
     }
@@ -107,7 +125,12 @@ __global__ __launch_bounds__(256) void mca_select_scores_kernel(const double *__
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int h = h0 + tc + 16 * b;
+#ifndef PM_MCA_SEL3
+            if (h < H) R[n * ldr + h] = acc[a][b] - ysum[a];
+#else
+            (void)ysum;
             if (h < H) R[n * ldr + h] = acc[a][b];
+#endif
         }
     }
 }

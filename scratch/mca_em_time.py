@@ -2,8 +2,12 @@
 ground truth for 0.5 s, then the timed iterations and the per-kernel times -- the state the bench line reports (the
 posteriors of converged parameters skip fewer terms than those of the starting point, which scratch/mca_kernel_time.py
 times).  PYTHONPATH=. python scratch/mca_em_time.py"""
+import os
 import time
 import torch
+from prosper_amd import _lib
+if os.environ.get('PM_LIB_PATH'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['PM_LIB_PATH'])
 from prosper_amd.em.camodels.bsc_et import KernelTimer
 from prosper_amd.em.camodels.mca_et import MCA_ET
 
