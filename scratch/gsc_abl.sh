@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
   mkdir -p scratch/libs
   FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Iinclude -Iprosper_amd/csrc"
-  for a in 1 2 4 8 16 32 64 127; do
+  for a in ${2:-1 2 4 8 16 32 64 128}; do
     /opt/rocm/bin/hipcc $FL -DPM_GSC_ABL=$a -c prosper_amd/csrc/gsc_kernels.hip -o /tmp/gsc_abl$a.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/libs/libgabl$a.so $(ls prosper_amd/csrc/build/*.o | grep -v gsc_kernels.o) /tmp/gsc_abl$a.o &
   done

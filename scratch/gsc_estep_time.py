@@ -32,7 +32,8 @@ if sys.argv[1:] == ["save"]:
     res = m._resident(Y)
     csz = None
     out = m.E_step(An(T=1.0), p, m.select_Hprimes(p, {"y": Y}))
-    np.savez(f, csz_min=float(out['_sums'][1].abs().min()), **p)
+    dmin = min(float(out['_sums'][0].abs().min()), float(out['xpt_szsz'].sum(axis=0).diagonal().abs().min()))
+    np.savez(f, csz_min=float(out['_sums'][1].abs().min()), diag_min=dmin, **p)
     sys.exit(0)
 z = np.load(f)
 p = {k: z[k] for k in ("W", "pi", "mu", "psi_sq")}
@@ -44,17 +45,24 @@ tdev = torch.zeros(9 * Hm, dtype=torch.float64, device=dev)
 tdev[:8 * Hm] = par["tables"].reshape(-1)[:8 * Hm]
 tdev[8 * Hm] = 1.0 / par["s2"]
 tdev[8 * Hm + 1] = float(z["csz_min"]) * 2.0 ** -75
+if os.environ.get("PAIR_THR", "1") == "1":
+    tdev[8 * Hm + 2] = float(z["diag_min"]) * 2.0 ** -75
 lists = os.environ.get("LISTS", "1") == "1"
+fuse = os.environ.get("FUSE", "0") == "1"
+if fuse:
+    _A, A = A, None
+kw = {"Wst": par["Wst"]} if fuse else {}
 for _ in range(30):
-    out = m._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], tdev, 0.0, 1.0, None, lists=lists)
+    out = m._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], tdev, 0.0, 1.0, None, lists=lists, **kw)
 torch.cuda.synchronize()
 best = 1e9
 for _ in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        out = m._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], tdev, 0.0, 1.0, None, lists=lists)
+        out = m._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], tdev, 0.0, 1.0, None, lists=lists, **kw)
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 20)
 L = getattr(out[3], "_pm_lists", None)
+print("fuse %d " % fuse, end="")
 print("estep call %.4f ms (incl. stats zero fill + fold launch)  dense rows %s" % (best, int(L[3].item()) if L else None))

@@ -24,6 +24,8 @@
 #include "prosper_hip.h"
 #include "pm_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int ROWS = 16;
@@ -149,7 +151,7 @@ struct GscTables {
 #ifndef PM_GSC_ABL
 #define PM_GSC_ABL 0      // timing-only ablation builds (scratch/gsc_abl.sh): bits switch phases off, results are wrong
 #endif
-// -DPM_GSC_STAMPS (scratch/gsc_stamps.py, never in the shipped library): wavefront 0 of every 37th workgroup writes s_memrealtime
+// -DPM_GSC_STAMPS (scratch/gsc_stamps.sh, never in the shipped library): wavefront 0 of every 37th workgroup writes s_memrealtime
 // (100 MHz) at the phase boundaries of its first datapoints into pm_gsc_stamps[workgroup / 37][datapoint][phase]
 #ifdef PM_GSC_STAMPS
 __device__ unsigned long long pm_gsc_stamps[32][12][10];
@@ -172,9 +174,134 @@ __device__ unsigned long long pm_gsc_stamps[32][12][10];
 // xpt_sz of the previous EM step (pm_gsc_mstep_finish_f64) -- what a list drops from a column of the product is below
 // N thr max|left operand| <= 2^-57 of that column's own scale for N <= 2^18 (2^-52: N = 8 M), under the rounding of the sums
 // themselves; thr = 0 (first step, a dead latent's column) keeps everything: every row is dense then, correct and slow.
+// FUSE: the scores a = (Sigma^-1 W)^T y are formed INSIDE the E-step kernel (f64 MFMA 16x16x4) instead of by a GEMM launch in
+// front of it: the launch with its own ramp and tail (0.23 ms of a 1.26 ms EM iteration at config 4) is gone, and its matrix
+// instructions run in the issue slots the latency-bound pass leaves empty (a SIMD issues in under half of its cycles, DESIGN.md
+// 4.5).  A workgroup walks BLOCKS of 64 datapoints: wavefront w accumulates datapoints 16 w .. 16 w + 15 against all 128 latents
+// (64 accumulator registers, dead again before the passes start), operands streamed through a two-stage LDS-DMA ring of
+// [64 datapoint rows | 128 latent rows] x 8 columns (12 KB a stage) that ALIASES the per-datapoint arrays of the pass (idle during
+// the block's GEMM; the deferred pair atomics are sent first) -- per datapoint 2 KB of Y and 4 KB of W cross from L2, against
+// 24 KB when every 16-row group pulled W through the vector cache (the first version of this: 1.09 ms against 0.63 + 0.23).  The
+// block's scores go to the caller's N x H scratch (each wavefront its own sixteen rows) and the four passes over it read them back
+// from L2, prefetching as before.  What does not fill whole rounds of 64-row blocks runs as 16-row MINI blocks (wavefront w: two
+// of the eight latent tiles), so that the ragged end of the shard costs one pass, not four.
+struct GscFuse {
+    const double *Y;       // (N, ldy) datapoints
+    int64_t ldy;
+    const double *Wt;      // (H, ldw) = W^T, or (Sigma^-1 W)^T for a diagonal / full noise covariance; H = 128
+    int64_t ldw;
+    int D;                 // a multiple of 8
+    double *scratch;       // (N, lds) scores, written then read by the same workgroup
+    int64_t nb64;          // 64-row blocks (rows [0, 64 nb64)); 16-row mini blocks cover the rest
+};
+typedef double gd2 __attribute__((ext_vector_type(2)));
+typedef double gd4 __attribute__((ext_vector_type(4)));
+constexpr int GF_DK = 8, GF_YROWS = 64, GF_STAGE = (GF_YROWS + 128) * GF_DK;     // doubles per ring stage (12 KB)
+constexpr int GF_RING_BYTES = 2 * GF_STAGE * 8;
+
+// acc of lane (m, kk) = (lane & 15, lane >> 4), tile t, entry i: datapoint r0 + arow0 + kk + 4 i, latent 16 t + m.
+// A stage is [rows][8 doubles]; pair p (16 B) of row R sits in slot p ^ PI(R >> 2), PI = {0, 3, 2, 1} (bsc_fused8.hip: every
+// group of 16 lanes of a ds_read_b128 then falls into 16 different bank quads).
+// (Not inlined on purpose: the pass around it keeps ~100 registers of per-lane state live across its datapoints; as a call, that
+// state is saved once per block at the boundary instead of squeezing the 64 accumulators out of the K-loop.)
+__device__ __forceinline__ uint64_t g_uni64(uint64_t v) {      // a wavefront-uniform value back in scalar registers
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+#ifdef PM_GSC_BLOCK_NOINLINE       // (a call here lost the pass behind it on the GPU: wrong results, not pursued)
+#define PM_GSC_BLOCK_ATTR __attribute__((noinline))
+#else
+#define PM_GSC_BLOCK_ATTR __forceinline__
+#endif
+__device__ PM_GSC_BLOCK_ATTR void gsc_scores_block(const GscFuse &Fin, double *ring, int64_t lds_, int64_t r0_, int64_t N_,
+                                                            bool full_) {
+    // (arguments of a device function arrive in vector registers: everything uniform goes back to scalar ones)
+    GscFuse F;
+    F.Y = reinterpret_cast<const double *>(g_uni64((uint64_t)Fin.Y));
+    F.ldy = (int64_t)g_uni64((uint64_t)Fin.ldy);
+    F.Wt = reinterpret_cast<const double *>(g_uni64((uint64_t)Fin.Wt));
+    F.ldw = (int64_t)g_uni64((uint64_t)Fin.ldw);
+    F.D = __builtin_amdgcn_readfirstlane(Fin.D);
+    F.scratch = reinterpret_cast<double *>(g_uni64((uint64_t)Fin.scratch));
+    const int64_t lds = (int64_t)g_uni64((uint64_t)lds_), r0 = (int64_t)g_uni64((uint64_t)r0_), N = (int64_t)g_uni64((uint64_t)N_);
+    const bool full = __builtin_amdgcn_readfirstlane((int)full_) != 0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    gd4 acc[8];
+    const int dr = lane >> 2, dj = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+    const int arow0 = full ? 16 * wave : 0;
+    const unsigned tmask = full ? 0xFFu : (3u << (2 * wave));
+    const char *ybase, *wbase;
+    uint32_t yoff, woff;
+    {
+        int64_t ya = r0 + arow0;
+        ya = ya < N ? ya : N - 1;
+        int64_t yr = r0 + arow0 + dr;
+        yr = yr < N ? yr : N - 1;
+        ybase = reinterpret_cast<const char *>(F.Y + ya * F.ldy);
+        yoff = (uint32_t)((yr - ya) * F.ldy * 8 + 16 * dj);
+        wbase = reinterpret_cast<const char *>(F.Wt + (int64_t)(32 * wave) * F.ldw);
+        woff = (uint32_t)((int64_t)dr * F.ldw * 8 + 16 * dj);
+    }
+    const int64_t w16 = 16 * F.ldw * 8;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) double *)(ring));
+    auto dma1 = [&](unsigned dst, uint32_t voff, const char *base) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(base)
+                     : "memory");
+    };
+    const bool move_y = full || wave == 0;
+    auto dma = [&](int kt, int stage) {
+        const unsigned dst = lds0 + (unsigned)stage * (unsigned)(GF_STAGE * 8);
+        const int64_t k0 = (int64_t)kt * (GF_DK * 8);
+        if (move_y) dma1(dst + (unsigned)arow0 * 64u, yoff, ybase + k0);
+        dma1(dst + (unsigned)(GF_YROWS + 32 * wave) * 64u, woff, wbase + k0);
+        dma1(dst + (unsigned)(GF_YROWS + 32 * wave + 16) * 64u, woff, wbase + w16 + k0);
+    };
+    const int frow = lane & 15, fk = lane >> 4;
+    const int sw = (4 - (frow >> 2)) & 3;
+    const int a_off = (arow0 + frow) * GF_DK + ((fk ^ sw) << 1);
+    const int b_off = (GF_YROWS + frow) * GF_DK + ((fk ^ sw) << 1);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = gd4{0.0, 0.0, 0.0, 0.0};
+    const int nk = F.D / GF_DK;
+    dma(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // my share of step kt has landed; after the barrier everybody's has, and everybody is done reading the other stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
+        typedef __attribute__((address_space(3))) const gd2 *lds_gd2;     // (ds_read_b128, not a flat load)
+        const __attribute__((address_space(3))) double *st = (const __attribute__((address_space(3))) double *)ring + (kt & 1) * GF_STAGE;
+        const gd2 fa = *(lds_gd2)(st + a_off);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            gd2 fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb[t] = *(lds_gd2)(st + b_off + (4 * g + t) * 16 * GF_DK);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if ((tmask >> (4 * g + t)) & 1u)
+                    acc[4 * g + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.x, fb[t].x, acc[4 * g + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if ((tmask >> (4 * g + t)) & 1u)
+                    acc[4 * g + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.y, fb[t].y, acc[4 * g + t], 0, 0, 0);
+        }
+    }
+    const int j = lane & 15, row = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if ((tmask >> t) & 1u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t nr = r0 + arow0 + row + 4 * i;
+                if (nr < N) ((__attribute__((address_space(1))) double *)F.scratch)[nr * lds + 16 * t + j] = acc[t][i];
+            }
+        }
+}
+
 constexpr int GSC_DENSE_CAP = 512;          // datapoints per workgroup in LIST mode at most (the launcher sizes the grid)
-template <int VPL, int GMAX, bool LPJ, bool LACC, bool LIST = false>
-__global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void gsc_estep_kernel(const double *__restrict__ scores, int64_t lds,
+template <int VPL, int GMAX, bool LPJ, bool LACC, bool LIST = false, bool FUSE = false>
+__global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void gsc_estep_kernel(const double *__restrict__ scores_in, int64_t lds,
                                                          const double *__restrict__ gram,
                                                          const double *__restrict__ psi,
                                                          const double *__restrict__ ynorm2, GscTables T,
@@ -185,8 +312,10 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                                                          double *__restrict__ stats, double *__restrict__ logpj,
                                                          int64_t ldl, uint16_t *__restrict__ nz_idx,
                                                          double *__restrict__ nz_val, int32_t *__restrict__ dense_rows,
-                                                         int32_t *__restrict__ dense_count) {
+                                                         int32_t *__restrict__ dense_count, GscFuse F) {
     static_assert(!LIST || (LACC && !LPJ), "lists ride on the statistics form of the kernel");
+    static_assert(!FUSE || (LACC && !LPJ && VPL == 8), "the fused scores block: statistics form, H = 128");
+    const double *scores = FUSE ? F.scratch : scores_in;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_ndense, s_dbase;
     __shared__ int32_t s_dense[LIST ? GSC_DENSE_CAP : 1];
@@ -210,12 +339,14 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     }
     // the state masks sit in LDS behind the per-datapoint arrays: the multi-cause loop then issues no
     // vector-memory operation at all (see the deferred pair atomics below)
-    uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_dp + ROWS * dp_stride);
+    // (FUSE: the per-datapoint arrays double as the operand ring of the scores blocks -- at least that large)
+    const int dp_region = (FUSE && ROWS * dp_stride < 2 * GF_STAGE) ? 2 * GF_STAGE : ROWS * dp_stride;
+    uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_dp + dp_region);
     for (int s = tid; s < S; s += 256) s_masks[s] = masks[s];
     // LACC: [3][4 wavefronts][H] accumulators (column sums of xpt_s, of xpt_sz, the singletons' diagonal of sum xpt_szsz) behind the masks (8-byte aligned); the four datapoint rows of a wavefront add
     // into the same slots (LDS atomics, 4-way same-address: 16 instructions per four datapoints, nothing beside the
     // ~3300 the rest of them costs) -- per-row private slots cost 32 KB and the third workgroup per CU
-    double *s_acc = reinterpret_cast<double *>(smem + ((8 * (size_t)(8 * H + ROWS * dp_stride) + 2 * (size_t)S + 7) & ~(size_t)7));
+    double *s_acc = reinterpret_cast<double *>(smem + ((8 * (size_t)(8 * H + dp_region) + 2 * (size_t)S + 7) & ~(size_t)7));
     if (LACC)
         for (int e = tid; e < 3 * 4 * H; e += 256) s_acc[e] = 0.0;
     double *acc_mine = s_acc + (size_t)wave * H + j;                    // + 16 i: latent j + 16 i; + 4 * H: next quantity
@@ -249,14 +380,6 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     int myc_prev = 0;
     double nf_prev = 0.0;
     bool pend = false;
-    // Entries of a datapoint's blocks below thr_p are not sent.  The pass is bound by its vector-memory traffic, and the sixty
-    // f64 atomics per datapoint are the largest single item of it (a build without them runs 0.09 ms of 0.63 faster at config
-    // 4); most datapoints put all their weight on one or two states, so that all but a few entries of their blocks are
-    // ~1e-20 of the others.  thr_p = 2^-75 of the smallest diagonal entry of the PREVIOUS EM step's all-reduced sums (tables[8 H
-    // + 2], pm_gsc_mstep_finish_f64; 0 -- everything is sent -- when the tables come from the host): what is dropped from any
-    // entry of sum xpt_ss / sum xpt_szsz stays below N thr_p <= 2^-57 of the smallest diagonal entry for N <= 2^18, under the
-    // rounding of the diagonal sums themselves -- nothing the inverses, the element-wise psi_sq update or sigma_sq can see.
-    const double thr_p = (inv_s2_host != 0.0 || H <= 2) ? 0.0 : T.c0[8 * (int64_t)H + 2];
 
     // previous datapoint's blocks -> global sums (xpt_ss: upper triangle, mirrored by the host; candidates are sorted by
     // index, so ci <= ck for i <= k); accumulators cleared for the next one
@@ -271,9 +394,8 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 if (pend && !(PM_GSC_ABL & 16)) {
                     // xpt_ss is symmetric: upper triangle only; xpt_szsz = kappa kappa^T + Lambda^-1 is NOT once psi_sq has
                     // been through an M-step (gsc_et.py:660-675 leaves it non-symmetric): both triangles, as they are
-                    const double vss = s_ass[p] * nf_prev, vzz = s_aszsz[p] * nf_prev;
-                    if (k >= i && vss > thr_p) pm_atomic_add(g_ss + (int64_t)ci * H + ck, vss);
-                    if (__builtin_fabs(vzz) > thr_p) pm_atomic_add(g_szsz + (int64_t)ci * H + ck, vzz);
+                    if (k >= i) pm_atomic_add(g_ss + (int64_t)ci * H + ck, s_ass[p] * nf_prev);
+                    pm_atomic_add(g_szsz + (int64_t)ci * H + ck, s_aszsz[p] * nf_prev);
                 }
                 if (clear) {
                     s_ass[p] = 0.0;
@@ -290,24 +412,22 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     // wave cycles; a build without the stores ran 0.07 ms faster).
     double apre[VPL];
     double yn_pre = 0.0;
-    auto prefetch = [&](int64_t g) {
-        const int64_t n = g * ROWS + wave * 4 + row;
-        const int64_t nn = (g < groups && n < N) ? n : N - 1;
+    auto prefetch = [&](int64_t n) {
+        const int64_t nn = (n < N) ? n : N - 1;
         const double *ar = scores + nn * lds;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) apre[i] = (j + 16 * i < H) ? ar[j + 16 * i] : 0.0;
         yn_pre = ynorm2[nn];
     };
+    // one datapoint per 16-lane row: n; n_next: the datapoint this row takes up next (its scores row is requested early)
     int stamp_dp = 0;
     (void)stamp_dp;
-    prefetch(blockIdx.x);
-    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const int64_t n = grp * ROWS + wave * 4 + row;
+    auto body = [&](const int64_t n, const int64_t n_next) {
         const bool live = n < N;
+        GSC_STAMP(0);
         const int64_t nn = live ? n : N - 1;
         const double *arow = scores + nn * lds;
         const double yn = yn_pre;
-        GSC_STAMP(0);
 
         // ---- candidates: top-H' scores, then sorted by latent index (gsc_et.py:726-728)
         int myc = 0;
@@ -363,9 +483,9 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             if (j < Hp) myc = cand[nn * Hp + j];
         }
 
+        GSC_STAMP(1);
         // ---- candidate blocks -> LDS, accumulators cleared.  Candidate k of this datapoint sits in lane
         // rowbase + k: ds_bpermute fetches it (uniform trip counts: every source lane stays active)
-        GSC_STAMP(1);
         if (j < Hp) {
             s_ac[j] = arow[myc];
             s_as[j] = 0.0;
@@ -378,8 +498,8 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             const int ci = __builtin_amdgcn_ds_bpermute((rowbase + i) << 2, myc);
             const int ck = __builtin_amdgcn_ds_bpermute((rowbase + k) << 2, myc);
             if (ok) {
-                s_Gc[p] = (PM_GSC_ABL & 128) ? (ci == ck ? 250.0 : 1.0) : gram[(int64_t)ci * H + ck];
-                s_Pc[p] = (PM_GSC_ABL & 128) ? (ci == ck ? 1.1 : 0.0) : psi[(int64_t)ci * H + ck];
+                s_Gc[p] = gram[(int64_t)ci * H + ck];
+                s_Pc[p] = psi[(int64_t)ci * H + ck];
             }
         }
         // every load of this datapoint has landed before the atomics below are issued -- said explicitly, so that
@@ -534,7 +654,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 }
         }
         GSC_STAMP(6);
-        prefetch(grp + gridDim.x);                          // (ahead of the stores below: see `apre`; unconditional, so
+        prefetch(n_next);                                   // (ahead of the stores below: see `apre`; unconditional, so
                                                             // that the row is not carried across the loop when unused)
         unsigned long long sigb[LIST ? VPL : 1];            // ballots of "significant" per slot (scalar registers)
         int nsig = 0;
@@ -590,6 +710,40 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
 #ifdef PM_GSC_STAMPS
         ++stamp_dp;
 #endif
+    };
+    if constexpr (!FUSE) {
+        prefetch(blockIdx.x * ROWS + wave * 4 + row);
+        for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x)
+            body(grp * ROWS + wave * 4 + row, (grp + gridDim.x) * ROWS + wave * 4 + row);
+    } else {
+        // units: 64-row blocks [0, nb64), then 16-row mini blocks; unit u belongs to workgroup u mod gridDim.x
+        const int64_t mini0 = 64 * F.nb64;
+        const int64_t nunits = F.nb64 + (N - mini0 + ROWS - 1) / ROWS;
+        for (int64_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+            const bool full = u < F.nb64;
+            const int64_t r0 = full ? 64 * u : mini0 + ROWS * (u - F.nb64);
+            // the ring takes the place of the per-datapoint arrays: the last datapoint's pair blocks leave first
+            flush_pairs(true);
+            pend = false;
+            if (LIST) {     // (room for this unit's dense datapoints: a workgroup may walk more than GSC_DENSE_CAP of them)
+                __syncthreads();
+                const int nd = s_ndense;
+                if (nd > GSC_DENSE_CAP - 64) {
+                    if (tid == 0) s_dbase = atomicAdd(dense_count, nd);
+                    __syncthreads();
+                    for (int e = tid; e < nd; e += 256) dense_rows[s_dbase + e] = s_dense[e];
+                    __syncthreads();
+                    if (tid == 0) s_ndense = 0;
+                }
+            }
+            __syncthreads();
+            gsc_scores_block(F, s_dp, lds, r0, N, full);
+            __syncthreads();      // the ring is free again; every score of the unit is visible to the workgroup
+            const int rounds = full ? 4 : 1;
+            const int64_t base = full ? r0 + 16 * wave + row : r0 + 4 * wave + row;
+            prefetch(base);
+            for (int i = 0; i < rounds; ++i) body(base + 4 * i, (i + 1 < rounds) ? base + 4 * (i + 1) : base);
+        }
     }
     flush_pairs(false);
 
@@ -694,6 +848,11 @@ extern "C" int64_t pm_gsc_stats_len(int64_t H) { return 2 * H * H + 3 * H + (PM_
 static size_t gsc_shmem(int64_t H, int64_t Hprime, int64_t S) {
     return sizeof(double) * (8 * H + ROWS * (48 + 4 * Hprime * Hprime) + (S + 3) / 4);
 }
+// (FUSE: the operand ring of the scores blocks lies over the per-datapoint arrays; what it needs beyond them)
+static size_t gsc_ring_pad(int64_t Hprime) {
+    const size_t dp = sizeof(double) * ROWS * (48 + 4 * Hprime * Hprime);
+    return dp < (size_t)GF_RING_BYTES ? (size_t)GF_RING_BYTES - dp : 0;
+}
 // ... with the per-wavefront accumulators of the column sums behind it (LACC); used when three workgroups still fit a CU
 static size_t gsc_shmem_lacc(int64_t H, int64_t Hprime, int64_t S) {
     return gsc_shmem(H, Hprime, S) + sizeof(double) * (3 * 4 * H + 1);
@@ -791,16 +950,6 @@ __global__ __launch_bounds__(1024) void gsc_mstep_finish_kernel(
         __syncthreads();
     }
     if (tid == 0 && H > 1) tables[8 * H + 1] = ldexp(s_red[0], -75);
-    // tables[8 H + 2]: below this an entry of a datapoint's pair blocks is not sent (gsc_estep_kernel, thr_p): 2^-75 of the smallest
-    // diagonal entry of sum xpt_ss (= sum xpt_s) and sum xpt_szsz
-    __syncthreads();
-    s_red[tid] = tid < H ? fmin(fabs(sum_s[tid]), fabs(sum_zz[(int64_t)tid * H + tid])) : INFINITY;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (tid < w) s_red[tid] = fmin(s_red[tid], s_red[tid + w]);
-        __syncthreads();
-    }
-    if (tid == 0 && H > 2) tables[8 * H + 2] = ldexp(s_red[0], -75);
 }
 }  // namespace
 
@@ -823,17 +972,22 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
                             int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
                             int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
                             double *stats, double *logpj, int64_t ldl, void *stream, uint16_t *nz_idx = nullptr,
-                            double *nz_val = nullptr, int32_t *dense_rows = nullptr, int32_t *dense_count = nullptr) {
+                            double *nz_val = nullptr, int32_t *dense_rows = nullptr, int32_t *dense_count = nullptr,
+                            const GscFuse *fuse = nullptr) {
     if (N == 0) return PM_OK;
     if (logpj && ldl < 1 + H + S) return PM_EINVAL;
     if (!scores || !gram || !psi_sq || !ynorm2 || !tables || !cand || !xpt_s || !xpt_sz || !stats || N < 0 || H <= 0 ||
         Hprime <= 0 || S < 0 || lds < H || ldx < H || (S > 0 && !state_masks) || !(sigma_sq >= 0.0))
         return PM_EINVAL;
     if (!pm_gsc_supported(H, Hprime, gamma)) return PM_ERANGE;
+    if (fuse && (!fuse->Y || !fuse->Wt || fuse->D <= 0 || fuse->ldy < fuse->D || fuse->ldw < fuse->D || logpj)) return PM_EINVAL;
+    if (fuse && (((fuse->ldy | fuse->ldw) & 1) || ((uintptr_t)fuse->Y & 15) || ((uintptr_t)fuse->Wt & 15))) return PM_EINVAL;
+    GscFuse F = fuse ? *fuse : GscFuse{nullptr, 0, nullptr, 0, 0, nullptr, 0};
     GscTables T{tables, tables + H, tables + 2 * H, tables + 3 * H, tables + 4 * H, tables + 5 * H, tables + 6 * H,
                 tables + 7 * H};
-    const bool lacc = gsc_shmem_lacc(H, Hprime, S) <= 53 * 1024;
-    const size_t shmem = lacc ? gsc_shmem_lacc(H, Hprime, S) : gsc_shmem(H, Hprime, S);
+    const size_t ring_pad = fuse ? gsc_ring_pad(Hprime) : 0;
+    const bool lacc = gsc_shmem_lacc(H, Hprime, S) + ring_pad <= 53 * 1024;
+    const size_t shmem = (lacc ? gsc_shmem_lacc(H, Hprime, S) : gsc_shmem(H, Hprime, S)) + ring_pad;
     if (gsc_shmem(H, Hprime, S) > 64 * 1024) return PM_ERANGE;
     // ONE resident round of workgroups (three per CU for the tuned instantiations), each walking its share of the
     // datapoints: 2048 workgroups -- 2.7 rounds, the last one two thirds full, and 2048 table loads / accumulator flushes --
@@ -849,6 +1003,10 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         if (groups < need) groups = need;
         if (groups > INT32_MAX) return PM_ERANGE;
     }
+    if (fuse) {     // whole rounds of 64-row blocks; a last round at least half full stays one, anything else runs as mini blocks
+        const int64_t B = N / 64, rounds = B / groups, r64 = B - rounds * groups;
+        F.nb64 = (2 * r64 >= groups) ? B : rounds * groups;
+    }
     dim3 grid((unsigned)groups), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double inv_s2 = sigma_sq > 0.0 ? 1.0 / sigma_sq : 0.0;   // 0: tables[8 H] holds it (pm_gsc_mstep_finish_f64)
@@ -857,7 +1015,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, L, A>), shmem)) return e;       \
         hipLaunchKernelGGL((gsc_estep_kernel<V, G, L, A>), grid, block, shmem, s, scores, lds, gram, psi_sq, ynorm2, T, \
                            state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select, cand, xpt_s, xpt_sz,  \
-                           ldx, stats, logpj, ldl, nullptr, nullptr, nullptr, nullptr);                                \
+                           ldx, stats, logpj, ldl, nullptr, nullptr, nullptr, nullptr, F);                             \
     } while (0)
 #define PM_LAUNCH_LIST(V, G)                                                                                           \
     do {                                                                                                               \
@@ -865,7 +1023,15 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
             return e;                                                                                                  \
         hipLaunchKernelGGL((gsc_estep_kernel<V, G, false, true, true>), grid, block, shmem, s, scores, lds, gram,      \
                            psi_sq, ynorm2, T, state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select,    \
-                           cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, nz_idx, nz_val, dense_rows, dense_count);      \
+                           cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, nz_idx, nz_val, dense_rows, dense_count, F);   \
+    } while (0)
+#define PM_LAUNCH_FUSE(V, G, LI)                                                                                        \
+    do {                                                                                                               \
+        if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, false, true, LI, true>), shmem)) \
+            return e;                                                                                                  \
+        hipLaunchKernelGGL((gsc_estep_kernel<V, G, false, true, LI, true>), grid, block, shmem, s, scores, lds, gram,  \
+                           psi_sq, ynorm2, T, state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select,    \
+                           cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, nz_idx, nz_val, dense_rows, dense_count, F);   \
     } while (0)
 #define PM_LAUNCH(V, G)                         \
     do {                                        \
@@ -885,7 +1051,11 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         else if (gamma <= 6) PM_LAUNCH(V, 6); \
         else PM_LAUNCH(V, 8);                 \
     } while (0)
-    if (nz_idx) {
+    if (fuse) {
+        if (!lacc || gamma > 3 || H != 128 || fuse->D % GF_DK) return PM_ERANGE;
+        if (nz_idx) { if (gamma <= 2) PM_LAUNCH_FUSE(8, 2, true); else PM_LAUNCH_FUSE(8, 3, true); }
+        else { if (gamma <= 2) PM_LAUNCH_FUSE(8, 2, false); else PM_LAUNCH_FUSE(8, 3, false); }
+    } else if (nz_idx) {
         if (H <= 128) {
             if (gamma <= 2) PM_LAUNCH_LIST(8, 2);
             else PM_LAUNCH_LIST(8, 3);
@@ -903,6 +1073,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
 #undef PM_LAUNCH
 #undef PM_LAUNCH_LA
 #undef PM_LAUNCH_LIST
+#undef PM_LAUNCH_FUSE
     {
         const int64_t rows_per_block = 512;
         const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
@@ -982,6 +1153,34 @@ extern "C" int pm_gsc_estep_lists_f64(const double *scores, int64_t lds, const d
     return gsc_estep_launch(scores, lds, gram, psi_sq, ynorm2, tables, state_masks, S, gamma, beta, sigma_sq, N, H, Hprime,
                             do_select, cand, xpt_s, xpt_sz, ldx, stats, nullptr, 0, stream, nz_idx, nz_val, dense_rows,
                             dense_count);
+}
+
+// The same pass with the scores formed inside it (gsc_estep_kernel, FUSE): no N x H GEMM launch in front of the E-step.
+// `scratch` (N x lds) receives the scores (each workgroup reads its own rows back); nz_idx == NULL: no lists.
+extern "C" int pm_gsc_fused_supported(int64_t H, int64_t Hprime, int64_t gamma, int64_t D) {
+    if (!pm_gsc_supported(H, Hprime, gamma) || gamma > 3 || H != 128 || D <= 0 || D % GF_DK) return 0;
+    int64_t S = 0, c = Hprime;
+    for (int64_t g = 2; g <= gamma && g <= Hprime; ++g) {
+        c = c * (Hprime - g + 1) / g;
+        S += c;
+    }
+    return gsc_shmem_lacc(H, Hprime, S) + gsc_ring_pad(Hprime) <= 53 * 1024 ? 1 : 0;
+}
+
+extern "C" int pm_gsc_estep_fused_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, int64_t D, double *scratch,
+                                      int64_t lds, const double *gram, const double *psi_sq, const double *ynorm2,
+                                      const double *tables, const uint16_t *state_masks, int64_t S, int64_t gamma,
+                                      double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime, int do_select,
+                                      int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx, double *stats,
+                                      uint16_t *nz_idx, double *nz_val, int32_t *dense_rows, int32_t *dense_count,
+                                      void *stream) {
+    if (!Y || !Wt || !scratch || D <= 0 || D > INT32_MAX) return PM_EINVAL;
+    if (nz_idx && (!nz_val || !dense_rows || !dense_count)) return PM_EINVAL;
+    if (!pm_gsc_fused_supported(H, Hprime, gamma, D)) return PM_ERANGE;
+    const GscFuse F{Y, ldy, Wt, ldw, (int)D, scratch, 0};
+    return gsc_estep_launch(scratch, lds, gram, psi_sq, ynorm2, tables, state_masks, S, gamma, beta, sigma_sq, N, H, Hprime,
+                            do_select, cand, xpt_s, xpt_sz, ldx, stats, nullptr, 0, stream, nz_idx, nz_val, dense_rows,
+                            dense_count, &F);
 }
 
 extern "C" int pm_gsc_estep_lpj_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,

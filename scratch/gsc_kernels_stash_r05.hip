@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "prosper_hip.h"
 #include "pm_common.h"
@@ -172,8 +173,18 @@ __device__ unsigned long long pm_gsc_stamps[32][12][10];
 // xpt_sz of the previous EM step (pm_gsc_mstep_finish_f64) -- what a list drops from a column of the product is below
 // N thr max|left operand| <= 2^-57 of that column's own scale for N <= 2^18 (2^-52: N = 8 M), under the rounding of the sums
 // themselves; thr = 0 (first step, a dead latent's column) keeps everything: every row is dense then, correct and slow.
+// STASH (with LACC): the scores row of a datapoint is parked in LDS when it arrives and every later phase reads it there.  A
+// timeline of the pass (-DPM_GSC_STAMPS, config 4) showed 36.6 us per datapoint of which the singleton and the expectation
+// phase took 8.1 and 7.8 -- a few hundred instructions each: both re-read the row from L2 / the vector cache, and a load cannot
+// be waited for ahead of the sixty pair atomics and eighteen stores issued before it (s_waitcnt vmcnt counts in issue order);
+// another 3.6 us went to the candidates' gathers behind the candidate store.  The 16 KB of rows (H = 128) fit beside three
+// workgroups per CU once the column-sum accumulators are two copies instead of four, the candidate slots of the per-datapoint
+// arrays 8 instead of 16 wide, the dense-row list 256 entries, and two of the eight tables (c1, 1 / lam) are formed from the
+// others.  Row r of a wavefront swaps its 16-latent blocks pairwise when r is odd, so that the two rows a ds_write_b64 / ds_read_b64
+// serves together fall into different banks.
 constexpr int GSC_DENSE_CAP = 512;          // datapoints per workgroup in LIST mode at most (the launcher sizes the grid)
-template <int VPL, int GMAX, bool LPJ, bool LACC, bool LIST = false>
+constexpr int GSC_DENSE_CAP_STASH = 256;
+template <int VPL, int GMAX, bool LPJ, bool LACC, bool LIST = false, bool STASH = false>
 __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void gsc_estep_kernel(const double *__restrict__ scores, int64_t lds,
                                                          const double *__restrict__ gram,
                                                          const double *__restrict__ psi,
@@ -187,27 +198,37 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                                                          double *__restrict__ nz_val, int32_t *__restrict__ dense_rows,
                                                          int32_t *__restrict__ dense_count) {
     static_assert(!LIST || (LACC && !LPJ), "lists ride on the statistics form of the kernel");
+    static_assert(!STASH || (LACC && !LPJ), "the row stash rides on the statistics form of the kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_ndense, s_dbase;
-    __shared__ int32_t s_dense[LIST ? GSC_DENSE_CAP : 1];
+    __shared__ int s_ndw[4];        // STASH: a list of 64 per wavefront, sent early if it ever fills (the grid stays one resident round)
+    __shared__ int32_t s_dense[LIST ? (STASH ? GSC_DENSE_CAP_STASH : GSC_DENSE_CAP) : 1];
     const double thr = LIST ? T.c0[8 * (int64_t)H + 1] : 0.0;
     if (LIST && threadIdx.x == 0) s_ndense = 0;
+    if (LIST && STASH && threadIdx.x < 4) s_ndw[threadIdx.x] = 0;
     // 1 / sigma^2 from the host, or (0 there) from the ninth table row an M-step on the device has left
     const double inv_s2 = (inv_s2_host != 0.0) ? inv_s2_host : T.c0[8 * (int64_t)H];
-    // [ 8 tables (H) | per datapoint: ac (16) Gc Pc ass aszsz as (16) asz (16) | state masks (S x u16) ]
+    // [ 8 tables (H; STASH: 6) | per datapoint: ac (SL) Gc Pc ass aszsz as (SL) asz (SL) | state masks (S x u16) | LACC | STASH ]
+    constexpr int NTAB = STASH ? 6 : 8;
     double *s_tab = reinterpret_cast<double *>(smem);
-    double *s_c0 = s_tab, *s_c1 = s_tab + H, *s_gm = s_tab + 2 * H, *s_il = s_tab + 3 * H, *s_kl = s_tab + 4 * H;
-    double *s_ilam = s_tab + 5 * H, *s_mu = s_tab + 6 * H, *s_lpi = s_tab + 7 * H;
+    double *s_c0 = s_tab, *s_gm = s_tab + H, *s_il = s_tab + 2 * H, *s_kl = s_tab + 3 * H, *s_mu = s_tab + 4 * H;
+    double *s_lpi = s_tab + 5 * H, *s_c1 = s_tab + (STASH ? 0 : 6) * H, *s_ilam = s_tab + (STASH ? 0 : 7) * H;   // (STASH: unused)
     const int HH = Hp * Hp;
-    const int dp_stride = 16 + 4 * HH + 2 * 16;
-    double *s_dp = s_tab + 8 * H;
+    const int SL = (STASH && Hp <= 8) ? 8 : 16;
+    const int dp_stride = 3 * SL + 4 * HH;
+    double *s_dp = s_tab + NTAB * H;
+    const double s2_ = STASH ? 1.0 / inv_s2 : 0.0, two_is2 = 2.0 * inv_s2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: keep it scalar
     const int j = lane & 15, row = lane >> 4;
     for (int h = tid; h < H; h += 256) {
-        s_c0[h] = T.c0[h]; s_c1[h] = T.c1[h]; s_gm[h] = T.gm[h]; s_il[h] = T.il[h]; s_kl[h] = T.kl[h];
-        s_ilam[h] = T.ilam[h]; s_mu[h] = T.mu[h]; s_lpi[h] = T.lpi[h];
+        s_c0[h] = T.c0[h]; s_gm[h] = T.gm[h]; s_il[h] = T.il[h]; s_kl[h] = T.kl[h];
+        s_mu[h] = T.mu[h]; s_lpi[h] = T.lpi[h];
+        if (!STASH) { s_c1[h] = T.c1[h]; s_ilam[h] = T.ilam[h]; }
     }
+    // c1 = 2 mu / s2 and 1 / lam = kl s2 where the tables are not in LDS
+    auto tab_c1 = [&](int h) { return STASH ? two_is2 * s_mu[h] : s_c1[h]; };
+    auto tab_ilam = [&](int h) { return STASH ? s_kl[h] * s2_ : s_ilam[h]; };
     // the state masks sit in LDS behind the per-datapoint arrays: the multi-cause loop then issues no
     // vector-memory operation at all (see the deferred pair atomics below)
     uint16_t *s_masks = reinterpret_cast<uint16_t *>(s_dp + ROWS * dp_stride);
@@ -215,17 +236,21 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     // LACC: [3][4 wavefronts][H] accumulators (column sums of xpt_s, of xpt_sz, the singletons' diagonal of sum xpt_szsz) behind the masks (8-byte aligned); the four datapoint rows of a wavefront add
     // into the same slots (LDS atomics, 4-way same-address: 16 instructions per four datapoints, nothing beside the
     // ~3300 the rest of them costs) -- per-row private slots cost 32 KB and the third workgroup per CU
-    double *s_acc = reinterpret_cast<double *>(smem + ((8 * (size_t)(8 * H + ROWS * dp_stride) + 2 * (size_t)S + 7) & ~(size_t)7));
+    constexpr int NCP = STASH ? 2 : 4;         // copies of the column-sum accumulators (STASH: wavefronts 2 c, 2 c + 1 share copy c)
+    double *s_acc = reinterpret_cast<double *>(smem + ((8 * (size_t)(NTAB * H + ROWS * dp_stride) + 2 * (size_t)S + 7) & ~(size_t)7));
     if (LACC)
-        for (int e = tid; e < 3 * 4 * H; e += 256) s_acc[e] = 0.0;
-    double *acc_mine = s_acc + (size_t)wave * H + j;                    // + 16 i: latent j + 16 i; + 4 * H: next quantity
+        for (int e = tid; e < 3 * NCP * H; e += 256) s_acc[e] = 0.0;
+    double *acc_mine = s_acc + (size_t)(STASH ? wave >> 1 : wave) * H + j;   // + 16 i: latent j + 16 i; + NCP * H: next quantity
+    // STASH: [16 datapoints][H] behind the accumulators; latent h of this lane's row sits at h ^ rsw
+    double *s_row = s_acc + 3 * NCP * H + (size_t)(wave * 4 + row) * H;
+    const int rsw = (row & 1) << 4;
     __shared__ double s_E[128];                           // 2^(j/128): pm_exp_tab's table
     if (tid < 128) s_E[tid] = pm_powtab_dev[256 + tid];
     const double *etab = s_E - 256;
     double *s_ac = s_dp + (wave * 4 + row) * dp_stride;   // a at the candidates
-    double *s_Gc = s_ac + 16, *s_Pc = s_Gc + HH;
+    double *s_Gc = s_ac + SL, *s_Pc = s_Gc + HH;
     double *s_ass = s_Pc + HH, *s_aszsz = s_ass + HH;
-    double *s_as = s_aszsz + HH, *s_asz = s_as + 16;
+    double *s_as = s_aszsz + HH, *s_asz = s_as + SL;
     __syncthreads();
 
     const double tiny = 2.2250738585072014e-308, fmin_ = -1.7976931348623157e308;
@@ -249,14 +274,6 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     int myc_prev = 0;
     double nf_prev = 0.0;
     bool pend = false;
-    // Entries of a datapoint's blocks below thr_p are not sent.  The pass is bound by its vector-memory traffic, and the sixty
-    // f64 atomics per datapoint are the largest single item of it (a build without them runs 0.09 ms of 0.63 faster at config
-    // 4); most datapoints put all their weight on one or two states, so that all but a few entries of their blocks are
-    // ~1e-20 of the others.  thr_p = 2^-75 of the smallest diagonal entry of the PREVIOUS EM step's all-reduced sums (tables[8 H
-    // + 2], pm_gsc_mstep_finish_f64; 0 -- everything is sent -- when the tables come from the host): what is dropped from any
-    // entry of sum xpt_ss / sum xpt_szsz stays below N thr_p <= 2^-57 of the smallest diagonal entry for N <= 2^18, under the
-    // rounding of the diagonal sums themselves -- nothing the inverses, the element-wise psi_sq update or sigma_sq can see.
-    const double thr_p = (inv_s2_host != 0.0 || H <= 2) ? 0.0 : T.c0[8 * (int64_t)H + 2];
 
     // previous datapoint's blocks -> global sums (xpt_ss: upper triangle, mirrored by the host; candidates are sorted by
     // index, so ci <= ck for i <= k); accumulators cleared for the next one
@@ -271,9 +288,8 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 if (pend && !(PM_GSC_ABL & 16)) {
                     // xpt_ss is symmetric: upper triangle only; xpt_szsz = kappa kappa^T + Lambda^-1 is NOT once psi_sq has
                     // been through an M-step (gsc_et.py:660-675 leaves it non-symmetric): both triangles, as they are
-                    const double vss = s_ass[p] * nf_prev, vzz = s_aszsz[p] * nf_prev;
-                    if (k >= i && vss > thr_p) pm_atomic_add(g_ss + (int64_t)ci * H + ck, vss);
-                    if (__builtin_fabs(vzz) > thr_p) pm_atomic_add(g_szsz + (int64_t)ci * H + ck, vzz);
+                    if (k >= i) pm_atomic_add(g_ss + (int64_t)ci * H + ck, s_ass[p] * nf_prev);
+                    pm_atomic_add(g_szsz + (int64_t)ci * H + ck, s_aszsz[p] * nf_prev);
                 }
                 if (clear) {
                     s_ass[p] = 0.0;
@@ -308,6 +324,11 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
         const double *arow = scores + nn * lds;
         const double yn = yn_pre;
         GSC_STAMP(0);
+        if (STASH) {          // the row, parked for the phases behind the selection
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (j + 16 * i < H) s_row[(j + 16 * i) ^ rsw] = apre[i];
+        }
 
         // ---- candidates: top-H' scores, then sorted by latent index (gsc_et.py:726-728)
         int myc = 0;
@@ -323,7 +344,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 if (h < H) {  // singleton log-posterior without prior (gsc_et.py:795-805)
                     const double ai = apre[i];
                     const double bb = ai - s_gm[h];
-                    double v = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h];
+                    double v = s_c0[h] - yn * inv_s2 + tab_c1(h) * ai + bb * bb * s_il[h];
                     if (v != v || v < fmin_) v = fmin_;
                     if (isinf(v)) v = 0.0;
                     uint64_t b = (uint64_t)__double_as_longlong(v);
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             g_sync();
             if (j < Hp) myc = (int)s_as[j];
             g_sync();
-            if (live && j < Hp) cand[n * Hp + j] = myc;
+            if (!STASH && live && j < Hp) cand[n * Hp + j] = myc;     // (STASH: stored behind the gathers below)
         } else {
             if (j < Hp) myc = cand[nn * Hp + j];
         }
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
         // rowbase + k: ds_bpermute fetches it (uniform trip counts: every source lane stays active)
         GSC_STAMP(1);
         if (j < Hp) {
-            s_ac[j] = arow[myc];
+            s_ac[j] = STASH ? s_row[myc ^ rsw] : arow[myc];
             s_as[j] = 0.0;
             s_asz[j] = 0.0;
         }
@@ -386,6 +407,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
         // the compiler has no reason to drain the counter (and with it the atomics) further down
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), other counters untouched
         GSC_STAMP(2);
+        if (STASH && do_select && live && j < Hp) cand[n * Hp + j] = myc;
         g_sync();
         flush_pairs(true);
         g_sync();
@@ -489,9 +511,9 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             double p = 0.0;
             if (h < H) {
                 // the un-clamped singleton log-posterior (the score clamps are selection-only)
-                const double ai = arow2[h];
+                const double ai = STASH ? s_row[h ^ rsw] : arow2[h];
                 const double bb = ai - s_gm[h];
-                const double lp = s_c0[h] - yn * inv_s2 + s_c1[h] * ai + bb * bb * s_il[h] + s_lpi[h];
+                const double lp = s_c0[h] - yn * inv_s2 + tab_c1(h) * ai + bb * bb * s_il[h] + s_lpi[h];
                 if (LPJ && live) logpj[n * ldl + 1 + h] = lp;
                 p = (PM_GSC_ABL & 2) ? lp : gsc_weight(lp * beta, etab);
                 Z += p;
@@ -510,14 +532,14 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             const int h = j + 16 * i;
             double kap = 0.0, il = 0.0;
             if (h < H) {      // (the score once more from the vector cache: eight registers less across the phase)
-                kap = (arow2[h] - s_gm[h]) * s_kl[h] + s_mu[h];
-                il = s_ilam[h];
+                kap = ((STASH ? s_row[h ^ rsw] : arow2[h]) - s_gm[h]) * s_kl[h] + s_mu[h];
+                il = tab_ilam(h);
             }
             xsz[i] = xs[i] * kap;
             // singles contribute to the diagonals of sum xpt_ss / xpt_szsz (multi-cause diagonal terms went
             // through the block atomics above)
             if (LACC) {
-                if (live && h < H) atomicAdd(&acc_mine[8 * H + 16 * i], xs[i] * (kap * kap + il) * nf);
+                if (live && h < H) atomicAdd(&acc_mine[2 * NCP * H + 16 * i], xs[i] * (kap * kap + il) * nf);
             } else if (live) {
                 dszsz[i] += xs[i] * (kap * kap + il) * nf;
             }
@@ -550,7 +572,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 }
                 if (LACC && !(PM_GSC_ABL & 8)) {
                     atomicAdd(&acc_mine[16 * i], vs);
-                    atomicAdd(&acc_mine[4 * H + 16 * i], vz);
+                    atomicAdd(&acc_mine[NCP * H + 16 * i], vz);
                 }
                 sig = LIST && (__builtin_fabs(vz) > thr || vs > thr);
             }
@@ -579,13 +601,28 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 if (j >= nsig) li[j] = 0xFFFF;
             } else {
                 li[j] = 0xFFFF;
-                if (j == 0) s_dense[atomicAdd(&s_ndense, 1)] = (int32_t)n;
+                if (j == 0) {
+                    if (STASH) s_dense[wave * 64 + atomicAdd(&s_ndw[wave], 1)] = (int32_t)n;
+                    else s_dense[atomicAdd(&s_ndense, 1)] = (int32_t)n;
+                }
             }
         }
         myc_prev = myc;
         nf_prev = nf;
         pend = live;
         g_sync();
+        if (LIST && STASH) {        // my list about to overflow (never at config 4: a fifth of ~65 datapoints): send it now
+            const int c = __builtin_amdgcn_readfirstlane(s_ndw[wave]);
+            if (c > 60) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(dense_count, c);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (lane < c) dense_rows[base + lane] = s_dense[wave * 64 + lane];
+                g_sync();
+                if (lane == 0) s_ndw[wave] = 0;
+                g_sync();
+            }
+        }
         GSC_STAMP(8);
 #ifdef PM_GSC_STAMPS
         ++stamp_dp;
@@ -599,16 +636,25 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     __syncthreads();
     double *g_cs = stats + 2 * (int64_t)H * H;          // [column sums of xpt_s | of xpt_sz | singleton diagonal of sum xpt_szsz]
     if (LIST) {       // the workgroup's dense datapoints -> the global list (order among workgroups: as the atomics land)
+        if (STASH) {      // the four wavefronts' lists behind one another: still ONE global atomic per workgroup
+            const int c0 = s_ndw[0], c1 = s_ndw[1], c2 = s_ndw[2], c3 = s_ndw[3];
+            if (tid == 0) s_dbase = (c0 + c1 + c2 + c3) ? atomicAdd(dense_count, c0 + c1 + c2 + c3) : 0;
+            __syncthreads();
+            const int mine = wave == 0 ? c0 : wave == 1 ? c1 : wave == 2 ? c2 : c3;
+            const int before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+            if (lane < mine) dense_rows[s_dbase + before + lane] = s_dense[wave * 64 + lane];
+        } else {
         const int nd = s_ndense;
         if (tid == 0) s_dbase = nd ? atomicAdd(dense_count, nd) : 0;
         __syncthreads();
         for (int e = tid; e < nd; e += 256) dense_rows[s_dbase + e] = s_dense[e];
+        }
     }
     if (LACC) {       // [column sums of xpt_s | of xpt_sz | singleton diagonal]: the four wavefronts' slots, then one atomic each
         for (int e = tid; e < 3 * H; e += 256) {
             const int q = e / H, h = e - q * H;
-            const double *src = s_acc + (size_t)q * 4 * H + h;
-            const double v = (src[0] + src[H]) + (src[2 * (size_t)H] + src[3 * (size_t)H]);
+            const double *src = s_acc + (size_t)q * NCP * H + h;
+            const double v = STASH ? src[0] + src[H] : (src[0] + src[H]) + (src[2 * (size_t)H] + src[3 * (size_t)H]);
             if (v != 0.0) pm_atomic_add(g_cs + e, v);
         }
         return;
@@ -697,6 +743,17 @@ static size_t gsc_shmem(int64_t H, int64_t Hprime, int64_t S) {
 // ... with the per-wavefront accumulators of the column sums behind it (LACC); used when three workgroups still fit a CU
 static size_t gsc_shmem_lacc(int64_t H, int64_t Hprime, int64_t S) {
     return gsc_shmem(H, Hprime, S) + sizeof(double) * (3 * 4 * H + 1);
+}
+
+// ... and the STASH layout: six tables, 8-wide candidate slots (H' <= 8), two accumulator copies, the sixteen parked rows
+static size_t gsc_shmem_stash(int64_t H, int64_t Hprime, int64_t S) {
+    const int64_t SL = Hprime <= 8 ? 8 : 16;
+    return sizeof(double) * (6 * H + ROWS * (3 * SL + 4 * Hprime * Hprime) + (S + 3) / 4 + 3 * 2 * H + 1 + ROWS * H);
+}
+// three workgroups per CU: 160 KB of LDS in 512-byte granules, minus the kernel's static arrays (dense-row list, exp table)
+static bool gsc_stash_fits(int64_t H, int64_t Hprime, int64_t S, bool list) {
+    const size_t stat = 1024 + 16 + (list ? 4 * GSC_DENSE_CAP_STASH : 4);
+    return H % 32 == 0 && ((gsc_shmem_stash(H, Hprime, S) + stat + 511) / 512) * 512 * 3 <= 160 * 1024;
 }
 
 extern "C" int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma) {
@@ -791,16 +848,6 @@ __global__ __launch_bounds__(1024) void gsc_mstep_finish_kernel(
         __syncthreads();
     }
     if (tid == 0 && H > 1) tables[8 * H + 1] = ldexp(s_red[0], -75);
-    // tables[8 H + 2]: below this an entry of a datapoint's pair blocks is not sent (gsc_estep_kernel, thr_p): 2^-75 of the smallest
-    // diagonal entry of sum xpt_ss (= sum xpt_s) and sum xpt_szsz
-    __syncthreads();
-    s_red[tid] = tid < H ? fmin(fabs(sum_s[tid]), fabs(sum_zz[(int64_t)tid * H + tid])) : INFINITY;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (tid < w) s_red[tid] = fmin(s_red[tid], s_red[tid + w]);
-        __syncthreads();
-    }
-    if (tid == 0 && H > 2) tables[8 * H + 2] = ldexp(s_red[0], -75);
 }
 }  // namespace
 
@@ -833,7 +880,10 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
     GscTables T{tables, tables + H, tables + 2 * H, tables + 3 * H, tables + 4 * H, tables + 5 * H, tables + 6 * H,
                 tables + 7 * H};
     const bool lacc = gsc_shmem_lacc(H, Hprime, S) <= 53 * 1024;
-    const size_t shmem = lacc ? gsc_shmem_lacc(H, Hprime, S) : gsc_shmem(H, Hprime, S);
+    // the tuned instantiations (H = 128, gamma <= 3: three wavefronts per SIMD) park the scores rows in LDS when that still fits
+    const bool stash = lacc && !logpj && H == 128 && gamma <= 3 && gsc_stash_fits(H, Hprime, S, nz_idx != nullptr) &&
+                       !getenv("PM_GSC_NO_STASH");
+    const size_t shmem = stash ? gsc_shmem_stash(H, Hprime, S) : lacc ? gsc_shmem_lacc(H, Hprime, S) : gsc_shmem(H, Hprime, S);
     if (gsc_shmem(H, Hprime, S) > 64 * 1024) return PM_ERANGE;
     // ONE resident round of workgroups (three per CU for the tuned instantiations), each walking its share of the
     // datapoints: 2048 workgroups -- 2.7 rounds, the last one two thirds full, and 2048 table loads / accumulator flushes --
@@ -846,7 +896,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
     if (nz_idx) {      // LIST: a workgroup's dense rows wait in GSC_DENSE_CAP slots of LDS
         if (!lacc || logpj || gamma > 3 || H <= 64 || H > 256 || !nz_val || !dense_rows || !dense_count) return PM_ERANGE;
         const int64_t per_wg = GSC_DENSE_CAP / ROWS, need = ((N + ROWS - 1) / ROWS + per_wg - 1) / per_wg;
-        if (groups < need) groups = need;
+        if (!stash && groups < need) groups = need;      // (the stash form sends a full list early instead)
         if (groups > INT32_MAX) return PM_ERANGE;
     }
     dim3 grid((unsigned)groups), block(256);
@@ -864,6 +914,14 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, false, true, true>), shmem))   \
             return e;                                                                                                  \
         hipLaunchKernelGGL((gsc_estep_kernel<V, G, false, true, true>), grid, block, shmem, s, scores, lds, gram,      \
+                           psi_sq, ynorm2, T, state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select,    \
+                           cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, nz_idx, nz_val, dense_rows, dense_count);      \
+    } while (0)
+#define PM_LAUNCH_STASH(G, LI)                                                                                         \
+    do {                                                                                                               \
+        if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<8, G, false, true, LI, true>), shmem)) \
+            return e;                                                                                                  \
+        hipLaunchKernelGGL((gsc_estep_kernel<8, G, false, true, LI, true>), grid, block, shmem, s, scores, lds, gram,  \
                            psi_sq, ynorm2, T, state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select,    \
                            cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, nz_idx, nz_val, dense_rows, dense_count);      \
     } while (0)
@@ -885,7 +943,10 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         else if (gamma <= 6) PM_LAUNCH(V, 6); \
         else PM_LAUNCH(V, 8);                 \
     } while (0)
-    if (nz_idx) {
+    if (stash) {
+        if (nz_idx) { if (gamma <= 2) PM_LAUNCH_STASH(2, true); else PM_LAUNCH_STASH(3, true); }
+        else { if (gamma <= 2) PM_LAUNCH_STASH(2, false); else PM_LAUNCH_STASH(3, false); }
+    } else if (nz_idx) {
         if (H <= 128) {
             if (gamma <= 2) PM_LAUNCH_LIST(8, 2);
             else PM_LAUNCH_LIST(8, 3);
@@ -903,6 +964,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
 #undef PM_LAUNCH
 #undef PM_LAUNCH_LA
 #undef PM_LAUNCH_LIST
+#undef PM_LAUNCH_STASH
     {
         const int64_t rows_per_block = 512;
         const int64_t blocks = (N + rows_per_block - 1) / rows_per_block;
@@ -910,7 +972,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         const int64_t HH2 = 2 * H * H;
         hipLaunchKernelGGL(pm_fold_copies_kernel, dim3((unsigned)((HH2 + 255) / 256)), dim3(256), 0, s, stats,
                            stats + HH2 + 3 * H, HH2);
-        if (!lacc || logpj)
+        if (!lacc || logpj)     // (the stash implies lacc)
             hipLaunchKernelGGL(gsc_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xpt_s, xpt_sz, ldx, N, (int)H,
                                rows_per_block, g_cs, g_cs + H);
     }

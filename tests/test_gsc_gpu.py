@@ -380,6 +380,10 @@ def test_gsc_mstep_finish_kernel(H, D, learn):
     want[8, 1] = float(np.abs(sum_sz).min()) * 2.0 ** -75     # the list threshold of the next E-step (pm_gsc_estep_lists_f64)
     thr_got, tab[8, 1] = tab[8, 1], want[8, 1]
     np.testing.assert_allclose(thr_got, want[8, 1], rtol=1e-14)
+    # ... and the threshold below which an entry of a datapoint's pair blocks is not sent (gsc_estep_kernel, thr_p)
+    want[8, 2] = min(float(np.abs(sum_s).min()), float(np.abs(np.diag(sum_zz)).min())) * 2.0 ** -75
+    thr_got, tab[8, 2] = tab[8, 2], want[8, 2]
+    np.testing.assert_allclose(thr_got, want[8, 2], rtol=1e-14)
     np.testing.assert_allclose(tab, want, rtol=1e-10, atol=1e-12)
 
 
@@ -570,6 +574,49 @@ def test_gsc_lists_with_zero_threshold_keep_every_row_dense():
         _lib.call("pm_gemm_tn_acc_rows_f64", _ptr(big), big.stride(0), _ptr(xsz), big.stride(0), _ptr(got), H, D + 2 * H, H,
                   _ptr(rows), _ptr(cnt), N, N, st)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-11, atol=1e-13 * np.abs(want).max())
+
+
+def test_gsc_pair_block_threshold_drops_nothing_visible():
+    """With tables from the device (sigma_sq = 0) the E-step kernel sends an entry of a datapoint's xpt_ss / xpt_szsz blocks only
+    if it exceeds tables[8 H + 2] = 2^-75 of the smallest diagonal entry of the previous step's sums.  Against the same pass
+    with threshold 0: identical moments and column sums, block sums equal to within N * threshold -- and a threshold large enough
+    to matter really drops entries (the switch is live)."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    D, H, Hp, gamma, N = 256, 128, 6, 3, 4000
+    rng = np.random.RandomState(47)
+    W_gt = rng.normal(size=(D, H))
+    S = rng.random_sample((N, H)) < 2.0 / H
+    y = (S * (1.5 + rng.normal(size=(N, H)))) @ W_gt.T + rng.normal(size=(N, D))
+    p = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.4),
+         "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+    m = GSC(D, H, Hp, gamma, 'scalar')
+    res = m._resident(y)
+    par = m._tables_for(p, res)
+    A = m._gemm_nt(res["Y"], par["Wst"], m._buf("scores", (N, H)), "scores_gemm")
+    outs = {}
+    for thr in (0.0, None, 1e-3):
+        tdev = torch.zeros(9 * H, dtype=torch.float64, device=m.device)
+        tdev[:8 * H] = par["tables"].reshape(-1)[:8 * H]
+        tdev[8 * H] = 1.0 / par["s2"]
+        if thr is None:       # what pm_gsc_mstep_finish_f64 would leave: from this very pass's sums
+            st0 = outs[0.0][3]
+            diag = torch.minimum(st0[2 * H * H:2 * H * H + H].abs(),
+                                 (st0[H * H:2 * H * H].view(H, H).diagonal() + st0[2 * H * H + 2 * H:2 * H * H + 3 * H]).abs())
+            thr = float(diag.min()) * 2.0 ** -75
+            assert thr > 0.0
+        tdev[8 * H + 2] = thr
+        cand, xs, xsz, stats = m._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], tdev, 0.0, 1.0, None)
+        outs[thr] = (cand.clone(), xs.clone(), xsz.clone(), stats[:2 * H * H + 3 * H].clone())
+    (k0, kt, kbig) = sorted(outs)
+    a, b, c = outs[k0], outs[kt], outs[kbig]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(a[3][2 * H * H:], b[3][2 * H * H:])                         # column sums, singleton diagonal: untouched
+    # (same entries in another order of arrival: the atomics' rounding, 1e-16 of an entry's own scale, is there in both)
+    diff = (a[3][:2 * H * H] - b[3][:2 * H * H]).abs().cpu().numpy()
+    scale = a[3][:2 * H * H].abs().cpu().numpy()
+    assert (diff <= N * kt + 1e-13 * scale).all(), float((diff - 1e-13 * scale).max())
+    dropped = (a[3][:2 * H * H] - c[3][:2 * H * H]).abs().max()
+    assert float(dropped) > 1e-4, float(dropped)
 
 
 def test_config4_full_shard_against_oracle():
