@@ -124,6 +124,7 @@ class GSC(DeviceCAModel):
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.fuse_moment_gemm = True      # [Y | xs | xsz]^T xsz as one GEMM (a plain attribute: tests flip it)
         self.overlap_moments = True       # ... the two parts on two streams (an HBM stream beside an MFMA GEMM)
+        self.overlap_scores = True        # the next step's scores GEMM on a second stream beside Gram / finish kernel / download
         self.sparse_moments = True        # ... split into listed rows (sparse product) + gathered dense rows, when the
                                           # M-step itself launched the E-step (pm_gsc_estep_lists_f64)
         self._spec = None        # next step's whole E-step, launched by M_step from device-side parameters
@@ -372,14 +373,15 @@ class GSC(DeviceCAModel):
         return self._launch_estep(res, A, par["G"], par["psi_d"], par["yn"], par["tables"], par["s2"], anneal_T, cand_in,
                                   logpj)
 
-    def _launch_estep(self, res, A, G, psi_d, yn, tables, s2, anneal_T, cand_in, logpj=None, lists=False):
+    def _launch_estep(self, res, A, G, psi_d, yn, tables, s2, anneal_T, cand_in, logpj=None, lists=False, zeros=None):
         """The fused select / E-step kernel on scores ``A``; ``s2 == 0.0``: 1/sigma_sq sits in the ninth row of
         ``tables`` (an M-step that finished on the device).  Returns (cand, xpt_s, xpt_sz, stats)."""
         N = res["Y"].shape[0]
         H, Hp, S = self.H, self.Hprime, self.no_states
         masks = self._masks()
         n_stats = _lib.load().pm_gsc_stats_len(H)
-        stats = torch.zeros(n_stats, dtype=torch.float64, device=self.device)
+        # (`zeros`: a zeroed statistics buffer and dense-row counter the caller filled earlier, off the critical path)
+        stats = zeros[0] if zeros is not None else torch.zeros(n_stats, dtype=torch.float64, device=self.device)
         # xpt_s and xpt_sz side by side, and BEHIND A COPY OF Y, in one (N, D + 2H) buffer: the M-step then gets all three
         # contractions over the datapoints -- [Y | xs | xsz]^T . xsz = [Wp ; xs^T xsz ; xsz^T xsz] -- from a single GEMM
         # launch (0.43 instead of 0.56 ms at config 4: one (D + 2H) x H output keeps the chip fuller than two D x H
@@ -416,7 +418,7 @@ class GSC(DeviceCAModel):
                          torch.empty((N, 16), dtype=torch.float64, device=self.device),
                          torch.empty(N, dtype=torch.int32, device=self.device))
             nz_idx, nz_val, dense_rows = lb[k]
-            dense_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            dense_count = zeros[1] if zeros is not None else torch.zeros(1, dtype=torch.int32, device=self.device)
             self._call("estep", "pm_gsc_estep_lists_f64", _ptr(A), H, _ptr(G), _ptr(psi_d), _ptr(yn),
                        _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
                        ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
@@ -639,8 +641,15 @@ class GSC(DeviceCAModel):
             # the old parameters for pm_gsc_mstep_finish_f64, uploaded NOW: enqueued in front of the contraction they are on
             # the device long before the finish kernel wants them (uploaded next to it, the copy and its latency sat in the
             # middle of the M-step's chain of small launches: ~30 us of idle device per step)
-            old_dev = self._upload("gsc_old", np.concatenate([np.asarray(model_params[k], dtype=np.float64).reshape(-1)
-                                                               for k in ('pi', 'mu', 'psi_sq', 'sigma_sq')]))
+            # (inside an EM loop they ARE on the device: the previous M-step's own result, if the caller handed it back
+            # unchanged -- an upload here, which the contraction's stream waits for, left the device idle for ~40 us per step)
+            kept, self._dev_params = getattr(self, "_dev_params", None), None
+            if kept is not None and all(np.array_equal(np.asarray(model_params[k]), kept[1][k])
+                                        for k in ('pi', 'mu', 'psi_sq', 'sigma_sq')):
+                old_dev = kept[0]
+            else:
+                old_dev = self._upload("gsc_old", np.concatenate([np.asarray(model_params[k], dtype=np.float64).reshape(-1)
+                                                                   for k in ('pi', 'mu', 'psi_sq', 'sigma_sq')]))
         xs, xsz = dev(suff_stats['xpt_s']), dev(suff_stats['xpt_sz'])
         ld = xs.stride(0) if xs.dim() == 2 else 0
         paired = (xs.dim() == 2 and xs.stride(1) == 1 and xsz.stride() == (ld, 1) and H % 2 == 0 and ld % 2 == 0
@@ -665,7 +674,10 @@ class GSC(DeviceCAModel):
         # one buffer, one download: [statistics (all-reduced) | 2 inverses + 4 pivots | W_new^T | pi mu psi_sq sigma_sq]
         n_inv, n_par = 2 * nHH + 4 + 2, 2 * H + nHH + 1          # (+ 2: the warm starts' accepted flags)
         o_inv = n_stat + (n_stat & 1)               # (16-byte alignment for the GEMM's vector loads)
-        whole = torch.zeros(o_inv + n_inv + nWp + n_par, dtype=torch.float64, device=self.device)
+        n_whole = o_inv + n_inv + nWp + n_par
+        whole, self._whole_next = getattr(self, "_whole_next", None), None        # (zeroed by the previous M-step, off the
+        if whole is None or whole.numel() != n_whole or whole.device != torch.device(self.device):  # critical path)
+            whole = torch.zeros(n_whole, dtype=torch.float64, device=self.device)
         packed = whole[:n_stat]
         if my_N:
             s = self._stream()
@@ -764,7 +776,21 @@ class GSC(DeviceCAModel):
         # an EM loop on a flat annealing schedule that E-step is launched right here (E_step adopts it iff it is called
         # with exactly the parameters this M-step returns).  The host still receives everything with the one download.
         fin = None
+        scores_side = None
         if Wt_next is not None and self.speculate_estep and my_N and old_dev is not None:
+            if self.overlap_scores and self.timer is None:
+                # the scores GEMM needs W_new^T only: it starts here on the second stream while the main one still runs the
+                # Gram product, the one-workgroup finish kernel and the download (0.04 ms of a mostly idle device at config 4)
+                side = getattr(self, "_side_stream", None)
+                if side is None:
+                    side = self._side_stream = torch.cuda.Stream(device=self.device)
+                solved = torch.cuda.Event()
+                solved.record()
+                side.wait_event(solved)
+                with torch.cuda.stream(side):
+                    A_side = self._gemm_nt(Y, Wt_next, self._buf("scores_spec", (my_N, H)), "scores_gemm")
+                    scores_side = (A_side, torch.cuda.Event())
+                    scores_side[1].record(side)
             G_next = self._gemm_nt(Wt_next, Wt_next, torch.empty((H, H), dtype=torch.float64, device=self.device),
                                    "gram_gemm")
             learn = sum(bit for bit, k in ((1, 'pi'), (2, 'mu'), (4, 'psi_sq'), (8, 'sigma_sq')) if k in self.to_learn)
@@ -778,11 +804,19 @@ class GSC(DeviceCAModel):
             if fin is None:
                 self._speculate(res, Wt_next)
                 return
-            A = self._gemm_nt(Y, Wt_next, self._buf("scores_spec", (my_N, H)), "scores_gemm")
+            # zero fills of the next pass / the next M-step: enqueued while the scores GEMM still runs beside this stream
+            zeros = (torch.zeros(int(_lib.load().pm_gsc_stats_len(H)), dtype=torch.float64, device=self.device),
+                     torch.zeros(1, dtype=torch.int32, device=self.device))
+            self._whole_next = torch.zeros(n_whole, dtype=torch.float64, device=self.device)
+            if scores_side is not None:
+                A = scores_side[0]
+                torch.cuda.current_stream(self.device).wait_event(scores_side[1])
+            else:
+                A = self._gemm_nt(Y, Wt_next, self._buf("scores_spec", (my_N, H)), "scores_gemm")
             self._seed = {"ykey": res["key"], "Wt": Wt_next, "G": fin["G"], "A": A, "W_host": None}
             if self._in_step and self._flat_schedule:
                 fin["out"] = self._launch_estep(res, A, fin["G"], fin["psi"], res["ynorm2"], fin["tdev"], 0.0,
-                                                anneal['T'], None, lists=True)
+                                                anneal['T'], None, lists=True, zeros=zeros)
 
         if packed.is_cuda:
             n_down = o_par + n_par if fin is not None else (o_par if Wt_next is not None else
@@ -824,6 +858,9 @@ class GSC(DeviceCAModel):
                     model_params[k] = dev_params[lo:hi].reshape(shape).copy()
             if 'sigma_sq' in self.to_learn:
                 model_params['sigma_sq'] = float(dev_params[-1])
+            # (the parameters as the device holds them: the next M-step's `old` if they come back unchanged)
+            self._dev_params = (whole[o_par:o_par + n_par],
+                                {k: np.array(model_params[k], dtype=np.float64, copy=True) for k in ('pi', 'mu', 'psi_sq', 'sigma_sq')})
             if fin["out"] is not None:
                 self._spec = {"res": res, "T": anneal['T'], "out": fin["out"],
                               "params": {k: np.array(model_params[k], dtype=np.float64, copy=True) for k in self._PARAM_KEYS}}

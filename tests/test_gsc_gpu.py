@@ -610,7 +610,8 @@ def test_gsc_pair_block_threshold_drops_nothing_visible():
     (k0, kt, kbig) = sorted(outs)
     a, b, c = outs[k0], outs[kt], outs[kbig]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    assert torch.equal(a[3][2 * H * H:], b[3][2 * H * H:])                         # column sums, singleton diagonal: untouched
+    # column sums, singleton diagonal: untouched (atomics in another order of arrival: rounding only)
+    np.testing.assert_allclose(b[3][2 * H * H:].cpu().numpy(), a[3][2 * H * H:].cpu().numpy(), rtol=1e-13)
     # (same entries in another order of arrival: the atomics' rounding, 1e-16 of an entry's own scale, is there in both)
     diff = (a[3][:2 * H * H] - b[3][:2 * H * H]).abs().cpu().numpy()
     scale = a[3][:2 * H * H].abs().cpu().numpy()
