@@ -513,9 +513,10 @@ int pm_dsc_estep_mstats_f64(const double *scores, int64_t lds, const double *gra
 /* Shapes the GSC kernel covers: H <= 512, gamma <= 8 (g x g systems solved in registers; instantiated for 2, 3, 4, 6, 8). */
 int pm_gsc_supported(int64_t H, int64_t Hprime, int64_t gamma);
 
-/* stats (float64): [ sum_n xpt_ss, upper triangle, multi-cause part (H*H) |
- *                    sum_n xpt_szsz, upper triangle, multi-cause part (H*H) |
- *                    sum_n xpt_s (H) | sum_n xpt_sz (H) | singleton diagonal of sum_n xpt_szsz (H) |
+/* stats (float64): [ sum_n xpt_ss, STRICT upper triangle, multi-cause part (H*H; its diagonal is sum_n xpt_s and is not formed here) |
+ *                    sum_n xpt_szsz, both triangles as they are, multi-cause part (H*H) |
+ *                    sum_n xpt_s (H) | sum_n xpt_sz (H) | diagonal of sum_n xpt_szsz that is not in the block above (H): the
+ *                    singletons', and -- where the kernel keeps its column sums in LDS -- the multi-cause states' too |
  *                    scratch: seven more copies of the first 2*H*H entries ]
  * diag(sum xpt_ss) = sum_n xpt_s (s_h^2 = s_h).  The kernel accumulates the (H,H) blocks per XCD (one L2 each)
  * and folds the copies into the first 2*H*H entries (clearing the scratch) before it returns: the caller zeroes the

@@ -271,9 +271,13 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 if (pend && !(PM_GSC_ABL & 16)) {
                     // xpt_ss is symmetric: upper triangle only; xpt_szsz = kappa kappa^T + Lambda^-1 is NOT once psi_sq has
                     // been through an M-step (gsc_et.py:660-675 leaves it non-symmetric): both triangles, as they are
+                    // The diagonals stay at home: diag(sum xpt_ss) IS the column sum of xpt_s (s_h^2 = s_h; nobody reads the
+                    // diagonal of the block sum), and with the LDS accumulators (LACC) the diagonal of xpt_szsz joins the singletons'
+                    // there -- twelve of a datapoint's atomics, and the ones that always clear the threshold.
                     const double vss = s_ass[p] * nf_prev, vzz = s_aszsz[p] * nf_prev;
-                    if (k >= i && vss > thr_p) pm_atomic_add(g_ss + (int64_t)ci * H + ck, vss);
-                    if (__builtin_fabs(vzz) > thr_p) pm_atomic_add(g_szsz + (int64_t)ci * H + ck, vzz);
+                    if (k > i && vss > thr_p) pm_atomic_add(g_ss + (int64_t)ci * H + ck, vss);
+                    if (LACC && k == i) atomicAdd(&s_acc[2 * 4 * H + wave * H + ci], vzz);
+                    else if (__builtin_fabs(vzz) > thr_p) pm_atomic_add(g_szsz + (int64_t)ci * H + ck, vzz);
                 }
                 if (clear) {
                     s_ass[p] = 0.0;
