@@ -88,6 +88,11 @@ int pm_row_sqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, double
 int pm_col_moments_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *center,
                        double *sums, void *stream);
 
+/* sums[d] += sum over the datapoints n with lse[n] >= cut of Y[n,d]: my_data_sum of BSC_ET.M_step when 'mu' is learned
+ * (bsc_et.py:422-430) over the datapoints the truncation keeps (:247-258; cut = -inf keeps all).  `sums` is accumulated into. */
+int pm_col_sum_kept_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *lse, double cut, double *sums,
+                        void *stream);
+
 /* out[n] = sum_d w[d] Y[n,d]^2 -- y^T Sigma^-1 y of GSC with a diagonal noise covariance
  * (gsc_et.py:418-419, 476, 780-781). */
 int pm_row_wsqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *w, double *out,
@@ -581,6 +586,16 @@ int pm_gsc_estep_lpj_f64(const double *scores, int64_t lds, const double *gram, 
                          int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
                          double *stats, double *logpj, int64_t ldl, void *stream);
 
+/* ... and every datapoint's un-normalised sums over the multi-cause states -- what GSC.compute_posterior_hprime returns for a
+ * data cluster (gsc_et.py:260-398) -- blocks (N, ldb >= 2 Hprime^2 + 2 Hprime + 1):
+ * [sum_s p_s [i, k in s] | sum_s p_s (kappa kappa^T + Lambda^-1)_ik | sum_s p_s [i in s] | sum_s p_s kappa_i | sum_s p_s] over the
+ * candidate positions i, k in the order of `cand`, p_s = exp(beta lp_s) with the reference's clamp to `tiny`. */
+int pm_gsc_estep_lpj_blocks_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                                const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                                int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                                int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx, double *stats,
+                                double *logpj, int64_t ldl, double *blocks, int64_t ldb, void *stream);
+
 /* GSC.component_scores (gsc_et.py:752-809): singleton log-posteriors without the prior, clamped as the reference
  * clamps them (NaN / below -DBL_MAX -> -DBL_MAX, +-inf -> 0), out (N, ldo >= H).  `scores`, `ynorm2`, `tables`
  * (rows c0, c1, gm, il are read), `sigma_sq` (> 0) as for pm_gsc_estep_f64. */
@@ -606,6 +621,18 @@ int pm_infer_topk_f64(const double *logpj, int64_t ldl, const int32_t *cand, con
 int pm_infer_topk_cols_f64(const double *logpj, int64_t ldl, const int32_t *cand, const uint16_t *state_masks, int64_t N,
                            int64_t H, int64_t Hprime, int64_t S, int64_t single_cols, int64_t topK, int32_t *top_idx,
                            double *top_lpc, double *top_rel, double *marg, int64_t ldm, void *stream);
+
+/* TSC_ET.inference after compute_lpj (tsc_et.py:546-680): logpj (N, ldl >= S) holds ONE log-joint per row of the ternary state
+ * table, state_vals (S, Hprime) int8 the latent values -1 / 0 / +1 per candidate position, cand (N, Hprime) may repeat a latent.
+ * rank != 0: top_idx (N, topK) = the best states descending by (value, column), and tie[n] = 1 when two of row n's topK + 1
+ * best are exactly equal -- the order NumPy's argsort()[::-1] (:626) gives exact ties is not a function of (value, column),
+ * so the caller ranks those rows with NumPy and calls again with rank == 0, top_idx given.  Either way: top_lpc / top_post
+ * (N, topK) normalised log-probabilities / probabilities; m_out / am_out (N, H; am_out may be NULL) the signed / absolute
+ * marginals sum_s p_s v and sum_s p_s |v| written at the candidates in position order (a repeated candidate's last position
+ * wins, :640-655); s_out (N, topK, H) int8 the top states written likewise.  Entries of other latents are left as they are. */
+int pm_infer_topk_signed_f64(const double *logpj, int64_t ldl, const int32_t *cand, const int8_t *state_vals, int64_t N,
+                             int64_t H, int64_t Hprime, int64_t S, int64_t topK, int rank, int32_t *top_idx, double *top_lpc,
+                             double *top_post, int32_t *tie, int8_t *s_out, double *m_out, double *am_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -129,9 +129,14 @@ SIGNATURES = {
                                          i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "pm_gsc_estep_lpj_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
                                        i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp]),
+    "pm_gsc_estep_lpj_blocks_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
+                                              i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp]),
+    "pm_col_sum_kept_f64": (C.c_int, [c_dp, i64, i64, i64, c_dp, C.c_double, c_dp, c_dp]),
     "pm_infer_topk_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp]),
     "pm_infer_topk_cols_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, i64, i64, c_dp, c_dp, c_dp, c_dp, i64,
                                          c_dp]),
+    "pm_infer_topk_signed_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, c_dp,
+                                           c_dp, c_dp, c_dp, c_dp]),
     "pm_gsc_component_scores_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_double, i64, i64, c_dp, i64, c_dp]),
 }
 

@@ -722,6 +722,26 @@ __global__ __launch_bounds__(256) void col_moments_f64_kernel(const double *__re
     }
 }
 
+// sums[d] += sum over the datapoints with lse[n] >= cut of Y[n,d]: my_data_sum of BSC_ET.M_step when 'mu' is learned
+// (bsc_et.py:422-430), over the rows the truncation keeps (:247-258).  Same walk as col_moments_f64_kernel.
+__global__ __launch_bounds__(256) void col_sum_kept_f64_kernel(const double *__restrict__ Y, int64_t ldy, int64_t N, int D,
+                                                                const double *__restrict__ lse, double cut,
+                                                                double *__restrict__ sums, int64_t rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < D; d += gridDim.x * 256) {
+        double a0 = 0.0, a1 = 0.0;
+        int64_t n = r0;
+        for (; n + 1 < r1; n += 2) {
+            const double u = Y[n * ldy + d], v = Y[(n + 1) * ldy + d];
+            a0 += (lse[n] >= cut) ? u : 0.0;
+            a1 += (lse[n + 1] >= cut) ? v : 0.0;
+        }
+        if (n < r1 && lse[n] >= cut) a0 += Y[n * ldy + d];
+        pm_atomic_add(sums + d, a0 + a1);
+    }
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int resident_slots() {  // workgroups of these kernels resident at once: 2 per CU
@@ -947,6 +967,21 @@ extern "C" int pm_col_moments_f64(const double *Y, int64_t ldy, int64_t N, int64
     gy = (N + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(col_moments_f64_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), Y,
                        ldy, N, (int)D, center, sums, rows_per_block);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_col_sum_kept_f64(const double *Y, int64_t ldy, int64_t N, int64_t D, const double *lse, double cut,
+                                   double *sums, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!Y || !lse || !sums || N < 0 || D <= 0 || ldy < D) return PM_EINVAL;
+    if (D > INT32_MAX) return PM_ERANGE;
+    const unsigned gx = (unsigned)((D + 255) / 256 > 64 ? 64 : (D + 255) / 256);
+    int64_t gy = (2 * (int64_t)resident_slots() + gx - 1) / gx;
+    if (gy > N) gy = N;
+    const int64_t rows_per_block = (N + gy - 1) / gy;
+    gy = (N + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(col_sum_kept_f64_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), Y, ldy,
+                       N, (int)D, lse, cut, sums, rows_per_block);
     return (int)hipGetLastError();
 }
 

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                                                          double *__restrict__ stats, double *__restrict__ logpj,
                                                          int64_t ldl, uint16_t *__restrict__ nz_idx,
                                                          double *__restrict__ nz_val, int32_t *__restrict__ dense_rows,
-                                                         int32_t *__restrict__ dense_count) {
+                                                         int32_t *__restrict__ dense_count, double *__restrict__ blocks,
+                                                         int64_t ldb) {
     static_assert(!LIST || (LACC && !LPJ), "lists ride on the statistics form of the kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_ndense, s_dbase;
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
 
         // ---- multi-cause states
         double Z = (j == 0) ? exp(-yn * inv_s2 * beta) : 0.0;       // null state (not clamped upstream: libm)
+        double Zm = 0.0;                                            // (LPJ + blocks: the multi-cause states' weights alone)
         if (LPJ && live && j == 0) logpj[n * ldl] = -yn * inv_s2;
         for (int s0 = 0; s0 < ((PM_GSC_ABL & 1) ? 0 : S); s0 += 16) {
             const int s = s0 + j;
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             if (LPJ && live && valid) logpj[n * ldl + 1 + H + s] = lp;
             const double p = gsc_weight(lp * beta, etab);
             if (valid) Z += p;
+            if (LPJ && valid) Zm += p;
 #pragma unroll
             for (int r = 0; r < GMAX; ++r) {
                 if (r < g) {                                   // g == 0 for the padding lanes of the last trip
@@ -481,6 +484,23 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
         }
 
         GSC_STAMP(4);
+        if (LPJ && blocks && live) {
+            // compute_posterior_hprime (gsc_et.py:260-398): this datapoint's un-normalised sums over the multi-cause states, as
+            // they stand in LDS -- [E[s s^T] (H'^2) | E[sz sz^T] (H'^2) | E[s] (H') | E[sz] (H') | sum of the weights]
+            g_sync();
+            double *bo = blocks + n * ldb;
+            for (int p0 = 0; p0 < HH; p0 += 16)
+                if (p0 + j < HH) {
+                    bo[p0 + j] = s_ass[p0 + j];
+                    bo[HH + p0 + j] = s_aszsz[p0 + j];
+                }
+            if (j < Hp) {
+                bo[2 * HH + j] = s_as[j];
+                bo[2 * HH + Hp + j] = s_asz[j];
+            }
+            const double zm = g_row_sum(Zm);
+            if (j == 0) bo[2 * HH + 2 * Hp] = zm;
+        }
         // ---- singletons (gsc_et.py:752-809 with the prior): the scores row is read again (it is still in L2 /
         // the vector cache) rather than held in registers across the loop above
         int64_t row_off = nn * lds;
@@ -827,8 +847,10 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
                             int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
                             int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
                             double *stats, double *logpj, int64_t ldl, void *stream, uint16_t *nz_idx = nullptr,
-                            double *nz_val = nullptr, int32_t *dense_rows = nullptr, int32_t *dense_count = nullptr) {
+                            double *nz_val = nullptr, int32_t *dense_rows = nullptr, int32_t *dense_count = nullptr,
+                            double *blocks = nullptr, int64_t ldb = 0) {
     if (N == 0) return PM_OK;
+    if (blocks && (!logpj || ldb < 2 * Hprime * Hprime + 2 * Hprime + 1)) return PM_EINVAL;
     if (logpj && ldl < 1 + H + S) return PM_EINVAL;
     if (!scores || !gram || !psi_sq || !ynorm2 || !tables || !cand || !xpt_s || !xpt_sz || !stats || N < 0 || H <= 0 ||
         Hprime <= 0 || S < 0 || lds < H || ldx < H || (S > 0 && !state_masks) || !(sigma_sq >= 0.0))
@@ -861,7 +883,7 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
         if (int e = allow_lds_gsc(reinterpret_cast<const void *>(gsc_estep_kernel<V, G, L, A>), shmem)) return e;       \
         hipLaunchKernelGGL((gsc_estep_kernel<V, G, L, A>), grid, block, shmem, s, scores, lds, gram, psi_sq, ynorm2, T, \
                            state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select, cand, xpt_s, xpt_sz,  \
-                           ldx, stats, logpj, ldl, nullptr, nullptr, nullptr, nullptr);                                \
+                           ldx, stats, logpj, ldl, nullptr, nullptr, nullptr, nullptr, blocks, ldb);                   \
     } while (0)
 #define PM_LAUNCH_LIST(V, G)                                                                                           \
     do {                                                                                                               \
@@ -869,7 +891,8 @@ static int gsc_estep_launch(const double *scores, int64_t lds, const double *gra
             return e;                                                                                                  \
         hipLaunchKernelGGL((gsc_estep_kernel<V, G, false, true, true>), grid, block, shmem, s, scores, lds, gram,      \
                            psi_sq, ynorm2, T, state_masks, (int)S, beta, inv_s2, N, (int)H, (int)Hprime, do_select,    \
-                           cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, nz_idx, nz_val, dense_rows, dense_count);      \
+                           cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, nz_idx, nz_val, dense_rows, dense_count,       \
+                           nullptr, 0);                                                                                \
     } while (0)
 #define PM_LAUNCH(V, G)                         \
     do {                                        \
@@ -996,6 +1019,22 @@ extern "C" int pm_gsc_estep_lpj_f64(const double *scores, int64_t lds, const dou
     if (!logpj) return PM_EINVAL;
     return gsc_estep_launch(scores, lds, gram, psi_sq, ynorm2, tables, state_masks, S, gamma, beta, sigma_sq, N, H, Hprime,
                             do_select, cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, stream);
+}
+
+// pm_gsc_estep_lpj_f64 that also hands out every datapoint's un-normalised sums over the multi-cause states (what
+// GSC.compute_posterior_hprime returns, gsc_et.py:260-398), blocks (N, ldb >= 2 H'^2 + 2 H' + 1):
+// [sum_s p_s 1 1^T (H' x H') | sum_s p_s (kappa kappa^T + Lambda^-1) (H' x H') | sum_s p_s (H') | sum_s p_s kappa (H') | sum_s p_s],
+// over the candidates in the order of `cand`; p_s = exp(beta lp_s) clamped as the reference clamps it.
+extern "C" int pm_gsc_estep_lpj_blocks_f64(const double *scores, int64_t lds, const double *gram, const double *psi_sq,
+                                           const double *ynorm2, const double *tables, const uint16_t *state_masks, int64_t S,
+                                           int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
+                                           int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx,
+                                           double *stats, double *logpj, int64_t ldl, double *blocks, int64_t ldb,
+                                           void *stream) {
+    if (!logpj || !blocks) return PM_EINVAL;
+    return gsc_estep_launch(scores, lds, gram, psi_sq, ynorm2, tables, state_masks, S, gamma, beta, sigma_sq, N, H, Hprime,
+                            do_select, cand, xpt_s, xpt_sz, ldx, stats, logpj, ldl, stream, nullptr, nullptr, nullptr, nullptr,
+                            blocks, ldb);
 }
 
 // component_scores (gsc_et.py:752-809): the singleton log-posterior of every latent WITHOUT the prior, with the

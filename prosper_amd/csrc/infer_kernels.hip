@@ -87,7 +87,112 @@ __global__ __launch_bounds__(256) void infer_topk_kernel(const double *__restric
     }
 }
 
+
+// TSC_ET.inference (prosper/em/camodels/tsc_et.py:546-680) after compute_lpj: one log-joint per row of the ternary state table
+// (no null / one-cause prefix), latent values -1 / 0 / +1 per candidate POSITION (state_vals, S x Hp), candidates with
+// possible repeats.  One wavefront per datapoint:
+//   top-K states of the normalised posterior, descending by (value, column) -- and a FLAG when two of the K + 1 best are exactly
+//   equal: states that differ only in which position of a repeated candidate carries the value tie exactly, and the order
+//   NumPy's argsort()[::-1] (:626, an introsort) leaves them in is not a function of (value, column); the caller re-ranks the
+//   flagged rows with NumPy itself and calls again with rank == 0 (top_idx given);
+//   signed and absolute marginals per position, sum_s p_s v_sj and sum_s p_s |v_sj| (:640-655);
+//   the writes into s (N, topK, H) / m / am (N, H) in position order, so that a repeated candidate's LAST position wins, as
+//   upstream; entries of latents outside the candidates are left as they are (upstream never clears a re-run datapoint's).
+__global__ __launch_bounds__(256) void infer_topk_signed_kernel(const double *__restrict__ logpj, int64_t ldl,
+                                                                 const int32_t *__restrict__ cand,
+                                                                 const int8_t *__restrict__ vals, int64_t N, int H, int Hp,
+                                                                 int S, int topK, int rank, int32_t *__restrict__ top_idx,
+                                                                 double *__restrict__ top_lpc, double *__restrict__ top_post,
+                                                                 int32_t *__restrict__ tie, int8_t *__restrict__ s_out,
+                                                                 double *__restrict__ m_out, double *__restrict__ am_out,
+                                                                 int write_am) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t n = wave0; n < N; n += nwaves) {
+        const double *row = logpj + n * ldl;
+        double mx = -INFINITY;
+        for (int k = lane; k < S; k += 64) mx = fmax(mx, row[k]);
+        mx = pm_wave_max(mx);
+        double sum = 0.0;
+        for (int k = lane; k < S; k += 64) sum += exp(row[k] - mx);
+        sum = pm_wave_sum(sum);
+        const double lse = mx + log(sum);
+        if (rank) {
+            double pv = INFINITY;
+            int pi = 0x7FFFFFFF, tied = 0;
+            for (int r = 0; r <= topK && r < S; ++r) {          // (one round past topK: a tie across the cut counts too)
+                double bv = -INFINITY;
+                int bi = -1;
+                for (int k = lane; k < S; k += 64) {
+                    const double v = row[k];
+                    const bool below = (v < pv) || (v == pv && k < pi);
+                    const bool better = (v > bv) || (v == bv && k > bi);
+                    if (below && better && v == v) {
+                        bv = v;
+                        bi = k;
+                    }
+                }
+                pm_wave_argmax(bv, bi);
+                if (r > 0 && bi >= 0 && bv == pv) tied = 1;
+                if (r < topK && lane == 0) top_idx[n * topK + r] = bi;
+                pv = bv;
+                pi = bi;
+                if (bi < 0) pv = -INFINITY, pi = -1;
+            }
+            if (lane == 0) tie[n] = tied;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (top_idx written above is read below)
+        for (int r = lane; r < topK; r += 64) {
+            const int k = top_idx[n * topK + r];
+            const double v = (k >= 0 && k < S) ? row[k] : -INFINITY;
+            top_lpc[n * topK + r] = v - lse;
+            top_post[n * topK + r] = exp(v - lse);
+        }
+        // marginals per position, then the writes in position order (lane 0: the order is the contract)
+        for (int j = 0; j < Hp; ++j) {
+            double a = 0.0, b = 0.0;
+            for (int k = lane; k < S; k += 64) {
+                const double pk = exp(row[k] - lse);
+                const int v = vals[(int64_t)k * Hp + j];
+                a += pk * (double)v;
+                b += pk * (double)(v < 0 ? -v : v);
+            }
+            a = pm_wave_sum(a);
+            b = pm_wave_sum(b);
+            if (lane == 0) {
+                const int c = cand[n * Hp + j];
+                m_out[n * H + c] = a;
+                if (write_am) am_out[n * H + c] = b;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // position j + 1 may hit the same latent
+        }
+        for (int r = lane; r < topK; r += 64) {
+            const int k = top_idx[n * topK + r];
+            if (k < 0 || k >= S) continue;
+            int8_t *srow = s_out + (n * topK + r) * H;
+            for (int j = 0; j < Hp; ++j) srow[cand[n * Hp + j]] = vals[(int64_t)k * Hp + j];   // (a lane's own stores: in order)
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int pm_infer_topk_signed_f64(const double *logpj, int64_t ldl, const int32_t *cand, const int8_t *state_vals,
+                                        int64_t N, int64_t H, int64_t Hprime, int64_t S, int64_t topK, int rank,
+                                        int32_t *top_idx, double *top_lpc, double *top_post, int32_t *tie, int8_t *s_out,
+                                        double *m_out, double *am_out, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!logpj || !cand || !state_vals || !top_idx || !top_lpc || !top_post || !s_out || !m_out || N < 0 || H <= 0 ||
+        Hprime <= 0 || S <= 0 || topK <= 0 || ldl < S || (rank && !tie))
+        return PM_EINVAL;
+    if (Hprime > PM_MAX_HPRIME || topK > S) return PM_ERANGE;
+    int64_t blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(infer_topk_signed_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), logpj,
+                       ldl, cand, state_vals, N, (int)H, (int)Hprime, (int)S, (int)topK, rank, top_idx, top_lpc, top_post, tie,
+                       s_out, m_out, am_out ? am_out : m_out, am_out ? 1 : 0);
+    return (int)hipGetLastError();
+}
 
 extern "C" int pm_infer_topk_f64(const double *logpj, int64_t ldl, const int32_t *cand, const uint16_t *state_masks,
                                  int64_t N, int64_t H, int64_t Hprime, int64_t S, int64_t topK, int32_t *top_idx,

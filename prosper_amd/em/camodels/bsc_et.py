@@ -642,7 +642,8 @@ class BSC_ET(DeviceCAModel):
             stats = ms["stats"]                       # (the workspace that pass accumulated into: see _launch_estep)
         else:
             self._stats_flip = 1 - getattr(self, "_stats_flip", 0)
-            stats = self._buf("stats%d" % self._stats_flip, (n_stats,))
+            # (with 'mu' learned the D column sums of the kept datapoints ride behind the statistics: one buffer, one all-reduce)
+            stats = self._buf("stats%d" % self._stats_flip, (n_stats + (D if 'mu' in self.to_learn else 0),))[:n_stats]
         self._ws["stats"] = stats                     # (the workspace of THIS M-step, for tools and tests)
         done, nz = 0, None
         if (ms is not None and ms["res"] is res and ms["stats"] is stats and ms["expect"] is expect and ms["cand"] is cand
@@ -699,10 +700,13 @@ class BSC_ET(DeviceCAModel):
         elif my_N:
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, st)
         need_mu = 'mu' in self.to_learn
-        if need_mu:
-            keep = (lse >= lse_cut).to(torch.float64)
-            data_sum = torch.mv(Y.t(), keep) if my_N else torch.zeros(D, dtype=torch.float64, device=self.device)
-            packed = torch.cat([stats, data_sum])
+        if need_mu:       # my_data_sum over the kept datapoints (bsc_et.py:422-430): one pass over the shard
+            packed = self._ws["stats%d" % self._stats_flip]
+            assert packed.numel() == n_stats + D and packed.data_ptr() == stats.data_ptr()
+            packed[n_stats:].zero_()
+            if my_N:
+                self._call("data_sum", "pm_col_sum_kept_f64", _ptr(Y), Y.stride(0), my_N, D, _ptr(lse),
+                           ctypes.c_double(lse_cut), ctypes.c_void_p(packed.data_ptr() + 8 * n_stats), st)
         else:
             packed = stats
 

@@ -518,55 +518,32 @@ class GSC(DeviceCAModel):
                'pstr_szsz': np.zeros((n, H, H)), 'post_nfac_n': np.zeros(n)}
         if n == 0 or S == 0:
             return out
-        # log-joints of the states over the SORTED candidates (the kernel's enumeration)
-        order = np.argsort(comps, kind="stable")
-        sorted_c = comps[order]
+        # One pass of the E-step kernel with the candidates handed in, SORTED (its enumeration): besides the log-joints it leaves
+        # every datapoint's sums over the multi-cause states as they stand in its LDS blocks (pm_gsc_estep_lpj_blocks_f64) --
+        # the state weights exp(beta lp) with the reference's clamp, kappa and Lambda^-1 are the kernel's own.  The blocks are
+        # indexed by candidate POSITION; scattering them by latent index makes the caller's order of the candidates immaterial.
+        sorted_c = np.sort(comps, kind="stable")
         res = self._resident(y)
+        par = self._tables_for(model_params, res)
         cand_in = self._device_candidates(np.tile(sorted_c[None, :], (n, 1)), n)
+        A = self._gemm_nt(res["Y"], par["Wst"], self._buf("scores", (n, H)), "scores_gemm")
+        ldb = 2 * Hp * Hp + 2 * Hp + 1
+        blocks = torch.empty((n, ldb), dtype=torch.float64, device=dev)
         logpj = torch.empty((n, 1 + H + S), dtype=torch.float64, device=dev)
-        self._run(1.0, model_params, res, cand_in, logpj=logpj)
-        lp = logpj[:, 1 + H:]
-        SM = self.state_matrix.astype(bool)
-        rank = np.empty(Hp, dtype=np.int64)
-        rank[order] = np.arange(Hp)                     # position of caller's candidate j among the sorted ones
-        index_of = {tuple(np.nonzero(row)[0]): i for i, row in enumerate(SM)}
-        W = torch.from_numpy(np.asarray(model_params['W'], dtype=np.float64)).to(dev)
-        mu = torch.from_numpy(np.asarray(model_params['mu'], dtype=np.float64)).to(dev)
-        psi = torch.from_numpy(np.asarray(model_params['psi_sq'], dtype=np.float64)).to(dev)
-        sig = np.asarray(model_params['sigma_sq'], dtype=np.float64)
-        Y = res["Y"]
-        P_s = torch.zeros((n, H), dtype=torch.float64, device=dev)
-        P_sz = torch.zeros_like(P_s)
-        P_ss = torch.zeros((n, H, H), dtype=torch.float64, device=dev)
-        P_zz = torch.zeros_like(P_ss)
-        nfac = torch.zeros(n, dtype=torch.float64, device=dev)
-        if sig.ndim == 2:
-            Sinv = torch.linalg.inv(torch.from_numpy(sig).to(dev))
-        for s_i, row in enumerate(SM):
-            a = np.nonzero(row)[0]                       # active positions in the CALLER's candidate order
-            lat = torch.from_numpy(comps[a]).to(dev)
-            k_i = index_of[tuple(sorted(rank[a]))]       # the same set of latents in the kernel's enumeration
-            post = torch.exp(lp[:, k_i] * beta)
-            post = torch.where(torch.isnan(post) | (post < tiny), torch.full_like(post, tiny), post)
-            W_s, mu_s = W[:, lat], mu[lat]
-            psi_s = psi[lat][:, lat]
-            if sig.ndim == 0:
-                sW = W_s / float(sig)
-            elif sig.ndim == 1:
-                sW = W_s / torch.from_numpy(sig).to(dev)[:, None]
-            else:
-                sW = Sinv @ W_s
-            lam_inv = torch.linalg.inv(sW.t() @ W_s + torch.linalg.inv(psi_s))
-            kappa = (Y - (W_s @ mu_s)[None, :]) @ (lam_inv @ sW.t()).t() + mu_s[None, :]
-            ksq = kappa[:, :, None] * kappa[:, None, :] + lam_inv[None, :, :]
-            nfac += post
-            P_s[:, lat] += post[:, None]
-            P_sz[:, lat] += kappa * post[:, None]
-            ii, jj = torch.meshgrid(lat, lat, indexing="ij")
-            P_ss[:, ii, jj] += post[:, None, None]
-            P_zz[:, ii, jj] += ksq * post[:, None, None]
-        out = {'pstr_s': P_s.cpu().numpy(), 'pstr_ss': P_ss.cpu().numpy(), 'pstr_sz': P_sz.cpu().numpy(),
-               'pstr_szsz': P_zz.cpu().numpy(), 'post_nfac_n': nfac.cpu().numpy()}
+        both = torch.empty((n, 2 * H), dtype=torch.float64, device=dev)
+        stats = torch.zeros(int(_lib.load().pm_gsc_stats_len(H)), dtype=torch.float64, device=dev)
+        self._call("estep", "pm_gsc_estep_lpj_blocks_f64", _ptr(A), H, _ptr(par["G"]), _ptr(par["psi_d"]), _ptr(par["yn"]),
+                   _ptr(par["tables"]), _ptr(self._masks()), S, self.gamma, ctypes.c_double(beta), ctypes.c_double(par["s2"]),
+                   n, H, Hp, 0, _ptr(cand_in), _ptr(both), ctypes.c_void_p(both.data_ptr() + 8 * H), 2 * H, _ptr(stats),
+                   _ptr(logpj), logpj.stride(0), _ptr(blocks), ldb, self._stream())
+        blk = blocks.cpu().numpy()
+        HH = Hp * Hp
+        ii, kk = np.meshgrid(sorted_c, sorted_c, indexing="ij")
+        out['pstr_ss'][:, ii, kk] = blk[:, :HH].reshape(n, Hp, Hp)
+        out['pstr_szsz'][:, ii, kk] = blk[:, HH:2 * HH].reshape(n, Hp, Hp)
+        out['pstr_s'][:, sorted_c] = blk[:, 2 * HH:2 * HH + Hp]
+        out['pstr_sz'][:, sorted_c] = blk[:, 2 * HH + Hp:2 * HH + 2 * Hp]
+        out['post_nfac_n'][:] = blk[:, 2 * HH + 2 * Hp]
         return out
 
     def candidates(self, model_params, my_data):

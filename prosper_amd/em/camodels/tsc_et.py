@@ -120,36 +120,44 @@ class TSC_ET(DeviceCAModel):
                 cd = (cand.tensor if isinstance(cand, DeviceArray) else torch.as_tensor(np.asarray(cand)).to(dev)).long()
                 n_cur, S = lp.shape
                 Hp = self.Hprime
-                rel = lp - lp.max(dim=1, keepdim=True).values
-                pjc = torch.exp(rel)
-                denom = pjc.sum(dim=1, keepdim=True)
-                lpc = rel - torch.log(denom)
-                post = pjc / denom
                 k_eff = min(topK, S)
-                # states that differ only in WHICH position of a repeated candidate is active tie exactly; their
-                # order is whatever NumPy's argsort makes of it upstream (tsc_et.py:626) -- rank on the host
-                order = np.argsort(lpc.cpu().numpy(), axis=-1)[:, ::-1][:, :k_eff]
-                top_idx = torch.from_numpy(np.ascontiguousarray(order)).to(dev)
-                top_val = torch.gather(lpc, 1, top_idx)
+                # top-K states, signed / absolute marginals and the writes into s / m / am in position order: one HIP pass
+                # (pm_infer_topk_signed_f64).  States that differ only in WHICH position of a repeated candidate is active tie
+                # exactly, and the order NumPy's argsort()[::-1] (tsc_et.py:626, an introsort) gives exact ties is not a
+                # function of (value, column): the kernel flags the rows with a tie among their topK + 1 best, those -- a
+                # handful -- are ranked with NumPy itself, and the pass runs again with the ranking handed in.
+                lp = lp.contiguous() if lp.stride(1) != 1 else lp
+                cd32 = cd.to(torch.int32).contiguous()
+                vals = torch.from_numpy(np.ascontiguousarray(self.state_matrix.astype(np.int8))).to(dev)
+                top_idx = torch.empty((n_cur, k_eff), dtype=torch.int32, device=dev)
+                top_lpc = torch.empty((n_cur, k_eff), dtype=torch.float64, device=dev)
+                top_post = torch.empty((n_cur, k_eff), dtype=torch.float64, device=dev)
+                tie = torch.zeros(n_cur, dtype=torch.int32, device=dev)
+                s_blk = res_s[ind_n, :k_eff].contiguous()
+                m_blk, am_blk = res_m[ind_n].contiguous(), res_am[ind_n].contiguous()
+
+                def run(rank):
+                    self._call("infer_topk", "pm_infer_topk_signed_f64", _ptr(lp), lp.stride(0), _ptr(cd32), _ptr(vals), n_cur,
+                               H, Hp, S, k_eff, rank, _ptr(top_idx), _ptr(top_lpc), _ptr(top_post), _ptr(tie), _ptr(s_blk),
+                               _ptr(m_blk), _ptr(am_blk) if abs_marginal else None, self._stream())
+                run(1)
+                if bool((top_idx < 0).any()):
+                    raise _lib.HipError("inference: non-finite log-joints (NaN) in %d datapoint(s)"
+                                        % int((top_idx < 0).any(dim=1).sum()))
+                tied = torch.nonzero(tie).flatten()
+                if tied.numel():
+                    rows = lp[tied].cpu().numpy()
+                    rel = rows - rows.max(axis=1, keepdims=True)
+                    lpc = rel - np.log(np.exp(rel).sum(axis=1, keepdims=True))
+                    order = np.argsort(lpc, axis=-1)[:, ::-1][:, :k_eff]
+                    top_idx[tied] = torch.from_numpy(np.ascontiguousarray(order).astype(np.int32)).to(dev)
+                    run(0)
                 res_Hprime[ind_n] = float(self.Hprime)
                 res_gamma[ind_n] = float(self.gamma)
-                SM = torch.from_numpy(self.state_matrix.astype(np.int8)).to(dev)
-                SMf = SM.to(torch.float64)
-                s_blk = res_s[ind_n, :k_eff].clone()
-                rows = SM[top_idx]                                        # (n, k_eff, Hp) latent values
-                marg = post @ SMf                                         # (n, Hp)
-                amarg = post @ SMf.abs()
-                m_blk, am_blk = res_m[ind_n].clone(), res_am[ind_n].clone()
-                rn = torch.arange(n_cur, device=dev)
-                for j in range(Hp):                                       # in order: the last position wins
-                    s_blk[rn[:, None], torch.arange(k_eff, device=dev)[None, :], cd[:, j][:, None]] = rows[:, :, j]
-                    m_blk[rn, cd[:, j]] = marg[:, j]
-                    if abs_marginal:
-                        am_blk[rn, cd[:, j]] = amarg[:, j]
                 res_s[ind_n, :k_eff] = s_blk
                 res_m[ind_n] = m_blk
                 res_am[ind_n] = am_blk
-                res_p[ind_n, :k_eff] = top_val if logprob else torch.gather(post, 1, top_idx)
+                res_p[ind_n, :k_eff] = top_lpc if logprob else top_post
                 if not adaptive:
                     break
                 which = ((res_s[:, 0, :] != 0).sum(-1) == self.gamma)

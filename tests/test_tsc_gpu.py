@@ -118,11 +118,18 @@ def test_tsc_inference_matches_reference(tag, kw, capsys):
     from prosper_amd.em.camodels.tsc_et import TSC_ET
     g = golden("tsc_inference.npz")
     D, H, Hp, gamma = int(g["D"]), int(g["H"]), int(g["Hprime"]), int(g["gamma"])
+    from prosper_amd.em.camodels._device import KernelTimer
     m = TSC_ET(D, H, Hp, gamma)
     S0 = m.state_matrix.shape[0]
+    m.timer = KernelTimer()
     with np.errstate(invalid="ignore"):
         res = m.inference(_An(T=1.0), {"W": g["W"].copy(), "pi": float(g["pi"]), "sigma": float(g["sigma"])},
                           {"y": g["y"]}, **kw)
+    # ranking, marginals and the writes into s / m / am are one HIP pass (pm_infer_topk_signed_f64); this golden has rows with
+    # exactly tied states among their best, which the kernel flags and NumPy ranks: the pass runs a second time for them
+    launches = m.timer.summary()["infer_topk"][0]
+    m.timer = None
+    assert launches >= 2 if tag == "plain" else launches >= 1
     assert (m.Hprime, m.gamma, m.state_matrix.shape[0]) == (Hp, gamma, S0)
     assert np.array_equal(res["gamma"], g[tag + "_gamma"]) and np.array_equal(res["Hprime"], g[tag + "_Hprime"])
     np.testing.assert_allclose(res["p"], g[tag + "_p"], rtol=1e-8, atol=1e-12)
