@@ -171,17 +171,23 @@ extern "C" int pm_gemm_nt_small_f64(const double *A, int64_t lda, const double *
 extern "C" int pm_gemm_nn_small_f64(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                                     int64_t M, int64_t N, int64_t K, void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldb < N || ldc < N) return PM_EINVAL;
-    if (M > 1024 || N > 65536) return PM_ERANGE;
-    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16)), block(64 * SW);
+    if (M > 1024) return PM_ERANGE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int al = (al16(A) && lda % 2 == 0 && K % 4 == 0) ? 1 : 0;
     const int64_t per_wave = ((K + CH - 1) / CH + SW - 1) / SW;
+    // (columns in slabs of 65536: the solve products of an M-step with more observed dimensions than one grid row holds)
+    for (int64_t n0 = 0; n0 < N; n0 += 65536) {
+        const int64_t Nc = N - n0 < 65536 ? N - n0 : 65536;
+        const double *Bc = B + n0;
+        double *Cc = C + n0;
+        const dim3 grid((unsigned)((Nc + 15) / 16), (unsigned)((M + 15) / 16)), block(64 * SW);
 #define PM_NN_SMALL(U) \
-    hipLaunchKernelGGL((gemm_nn_small_kernel<U>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, K, al)
-    if (per_wave <= 1) PM_NN_SMALL(1);
-    else if (per_wave <= 2) PM_NN_SMALL(2);
-    else if (per_wave <= 4) PM_NN_SMALL(4);
-    else PM_NN_SMALL(8);
+    hipLaunchKernelGGL((gemm_nn_small_kernel<U>), grid, block, 0, s, A, lda, Bc, ldb, Cc, ldc, (int)M, (int)Nc, K, al)
+        if (per_wave <= 1) PM_NN_SMALL(1);
+        else if (per_wave <= 2) PM_NN_SMALL(2);
+        else if (per_wave <= 4) PM_NN_SMALL(4);
+        else PM_NN_SMALL(8);
 #undef PM_NN_SMALL
+    }
     return (int)hipGetLastError();
 }

@@ -549,20 +549,25 @@ class DeviceCAModel(CAModel):
         per ``step`` -- select_Hprimes, E_step and M_step see the same array object there, and a 256 x 128 comparison costs
         27 us of host time that sits on the loop's critical path (three of them per step until round 4: the device idled
         ~0.1 ms per 0.7 ms iteration waiting for the E-step launch)."""
+        W_in = W
         W = np.asarray(W, dtype=np.float64)
         par = self._par
-        tag = (getattr(self, "_step_id", 0), id(W)) if getattr(self, "_in_step", False) else None
-        if tag is not None and par.get("checked") == tag and par.get("ykey") == res["key"]:
+        # The once-per-step shortcut keys on the IDENTITY of the caller's array, so only for an object that is already the
+        # float64 ndarray the comparison would read (a converted temporary's id() can be recycled), and the record keeps a
+        # reference to it (an id() is only unique among live objects).  Contract: W is not edited in place between
+        # select_Hprimes, E_step and M_step of one ``step`` (CAModel.step never does).
+        tag = (getattr(self, "_step_id", 0), id(W)) if (getattr(self, "_in_step", False) and W is W_in) else None
+        if tag is not None and par.get("checked") == tag and par.get("checked_obj") is W and par.get("ykey") == res["key"]:
             return par
         if getattr(self, "_seed_rec", None) is not None:
             seeded = self._take_seed(W, res)
             if seeded is not None:           # W^T, Gram matrix and scores left on the device by the last M-step
-                seeded["checked"] = tag
+                seeded["checked"], seeded["checked_obj"] = tag, (W if tag is not None else None)
                 self._par = seeded
                 return seeded
         if par.get("ykey") == res["key"] and par.get("W") is not None and par["W"].shape == W.shape \
                 and np.array_equal(par["W"], W):
-            par["checked"] = tag
+            par["checked"], par["checked_obj"] = tag, (W if tag is not None else None)
             return par
         Wt = self._upload("W", W).t().contiguous()
         G = self._gemm_nt(Wt, Wt, self._buf("gram", (self.H, self.H)), "gram_gemm")
@@ -570,7 +575,8 @@ class DeviceCAModel(CAModel):
         A = self._buf("scores", (Y.shape[0], self.H))
         if Y.shape[0]:
             self._gemm_nt(Y, Wt, A, "scores_gemm")
-        self._par = {"ykey": res["key"], "W": W.copy(), "Wt": Wt, "G": G, "A": A, "checked": tag}
+        self._par = {"ykey": res["key"], "W": W.copy(), "Wt": Wt, "G": G, "A": A, "checked": tag,
+                     "checked_obj": W if tag is not None else None}
         return self._par
 
     def _take_seed(self, W, res):

@@ -130,6 +130,7 @@ class GSC(DeviceCAModel):
         self._spec = None        # next step's whole E-step, launched by M_step from device-side parameters
         self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
         self.spec_hits = 0
+        self.inverse_fallbacks = 0    # EM steps whose device inverses were rejected (host LAPACK took over, speculation void)
         self._in_step = False
         self._anneal_sig = None
         self._flat_schedule = False
@@ -730,6 +731,8 @@ class GSC(DeviceCAModel):
             # the reference inverts it as it is (:625): the left-sided Newton-Schulz refinement of pm_inverse_warm_batch_f64
             # (its result is the inverse of the transpose -- what W_new^T = (A^-1)^T Wp^T needs), started from the previous
             # EM step's inverses or, cold, from the sweep's inverses of the upper-mirrored matrices (within ~1e-6).
+            # (PM_WARM_INVERSE=0 only forces the cold START below; the Newton-Schulz pass itself is not optional here -- it is what
+            # inverts the general matrix, the sweep alone only knows its upper-mirrored stand-in)
             dadd = self._eps_diag(H, eps)
             prev = getattr(self, "_inv_prev", None)
             if not (prev is not None and tuple(prev.shape) == (2, H, H) and os.environ.get("PM_WARM_INVERSE", "1") == "1"):
@@ -822,6 +825,9 @@ class GSC(DeviceCAModel):
                 inverses = (tail[nHH:2 * nHH].reshape(H, H).T, tail[:nHH].reshape(H, H))    # (zz^-1, (ss + eps I)^-1)
         if inverses is None:
             self._inv_prev = None             # never warm-start the next inverses from rejected ones
+            # (counted: a psi_sq asymmetric enough for the symmetrised cold start to be rejected step after step would put
+            # every step on the host fallback -- correct results, a silent performance cliff otherwise)
+            self.inverse_fallbacks += 1
         if inverses is None or W_given is None or not np.isfinite(W_given).all():
             W_given, self._seed, dev_params = None, None, None       # host fallback: whatever was speculated is void
         elif self._seed is not None:
