@@ -152,7 +152,8 @@ class BSC_ET(DeviceCAModel):
     def install_parameters(self, data, Wt_dev, Wt_host):
         """Install a W^T (H,D) that already lives on the device -- the state an M-step leaves behind --
         for the shard ``data['y']``: the Gram matrix is recomputed and scores of earlier parameters are
-        dropped.  ``Wt_host`` is the caller's host copy of the same matrix (checked against the W of later calls)."""
+        dropped.  ``Wt_host`` is the caller's host copy of the same matrix (checked against the W of later calls: it is
+        kept by reference, so it must not share memory with an array the caller goes on to edit)."""
         res = self._resident(data['y'])
         G = self._gemm_nt(Wt_dev, Wt_dev, self._buf("gram", (self.H, self.H)), "gram_gemm")
         par = self._seed_params(res, Wt_dev, G, False)
@@ -824,7 +825,9 @@ class BSC_ET(DeviceCAModel):
                     Xr = self._redo_dev
                     G = self._gemm_nt(Xr, Xr, torch.empty((H, H), dtype=torch.float64, device=Xr.device), "gram_gemm")
                     par = self._seed_params(res, Xr, G, False)
-                    par["Whost"] = W_new
+                    # (a PRIVATE snapshot: the caller gets a view of W_new and may edit it in place -- found by
+                    # tests/test_call_sequences_gpu.py: the shared array hid such an edit from _same_W)
+                    par["Whost"] = W_new.copy()
                     self._par = par
                 self._spec_estep = None
             elif ok:

@@ -1,0 +1,336 @@
+"""Randomised call sequences against the oracle: the host layer of the HIP models is stateful -- resident shards, parameters
+left on the device, speculatively launched E-steps, statistics workspaces that alternate, non-zero lists, warm-started
+inverses -- and decides by array identity and cached snapshots what it may reuse (camodels/bsc_et.py, gsc_et.py, mca_et.py,
+dsc_et.py, _device.py).  Hand-picked transparency tests found the stale-state defects of rounds 2-4 one at a time; here seeded
+random sequences over
+
+    step | select -> E -> M by hand | ... looking at the candidates first | ... handing NumPy copies to M_step | E_step alone |
+    edit W in place | replace pi / sigma | fresh copies of all parameters | change T | toggle Ncut_factor / anneal_prior |
+    partial data | swap the data shard | (BSC) install_parameters
+
+run on ONE model instance per sequence, and every result is compared with the oracle applied to a deep copy of the same inputs
+(oracle/*_oracle.py: the reference's algorithm restated on the CPU, pinned to the reference by tests/golden).  Small shapes:
+the point is the bookkeeping, not the kernels' numerics (tests/test_*_gpu.py hold those)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class _An(dict):
+    crit_params = []
+
+    def __missing__(self, k):
+        return 0.0
+
+    def as_dict(self):
+        return dict(self)
+
+
+def _copy(p):
+    return {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+
+
+def _close(got, ref, rtol, atol_rel, what):
+    ref = np.asarray(ref, dtype=np.float64)
+    np.testing.assert_allclose(np.asarray(got, dtype=np.float64), ref, rtol=rtol,
+                               atol=atol_rel * max(1.0, float(np.abs(ref).max())), err_msg=what)
+
+
+# --------------------------------------------------------------------------------------------------------------- adapters
+class _BSC:
+    name, keys, has_cut, n_seq = "bsc", ("W", "pi", "sigma"), True, 200
+    D, H, Hp, gamma = 20, 12, 5, 3
+
+    def __init__(self):
+        from oracle import bsc_oracle as O
+        self.O = O
+        self.omodel = O.make_model(self.D, self.H, self.Hp, self.gamma)
+
+    def make(self):
+        from prosper_amd.em.camodels.bsc_et import BSC_ET
+        return BSC_ET(self.D, self.H, self.Hp, self.gamma)
+
+    def data(self, rng, N):
+        self.W_gt = getattr(self, "W_gt", None) if getattr(self, "W_gt", None) is not None else rng.normal(size=(self.D, self.H))
+        return self.O.generate_bsc_data(self.W_gt, 2.0 / self.H, 1.0, N, rng)[0]
+
+    def init(self, rng):
+        return {"W": self.W_gt + 0.2 * rng.normal(size=(self.D, self.H)), "pi": 2.5 / self.H, "sigma": 1.1}
+
+    def oracle(self, an, params, y):
+        oa = self.O.Anneal(an)
+        oa.crit_params = []
+        p = {k: params[k] for k in self.keys}
+        if "mu" in params:
+            p["mu"] = params["mu"]
+        new, log = self.O.em_step(oa, self.omodel, p, y, stats_fn=self.O.m_step_stats_vec, vec=True)
+        self.cond = float(np.linalg.cond(log["stats"]["Wq"]))          # (W_new solves a system with this matrix)
+        return new, log["candidates"], log["logpj"]
+
+    def tie_rows(self, got, cand, params, y):
+        """Rows whose candidates differ from the oracle's; each must be an exact tie of the ranked scores (the reference's
+        argsort leaves the order of equal scores to NumPy's introsort), else it is a defect."""
+        got = np.asarray(got).astype(np.int64)
+        bad = np.nonzero((got != cand).any(axis=1))[0]
+        if bad.size:
+            sc = self.rank_scores(params, y)
+            a, b = np.take_along_axis(sc[bad], got[bad], 1), np.take_along_axis(sc[bad], cand[bad], 1)
+            assert np.array_equal(np.sort(a, axis=1), np.sort(b, axis=1)), \
+                "%d rows with other candidates than the oracle's, not ties: e.g. row %d %s vs %s" % (bad.size, bad[0], got[bad[0]], cand[bad[0]])
+        return bad
+
+    def rank_scores(self, params, y):
+        W = np.asarray(params["W"])
+        return (y @ W) / np.sqrt((W * W).sum(axis=0))[None, :]
+
+    def check_estep(self, data, ss, cand, logpj, params, y):
+        bad = self.tie_rows(data["candidates"], cand, params, y)
+        ok = np.ones(cand.shape[0], dtype=bool)
+        ok[bad] = False
+        np.testing.assert_allclose(np.asarray(ss["logpj"])[ok], logpj[ok], rtol=1e-10, atol=1e-9)
+        return bad.size == 0
+
+    def foreign(self, data, ss, y):
+        return {"y": y, "candidates": np.asarray(data["candidates"]).astype(np.int64)}, {"logpj": np.array(np.asarray(ss["logpj"]))}
+
+    cond = 1.0
+
+    def check_params(self, new, ref, log=None):
+        tol = max(1e-8, 20 * self.cond * np.finfo(float).eps)
+        for k in self.keys:
+            _close(new[k], ref[k], 100 * tol, tol, "%s %s (cond %.2e)" % (self.name, k, self.cond))
+
+    def scale(self, params, rng):
+        params["pi"] = float(params["pi"]) * rng.uniform(0.8, 1.2)
+        params["sigma"] = float(params["sigma"]) * rng.uniform(0.9, 1.1)
+
+
+class _MCA(_BSC):
+    name, keys = "mca", ("W", "pi", "sigma")
+
+    def __init__(self):
+        from oracle import mca_oracle as O, bsc_oracle as B
+        self.O, self.B = O, B
+        self.omodel = B.make_model(self.D, self.H, self.Hp, self.gamma)
+
+    def make(self):
+        from prosper_amd.em.camodels.mca_et import MCA_ET
+        return MCA_ET(self.D, self.H, self.Hp, self.gamma)
+
+    def data(self, rng, N):
+        if getattr(self, "W_gt", None) is None:
+            self.W_gt = np.abs(rng.normal(size=(self.D, self.H))) * 3.0 + 0.1
+        return self.O.generate_mca_data(self.W_gt, 2.0 / self.H, 1.0, N, rng)[0]
+
+    def init(self, rng):
+        return {"W": self.W_gt * rng.uniform(0.8, 1.25, size=self.W_gt.shape), "pi": 2.5 / self.H, "sigma": 1.1}
+
+    def oracle(self, an, params, y):
+        oa = self.B.Anneal(an)
+        new, log = self.O.em_step(oa, self.omodel, {k: params[k] for k in self.keys}, y, vec=True)
+        return new, log["candidates"], log["logpj"]
+
+    def rank_scores(self, params, y):       # (a latent that lies below the datapoint everywhere scores exactly 0: ties happen)
+        return self.O.select_scores_vec(self.O.check_params(_copy(params))["W"], y)
+
+
+class _DSC(_BSC):
+    name, keys, n_seq = "dsc", ("W", "pi", "sigma"), 100
+    D, H, Hp, gamma = 16, 10, 4, 2
+    states = np.array([-1.0, 0.0, 1.0, 2.0])
+
+    def __init__(self):
+        from oracle import dsc_oracle as O, bsc_oracle as B
+        self.O, self.B = O, B
+        self.omodel = O.make_model(self.D, self.H, self.Hp, self.gamma, self.states)
+
+    def make(self):
+        from prosper_amd.em.camodels.dsc_et import DSC_ET
+        return DSC_ET(self.D, self.H, self.Hp, self.gamma, states=self.states.copy())
+
+    def data(self, rng, N):
+        if getattr(self, "W_gt", None) is None:
+            self.W_gt = rng.normal(size=(self.D, self.H))
+        pi = np.array([0.06, 0.8, 0.1, 0.04])
+        s = self.states[rng.choice(4, size=(N, self.H), p=pi)]
+        return s @ self.W_gt.T + rng.normal(size=(N, self.D))
+
+    def init(self, rng):
+        return {"W": self.W_gt + 0.2 * rng.normal(size=(self.D, self.H)), "pi": np.array([0.08, 0.76, 0.1, 0.06]), "sigma": 1.1}
+
+    def oracle(self, an, params, y):
+        oa = self.B.Anneal(an)
+        new, log = self.O.em_step(oa, self.omodel, {k: params[k] for k in self.keys}, y, vec=True)
+        self.cond = float(np.linalg.cond(log["stats"]["Wq"]))
+        return new, log["candidates"], log["logpj"]
+
+    def rank_scores(self, params, y):
+        return self.O.select_scores_vec(self.omodel, params["W"], params["pi"], params["sigma"], y)
+
+    def scale(self, params, rng):
+        pi = np.asarray(params["pi"]) * rng.uniform(0.8, 1.25, size=4)
+        params["pi"] = pi / pi.sum()
+        params["sigma"] = float(params["sigma"]) * rng.uniform(0.9, 1.1)
+
+
+class _GSC(_BSC):
+    name, keys, has_cut, n_seq = "gsc", ("W", "pi", "mu", "psi_sq", "sigma_sq"), False, 200
+    D, H, Hp, gamma = 20, 12, 4, 3
+
+    def __init__(self):
+        from oracle import gsc_oracle as O
+        self.O = O
+        self.omodel = O.make_model(self.D, self.H, self.Hp, self.gamma)
+
+    def make(self):
+        from prosper_amd.em.camodels.gsc_et import GSC
+        return GSC(self.D, self.H, self.Hp, self.gamma, "scalar")
+
+    def data(self, rng, N):
+        if getattr(self, "gt", None) is None:
+            self.gt = {"W": rng.normal(size=(self.D, self.H)), "pi": np.full(self.H, 2.0 / self.H), "mu": np.full(self.H, 1.5),
+                       "psi_sq": np.eye(self.H), "sigma_sq": 1.0}
+        return self.O.generate_gsc_data(self.gt, N, rng)[0]
+
+    def init(self, rng):
+        H, Q = self.H, 0.05 * rng.normal(size=(self.H, self.H))
+        return {"W": self.gt["W"] + 0.1 * rng.normal(size=(self.D, H)),
+                "pi": np.clip(self.gt["pi"] * rng.uniform(0.8, 1.3, size=H), 0.01, 0.9), "mu": self.gt["mu"] + 0.1 * rng.normal(size=H),
+                "psi_sq": np.diag(rng.uniform(0.7, 1.4, size=H)) + Q @ Q.T, "sigma_sq": 1.2}
+
+    def oracle(self, an, params, y):
+        new, log = self.O.em_step(self.O.Anneal(T=an["T"]), self.omodel, _copy({k: params[k] for k in self.keys}), y)
+        return new, log["candidates"], log["suff"]
+
+    def rank_scores(self, params, y):
+        return self.O.component_scores(params, y)
+
+    def check_estep(self, data, ss, cand, suff, params, y):
+        assert np.array_equal(np.asarray(data["candidates"]).astype(np.int64), cand)
+        np.testing.assert_allclose(np.asarray(ss["xpt_s"]), suff["xpt_s"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(np.asarray(ss["xpt_sz"]), suff["xpt_sz"], rtol=1e-8, atol=1e-12)
+        return True
+
+    def foreign(self, data, ss, y):
+        tot = lambda k: ss[k].sum(axis=0).cpu().numpy()[None]          # (1, H, H): M_step only ever sums over axis 0
+        return ({"y": y, "candidates": np.asarray(data["candidates"]).astype(np.int64)},
+                {"xpt_s": np.array(np.asarray(ss["xpt_s"])), "xpt_sz": np.array(np.asarray(ss["xpt_sz"])),
+                 "xpt_ss": tot("xpt_ss"), "xpt_szsz": tot("xpt_szsz")})
+
+    def check_params(self, new, ref, suff=None):
+        tol = 1e-7
+        if suff is not None:
+            tol = max(1e-8, 50 * np.linalg.cond(suff["xpt_szsz"].sum(0)) * np.finfo(float).eps)
+        for k in self.keys:
+            np.testing.assert_allclose(new[k], ref[k], rtol=10 * tol, atol=tol * max(1.0, float(np.abs(ref[k]).max())),
+                                       err_msg="gsc " + k)
+
+    def scale(self, params, rng):
+        params["pi"] = np.clip(np.asarray(params["pi"]) * rng.uniform(0.9, 1.1, size=self.H), 1e-3, 0.9)
+        params["sigma_sq"] = float(params["sigma_sq"]) * rng.uniform(0.9, 1.1)
+
+
+class _BSCFast(_BSC):          # the shape class of the one-kernel E-step (bsc_fused8.hip: H in (128, 256], H' = 8) and its speculation
+    n_seq = 40
+    D, H, Hp, gamma = 64, 160, 8, 3
+
+
+class _GSCFast(_GSC):          # lists + gathered GEMM + the M-step that launches the next E-step (H = 128, (D + 2 H) % 128 == 0)
+    n_seq = 12
+    D, H, Hp, gamma = 128, 128, 6, 3
+
+
+class _MCAFast(_MCA):          # the fused E-step + M-statistics pass at config-5 latent dimensions
+    n_seq = 15
+    D, H, Hp, gamma = 64, 128, 8, 3
+
+
+_ADAPTERS = {"bsc": _BSC, "mca": _MCA, "dsc": _DSC, "gsc": _GSC, "bsc_fast": _BSCFast, "gsc_fast": _GSCFast,
+             "mca_fast": _MCAFast}
+_COMPARE = ("step", "step", "manual", "peek", "foreign", "estep", "partial")
+_MUTATE = ("edit_W", "scale", "copies", "T", "cut", "prior", "swap", "install")
+
+
+def _run_sequence(A, seed):
+    rng = np.random.RandomState(seed)
+    shards = [A.data(rng, int(rng.randint(150, 320)) + 4 * A.H) for _ in range(2)]
+    params = A.init(rng)
+    an = _An(T=1.0)
+    m = A.make()
+    cur, n_cmp, trail, ties = 0, 0, [], [0]
+    for it in range(9):
+        op = rng.choice(_COMPARE) if (it % 2 == 0 or rng.rand() < 0.4) else rng.choice(_MUTATE)
+        trail.append(op)
+        y = shards[cur]
+        try:
+            if op == "edit_W":                        # the caller's own array, edited in place
+                i, j = rng.randint(A.D), rng.randint(A.H)
+                params["W"][i, j] *= 1.0 + 0.05 * rng.rand()
+            elif op == "scale":
+                A.scale(params, rng)
+            elif op == "copies":
+                params = _copy(params)
+            elif op == "T":
+                an["T"] = float(rng.choice([1.0, 1.15, 1.6]))
+            elif op == "cut":
+                if A.has_cut:
+                    an["Ncut_factor"] = float(rng.choice([0.0, 0.5, 0.9]))
+            elif op == "prior":
+                if A.name[:3] in ("bsc", "dsc"):
+                    an["anneal_prior"] = bool(rng.rand() < 0.5)
+            elif op == "swap":
+                cur = 1 - cur
+            elif op == "install":
+                if A.name.startswith("bsc"):         # the state an M-step leaves on the device, installed by hand (bench.py)
+                    Wt_host = np.array(np.asarray(params["W"]).T, order="C", copy=True)      # (kept by reference: a private copy)
+                    m.install_parameters({"y": y}, torch.from_numpy(Wt_host).to(m.device), Wt_host)
+            else:
+                n_cmp += 1
+                an["partial"] = 0.6 if op == "partial" else 0.0
+                snap = _copy(params)
+                y_ref = y
+                if op == "partial":
+                    np.random.seed(seed * 100 + it)
+                    sel = np.sort(np.random.permutation(y.shape[0])[:int(np.ceil(y.shape[0] * 0.6))])
+                    y_ref = y[sel]
+                    np.random.seed(seed * 100 + it)
+                ref, cand, est = A.oracle(an, snap, y_ref)
+                if op in ("step", "partial"):
+                    new = m.step(an, params, {"y": y})
+                    if A.name[:3] != "gsc" and len(A.tie_rows(m.select_Hprimes(m.check_params(_copy(snap)), {"y": y_ref})["candidates"],
+                                                          cand, snap, y_ref)):
+                        params = _copy(ref)
+                        ties[0] += 1
+                        continue
+                else:
+                    p = m.check_params(params)
+                    data = m.select_Hprimes(p, {"y": y})
+                    if op == "peek":
+                        A.tie_rows(data["candidates"] if A.name[:3] != "gsc" else m.candidates(p, {"y": y}), cand, snap, y)
+                    ss = m.E_step(an, p, data)
+                    same = A.check_estep(data, ss, cand, est, snap, y)
+                    if op == "estep":
+                        continue
+                    if not same:      # a tie in the selection: another (equally valid) state set from here on -- rejoin the oracle
+                        params = _copy(ref)
+                        ties[0] += 1
+                        continue
+                    if op == "foreign":
+                        data, ss = A.foreign(data, ss, y)
+                    new = m.M_step(an, p, ss, data)
+                A.check_params(new, ref, est if A.name[:3] == "gsc" else None)
+                params = new                              # the model's own arrays go back in (what an EM loop does)
+        except AssertionError as e:
+            raise AssertionError("%s seed %d, ops %s: %s" % (A.name, seed, [str(o) for o in trail], str(e)[:1500]))
+    return n_cmp
+
+
+@pytest.mark.parametrize("name", sorted(_ADAPTERS))
+def test_random_call_sequences_match_the_oracle(name):
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    A = _ADAPTERS[name]()
+    total = sum(_run_sequence(A, 1000 + s) for s in range(A.n_seq))
+    assert total >= 4 * A.n_seq
