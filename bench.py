@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--em-steps", type=int, default=20, help="full EM iterations timed for em_iter_ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-models", action="store_true", help="skip the GSC / MCA EM-iteration side measurements")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the E-step passes at off-config shapes")
     ap.add_argument("--cpu-budget", type=float, default=8.0)
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed E-step passes by wall time before the warm-up")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
@@ -237,6 +238,133 @@ def other_models(dev, Anneal, steps=20):
                         "dsc_estep16_ms_kernel (log-joints of the K-ary states + the M-step's row statistics, one pass)")
     except Exception as e:   # never lose the headline over the side measurements
         out["error"] = repr(e)
+    gc.enable()
+    return out
+
+
+OTHER_SHAPES = ((256, 128, 6, 3), (1024, 256, 6, 3), (1024, 256, 10, 4), (784, 400, 8, 3), (1024, 512, 8, 4), (4096, 1024, 10, 3))
+
+
+def other_shapes(dev, Anneal, budget_s=40.0):
+    """The E-step pass (the headline's estep_pass: new W^T installed, Gram + scores + selection + log-joints recomputed) at
+    shapes the reference accepts (it asserts only H' <= H, gamma <= H': camodels/__init__.py:90-91) but no BASELINE config
+    names -- datapoints/s, the fraction of the f64 MFMA roof the scores GEMM's flops amount to (2 D H per datapoint), the
+    fraction of the HBM roof (SURVEY 8d's bytes: y, candidates, logpj) and WHICH code path the host layer took: only
+    H in (128, 256], H' = 8, gamma in {3, 4} runs the tuned 16-wavefront kernel.  Also GSC with gamma = 4 and MCA with H' = 10
+    (EM iteration).  N: 1.2 GB of data per shape at most.  Informational; tests/test_limits_gpu.py holds the same shapes
+    to the oracle."""
+    import gc
+    import numpy as np
+    import torch
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    from prosper_amd.em.camodels._device import KernelTimer
+    out, t_start = [], time.perf_counter()
+    gc.collect()
+    for (D, H, Hp, gamma) in OTHER_SHAPES:
+        rec = {"model": "BSC_ET", "D": D, "H": H, "Hprime": Hp, "gamma": gamma}
+        try:
+            if time.perf_counter() - t_start > budget_s:
+                rec["skipped"] = "time budget"
+                out.append(rec)
+                continue
+            N = int(min(200_000, (1.2e9 / (8 * D)) // 1024 * 1024))
+            g = torch.Generator(device=dev).manual_seed(0)
+            W_gt = torch.randn(D, H, generator=g, device=dev, dtype=torch.float64)
+            Y = torch.empty(N, D, dtype=torch.float64, device=dev)
+            for lo in range(0, N, 25_000):
+                n = min(25_000, N - lo)
+                S = (torch.rand(n, H, generator=g, device=dev) < 4.0 / H).to(torch.float64)
+                Y[lo:lo + n] = S @ W_gt.t() + torch.randn(n, D, generator=g, device=dev, dtype=torch.float64)
+            Wt_dev = (W_gt + 0.1 * torch.randn(D, H, generator=g, device=dev, dtype=torch.float64)).t().contiguous()
+            Wt_host = Wt_dev.cpu().numpy()
+            params = {"W": Wt_host.T, "pi": 4.0 / H, "sigma": 1.0}
+            m = BSC_ET(D, H, Hp, gamma)
+            data, an = {"y": Y}, Anneal(T=1.0)
+
+            def estep_pass():
+                m.install_parameters(data, Wt_dev, Wt_host)
+                return m.E_step(an, params, m.select_Hprimes(params, data))
+            tw = time.perf_counter()
+            while time.perf_counter() - tw < 0.25:
+                estep_pass()
+                torch.cuda.synchronize()
+            gc.disable()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                estep_pass()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 10 * 1e3
+            gc.enable()
+            m.timer = kt = KernelTimer()
+            for _ in range(2):
+                estep_pass()
+            m.timer = None
+            ks = {k: round(v[1], 4) for k, v in kt.summary().items()}
+            K = 1 + H + m.no_states
+            dps = N / (ms * 1e-3)
+            rec.update({"N": N, "K": K, "ms_per_pass": round(ms, 4), "dp_per_s": round(dps),
+                        "estep_mfma_frac": round(dps * 2 * D * H / 78.6e12, 4),
+                        "estep_hbm_frac": round(dps * (8 * D + 4 * Hp + 8 * K) / 8e12, 4),
+                        "path": ("one kernel, 16-wavefront tile (bsc_fused8.hip)" if (m._fused() and m._tile8_whole_shard()) else
+                                 "one kernel, 4-wavefront tile (bsc_fused.hip)" if m._fused() else
+                                 "scores GEMM + 16-lane row kernel (bsc_rows16.hip)" if "select_estep" in ks else
+                                 "scores GEMM + select + E-step kernels (bsc_kernels.hip)"),
+                        "kernels_ms": ks})
+            del Y, m
+            torch.cuda.empty_cache()
+        except Exception as e:
+            rec["error"] = repr(e)[:300]
+        out.append(rec)
+    # --- GSC with gamma = 4 (g x g systems in registers: one wavefront per SIMD), MCA with H' = 10: EM iterations
+    try:
+        from prosper_amd.em.camodels.gsc_et import GSC
+        from prosper_amd.em.camodels.mca_et import MCA_ET
+        Dm, Hm = 256, 128
+        g = torch.Generator(device=dev).manual_seed(5)
+        rng = np.random.RandomState(5)
+        for name, N in (("gsc", 100_000), ("mca", 50_000)):
+            if time.perf_counter() - t_start > budget_s + 15.0:
+                out.append({"model": name, "skipped": "time budget"})
+                continue
+            W_gt = torch.randn(Dm, Hm, generator=g, device=dev, dtype=torch.float64)
+            Y = torch.empty(N, Dm, dtype=torch.float64, device=dev)
+            if name == "gsc":
+                for lo in range(0, N, 25_000):
+                    S = (torch.rand(25_000, Hm, generator=g, device=dev) < 2.0 / Hm).to(torch.float64)
+                    Z = S * (1.5 + torch.randn(25_000, Hm, generator=g, device=dev, dtype=torch.float64))
+                    Y[lo:lo + 25_000] = Z @ W_gt.t() + torch.randn(25_000, Dm, generator=g, device=dev, dtype=torch.float64)
+                p = {"W": W_gt.cpu().numpy() + 0.1 * rng.normal(size=(Dm, Hm)), "pi": np.full(Hm, 2.0 / Hm),
+                     "mu": np.full(Hm, 1.4), "psi_sq": np.eye(Hm) * 1.1, "sigma_sq": 1.2}
+                m, what = GSC(Dm, Hm, 6, 4, 'scalar'), "GSC D=256 H=128 H'=6 gamma=4"
+            else:
+                W_gt = W_gt.abs() * 2 + 0.1
+                for lo in range(0, N, 25_000):
+                    S = torch.rand(25_000, Hm, generator=g, device=dev) < 2.0 / Hm
+                    Wm = torch.where(S[:, None, :], W_gt[None, :, :].expand(25_000, Dm, Hm),
+                                     torch.zeros((), dtype=torch.float64, device=dev)).max(dim=2).values
+                    Y[lo:lo + 25_000] = Wm + torch.randn(25_000, Dm, generator=g, device=dev, dtype=torch.float64)
+                p = {"W": (W_gt * 1.05).cpu().numpy(), "pi": 2.0 / Hm, "sigma": 1.0}
+                m, what = MCA_ET(Dm, Hm, 10, 3), "MCA_ET D=256 H=128 H'=10 gamma=3"
+            tw = time.perf_counter()
+            while time.perf_counter() - tw < 0.3:
+                p = m.step(Anneal(T=1.0), p, {"y": Y})
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                p = m.step(Anneal(T=1.0), p, {"y": Y})
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 10 * 1e3
+            m.timer = kt = KernelTimer()
+            for _ in range(2):
+                p = m.step(Anneal(T=1.0), p, {"y": Y})
+            m.timer = None
+            out.append({"model": what, "N": N, "em_iter_ms": round(ms, 4), "dp_per_s_em": round(N / (ms * 1e-3)),
+                        "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kt.summary().items())}})
+            del Y, m
+            torch.cuda.empty_cache()
+    except Exception as e:
+        out.append({"model": "gsc/mca", "error": repr(e)[:300]})
     gc.enable()
     return out
 
@@ -484,6 +612,14 @@ def main():
         model.invalidate_data()
         torch.cuda.empty_cache()
         others = other_models(dev, Anneal)
+    shapes = None
+    if rank == 0 and world == 1 and not args.no_other_shapes:
+        if others is None:
+            del Y
+            data.clear()
+            model.invalidate_data()
+            torch.cuda.empty_cache()
+        shapes = other_shapes(dev, Anneal)
 
     # the all-reduce of the M-step statistics, timed with events around the collective (EM loop above)
     ar = comm.collective_times()
@@ -591,6 +727,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "other_models": others,
+            "other_shapes": shapes,
         }
         print(json.dumps(out))
     if world > 1:

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256, VPL <= 16 ? (NZ && VPL == 16 ? 3 : 4) : 1) voi
     }
 }
 
+constexpr size_t PM_ROWS16_LDS_MAX = 156 * 1024;
 inline int64_t grid_groups(int64_t N) {
     const int64_t groups = (N + ROWS - 1) / ROWS;
     const int64_t cap = 256 * 8;      // persistent grid: two rounds of resident workgroups walk the groups
@@ -369,7 +370,9 @@ static int allow_lds16(const void *kernel, size_t bytes) {
 // The fast path covers H <= 512 (VPL <= 32 scores per lane) and states that fit the LDS areas.
 extern "C" int pm_bsc_rows16_supported(int64_t H, int64_t Hprime, int64_t S) {
     if (H <= 0 || H > 512 || Hprime <= 0 || Hprime > PM_MAX_HPRIME || Hprime > H || S < 0 || S > 4096) return 0;
-    return make_layout((int)H, (int)Hprime, (int)S, 0).bytes <= 64 * 1024 ? 1 : 0;
+    // (up to the CU's whole LDS less a margin for the kernels' static arrays: beyond 80 KB one workgroup per CU -- four wavefronts
+    // -- which still beats the generic two-launch path by a third at H = 256, H' = 10, gamma = 4: DESIGN.md, shape sweep)
+    return make_layout((int)H, (int)Hprime, (int)S, 0).bytes <= PM_ROWS16_LDS_MAX ? 1 : 0;
 }
 
 // The list-writing M-step pass needs one more score row per datapoint slot (ROWS * H doubles) than the plain one.
@@ -381,7 +384,7 @@ static size_t mstep_rows16_lds(int64_t H, int64_t Hprime, int64_t S, bool lists)
 
 extern "C" int pm_bsc_rows16_nz_supported(int64_t H, int64_t Hprime, int64_t S) {
     if (!pm_bsc_rows16_supported(H, Hprime, S) || H > 256) return 0;       // (list indices are uint16 slots of <= 256 latents)
-    return mstep_rows16_lds(H, Hprime, S, true) <= 64 * 1024 ? 1 : 0;
+    return mstep_rows16_lds(H, Hprime, S, true) <= PM_ROWS16_LDS_MAX ? 1 : 0;
 }
 
 extern "C" int pm_bsc_select_estep_f64(const double *scores, int64_t lds, const double *gram, const double *ynorm2,
@@ -500,7 +503,7 @@ extern "C" int pm_bsc_mstep_rows16_nz_f64(const double *logpj, int64_t ldl, cons
     if (N == 0) return PM_OK;
     if (nz_idx && !pm_bsc_rows16_nz_supported(H, Hprime, S)) return PM_ERANGE;
     const size_t shmem = mstep_rows16_lds(H, Hprime, S, nz_idx != nullptr);
-    if (shmem > 64 * 1024) return PM_ERANGE;
+    if (shmem > PM_ROWS16_LDS_MAX) return PM_ERANGE;
     dim3 grid((unsigned)grid_groups(N)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PM_LAUNCH(V)                                                                                               \

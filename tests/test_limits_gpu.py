@@ -106,3 +106,71 @@ def test_at_a_documented_limit_runs(what, make):
     model, params, y = make()
     new = model.step(_An(T=1.0), params, {"y": y})
     assert np.isfinite(np.asarray(new["W"])).all()
+
+
+# ---------------------------------------------------------------------------------------------- off-config shapes
+_SWEEP = [(256, 128, 6, 3, 300), (1024, 256, 6, 3, 200), (1024, 256, 10, 4, 120), (784, 400, 8, 3, 120), (1024, 512, 8, 4, 96),
+          (4096, 1024, 10, 3, 40)]
+
+
+@pytest.mark.parametrize("D,H,Hp,gamma,N", _SWEEP)
+def test_bsc_off_config_shapes_match_the_oracle(D, H, Hp, gamma, N):
+    """The shapes bench.py's `other_shapes` times (the reference accepts any H' <= H, gamma <= H'; BASELINE names one): whichever
+    code path the host layer picks for them -- the 4-wavefront one-kernel pass, scores GEMM + 16-lane row kernel (now with up to
+    the CU's whole LDS), the generic kernels -- candidates, log-joints and the M-step agree with the oracle."""
+    from oracle import bsc_oracle as O
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    rng = np.random.RandomState(D + H + Hp)
+    W_gt = rng.normal(size=(D, H))
+    y, _ = O.generate_bsc_data(W_gt, 4.0 / H, 1.0, N, rng)
+    params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 4.0 / H, "sigma": 1.1}
+    an = O.Anneal(T=1.1, Ncut_factor=0.0, anneal_prior=False)
+    an.crit_params = []
+    ref, log = O.em_step(an, O.make_model(D, H, Hp, gamma), dict(params), y, stats_fn=O.m_step_stats_vec, vec=True)
+    m = BSC_ET(D, H, Hp, gamma)
+    data = m.select_Hprimes(params, {"y": y})
+    ss = m.E_step(_An(T=1.1), params, data)
+    assert np.array_equal(np.asarray(data["candidates"]).astype(np.int64), log["candidates"])
+    np.testing.assert_allclose(np.asarray(ss["logpj"]), log["logpj"], rtol=1e-10, atol=1e-8)
+    new = m.M_step(_An(T=1.1), params, ss, data)
+    # (N < H: Wq is rank-deficient and W_new is only defined up to LAPACK's SVD cutoff -- the statistics pin the path)
+    np.testing.assert_allclose(new["pi"], ref["pi"], rtol=1e-9)
+    np.testing.assert_allclose(new["sigma"], ref["sigma"], rtol=1e-9)
+    st, lib = m._ws["stats"].cpu().numpy(), __import__("prosper_amd._lib", fromlist=["load"]).load()
+    Wp = st[:lib.pm_bsc_stats_offset_wq(H, D)].reshape(H, D)
+    np.testing.assert_allclose(Wp, log["stats"]["Wp"], rtol=1e-9, atol=1e-9 * np.abs(log["stats"]["Wp"]).max())
+
+
+def test_gsc_gamma4_and_mca_hprime10_match_the_oracle():
+    """GSC at config-4 dimensions with gamma = 4 (the g x g systems in registers at one wavefront per SIMD) and MCA at config-5
+    dimensions with H' = 10: the other two entries of bench.py's `other_shapes`."""
+    from oracle import gsc_oracle as G, mca_oracle as M, bsc_oracle as B
+    from prosper_amd.em.camodels.gsc_et import GSC
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    D, H = 256, 128
+    rng = np.random.RandomState(5)
+    gt = {"W": rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.5), "psi_sq": np.eye(H), "sigma_sq": 1.0}
+    y, _, _ = G.generate_gsc_data(gt, 700, rng)
+    params = {"W": gt["W"] + 0.1 * rng.normal(size=(D, H)), "pi": gt["pi"] * 1.1, "mu": gt["mu"] + 0.1 * rng.normal(size=H),
+              "psi_sq": np.diag(rng.uniform(0.7, 1.4, size=H)), "sigma_sq": 1.2}
+    cp = lambda q: {k: np.array(v, copy=True) for k, v in q.items()}
+    ref, log = G.em_step(G.Anneal(T=1.0), G.make_model(D, H, 6, 4), cp(params), y)
+    new = GSC(D, H, 6, 4, "scalar").step(_An(T=1.0), cp(params), {"y": y})
+    tol = max(1e-8, 50 * np.linalg.cond(log["suff"]["xpt_szsz"].sum(0)) * np.finfo(float).eps)
+    for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
+        np.testing.assert_allclose(new[k], ref[k], rtol=10 * tol, atol=tol * max(1.0, np.abs(ref[k]).max()), err_msg=k)
+    Wm = np.abs(rng.normal(size=(D, H))) * 2 + 0.1
+    ym, _ = M.generate_mca_data(Wm, 2.0 / H, 1.0, 300, rng)
+    pm = {"W": Wm * rng.uniform(0.9, 1.1, size=Wm.shape), "pi": 2.0 / H, "sigma": 1.0}
+    refm, logm = M.em_step(B.Anneal(T=1.0), B.make_model(D, H, 10, 3), dict(pm), ym, vec=True)
+    mm = MCA_ET(D, H, 10, 3)
+    data = mm.select_Hprimes(mm.check_params(dict(pm)), {"y": ym})
+    if np.array_equal(np.asarray(data["candidates"]).astype(np.int64), logm["candidates"]):     # (no tie of zero distances)
+        newm = mm.step(_An(T=1.0), dict(pm), {"y": ym})
+        np.testing.assert_allclose(newm["W"], refm["W"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(newm["pi"], refm["pi"], rtol=1e-9)
+        np.testing.assert_allclose(newm["sigma"], refm["sigma"], rtol=1e-9)
+    else:
+        sc = M.select_scores_vec(M.check_params(dict(pm))["W"], ym)
+        got = np.asarray(data["candidates"]).astype(np.int64)
+        assert np.array_equal(np.sort(np.take_along_axis(sc, got, 1), 1), np.sort(np.take_along_axis(sc, logm["candidates"], 1), 1))
