@@ -619,7 +619,11 @@ def test_bsc_step_matches_oracle(dev, D, H, Hp, gamma, N, T, ncut, ap):
 
     m = BSC_ET(D, H, Hp, gamma)
     if Hp == 16:
-        assert m._state_tables()["fast"] and not m._state_tables()["fast_nz"]
+        # (round 5: the 16-lane row kernels may take the CU's whole LDS, so the list-writing M-step pass fits here too; the
+        # H = 240 case keeps the plain pass + dense statistics GEMM combination of the round-3 advisor finding covered)
+        assert m._state_tables()["fast"] and m._state_tables()["fast_nz"]
+        if H == 240:
+            m._state_tables()["fast_nz"] = False
     h = dlog.set_handler(("L", "N_use"), StoreInMemory)
     try:
         new = m.step(_An(T=T, Ncut_factor=ncut, anneal_prior=ap), dict(params), {"y": y})
