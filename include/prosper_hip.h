@@ -36,6 +36,33 @@ extern "C" {
 
 /* ABI version (major*1000 + minor); bumped when a signature changes. */
 int pm_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Deterministic reductions (libprosper_hip_det.so: the same sources built with -DPM_DETERMINISTIC)
+ * ---------------------------------------------------------------------------------------
+ * The M-step statistics are sums over datapoints formed with f64 atomics; the order the addends land in changes from run to
+ * run and with it the last bits of the sums (the reference at a fixed number of ranks is deterministic).  In the deterministic
+ * build every addend is rounded to a multiple of a quantum q_c = 2^-52 M_c before it is added, M_c a power of two no partial
+ * sum of its category can exceed: all additions are then exact and the result is independent of their order -- the same
+ * bits in every run.  pm_det_build(): 1 in that build, 0 in the default one (whose kernels contain none of this).
+ * pm_det_set_quanta(unit, M8, stream): the eight magic constants 1.5 M_c of one kernel family (host memory; copied before the
+ * family's next launch on `stream`; PM_ERANGE-like -2 in the default build).  Categories per family:
+ *   PM_DET_BSC_FUSED8 / PM_DET_DSC   0 Wq, mus, counts (sums of probabilities)   1 sum of q e   2 sum of log-evidences
+ *   PM_DET_WP_SPARSE                 0 Wp (sums of E[s] y)
+ *   PM_DET_GSC                       0 xpt_s / xpt_ss sums   1 xpt_sz sums   2 xpt_szsz sums
+ *   PM_DET_GEMM                      0 the K-slices of pm_gemm_tn_acc_f64
+ *   PM_DET_MCA                       0 Wq   1 Wp   2 pi   3 sum of q e   4 sums of log-evidences */
+#define PM_DET_BSC_FUSED8 0
+#define PM_DET_WP_SPARSE 1
+#define PM_DET_GSC 2
+#define PM_DET_GEMM 3
+#define PM_DET_MCA 4
+#define PM_DET_DSC 5
+#define PM_DET_BSC_ROWS16 6   /* the other BSC kernel files: categories as PM_DET_BSC_FUSED8 */
+#define PM_DET_BSC_FUSED 7
+#define PM_DET_BSC_KERNELS 8
+int pm_det_build(void);
+int pm_det_set_quanta(int unit, const double *M8, void *stream);
 const char *pm_error_string(int code);
 
 /* ---------------------------------------------------------------------------------------

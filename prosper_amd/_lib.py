@@ -137,6 +137,8 @@ SIGNATURES = {
                                          c_dp]),
     "pm_infer_topk_signed_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, c_dp,
                                            c_dp, c_dp, c_dp, c_dp]),
+    "pm_det_build": (C.c_int, []),
+    "pm_det_set_quanta": (C.c_int, [C.c_int, c_dp, c_dp]),
     "pm_gsc_component_scores_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_double, i64, i64, c_dp, i64, c_dp]),
 }
 
@@ -146,27 +148,41 @@ class HipError(RuntimeError):
 
 
 _lib = None
+_lib_det = None
+LIB_PATH_DET = os.path.join(os.path.dirname(LIB_PATH), "libprosper_hip_det.so")
+DET_UNITS = {"bsc_fused8": 0, "wp_sparse": 1, "gsc": 2, "gemm": 3, "mca": 4, "dsc": 5, "bsc_rows16": 6, "bsc_fused": 7,
+             "bsc_kernels": 8}      # PM_DET_* of prosper_hip.h
 
 
-def load():
-    """Load the shared library once and attach prototypes."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def _open(path, what):
     # torch bundles its own libamdhip64.so.7; it must be the ONE HIP runtime in the process
     # (pointers and streams handed to the C ABI come from it).  Loading ours first would pull
     # /opt/rocm's copy of the same soname and leave torch and the kernels on different runtimes.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
-        raise HipError("libprosper_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                       "or prosper_amd/csrc/build.sh (looked in %s)" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    if not os.path.exists(path):
+        raise HipError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or prosper_amd/csrc/build.sh (looked in %s)" % (what, path))
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load(det=False):
+    """Load the shared library once and attach prototypes.  ``det``: the deterministic build (libprosper_hip_det.so: the same
+    sources with order-independent reductions, include/prosper_hip.h) that ``model.deterministic = True`` runs on."""
+    global _lib, _lib_det
+    if det:
+        if _lib_det is None:
+            _lib_det = _open(LIB_PATH_DET, "libprosper_hip_det.so")
+            if _lib_det.pm_det_build() != 1:
+                raise HipError("%s is not a deterministic build" % LIB_PATH_DET)
+        return _lib_det
+    if _lib is None:
+        _lib = _open(LIB_PATH, "libprosper_hip.so")
+    return _lib
 
 
 def check(code, what=""):
@@ -175,6 +191,6 @@ def check(code, what=""):
         raise HipError("%s failed: %s (code %d)" % (what or "libprosper_hip call", msg, code))
 
 
-def call(name, *args):
+def call(name, *args, det=False):
     """Invoke an int-returning entry point and raise on a non-zero status."""
-    check(getattr(load(), name)(*args), name)
+    check(getattr(load(det), name)(*args), name)

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void bsc_estep_fused_kernel(
         if (tid < 3) {
             double v = 0.0;
             for (int w = 0; w < 4; ++w) v += red[w * 3 + tid];
-            if (v != 0.0) pm_atomic_add(sc + tid, v);
+            if (v != 0.0) pm_atomic_add(sc + tid, PM_Q(v, tid == 0 ? 1 : tid == 1 ? 2 : 0));
         }
         double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, Dstats);
         if (tid < H) {
@@ -415,3 +415,5 @@ extern "C" int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double
 #undef PM_LAUNCH_FM
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(bsc_fused)

@@ -832,7 +832,7 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
                                             mk &= mk - 1;
                                             const int ck = cl[kk];
                                             const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
-                                            pm_atomic_add(wq + (int64_t)lo * H + hi, w);
+                                            pm_atomic_add(wq + (int64_t)lo * H + hi, PM_Q(w, 0));
                                         }
                                     }
                                 }
@@ -847,12 +847,12 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
                 const double v = Bp[j32];
                 const int ci = cl[pair_i], ck = cl[pair_k];
                 const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
-                if (!(PM_F8_SKIP & (64 | 256)) && live && v != 0.0) pm_atomic_add(wq + (int64_t)lo * H + hi, v);
+                if (!(PM_F8_SKIP & (64 | 256)) && live && v != 0.0) pm_atomic_add(wq + (int64_t)lo * H + hi, PM_Q(v, 0));
                 if (j32 < PAIR_ENTRIES - 32) {
                     const double v2 = Bp[32 + j32];
                     const int c2 = cl[4 + j32], c7 = cl[7];
                     const int lo2 = c2 < c7 ? c2 : c7, hi2 = c2 < c7 ? c7 : c2;
-                    if (!(PM_F8_SKIP & (64 | 256)) && live && v2 != 0.0) pm_atomic_add(wq + (int64_t)lo2 * H + hi2, v2);
+                    if (!(PM_F8_SKIP & (64 | 256)) && live && v2 != 0.0) pm_atomic_add(wq + (int64_t)lo2 * H + hi2, PM_Q(v2, 0));
                 }
             }
             char *erow = exp_t + ((uint32_t)lrow * (uint32_t)lde * 8u + (uint32_t)j32 * 8u);
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
                     v = (a[i] + Pm[h]) * inv;
                     if (!(PM_F8_SKIP & 32)) *reinterpret_cast<double *>(erow + 256 * i) = v;
                     if (!(PM_F8_SKIP & 64) && live && __any(v != 0.0)) {
-                        if (v != 0.0) atomicAdd(&t_mus[h], v);
+                        if (v != 0.0) atomicAdd(&t_mus[h], PM_Q(v, 0));       // (the one LDS accumulator all wavefronts share)
                     }
                 }
                 if (lists) {
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
         if (tid < 3) {
             double v = 0.0;
             for (int w = 0; w < NWAVES; ++w) v += red[16 * tid + w];
-            if (v != 0.0) pm_atomic_add(sc + tid, v);
+            if (v != 0.0) pm_atomic_add(sc + tid, PM_Q(v, tid == 0 ? 1 : tid == 1 ? 2 : 0));    // sum q e | sum lse | count
         }
         double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, Dstats);
         double *g_qd = stats + pm_bsc_stats_offset_qdiag_dev(H, Dstats);
@@ -1075,3 +1075,5 @@ extern "C" int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const do
 #undef PM_LAUNCH8SMT
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(bsc_fused8)

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows_kernel(const double *__res
             const double q = exp(fh - l);
             sig += q * ((fh - ppil) * inv_ecoef);
             s_es[h] = q;
-            atomicAdd(&s_qdiag[h], q);
+            atomicAdd(&s_qdiag[h], PM_Q(q, 0));
         }
         for (int s = lane; s < S; s += 64) {
             const double fv = f[1 + H + s];
@@ -273,10 +273,10 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows_kernel(const double *__res
             const int ci = cn[i], cj = cn[j];
             if (i == j) {
                 s_es[ci] += m2;  // E[s_c] = q1_c + sum_{s containing c} q_s ; candidates are distinct
-                pm_atomic_add(Wq + (int64_t)ci * H + ci, m2);
+                pm_atomic_add(Wq + (int64_t)ci * H + ci, PM_Q(m2, 0));
             } else {
                 const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;
-                pm_atomic_add(Wq + (int64_t)lo * H + hi, m2);
+                pm_atomic_add(Wq + (int64_t)lo * H + hi, PM_Q(m2, 0));
             }
         }
         wave_lds_sync();
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows_kernel(const double *__res
         for (int h = lane; h < H; h += 64) {
             const double v = s_es[h];
             erow[h] = v;
-            atomicAdd(&s_mus[h], v);
+            atomicAdd(&s_mus[h], PM_Q(v, 0));
         }
         wave_lds_sync();
     }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void bsc_mstep_rows_kernel(const double *__res
     if (tid < 3) {
         double v = 0.0;
         for (int w = 0; w < WAVES; ++w) v += s_red[w * 3 + tid];
-        if (v != 0.0) pm_atomic_add(sc + tid, v);
+        if (v != 0.0) pm_atomic_add(sc + tid, PM_Q(v, tid == 0 ? 1 : tid == 1 ? 2 : 0));
     }
     double *g_qdiag = stats + pm_bsc_stats_offset_qdiag_dev(H, D);
     double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, D);
@@ -395,3 +395,5 @@ extern "C" int pm_bsc_mstep_rows_f64(const double *logpj, int64_t ldl, const dou
                        pair_states, *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats);
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(bsc_kernels)

@@ -256,13 +256,13 @@ __global__ __launch_bounds__(256, VPL <= 16 ? (NZ && VPL == 16 ? 3 : 4) : 1) voi
             const int ck = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, myc);
             if (k >= i && m2 != 0.0) {
                 const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
-                pm_atomic_add(Wq + (int64_t)lo * H + hi, m2);
+                pm_atomic_add(Wq + (int64_t)lo * H + hi, PM_Q(m2, 0));
             }
         }
         // E[s_c] = q1_c + sum_{s containing c} q_s: the owner lane of latent c adds the diagonal term
         if (j < Hp) {
             const double m1 = s_m2[j * Hp + j];
-            if (m1 != 0.0) atomicAdd(&s_mus[myc], m1);
+            if (m1 != 0.0) atomicAdd(&s_mus[myc], PM_Q(m1, 0));
         }
         // the row of singleton weights goes out first; the candidates' multi-cause terms are added to it by the
         // lanes that own them once those stores have completed (8 f64 atomics per datapoint instead of a
@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256, VPL <= 16 ? (NZ && VPL == 16 ? 3 : 4) : 1) voi
     for (int i = 0; i < VPL; ++i) {
         const int h = j + 16 * i;
         if (h < H) {
-            atomicAdd(&s_qdiag[h], qd[i]);
-            atomicAdd(&s_mus[h], qd[i]);
+            atomicAdd(&s_qdiag[h], PM_Q(qd[i], 0));
+            atomicAdd(&s_mus[h], PM_Q(qd[i], 0));
         }
     }
     sig = pm_wave_sum(sig);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, VPL <= 16 ? (NZ && VPL == 16 ? 3 : 4) : 1) voi
     if (tid < 3) {
         double v = 0.0;
         for (int w = 0; w < 4; ++w) v += s_red[w * 3 + tid];
-        if (v != 0.0) pm_atomic_add(sc + tid, v);
+        if (v != 0.0) pm_atomic_add(sc + tid, PM_Q(v, tid == 0 ? 1 : tid == 1 ? 2 : 0));
     }
     double *g_qdiag = stats + pm_bsc_stats_offset_qdiag_dev(H, D);
     double *g_mus = stats + pm_bsc_stats_offset_mus_dev(H, D);
@@ -529,3 +529,5 @@ extern "C" int pm_bsc_mstep_rows16_nz_f64(const double *logpj, int64_t ldl, cons
 #undef PM_LAUNCH
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(bsc_rows16)

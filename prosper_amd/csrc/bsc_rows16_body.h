@@ -653,7 +653,7 @@ __device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, i
             const double v = valid ? m2[p] * inv : 0.0;
             if (live && v != 0.0) {
                 const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
-                pm_atomic_add(A.wq + (int64_t)lo * H + hi, v);
+                pm_atomic_add(A.wq + (int64_t)lo * H + hi, PM_Q(v, 0));
             }
         }
         wave_lds_sync16();
@@ -666,7 +666,7 @@ __device__ __forceinline__ void row_estep_compute(double (&a)[VPL], double yn, i
                 if (live) {
                     erow[h] = v;
                     if (__any(v != 0.0)) {
-                        if (v != 0.0) atomicAdd(&L.mus[h], v);
+                        if (v != 0.0) atomicAdd(&L.mus[h], PM_Q(v, 0));
                     }
                 }
             }

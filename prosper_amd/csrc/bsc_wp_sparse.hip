@@ -119,7 +119,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(6
             for (int t = 0; t < cnt; ++t) {
                 const int src = 16 * (u & 3) + t;
                 const int h = __builtin_amdgcn_readlane(b.ix[u >> 2], src);
-                atomicAdd(arow + h * SP_DC, readlane_f64(b.v[u >> 2], src) * b.y[u]);
+                atomicAdd(arow + h * SP_DC, PM_Q(readlane_f64(b.v[u >> 2], src) * b.y[u], 0));
             }
         }
     };
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(6
             const double vs = lane < PM_BSC_NZ_MAX ? nz_val[(int64_t)n * PM_BSC_NZ_MAX + lane] : 0.0;
             const int cnt = __popc((uint32_t)__ballot(ixs != 0xFFFF) & 0xFFFFu);
             for (int t = 0; t < cnt; ++t)
-                atomicAdd(arow + __builtin_amdgcn_readlane(ixs, t) * SP_DC, readlane_f64(vs, t) * yv);
+                atomicAdd(arow + __builtin_amdgcn_readlane(ixs, t) * SP_DC, PM_Q(readlane_f64(vs, t) * yv, 0));
         }
     }
     __syncthreads();
@@ -212,3 +212,5 @@ static int wp_sparse_launch(const uint16_t *nz_idx, const double *nz_val, const 
                        rpg, transposed);
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(bsc_wp_sparse)

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_MS_WPE : 2) 
             rowv[i] *= inv;
             if (h < H) {
                 const double q2 = qd[i] * inv;
-                if (q2 != 0.0) atomicAdd(&s_qdiag[h], q2);
+                if (q2 != 0.0) atomicAdd(&s_qdiag[h], PM_Q(q2, 0));
             }
         }
         wave_sync_lds_dsc();
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_MS_WPE : 2) 
             const double v = s_B[p] * inv;
             if (v == 0.0) continue;
             const int r = cj < ck ? cj : ck, cc = cj < ck ? ck : cj;
-            pm_atomic_add(Wq + (int64_t)r * H + cc, v);          // upper triangle (pm_spd_inverse_f64 layout)
+            pm_atomic_add(Wq + (int64_t)r * H + cc, PM_Q(v, 0));          // upper triangle (pm_spd_inverse_f64 layout)
         }
         wave_sync_lds_dsc();
     }
@@ -753,13 +753,13 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_MS_WPE : 2) 
 #pragma unroll
     for (int k = 0; k < KM; ++k) cnt[k] = pm_wave_sum(cnt[k]);
     if (lane == 0) {
-        atomicAdd(&s_scal[0], sig);
-        atomicAdd(&s_scal[1], fs);
+        atomicAdd(&s_scal[0], PM_Q(sig, 1));
+        atomicAdd(&s_scal[1], PM_Q(fs, 2));
         atomicAdd(&s_scal[2], kept);
         if (overflow != 0.0) atomicAdd(&s_scal[3], overflow);
 #pragma unroll
         for (int k = 0; k < KM; ++k)
-            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], cnt[k]);
+            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], PM_Q(cnt[k], 0));
     }
     __syncthreads();
     double *g_qdiag = stats + (int64_t)H * D + (int64_t)H * H;
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
                 ++c;
             }
             s_row[h] = row;
-            if (qd != 0.0) atomicAdd(&s_qdiag[h], qd);
+            if (qd != 0.0) atomicAdd(&s_qdiag[h], PM_Q(qd, 0));
         }
         wave_sync_lds_dsc();
         for (int s = lane; s < S; s += 64) {
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
             const double v = s_B[p];
             if (v == 0.0) continue;
             const int r = cj < ck ? cj : ck, cc = cj < ck ? ck : cj;
-            pm_atomic_add(Wq + (int64_t)r * H + cc, v);      // upper triangle (pm_spd_inverse_f64 layout)
+            pm_atomic_add(Wq + (int64_t)r * H + cc, PM_Q(v, 0));      // upper triangle (pm_spd_inverse_f64 layout)
         }
         wave_sync_lds_dsc();
     }
@@ -915,12 +915,12 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
 #pragma unroll
     for (int k = 0; k < PM_DSC_MAX_K; ++k) cnt[k] = pm_wave_sum(cnt[k]);
     if (lane == 0) {
-        atomicAdd(&s_scal[0], sig);
-        atomicAdd(&s_scal[1], fs);
+        atomicAdd(&s_scal[0], PM_Q(sig, 1));
+        atomicAdd(&s_scal[1], PM_Q(fs, 2));
         atomicAdd(&s_scal[2], kept);
 #pragma unroll
         for (int k = 0; k < PM_DSC_MAX_K; ++k)
-            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], cnt[k]);
+            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], PM_Q(cnt[k], 0));
     }
     __syncthreads();
     double *g_qdiag = stats + (int64_t)H * D + (int64_t)H * H;
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_M16_WPE : 2)
                 const int h = j + 16 * i;
                 if (h < H) {
                     s_row[h] = rowv[i];
-                    if (qd[i] != 0.0) atomicAdd(&s_qdiag[h], qd[i]);
+                    if (qd[i] != 0.0) atomicAdd(&s_qdiag[h], PM_Q(qd[i], 0));
                 }
             }
         }
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_M16_WPE : 2)
             const double v = s_B[p];
             if (v == 0.0) continue;
             const int r = cj < ck ? cj : ck, cc = cj < ck ? ck : cj;
-            pm_atomic_add(Wq + (int64_t)r * H + cc, v);          // upper triangle (pm_spd_inverse_f64 layout)
+            pm_atomic_add(Wq + (int64_t)r * H + cc, PM_Q(v, 0));          // upper triangle (pm_spd_inverse_f64 layout)
         }
         wave_sync_lds_dsc();
     }
@@ -1132,13 +1132,13 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_M16_WPE : 2)
 #pragma unroll
     for (int k = 0; k < PM_DSC_MAX_K; ++k) cnt[k] = pm_wave_sum(cnt[k]);
     if (lane == 0) {
-        atomicAdd(&s_scal[0], sig);
-        atomicAdd(&s_scal[1], fs);
+        atomicAdd(&s_scal[0], PM_Q(sig, 1));
+        atomicAdd(&s_scal[1], PM_Q(fs, 2));
         atomicAdd(&s_scal[2], kept);
         if (overflow != 0.0) atomicAdd(&s_scal[3], overflow);
 #pragma unroll
         for (int k = 0; k < PM_DSC_MAX_K; ++k)
-            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], cnt[k]);
+            if (cnt[k] != 0.0) atomicAdd(&s_cnt[k], PM_Q(cnt[k], 0));
     }
     __syncthreads();
     double *g_qdiag = stats + (int64_t)H * D + (int64_t)H * H;
@@ -1424,3 +1424,5 @@ extern "C" int pm_tsc_select_scores_f64(const double *scores, int64_t lds, const
                        static_cast<hipStream_t>(stream), scores, lds, gram, N, (int)H, R, ldr);
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(dsc)

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_dma_kernel(const double *_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (n0 + wn * 64 + j * 16 + frow < N) {
-                    if (split) pm_atomic_add(crow + j * 16, acc[i][j][r]);
+                    if (split) pm_atomic_add(crow + j * 16, PM_Q(acc[i][j][r], 0));
                     else crow[j * 16] = acc[i][j][r];
                 }
             }
@@ -503,7 +503,7 @@ __device__ __forceinline__ void tn_tile(const double *__restrict__ A, int64_t ld
             double *crow = C + (int64_t)row * ldc + n0 + wn * 64 + fcol;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (!EDGE || n0 + wn * 64 + j * 16 + fcol < N) pm_atomic_add(crow + j * 16, acc[i][j][r]);
+                if (!EDGE || n0 + wn * 64 + j * 16 + fcol < N) pm_atomic_add(crow + j * 16, PM_Q(acc[i][j][r], 0));
             }
         }
     }
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_dma_kernel(const double *_
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pm_atomic_add(cbase + (int64_t)(i * 16 + 4 * r) * ldc + j * 16, acc[i][j][r]);
+            for (int j = 0; j < 4; ++j) pm_atomic_add(cbase + (int64_t)(i * 16 + 4 * r) * ldc + j * 16, PM_Q(acc[i][j][r], 0));
 }
 
 // out[n] = sum_d Y[n,d]^2; one wavefront per row, lanes stride the row.
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void col_moments_f64_kernel(const double *__re
             const double u = Y[n * ldy + d] - c;
             a0 += center ? u * u : u;
         }
-        pm_atomic_add(sums + d, a0 + a1);
+        pm_atomic_add(sums + d, PM_Q(a0 + a1, 1));
     }
 }
 
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void col_sum_kept_f64_kernel(const double *__r
             a1 += (lse[n + 1] >= cut) ? v : 0.0;
         }
         if (n < r1 && lse[n] >= cut) a0 += Y[n * ldy + d];
-        pm_atomic_add(sums + d, a0 + a1);
+        pm_atomic_add(sums + d, PM_Q(a0 + a1, 1));
     }
 }
 
@@ -996,3 +996,5 @@ extern "C" int pm_row_wsqnorm_f64(const double *Y, int64_t ldy, int64_t N, int64
                        Y, ldy, N, (int)D, w, out);
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(gemm)

@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                     // diagonal of the block sum), and with the LDS accumulators (LACC) the diagonal of xpt_szsz joins the singletons'
                     // there -- twelve of a datapoint's atomics, and the ones that always clear the threshold.
                     const double vss = s_ass[p] * nf_prev, vzz = s_aszsz[p] * nf_prev;
-                    if (k > i && vss > thr_p) pm_atomic_add(g_ss + (int64_t)ci * H + ck, vss);
+                    if (k > i && vss > thr_p) pm_atomic_add(g_ss + (int64_t)ci * H + ck, PM_Q(vss, 0));
                     if (LACC && k == i) atomicAdd(&s_acc[2 * 4 * H + wave * H + ci], vzz);
-                    else if (__builtin_fabs(vzz) > thr_p) pm_atomic_add(g_szsz + (int64_t)ci * H + ck, vzz);
+                    else if (__builtin_fabs(vzz) > thr_p) pm_atomic_add(g_szsz + (int64_t)ci * H + ck, PM_Q(vzz, 2));
                 }
                 if (clear) {
                     s_ass[p] = 0.0;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
             const int q = e / H, h = e - q * H;
             const double *src = s_acc + (size_t)q * 4 * H + h;
             const double v = (src[0] + src[H]) + (src[2 * (size_t)H] + src[3 * (size_t)H]);
-            if (v != 0.0) pm_atomic_add(g_cs + e, v);
+            if (v != 0.0) pm_atomic_add(g_cs + e, PM_Q(v, q));           // (categories 0 | 1 | 2 = xpt_s | xpt_sz | xpt_szsz sums)
         }
         return;
     }
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     for (int i = 0; i < (LACC ? 1 : VPL); ++i) {
         const int h = j + 16 * i;
         const double c_d = g_col_sum(dszsz[i]);             // rows of the wave first
-        if (row == 0 && h < H) atomicAdd(&s_c0[h], c_d);
+        if (row == 0 && h < H) atomicAdd(&s_c0[h], PM_Q(c_d, 2));
     }
     __syncthreads();
     double *g_dszsz = g_cs + 2 * H;
@@ -694,8 +694,8 @@ __global__ __launch_bounds__(256) void gsc_colsum_kernel(const double *__restric
                 sa += s_part[0][q * cols + tid];
                 sb += s_part[1][q * cols + tid];
             }
-            if (sa != 0.0) pm_atomic_add(g_cs + h0 + tid, sa);
-            if (sb != 0.0) pm_atomic_add(g_csz + h0 + tid, sb);
+            if (sa != 0.0) pm_atomic_add(g_cs + h0 + tid, PM_Q(sa, 0));
+            if (sb != 0.0) pm_atomic_add(g_csz + h0 + tid, PM_Q(sb, 1));
         }
         __syncthreads();
     }
@@ -1071,3 +1071,5 @@ extern "C" int pm_gsc_component_scores_f64(const double *scores, int64_t lds, co
                        scores, lds, ynorm2, tables, 1.0 / sigma_sq, N, (int)H, out, ldo);
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(gsc)

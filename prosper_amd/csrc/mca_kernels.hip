@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
             if (q != 0.0) {
                 st_sigma += q * e;
                 st_pi += q;
-                atomicAdd(&s_q1sum[h], q);
+                atomicAdd(&s_q1sum[h], PM_Q(q, 2));
             }
             qrow[h] = q;
         }
@@ -541,8 +541,8 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                         if (d < D) {
                             const double aid = SIGNED ? V[j][i] * g : V[j][i] * g * Wrm1[base + d];
                             if (aid != 0.0 && (PM_MCA_ABL != 1 || aid == 1.2345e-300)) {
-                                pm_atomic_add(Wp + base + d, aid * y[i]);
-                                pm_atomic_add(Wq + base + d, aid);
+                                pm_atomic_add(Wp + base + d, PM_Q(aid * y[i], 1));
+                                pm_atomic_add(Wq + base + d, PM_Q(aid, 0));
                             }
                         }
                     }
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
     if (tid < 4) {
         double v = 0.0;
         for (int w = 0; w < waves; ++w) v += s_red[w * 4 + tid];
-        if (v != 0.0) pm_atomic_add(sc + tid, v);
+        if (v != 0.0) pm_atomic_add(sc + tid, PM_Q(v, tid == 1 ? 3 : tid == 2 ? 4 : 2));    // pi | sum q e | sum lse | count
     }
     for (int h = tid; h < H; h += blockDim.x) {
         const double v = s_q1sum[h];
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
             if (q != 0.0) {
                 st_sigma += q * ((fh - P.pil_bar) / P.pre1);
                 st_pi += q;
-                atomicAdd(&s_q1sum[h], q);
+                atomicAdd(&s_q1sum[h], PM_Q(q, 2));
             }
             qrow[h] = q;
         }
@@ -743,8 +743,8 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
                         const int d = lane + 64 * i;
                         if (d < Dl) {
                             const double aid = SIGNED ? V[j][i] : V[j][i] * Wrm1[base + d];  // Aid[j,d] (mca_et.py:309)
-                            pm_atomic_add(Wp + base + d, aid * y[i]);
-                            pm_atomic_add(Wq + base + d, aid);
+                            pm_atomic_add(Wp + base + d, PM_Q(aid * y[i], 1));
+                            pm_atomic_add(Wq + base + d, PM_Q(aid, 0));
                         }
                     }
                 }
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
     if (tid < 4) {
         double v = 0.0;
         for (int w = 0; w < waves; ++w) v += s_red[w * 4 + tid];
-        if (v != 0.0) pm_atomic_add(sc + tid, v);
+        if (v != 0.0) pm_atomic_add(sc + tid, PM_Q(v, tid == 1 ? 3 : tid == 2 ? 4 : 2));    // pi | sum q e | sum lse | count
     }
     for (int h = tid; h < H; h += blockDim.x) {
         const double v = s_q1sum[h];
@@ -1040,3 +1040,5 @@ extern "C" int pm_mca_w_update_f64(const double *stats, const double *wt, int64_
                        stats, wt, (int)H, (int)D, w_tol, wt_new, wt_clamped);
     return (int)hipGetLastError();
 }
+
+PM_DET_SETTER(mca)

@@ -13,6 +13,32 @@ __device__ __forceinline__ void pm_atomic_add(double *p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- deterministic build (-DPM_DETERMINISTIC -> libprosper_hip_det.so; `model.deterministic = True`) --------------------------
+// The statistics of an M-step are sums over datapoints formed with f64 atomics (LDS and global): the order in which the
+// addends arrive changes from run to run and with it the rounding of every partial sum -- two identical EM loops drift apart
+// in the last bits (and, where a parameter is an element-wise ratio of two such sums, visibly: MCA).  Rounding each addend, before
+// it is added, to a multiple of q = 2^-52 M (M >= any partial sum of its accumulator, a power of two the host derives from
+// rigorous bounds on the data and parameters) makes every addition EXACT -- multiples of q below 2^53 q are closed under f64
+// addition -- so the result no longer depends on the order: same bits every run, on any schedule.  Price: two adds per atomic and
+// an error of at most half a quantum per addend (n 2^-53 M in the worst case, ~sqrt(n) 2^-53 M typically -- the size of the
+// rounding error the plain sum makes on its LARGEST entries, spread over all of them).  The default build compiles PM_Q to
+// nothing: its kernels are bit-for-bit the ones that were tuned.
+//   PM_Q(v, c)   v rounded to category c's quantum (pm_det_M[c] = 1.5 * 2^e: the add / subtract trick)
+//   each translation unit with accumulators has its own pm_det_M and a setter the host calls before its launches
+#ifdef PM_DETERMINISTIC
+static __device__ double pm_det_M[8];
+#define PM_Q(v, c) (((v) + pm_det_M[c]) - pm_det_M[c])
+#define PM_DET_SETTER(unit)                                                                                      \
+    extern "C" int prosper_det_set_##unit(const double *M8, void *stream) {                                     \
+        return (int)hipMemcpyToSymbolAsync(HIP_SYMBOL(pm_det_M), M8, 8 * sizeof(double), 0, hipMemcpyHostToDevice, \
+                                           static_cast<hipStream_t>(stream));                                    \
+    }
+#else
+#define PM_Q(v, c) (v)
+#define PM_DET_SETTER(unit) \
+    extern "C" int prosper_det_set_##unit(const double *, void *) { return -2; }
+#endif
+
 // MI355X has 8 XCDs with one L2 each.  f64 atomics from all of them on the same few thousand lines bounce those
 // lines between the L2s; hot (H,H) / (H,D) accumulators are therefore kept once per XCD -- copy 0 in the
 // documented slot, copies 1..7 in a scratch tail of the statistics buffer -- and folded by pm_fold_copies_kernel.

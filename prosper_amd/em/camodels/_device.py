@@ -189,6 +189,11 @@ class DeviceCAModel(CAModel):
         self._par = {}           # per-step parameter products
         self._ws = {}            # workspaces keyed by name
         self.timer = None        # optional KernelTimer (bench.py)
+        # True: every kernel runs from libprosper_hip_det.so (the same sources with -DPM_DETERMINISTIC: addends of the M-step's
+        # atomics rounded to a common quantum first, so their sums do not depend on the order they land in -- pm_common.h) and
+        # the host takes no shortcut whose operand order varies: two identical EM loops then agree bit for bit.  Opt-in: a few
+        # per cent slower, and sums carry the rounding error of their largest entries on all of them.
+        self.deterministic = False
         self._pin = {}           # pinned staging buffers for asynchronous parameter uploads
         self._pin_out = {}       # pinned buffers of the device->host copies (one per M-step), by slot
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'   # next step's GEMMs behind the M-step download
@@ -222,10 +227,37 @@ class DeviceCAModel(CAModel):
 
     def _call(self, label, entry, *args):
         """Enqueue one C-ABI entry point on the current stream (raises on a bad status)."""
+        det = self.deterministic
         if self.timer is None:
-            _lib.call(entry, *args)
+            _lib.call(entry, *args, det=det)
         else:
-            self.timer.launch(label, lambda: _lib.call(entry, *args))
+            self.timer.launch(label, lambda: _lib.call(entry, *args, det=det))
+
+    # ---- deterministic reductions (libprosper_hip_det.so) ------------------------------------------------------------
+    @staticmethod
+    def _magic(bound):
+        """1.5 * 2^e with 2^(e-1) >= bound: adding and subtracting it rounds a value to a multiple of 2^(e-52) (PM_Q)."""
+        b = float(bound)
+        if not np.isfinite(b) or b <= 0.0:
+            return 0.0
+        return 1.5 * 2.0 ** (int(np.ceil(np.log2(b))) + 1)
+
+    def _det_set(self, unit, bounds):
+        """Install the quanta of one kernel family (include/prosper_hip.h: pm_det_set_quanta) ahead of its next launches:
+        ``bounds[c]`` = what no partial sum of category c can exceed on this shard with these parameters."""
+        M = (ctypes.c_double * 8)(*([self._magic(b) for b in bounds] + [0.0] * (8 - len(bounds))))
+        keep = self.__dict__.setdefault("_det_keep", [])
+        keep.append(M)
+        del keep[:-16]
+        _lib.call("pm_det_set_quanta", _lib.DET_UNITS[unit], M, self._stream(), det=True)
+
+    def _det_data_bounds(self, res):
+        """(max |y_nd|, max |y_n|) over the resident shard: constants of the data, once per shard."""
+        b = res.get("det_bounds")
+        if b is None:
+            Y = res["Y"]
+            b = res["det_bounds"] = ((float(Y.abs().max()), float(res["ynorm2"].max().sqrt())) if Y.shape[0] else (0.0, 0.0))
+        return b
 
     def step(self, anneal, model_params, my_data):
         """CAModel.step (camodels/__init__.py:163-193); the E-step knows that the M-step follows with the same arguments."""
@@ -252,6 +284,8 @@ class DeviceCAModel(CAModel):
         if not N:
             return out
         st = self._stream()
+        if self.deterministic:
+            self._det_dsc_quanta(res, par, P, prior, Kt)
         fuse = (getattr(self, "_in_step", False) and getattr(self, "fuse_mstats", True) and anneal['Ncut_factor'] <= 0.0
                 and bool(lib.pm_dsc_estep_mstats_supported(H, Hp, S, int(P.K), int(P.flags))))
         if fuse:
@@ -270,6 +304,21 @@ class DeviceCAModel(CAModel):
             self._call("estep", "pm_dsc_estep_f64", _ptr(par["A"]), H, _ptr(par["G"]), _ptr(res["ynorm2"]), _ptr(cand),
                        _ptr(tab), S, _ptr(prior), ctypes.byref(P), N, H, Hp, _ptr(logpj), Kt, _ptr(lse), st)
         return out
+
+    def _det_dsc_quanta(self, res, par, P, prior, Kt):
+        """Deterministic mode, DSC / TSC: bounds of the statistics' partial sums (latent values v_k, |v| <= vmax) -> quanta of
+        the row kernels, the sparse product and the dense GEMM behind its gate (pm_common.h, PM_Q).  Set ahead of the E-step,
+        whose parameters the M-step of the same EM step shares."""
+        ymax, ynmax = self._det_data_bounds(res)
+        W = np.asarray(par["W"], dtype=np.float64)
+        wn = float(np.sqrt((W * W).sum(axis=0)).max()) if W.size else 0.0
+        vmax = float(max(abs(P.values[k]) for k in range(int(P.K))))
+        emax = (ynmax + self.gamma * vmax * wn) ** 2
+        lpmax = abs(P.pscale) * float(prior.abs().max()) + abs(P.ecoef) * emax + np.log(max(Kt, 2))
+        n = float(res["Y"].shape[0])
+        self._det_set("dsc", [n * max(1.0, vmax * vmax), n * emax, n * lpmax])
+        self._det_set("wp_sparse", [n * vmax * ymax])
+        self._det_set("gemm", [n * max(1.0, vmax) * ymax, n * ymax])
 
     def _dsc_fused_stats(self, logpj, res, cand, P, pi_key, lse_cut):
         """The statistics workspace the E-step pass has already filled for exactly this M-step, or None."""

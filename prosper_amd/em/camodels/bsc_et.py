@@ -490,7 +490,9 @@ class BSC_ET(DeviceCAModel):
             cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
             mode = 3
         mstats, rows = None, 0
-        if N and want_ms and self.fuse_mstats and self._fused() and Hp <= 8 and 'mu' not in self.to_learn:
+        # (deterministic mode: the statistics come from the M-step's own pass, which knows the parameters its quanta derive from)
+        if N and want_ms and self.fuse_mstats and self._fused() and Hp <= 8 and 'mu' not in self.to_learn \
+                and not self.deterministic:
             n_stats = _lib.load().pm_bsc_stats_len(H, D)
             # two statistics workspaces alternate: the M-step that launches the NEXT E-step (speculation) still reads its
             # own Wp -- the right-hand side of the W solve, and of the host fallback -- from the other one
@@ -637,6 +639,8 @@ class BSC_ET(DeviceCAModel):
         expect = self._buf("expect", (my_N, H))
         P = self._estep_params(anneal, pies, sigma, mu)
         st = self._stream()
+        if self.deterministic and my_N:
+            self._det_quanta(res, np.asarray(model_params['W'], dtype=np.float64), mu, P, N)
         # statistics the E-step pass has already produced for its first `done` rows (same shard, candidates, scalars)
         ms = getattr(logpj, "mstats", None) if isinstance(logpj, DeviceArray) else None
         if ms is not None and any(ms["stats"] is self._ws.get("stats%d" % k) for k in (0, 1)):
@@ -714,6 +718,23 @@ class BSC_ET(DeviceCAModel):
         # the exchange of the step (replaces bsc_et.py:225,258,266,373,374,387,417,426,427)
         comm.allreduce_device(packed)
         return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res, None, anneal)
+
+    def _det_quanta(self, res, W_DH, mu, P, N):
+        """Deterministic mode: bounds no partial sum of the M-step's statistics can exceed on this shard with these
+        parameters -> the quanta of the kernels about to run (pm_common.h, PM_Q).  Energies: |y - mu - sum_{h in s} W_h|^2
+        <= (|y| + |mu| + gamma max|W_h|)^2; log-joints: prior + |ecoef| energy; sums of probabilities: N."""
+        ymax, ynmax = self._det_data_bounds(res)
+        wn = float(np.sqrt((W_DH * W_DH).sum(axis=0)).max()) if W_DH.size else 0.0
+        mun, mumax = float(np.linalg.norm(mu)), float(np.abs(mu).max()) if np.size(mu) else 0.0
+        emax = (ynmax + mun + self.gamma * wn) ** 2
+        K = 1 + self.H + self.no_states
+        lpmax = abs(P.prior_scale * P.pil_bar) * self.gamma + abs(P.ecoef) * emax + np.log(K)
+        n = float(max(N, res["Y"].shape[0]))
+        cats = [n, n * emax, n * lpmax]
+        for unit in ("bsc_rows16", "bsc_kernels", "bsc_fused", "bsc_fused8"):
+            self._det_set(unit, cats)
+        self._det_set("wp_sparse", [n * (ymax + mumax)])
+        self._det_set("gemm", [n * (ymax + mumax), n * (ymax + mumax)])
 
     def _scalar_updates(self, host, pies, sigma, E_pi_gamma):
         """pi and sigma updates (bsc_et.py:393-420) from the head of the downloaded statistics, ``host`` =

@@ -365,6 +365,8 @@ class GSC(DeviceCAModel):
         N, D = Y.shape
         H, Hp, S = self.H, self.Hprime, self.no_states
         par = self._tables_for(model_params, res)
+        if self.deterministic and N:
+            self._det_quanta(res, model_params)
         A = None
         if N:
             A = par.pop("scores", None)          # left by the previous M-step (_speculate); good for one pass
@@ -410,8 +412,8 @@ class GSC(DeviceCAModel):
                        _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
                        ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
                        _ptr(stats), _ptr(logpj), logpj.stride(0), self._stream())
-        elif N and lists and self.fuse_moment_gemm and self.sparse_moments and cand_in is None and \
-                _lib.load().pm_gsc_lists_supported(H, Hp, self.gamma, D):
+        elif N and lists and self.fuse_moment_gemm and self.sparse_moments and cand_in is None and not self.deterministic \
+                and _lib.load().pm_gsc_lists_supported(H, Hp, self.gamma, D):
             # (`tables` comes from pm_gsc_mstep_finish_f64 here: its slot 8 H + 1 holds the list threshold)
             lb = res.setdefault("gsc_lists", [None, None])
             if lb[k] is None:
@@ -615,7 +617,10 @@ class GSC(DeviceCAModel):
             return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float64)).to(self.device)
 
         old_dev = None
-        if self.speculate and self.speculate_estep and self.sigma_sq_type == 'scalar' and my_N and 'W' in self.to_learn:
+        if self.deterministic and my_N:
+            self._det_quanta(res, model_params)
+        if self.speculate and self.speculate_estep and self.sigma_sq_type == 'scalar' and my_N and 'W' in self.to_learn \
+                and not self.deterministic:
             # the old parameters for pm_gsc_mstep_finish_f64, uploaded NOW: enqueued in front of the contraction they are on
             # the device long before the finish kernel wants them (uploaded next to it, the copy and its latency sat in the
             # middle of the M-step's chain of small launches: ~30 us of idle device per step)
@@ -757,7 +762,8 @@ class GSC(DeviceCAModel):
         # with exactly the parameters this M-step returns).  The host still receives everything with the one download.
         fin = None
         scores_side = None
-        if Wt_next is not None and self.speculate_estep and my_N and old_dev is not None:
+        # (deterministic mode: the next E-step is launched by E_step itself, from host-side parameters whose norms bound its sums)
+        if Wt_next is not None and self.speculate_estep and my_N and old_dev is not None and not self.deterministic:
             if self.overlap_scores and self.timer is None:
                 # the scores GEMM needs W_new^T only: it starts here on the second stream while the main one still runs the
                 # Gram product, the one-workgroup finish kernel and the download (0.04 ms of a mostly idle device at config 4)
@@ -851,6 +857,25 @@ class GSC(DeviceCAModel):
         with small_blas():
             return self._update(model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss,
                                 sum_xpt_szsz, sum_yy, data_sq, inverses, W_given)
+
+    def _det_quanta(self, res, model_params):
+        """Deterministic mode (scalar sigma_sq): bounds of the sums the E-step kernel and the moment GEMM accumulate.  Posterior
+        means: |kappa| <= |mu| + min(|y| / min_h |W_h|, |Psi| |W_a| (|y| + |W_a| |mu_a|) / sigma^2)  (Lambda >= Psi^-1);
+        second moments: kappa^2 + Lambda^-1 <= kappa^2 + max psi_hh."""
+        if self.sigma_sq_type != 'scalar':
+            raise _lib.HipError("GSC: deterministic mode is built for scalar sigma_sq")
+        ymax, ynmax = self._det_data_bounds(res)
+        W = np.asarray(model_params['W'], dtype=np.float64)
+        mu, psi = np.asarray(model_params['mu'], dtype=np.float64), np.asarray(model_params['psi_sq'], dtype=np.float64)
+        s2 = float(model_params['sigma_sq'])
+        wn = np.sqrt((W * W).sum(axis=0))
+        mumax, g = float(np.abs(mu).max()), self.gamma
+        wa = np.sqrt(g) * float(wn.max())
+        zb = mumax + min(ynmax / max(float(wn.min()), 1e-300),
+                         float(np.abs(psi).sum(axis=1).max()) * wa * (ynmax + wa * np.sqrt(g) * mumax) / s2)
+        n = float(res["Y"].shape[0])
+        self._det_set("gsc", [n, n * zb, n * (zb * zb + float(np.abs(np.diag(psi)).max()))])
+        self._det_set("gemm", [n * max(ymax, 1.0, zb) * zb])
 
     def _eps_diag(self, H, eps):
         """[eps ... eps | 0 ... 0]: the diagonal terms of the batched inverse of (sum_ss + eps I, sum_zz)."""

@@ -175,6 +175,8 @@ class MCA_ET(DeviceCAModel):
         lseb = torch.empty((N,), dtype=torch.float64, device=self.device)
         tracing.tracepoint("E_step:iterating")
         fused = None
+        if N and self.deterministic:
+            self._det_quanta(res, model_params, P, K)
         if N:
             A = self._gemm_nt(Y, par["Wt"], self._buf("scores", (N, H)), "scores_gemm")
             hp_tile = 4 if Hp <= 4 else 8 if Hp <= 8 else 12
@@ -257,6 +259,8 @@ class MCA_ET(DeviceCAModel):
             stats.zero_()
             q1 = self._buf("mca_q1", (my_N, H))
             P = self._params(anneal, pies, sigma, par["rho"])
+            if my_N and self.deterministic:
+                self._det_quanta(res, model_params, P, K)
             if my_N:
                 self._call("mstep_rows", "pm_mca_mstep_rows_f64", _ptr(lp), K, _ptr(lse1), _ptr(lseb),
                            ctypes.c_double(lse_cut), _ptr(Y), D, _ptr(par["Wrho"]), _ptr(par["Wrm1"]), _ptr(cand),
@@ -268,6 +272,19 @@ class MCA_ET(DeviceCAModel):
         comm.allreduce_device(stats)      # replaces mca_et.py:208,253,340,341,357,366,371
         self._mstep_res = res
         return self._finalize(stats, model_params, par, A_pi_gamma, B_pi_gamma)
+
+    def _det_quanta(self, res, model_params, P, K):
+        """Deterministic mode: bounds of the statistics' partial sums -> quanta (pm_common.h, PM_Q).  Every M-step weight
+        q_s (W_j / Wbar_s)^(rho-1) is <= 1 (Wbar_s >= each of its terms), so Wq <= N and |Wp| <= N max|y|; energies
+        |Wbar_s - y|^2 <= (|y| + gamma max|W_h|)^2."""
+        ymax, ynmax = self._det_data_bounds(res)
+        W = np.maximum(np.abs(np.asarray(model_params['W'], dtype=np.float64)), self.W_tol)
+        wn = float(np.sqrt((W * W).sum(axis=0)).max())
+        emax = (ynmax + self.gamma * wn) ** 2
+        lpmax = (abs(P.pil_bar) * self.gamma + abs(P.pre1) * emax) * max(1.0, abs(P.beta)) + np.log(max(K, 2))
+        n = float(res["Y"].shape[0])
+        self._det_set("mca", [n, n * ymax, n * self.gamma, n * emax, n * lpmax])
+        self._det_set("gemm", [n * ymax, n * ymax])
 
     def _finalize(self, stats, model_params, par, A_pi_gamma, B_pi_gamma):
         """Element-wise W update and the scalars (mca_et.py:333-377), one device->host copy."""

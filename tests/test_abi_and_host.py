@@ -26,6 +26,20 @@ def test_library_exports_every_declared_symbol():
     assert b"invalid" in lib.pm_error_string(-1)
 
 
+def test_deterministic_build_exports_the_same_abi():
+    """libprosper_hip_det.so (the same sources with -DPM_DETERMINISTIC) exports every declared symbol too, says so, and the default
+    build refuses quanta (its kernels contain no quantisation)."""
+    from prosper_amd import _lib
+    import ctypes
+    det, lib = _lib.load(det=True), _lib.load()
+    for name in _lib.SIGNATURES:
+        assert hasattr(det, name), name
+    assert det.pm_det_build() == 1 and lib.pm_det_build() == 0
+    M = (ctypes.c_double * 8)()
+    assert lib.pm_det_set_quanta(0, M, None) == -2
+    assert det.pm_det_set_quanta(99, M, None) == -1
+
+
 def test_stats_layout_helpers():
     from prosper_amd import _lib
     lib = _lib.load()

@@ -1,0 +1,150 @@
+"""Deterministic-reduction mode (`model.deterministic = True`, libprosper_hip_det.so): the reference at a fixed number of ranks
+is deterministic, the HIP path sums its M-step statistics with f64 atomics whose order changes from run to run.  In the
+deterministic build every addend is rounded to a common quantum first (pm_common.h, PM_Q), so the sums -- and with them every
+parameter -- come out bit for bit the same in every run; and because nothing else changes, comparing it with the default build
+step by step doubles as a race detector for the atomics (a lost or doubled update is no rounding-level difference)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class _An(dict):
+    crit_params = []
+
+    def __missing__(self, k):
+        return 0.0
+
+    def as_dict(self):
+        return dict(self)
+
+
+def _copy(p):
+    return {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+
+
+def _bsc(shape):
+    from oracle import bsc_oracle as O
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, g, N = shape
+    rng = np.random.RandomState(11)
+    W = rng.normal(size=(D, H))
+    y = O.generate_bsc_data(W, 2.0 / H, 1.0, N, rng)[0]
+    return (lambda: BSC_ET(D, H, Hp, g)), {"W": W + 0.2 * rng.normal(size=(D, H)), "pi": 2.5 / H, "sigma": 1.1}, y, ("W", "pi", "sigma")
+
+
+def _mca(shape):
+    from oracle import mca_oracle as O
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    D, H, Hp, g, N = shape
+    rng = np.random.RandomState(12)
+    W = np.abs(rng.normal(size=(D, H))) * 3 + 0.1
+    y = O.generate_mca_data(W, 2.0 / H, 1.0, N, rng)[0]
+    return (lambda: MCA_ET(D, H, Hp, g)), {"W": W * rng.uniform(0.9, 1.1, size=W.shape), "pi": 2.5 / H, "sigma": 1.1}, y, ("W", "pi", "sigma")
+
+
+def _dsc(shape):
+    from prosper_amd.em.camodels.dsc_et import DSC_ET
+    D, H, Hp, g, N = shape
+    rng = np.random.RandomState(13)
+    states = np.array([-1.0, 0.0, 1.0, 2.0])
+    W = rng.normal(size=(D, H))
+    s = states[rng.choice(4, size=(N, H), p=[0.04, 0.88, 0.05, 0.03])]
+    y = s @ W.T + rng.normal(size=(N, D))
+    return ((lambda: DSC_ET(D, H, Hp, g, states=states.copy())),
+            {"W": W + 0.2 * rng.normal(size=(D, H)), "pi": np.array([0.05, 0.85, 0.06, 0.04]), "sigma": 1.1}, y, ("W", "pi", "sigma"))
+
+
+def _gsc(shape):
+    from oracle import gsc_oracle as O
+    from prosper_amd.em.camodels.gsc_et import GSC
+    D, H, Hp, g, N = shape
+    rng = np.random.RandomState(14)
+    gt = {"W": rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.5), "psi_sq": np.eye(H), "sigma_sq": 1.0}
+    y = O.generate_gsc_data(gt, N, rng)[0]
+    p = {"W": gt["W"] + 0.1 * rng.normal(size=(D, H)), "pi": gt["pi"] * 1.1, "mu": gt["mu"] + 0.1 * rng.normal(size=H),
+         "psi_sq": np.diag(rng.uniform(0.7, 1.4, size=H)), "sigma_sq": 1.2}
+    return (lambda: GSC(D, H, Hp, g, "scalar")), p, y, ("W", "pi", "mu", "psi_sq", "sigma_sq")
+
+
+_CASES = {
+    "bsc_small": (_bsc, (20, 12, 5, 3, 700)), "bsc_fast": (_bsc, (64, 160, 8, 3, 1500)),      # fast: the 16-wavefront kernel's shapes
+    "mca": (_mca, (64, 128, 8, 3, 900)), "dsc": (_dsc, (32, 24, 5, 3, 900)), "gsc": (_gsc, (128, 128, 6, 3, 1200)),
+}
+
+
+def _loop(make, p0, y, keys, steps, det, schedule):
+    m = make()
+    m.deterministic = det
+    p, traj = _copy(p0), []
+    for it in range(steps):
+        p = m.step(_An(schedule(it)), p, {"y": y})
+        traj.append({k: np.array(p[k], copy=True) for k in keys})
+    return traj
+
+
+@pytest.mark.parametrize("case", sorted(_CASES))
+def test_deterministic_mode_repeats_bit_for_bit(case):
+    """The same 50-step EM loop twice (annealing, and for the models that have it a data-truncation phase): every parameter of
+    every step identical to the last bit; and the loop stays within rounding of the default build's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    fn, shape = _CASES[case]
+    make, p0, y, keys = fn(shape)
+    cut = case.startswith(("bsc", "mca", "dsc"))
+    schedule = lambda it: {"T": 1.5 if it < 10 else 1.0, "Ncut_factor": 0.6 if (cut and it >= 30) else 0.0}
+    a = _loop(make, p0, y, keys, 50, True, schedule)
+    b = _loop(make, p0, y, keys, 50, True, schedule)
+    for it, (pa, pb) in enumerate(zip(a, b)):
+        for k in keys:
+            assert np.array_equal(pa[k], pb[k]), "%s: step %d, %s differs between two deterministic runs" % (case, it, k)
+    assert all(np.isfinite(a[-1][k]).all() for k in keys)
+
+
+@pytest.mark.parametrize("case", sorted(_CASES))
+def test_deterministic_mode_agrees_with_the_default_build_step_by_step(case):
+    """One EM step from the same parameters in both builds, over a short trajectory: the quantum costs at most the rounding
+    error the plain sums make on their largest entries (1e-9 here; a lost or doubled atomic update would be orders above)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    fn, shape = _CASES[case]
+    make, p0, y, keys = fn(shape)
+    md, mp = make(), make()
+    md.deterministic = True
+    p = _copy(p0)
+    for it in range(8):
+        an = _An(T=1.3 if it < 3 else 1.0, Ncut_factor=0.5 if (it >= 6 and not case.startswith("gsc")) else 0.0)
+        qd = md.step(an, _copy(p), {"y": y})
+        qp = mp.step(an, _copy(p), {"y": y})
+        for k in keys:
+            ref = np.asarray(qp[k], dtype=np.float64)
+            got = np.asarray(qd[k], dtype=np.float64)
+            if case == "mca" and k == "W":
+                # W_new = Wp / Wq element by element: where both are a few quanta the ratio is ill-determined in either build
+                # (a quantum is 2^-52 of the bound N on Wq: an element whose Wq is 1e-6 keeps seven digits)
+                rel = np.abs(got - ref) / (np.abs(ref) + 1e-300)
+                assert (rel <= 1e-7).mean() > 0.95 and np.median(rel) < 1e-11, \
+                    "%s step %d: %d elements of W apart, median %.2e" % (case, it, int((rel > 1e-7).sum()), np.median(rel))
+                continue
+            np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(ref).max())),
+                                       err_msg="%s step %d %s" % (case, it, k))
+        p = {k: qp[k] for k in qp}
+
+
+def test_default_build_is_not_bitwise_reproducible_where_the_deterministic_one_is():
+    """What the mode is for: the same loop in the DEFAULT build at a size where many atomics race (BSC, 20k datapoints) --
+    two runs are expected to differ in the last bits somewhere (reported, not required: nothing forces a race to show), the
+    deterministic build's two runs may not."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    make, p0, y, keys = _bsc((64, 160, 8, 3, 20000))
+    sched = lambda it: {"T": 1.0}
+    runs = {det: [_loop(make, p0, y, keys, 12, det, sched) for _ in range(2)] for det in (False, True)}
+    differing = {det: sum(any(not np.array_equal(a[k], b[k]) for k in keys) for a, b in zip(*runs[det])) for det in runs}
+    print("steps (of 12) whose parameters differ between two identical runs: default build %d, deterministic build %d"
+          % (differing[False], differing[True]))
+    assert differing[True] == 0
+    for a, b in zip(runs[False][0], runs[True][0]):          # ... and the two builds stay within rounding of each other
+        for k in keys:
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-7, atol=1e-9 * max(1.0, float(np.abs(a[k]).max())))
