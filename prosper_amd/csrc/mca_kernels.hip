@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
     // rho = 21 (every temperature T <= 1.05), unsigned W: the log / exp-free power (pm_pow_m20_21)
     __shared__ __attribute__((aligned(16))) double s_rt[PM_ROOT21_LEN + 1];
     const bool r21 = P.signed_w == 0.0 && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
+    const bool r6 = P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 6.0) < 1e-9;       // (MMCA's steady rho; either sign of W)
     if (r21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
+    else if (r6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
     __syncthreads();
 
     const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
@@ -206,7 +208,8 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
                 // MMCA: T may be negative or 0 (mmca_et.py:191: sign(t) exp(log|t| / rho)); for MCA T > 0
                 const double aT = fabs(T[i]);
                 const double wbar = (aT > 0.0) ? (r21 ? aT * pm_pow_m20_21(aT, s_rt)
-                                                      : copysign(pm_pow_tab(aT, P.inv_rho, s_tab), T[i]))
+                                                  : r6 ? copysign(aT * pm_pow_m5_6(aT, s_rt), T[i])
+                                                       : copysign(pm_pow_tab(aT, P.inv_rho, s_tab), T[i]))
                                                : 0.0;
                 const double df = wbar - y[i];
                 part = fma(df, df, part);
@@ -277,8 +280,9 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
 // smaller than its final value, so nothing underflows that would survive in the two-pass form.
 // ---------------------------------------------------------------------------------------------
 
-// RHO21: rho = 21 (every temperature T <= 1.05, unsigned W): the states' power through pm_pow_m20_21 (no log / exp)
-template <int DPL, int HP, bool SIGNED, bool RHO21>
+// ROOT = 21: rho = 21 (every temperature T <= 1.05, unsigned W): the states' power through pm_pow_m20_21 (no log / exp);
+// ROOT = 6: rho = 6 (MMCA at every T <= 1.2): pm_pow_m5_6; ROOT = 0: any rho, the table power
+template <int DPL, int HP, bool SIGNED, int ROOT>      // ROOT: 21 / 6 = the log / exp-free powers of those rho, 0 = the table power
 __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
                                        const double *__restrict__ wnorm2, const double *__restrict__ ynorm2,
                                        const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
     double *s_rt = s_tab + PM_POWTAB_LEN;
     double *s_q1sum = s_rt + PM_ROOT21_LEN + 1;          // (+ 1: 16-byte alignment of what follows stays as it was)
     pm_load_powtab(s_tab, tid, blockDim.x);
-    if (RHO21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
+    if (ROOT == 21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
+    if (ROOT == 6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
     double *s_red = s_q1sum + H;
     const size_t per_wave = (size_t)(SIGNED ? 2 : 1) * HP * DS + S;
     double *s_wr = s_red + 4 * waves + (size_t)wave * per_wave;
@@ -370,7 +375,8 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
             for (int i = 0; i < DPL; ++i) {
                 const double aT = SIGNED ? fabs(T[i]) : T[i];      // (unsigned W: T is a sum of W^rho >= 0)
                 const double r = (PM_MCA_ABL == 2) ? aT * 0.37
-                                 : (RHO21 ? pm_pow_m20_21(aT, s_rt) : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
+                                 : (ROOT == 21 ? pm_pow_m20_21(aT, s_rt) : ROOT == 6 ? pm_pow_m5_6(aT, s_rt)
+                                                                                 : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
                 const double wb = (aT > 0.0) ? aT * r : 0.0;
                 const double df = (SIGNED ? copysign(wb, T[i]) : wb) - y[i];
                 partP = fma(df, df, partP);
@@ -397,7 +403,8 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                 // M-step weights (no division).  Padding dimensions have T = 0: Wbar = 0, never scattered.
                 const double aT = SIGNED ? fabs(T[i]) : T[i];      // (unsigned W: T is a sum of W^rho >= 0)
                 const double r = (PM_MCA_ABL == 2) ? aT * 0.37
-                                 : (RHO21 ? pm_pow_m20_21(aT, s_rt) : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
+                                 : (ROOT == 21 ? pm_pow_m20_21(aT, s_rt) : ROOT == 6 ? pm_pow_m5_6(aT, s_rt)
+                                                                                 : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
                 const double wb = (aT > 0.0) ? aT * r : 0.0;
                 const double df = (SIGNED ? copysign(wb, T[i]) : wb) - y[i];
                 partN = fma(df, df, partN);
@@ -608,7 +615,9 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
     for (int h = tid; h < H; h += blockDim.x) s_q1sum[h] = 0.0;
     __shared__ __attribute__((aligned(16))) double s_rt[PM_ROOT21_LEN + 1];       // (see mca_estep_kernel)
     const bool r21 = !SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
+    const bool r6 = SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 6.0) < 1e-9;
     if (r21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
+    else if (r6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
     __syncthreads();
 
     // multi-cause numerator / denominator (stats[0 .. H*D) = Q1^T Y by the GEMM): this XCD's copy, folded by
@@ -721,7 +730,7 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
                         // q_s min(1, (|W_jd| / |Wbar_sd|)^(rho-1)), (.)^(rho-1) = |W_jd|^(rho-1) |Wbar_sd| / |t_sd|;
                         // t = 0 gives Wbar = 0 and the factor 1 (mmca_et.py:316-324: max(-inf - Wl, 0) = 0)
                         const double aT = fabs(T[i]);
-                        v[i] = (aT > 0.0) ? q * pm_pow_tab(aT, P.inv_rho - 1.0, s_tab) : INFINITY;
+                        v[i] = (aT > 0.0) ? q * (r6 ? pm_pow_m5_6(aT, s_rt) : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab)) : INFINITY;
                     }
                 }
 #pragma unroll
@@ -942,19 +951,33 @@ int launch_fused_hp(int Hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, 
 #else
     const bool rho21 = !SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
 #endif
+    // rho = 6 (MMCA at T <= 1.2, mmca_et.py:37): pm_pow_m5_6
+#ifdef PM_MCA_NO_ROOT6          // (A/B builds: scratch/mca_ab.sh)
+    const bool rho6 = false;
+#else
+    const bool rho6 = SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 6.0) < 1e-9;
+#endif
 #define PM_CASE(HPV)                                                                                                  \
     case HPV: {                                                                                                       \
         if (rho21) {                                                                                                  \
-            if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, false, true>), shmem)) \
+            if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, false, 21>), shmem)) \
                 return e;                                                                                             \
-            hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, false, true>), grid, block, shmem, s, scores, lds, wnorm2, \
+            hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, false, 21>), grid, block, shmem, s, scores, lds, wnorm2, \
                                ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, \
                                ldq, stats);                                                                           \
             return (int)hipGetLastError();                                                                            \
         }                                                                                                             \
-        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, SIGNED, false>), shmem)) \
+        if (rho6) {                                                                                                   \
+            if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, true, 6>), shmem)) \
+                return e;                                                                                             \
+            hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, true, 6>), grid, block, shmem, s, scores, lds, wnorm2, \
+                               ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, \
+                               ldq, stats);                                                                           \
+            return (int)hipGetLastError();                                                                            \
+        }                                                                                                             \
+        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, SIGNED, 0>), shmem)) \
             return e;                                                                                                 \
-        hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, SIGNED, false>), grid, block, shmem, s, scores, lds, wnorm2, \
+        hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, SIGNED, 0>), grid, block, shmem, s, scores, lds, wnorm2, \
                            ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, ldq, \
                            stats);                                                                                    \
         return (int)hipGetLastError();                                                                                \

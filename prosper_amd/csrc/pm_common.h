@@ -258,6 +258,41 @@ __device__ __forceinline__ double pm_pow_m20_21(double x, const double *rt) {
     return __hiloint2double(__double2hiint(v) + (int)((1000u - 20u * q) << 20), __double2loint(v));
 }
 
+// x^(1/6 - 1) = x^(-5/6) for NORMAL x > 0: the same construction for rho = 6 -- MMCA's power at every temperature T <= 1.2
+// (mmca_et.py:37, 127-199: rho = 1 / (1 - 1 / max(T, 1.2))), the steady state of its runs.  x = 2^(6 q + r) m, x' = 2^r m,
+// y0 = 2^(-r/6) r_i^(1/6) (1 - d / 6) (error 7 d^2 / 72 < 6e-6), x'^(-5/6) = y0^5 (1 - res)^(-5/6), res = 1 - x' y0^6 (|res| < 4e-5:
+// three series terms, the fourth is 1e-18).  12 f64 + 11 integer instructions.  `rt` from pm_load_root6 (layout of pm_load_root21).
+__device__ __forceinline__ void pm_load_root6(double *rt, const double *powtab, int tid, int nthreads) {
+    for (int i = tid; i < 128; i += nthreads) {
+        const double ri = powtab[2 * i];
+        rt[2 * i] = ri;
+        rt[2 * i + 1] = pow(ri, 1.0 / 6.0);
+    }
+    for (int r = tid; r < 6; r += nthreads) rt[256 + r] = exp2(-(double)r / 6.0);
+}
+__device__ __forceinline__ double pm_pow_m5_6(double x, const double *rt) {
+    typedef double pm_d2 __attribute__((ext_vector_type(2)));
+    const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
+    const unsigned idx = (hi >> 13) & 127u;
+    const pm_d2 rs = reinterpret_cast<const pm_d2 *>(rt)[idx];
+    const unsigned eu = (hi >> 20) + 27u;                    // biased exponent - 1023 + 1050 (= 6 * 175) in [28, 2073]
+    const unsigned q = (eu * 10923u) >> 16;                  // eu / 6 (exact on that range)
+    const unsigned r = eu - 6u * q;
+    const unsigned mant = hi & 0x000FFFFFu;
+    const double m = __hiloint2double((int)(mant | 0x3FF00000u), (int)lo);             // [1, 2)
+    const double xp = __hiloint2double((int)(mant | ((1023u + r) << 20)), (int)lo);    // 2^r m
+    const double d = fma(m, rs.x, -1.0);
+    const double y0 = (rs.y * rt[256 + r]) * fma(d, -1.0 / 6.0, 1.0);
+    const double y2 = y0 * y0, y4 = y2 * y2;
+    const double y5 = y4 * y0;
+    const double res = fma(-xp, y5 * y0, 1.0);
+    double t = fma(res, 5.0 * 11.0 * 17.0 / (6.0 * 216.0), 5.0 * 11.0 / (2.0 * 36.0));
+    t = fma(t, res, 5.0 / 6.0);
+    const double v = fma(y5, t * res, y5);
+    // * 2^(-5 (q - 175))
+    return __hiloint2double(__double2hiint(v) + (int)((875u - 5u * q) << 20), __double2loint(v));
+}
+
 // e^x for x <= ~700 from the same tables: x = k ln2/128 + r (two-part ln2/128, |r| <= ln2/256), e^r by a degree-5
 // polynomial, 2^(k/128) = 2^N E_j.  Arguments below -708 return ~1e-308 (callers only scale by it).  14 VALU slots and one
 // LDS lookup; relative error <= 2.3e-16.
