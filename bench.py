@@ -67,8 +67,8 @@ def parse():
     return ap.parse_args()
 
 
-VALU_COUNTS = "r04_valu_counts.json"
-PMC_TRAFFIC = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+VALU_COUNTS = "r05_valu_counts.json"
+PMC_TRAFFIC = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def _library_sha16():
