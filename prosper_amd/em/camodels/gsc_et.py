@@ -662,6 +662,57 @@ class GSC(DeviceCAModel):
         if whole is None or whole.numel() != n_whole or whole.device != torch.device(self.device):  # critical path)
             whole = torch.zeros(n_whole, dtype=torch.float64, device=self.device)
         packed = whole[:n_stat]
+        o = nWp + 2 * nHH
+        o2 = o + 2 * nHH
+        o_wt, o_par = o_inv + n_inv, o_inv + n_inv + nWp
+        at = lambda off: ctypes.c_void_p(whole.data_ptr() + 8 * off)
+        yy = res.get("ynorm2_sum")                   # sum_n |y_n|^2: a constant of the resident shard
+        if yy is None:
+            yy = res["ynorm2_sum"] = res["ynorm2"].sum().reshape(1)
+
+        def invert(st):
+            """The two H x H inverses of the update (gsc_et.py:625, 673) on the device, ahead of the download: a 128 x 128 LAPACK
+            inverse costs 0.4 ms of host time each while the GPU idles.  [sum_ss ; sum_zz] sit back to back in the statistics;
+            inverses are stored in that order: [(sum_ss + eps I)^-1 ; sum_zz^-1 ; 4 pivots].  sum_zz is a GENERAL matrix from the
+            second EM step on (psi_sq is not symmetric any more: gsc_et.py:660-675) and the reference inverts it as it is (:625):
+            the left-sided Newton-Schulz refinement of pm_inverse_warm_batch_f64 (its result is the inverse of the transpose --
+            what W_new^T = (A^-1)^T Wp^T needs), started from the previous EM step's inverses or, cold, from the sweep's inverses
+            of the upper-mirrored matrices (within ~1e-6).  (PM_WARM_INVERSE=0 only forces the cold START; the Newton-Schulz pass
+            itself is not optional here -- it is what inverts the general matrix.)"""
+            dadd = self._eps_diag(H, eps)
+            prev = getattr(self, "_inv_prev", None)
+            if not (prev is not None and tuple(prev.shape) == (2, H, H) and os.environ.get("PM_WARM_INVERSE", "1") == "1"):
+                # ONE launch, one workgroup per matrix: the two sweeps run side by side on two CUs
+                self._call("spd_inverse", "pm_spd_inverse_batch_f64", at(o), H, nHH, _ptr(dadd), H, None, at(o_inv), H, nHH,
+                           at(o_inv + 2 * nHH), 2, st)
+                prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H).clone()
+            work = self._buf("spd_warm_work", (2 * int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
+            self._call("spd_inverse", "pm_inverse_warm_batch_f64", at(o), H, nHH, _ptr(dadd), H, _ptr(prev), nHH,
+                       _ptr(work), at(o_inv), nHH, at(o_inv + 2 * nHH), at(o_inv + 2 * nHH + 4), 2, 2, st)
+            self._inv_prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H)     # (`whole` is this step's own tensor: no copy)
+
+        def pack_and_invert():
+            """[sum_ss | sum_zz | sum_s | sum_sz | sum |y|^2] straight from the E-step kernel's buffer, then the inverses."""
+            st = self._stream()
+            self._call("pack_stats", "pm_gsc_pack_stats_f64", _ptr(raw[0]), H, _ptr(yy),
+                       ctypes.c_void_p(packed.data_ptr() + 8 * o), st)
+            invert(st)
+
+        # On one rank the inverses need nothing but the E-step kernel's own sums: their chain of eight small launches (~60 us on
+        # a mostly idle device) runs on a stream of its own BESIDE the contraction over the datapoints instead of behind it.
+        inv_early = None
+        if (raw is not None and my_N and whole.is_cuda and H <= 256 and getattr(comm, "size", 1) == 1 and self.overlap_moments
+                and self.timer is None and not self.deterministic):
+            s3 = getattr(self, "_inv_stream", None)
+            if s3 is None:
+                s3 = self._inv_stream = torch.cuda.Stream(device=self.device)
+            fork3 = torch.cuda.Event()
+            fork3.record()
+            s3.wait_event(fork3)
+            with torch.cuda.stream(s3):
+                pack_and_invert()
+                inv_early = torch.cuda.Event()
+                inv_early.record(s3)
         if my_N:
             s = self._stream()
             lists = getattr(raw[0], "_pm_lists", None) if (raw is not None and big is not None and self._in_step) else None
@@ -707,12 +758,9 @@ class GSC(DeviceCAModel):
                            ctypes.c_void_p(packed.data_ptr() + 8 * nWp), H, H, H, my_N, s)
                 self._call("moment_gemm", "pm_gemm_tn_acc_f64", _ptr(xsz), H, _ptr(xsz), H,
                            ctypes.c_void_p(packed.data_ptr() + 8 * (nWp + nHH)), H, H, H, my_N, s)
-        o = nWp + 2 * nHH
-        o2 = o + 2 * nHH
-        yy = res.get("ynorm2_sum")                   # sum_n |y_n|^2: a constant of the resident shard
-        if yy is None:
-            yy = res["ynorm2_sum"] = res["ynorm2"].sum().reshape(1)
-        if raw is not None:      # [sum_ss | sum_zz | sum_s | sum_sz | sum |y|^2] straight from the E-step kernel's buffer
+        if inv_early is not None:
+            pass
+        elif raw is not None:
             self._call("pack_stats", "pm_gsc_pack_stats_f64", _ptr(raw[0]), H, _ptr(yy),
                        ctypes.c_void_p(packed.data_ptr() + 8 * o), self._stream())
         else:
@@ -725,30 +773,11 @@ class GSC(DeviceCAModel):
         comm.allreduce_device(packed)      # replaces gsc_et.py:608-610,620,668,671,713
         data_sq = self._data_second_moment(res) if 'sigma_sq' in self.to_learn else None
         st = self._stream()
-        at = lambda off: ctypes.c_void_p(whole.data_ptr() + 8 * off)
-        o_wt, o_par = o_inv + n_inv, o_inv + n_inv + nWp
         have_inv = packed.is_cuda and H <= 256
-        if have_inv:
-            # the two H x H inverses of the update (gsc_et.py:625, 673) on the device, ahead of the download: a
-            # 128 x 128 LAPACK inverse costs 0.4 ms of host time each while the GPU idles.  [sum_ss ; sum_zz] sit back
-            # to back in the statistics; inverses are stored in that order: [(sum_ss + eps I)^-1 ; sum_zz^-1 ; 4 pivots]
-            # sum_zz is a GENERAL matrix from the second EM step on (psi_sq is not symmetric any more: gsc_et.py:660-675) and
-            # the reference inverts it as it is (:625): the left-sided Newton-Schulz refinement of pm_inverse_warm_batch_f64
-            # (its result is the inverse of the transpose -- what W_new^T = (A^-1)^T Wp^T needs), started from the previous
-            # EM step's inverses or, cold, from the sweep's inverses of the upper-mirrored matrices (within ~1e-6).
-            # (PM_WARM_INVERSE=0 only forces the cold START below; the Newton-Schulz pass itself is not optional here -- it is what
-            # inverts the general matrix, the sweep alone only knows its upper-mirrored stand-in)
-            dadd = self._eps_diag(H, eps)
-            prev = getattr(self, "_inv_prev", None)
-            if not (prev is not None and tuple(prev.shape) == (2, H, H) and os.environ.get("PM_WARM_INVERSE", "1") == "1"):
-                # ONE launch, one workgroup per matrix: the two sweeps run side by side on two CUs
-                self._call("spd_inverse", "pm_spd_inverse_batch_f64", at(o), H, nHH, _ptr(dadd), H, None, at(o_inv), H, nHH,
-                           at(o_inv + 2 * nHH), 2, st)
-                prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H).clone()
-            work = self._buf("spd_warm_work", (2 * int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
-            self._call("spd_inverse", "pm_inverse_warm_batch_f64", at(o), H, nHH, _ptr(dadd), H, _ptr(prev), nHH,
-                       _ptr(work), at(o_inv), nHH, at(o_inv + 2 * nHH), at(o_inv + 2 * nHH + 4), 2, 2, st)
-            self._inv_prev = whole[o_inv:o_inv + 2 * nHH].view(2, H, H)     # (`whole` is this step's own tensor: no copy)
+        if inv_early is not None:
+            torch.cuda.current_stream(self.device).wait_event(inv_early)
+        elif have_inv:
+            invert(st)
         Wt_next = None
         self._seed = None
         if have_inv and 'W' in self.to_learn and self.sigma_sq_type == 'scalar' and self.speculate:
