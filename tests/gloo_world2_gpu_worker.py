@@ -12,6 +12,8 @@ the host), each running the real HIP kernels on its `stride_data` shard of the d
     (D=256 H=128 H'=6 gamma=3, N = 1001: per-XCD statistics scratch, the batched warm inverse, the device-side M-step
     tail), three EM steps each against the oracle's single-process steps (MCA: its free-running trajectory; GSC: the oracle's
     step from the same parameters), bitwise rank identity after every step.
+Last, BSC at config-2 dimensions in DETERMINISTIC mode (libprosper_hip_det.so): the same sharded loop twice, bitwise equal between
+the runs and between the ranks.
 Rank 0 holds the oracle; its verdict is shared after every step (`agree`), so a failed comparison ends BOTH ranks at
 once with the assertion's text instead of leaving rank 1 in the next collective until the parent's timeout.
 Prints "ok <rank>" on success."""
@@ -180,6 +182,29 @@ def main():
                                                err_msg="%s (step %d, cond %.2e)" % (k, step, cond))
             agree(check_gsc, "config-4 step %d" % step)
             p = {k: np.array(p[k], copy=True) for k in gkeys}
+        # ---- deterministic mode across ranks: the same sharded 4-step loop twice -- fused kernels, then a
+        # truncation step through the distributed radix select -- bit for bit the same W / pi / sigma in both runs, on both ranks
+        D, H, Hp, gamma, N = 1024, 256, 8, 4, 2001
+        rng = np.random.RandomState(31)
+        W_gt = rng.normal(size=(D, H))
+        y, _ = O.generate_bsc_data(W_gt, 3.0 / H, 1.0, N, rng)
+        p0 = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 3.0 / H, "sigma": 1.05}
+        lo, hi = parallel.stride_data(N, comm=comm)
+        runs = []
+        for rep in range(2):
+            md = BSC_ET(D, H, Hp, gamma, comm=comm)
+            md.deterministic = True
+            p, traj = dict(p0), []
+            shard = {"y": y[lo:hi].copy()}
+            for step, (T, ncut) in enumerate([(1.1, 0.0), (1.0, 0.0), (1.0, 0.8), (1.0, 0.8)]):
+                p = md.step(An(T=T, Ncut_factor=ncut), p, shard)
+                same_on_all_ranks(p, "deterministic run %d step %d" % (rep, step))
+                traj.append({k: np.array(p[k], copy=True) for k in ("W", "pi", "sigma")})
+            runs.append(traj)
+            del md
+        for step, (a, b) in enumerate(zip(*runs)):
+            for k in ("W", "pi", "sigma"):
+                assert np.array_equal(a[k], b[k]), "deterministic mode, rank %d: step %d %s differs between two runs" % (rank, step, k)
         comm.Barrier()
         print("ok %d" % rank)
     finally:
