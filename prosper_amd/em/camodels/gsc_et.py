@@ -124,6 +124,7 @@ class GSC(DeviceCAModel):
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.fuse_moment_gemm = True      # [Y | xs | xsz]^T xsz as one GEMM (a plain attribute: tests flip it)
         self.overlap_moments = True       # ... the two parts on two streams (an HBM stream beside an MFMA GEMM)
+        self.early_inverse = True         # one rank: the inverse chain on a stream of its own beside the contraction
         self.overlap_scores = True        # the next step's scores GEMM on a second stream beside Gram / finish kernel / download
         self.sparse_moments = True        # ... split into listed rows (sparse product) + gathered dense rows, when the
                                           # M-step itself launched the E-step (pm_gsc_estep_lists_f64)
@@ -702,6 +703,7 @@ class GSC(DeviceCAModel):
         # a mostly idle device) runs on a stream of its own BESIDE the contraction over the datapoints instead of behind it.
         inv_early = None
         if (raw is not None and my_N and whole.is_cuda and H <= 256 and getattr(comm, "size", 1) == 1 and self.overlap_moments
+                and self.early_inverse
                 and self.timer is None and not self.deterministic):
             s3 = getattr(self, "_inv_stream", None)
             if s3 is None:
