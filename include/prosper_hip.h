@@ -594,6 +594,7 @@ int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, cons
  * PM_BSC_NZ_MAX entries above the threshold tables[8 H + 1] leaves them as a list (nz_idx / nz_val, N x PM_BSC_NZ_MAX,
  * format of pm_bsc_estep_fused8_nz_f64; for pm_wp_sparse_t_f64), any other row an empty list and its index in
  * dense_rows[0 .. *dense_count) (for pm_gemm_tn_acc_rows_f64; *dense_count = 0 at launch; order as the workgroups finish).
+ * nz_val holds TWO planes of N x PM_BSC_NZ_MAX doubles: xpt_sz at the listed entries, then xpt_s at them (pm_gsc_list_pairs_f64).
  * The threshold is written by pm_gsc_mstep_finish_f64 (2^-75 of the smallest |column sum| of xpt_sz over all ranks: what
  * the lists drop is below the rounding of the sums); 0 keeps every row dense.  Where pm_gsc_lists_supported(H, Hprime,
  * gamma, D), else PM_ERANGE. */
@@ -603,6 +604,14 @@ int pm_gsc_estep_lists_f64(const double *scores, int64_t lds, const double *gram
                            int64_t gamma, double beta, double sigma_sq, int64_t N, int64_t H, int64_t Hprime,
                            int do_select, int32_t *cand, double *xpt_s, double *xpt_sz, int64_t ldx, double *stats,
                            uint16_t *nz_idx, double *nz_val, int32_t *dense_rows, int32_t *dense_count, void *stream);
+
+/* xs^T xsz and xsz^T xsz of GSC's M-step (gsc_et.py:603-610) over the LISTED datapoints from the lists alone (outer products of
+ * a datapoint's listed entries): out[0 .. H*H) += sum_n xs_n xsz_n^T, out[H*H .. 2 H*H) += sum_n xsz_n xsz_n^T over the entries
+ * nz_idx lists.  nz_val_s / nz_val: xpt_s / xpt_sz at those entries -- pm_gsc_estep_lists_f64 leaves them as the second and the
+ * first plane of its `nz_val` (which therefore holds 2 x N x PM_BSC_NZ_MAX doubles).  The sparse product then streams the D
+ * columns of Y only.  H in {64, 128, 192, 256}, else PM_ERANGE. */
+int pm_gsc_list_pairs_f64(const uint16_t *nz_idx, const double *nz_val_s, const double *nz_val, int64_t N, int64_t H,
+                          double *out, void *stream);
 
 /* The same pass, also writing every state's log-joint -- what GSC.compute_lpj returns (gsc_et.py:811-944): no
  * annealing, prior odds included -- to logpj (N, ldl >= 1 + H + S): [null state ; singletons h = 0..H-1 ; multi-cause

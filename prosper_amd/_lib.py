@@ -127,6 +127,7 @@ SIGNATURES = {
     "pm_gsc_lists_supported": (C.c_int, [i64, i64, i64, i64]),
     "pm_gsc_estep_lists_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
                                          i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "pm_gsc_list_pairs_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, i64, c_dp, c_dp]),
     "pm_gsc_estep_lpj_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,
                                        i64, i64, i64, C.c_int, c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp]),
     "pm_gsc_estep_lpj_blocks_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, i64, i64, C.c_double, C.c_double,

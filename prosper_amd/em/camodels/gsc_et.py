@@ -124,6 +124,8 @@ class GSC(DeviceCAModel):
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self.fuse_moment_gemm = True      # [Y | xs | xsz]^T xsz as one GEMM (a plain attribute: tests flip it)
         self.overlap_moments = True       # ... the two parts on two streams (an HBM stream beside an MFMA GEMM)
+        self.list_pairs = False           # the H x H blocks of listed datapoints from their lists, the sparse product over Y only:
+                                          # sparse 0.22 -> 0.13 ms + pairs kernel 0.07 -- the EM iteration does not move (rounds 4, 5)
         self.early_inverse = True         # one rank: the inverse chain on a stream of its own beside the contraction
         self.overlap_scores = True        # the next step's scores GEMM on a second stream beside Gram / finish kernel / download
         self.sparse_moments = True        # ... split into listed rows (sparse product) + gathered dense rows, when the
@@ -419,7 +421,7 @@ class GSC(DeviceCAModel):
             lb = res.setdefault("gsc_lists", [None, None])
             if lb[k] is None:
                 lb[k] = (torch.empty((N, 16), dtype=torch.int16, device=self.device),
-                         torch.empty((N, 16), dtype=torch.float64, device=self.device),
+                         torch.empty((2, N, 16), dtype=torch.float64, device=self.device),   # xpt_sz | xpt_s at the listed entries
                          torch.empty(N, dtype=torch.int32, device=self.device))
             nz_idx, nz_val, dense_rows = lb[k]
             dense_count = zeros[1] if zeros is not None else torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -734,8 +736,17 @@ class GSC(DeviceCAModel):
                         side = self._side_stream = torch.cuda.Stream(device=self.device)
                     fork = torch.cuda.Event()
                     fork.record()
-                self._call("stats_sparse", "pm_wp_sparse_t_f64", _ptr(lists[0]), _ptr(lists[1]), _ptr(big), ldx, _ptr(packed),
-                           H, my_N, H, D + 2 * H, s)
+                if self.list_pairs and H % 64 == 0:
+                    # the two H x H blocks of the listed datapoints as outer products of their lists (pm_gsc_list_pairs_f64):
+                    # the sparse product then streams the D columns of Y only -- half the bytes at config 4
+                    self._call("stats_sparse", "pm_wp_sparse_t_f64", _ptr(lists[0]), _ptr(lists[1]), _ptr(big), ldx,
+                               _ptr(packed), H, my_N, H, D, s)
+                    self._call("stats_pairs", "pm_gsc_list_pairs_f64", _ptr(lists[0]),
+                               ctypes.c_void_p(lists[1].data_ptr() + 8 * 16 * my_N), _ptr(lists[1]), my_N, H,
+                               ctypes.c_void_p(packed.data_ptr() + 8 * nWp), s)
+                else:
+                    self._call("stats_sparse", "pm_wp_sparse_t_f64", _ptr(lists[0]), _ptr(lists[1]), _ptr(big), ldx,
+                               _ptr(packed), H, my_N, H, D + 2 * H, s)
                 if side is not None:
                     side.wait_event(fork)
                     s = ctypes.c_void_p(side.cuda_stream)

@@ -28,6 +28,7 @@ m.sparse_moments = os.environ.get('SPM', '1') == '1'
 m.overlap_moments = os.environ.get('OVL', '1') == '1'
 m.fuse_scores = os.environ.get('FUSE', '0') == '1'
 m.early_inverse = os.environ.get('EARLY', '1') == '1'
+m.list_pairs = os.environ.get('PAIRS', '1') == '1'
 m.overlap_scores = os.environ.get('OVS', '1') == '1'
 t = time.perf_counter()
 while time.perf_counter() - t < 0.5:

@@ -506,9 +506,10 @@ def test_gsc_sparse_moments_equal_the_dense_contraction(dead):
         learn = ('W', 'mu', 'psi_sq', 'sigma_sq')        # pi stays: latent 7 stays dead through the loop
     an = _An(T=1.0)
     runs, counts = [], None
-    for sparse in (True, False):
+    for sparse, pairs in ((True, False), (False, False), (True, True)):
         m = GSC(D, H, Hp, gamma, 'scalar', to_learn=list(learn))
         m.sparse_moments = sparse
+        m.list_pairs = pairs          # (True: the H x H blocks of listed datapoints from their lists, pm_gsc_list_pairs_f64)
         p = {k: np.array(v, copy=True) for k, v in p0.items()}
         traj = []
         for it in range(7):
@@ -520,16 +521,17 @@ def test_gsc_sparse_moments_equal_the_dense_contraction(dead):
         if sparse:
             names = set(m.timer.summary())
             m.timer = None
-            assert m.spec_hits >= 3
+            assert m.spec_hits >= 3 and (("stats_pairs" in names) == pairs)
             res = m._resident(y)
             lists = [l for l in res.get("gsc_lists", []) if l is not None]
             assert lists, "the list form of the E-step never ran"
             assert "stats_sparse" in names, names
             empty = (lists[0][0][:, 0].cpu().numpy().view(np.uint16) == 0xFFFF)
             counts = (int(empty.sum()), N)
-    for a, b in zip(*runs):
-        for k in p0:
-            np.testing.assert_allclose(a[k], b[k], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(b[k]).max()), err_msg=k)
+    for other in (runs[0], runs[2]):
+        for a, b in zip(other, runs[1]):
+            for k in p0:
+                np.testing.assert_allclose(a[k], b[k], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(b[k]).max()), err_msg=k)
     # (the "dead" latent still collects 1 / (H + S) of every datapoint whose weights are ALL the clamp, so its column sum --
     # and with it the threshold -- stays ordinary: its 1e-243 entries elsewhere are dropped, as they should be)
     n_dense, n_all = counts
