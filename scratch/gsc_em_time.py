@@ -23,7 +23,7 @@ for lo in range(0, N, 50_000):
     Y[lo:lo + 50_000] = Z @ W_gt.t() + torch.randn(50_000, Dm, generator=g, device=dev, dtype=torch.float64)
 p = {"W": W_gt.cpu().numpy() + 0.1 * rng.normal(size=(Dm, Hm)), "pi": np.full(Hm, 2.0 / Hm), "mu": np.full(Hm, 1.4),
      "psi_sq": np.eye(Hm) * 1.1, "sigma_sq": 1.2}
-m = GSC(Dm, Hm, 6, 3, 'scalar')
+m = GSC(Dm, Hm, 6, int(os.environ.get('GAMMA', '3')), 'scalar')
 m.sparse_moments = os.environ.get('SPM', '1') == '1'
 m.overlap_moments = os.environ.get('OVL', '1') == '1'
 m.fuse_scores = os.environ.get('FUSE', '0') == '1'
