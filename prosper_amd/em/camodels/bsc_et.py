@@ -490,9 +490,13 @@ class BSC_ET(DeviceCAModel):
             cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
             mode = 3
         mstats, rows = None, 0
-        # (deterministic mode: the statistics come from the M-step's own pass, which knows the parameters its quanta derive from)
+        # (deterministic mode: the quanta of the statistics derive from W's column norms -- a pass whose W^T exists only on the
+        # device so far, the M-step's speculative launch, carries no statistics; the M-step's own pass forms them then)
+        Wh = par.get("Whost")
         if N and want_ms and self.fuse_mstats and self._fused() and Hp <= 8 and 'mu' not in self.to_learn \
-                and not self.deterministic:
+                and (not self.deterministic or Wh is not None):
+            if self.deterministic:
+                self._det_quanta(res, Wh.T if par["Whost_T"] else Wh, np.full(1, np.sqrt(max(P.mu_sqnorm, 0.0))), P, N)
             n_stats = _lib.load().pm_bsc_stats_len(H, D)
             # two statistics workspaces alternate: the M-step that launches the NEXT E-step (speculation) still reads its
             # own Wp -- the right-hand side of the W solve, and of the host fallback -- from the other one
