@@ -26,6 +26,12 @@
 // documented part of the statistics buffer; the per-XCD copies of [Wp | Wq] follow it (pm_common.h)
 __host__ __device__ static inline int64_t mca_stats_base(int64_t H, int64_t D) { return 3 * H * D + H + PM_MCA_NSCALARS; }
 
+#ifndef PM_MCA_TSUM
+#define PM_MCA_TSUM 0   // the states' row sums in the fused pass: 1 prefix in registers + the new row a trip ahead, 0 the same without the read-ahead, 2 two rows per state
+#endif
+#ifndef PM_MCA_VDEFER
+#define PM_MCA_VDEFER 0 // a state's V update (and the rare rescaling) at the top of the next trip: one straight-line block for both stages
+#endif
 #ifndef PM_MCA_ABL
 #define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates, 4 T sums from candidate 0 only, 5 no wave reduction, 6 no exponential, 7 no states at all (S = 0)
 #endif
@@ -283,7 +289,8 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
 // ROOT = 21: rho = 21 (every temperature T <= 1.05, unsigned W): the states' power through pm_pow_m20_21 (no log / exp);
 // ROOT = 6: rho = 6 (MMCA at every T <= 1.2): pm_pow_m5_6; ROOT = 0: any rho, the table power
 template <int DPL, int HP, bool SIGNED, int ROOT>      // ROOT: 21 / 6 = the log / exp-free powers of those rho, 0 = the table power
-__global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
+__global__ __launch_bounds__(256, (HP <= 8 && ROOT == 0 ? 2 : 1))     // (the table power at H' <= 8 would take 258 registers: keep two wavefronts per SIMD; the others fit uncapped, and schedule better so)
+void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
                                        const double *__restrict__ wnorm2, const double *__restrict__ ynorm2,
                                        const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
                                        const double *__restrict__ Wrm1, const int32_t *__restrict__ cand,
@@ -359,44 +366,66 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
         // both sit in ONE straight-line block and the scheduler interleaves them; the V update is predicated with 0/1
         // factors instead of per-candidate branches for the same reason.
         double wbP[DPL], partP = 0.0;      // state s: |T|^(1/rho - 1) (0 / +inf for T = 0, see below), squared error
-        unsigned maskP = S > 0 ? (unsigned)__builtin_amdgcn_readfirstlane((int)masks[0]) : 0u;      // (scalar registers)
-        unsigned mask_load = S > 0 ? masks[S > 1 ? 1 : 0] : 0u;
-        {
-            double T[DPL];
+        // T of a state = the sum of its candidates' rows in ascending order = (the sum over all but its highest candidate)
+        // + that candidate's row.  The states arrive as itertools.combinations lists them: consecutive ones share that
+        // prefix (56 of config 5's 84), so the prefix sum stays in registers (Pf, its mask in a scalar) and a state costs ONE
+        // row read -- requested a trip ahead, its LDS latency under the previous state's work -- and DPL additions, with
+        // no branch in the common case; the bits are those of the straight sum (0 + x = x).  [round 5; before: eight bit
+        // tests and up to gamma read -> wait -> add blocks per state, 1.0 of the pass's 7.4 ms]
+        double Pf[DPL];
+        unsigned pfx = 0xFFFFFFFFu;
+        auto sum_rows = [&](unsigned mm, double (&out)[DPL]) {      // the straight sum (uniform bit tests)
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+            for (int i = 0; i < DPL; ++i) out[i] = 0.0;
 #pragma unroll
             for (int j = 0; j < HP; ++j)
-                if ((maskP >> j) & 1u) {
+                if ((mm >> j) & 1u) {
 #pragma unroll
-                    for (int i = 0; i < DPL; ++i) T[i] += s_wr[j * DS + lane + 64 * i];
+                    for (int i = 0; i < DPL; ++i) out[i] += s_wr[j * DS + lane + 64 * i];
                 }
+        };
+        auto row_of = [&](unsigned m, double (&row)[DPL]) {
+            const int hb = 31 - __builtin_clz(m | 1u);
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const double aT = SIGNED ? fabs(T[i]) : T[i];      // (unsigned W: T is a sum of W^rho >= 0)
-                const double r = (PM_MCA_ABL == 2) ? aT * 0.37
-                                 : (ROOT == 21 ? pm_pow_m20_21(aT, s_rt) : ROOT == 6 ? pm_pow_m5_6(aT, s_rt)
-                                                                                 : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
-                const double wb = (aT > 0.0) ? aT * r : 0.0;
-                const double df = (SIGNED ? copysign(wb, T[i]) : wb) - y[i];
-                partP = fma(df, df, partP);
-                wbP[i] = (aT > 0.0) ? r : (SIGNED ? INFINITY : 0.0);
+            for (int i = 0; i < DPL; ++i) row[i] = s_wr[hb * DS + lane + 64 * i];
+        };
+#if PM_MCA_TSUM == 2
+        // two rows per state (its two highest candidates), the sum of the others cached: no branch for 77 of 84 states
+        auto state_T = [&](unsigned m, const double (&)[DPL], double (&T)[DPL]) {
+            const int hb = 31 - __builtin_clz(m | 1u);
+            const unsigned pm = m & ~(1u << hb);
+            const int hb2 = 31 - __builtin_clz(pm | 1u);
+            const unsigned pm2 = pm & ~(1u << hb2);
+            if (pm == 0u) {                       // fewer than two candidates: never among the multi-cause states
+                asm volatile("" ::: "memory");
+                sum_rows(m, T);
+                return;
             }
-        }
-        for (int s = 0; s < ((PM_MCA_ABL == 7) ? 0 : S); ++s) {
-            // wave-uniform masks; the one after next is requested now (vector-memory latency under this trip's work)
-            const unsigned maskN = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_load);
-            mask_load = masks[s + 2 < S ? s + 2 : S - 1];
-            // ---- stage A, state s + 1 (the last trip computes a dummy) ----
-            double T[DPL], wbN[DPL], partN = 0.0;
+            if (pm2 != pfx) {
+                sum_rows(pm2, Pf);
+                pfx = pm2;
+            }
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+            for (int i = 0; i < DPL; ++i) T[i] = (Pf[i] + s_wr[hb2 * DS + lane + 64 * i]) + s_wr[hb * DS + lane + 64 * i];
+        };
+#else
+        auto state_T = [&](unsigned m, const double (&row)[DPL], double (&T)[DPL]) {
+            const int hb = 31 - __builtin_clz(m | 1u);
+            const unsigned pm = m & ~(1u << hb);
+            if (pm != pfx) {                      // uniform: the prefix changed (28 of 84 states)
+                sum_rows(pm, Pf);
+                pfx = pm;
+            }
 #pragma unroll
-            for (int j = 0; j < HP; ++j)
-                if (((maskN >> j) & 1u) && (PM_MCA_ABL != 4 || j == 0)) {
+            for (int i = 0; i < DPL; ++i) T[i] = Pf[i] + (PM_MCA_TSUM == 0 ? s_wr[hb * DS + lane + 64 * i] : row[i]);
+            if (m == 0u) {                        // (no candidate at all: never among the multi-cause states)
+                asm volatile("" ::: "memory");    // (a real branch, not eight selects per state)
 #pragma unroll
-                    for (int i = 0; i < DPL; ++i) T[i] += s_wr[j * DS + lane + 64 * i];
-                }
+                for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+            }
+        };
+#endif
+        auto state_pow = [&](const double (&T)[DPL], double (&wb_out)[DPL], double &part) {
 #pragma unroll
             for (int i = 0; i < DPL; ++i) {
                 // ONE power per element: r = |T|^(1/rho - 1) gives |Wbar| = |T| r here and Wbar / T = r for the
@@ -407,14 +436,98 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                                                                                  : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
                 const double wb = (aT > 0.0) ? aT * r : 0.0;
                 const double df = (SIGNED ? copysign(wb, T[i]) : wb) - y[i];
-                partN = fma(df, df, partN);
-                wbN[i] = (aT > 0.0) ? r : (SIGNED ? INFINITY : 0.0);
+                part = fma(df, df, part);
+                wb_out[i] = (aT > 0.0) ? r : (SIGNED ? INFINITY : 0.0);
             }
+        };
+        // state s's V update: w |T|^(1/rho - 1) into the rows of its own candidates [signed W: times W^(rho - 1)'s row]
+        double vD[DPL], wD = 0.0, scD = 0.0;
+        unsigned maskD = 0u;
+        bool rescD = false;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) vD[i] = 0.0;
+        auto v_update = [&]() {
+            if (PM_MCA_VDEFER && rescD) {
+                const double sc = exp(scD);
+#pragma unroll
+                for (int j = 0; j < HP; ++j)
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) V[j][i] *= sc;
+            }
+            if (!SIGNED) {
+#ifndef PM_MCA_VPRED
+                // (round 3: uniform branches instead of 0/1 factors over all H' candidates -- 2.7 of 8 rows per state at
+                // config 5: 8.15 -> 7.82 ms; -DPM_MCA_VPRED restores the predicated form)
+#pragma unroll
+                for (int j = 0; j < HP; ++j) {
+                    if ((maskD >> j) & 1u) {      // uniform (scalar) branch: only the state's own candidates are touched
+#pragma unroll
+                        for (int i = 0; i < DPL; ++i) V[j][i] += vD[i];
+                    }
+                }
+#else
+#pragma unroll
+                for (int j = 0; j < HP; ++j) {
+                    const double sel = (((maskD >> j) & 1u) && (PM_MCA_ABL != 3 || wD == 1.2345e-300)) ? 1.0 : 0.0;   // uniform
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) V[j][i] = fma(sel, vD[i], V[j][i]);
+                }
+#endif
+            } else {
+#pragma unroll
+                for (int j = 0; j < HP; ++j)
+                    if ((maskD >> j) & 1u) {
+#pragma unroll
+                        for (int i = 0; i < DPL; ++i)   // T = 0: w * inf = inf (w > 0) or NaN (w = 0); fmin returns w
+                            V[j][i] += fmin(wD, wD * vD[i] * s_wm[j * DS + lane + 64 * i]);
+                    }
+            }
+        };
+        unsigned maskP = S > 0 ? (unsigned)__builtin_amdgcn_readfirstlane((int)masks[0]) : 0u;      // (scalar registers)
+        unsigned maskN = S > 0 ? (unsigned)__builtin_amdgcn_readfirstlane((int)masks[S > 1 ? 1 : 0]) : 0u;
+        unsigned mask_load = S > 0 ? masks[S > 2 ? 2 : S - 1] : 0u;
+        double rowN[DPL];
+        {
+            double T[DPL], row0[DPL];
+            if (PM_MCA_TSUM == 1) row_of(maskP, row0);
+            state_T(maskP, row0, T);
+            if (PM_MCA_TSUM == 1) row_of(maskN, rowN);
+            state_pow(T, wbP, partP);
+        }
+        for (int s = 0; s < ((PM_MCA_ABL == 7) ? 0 : S); ++s) {
+            // wave-uniform masks; the one three states on is requested now (vector-memory latency under this trip's
+            // work), the row of the state after next as soon as its mask is here
+            const unsigned maskNN = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_load);
+            mask_load = masks[s + 3 < S ? s + 3 : S - 1];
+            if (PM_MCA_VDEFER) v_update();         // state s - 1 (nothing in the first trip: maskD = 0)
+            double rowNN[DPL];
+            if (PM_MCA_TSUM == 1) row_of(maskNN, rowNN);
+            // ---- stage A, state s + 1 (the last trip computes a dummy) ----
+            double T[DPL], wbN[DPL], partN = 0.0;
+            if (PM_MCA_ABL == 4) {
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) T[i] = s_wr[lane + 64 * i];
+            } else {
+                state_T(maskN, rowN, T);
+            }
+            state_pow(T, wbN, partN);
             // ---- stage B, state s ----
             const double part = (PM_MCA_ABL == 5) ? partP * 64.0 : pm_wave_sum_dpp(partP);   // wave-uniform
             if (lane == 0) s_e[s] = part;
             const double bf = P.beta * (P.pil_bar * (double)__builtin_popcount(maskP) + P.pre1 * part);
-            double w = (PM_MCA_ABL == 6) ? (bf - M) * 0.001 + 1.0 : pm_exp_tab(bf - M, s_tab);   // (meaningless if the branch below is taken)
+            double w = (PM_MCA_ABL == 6) ? (bf - M) * 0.001 + 1.0 : pm_exp_tab(bf - M, s_tab);   // (meaningless if the reference level moves)
+#if PM_MCA_VDEFER
+            // the reference level moves (uniform; the first state, then hardly ever): selects here, the rescaling of V and
+            // this state's V update at the top of the next trip -- nothing branches between the two stages' chains
+            rescD = bf > M + 50.0;
+            scD = M - bf;
+            M = rescD ? bf : M;
+            w = rescD ? 1.0 : w;
+            maskD = maskP;
+            wD = w;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) vD[i] = SIGNED ? wbP[i] : w * wbP[i];
+#else
             if (bf > M + 50.0) {                                        // uniform; the first state, then hardly ever
                 const double sc = exp(M - bf);
 #pragma unroll
@@ -424,42 +537,22 @@ __global__ __launch_bounds__(256) void mca_estep_fused_kernel(const double *__re
                 M = bf;
                 w = 1.0;
             }
-            if (!SIGNED) {
-                double v[DPL];
+            maskD = maskP;
+            wD = w;
 #pragma unroll
-                for (int i = 0; i < DPL; ++i) v[i] = w * wbP[i];
-#ifndef PM_MCA_VPRED
-                // (round 3: uniform branches instead of 0/1 factors over all H' candidates -- 2.7 of 8 rows per state at
-                // config 5: 8.15 -> 7.82 ms; -DPM_MCA_VPRED restores the predicated form)
-#pragma unroll
-                for (int j = 0; j < HP; ++j) {
-                    if ((maskP >> j) & 1u) {      // uniform (scalar) branch: only the state's own candidates are touched
-#pragma unroll
-                        for (int i = 0; i < DPL; ++i) V[j][i] += v[i];
-                    }
-                }
-#else
-#pragma unroll
-                for (int j = 0; j < HP; ++j) {
-                    const double sel = (((maskP >> j) & 1u) && (PM_MCA_ABL != 3 || w == 1.2345e-300)) ? 1.0 : 0.0;   // uniform
-#pragma unroll
-                    for (int i = 0; i < DPL; ++i) V[j][i] = fma(sel, v[i], V[j][i]);
-                }
+            for (int i = 0; i < DPL; ++i) vD[i] = SIGNED ? wbP[i] : w * wbP[i];
+            v_update();
 #endif
-            } else {
-#pragma unroll
-                for (int j = 0; j < HP; ++j)
-                    if ((maskP >> j) & 1u) {
-#pragma unroll
-                        for (int i = 0; i < DPL; ++i)   // T = 0: w * inf = inf (w > 0) or NaN (w = 0); fmin returns w
-                            V[j][i] += fmin(w, w * wbP[i] * s_wm[j * DS + lane + 64 * i]);
-                    }
-            }
             partP = partN;
             maskP = maskN;
+            maskN = maskNN;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) wbP[i] = wbN[i];
+            for (int i = 0; i < DPL; ++i) {
+                wbP[i] = wbN[i];
+                if (PM_MCA_TSUM == 1) rowN[i] = rowNN[i];
+            }
         }
+        if (PM_MCA_VDEFER) v_update();             // the last state
         wave_sync_lds();
 
         // log-pseudo-joints and the two log-evidences (as mca_estep_kernel)

@@ -2,6 +2,9 @@
 import os, sys, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from prosper_amd import _lib
+if os.environ.get('PM_LIB_PATH'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['PM_LIB_PATH'])
 from prosper_amd.em.camodels.dsc_et import DSC_ET
 from prosper_amd.em.camodels.tsc_et import TSC_ET
 from prosper_amd.em.camodels._device import KernelTimer
