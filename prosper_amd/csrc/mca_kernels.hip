@@ -191,38 +191,76 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
         // multi-cause states: e_s = sum_d (Wbar_sd - y_d)^2.  Padding dimensions hold W^rho = 0 and y = 0:
         // Wbar = 0 there and they add nothing, so the loop body is branch-free and the DPL powers of a
         // lane are independent instruction streams.
-        unsigned mask_next = S > 0 ? masks[0] : 0u;
-        for (int s = 0; s < S; ++s) {
-            // wave-uniform; the next state's mask is requested now so that its (vector-memory) latency is covered
-            // by this state's powers instead of stalling the top of the next trip
-            const unsigned mask = mask_next;
-            mask_next = masks[s + 1 < S ? s + 1 : s];
-            double T[DPL];
+        // Round 5: TWO states per trip (2 * DPL independent power chains and two interleaved wave reductions: without the
+        // fused pass's second pipeline stage a lone state's chain is all latency), the 64 masks of a batch in a lane
+        // register (one load per batch instead of one vector-memory round trip per state), and the row sums as in the
+        // fused pass: the sum over all but the state's highest candidate stays in registers while consecutive states
+        // share it (itertools.combinations order), so a state reads one row; same bits as the straight sum.
+        auto states = [&](auto root_tag) {
+            constexpr int ROOT = decltype(root_tag)::value;
+            double Pf[DPL];
+            unsigned pfx = 0xFFFFFFFFu;
+            auto T_of = [&](unsigned m, double (&T)[DPL]) {
+                const int hb = 31 - __builtin_clz(m | 1u);
+                unsigned pm = m & ~(1u << hb);
+                if (pm != pfx) {                  // uniform
+                    pfx = pm;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) T[i] = 0.0;
-            unsigned m = mask;
-            while (m) {
-                const int j = __builtin_ctz(m);
-                m &= m - 1;
-                const double *wr = s_wr + j * DS + lane;
+                    for (int i = 0; i < DPL; ++i) Pf[i] = 0.0;
+                    while (pm) {
+                        const int j = __builtin_ctz(pm);
+                        pm &= pm - 1;
+                        const double *wr = s_wr + j * DS + lane;
 #pragma unroll
-                for (int i = 0; i < DPL; ++i) T[i] += wr[64 * i];
+                        for (int i = 0; i < DPL; ++i) Pf[i] += wr[64 * i];
+                    }
+                }
+                const double *wr = s_wr + hb * DS + lane;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) T[i] = Pf[i] + wr[64 * i];
+                if (m == 0u) {                    // (no candidate: never among the multi-cause states)
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+                }
+            };
+            auto energy = [&](const double (&T)[DPL]) {
+                double part = 0.0;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    // MMCA: T may be negative or 0 (mmca_et.py:191: sign(t) exp(log|t| / rho)); for MCA T > 0
+                    const double aT = fabs(T[i]);
+                    const double wbar = (aT > 0.0) ? (ROOT == 21 ? aT * pm_pow_m20_21(aT, s_rt)
+                                                      : ROOT == 6 ? copysign(aT * pm_pow_m5_6(aT, s_rt), T[i])
+                                                                  : copysign(pm_pow_tab(aT, P.inv_rho, s_tab), T[i]))
+                                                   : 0.0;
+                    const double df = wbar - y[i];
+                    part = fma(df, df, part);
+                }
+                return part;
+            };
+            for (int s0 = 0; s0 < S; s0 += 64) {
+                const unsigned ml = masks[s0 + lane < S ? s0 + lane : S - 1];
+                const int cnt = S - s0 < 64 ? S - s0 : 64;
+                for (int k = 0; k < cnt; k += 2) {
+                    const unsigned m0 = (unsigned)__builtin_amdgcn_readlane((int)ml, k);
+                    const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)ml, k + 1 < 64 ? k + 1 : k);   // (a repeat at the odd end)
+                    double T0[DPL], T1[DPL];
+                    T_of(m0, T0);
+                    T_of(m1, T1);
+                    double p0 = energy(T0), p1 = energy(T1);
+                    p0 = pm_wave_sum_dpp(p0);
+                    p1 = pm_wave_sum_dpp(p1);
+                    if (lane == 0) {
+                        s_e[s0 + k] = p0;
+                        if (k + 1 < cnt) s_e[s0 + k + 1] = p1;
+                    }
+                }
             }
-            double part = 0.0;
-#pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                // MMCA: T may be negative or 0 (mmca_et.py:191: sign(t) exp(log|t| / rho)); for MCA T > 0
-                const double aT = fabs(T[i]);
-                const double wbar = (aT > 0.0) ? (r21 ? aT * pm_pow_m20_21(aT, s_rt)
-                                                  : r6 ? copysign(aT * pm_pow_m5_6(aT, s_rt), T[i])
-                                                       : copysign(pm_pow_tab(aT, P.inv_rho, s_tab), T[i]))
-                                               : 0.0;
-                const double df = wbar - y[i];
-                part = fma(df, df, part);
-            }
-            part = pm_wave_sum_dpp(part);
-            if (lane == 0) s_e[s] = part;
-        }
+        };
+        if (r21) states(std::integral_constant<int, 21>{});
+        else if (r6) states(std::integral_constant<int, 6>{});
+        else states(std::integral_constant<int, 0>{});
         wave_sync_lds();
 
         // log-pseudo-joints and the two log-evidences (beta = 1 for Q, beta = 1/T for the weights)
@@ -764,26 +802,88 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
 #pragma unroll
             for (int i = 0; i < DPL; ++i) V[j][i] = 0.0;
         unsigned touched = 0;
+        // Round 5: the batch's masks ride in a lane register beside the states' log-joints (before: one vector-memory
+        // round trip per live state), the row sums keep the shared prefix in registers as in the fused pass (one row
+        // read per state, same bits), and TWO live states go through the powers together (2 * DPL independent chains).
+        double Pf[DPL];
+        unsigned pfx = 0xFFFFFFFFu;
+        auto T_of = [&](unsigned m, double (&T)[DPL]) {
+            const int hb = 31 - __builtin_clz(m | 1u);
+            unsigned pm = m & ~(1u << hb);
+            if (pm != pfx) {                      // uniform
+                pfx = pm;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) Pf[i] = 0.0;
+                while (pm) {
+                    const int j = __builtin_ctz(pm);
+                    pm &= pm - 1;
+                    const double *wr = s_wr + j * DS + lane;
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) Pf[i] += wr[64 * i];
+                }
+            }
+            const double *wr = s_wr + hb * DS + lane;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) T[i] = Pf[i] + wr[64 * i];
+            if (m == 0u) {                        // (no candidate: never among the multi-cause states)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) T[i] = 0.0;
+            }
+        };
+        auto weights = [&](const double (&T)[DPL], double q, double (&v)[DPL]) {
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                if (!SIGNED) {
+                    // q_s Wbar_sd / T_sd = q_s T^(1/rho - 1); padding: T = 0
+                    v[i] = (T[i] > 0.0) ? q * (r21 ? pm_pow_m20_21(T[i], s_rt) : pm_pow_tab(T[i], P.inv_rho - 1.0, s_tab)) : 0.0;
+                } else {
+                    // q_s min(1, (|W_jd| / |Wbar_sd|)^(rho-1)), (.)^(rho-1) = |W_jd|^(rho-1) |Wbar_sd| / |t_sd|;
+                    // t = 0 gives Wbar = 0 and the factor 1 (mmca_et.py:316-324: max(-inf - Wl, 0) = 0)
+                    const double aT = fabs(T[i]);
+                    v[i] = (aT > 0.0) ? q * (r6 ? pm_pow_m5_6(aT, s_rt) : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab)) : INFINITY;
+                }
+            }
+        };
+        auto v_update = [&](unsigned mask, double q, const double (&v)[DPL]) {
+#pragma unroll
+            for (int j = 0; j < HP; ++j)
+                if ((mask >> j) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i)
+                        V[j][i] += SIGNED ? fmin(q, v[i] * s_wm[j * DS + lane + 64 * i]) : v[i];
+                }
+        };
         for (int s0 = 0; s0 < S; s0 += 64) {
             const int sl = s0 + lane;
             double dl = -INFINITY, fl = 0.0;
+            unsigned ml = 0u;
             if (sl < S) {
                 fl = f[1 + H + sl];
                 dl = P.beta * fl - lb;
+                ml = masks[sl];
             }
             const double ql = exp(dl);        // this lane's state; broadcast below (one exp per 64 states)
             unsigned long long live = __ballot(dl > qcut);
             while (live) {
                 const int src = __builtin_ctzll(live);
                 live &= live - 1;
-                const int s = s0 + src;
-                const unsigned mask = masks[s];
-                const double fs = pm_readlane_f64(fl, src);
-                const double q = pm_readlane_f64(ql, src);
+                const bool two = live != 0ull;
+                const int src2 = two ? __builtin_ctzll(live) : src;
+                live &= live - 1;             // (0 & anything = 0)
+                const unsigned mask = (unsigned)__builtin_amdgcn_readlane((int)ml, src);
+                const unsigned mask2 = (unsigned)__builtin_amdgcn_readlane((int)ml, src2);
+                const double fs = pm_readlane_f64(fl, src), fs2 = pm_readlane_f64(fl, src2);
+                const double q = pm_readlane_f64(ql, src), q2 = pm_readlane_f64(ql, src2);
                 if (first && lane == 0) {
                     const double ns = (double)__builtin_popcount(mask);
                     st_pi += q * ns;
                     st_sigma += q * ((fs - P.pil_bar * ns) / P.pre1);
+                    if (two) {
+                        const double ns2 = (double)__builtin_popcount(mask2);
+                        st_pi += q2 * ns2;
+                        st_sigma += q2 * ((fs2 - P.pil_bar * ns2) / P.pre1);
+                    }
                 }
                 if (!staged) {  // first significant state: stage y and W^rho[cand] once
 #pragma unroll
@@ -802,37 +902,17 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
                     }
                     wave_sync_lds();
                     staged = true;
+                    pfx = 0xFFFFFFFFu;        // (the rows changed under the cached prefix)
                 }
-                touched |= mask;
-                // T for all of the lane's dimensions, then DPL independent powers, then the scatter into V
-                double T[DPL], v[DPL];
-#pragma unroll
-                for (int i = 0; i < DPL; ++i) T[i] = 0.0;
-#pragma unroll
-                for (int j = 0; j < HP; ++j)
-                    if ((mask >> j) & 1u) {
-#pragma unroll
-                        for (int i = 0; i < DPL; ++i) T[i] += s_wr[j * DS + lane + 64 * i];
-                    }
-#pragma unroll
-                for (int i = 0; i < DPL; ++i) {
-                    if (!SIGNED) {
-                        // q_s Wbar_sd / T_sd = q_s T^(1/rho - 1); padding: T = 0
-                        v[i] = (T[i] > 0.0) ? q * (r21 ? pm_pow_m20_21(T[i], s_rt) : pm_pow_tab(T[i], P.inv_rho - 1.0, s_tab)) : 0.0;
-                    } else {
-                        // q_s min(1, (|W_jd| / |Wbar_sd|)^(rho-1)), (.)^(rho-1) = |W_jd|^(rho-1) |Wbar_sd| / |t_sd|;
-                        // t = 0 gives Wbar = 0 and the factor 1 (mmca_et.py:316-324: max(-inf - Wl, 0) = 0)
-                        const double aT = fabs(T[i]);
-                        v[i] = (aT > 0.0) ? q * (r6 ? pm_pow_m5_6(aT, s_rt) : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab)) : INFINITY;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < HP; ++j)
-                    if ((mask >> j) & 1u) {
-#pragma unroll
-                        for (int i = 0; i < DPL; ++i)
-                            V[j][i] += SIGNED ? fmin(q, v[i] * s_wm[j * DS + lane + 64 * i]) : v[i];
-                    }
+                touched |= mask | mask2;
+                // T for all of the lane's dimensions, then 2 * DPL independent powers, then the scatter into V
+                double T[DPL], T2[DPL], v[DPL], v2[DPL];
+                T_of(mask, T);
+                T_of(mask2, T2);
+                weights(T, q, v);
+                weights(T2, q2, v2);
+                v_update(mask, q, v);
+                if (two) v_update(mask2, q2, v2);
             }
         }
         if (staged) {
