@@ -336,11 +336,14 @@ int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const double *Wt, int6
  * given): nz_idx (N x PM_BSC_NZ_MAX uint16: latent indices, unused slots 0xFFFF) and nz_val (N x PM_BSC_NZ_MAX).  Past the
  * annealing phase a posterior of the truncated state set puts weight on a handful of latents (3.7 of 256 per datapoint
  * on config 2), and the M-step's Wp = E[s]^T Y (bsc_et.py:339-363) needs only those rows of the product.  A row with more
- * than PM_BSC_NZ_MAX non-zeros is counted in scalars[3]; `expect` is complete either way.
+ * than PM_BSC_NZ_MAX non-zeros is counted in scalars[3], slot 0 of its list reads PM_BSC_NZ_OVERFLOW, and ITS dense row is
+ * stored in `expect`; the dense row of a datapoint whose list is complete is NOT stored (round 5: the list is the row -- N x H
+ * doubles of write traffic per step less; pm_bsc_expand_lists_gated_f64 rebuilds those rows when the dense product runs).
  * Statistics of the whole-shard passes (pm_bsc_fused8_whole_shard; both entries): the diagonal of the second moments is
  * left in `qdiag` in full (= mus: E[s_h^2] = E[s_h]) and the diagonal of the Wq block stays zero -- the assembled matrix
  * upper + upper^T - diag(upper) + diag(qdiag) is the same, no fix-up pass is needed. */
 #define PM_BSC_NZ_MAX 16
+#define PM_BSC_NZ_OVERFLOW 0xFFFEu      /* nz_idx[n][0] of a datapoint whose list overflowed (its dense row is in `expect`) */
 int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
                                const double *ynorm2, const double *wmu, const double *ymu,
                                const uint16_t *state_masks, const uint16_t *state_parents,
@@ -354,6 +357,16 @@ int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const double *Wt, i
  * list overflowed: pm_gemm_tn_acc_gated_f64 on `expect` does the work then).  H <= 256. */
 int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *stats,
                          int64_t N, int64_t H, int64_t D, void *stream);
+/* The dense rows pm_bsc_estep_fused8_nz_f64 did not store, for the dense product that runs when some list overflowed:
+ * expect[n, :] = 0, then expect[n, nz_idx[n,t]] = nz_val[n,t], for every datapoint whose list is complete (slot 0 is not
+ * PM_BSC_NZ_OVERFLOW).  Decided on the device like the products themselves: returns at once unless *gate (scalars[3]) is
+ * non-zero.  Enqueue it between pm_bsc_wp_sparse_f64 and pm_gemm_tn_acc_gated_f64 (or use pm_bsc_wp_sparse_expand_f64). */
+int pm_bsc_expand_lists_gated_f64(const uint16_t *nz_idx, const double *nz_val, double *expect, int64_t lde,
+                                  int64_t N, int64_t H, const double *gate, void *stream);
+/* pm_bsc_wp_sparse_f64 and pm_bsc_expand_lists_gated_f64 in ONE launch (what the M-step enqueues): the sparse product, or --
+ * scalars[3] of `stats` non-zero -- the completion of `expect` for the dense product behind it. */
+int pm_bsc_wp_sparse_expand_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *stats,
+                                double *expect, int64_t lde, int64_t N, int64_t H, int64_t D, void *stream);
 /* The same accumulation for any model whose statistics start with Wp = E[s]^T Y (DSC / TSC, dsc_et.py:703-735): Wp (H x D,
  * leading dimension ldw) and the device-side gate (a double: non-zero = skip) are given explicitly. */
 int pm_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp, int64_t ldw,

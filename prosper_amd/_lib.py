@@ -84,6 +84,8 @@ SIGNATURES = {
                                              C.c_int, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp, c_dp, C.c_int,
                                              c_dp]),
     "pm_bsc_wp_sparse_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, i64, i64, i64, c_dp]),
+    "pm_bsc_expand_lists_gated_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, i64, i64, c_dp, c_dp]),
+    "pm_bsc_wp_sparse_expand_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, c_dp]),
     "pm_gemm_tn_acc_gated_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp, c_dp]),
     "pm_gemm_tn_acc_rows_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp, c_dp, i64, i64, c_dp]),
     "pm_bsc_mstep_rows16_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64,

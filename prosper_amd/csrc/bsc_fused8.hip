@@ -856,9 +856,13 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
                 }
             }
             char *erow = exp_t + ((uint32_t)lrow * (uint32_t)lde * 8u + (uint32_t)j32 * 8u);
-            // the row's non-zeros as a list as well (pm_bsc_wp_sparse_f64 multiplies them into the data): up to
+            // the row's non-zeros as a list (pm_bsc_wp_sparse_f64 multiplies them into the data): up to
             // PM_BSC_NZ_MAX (index, value) pairs in the order the lanes hold them, unused index slots 0xFFFF; a longer
-            // row counts in the statistics' overflow scalar and the dense product runs instead
+            // row counts in the statistics' overflow scalar and the dense product runs instead.  With lists the DENSE row
+            // is stored only when its list overflowed (slot 0 of the list then reads PM_BSC_NZ_OVERFLOW): a row with a
+            // complete list IS its list, and N x H doubles of write traffic per step (410 MB at config 2) stay at home
+            // [round 5; pm_bsc_expand_lists_gated_f64 rebuilds the dense rows of listed datapoints if the dense product
+            // has to run after all].
             const bool lists = nz_idx != nullptr;
             uint16_t *nzi = nz_idx + (m0 + lrow) * PM_BSC_NZ_MAX;
             double *nzv = nz_val + (m0 + lrow) * PM_BSC_NZ_MAX;
@@ -869,7 +873,7 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
                 double v = 0.0;
                 if (FULL || h < H) {
                     v = (a[i] + Pm[h]) * inv;
-                    if (!(PM_F8_SKIP & 32)) *reinterpret_cast<double *>(erow + 256 * i) = v;
+                    if (!(PM_F8_SKIP & 32) && !lists) *reinterpret_cast<double *>(erow + 256 * i) = v;
                     if (!(PM_F8_SKIP & 64) && live && __any(v != 0.0)) {
                         if (v != 0.0) atomicAdd(&t_mus[h], PM_Q(v, 0));       // (the one LDS accumulator all wavefronts share)
                     }
@@ -887,10 +891,19 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
                     }
                 }
             }
+            if (lists && nzn > PM_BSC_NZ_MAX && !(PM_F8_SKIP & 32)) {      // (uniform over the datapoint's 32 lanes)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) {
+                    const int h = j32 + 32 * i;
+                    if (FULL || h < H) *reinterpret_cast<double *>(erow + 256 * i) = (a[i] + Pm[h]) * inv;
+                }
+            }
             if (lists && live) {
                 if (j32 < PM_BSC_NZ_MAX && (uint32_t)j32 >= nzn) nzi[j32] = 0xFFFFu;
-                if (j32 == 0 && nzn > PM_BSC_NZ_MAX)
+                if (j32 == 0 && nzn > PM_BSC_NZ_MAX) {
+                    nzi[0] = PM_BSC_NZ_OVERFLOW;       // (behind the slot's own entry: same wavefront, same address, in order)
                     pm_atomic_add(stats + pm_bsc_stats_offset_scalars_dev(H, Dstats) + 3, 1.0);
+                }
             }
             wave_lds_sync16();       // P is the next pass's list area
         }

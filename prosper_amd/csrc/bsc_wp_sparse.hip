@@ -38,6 +38,22 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// The dense rows the list-writing E-step pass did not store (pm_bsc_estep_fused8_nz_f64 keeps the dense E[s] row of a
+// datapoint only when its list overflowed), rebuilt from the lists for the dense product: sixteen lanes per datapoint clear
+// the row, then lane t scatters entry t (same wavefront, program order).  `group` of `groups` sixteen-lane groups.
+__device__ __forceinline__ void expand_listed_rows(const uint16_t *__restrict__ nz_idx, const double *__restrict__ nz_val,
+                                                   double *__restrict__ expect, int64_t lde, int64_t N, int H,
+                                                   int64_t group, int64_t groups, int t) {
+    for (int64_t n = group; n < N; n += groups) {
+        if (nz_idx[n * PM_BSC_NZ_MAX] == PM_BSC_NZ_OVERFLOW) continue;       // (its dense row is there)
+        double *row = expect + n * lde;
+        for (int h = t; h < H; h += 16) row[h] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        const uint16_t h = nz_idx[n * PM_BSC_NZ_MAX + t];
+        if (h != 0xFFFFu && h < H) row[h] = nz_val[n * PM_BSC_NZ_MAX + t];
+    }
+}
+
 // (amdgpu_waves_per_eu(6, 6): 80 registers instead of 82 -- two spilled dwords -- so that four of these wavefronts per SIMD
 // leave room for ONE workgroup of the gathered f64 GEMM (176 registers a wavefront) on the same CU: GSC's M-step runs the two
 // on two streams, an HBM stream beside an MFMA kernel, 1.29 -> 1.24 ms per EM iteration at config 4; at 82 registers the GEMM's
@@ -48,9 +64,17 @@ __global__ __launch_bounds__(SP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(6
                                                                       double *__restrict__ Wp, int64_t ldw,
                                                                       const double *__restrict__ gate, int64_t N, int H,
                                                                       int D, int nchunks, int64_t rows_per_group,
-                                                                      int transposed) {
+                                                                      int transposed, double *__restrict__ expand_to,
+                                                                      int64_t lde) {
     extern __shared__ __attribute__((aligned(16))) double acc[];          // [H][SP_DC]
-    if (gate && *gate != 0.0) return;          // some list overflowed: the dense product runs instead
+    if (gate && *gate != 0.0) {                // some list overflowed: the dense product runs instead --
+        // -- on `expand_to`, whose rows of listed datapoints this launch fills in first (no launch of its own: the
+        // gated-off pair of a step costs one empty launch, not two)
+        if (expand_to)
+            expand_listed_rows(nz_idx, nz_val, expand_to, lde, N, H, (int64_t)blockIdx.x * (SP_WAVES * 4) + (threadIdx.x >> 4),
+                               (int64_t)gridDim.x * (SP_WAVES * 4), threadIdx.x & 15);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroups are dealt round-robin over the 8 XCDs: chunk = 8 k + (blockIdx & 7) keeps a chunk on one XCD (fewer
     // than 8 chunks -- D <= 448 -- : plain enumeration, every workgroup has work)
@@ -169,7 +193,18 @@ extern "C" int pm_bsc_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val
 }
 
 static int wp_sparse_launch(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp,
-                            int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, int transposed, void *stream);
+                            int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, int transposed, void *stream,
+                            double *expand_to = nullptr, int64_t lde = 0);
+
+// pm_bsc_wp_sparse_f64 for lists whose pass kept only the overflowed datapoints' dense rows: if the gate is set, the launch
+// completes `expect` from the lists instead of returning at once (pm_bsc_expand_lists_gated_f64 without its launch).
+extern "C" int pm_bsc_wp_sparse_expand_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy,
+                                           double *stats, double *expect, int64_t lde, int64_t N, int64_t H, int64_t D,
+                                           void *stream) {
+    if (!stats || !expect || lde < H) return PM_EINVAL;
+    return wp_sparse_launch(nz_idx, nz_val, Y, ldy, stats, D, stats + pm_bsc_stats_offset_scalars_dev(H, D) + 3, N, H, D, 0,
+                            stream, expect, lde);
+}
 
 extern "C" int pm_wp_sparse_f64(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp,
                                 int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, void *stream) {
@@ -187,7 +222,8 @@ extern "C" int pm_wp_sparse_t_f64(const uint16_t *nz_idx, const double *nz_val, 
 }
 
 static int wp_sparse_launch(const uint16_t *nz_idx, const double *nz_val, const double *Y, int64_t ldy, double *Wp,
-                            int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, int transposed, void *stream) {
+                            int64_t ldw, const double *gate, int64_t N, int64_t H, int64_t D, int transposed, void *stream,
+                            double *expand_to, int64_t lde) {
     if (!nz_idx || !nz_val || !Y || !Wp || N < 0 || H <= 0 || D <= 0 || ldy < D) return PM_EINVAL;
     if (H > 256 || D > INT32_MAX || N > INT32_MAX - 4096) return PM_ERANGE;
     if (N == 0) return PM_OK;
@@ -209,8 +245,34 @@ static int wp_sparse_launch(const uint16_t *nz_idx, const double *nz_val, const 
         return e;
     hipLaunchKernelGGL(bsc_wp_sparse_kernel, dim3((unsigned)(slots * groups)), dim3(SP_WAVES * 64), shmem,
                        static_cast<hipStream_t>(stream), nz_idx, nz_val, Y, ldy, Wp, ldw, gate, N, (int)H, (int)D, nchunks,
-                       rpg, transposed);
+                       rpg, transposed, expand_to, lde);
     return (int)hipGetLastError();
 }
 
 PM_DET_SETTER(bsc_wp_sparse)
+
+// ---------------------------------------------------------------------------------------------
+// The dense rows the list-writing E-step pass did not store (pm_bsc_estep_fused8_nz_f64 stores the dense E[s] row of a
+// datapoint only when its list overflowed): rebuilt from the lists when -- and only when -- the dense product has to
+// run (*gate != 0: some list of the shard overflowed).  Sixteen lanes per datapoint: the row is cleared with 16-byte
+// stores, then lane t scatters entry t.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bsc_expand_lists_kernel(const uint16_t *__restrict__ nz_idx,
+                                                               const double *__restrict__ nz_val,
+                                                               double *__restrict__ expect, int64_t lde, int64_t N, int H,
+                                                               const double *__restrict__ gate) {
+    if (*gate == 0.0) return;
+    expand_listed_rows(nz_idx, nz_val, expect, lde, N, H, (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4),
+                       (int64_t)gridDim.x * (blockDim.x >> 4), threadIdx.x & 15);
+}
+
+extern "C" int pm_bsc_expand_lists_gated_f64(const uint16_t *nz_idx, const double *nz_val, double *expect, int64_t lde,
+                                             int64_t N, int64_t H, const double *gate, void *stream) {
+    if (!nz_idx || !nz_val || !expect || !gate || N < 0 || H <= 0 || lde < H) return PM_EINVAL;
+    if (H > 65534) return PM_ERANGE;
+    if (N == 0) return PM_OK;
+    const int64_t blocks = (N + 15) / 16;
+    hipLaunchKernelGGL(bsc_expand_lists_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), nz_idx, nz_val, expect, lde, N, (int)H, gate);
+    return (int)hipGetLastError();
+}

@@ -259,7 +259,8 @@ class BSC_ET(DeviceCAModel):
                 nz = (self._buf("nz_idx", (N, nz_max), torch.int16), self._buf("nz_val", (N, nz_max)))
                 args = args + (_ptr(nz[0]), _ptr(nz[1]))
                 entry = "pm_bsc_estep_fused8_nz_f64"
-                self._nz = {"idx": nz[0], "val": nz[1], "stats": mstats[1], "rows": N}
+                # ("listed": the pass stores the dense E[s] row of a datapoint only when its list overflowed)
+                self._nz = {"idx": nz[0], "val": nz[1], "stats": mstats[1], "rows": N, "dense_rows": "overflowed"}
             if main_rows > 0:
                 self._call("estep_fused", entry, *(args + (1, self._stream())))
             if main_rows < main:
@@ -702,11 +703,19 @@ class BSC_ET(DeviceCAModel):
         if my_N and done == my_N and nz is not None and nz["stats"] is stats and nz["rows"] == my_N:
             # the lists of this very pass: sparse product, and the dense one behind the device-side gate (scalars[3])
             gate = ctypes.c_void_p(stats.data_ptr() + 8 * (_lib.load().pm_bsc_stats_offset_scalars(H, D) + 3))
-            self._call("stats_sparse", "pm_bsc_wp_sparse_f64", _ptr(nz["idx"]), _ptr(nz["val"]), _ptr(Y), Y.stride(0),
-                       _ptr(stats), my_N, H, D, st)
+            self._expect_rows = nz.get("dense_rows", "all")      # (for tools / tests: which rows of _ws["expect"] the pass stored)
+            if nz.get("dense_rows") == "overflowed":
+                # (the E-step pass stored the dense rows of the overflowed datapoints only: if the gate is set, this
+                # launch fills in the listed ones for the dense product instead of returning at once)
+                self._call("stats_sparse", "pm_bsc_wp_sparse_expand_f64", _ptr(nz["idx"]), _ptr(nz["val"]), _ptr(Y),
+                           Y.stride(0), _ptr(stats), _ptr(expect), H, my_N, H, D, st)
+            else:
+                self._call("stats_sparse", "pm_bsc_wp_sparse_f64", _ptr(nz["idx"]), _ptr(nz["val"]), _ptr(Y), Y.stride(0),
+                           _ptr(stats), my_N, H, D, st)
             self._call("stats_gemm", "pm_gemm_tn_acc_gated_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D,
                        my_N, gate, st)
         elif my_N:
+            self._expect_rows = "all"
             self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, st)
         need_mu = 'mu' in self.to_learn
         if need_mu:       # my_data_sum over the kept datapoints (bsc_et.py:422-430): one pass over the shard

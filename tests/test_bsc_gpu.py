@@ -681,6 +681,21 @@ def test_fused_estep_matches_two_kernel_path(dev, D, H, Hp, gamma, N, with_mu):
     np.testing.assert_allclose(out["fused"][2], out["rows16"][2], rtol=1e-12, atol=1e-10)
 
 
+def _expect_of(m):
+    """E[s] rows of the model's last statistics pass: the dense buffer, with the rows the list-writing pass did not store
+    (pm_bsc_estep_fused8_nz_f64 keeps the dense row of a datapoint only when its list overflowed) rebuilt from the lists."""
+    E = m._ws["expect"].cpu().numpy().copy()
+    if getattr(m, "_expect_rows", "all") == "overflowed":
+        idx = m._ws["nz_idx"].cpu().numpy().view(np.uint16).astype(np.int64)
+        val = m._ws["nz_val"].cpu().numpy()
+        listed = idx[:, 0] != 0xFFFE
+        E[listed] = 0.0
+        rows = np.repeat(np.arange(E.shape[0]), idx.shape[1]).reshape(idx.shape)
+        sel = (idx != 0xFFFF) & listed[:, None]
+        E[rows[sel], idx[sel]] = val[sel]
+    return E
+
+
 @pytest.mark.parametrize("D,H,Hp,gamma,N", [(1024, 256, 8, 4, 40000), (64, 200, 7, 3, 3000), (25, 10, 5, 3, 333)])
 def test_step_with_fused_mstep_statistics(dev, D, H, Hp, gamma, N):
     """Inside ``step`` with no data truncation ahead the fused E-step kernel also produces the M-step's per-datapoint
@@ -702,7 +717,7 @@ def test_step_with_fused_mstep_statistics(dev, D, H, Hp, gamma, N):
         finally:
             dlog.remove_handler(h)
         out[fuse] = (new, float(h.tables["L"][0]), int(h.tables["N_use"][0]), m._ws["stats"].cpu().numpy().copy(),
-                     m._ws["expect"].cpu().numpy().copy())
+                     _expect_of(m))
     a, b = out[True], out[False]
     assert a[2] == b[2] == N
     np.testing.assert_allclose(a[1], b[1], rtol=1e-12)
@@ -752,23 +767,36 @@ def test_sparse_wp_from_nonzero_lists(dev, N, T, overflow, D, H, gamma):
         names = []
         orig = m._call
         m._call = lambda label, name, *a, _o=orig, _n=names: (_n.append(name), _o(label, name, *a))[1]
+        if sparse:
+            m._buf("expect", (N, H)).fill_(float("nan"))       # (what the list-writing pass does not store stays NaN)
         new = m.step(_An(T=T), dict(params), {"y": y})
         out[sparse] = (new, m._ws["stats"].cpu().numpy().copy(), m._ws["expect"].cpu().numpy().copy(), names)
         if sparse:
             idx = m._ws["nz_idx"].cpu().numpy().view(np.uint16).astype(np.int64)
             val = m._ws["nz_val"].cpu().numpy()
+            E_lists = _expect_of(m)
     a, b = out[True], out[False]
-    assert "pm_bsc_wp_sparse_f64" in a[3] and "pm_gemm_tn_acc_gated_f64" in a[3]
-    assert "pm_bsc_wp_sparse_f64" not in b[3] and "pm_gemm_tn_acc_f64" in b[3]
+    assert a[3].index("pm_bsc_wp_sparse_expand_f64") < a[3].index("pm_gemm_tn_acc_gated_f64")
+    assert not any("wp_sparse" in n for n in b[3]) and "pm_gemm_tn_acc_f64" in b[3]
     o_sc = _lib.load().pm_bsc_stats_offset_scalars(H, D)
-    E = a[2]
+    E = b[2]                                                    # the dense pass (no lists) stores every row
+    assert np.isfinite(E).all()
     nnz = (E != 0).sum(axis=1)
     n_over = int(a[1][o_sc + 3])
     assert n_over == int((nnz > 16).sum())
     if overflow is not None:
         assert (n_over > 0) == overflow
-    # the lists: the non-zeros of the dense row, in ascending-lane order of the kernel, 0xFFFF behind them
+    # the lists: the non-zeros of the dense row, in ascending-lane order of the kernel, 0xFFFF behind them; slot 0 of an
+    # overflowed list is the marker, and only THOSE datapoints' dense rows are stored by the list-writing pass -- unless
+    # some list overflowed: then the dense product ran, behind pm_bsc_expand_lists_gated_f64, on a complete buffer
     ok = nnz <= 16
+    assert np.array_equal(idx[:, 0] == 0xFFFE, ~ok)
+    assert np.array_equal(a[2][~ok], E[~ok])
+    if n_over:
+        assert np.array_equal(a[2], E)
+    else:
+        assert np.isnan(a[2]).all()
+    assert np.array_equal(E_lists, E)
     cnt = (idx != 0xFFFF).sum(axis=1)
     assert np.array_equal(cnt[ok], nnz[ok])
     rebuilt = np.zeros_like(E)
@@ -778,7 +806,6 @@ def test_sparse_wp_from_nonzero_lists(dev, N, T, overflow, D, H, gamma):
     assert np.array_equal(rebuilt[ok], E[ok])
     assert all(len(set(r[r != 0xFFFF])) == (r != 0xFFFF).sum() for r in idx[ok][:500])
     # statistics and parameters
-    np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-300)
     sa, sb = a[1].copy(), b[1].copy()
     sa[o_sc + 3] = sb[o_sc + 3] = 0.0
     np.testing.assert_allclose(sa, sb, rtol=1e-9, atol=1e-11 * np.abs(sb).max())

@@ -140,6 +140,37 @@ def test_fused_estep_statistics_match_two_pass(cls_name, D, H, Hp, gamma, N):
         np.testing.assert_allclose(outs[0][1][k], outs[1][1][k], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("ncut", [0.0, 0.5])
+def test_mca_state_set_in_any_order_with_single_candidate_states(ncut):
+    """The row sums of the MCA kernels keep a prefix of the previous state's sum in registers (round 5): correct for ANY
+    state set, not only itertools.combinations order -- shuffled states and single-candidate rows in the state matrix
+    (a caller may edit `state_matrix`, as with the reference's attribute) against the oracle with the same matrix, on the
+    fused pass (ncut = 0) and the two-pass kernels (truncation)."""
+    from oracle import mca_oracle as M
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    D, H, Hp, gamma, N = 96, 24, 6, 3, 257
+    rng = np.random.RandomState(11)
+    W_gt = np.abs(rng.normal(size=(D, H))) * 2.0 + 0.1
+    y, _ = M.generate_mca_data(W_gt, 2.0 / H, 1.0, N, rng)
+    params = {"W": W_gt * (1 + 0.2 * rng.uniform(-1, 1, size=(D, H))), "pi": 2.4 / H, "sigma": 1.1}
+    model = M.make_model(D, H, Hp, gamma)
+    SM = np.asarray(model["SM"]).copy()
+    singles = np.zeros((3, Hp), dtype=SM.dtype)
+    singles[0, 0] = singles[1, 3] = singles[2, Hp - 1] = 1
+    SM = np.concatenate([SM, singles])[rng.permutation(SM.shape[0] + 3)]
+    assert SM.shape[0] % 2 == 0 and SM.shape[0] < 64          # (the odd / multi-batch cases: test_mca_step_matches_oracle)
+    SM = SM[:-1]                                              # ... an odd count here as well
+    model = dict(model, SM=SM, state_abs=SM.sum(axis=1), S=SM.shape[0])
+    ref, log = M.em_step(M.Anneal(T=1.0, Ncut_factor=ncut), model, dict(params), y, vec=True)
+    m = MCA_ET(D, H, Hp, gamma)
+    m.state_matrix, m.no_states, m.state_abs, m._masks_dev = SM.astype(np.uint8), SM.shape[0], SM.sum(axis=1), None
+    new = m.step(_An(T=1.0, Ncut_factor=ncut), dict(params), {"y": y})
+    np.testing.assert_allclose(new["W"], ref["W"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(new["pi"], ref["pi"], rtol=1e-9)
+    np.testing.assert_allclose(new["sigma"], ref["sigma"], rtol=1e-9)
+    np.testing.assert_allclose(new["Q"], ref["Q"], rtol=1e-10)
+
+
 # ------------------------------------------------------------------------- config-5 properties
 def test_config5_properties():
     """BASELINE config 5 dims (D=256 H=128 H'=8 gamma=3) at N = 6000, fused E+M pass (per-XCD copies of Wp/Wq and
