@@ -597,11 +597,13 @@ def main():
     gc.enable()
     if os.environ.get("PM_BENCH_DEBUG"):
         print("em step times ms:", " ".join("%.1f" % (x * 1e3) for x in em_ts), file=sys.stderr)
-    # ... and the same loop in its steady state (`em_iter_steady_ms`): EM steps 4..23 above still move the parameters a lot --
-    # the posteriors are broader there (longer non-zero lists, more candidate pairs with weight: the statistics pass and the
-    # sparse product cost 0.1-0.5 ms more per step, falling step by step; scratch/ns_resid.py: the inverse's warm start is
-    # accepted from the third step on, that is not it); 150 further steps (~0.35 s) later the loop runs the way a long EM
-    # run spends nearly all of its time
+    # ... and the same loop in its steady state (`em_iter_steady_ms`).  The window above starts three steps after a cold start
+    # (first-use allocations, the cold inverse: 36 / 6 / 5 ms steps with an idle GPU in between) and its first ~10 steps run
+    # 2.7 -> 2.3 ms although the parameters have stopped moving after the second step (sigma and the mean list length are
+    # constant from there; no list overflows): it is `estep_fused` itself that takes 2.04 -> 1.71 ms at constant work -- the
+    # clock ramping back up under the MFMA load (scratch/bsc_em_early.py, round 5; scratch/ns_resid.py: the inverse's warm
+    # start is accepted from the third step on, that is not it).  150 further steps (~0.35 s) later the loop runs the way a
+    # long EM run spends nearly all of its time
     gc.collect()
     gc.disable()
     for _ in range(150):            # (a fixed count: every rank must walk the same sequence of collectives)
