@@ -452,6 +452,10 @@ int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const double *wno
                             const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
                             int64_t Hprime, double *logpj, int64_t ldl, double *lse1, double *lseb,
                             double *q1, int64_t ldq, double *stats, void *stream);
+/* The per-step tables of the MCA / MMCA kernels from W^T (H x D, already clamped by check_params): tabs = [ W^T | sign(W) |W|^rho |
+ * |W|^(rho-1) ] (three H x D planes; mca_et.py:218-227, mmca_et.py:250-260 compute them with NumPy on the host) and
+ * wnorm2[h] = |W_h|^2.  The caller keeps the reference's assertions (finite logarithms, W^rho > 1e-86) on its host copy. */
+int pm_mca_tables_f64(const double *wt, int64_t H, int64_t D, double rho, double *tabs, double *wnorm2, void *stream);
 /* The element-wise W update of MCA_ET.M_step (mca_et.py:333-348) from the all-reduced `stats`
  * [G1 (H,D) | Wp_m (H,D) | Wq_m (H,D) | q1sum (H) | ...] and the current W^T (H,D): wt_new = (G1 W^2 + Wp_m) / (q1sum W^2 + Wq_m),
  * 0 / tiny where the denominator is below the smallest normal double; wt_clamped (or NULL) = max(wt_new, w_tol), what

@@ -100,6 +100,7 @@ SIGNATURES = {
     "pm_mca_mstep_rows_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_double, c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64,
                                         C.POINTER(McaParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
     "pm_mca_w_update_f64": (C.c_int, [c_dp, c_dp, i64, i64, C.c_double, c_dp, c_dp, c_dp]),
+    "pm_mca_tables_f64": (C.c_int, [c_dp, i64, i64, C.c_double, c_dp, c_dp, c_dp]),
     "pm_mca_estep_mstats_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64,
                                           C.POINTER(McaParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp,
                                           c_dp, i64, c_dp, c_dp]),

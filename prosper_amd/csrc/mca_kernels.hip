@@ -1227,6 +1227,44 @@ __global__ __launch_bounds__(256) void mca_wupdate_kernel(const double *__restri
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// The per-step tables of W (mca_et.py:218-227, mmca_et.py:250-260): W^T as given, sign(W)|W|^rho, |W|^(rho-1) and |W_h|^2
+// -- on the device, so that an EM loop never waits for the host's log / exp over H x D elements and a 3 H D upload between
+// the download of the new W and the next E-step (0.2-0.4 ms of idle device per step on the pool's slower hosts).  One
+// workgroup per latent; the row norm in a fixed tree (same bits every time).
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void mca_tables_kernel(const double *__restrict__ wt, int D, double rho,
+                                                         double *__restrict__ tabs, int64_t plane,
+                                                         double *__restrict__ wnorm2) {
+    __shared__ double s_part[4];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    double acc = 0.0;
+    for (int d = tid; d < D; d += 256) {
+        const double w = wt[(int64_t)h * D + d];
+        const double lw = log(fabs(w));
+        const double wr = exp(rho * lw);
+        tabs[(int64_t)h * D + d] = w;
+        tabs[plane + (int64_t)h * D + d] = copysign(wr, w);
+        tabs[2 * plane + (int64_t)h * D + d] = exp((rho - 1.0) * lw);
+        acc = fma(w, w, acc);
+    }
+    acc = pm_wave_sum(acc);
+    if ((tid & 63) == 0) s_part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) wnorm2[h] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+}  // namespace
+
+extern "C" int pm_mca_tables_f64(const double *wt, int64_t H, int64_t D, double rho, double *tabs, double *wnorm2,
+                                 void *stream) {
+    if (!wt || !tabs || !wnorm2 || H <= 0 || D <= 0 || !(rho > 0.0)) return PM_EINVAL;
+    if (D > INT32_MAX || H > INT32_MAX) return PM_ERANGE;
+    hipLaunchKernelGGL(mca_tables_kernel, dim3((unsigned)H), dim3(256), 0, static_cast<hipStream_t>(stream), wt, (int)D, rho,
+                       tabs, H * D, wnorm2);
+    return (int)hipGetLastError();
+}
+
 extern "C" int pm_mca_w_update_f64(const double *stats, const double *wt, int64_t H, int64_t D, double w_tol, double *wt_new,
                                    double *wt_clamped, void *stream) {
     if (!stats || !wt || !wt_new || H <= 0 || D <= 0) return PM_EINVAL;

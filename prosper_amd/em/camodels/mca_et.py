@@ -88,23 +88,43 @@ class MCA_ET(DeviceCAModel):
             self._masks_dev = ((self.Hprime, self.gamma), self._u16_dev(self._state_masks()))
         return self._masks_dev[1]
 
+    def _rho(self, T):
+        T_rho = np.maximum(T, self.rho_temp_bound)
+        return float(1. / (1. - 1. / T_rho))
+
+    def _tables_on_device(self, Wt_dev, rho):
+        """[W^T | sign(W)|W|^rho | |W|^(rho-1)] and |W_h|^2 from a device W^T (pm_mca_tables_f64), into the buffer set that
+        is NOT the current step's (a speculative build for the next step must not touch tables in use)."""
+        H, D = self.H, self.D
+        self._tab_flip = 1 - getattr(self, "_tab_flip", 0)
+        tabs = self._buf("mca_tabs%d" % self._tab_flip, (3, H, D))
+        wnorm2 = self._buf("mca_wn%d" % self._tab_flip, (H,))
+        self._call("tables", "pm_mca_tables_f64", _ptr(Wt_dev), H, D, ctypes.c_double(rho), _ptr(tabs), _ptr(wnorm2),
+                   self._stream())
+        return tabs, wnorm2
+
     def _tables_for(self, W_DH, T, res):
-        """Device copies of the per-step tables: W (H,D), |W_h|^2, W^rho, W^(rho-1)."""
+        """Device copies of the per-step tables: W (H,D), |W_h|^2, sign(W)|W|^rho, |W|^(rho-1) (mca_et.py:218-227,
+        mmca_et.py:250-260 -- there NumPy on the host; here pm_mca_tables_f64, so that an EM loop does not wait for the
+        host's log / exp over H x D elements: round 5).  The reference's assertions are kept, on W itself."""
         W = np.asarray(W_DH, dtype=np.float64)
         par = self._par
         if par.get("ykey") == res["key"] and par.get("T") == T and par.get("W") is not None \
                 and par["W"].shape == W.shape and np.array_equal(par["W"], W):
             return par
-        T_rho = np.maximum(T, self.rho_temp_bound)
-        rho = 1. / (1. - 1. / T_rho)
-        Wt = np.ascontiguousarray(W.T)                     # (H, D)
-        Wl = np.log(Wt)
-        host = np.stack([Wt, np.exp(rho * Wl), np.exp((rho - 1.) * Wl)])
-        assert np.isfinite(Wl).all() and np.isfinite(host[1]).all() and (host[1] > 1e-86).all()   # mca_et.py:224-227
-        dev = self._upload("mca_tabs", host)
-        wnorm2 = self._upload("mca_wn", (Wt * Wt).sum(axis=1))
-        self._par = {"ykey": res["key"], "T": T, "W": W.copy(order='K'), "Wt": dev[0], "Wrho": dev[1], "Wrm1": dev[2],
-                     "wnorm2": wnorm2, "rho": float(rho), "A": None}
+        rho = self._rho(T)
+        aW = np.abs(W) if self.signed_w else W
+        lo, hi = float(aW.min()), float(aW.max())
+        # finite logarithms; W^rho finite and > 1e-86 (mca_et.py:224-227, mmca_et.py:257-260: monotone in |W|)
+        assert np.isfinite(hi) and lo > 0.0 and rho * np.log(lo) > np.log(1e-86) and rho * np.log(hi) < 709.0
+        nxt, self._next_tabs = getattr(self, "_next_tabs", None), None
+        if nxt is not None and nxt["ykey"] == res["key"] and nxt["rho"] == rho and nxt["W"] is not None \
+                and nxt["W"].shape == W.shape and np.array_equal(nxt["W"], W):
+            tabs, wnorm2 = nxt["tabs"], nxt["wnorm2"]      # the last M-step built them from its own result, on the device
+        else:
+            tabs, wnorm2 = self._tables_on_device(self._upload("mca_Wt_in", np.ascontiguousarray(W.T)), rho)
+        self._par = {"ykey": res["key"], "T": T, "W": W.copy(order='K'), "Wt": tabs[0], "Wrho": tabs[1], "Wrm1": tabs[2],
+                     "wnorm2": wnorm2, "rho": rho, "A": None}
         return self._par
 
     def _params(self, anneal, pies, sigma, rho):
@@ -310,8 +330,15 @@ class MCA_ET(DeviceCAModel):
         res = getattr(self, "_mstep_res", None)
         seedable = (flat.is_cuda and learn_W and self.speculate and res is not None and res["Y"].shape[0] > 0
                     and type(self).select_Hprimes is MCA_ET.select_Hprimes)
+        self._next_tabs = None
         if seedable:
-            host = self._download(flat, then=lambda: self._seed_select(res, Wt_cl))
+            # behind the download: the next step's candidates AND its power tables from the clamped W^T on the device
+            # (valid if the caller hands this W back at the same temperature: checked by value in _tables_for)
+            def ahead():
+                self._seed_select(res, Wt_cl)
+                tabs, wnorm2 = self._tables_on_device(Wt_cl, par["rho"])
+                self._next_tabs = {"ykey": res["key"], "rho": par["rho"], "tabs": tabs, "wnorm2": wnorm2, "W": None}
+            host = self._download(flat, then=ahead)
         else:
             host = self._download(flat) if flat.is_cuda else flat.numpy()
         my_pi, my_sigma, ldenom_sum, N_use = float(host[0]), float(host[1]), float(host[2]), int(round(host[3]))
@@ -323,6 +350,8 @@ class MCA_ET(DeviceCAModel):
             W_new = host[4:4 + HD].reshape(H, D).copy().T
             if self._sel_seed is not None:
                 self._sel_seed["W"] = np.maximum(host[4:4 + HD].reshape(H, D), self.W_tol).T
+                if self._next_tabs is not None:
+                    self._next_tabs["W"] = self._sel_seed["W"]
         else:
             W_new = np.asarray(model_params['W'])
         if 'pi' in self.to_learn:

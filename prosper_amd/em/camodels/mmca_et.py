@@ -90,25 +90,6 @@ class MMCA_ET(MCA_ET):
         rho = 1. / (1. - 1. / T_rho)
         return float(np.maximum(np.minimum(rho, self.rho_ubound), self.rho_lbound))
 
-    def _tables_for(self, W_DH, T, res):
-        """Device copies of the per-step tables: W (H,D), |W_h|^2, sign(W)|W|^rho, |W|^(rho-1)."""
-        W = np.asarray(W_DH, dtype=np.float64)
-        par = self._par
-        if par.get("ykey") == res["key"] and par.get("T") == T and par.get("W") is not None \
-                and par["W"].shape == W.shape and np.array_equal(par["W"], W):
-            return par
-        rho = self._rho(T)
-        Wt = np.ascontiguousarray(W.T)                     # (H, D)
-        Wl = np.log(np.abs(Wt))
-        Wrho = np.exp(rho * Wl)
-        host = np.stack([Wt, np.sign(Wt) * Wrho, np.exp((rho - 1.) * Wl)])
-        assert np.isfinite(Wl).all() and np.isfinite(Wrho).all() and (Wrho > 1e-86).all()   # mmca_et.py:257-260
-        dev = self._upload("mca_tabs", host)
-        wnorm2 = self._upload("mca_wn", (Wt * Wt).sum(axis=1))
-        self._par = {"ykey": res["key"], "T": T, "W": W.copy(), "Wt": dev[0], "Wrho": dev[1], "Wrm1": dev[2],
-                     "wnorm2": wnorm2, "rho": rho, "A": None}
-        return self._par
-
     # ------------------------------------------------------------------ hot path
     @tracing.traced
     def select_Hprimes(self, model_params, data):
