@@ -130,7 +130,15 @@ def test_bsc_off_config_shapes_match_the_oracle(D, H, Hp, gamma, N):
     m = BSC_ET(D, H, Hp, gamma)
     data = m.select_Hprimes(params, {"y": y})
     ss = m.E_step(_An(T=1.1), params, data)
-    assert np.array_equal(np.asarray(data["candidates"]).astype(np.int64), log["candidates"])
+    cand = np.asarray(data["candidates"]).astype(np.int64)
+    same = (cand == log["candidates"]).all(axis=1)
+    if not same.all():
+        # a near-tie of the ranked scores (the device's come out of a split-K GEMM whose atomics sum in run-to-run order:
+        # seen once in a few hundred runs at H = 512); anything else is a defect
+        sc = (y @ params["W"]) / np.sqrt((params["W"] ** 2).sum(axis=0))[None, :]
+        a, b = (np.sort(np.take_along_axis(sc[~same], c[~same], 1), axis=1) for c in (cand, log["candidates"]))
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-11 * np.abs(sc).max())
+        pytest.skip("selection near-tie on this run: the rest of the comparison assumes the oracle's candidates")
     np.testing.assert_allclose(np.asarray(ss["logpj"]), log["logpj"], rtol=1e-10, atol=1e-8)
     new = m.M_step(_An(T=1.1), params, ss, data)
     # (N < H: Wq is rank-deficient and W_new is only defined up to LAPACK's SVD cutoff -- the statistics pin the path)
