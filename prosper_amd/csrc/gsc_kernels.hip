@@ -146,6 +146,9 @@ struct GscTables {
 // LACC: the column sums of xpt_s / xpt_sz and the singletons' diagonal of sum xpt_szsz are accumulated in LDS -- [3][4
 // wavefronts][H] accumulators, ds_add_f64 per lane and datapoint row, a copy per wavefront so that the four never contend --
 // and folded at the end: no second pass over the N x H moments (gsc_colsum_kernel read 410 MB again at config 4: 0.09 ms).
+#ifndef PM_GSC_LAUNDER
+#define PM_GSC_LAUNDER 1
+#endif
 #ifndef PM_GSC_ABL
 #define PM_GSC_ABL 0      // timing-only ablation builds (scratch/gsc_abl.sh): bits switch phases off, results are wrong
 #endif
@@ -361,9 +364,27 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
                 before_slot += __builtin_popcount(rowbits);
             }
             g_sync();
+#if PM_GSC_LAUNDER
+            {
+                int jq = j;
+                asm volatile("" : "+v"(jq));      // (see below: no spilled LDS address, no scratch reload here)
+                if (jq < Hp) myc = (int)s_as[jq];
+            }
+#else
             if (j < Hp) myc = (int)s_as[j];
+#endif
             g_sync();
+#if PM_GSC_LAUNDER
+            {   // (the lane's slot, opaque to the optimiser here: `cand + j` is otherwise a loop-invariant 64-bit address
+                // that gets SPILLED at three wavefronts per SIMD -- and a scratch reload is a vector-memory operation:
+                // its `s_waitcnt vmcnt(0)` drains the previous datapoint's stores before the candidate store may issue)
+                int jq = j;
+                asm volatile("" : "+v"(jq));
+                if (live && jq < Hp) cand[n * Hp + jq] = myc;
+            }
+#else
             if (live && j < Hp) cand[n * Hp + j] = myc;
+#endif
         } else {
             if (j < Hp) myc = cand[nn * Hp + j];
         }
@@ -371,11 +392,23 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
         // ---- candidate blocks -> LDS, accumulators cleared.  Candidate k of this datapoint sits in lane
         // rowbase + k: ds_bpermute fetches it (uniform trip counts: every source lane stays active)
         GSC_STAMP(1);
+#if PM_GSC_LAUNDER
+        {
+            int jq = j;
+            asm volatile("" : "+v"(jq));
+            if (jq < Hp) {
+                s_ac[jq] = arow[myc];
+                s_as[jq] = 0.0;
+                s_asz[jq] = 0.0;
+            }
+        }
+#else
         if (j < Hp) {
             s_ac[j] = arow[myc];
             s_as[j] = 0.0;
             s_asz[j] = 0.0;
         }
+#endif
         for (int p0 = 0; p0 < HH; p0 += 16) {
             const int p = p0 + j;
             const bool ok = p < HH;
