@@ -853,13 +853,14 @@ class GSC(DeviceCAModel):
         else:
             host = packed.numpy()
         dev_params = host[o_par:o_par + n_par] if fin is not None else None
-        W_given = host[o_wt:o_wt + nWp].reshape(H, D).T.copy() if Wt_next is not None else None
+        # (host time is on the loop's critical path on a slow host -- 0.58 ms of a 1.14 ms step, round 5: W comes back as the
+        # transposed VIEW of one contiguous (H, D) copy instead of a strided (D, H) one; the H x H sums are copied out of the
+        # pinned buffer only on the host-fallback path that reads them)
+        Wc = host[o_wt:o_wt + nWp].reshape(H, D).copy() if Wt_next is not None else None
+        W_given = Wc.T if Wc is not None else None
         Wp = host[:nWp].reshape(D, H)
         xs_xsz = host[nWp:nWp + nHH].reshape(H, H)
         xsz_xsz = host[nWp + nHH:nWp + 2 * nHH].reshape(H, H)
-        sum_xpt_ss = host[o:o + nHH].reshape(H, H).copy()
-        sum_xpt_szsz = host[o + nHH:o + 2 * nHH].reshape(H, H).copy()
-        sum_xpt_s, sum_xpt_sz = host[o2:o2 + H].copy(), host[o2 + H:o2 + 2 * H].copy()
         sum_yy = float(host[o2 + 2 * H])
 
         inverses = None
@@ -878,27 +879,39 @@ class GSC(DeviceCAModel):
             self.inverse_fallbacks += 1
         if inverses is None or W_given is None or not np.isfinite(W_given).all():
             W_given, self._seed, dev_params = None, None, None       # host fallback: whatever was speculated is void
-        elif self._seed is not None:
-            self._seed["W_host"] = W_given.copy()  # private snapshot of what model_params['W'] will hold: an in-place
-                                                   # edit by the caller must be seen as a different W
+        W_snap = None
+        if W_given is not None:
+            # ONE private snapshot of what model_params['W'] will hold, shared by everything that later asks "is this still the
+            # W I returned?": an in-place edit by the caller must be seen as a different W
+            W_snap = Wc.copy().T
+            if self._seed is not None:
+                self._seed["W_host"] = W_snap
         if dev_params is not None and np.isfinite(dev_params).all() and dev_params[-1] > 0:
             # the device's own update: what the caller gets is exactly what the launched E-step has used
             model_params['W'] = W_given
+            snap = {'W': W_snap}
             for k, lo, hi, shape in (('pi', 0, H, (H,)), ('mu', H, 2 * H, (H,)), ('psi_sq', 2 * H, 2 * H + nHH, (H, H))):
                 if k in self.to_learn:
                     model_params[k] = dev_params[lo:hi].reshape(shape).copy()
+                    snap[k] = dev_params[lo:hi].reshape(shape).copy()
+                else:
+                    snap[k] = np.array(model_params[k], dtype=np.float64, copy=True)
             if 'sigma_sq' in self.to_learn:
                 model_params['sigma_sq'] = float(dev_params[-1])
-            # (the parameters as the device holds them: the next M-step's `old` if they come back unchanged)
-            self._dev_params = (whole[o_par:o_par + n_par],
-                                {k: np.array(model_params[k], dtype=np.float64, copy=True) for k in ('pi', 'mu', 'psi_sq', 'sigma_sq')})
+            snap['sigma_sq'] = np.array(model_params['sigma_sq'], dtype=np.float64, copy=True)
+            # (the parameters as the device holds them: the next M-step's `old` if they come back unchanged; the same private
+            # snapshots serve the speculative E-step's check)
+            self._dev_params = (whole[o_par:o_par + n_par], snap)
             if fin["out"] is not None:
-                self._spec = {"res": res, "T": anneal['T'], "out": fin["out"],
-                              "params": {k: np.array(model_params[k], dtype=np.float64, copy=True) for k in self._PARAM_KEYS}}
+                self._spec = {"res": res, "T": anneal['T'], "out": fin["out"], "params": snap}
             return model_params
+        sum_xpt_ss = host[o:o + nHH].reshape(H, H).copy()
+        sum_xpt_szsz = host[o + nHH:o + 2 * nHH].reshape(H, H).copy()
+        sum_xpt_s, sum_xpt_sz = host[o2:o2 + H].copy(), host[o2 + H:o2 + 2 * H].copy()
         with small_blas():
             return self._update(model_params, N, Wp, xs_xsz, xsz_xsz, sum_xpt_s, sum_xpt_sz, sum_xpt_ss,
-                                sum_xpt_szsz, sum_yy, data_sq, inverses, W_given)
+                                sum_xpt_szsz, sum_yy, data_sq, inverses,
+                                None if W_given is None else np.ascontiguousarray(W_given))
 
     def _det_quanta(self, res, model_params):
         """Deterministic mode (scalar sigma_sq): bounds of the sums the E-step kernel and the moment GEMM accumulate.  Posterior
