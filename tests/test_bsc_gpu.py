@@ -1284,3 +1284,33 @@ def test_chunked_pipeline_matches_whole_shard(dev, overlap):
     new0, new1 = ref.M_step(an, params, s0, d0), m.M_step(an, params, s1, d1)
     for k in ("W", "pi", "sigma"):
         np.testing.assert_allclose(new1[k], new0[k], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("gate", [0.0, 3.0])
+def test_expand_lists_rebuilds_only_listed_rows_and_only_behind_the_gate(dev, gate):
+    """pm_bsc_expand_lists_gated_f64: rows whose list is complete are rebuilt from the list, rows marked PM_BSC_NZ_OVERFLOW keep
+    the dense row the E-step pass stored, and nothing is touched while the gate is 0."""
+    from prosper_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+    N, H = 1000, 200
+    idx = np.full((N, 16), 0xFFFF, dtype=np.uint16)
+    val = np.zeros((N, 16))
+    ref = rng.normal(size=(N, H))                                    # what the buffer holds before (stale / stored rows)
+    want = ref.copy()
+    over = rng.random_sample(N) < 0.2
+    for n in range(N):
+        k = rng.randint(0, 17)
+        hs = rng.choice(H, size=k, replace=False)
+        idx[n, :k], val[n, :k] = hs, rng.normal(size=k)
+        if over[n]:
+            idx[n, 0] = 0xFFFE
+        elif gate:
+            want[n] = 0.0
+            want[n, hs] = val[n, :k]
+    d_idx = torch.from_numpy(idx.view(np.int16)).to(dev)
+    d_val, d_E = torch.from_numpy(val).to(dev), torch.from_numpy(ref.copy()).to(dev)
+    d_gate = torch.tensor([gate], dtype=torch.float64, device=dev)
+    rc = lib.pm_bsc_expand_lists_gated_f64(_p(d_idx), _p(d_val), _p(d_E), H, N, H, _p(d_gate), _stream())
+    assert rc == 0
+    assert np.array_equal(d_E.cpu().numpy(), want)

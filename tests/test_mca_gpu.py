@@ -325,3 +325,34 @@ def test_mca_em_loop_seeded_selection_is_transparent():
     for k in ("W", "pi", "sigma"):
         # (the statistics are sums of f64 atomics: two runs of the same loop agree to ~1e-12, not bit for bit)
         np.testing.assert_allclose(runs[0][k], runs[1][k], rtol=1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("signed,rho", [(False, 21.0), (True, 6.0), (False, 3.7)])
+def test_power_tables_on_the_device_match_numpy(signed, rho):
+    """pm_mca_tables_f64 against the reference's host formulas (mca_et.py:218-227, mmca_et.py:250-260)."""
+    import ctypes
+    import torch
+    from prosper_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    H, D = 37, 300
+    Wt = np.abs(rng.normal(size=(H, D))) * 3 + 1e-3
+    if signed:
+        Wt *= rng.choice([-1.0, 1.0], size=(H, D))
+    dev = torch.device("cuda", 0)
+    d_W = torch.from_numpy(Wt).to(dev)
+    tabs = torch.empty((3, H, D), dtype=torch.float64, device=dev)
+    wn = torch.empty((H,), dtype=torch.float64, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.pm_mca_tables_f64(p(d_W), H, D, ctypes.c_double(rho), p(tabs), p(wn),
+                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    t = tabs.cpu().numpy()
+    Wl = np.log(np.abs(Wt))
+    assert np.array_equal(t[0], Wt)
+    # (exp(rho log w): the logarithm's rounding enters rho |log w| times -- both sides carry that, differently)
+    np.testing.assert_allclose(t[1], np.sign(Wt) * np.exp(rho * Wl), rtol=4e-14)
+    np.testing.assert_allclose(t[2], np.exp((rho - 1.0) * Wl), rtol=4e-14)
+    np.testing.assert_allclose(wn.cpu().numpy(), (Wt * Wt).sum(axis=1), rtol=1e-14)
