@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
     __shared__ __attribute__((aligned(16))) double s_rt[PM_ROOT21_LEN + 1];
     const bool r21 = P.signed_w == 0.0 && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
     const bool r6 = P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 6.0) < 1e-9;       // (MMCA's steady rho; either sign of W)
-    if (r21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
-    else if (r6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
+    if (!PM_POW_HWSEED && r21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);       // (the table seed's tables: A/B builds)
+    else if (!PM_POW_HWSEED && r6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
     __syncthreads();
 
     const int64_t wave0 = (int64_t)blockIdx.x * waves + wave;
@@ -346,8 +346,8 @@ void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
     double *s_rt = s_tab + PM_POWTAB_LEN;
     double *s_q1sum = s_rt + PM_ROOT21_LEN + 1;          // (+ 1: 16-byte alignment of what follows stays as it was)
     pm_load_powtab(s_tab, tid, blockDim.x);
-    if (ROOT == 21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
-    if (ROOT == 6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
+    if (!PM_POW_HWSEED && ROOT == 21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);  // (the table seed's tables: A/B builds)
+    if (!PM_POW_HWSEED && ROOT == 6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
     double *s_red = s_q1sum + H;
     const size_t per_wave = (size_t)(SIGNED ? 2 : 1) * HP * DS + S;
     double *s_wr = s_red + 4 * waves + (size_t)wave * per_wave;
@@ -747,8 +747,8 @@ __global__ __launch_bounds__(256) void mca_mstep_rows_kernel(const double *__res
     __shared__ __attribute__((aligned(16))) double s_rt[PM_ROOT21_LEN + 1];       // (see mca_estep_kernel)
     const bool r21 = !SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
     const bool r6 = SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 6.0) < 1e-9;
-    if (r21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);
-    else if (r6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
+    if (!PM_POW_HWSEED && r21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);       // (the table seed's tables: A/B builds)
+    else if (!PM_POW_HWSEED && r6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
     __syncthreads();
 
     // multi-cause numerator / denominator (stats[0 .. H*D) = Q1^T Y by the GEMM): this XCD's copy, folded by

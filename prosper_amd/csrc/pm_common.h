@@ -235,7 +235,30 @@ __device__ __forceinline__ void pm_load_root21(double *rt, const double *powtab,
     }
     for (int r = tid; r < 21; r += nthreads) rt[256 + r] = exp2(-(double)r / 21.0);
 }
+#ifndef PM_POW_HWSEED
+#define PM_POW_HWSEED 1     // the roots' seed from v_log_f32 / v_exp_f32 (round 5: no LDS lookup in the chain, 27 fewer registers in the MCA
+                            // pass: 7.0-7.17 -> 6.69 ms, 2.5e-16); 0: the round-4 table seed (two LDS lookups), kept for A/B builds
+#endif
 __device__ __forceinline__ double pm_pow_m20_21(double x, const double *rt) {
+#if PM_POW_HWSEED
+    // seed y0 ~ x'^(-1/21) = exp2(-log2(x') / 21) in f32 (x' = 2^r m in [1, 2^21): relative error ~1e-7, res = 1 - x' y0^21
+    // ~2e-6 -- inside the three series terms' reach); no table, no LDS access in the chain
+    const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
+    const unsigned eu = (hi >> 20) + 27u;
+    const unsigned q = (eu * 3121u) >> 16;
+    const unsigned r = eu - 21u * q;
+    const unsigned mant = hi & 0x000FFFFFu;
+    const double xp = __hiloint2double((int)(mant | ((1023u + r) << 20)), (int)lo);    // 2^r m
+    const double y0 = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)xp) * (-1.0f / 21.0f));
+    const double y2 = y0 * y0, y4 = y2 * y2, y8 = y4 * y4, y16 = y8 * y8;
+    const double y20 = y16 * y4;
+    const double res = fma(-xp, y20 * y0, 1.0);
+    double t = fma(res, 20.0 * 41.0 * 62.0 / (6.0 * 9261.0), 20.0 * 41.0 / (2.0 * 441.0));
+    t = fma(t, res, 20.0 / 21.0);
+    const double v = fma(y20, t * res, y20);
+    (void)rt;
+    return __hiloint2double(__double2hiint(v) + (int)((1000u - 20u * q) << 20), __double2loint(v));
+#else
     typedef double pm_d2 __attribute__((ext_vector_type(2)));
     const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
     const unsigned idx = (hi >> 13) & 127u;
@@ -256,6 +279,7 @@ __device__ __forceinline__ double pm_pow_m20_21(double x, const double *rt) {
     const double v = fma(y20, t * res, y20);
     // * 2^(-20 (q - 50))
     return __hiloint2double(__double2hiint(v) + (int)((1000u - 20u * q) << 20), __double2loint(v));
+#endif
 }
 
 // x^(1/6 - 1) = x^(-5/6) for NORMAL x > 0: the same construction for rho = 6 -- MMCA's power at every temperature T <= 1.2
@@ -271,6 +295,23 @@ __device__ __forceinline__ void pm_load_root6(double *rt, const double *powtab, 
     for (int r = tid; r < 6; r += nthreads) rt[256 + r] = exp2(-(double)r / 6.0);
 }
 __device__ __forceinline__ double pm_pow_m5_6(double x, const double *rt) {
+#if PM_POW_HWSEED
+    const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
+    const unsigned eu = (hi >> 20) + 27u;
+    const unsigned q = (eu * 10923u) >> 16;
+    const unsigned r = eu - 6u * q;
+    const unsigned mant = hi & 0x000FFFFFu;
+    const double xp = __hiloint2double((int)(mant | ((1023u + r) << 20)), (int)lo);    // 2^r m
+    const double y0 = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)xp) * (-1.0f / 6.0f));
+    const double y2 = y0 * y0, y4 = y2 * y2;
+    const double y5 = y4 * y0;
+    const double res = fma(-xp, y5 * y0, 1.0);
+    double t = fma(res, 5.0 * 11.0 * 17.0 / (6.0 * 216.0), 5.0 * 11.0 / (2.0 * 36.0));
+    t = fma(t, res, 5.0 / 6.0);
+    const double v = fma(y5, t * res, y5);
+    (void)rt;
+    return __hiloint2double(__double2hiint(v) + (int)((875u - 5u * q) << 20), __double2loint(v));
+#else
     typedef double pm_d2 __attribute__((ext_vector_type(2)));
     const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
     const unsigned idx = (hi >> 13) & 127u;
@@ -291,6 +332,7 @@ __device__ __forceinline__ double pm_pow_m5_6(double x, const double *rt) {
     const double v = fma(y5, t * res, y5);
     // * 2^(-5 (q - 175))
     return __hiloint2double(__double2hiint(v) + (int)((875u - 5u * q) << 20), __double2loint(v));
+#endif
 }
 
 // e^x for x <= ~700 from the same tables: x = k ln2/128 + r (two-part ln2/128, |r| <= ln2/256), e^r by a degree-5
