@@ -32,6 +32,12 @@ __host__ __device__ static inline int64_t mca_stats_base(int64_t H, int64_t D) {
 #ifndef PM_MCA_VDEFER
 #define PM_MCA_VDEFER 0 // a state's V update (and the rare rescaling) at the top of the next trip: one straight-line block for both stages
 #endif
+#ifndef PM_MCA_PAIR
+#define PM_MCA_PAIR -1  // two states per trip of the fused pass's state loop: -1 where one wavefront per SIMD runs anyway, 0 never, 1 always
+#endif
+#ifndef PM_MCA_NS
+#define PM_MCA_NS 2     // states per trip of that form
+#endif
 #ifndef PM_MCA_ABL
 #define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates, 4 T sums from candidate 0 only, 5 no wave reduction, 6 no exponential, 7 no states at all (S = 0)
 #endif
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
 // ROOT = 21: rho = 21 (every temperature T <= 1.05, unsigned W): the states' power through pm_pow_m20_21 (no log / exp);
 // ROOT = 6: rho = 6 (MMCA at every T <= 1.2): pm_pow_m5_6; ROOT = 0: any rho, the table power
 template <int DPL, int HP, bool SIGNED, int ROOT>      // ROOT: 21 / 6 = the log / exp-free powers of those rho, 0 = the table power
-__global__ __launch_bounds__(256, (HP <= 8 && ROOT == 0 ? 2 : 1))     // (the table power at H' <= 8 would take 258 registers: keep two wavefronts per SIMD; the others fit uncapped, and schedule better so)
+__global__ __launch_bounds__(256, (HP <= 8 && DPL <= 4 && ROOT == 0 && !(SIGNED && HP * DPL >= 24) ? 2 : 1))     // (the table power at H' <= 8, D <= 256 would take 258 registers: keep two wavefronts per SIMD; the others fit uncapped, and schedule better so; signed W with >= 24 KB of rows per wavefront runs one per SIMD anyway)
 void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
                                        const double *__restrict__ wnorm2, const double *__restrict__ ynorm2,
                                        const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
@@ -521,6 +527,100 @@ void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
                     }
             }
         };
+        // TWO states per trip where the pass runs ONE wavefront per SIMD anyway (signed W: two row sets, >= 24 KB of LDS per
+        // wavefront -- registers are free there, 278 of 512): stage A evaluates states s + 2 and s + 3 (2 * DPL independent power
+        // chains), stage B reduces, weighs and scatters states s and s + 1 -- their two wave reductions and exponentials
+        // interleave.  Same operations per state in the same order: the bits of the one-state loop.  MMCA config-5 dimensions:
+        // 10.67 -> 9.72 ms.  (At two wavefronts per SIMD the pair form needs 272 registers -- one wavefront, 9.0 against 6.65 ms.)
+        constexpr bool PAIRED = (PM_MCA_PAIR == 1) || (PM_MCA_PAIR < 0 && SIGNED && DPL <= 4 && HP * DPL >= 24);
+        if constexpr (PAIRED) {
+        constexpr int NS = PM_MCA_NS;                 // states per trip
+        auto mask_at = [&](int s) { return masks[s < S ? s : S - 1]; };
+        unsigned mP[NS], ld[NS];
+        double wbQ[NS][DPL], partQ[NS], rowX[DPL];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            mP[u] = S > 0 ? (unsigned)__builtin_amdgcn_readfirstlane((int)mask_at(u)) : 0u;
+            ld[u] = S > 0 ? mask_at(NS + u) : 0u;
+            partQ[u] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            double T[DPL];
+            state_T(mP[u], rowX, T);
+            state_pow(T, wbQ[u], partQ[u]);
+        }
+        auto weigh = [&](unsigned m, double bf, const double (&wb)[DPL]) {      // one state, the reference level may move
+            double w = pm_exp_tab(bf - M, s_tab);
+            if (bf > M + 50.0) {
+                const double sc = exp(M - bf);
+#pragma unroll
+                for (int j = 0; j < HP; ++j)
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) V[j][i] *= sc;
+                M = bf;
+                w = 1.0;
+            }
+            maskD = m;
+            wD = w;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) vD[i] = SIGNED ? wb[i] : w * wb[i];
+            v_update();
+        };
+        for (int s = 0; s < ((PM_MCA_ABL == 7) ? 0 : S); s += NS) {
+            unsigned mN[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                mN[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)ld[u]);
+                ld[u] = mask_at(s + 2 * NS + u);
+            }
+            // ---- stage A, states s + NS .. s + 2 NS - 1 (dummies past the end) ----
+            double TN[NS][DPL], wbN[NS][DPL], partN[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                partN[u] = 0.0;
+                state_T(mN[u], rowX, TN[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) state_pow(TN[u], wbN[u], partN[u]);
+            // ---- stage B, states s .. s + NS - 1 ----
+            double part[NS], bf[NS];
+            bool moves = false;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) part[u] = pm_wave_sum_dpp(partQ[u]);   // wave-uniform
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                if (lane == 0 && s + u < S) s_e[s + u] = part[u];
+                bf[u] = P.beta * (P.pil_bar * (double)__builtin_popcount(mP[u]) + P.pre1 * part[u]);
+                moves = moves || (s + u < S && bf[u] > M + 50.0);
+            }
+            if (moves) {                               // uniform; the first trip, then hardly ever: one by one
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+                    if (s + u < S) weigh(mP[u], bf[u], wbQ[u]);
+            } else {
+                double w[NS];
+#pragma unroll
+                for (int u = 0; u < NS; ++u) w[u] = pm_exp_tab(bf[u] - M, s_tab);
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+                    if (s + u < S) {
+                        maskD = mP[u];
+                        wD = w[u];
+#pragma unroll
+                        for (int i = 0; i < DPL; ++i) vD[i] = SIGNED ? wbQ[u][i] : w[u] * wbQ[u][i];
+                        v_update();
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                partQ[u] = partN[u];
+                mP[u] = mN[u];
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) wbQ[u][i] = wbN[u][i];
+            }
+        }
+        } else {
         unsigned maskP = S > 0 ? (unsigned)__builtin_amdgcn_readfirstlane((int)masks[0]) : 0u;      // (scalar registers)
         unsigned maskN = S > 0 ? (unsigned)__builtin_amdgcn_readfirstlane((int)masks[S > 1 ? 1 : 0]) : 0u;
         unsigned mask_load = S > 0 ? masks[S > 2 ? 2 : S - 1] : 0u;
@@ -591,6 +691,7 @@ void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
             }
         }
         if (PM_MCA_VDEFER) v_update();             // the last state
+        }
         wave_sync_lds();
 
         // log-pseudo-joints and the two log-evidences (as mca_estep_kernel)
