@@ -136,18 +136,28 @@ int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double *diag_add,
 
 /* The same inverse, warm-started: `prev_inv` (n x n, leading dimension n) is the inverse of a nearby matrix -- the
  * previous EM step's second moments.  Four Newton-Schulz steps X <- X + X (I - A X) on the matrix cores refine it into
- * `inv` (symmetrised); the Gauss-Jordan sweep is launched behind them and returns at once when the start residual
- * ||I - A prev_inv||_F was below 0.1 (then ||I - A inv|| < 1e-16 up to rounding and pivots = {min_i 1 / inv_ii, max_i A_ii}: a lower
- * bound of the smallest and an upper bound of the largest pivot of the sweep), else it overwrites `inv` with
- * the exact inverse as pm_spd_inverse_f64 would.  The decision is taken on the device from sums formed in a fixed
- * order and left for the caller in pivots[2] (`pivots`: THREE doubles here): 1.0 = the refinement stands, 0.0 = the sweep
- * ran (`inv` is then exact to cond(A) eps only: a caller that skipped the iterative refinement of its solve repeats it
- * with one).  `work`: pm_spd_inverse_warm_work_len(n) doubles; `full` (required, leading dimension ldo = n) receives the
- * assembled matrix.  Same role as pm_spd_inverse_f64 (np.linalg.lstsq(Wq, Wp), bsc_et.py:380). */
+ * `inv` (symmetrised); the Gauss-Jordan sweep is launched behind them and returns at once when the refinement converged:
+ * the LAST residual the iteration formed, R_3 = (I - A prev_inv)^8, is below 1e-8 in the Frobenius norm, so the result's
+ * is below 1e-16 up to rounding (round 6; until then the START residual had to be below 0.1 in the Frobenius norm, which
+ * rejected the few-per-cent-in-every-direction residuals of an annealing ramp although they converge).  Then pivots =
+ * {min_i 1 / inv_ii, max_i A_ii}: a lower bound of the smallest and an upper bound of the largest pivot of the sweep.  Else
+ * the sweep overwrites `inv` with the exact inverse as pm_spd_inverse_f64 would.  The decision is taken on the device from
+ * sums formed in a fixed order and left for the caller in pivots[2] (`pivots`: THREE doubles here): 1.0 = the refinement
+ * stands and ||I - A prev_inv||_F < 1, 2.0 = it stands from a start further away, 0.0 = the sweep ran (`inv` is then exact
+ * to cond(A) eps only: a caller that skipped the iterative refinement of its solve repeats it with one).  `work`:
+ * pm_spd_inverse_warm_work_len(n) doubles; `full` (required, leading dimension ldo = n) receives the assembled matrix.
+ * Same role as pm_spd_inverse_f64 (np.linalg.lstsq(Wq, Wp), bsc_et.py:380).
+ * pm_spd_inverse_warm_long_f64: the same from a start that may be FAR -- a data-truncation step (bsc_et.py:247-258) whose
+ * kept set jumped, a temperature step: the start is scaled by 1 / ||A prev_inv||_inf (both matrices are symmetric positive
+ * definite, so the scaled residual's spectrum lies in [0, 1) and the iteration converges from any such start) and eight +
+ * one steps run: accepted for ||A prev_inv||_inf / lambda_min(A prev_inv) up to ~14, ~60 us instead of the sweep's 0.3 ms. */
 int64_t pm_spd_inverse_warm_work_len(int64_t n);
 int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n, const double *prev_inv,
                             int64_t ldp, double *work, double *full, double *inv, int64_t ldo, double *pivots,
                             void *stream);
+int pm_spd_inverse_warm_long_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n,
+                                 const double *prev_inv, int64_t ldp, double *work, double *full, double *inv, int64_t ldo,
+                                 double *pivots, void *stream);
 
 /* `batch` warm-started inverses at once (every kernel of pm_spd_inverse_warm_f64 gets a batch dimension): matrix b is
  * read at upper + b*stride_in (diag_add + b*n), its previous inverse at prev_inv + b*stride_prev (dense n x n), its
@@ -192,6 +202,18 @@ int pm_spd_inverse_batch_f64(const double *upper, int64_t ldu, int64_t stride_in
 int pm_kth_hist_f64(const double *x, int64_t n, const uint64_t *state, int shift, int bits, uint64_t *hist, void *stream);
 int pm_kth_scan(uint64_t *hist, uint64_t *state, int shift, int bits, void *stream);
 int pm_kth_value_f64(const uint64_t *state, double *out, void *stream);
+/* The same select in 1 + 6 + 1 launches instead of 13 (round 6: what a data-truncation step pays once nothing else in it
+ * waits for the host): `hists` holds one histogram of 4096 bins PER ROUND (6 x 4096 uint64, zeroed by the caller -- one
+ * fill), `states` seven (prefix, k) pairs, slot 0 = (0, k) from the caller.  pm_kth_round_f64(round r) first repeats, in
+ * every workgroup, the scan of round r - 1 (its histogram -- sum-all-reduced by the caller between the two calls -- and
+ * states[r - 1]; `shift_prev` / `bits_prev`: that round's digit; workgroup 0 stores the result as states[r]), then
+ * histograms the digit [shift, shift + bits) of the values that agree with the prefix into hists[r].  pm_kth_final_f64
+ * scans the last round and converts: out[0] = the k-th largest, exactly the value a full sort returns.  The value stays
+ * on the device (pm_bsc_defer_apply_f64 reads it there).  n = 0 (an empty shard) is fine. */
+int pm_kth_round_f64(const double *x, int64_t n, uint64_t *states, uint64_t *hists, int round, int shift_prev, int bits_prev,
+                     int shift, int bits, void *stream);
+int pm_kth_final_f64(uint64_t *states, const uint64_t *hists, int rounds, int shift_prev, int bits_prev, double *out,
+                     void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Binary Sparse Coding (prosper/em/camodels/bsc_et.py)
@@ -352,6 +374,30 @@ int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const double *Wt, i
                                int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
                                double *expect, int64_t lde, double *stats, int64_t D_stats, uint16_t *nz_idx,
                                double *nz_val, int part, void *stream);
+/* DEFERRED statistics for a data-truncation step (bsc_et.py:247-258 keeps the N_use datapoints with the largest evidence;
+ * which ones is known only after the E-step of every rank).  pm_bsc_estep_fused8_defer_f64 is pm_bsc_estep_fused8_nz_f64
+ * that, given `records` (N x PM_BSC_DEFER_LD doubles), accumulates NOTHING into `stats` but the overflow count scalars[3]:
+ * per datapoint it leaves the non-zero list of E[s] (as above; the dense row when the list overflowed) and the record
+ * [36 entries k (k + 1) / 2 + i (i <= k candidate positions) of the multi-cause states' second moments, diagonal entries 0 |
+ * ecoef sum_k q_k e_k | pad].  `records` NULL: exactly pm_bsc_estep_fused8_nz_f64.
+ * pm_bsc_defer_apply_f64 then adds the records of the datapoints with lse[n] >= *cut (a DEVICE double: the radix select's
+ * result never visits the host; values below log(2^-1075) mean "keep all", bsc_et.py:253) into `stats` -- Wq pair block,
+ * mus = qdiag, sum q e, sum lse, kept count, i.e. what the in-pass statistics of the kept datapoints would have been
+ * (bsc_et.py:334-366, 395-415) -- and empties the lists (zeroes the dense rows) of the others, so that
+ * pm_bsc_wp_sparse_expand_f64 / pm_gemm_tn_acc_gated_f64 behind it see kept datapoints only.  H <= 256, Hprime = 8. */
+#define PM_BSC_DEFER_LD 40
+int pm_bsc_estep_fused8_defer_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
+                                  const double *ynorm2, const double *wmu, const double *ymu,
+                                  const uint16_t *state_masks, const uint16_t *state_parents,
+                                  const int32_t *size_offsets_host, int64_t S, int64_t gamma,
+                                  const pm_bsc_estep_params *params_host, int64_t N, int64_t D, int64_t H,
+                                  int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl, double *lse,
+                                  double *expect, int64_t lde, double *stats, int64_t D_stats, uint16_t *nz_idx,
+                                  double *nz_val, double *records, int part, void *stream);
+int pm_bsc_defer_apply_f64(const double *lse, const double *cut, const int32_t *cand, const double *records,
+                           uint16_t *nz_idx, const double *nz_val, double *expect, int64_t lde, double *stats,
+                           const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
+                           void *stream);
 /* Wp (the leading H x D block of `stats`) += sum_n sum_t nz_val[n,t] . Y[n,:] into row nz_idx[n,t]  -- my_Wp of
  * bsc_et.py:339-363 from the non-zero lists; returns at once on the device when scalars[3] of `stats` is non-zero (some
  * list overflowed: pm_gemm_tn_acc_gated_f64 on `expect` does the work then).  H <= 256. */

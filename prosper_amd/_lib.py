@@ -46,6 +46,7 @@ SIGNATURES = {
     "pm_spd_inverse_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp]),
     "pm_spd_inverse_warm_work_len": (i64, [i64]),
     "pm_spd_inverse_warm_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp]),
+    "pm_spd_inverse_warm_long_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp]),
     "pm_spd_inverse_warm_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp]),
     "pm_inverse_warm_batch_f64": (C.c_int, [c_dp, i64, i64, c_dp, i64, c_dp, i64, c_dp, c_dp, i64, c_dp, c_dp, i64, C.c_uint32,
                                             c_dp]),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "pm_kth_hist_f64": (C.c_int, [c_dp, i64, c_dp, C.c_int, C.c_int, c_dp, c_dp]),
     "pm_kth_scan": (C.c_int, [c_dp, c_dp, C.c_int, C.c_int, c_dp]),
     "pm_kth_value_f64": (C.c_int, [c_dp, c_dp, c_dp]),
+    "pm_kth_round_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_dp]),
+    "pm_kth_final_f64": (C.c_int, [c_dp, c_dp, C.c_int, C.c_int, C.c_int, c_dp, c_dp]),
     "pm_bsc_select_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp, c_dp]),
     "pm_bsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64,
                                    C.POINTER(EStepParams), i64, i64, i64, c_dp, i64, c_dp, c_dp]),
@@ -83,6 +86,12 @@ SIGNATURES = {
                                              C.POINTER(C.c_int32), i64, i64, C.POINTER(EStepParams), i64, i64, i64, i64,
                                              C.c_int, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp, c_dp, C.c_int,
                                              c_dp]),
+    "pm_bsc_estep_fused8_defer_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
+                                                C.POINTER(C.c_int32), i64, i64, C.POINTER(EStepParams), i64, i64, i64, i64,
+                                                C.c_int, c_dp, c_dp, i64, c_dp, c_dp, i64, c_dp, i64, c_dp, c_dp, c_dp,
+                                                C.c_int, c_dp]),
+    "pm_bsc_defer_apply_f64": (C.c_int, [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64, c_dp, C.POINTER(EStepParams),
+                                         i64, i64, i64, i64, c_dp]),
     "pm_bsc_wp_sparse_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, i64, i64, i64, c_dp]),
     "pm_bsc_expand_lists_gated_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, i64, i64, c_dp, c_dp]),
     "pm_bsc_wp_sparse_expand_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, i64, i64, i64, c_dp]),
@@ -151,6 +160,7 @@ class HipError(RuntimeError):
     pass
 
 
+MIN_VERSION = 1012
 _lib = None
 _lib_det = None
 LIB_PATH_DET = os.path.join(os.path.dirname(LIB_PATH), "libprosper_hip_det.so")
@@ -171,6 +181,11 @@ def _open(path, what):
         fn = getattr(lib, name)   # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
+    # (the statistics layouts and list conventions the host layer relies on changed under unchanged entry-point names more
+    # than once: refuse a library older than the one this package was written against)
+    if lib.pm_version() < MIN_VERSION:
+        raise HipError("%s is version %d, this package needs >= %d: rebuild it (prosper_amd/csrc/build.sh)"
+                       % (path, lib.pm_version(), MIN_VERSION))
     return lib
 
 

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
     const double *__restrict__ ymu, const uint16_t *__restrict__ masks, const uint16_t *__restrict__ parents,
     pm_bsc_estep_params P, int64_t N, int H, int mode, int32_t *__restrict__ cand, double *__restrict__ logpj,
     int64_t ldl, double *__restrict__ lse, double *__restrict__ expect, int64_t lde, double *__restrict__ stats,
-    int Dstats, int64_t row0, uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val) {
+    int Dstats, int64_t row0, uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val,
+    double *__restrict__ defer) {
     using SS = StateSet<HP, GAMMA>;
     constexpr bool W16 = !TAIL;                       // the main launch: sixteen wavefronts, 128 datapoints
     constexpr int TILE_ROWS = TAIL ? TAIL_ROWS : 128, NPASS = TAIL ? 1 : 4;
@@ -531,8 +532,11 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
     double *listA = Pm + j32;
     double *win = reinterpret_cast<double *>(area + A_WIN);
     int *cl = reinterpret_cast<int *>(area + A_MISC);
-    constexpr bool PAIRLDS = W16 && MSTATS;
-    double *Bp = reinterpret_cast<double *>(smem + T_PAIRS16) + (PAIRLDS ? slot : 0) * PAIR_ENTRIES;
+    // (round 6: the TAIL workgroup gathers its pair blocks in LDS as well -- behind its 16 areas; its ring is larger)
+    constexpr bool PAIRLDS = MSTATS;
+    constexpr int T_PAIRS = W16 ? T_PAIRS16 : LEAN_LDS_BYTES;
+    static_assert(LEAN_LDS_BYTES + 16 * PAIR_ENTRIES * 8 <= TAIL_RING_BYTES, "the TAIL workgroup's pair blocks fit its LDS");
+    double *Bp = reinterpret_cast<double *>(smem + T_PAIRS) + (PAIRLDS ? slot : 0) * PAIR_ENTRIES;
     // lane j32 flushes pair entry j32 = k (k + 1) / 2 + i (entries 32..35 = (4..7, 7) go with lanes 0..3)
     const int pair_k = (j32 >= 1) + (j32 >= 3) + (j32 >= 6) + (j32 >= 10) + (j32 >= 15) + (j32 >= 21) + (j32 >= 28);
     const int pair_i = j32 - pair_k * (pair_k + 1) / 2;
@@ -557,6 +561,12 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
     double *t_mus = reinterpret_cast<double *>(smem + T_MUS);
     const uint32_t *t_tab = reinterpret_cast<const uint32_t *>(smem + T_TAB);
     double m_sig = 0.0, m_fs = 0.0, m_cnt = 0.0;        // per-lane partial sums of the scalar statistics
+    // DEFERRED statistics (round 6; a data-truncation step, bsc_et.py:247-258: which datapoints count is known only once
+    // every log-evidence of every rank is): the pass accumulates NOTHING -- it leaves each datapoint's pair block and
+    // sum q e as a record of PM_BSC_DEFER_LD doubles beside its non-zero list, and bsc_defer_apply_kernel adds the records of
+    // the datapoints above the cut afterwards (320 B per datapoint instead of a second pass over 3.3 KB of log-joints).
+    const bool dfr = MSTATS && defer != nullptr;
+    char *rec_t = dfr ? reinterpret_cast<char *>(defer + m0 * PM_BSC_DEFER_LD) : nullptr;
 
     // scores of pass 0 -> LDS (TAIL: the wavefronts holding the K-sums write all 16 datapoints' rows)
     if (TAIL) {
@@ -786,7 +796,13 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
             double inv = __builtin_amdgcn_rcp(sum);
             inv = fma(fma(-sum, inv, 1.0), inv, inv);
             inv = fma(fma(-sum, inv, 1.0), inv, inv);
-            if (live) m_sig += qe * inv;
+            if (dfr) {
+                const double qrow = half_sum_f64(qe * inv);
+                if (j32 == 0 && live)
+                    *reinterpret_cast<double *>(rec_t + ((uint32_t)lrow * (PM_BSC_DEFER_LD * 8u) + PAIR_ENTRIES * 8u)) = qrow;
+            } else if (live) {
+                m_sig += qe * inv;
+            }
             // add[h]: the multi-cause states' share of E[s_h], gathered per candidate in LDS (P is free by now)
 #pragma unroll
             for (int i = 0; i < NJ; ++i) Pm[j32 + 32 * i] = 0.0;
@@ -845,14 +861,22 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
             if (PAIRLDS) {
                 // lane j32 flushes entry j32 = (pair_i, pair_k) and, lanes 0..3, entry 32 + j32 = (4 + j32, 7)
                 const double v = Bp[j32];
-                const int ci = cl[pair_i], ck = cl[pair_k];
-                const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
-                if (!(PM_F8_SKIP & (64 | 256)) && live && v != 0.0) pm_atomic_add(wq + (int64_t)lo * H + hi, PM_Q(v, 0));
-                if (j32 < PAIR_ENTRIES - 32) {
-                    const double v2 = Bp[32 + j32];
-                    const int c2 = cl[4 + j32], c7 = cl[7];
-                    const int lo2 = c2 < c7 ? c2 : c7, hi2 = c2 < c7 ? c7 : c2;
-                    if (!(PM_F8_SKIP & (64 | 256)) && live && v2 != 0.0) pm_atomic_add(wq + (int64_t)lo2 * H + hi2, PM_Q(v2, 0));
+                if (dfr) {
+                    char *rec = rec_t + ((uint32_t)lrow * (PM_BSC_DEFER_LD * 8u) + (uint32_t)j32 * 8u);
+                    if (live) {
+                        *reinterpret_cast<double *>(rec) = v;
+                        if (j32 < PAIR_ENTRIES - 32) *reinterpret_cast<double *>(rec + 256) = Bp[32 + j32];
+                    }
+                } else {
+                    const int ci = cl[pair_i], ck = cl[pair_k];
+                    const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
+                    if (!(PM_F8_SKIP & (64 | 256)) && live && v != 0.0) pm_atomic_add(wq + (int64_t)lo * H + hi, PM_Q(v, 0));
+                    if (j32 < PAIR_ENTRIES - 32) {
+                        const double v2 = Bp[32 + j32];
+                        const int c2 = cl[4 + j32], c7 = cl[7];
+                        const int lo2 = c2 < c7 ? c2 : c7, hi2 = c2 < c7 ? c7 : c2;
+                        if (!(PM_F8_SKIP & (64 | 256)) && live && v2 != 0.0) pm_atomic_add(wq + (int64_t)lo2 * H + hi2, PM_Q(v2, 0));
+                    }
                 }
             }
             char *erow = exp_t + ((uint32_t)lrow * (uint32_t)lde * 8u + (uint32_t)j32 * 8u);
@@ -874,7 +898,7 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
                 if (FULL || h < H) {
                     v = (a[i] + Pm[h]) * inv;
                     if (!(PM_F8_SKIP & 32) && !lists) *reinterpret_cast<double *>(erow + 256 * i) = v;
-                    if (!(PM_F8_SKIP & 64) && live && __any(v != 0.0)) {
+                    if (!(PM_F8_SKIP & 64) && live && !dfr && __any(v != 0.0)) {
                         if (v != 0.0) atomicAdd(&t_mus[h], PM_Q(v, 0));       // (the one LDS accumulator all wavefronts share)
                     }
                 }
@@ -916,8 +940,10 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
         const int lrow = TAIL ? slot : 16 * rg + fkM + 4 * rr;
         if (j32 < NPASS && lrow < rows_left) {
             lse[m0 + lrow] = lse_n;
-            m_fs += lse_n;
-            m_cnt += 1.0;
+            if (!dfr) {
+                m_fs += lse_n;
+                m_cnt += 1.0;
+            }
         }
     }
     if (MSTATS) {
@@ -957,6 +983,105 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
     (void)Bp;
     (void)pair_i;
     (void)pair_k;
+    (void)rec_t;
+}
+
+// ---- deferred statistics of a data-truncation step (round 6) ------------------------------------------------------------
+// bsc_et.py:247-258 keeps the N_use datapoints with the largest evidence; which ones is known only after the E-step of
+// every rank.  The pass above therefore leaves, per datapoint, the non-zero list of E[s] and a record of PM_BSC_DEFER_LD
+// doubles [36 pair entries k (k + 1) / 2 + i of the candidates' second moments | sum_k q_k e_k (times ecoef) | pad]; this
+// kernel adds the records of the datapoints with lse >= *cut into `stats` exactly as the pass would have (Wq pair block
+// with global atomics, mus = qdiag through an LDS accumulator, the three scalars) and EMPTIES the lists of the others, so
+// that the sparse product behind it skips them (a dropped datapoint whose list had overflowed gets a zero dense row).
+// Two flat, coalesced sweeps -- one thread per record double, then one per list slot: 100 MB at N = 200k, no dependent
+// loads beyond the datapoint's log-evidence (a wavefront per datapoint walking record after record took 0.10 ms).
+__global__ __launch_bounds__(256) void bsc_defer_apply_kernel(
+    const double *__restrict__ lse, const double *__restrict__ cut_dev, const int32_t *__restrict__ cand,
+    const double *__restrict__ rec, uint16_t *__restrict__ nz_idx, const double *__restrict__ nz_val,
+    double *__restrict__ expect, int64_t lde, double *__restrict__ stats, int64_t N, int H, int Dstats, double ecoef) {
+    __shared__ double s_mus[256];
+    __shared__ double s_red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_mus[tid] = 0.0;
+    __syncthreads();
+    double cut = cut_dev[0];
+    // log(2^-1075): the reference's un-stabilised evidence sums are exactly 0 there and `all_denoms >= 0` keeps every
+    // datapoint (bsc_et.py:253)
+    if (cut < -745.1332191019412) cut = -INFINITY;
+    double *wq = stats + pm_bsc_stats_offset_wq_dev(H, Dstats);
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + tid;
+    double sig = 0.0, fs = 0.0, cnt = 0.0;
+    // (a) the records: entry e = k (k + 1) / 2 + i < 36 is the pair (i, k) of candidate positions, i <= k (diagonal
+    // entries are zero: E[s_h^2] = E[s_h] goes through qdiag); entry 36 the datapoint's sum q e; the thread of pad entry 37
+    // takes the datapoint's log-evidence and count
+    for (int64_t t = t0; t < N * PM_BSC_DEFER_LD; t += stride) {
+        const int64_t n = t / PM_BSC_DEFER_LD;
+        const int e = (int)(t - n * PM_BSC_DEFER_LD);
+        const int ec = e < PAIR_ENTRIES ? e : 0;
+        const int pk = (ec >= 1) + (ec >= 3) + (ec >= 6) + (ec >= 10) + (ec >= 15) + (ec >= 21) + (ec >= 28);
+        const int pi = ec - pk * (pk + 1) / 2;
+        // (all four loads leave before any of them is looked at: a dropped datapoint's record is read for nothing, but no
+        // load waits for another)
+        const double l = lse[n];
+        const double v = rec[t];
+        const int ci = cand[n * 8 + pi], ck = cand[n * 8 + pk];
+        if (e > PAIR_ENTRIES + 1 || !(l >= cut)) continue;
+        if (e < PAIR_ENTRIES) {
+            if (v != 0.0) {
+                const int lo = ci < ck ? ci : ck, hi = ci < ck ? ck : ci;
+                pm_atomic_add(wq + (int64_t)lo * H + hi, PM_Q(v, 0));
+            }
+        } else if (e == PAIR_ENTRIES) {
+            sig += v;
+        } else {
+            fs += l;
+            cnt += 1.0;
+        }
+    }
+    // (b) the lists: slot j of datapoint n (the sixteen slots of a datapoint sit in one wavefront: all of them read slot 0
+    // before any of them rewrites it)
+    for (int64_t t = t0; t < N * PM_BSC_NZ_MAX; t += stride) {
+        const int64_t n = t / PM_BSC_NZ_MAX;
+        const int j = (int)(t - n * PM_BSC_NZ_MAX);
+        const double l = lse[n];
+        const bool over = nz_idx[n * PM_BSC_NZ_MAX] == PM_BSC_NZ_OVERFLOW;
+        const unsigned h = nz_idx[t];
+        const double v = nz_val[t];
+        if (!(l >= cut)) {
+            nz_idx[t] = 0xFFFFu;
+            if (over)
+                for (int hh = j; hh < H; hh += PM_BSC_NZ_MAX) expect[n * lde + hh] = 0.0;
+        } else if (!over) {
+            if (h != 0xFFFFu) atomicAdd(&s_mus[h], PM_Q(v, 0));
+        } else {
+            for (int hh = j; hh < H; hh += PM_BSC_NZ_MAX) {
+                const double w = expect[n * lde + hh];
+                if (w != 0.0) atomicAdd(&s_mus[hh], PM_Q(w, 0));
+            }
+        }
+    }
+    sig = pm_wave_sum(sig);
+    fs = pm_wave_sum(fs);
+    cnt = pm_wave_sum(cnt);
+    if (lane == 0) {
+        s_red[0][wave] = sig;
+        s_red[1][wave] = fs;
+        s_red[2][wave] = cnt;
+    }
+    __syncthreads();
+    double *sc = stats + pm_bsc_stats_offset_scalars_dev(H, Dstats);
+    if (tid < 3) {
+        double v = (s_red[tid][0] + s_red[tid][1]) + (s_red[tid][2] + s_red[tid][3]);
+        if (tid == 0) v /= ecoef;
+        if (v != 0.0) pm_atomic_add(sc + tid, PM_Q(v, tid == 0 ? 1 : tid == 1 ? 2 : 0));    // sum q e | sum lse | count
+    }
+    if (tid < H) {
+        const double v = s_mus[tid];
+        if (v != 0.0) {
+            pm_atomic_add(stats + pm_bsc_stats_offset_mus_dev(H, Dstats) + tid, v);
+            pm_atomic_add(stats + pm_bsc_stats_offset_qdiag_dev(H, Dstats) + tid, v);
+        }
+    }
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1025,6 +1150,36 @@ extern "C" int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const do
                                           int64_t Hprime, int mode, int32_t *cand, double *logpj, int64_t ldl,
                                           double *lse, double *expect, int64_t lde, double *stats, int64_t D_stats,
                                           uint16_t *nz_idx, double *nz_val, int part, void *stream) {
+    return pm_bsc_estep_fused8_defer_f64(Y, ldy, Wt, ldw, gram, ynorm2, wmu, ymu, state_masks, state_parents,
+                                         size_offsets_host, S, gamma, params_host, N, D, H, Hprime, mode, cand, logpj, ldl,
+                                         lse, expect, lde, stats, D_stats, nz_idx, nz_val, nullptr, part, stream);
+}
+
+extern "C" int pm_bsc_defer_apply_f64(const double *lse, const double *cut, const int32_t *cand, const double *records,
+                                      uint16_t *nz_idx, const double *nz_val, double *expect, int64_t lde, double *stats,
+                                      const pm_bsc_estep_params *params_host, int64_t N, int64_t H, int64_t D,
+                                      int64_t Hprime, void *stream) {
+    if (!lse || !cut || !cand || !records || !nz_idx || !nz_val || !expect || !stats || !params_host || N < 0 || lde < H)
+        return PM_EINVAL;
+    if (H <= 0 || H > 256 || Hprime != 8 || D <= 0 || params_host->ecoef == 0.0) return PM_ERANGE;
+    if (N == 0) return PM_OK;
+    int64_t blocks = (N * PM_BSC_DEFER_LD + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bsc_defer_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), lse,
+                       cut, cand, records, nz_idx, nz_val, expect, lde, stats, N, (int)H, (int)D, params_host->ecoef);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_bsc_estep_fused8_defer_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw,
+                                             const double *gram, const double *ynorm2, const double *wmu,
+                                             const double *ymu, const uint16_t *state_masks,
+                                             const uint16_t *state_parents, const int32_t *size_offsets_host, int64_t S,
+                                             int64_t gamma, const pm_bsc_estep_params *params_host, int64_t N, int64_t D,
+                                             int64_t H, int64_t Hprime, int mode, int32_t *cand, double *logpj,
+                                             int64_t ldl, double *lse, double *expect, int64_t lde, double *stats,
+                                             int64_t D_stats, uint16_t *nz_idx, double *nz_val, double *records, int part,
+                                             void *stream) {
+    if (records && !nz_idx) return PM_EINVAL;
     if ((nz_idx == nullptr) != (nz_val == nullptr) || (nz_idx && !stats)) return PM_EINVAL;
     if (!Y || !Wt || !gram || !ynorm2 || !cand || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || ldy < D ||
         ldw < D || !(mode & 3) || ((wmu == nullptr) != (ymu == nullptr)) || part < 0 || part > 2)
@@ -1053,7 +1208,7 @@ extern "C" int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const do
                            dim3((T) ? THREADS : 1024), (SH), s, Y, ldy,                                                \
                            Wt, ldw, (int)D, gram, ynorm2, wmu, ymu, state_masks, state_parents, P, (int64_t)(NN),    \
                            (int)H, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, (int64_t)(R0),      \
-                           nz_idx, nz_val);                                                                            \
+                           nz_idx, nz_val, records);                                                                   \
     } while (0)
 #define PM_LAUNCH8ST(G, F, T, GRID, SH, NN, R0)            \
     do {                                                    \

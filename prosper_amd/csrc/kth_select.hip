@@ -96,6 +96,132 @@ __global__ __launch_bounds__(256) void kth_scan_kernel(unsigned long long *__res
     }
 }
 
+// ---- round 6: the scan folded into the NEXT round's histogram kernel -------------------------------------------------------
+// A select used to be 6 x (histogram, scan) + a conversion = 13 launches of a few microseconds of work each: 0.17 ms of a
+// data-truncation step once that step had no other host round trip left.  Every workgroup of round r now first repeats the
+// scan of round r - 1 for itself (the all-reduced histogram of 4096 bins and the state it started from: ~2 us, the same
+// answer in every workgroup), workgroup 0 records the result for the round after, and the histograms of the six rounds are
+// six separate buffers zeroed by ONE fill: 1 + 6 + 1 launches.
+__device__ __forceinline__ void kth_scan_block(const unsigned long long *__restrict__ hist,
+                                               const unsigned long long *__restrict__ state_in, int shift, int bits,
+                                               unsigned long long *s_chunk, int *s_pick, unsigned long long *s_out) {
+    const int nb = 1 << bits, per = (nb + 255) / 256;
+    const int t = threadIdx.x;
+    unsigned long long mine[BINS / 256];
+    unsigned long long sum = 0;
+    for (int q = 0; q < per; ++q) {
+        const int b = t * per + q;
+        mine[q] = (b < nb) ? hist[b] : 0ull;
+        sum += mine[q];
+    }
+    s_chunk[t] = sum;
+    __syncthreads();
+    const unsigned long long k = state_in[1];
+    if (t < 64) {
+        // suffix sums of the 256 chunk totals, four chunks per lane + a wavefront scan (not 256 dependent LDS reads)
+        const unsigned long long c0 = s_chunk[4 * t], c1 = s_chunk[4 * t + 1], c2 = s_chunk[4 * t + 2], c3 = s_chunk[4 * t + 3];
+        unsigned long long tot = c0 + c1 + c2 + c3, suf = tot;             // inclusive suffix over lanes >= t
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_down(suf, off);
+            if (t + off < 64) suf += o;
+        }
+        const unsigned long long above_lane = suf - tot;                   // chunks of lanes > t
+        // the HIGHEST chunk c with above(c) + chunk[c] >= k (above(c): everything in higher chunks); chunk 0 if none --
+        // exactly the sequential scan of kth_scan_kernel
+        unsigned long long above = above_lane, my_above = 0;
+        int myq = -1;
+        const unsigned long long cs[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
+            if (myq < 0 && above + cs[q] >= k) {
+                myq = q;
+                my_above = above;
+            }
+            above += cs[q];
+        }
+        const unsigned long long bal = __ballot(myq >= 0);
+        if (bal) {
+            const int top = 63 - __builtin_clzll(bal);
+            if (t == top) {
+                *s_pick = 4 * t + myq;
+                s_out[1] = my_above;
+            }
+        } else if (t == 0) {
+            *s_pick = 0;
+            s_out[1] = above - c0;
+        }
+    }
+    __syncthreads();
+    if (t == *s_pick) {
+        unsigned long long above = s_out[1];
+        int q = per - 1;
+        for (; q > 0; --q) {
+            if (above + mine[q] >= k) break;
+            above += mine[q];
+        }
+        const unsigned long long d = (unsigned long long)(t * per + q);
+        s_out[0] = state_in[0] | (d << shift);
+        s_out[1] = k - above;
+    }
+    __syncthreads();
+}
+
+// states: 7 slots of (prefix, k); slot 0 = (0, k) from the caller, slot r = the state after the scan of round r - 1.
+// hists: 6 x BINS, zero on entry of round 0.  Round r: scan hists[r - 1] (r > 0), then histogram this round's digit.
+__global__ __launch_bounds__(256) void kth_round_kernel(const double *__restrict__ x, int64_t n,
+                                                         unsigned long long *__restrict__ states,
+                                                         unsigned long long *__restrict__ hists, int round,
+                                                         int shift_prev, int bits_prev, int shift, int bits) {
+    __shared__ unsigned int s_h[BINS];
+    __shared__ unsigned long long s_chunk[256];
+    __shared__ int s_pick;
+    __shared__ unsigned long long s_state[2];
+    for (int b = threadIdx.x; b < BINS; b += 256) s_h[b] = 0;
+    if (threadIdx.x == 0) s_pick = 0;
+    if (round > 0) {
+        kth_scan_block(hists + (size_t)(round - 1) * BINS, states + 2 * (round - 1), shift_prev, bits_prev, s_chunk, &s_pick,
+                       s_state);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            states[2 * round] = s_state[0];
+            states[2 * round + 1] = s_state[1];
+        }
+    } else {
+        if (threadIdx.x < 2) s_state[threadIdx.x] = states[threadIdx.x];
+        __syncthreads();
+    }
+    const int top = shift + bits;                     // bits [top, 64) are decided
+    const uint64_t prefix = s_state[0];
+    const uint64_t mask = (1ull << bits) - 1;
+    unsigned long long *hist = hists + (size_t)round * BINS;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t k = key_of(x[i]);
+        const bool match = (top >= 64) || ((k >> top) == (prefix >> top));
+        if (match) atomicAdd(&s_h[(k >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < BINS; b += 256) {
+        const unsigned int c = s_h[b];
+        if (c) atomicAdd(&hist[b], (unsigned long long)c);
+    }
+}
+
+// the last round's scan and the conversion back to a double
+__global__ __launch_bounds__(256) void kth_final_kernel(unsigned long long *__restrict__ states,
+                                                         const unsigned long long *__restrict__ hists, int rounds,
+                                                         int shift_prev, int bits_prev, double *__restrict__ out) {
+    __shared__ unsigned long long s_chunk[256];
+    __shared__ int s_pick;
+    __shared__ unsigned long long s_state[2];
+    if (threadIdx.x == 0) s_pick = 0;
+    kth_scan_block(hists + (size_t)(rounds - 1) * BINS, states + 2 * (rounds - 1), shift_prev, bits_prev, s_chunk, &s_pick,
+                   s_state);
+    if (threadIdx.x == 0) {
+        states[2 * rounds] = s_state[0];
+        states[2 * rounds + 1] = s_state[1];
+        out[0] = value_of(s_state[0]);
+    }
+}
+
 __global__ void kth_value_kernel(const unsigned long long *__restrict__ state, double *__restrict__ out) {
     out[0] = value_of(state[0]);
 }
@@ -127,5 +253,31 @@ extern "C" int pm_kth_value_f64(const uint64_t *state, double *out, void *stream
     if (!state || !out) return PM_EINVAL;
     hipLaunchKernelGGL(kth_value_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const unsigned long long *>(state), out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_kth_round_f64(const double *x, int64_t n, uint64_t *states, uint64_t *hists, int round, int shift_prev,
+                                int bits_prev, int shift, int bits, void *stream) {
+    if (n < 0 || !states || !hists || round < 0 || round > 5 || shift < 0 || bits < 1 || bits > 12 || shift + bits > 64 ||
+        (n > 0 && !x) || (round > 0 && (shift_prev < 0 || bits_prev < 1 || bits_prev > 12 || shift_prev + bits_prev > 64)))
+        return PM_EINVAL;
+    // (an empty shard still walks the rounds: workgroup 0 carries the state forward for the ranks that hold data)
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kth_round_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n,
+                       reinterpret_cast<unsigned long long *>(states), reinterpret_cast<unsigned long long *>(hists), round,
+                       shift_prev, bits_prev, shift, bits);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_kth_final_f64(uint64_t *states, const uint64_t *hists, int rounds, int shift_prev, int bits_prev, double *out,
+                                void *stream) {
+    if (!states || !hists || !out || rounds < 1 || rounds > 6 || shift_prev < 0 || bits_prev < 1 || bits_prev > 12 ||
+        shift_prev + bits_prev > 64)
+        return PM_EINVAL;
+    hipLaunchKernelGGL(kth_final_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<unsigned long long *>(states), reinterpret_cast<const unsigned long long *>(hists),
+                       rounds, shift_prev, bits_prev, out);
     return (int)hipGetLastError();
 }

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void ns_residual_kernel(const double *__restri
                                                           double *__restrict__ full, double *__restrict__ R,
                                                           double *__restrict__ L, double *__restrict__ partial,
                                                           int64_t stride_in, int64_t stride_x, int64_t stride_full,
-                                                          int64_t stride_work, unsigned general_mask) {
+                                                          int64_t stride_work, unsigned general_mask,
+                                                          double *__restrict__ rowabs) {
     __shared__ double s_t[4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.y * NS_T, j0 = blockIdx.x * NS_T;
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void ns_residual_kernel(const double *__restri
     R += blockIdx.z * stride_work;
     L += blockIdx.z * stride_work;
     partial += blockIdx.z * stride_work;
+    if (rowabs) rowabs += blockIdx.z * stride_work;
     if (full) {   // this tile of the assembled matrix: one element per thread
         const int i = i0 + (threadIdx.x >> 4), j = j0 + (threadIdx.x & 15);
         if (i < n && j < n) {
@@ -275,16 +277,60 @@ __global__ __launch_bounds__(256) void ns_residual_kernel(const double *__restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = i0 + (lane >> 4) + 4 * r;
-        if (i < n && j < n) {
+        const bool in = i < n && j < n;
+        if (in) {
             const double v = (i == j ? 1.0 : 0.0) - t[r];
             R[(int64_t)i * ld + j] = v;
             L[(int64_t)j * ld + i] = v;
             sq += v * v;
         }
+        if (rowabs) {       // this tile's share of sum_j |(A X0)_ij| (ns_scale_kernel: ||A X0||_inf bounds the spectral radius)
+            double ra = in ? fabs(t[r]) : 0.0;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) ra += __shfl_xor(ra, off);
+            if ((lane & 15) == 0 && i < n) rowabs[(int64_t)blockIdx.x * n + i] = ra;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
     if (lane == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+}
+
+// The LONG warm path (pm_spd_inverse_warm_long_f64): a start X0 whose residual is not small -- the second-moment matrix
+// of a data-truncation step whose kept set jumped, a temperature step -- still converges once it is SCALED: A and X0 are
+// symmetric positive definite, so A X0 has real positive eigenvalues, all <= ||A X0||_inf; with alpha = 1 / ||A X0||_inf the
+// residual I - alpha A X0 has its spectrum in [0, 1) and Newton-Schulz converges from ANY such start, quadratically once
+// below ~0.5: (1 - 1/x)^(2^k) for x = ||A X0||_inf / lambda_min(A X0).  Every workgroup derives alpha from the residual
+// kernel's row sums in the same fixed order, then rescales its tile: X' = alpha X0, R' = I - alpha A X0 = alpha R + (1 - alpha) I.
+__global__ __launch_bounds__(256) void ns_scale_kernel(const double *__restrict__ X0, int64_t stride_x0,
+                                                       double *__restrict__ Xs, double *__restrict__ R,
+                                                       double *__restrict__ L, const double *__restrict__ rowabs, int n,
+                                                       int tiles, int64_t ld, int64_t stride_work) {
+    __shared__ double s_m[256];
+    const int tid = threadIdx.x;
+    X0 += blockIdx.z * stride_x0;
+    Xs += blockIdx.z * stride_work;
+    R += blockIdx.z * stride_work;
+    L += blockIdx.z * stride_work;
+    rowabs += blockIdx.z * stride_work;
+    double rs = 0.0;
+    if (tid < n)
+        for (int t = 0; t < tiles; ++t) rs += rowabs[(int64_t)t * n + tid];
+    s_m[tid] = rs;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) s_m[tid] = fmax(s_m[tid], s_m[tid + off]);
+        __syncthreads();
+    }
+    const double nrm = s_m[0];
+    const double alpha = (nrm > 0.0 && nrm < INFINITY) ? 1.0 / nrm : 1.0;      // (NaN / inf: the guard rejects the result)
+    const int i = blockIdx.y * NS_T + (tid >> 4), j = blockIdx.x * NS_T + (tid & 15);
+    if (i < n && j < n) {
+        const double r = alpha * R[(int64_t)i * ld + j] + (i == j ? 1.0 - alpha : 0.0);
+        R[(int64_t)i * ld + j] = r;
+        L[(int64_t)j * ld + i] = r;
+        Xs[(int64_t)i * ld + j] = alpha * X0[(int64_t)i * ld + j];
+    }
 }
 
 // Xn = X + X R,  Rn = R R (= L^T R),  Ln = Rn^T  (LAST: only Xn)
@@ -293,7 +339,7 @@ __global__ __launch_bounds__(256) void ns_step_kernel(const double *__restrict__
                                                       const double *__restrict__ L, int n, int64_t ld,
                                                       double *__restrict__ Xn, double *__restrict__ Rn,
                                                       double *__restrict__ Ln, int64_t stride_x, int64_t stride_work,
-                                                      unsigned general_mask) {
+                                                      unsigned general_mask, double *__restrict__ partial_out) {
     __shared__ double s_t[2][4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.y * NS_T, j0 = blockIdx.x * NS_T;
@@ -319,6 +365,7 @@ __global__ __launch_bounds__(256) void ns_step_kernel(const double *__restrict__
     __syncthreads();
     if (wave != 0) return;
     const int j = j0 + (lane & 15);
+    double sq = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = i0 + (lane >> 4) + 4 * r;
@@ -329,8 +376,14 @@ __global__ __launch_bounds__(256) void ns_step_kernel(const double *__restrict__
                 const double v = ((s_t[1][0][r][lane] + s_t[1][1][r][lane]) + s_t[1][2][r][lane]) + s_t[1][3][r][lane];
                 Rn[(int64_t)i * ld + j] = v;
                 Ln[(int64_t)j * ld + i] = v;
+                sq += v * v;
             }
         }
+    }
+    if (!LAST && partial_out) {      // ||R_k||_F^2 of the LAST residual formed: what the guard of the result reads
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+        if (lane == 0) partial_out[blockIdx.z * stride_work + blockIdx.y * gridDim.x + blockIdx.x] = sq;
     }
 }
 
@@ -347,24 +400,37 @@ __global__ __launch_bounds__(256) void ns_finish_kernel(const double *__restrict
                                                         int64_t stride_in, const double *__restrict__ diag_add,
                                                         double *__restrict__ inv, int64_t ldo, int64_t stride_out,
                                                         double *__restrict__ pivots, double *__restrict__ accepted,
-                                                        int64_t accepted_stride, unsigned general_mask) {
+                                                        int64_t accepted_stride, unsigned general_mask,
+                                                        const double *__restrict__ partial0) {
     __shared__ double s_g[NMAX], s_lo[NMAX], s_hi[NMAX];
-    __shared__ int s_skip;
+    __shared__ int s_skip, s_small;
     const int tid = threadIdx.x;
     X += blockIdx.z * stride_x;
     partial += blockIdx.z * stride_x;
+    partial0 += blockIdx.z * stride_x;
     s_g[tid] = tid < n_partial ? partial[tid] : 0.0;
+    s_lo[tid] = tid < n_partial ? partial0[tid] : 0.0;
     __syncthreads();
     if (tid < 64) {
         double r2 = ((s_g[4 * tid] + s_g[4 * tid + 1]) + s_g[4 * tid + 2]) + s_g[4 * tid + 3];
+        double q2 = ((s_lo[4 * tid] + s_lo[4 * tid + 1]) + s_lo[4 * tid + 2]) + s_lo[4 * tid + 3];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
-        if (tid == 0) s_skip = (r2 < tol2) ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) {
+            r2 += __shfl_xor(r2, off);
+            q2 += __shfl_xor(q2, off);
+        }
+        if (tid == 0) {
+            s_skip = (r2 < tol2) ? 1 : 0;
+            s_small = (q2 < 1.0) ? 1 : 0;
+        }
     }
     __syncthreads();
-    // the decision itself, for the caller (the last word of this matrix's `work`): 1 = the refinement stands (inv is exact
-    // to rounding), 0 = the sweep behind this kernel computes inv (exact to cond(A) eps, as pm_spd_inverse_f64)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && accepted) accepted[blockIdx.z * accepted_stride] = s_skip ? 1.0 : 0.0;
+    // the decision itself, for the caller: 1 = the refinement stands (inv is exact to rounding) and the START residual was
+    // below 1 in the Frobenius norm (the short path would do next time too), 2 = it stands from a start further away (the
+    // long path's doing, or luck), 0 = the sweep behind this kernel computes inv (exact to cond(A) eps, as
+    // pm_spd_inverse_f64)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && accepted)
+        accepted[blockIdx.z * accepted_stride] = s_skip ? (s_small ? 1.0 : 2.0) : 0.0;
     if (!s_skip) return;
     const int i = blockIdx.y * NS_T + (tid >> 4), j = blockIdx.x * NS_T + (tid & 15);
     const bool gen = (general_mask >> blockIdx.z) & 1u;      // (a general matrix: X = (A^T)^-1 as it stands)
@@ -411,37 +477,56 @@ extern "C" int pm_spd_inverse_f64(const double *upper, int64_t ldu, const double
 
 extern "C" int64_t pm_spd_inverse_warm_work_len(int64_t n) {
     const int64_t tiles = (n + NS_T - 1) / NS_T;
-    return n > 0 ? 6 * n * n + tiles * tiles + 1 : 0;       // (+ 1: the accepted flag)
+    // (two (X, R, L) triples | the start residual's per-tile squares | the last residual's | row sums of |A X0| per tile
+    // column | the accepted flag)
+    return n > 0 ? 6 * n * n + 2 * tiles * tiles + tiles * n + 1 : 0;
 }
 
 static int launch_warm(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add, int64_t n,
                        const double *prev_inv, int64_t stride_prev, double *work, double *full, double *inv,
                        int64_t stride_out, double *pivots, int64_t batch, hipStream_t s, unsigned general_mask = 0u,
-                       double *accepted = nullptr) {
+                       double *accepted = nullptr, int nfull = 3, bool scaled = false) {
     const int tiles = (int)((n + NS_T - 1) / NS_T);
     const int64_t nn = n * n, wl = pm_spd_inverse_warm_work_len(n);
-    // work, per matrix: two (X, R, L) triples, then the residual's per-tile sums of squares
+    // work, per matrix: two (X, R, L) triples, then the per-tile sums of squares of the start residual and of the last one
+    // formed, the row sums of |A X0|, the accepted flag
     double *X[2] = {work, work + 3 * nn}, *R[2] = {work + nn, work + 4 * nn}, *L[2] = {work + 2 * nn, work + 5 * nn};
-    double *partial = work + 6 * nn;
+    double *partial0 = work + 6 * nn, *partial = partial0 + tiles * tiles, *rowabs = partial + tiles * tiles;
     const dim3 grid((unsigned)tiles, (unsigned)tiles, (unsigned)batch);
     hipLaunchKernelGGL(ns_residual_kernel, grid, dim3(256), 0, s, upper, ldu, diag_add, prev_inv, (int)n, n, full, R[0], L[0],
-                       partial, stride_in, stride_prev, stride_out, wl, general_mask);
-    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, prev_inv, (const double *)R[0], (const double *)L[0],
-                       (int)n, n, X[1], R[1], L[1], stride_prev, wl, general_mask);
-    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
-                       (const double *)L[1], (int)n, n, X[0], R[0], L[0], wl, wl, general_mask);
-    // a fourth step (residual R0^16 < 1e-16 for every start the guard accepts): the refined inverse is then exact to
-    // rounding and the caller's solve needs no refinement pass of its own (two H x H x D products saved per EM step)
-    hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, (const double *)X[0], (const double *)R[0],
-                       (const double *)L[0], (int)n, n, X[1], R[1], L[1], wl, wl, general_mask);
-    hipLaunchKernelGGL(ns_step_kernel<true>, grid, dim3(256), 0, s, (const double *)X[1], (const double *)R[1],
-                       (const double *)L[1], (int)n, n, X[0], (double *)nullptr, (double *)nullptr, wl, wl, general_mask);
-    hipLaunchKernelGGL(ns_finish_kernel, grid, dim3(256), 0, s, (const double *)X[0], (int)n, wl, (const double *)partial,
-                       tiles * tiles, 0.01, upper, ldu, stride_in, diag_add, inv, n, stride_out, pivots,
-                       accepted ? accepted : work + wl - 1, accepted ? (int64_t)1 : wl, general_mask);
+                       partial0, stride_in, stride_prev, stride_out, wl, general_mask, scaled ? rowabs : (double *)nullptr);
+    const double *Xsrc = prev_inv;
+    int64_t xstride = stride_prev;
+    if (scaled) {
+        hipLaunchKernelGGL(ns_scale_kernel, grid, dim3(256), 0, s, prev_inv, stride_prev, X[0], R[0], L[0],
+                           (const double *)rowabs, (int)n, tiles, n, wl);
+        Xsrc = X[0];
+        xstride = wl;
+    }
+    // nfull steps that also square the residual, then one that only updates X: the result's residual is R_nfull^2.  The
+    // guard reads ||R_nfull||_F < 1e-8 -- the LAST residual formed, not the start (round 6: on an annealing ramp the start
+    // residual is a few per cent in every direction, 0.3-0.7 in the Frobenius norm, and converges all the same) -- so the
+    // refined inverse is exact to rounding whenever it is accepted and the caller's solve needs no refinement pass of its
+    // own (two H x H x D products saved per EM step).  Three + one steps: every start with ||R_0||_2 < 0.075.
+    int b = 0;
+    for (int k = 0; k < nfull; ++k) {
+        hipLaunchKernelGGL(ns_step_kernel<false>, grid, dim3(256), 0, s, Xsrc, (const double *)R[b], (const double *)L[b],
+                           (int)n, n, X[1 - b], R[1 - b], L[1 - b], xstride, wl, general_mask,
+                           k == nfull - 1 ? partial : (double *)nullptr);
+        Xsrc = X[1 - b];
+        xstride = wl;
+        b = 1 - b;
+    }
+    hipLaunchKernelGGL(ns_step_kernel<true>, grid, dim3(256), 0, s, Xsrc, (const double *)R[b], (const double *)L[b], (int)n,
+                       n, X[1 - b], (double *)nullptr, (double *)nullptr, xstride, wl, general_mask, (double *)nullptr);
+    const double *Xfin = X[1 - b];
+    hipLaunchKernelGGL(ns_finish_kernel, grid, dim3(256), 0, s, Xfin, (int)n, wl, (const double *)partial, tiles * tiles,
+                       1e-16, upper, ldu, stride_in, diag_add, inv, n, stride_out, pivots,
+                       accepted ? accepted : work + wl - 1, accepted ? (int64_t)1 : wl, general_mask,
+                       (const double *)partial0);
     hipLaunchKernelGGL(spd_inverse_kernel, dim3((unsigned)batch), dim3(1024), 0, s, upper, ldu, diag_add, (int)n,
-                       (double *)nullptr, inv, n, pivots, stride_in, stride_out, (const double *)partial, tiles * tiles, 0.01,
-                       (const double *)X[0], wl);
+                       (double *)nullptr, inv, n, pivots, stride_in, stride_out, (const double *)partial, tiles * tiles, 1e-16,
+                       Xfin, wl);
     return (int)hipGetLastError();
 }
 
@@ -453,6 +538,17 @@ extern "C" int pm_spd_inverse_warm_f64(const double *upper, int64_t ldu, const d
     if (ldp != n || ldo != n) return PM_EINVAL;          // the work matrices share one leading dimension with them
     return launch_warm(upper, ldu, 0, diag_add, n, prev_inv, 0, work, full, inv, 0, pivots, 1, static_cast<hipStream_t>(stream),
                        0u, pivots + 2);
+}
+
+extern "C" int pm_spd_inverse_warm_long_f64(const double *upper, int64_t ldu, const double *diag_add, int64_t n,
+                                            const double *prev_inv, int64_t ldp, double *work, double *full, double *inv,
+                                            int64_t ldo, double *pivots, void *stream) {
+    if (!upper || !inv || !prev_inv || !work || !full || !pivots || n <= 0 || ldu < n || ldo < n || ldp < n) return PM_EINVAL;
+    if (n > NMAX) return PM_ERANGE;
+    if (ldp != n || ldo != n) return PM_EINVAL;
+    // eight + one steps from the scaled start: (1 - 1/x)^256 < 1e-8 for x = ||A X0||_inf / lambda_min(A X0) up to ~14
+    return launch_warm(upper, ldu, 0, diag_add, n, prev_inv, 0, work, full, inv, 0, pivots, 1, static_cast<hipStream_t>(stream),
+                       0u, pivots + 2, 8, true);
 }
 
 extern "C" int pm_spd_inverse_warm_batch_f64(const double *upper, int64_t ldu, int64_t stride_in, const double *diag_add,

@@ -149,6 +149,25 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _AnnealAt(object):
+    """Read-only view of a schedule at another position (``LinearAnnealing.__getitem__`` reads ``cur_pos``,
+    annealing.py:90-107); ``pos`` None: the schedule as it stands (objects without a position, e.g. a plain mapping)."""
+
+    def __init__(self, anneal, pos):
+        self._a, self._pos = anneal, pos
+
+    def __getitem__(self, name):
+        a = self._a
+        if self._pos is None:
+            return a[name]
+        old = a.cur_pos
+        a.cur_pos = self._pos
+        try:
+            return a[name]
+        finally:
+            a.cur_pos = old
+
+
 class KernelTimer(object):
     """HIP-event timing of individual kernel launches on the stream they are enqueued on
     (torch's current stream, which is the one handed to the C ABI).  bench.py attaches one
@@ -258,6 +277,43 @@ class DeviceCAModel(CAModel):
             Y = res["Y"]
             b = res["det_bounds"] = ((float(Y.abs().max()), float(res["ynorm2"].max().sqrt())) if Y.shape[0] else (0.0, 0.0))
         return b
+
+    def _anneal_point(self, anneal):
+        """What of an annealing point decides the inputs of an E-step: temperature, prior annealing, truncation, partial
+        data, and the parameter noise of ``noisify_params`` (prosper/em/__init__.py:63-107)."""
+        return (anneal['T'], bool(anneal['anneal_prior']), anneal['Ncut_factor'], anneal['partial']) + \
+            tuple(anneal[p + '_noise'] for p in sorted(self.noise_policy))
+
+    def _predict_anneal(self, anneal):
+        """The annealing point of the NEXT ``step`` -- what the M-step launches the next E-step with (_speculate_estep) -- or
+        None when it is not known.  A schedule is a pure function of its position (annealing.py:90-107; ``next`` ignores the
+        gain and always accepts, :116-130), so for a ``LinearAnnealing`` it is read at ``cur_pos + 1``; but only a
+        predictor that was RIGHT about the current step is trusted (a caller that does not advance the schedule between
+        steps gets the flat predictor: same point again), nothing is predicted past the schedule's end, and a next step
+        with parameter noise or partial data has inputs nobody knows yet.  A wrong prediction costs a dropped pass, never a
+        wrong result (E_step compares the scalars the pass was launched with)."""
+        sig = self._anneal_point(anneal)
+        prev_sig, prev_peek = getattr(self, "_sig_hist", (None, None))
+        peek, end = None, False
+        cur, steps = getattr(anneal, "cur_pos", None), getattr(anneal, "steps", None)
+        if isinstance(cur, int) and isinstance(steps, int):
+            if cur + 1 >= steps:
+                end = True
+            else:
+                peek = _AnnealAt(anneal, cur + 1)
+        nxt = None
+        if not end:
+            if peek is not None and prev_peek is not None and sig == prev_peek:
+                nxt = peek
+            elif sig == prev_sig:
+                nxt = peek if (peek is not None and self._anneal_point(peek) == sig) else _AnnealAt(anneal, cur)
+        self._sig_hist = (sig, self._anneal_point(peek) if peek is not None else None)
+        self._flat_schedule = (sig == prev_sig)
+        if nxt is not None:
+            nsig = self._anneal_point(nxt)
+            if nsig[3] not in (0, 1) or any(nsig[4:]):
+                nxt = None
+        return nxt
 
     def step(self, anneal, model_params, my_data):
         """CAModel.step (camodels/__init__.py:163-193); the E-step knows that the M-step follows with the same arguments."""
@@ -654,9 +710,13 @@ class DeviceCAModel(CAModel):
         if warm:
             piv = status if status is not None else torch.empty(3, dtype=torch.float64, device=Wq_u.device)
             work = self._buf("spd_warm_work", (int(_lib.load().pm_spd_inverse_warm_work_len(H)),))
-            # (pivots[2] <- the device's own verdict on the warm start: 1 = refinement accepted, 0 = the sweep ran)
-            self._call("spd_inverse", "pm_spd_inverse_warm_f64", _ptr(Wq_u), H, _ptr(qdiag), H, _ptr(prev), H, _ptr(work),
-                       _ptr(Wq), _ptr(Winv), H, _ptr(piv), self._stream())
+            # (pivots[2] <- the device's own verdict on the warm start: 1 / 2 = refinement accepted, 0 = the sweep ran)
+            # The LONG form (scaled start, eight + one steps, ~60 us) where the start is likely to be far: the step after
+            # one whose start was (``_warm_long``: _solve_accurate), and data-truncation steps, whose kept set can jump
+            # (``_warm_force_long``, set by the model's M_step) -- the short form would hand those to the 0.3 ms sweep.
+            long = getattr(self, "_warm_long", False) or getattr(self, "_warm_force_long", False)
+            self._call("spd_inverse", "pm_spd_inverse_warm_long_f64" if long else "pm_spd_inverse_warm_f64", _ptr(Wq_u), H,
+                       _ptr(qdiag), H, _ptr(prev), H, _ptr(work), _ptr(Wq), _ptr(Winv), H, _ptr(piv), self._stream())
         else:
             if status is not None:
                 piv = status
@@ -752,6 +812,7 @@ class DeviceCAModel(CAModel):
         now from the sweep's inverse: X0 + Winv (rhs - Wq X0), exactly what the cold path returns."""
         last, self._last_solve = getattr(self, "_last_solve", None), None
         self._refine_next = (flag == 0.0)
+        self._warm_long = (flag != 1.0)       # (a far start this time: the scaled long form next time)
         if flag != 0.0 or last is None:
             return None
         Wq, Winv, rhs = last
@@ -823,19 +884,12 @@ class DeviceCAModel(CAModel):
         comm = self.comm
         lse = lse.contiguous()
         dev = lse.device
+        n = int(lse.shape[0])
+        if lse.is_cuda:
+            return float(self._kth_select_dev(lse, N_use).item())
         state = torch.zeros(2, dtype=torch.int64, device=dev)
         state[1] = int(N_use)
         hist = torch.zeros(4096, dtype=torch.int64, device=dev)
-        n = int(lse.shape[0])
-        if lse.is_cuda:
-            st = self._stream()
-            for shift, bits in self.KTH_ROUNDS:
-                self._call("kth_hist", "pm_kth_hist_f64", _ptr(lse) if n else None, n, _ptr(state), shift, bits, _ptr(hist), st)
-                comm.allreduce_device(hist)
-                self._call("kth_scan", "pm_kth_scan", _ptr(hist), _ptr(state), shift, bits, st)
-            out = torch.empty(1, dtype=torch.float64, device=dev)
-            self._call("kth_value", "pm_kth_value_f64", _ptr(state), _ptr(out), st)
-            return float(out.item())
         # host tensors (tests): the same rounds on the same 64-bit keys
         b = lse.view(torch.int64)
         key = torch.where(b < 0, ~b, b | torch.iinfo(torch.int64).min)          # order-preserving as UNSIGNED 64-bit
@@ -857,6 +911,33 @@ class DeviceCAModel(CAModel):
             k -= above
         bits64 = (prefix & np.uint64(0x7FFFFFFFFFFFFFFF)) if (prefix >> np.uint64(63)) else ~prefix
         return float(np.array([bits64], dtype=np.uint64).view(np.float64)[0])
+
+    def _kth_select_dev(self, lse, N_use):
+        """The radix select of ``_kth_largest_global`` on a device tensor, result LEFT ON THE DEVICE (one double): the
+        deferred statistics of a data-truncation step (pm_bsc_defer_apply_f64) read the cut from there, so the step has no
+        host round trip between its E-step pass and its M-step kernels."""
+        comm = self.comm
+        lse = lse.contiguous()
+        dev = lse.device
+        n = int(lse.shape[0])
+        # one buffer, one fill: [states: 7 x (prefix, k) | pad | 6 histograms of 4096 bins]; slot 0 <- (0, N_use)
+        buf = torch.zeros(16 + 6 * 4096, dtype=torch.int64, device=dev)
+        buf[1:2].fill_(int(N_use))
+        states, hists = buf[:14], buf[16:].view(6, 4096)
+        st = self._stream()
+        prev = (0, 1)
+        for r, (shift, bits) in enumerate(self.KTH_ROUNDS):
+            if r and comm.size > 1:
+                comm.allreduce_device(hists[r - 1])
+            self._call("kth_round", "pm_kth_round_f64", _ptr(lse) if n else None, n, _ptr(states), _ptr(hists), r, prev[0],
+                       prev[1], shift, bits, st)
+            prev = (shift, bits)
+        if comm.size > 1:
+            comm.allreduce_device(hists[len(self.KTH_ROUNDS) - 1])
+        out = torch.empty(1, dtype=torch.float64, device=dev)
+        self._call("kth_final", "pm_kth_final_f64", _ptr(states), _ptr(hists), len(self.KTH_ROUNDS), prev[0], prev[1],
+                   _ptr(out), st)
+        return out
 
     # ------------------------------------------------------------------ inference ("next" row, SURVEY 8f)
     def inference(self, anneal, model_params, test_data, topK=10, logprob=False, adaptive=True,

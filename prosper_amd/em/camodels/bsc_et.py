@@ -50,12 +50,14 @@ class BSC_ET(DeviceCAModel):
         self.speculate = os.environ.get('PM_SPECULATE', '1') == '1'
         self._in_step = False
         self._spec_estep = None  # next step's E-step, launched by the M-step (_speculate_estep)
-        self._anneal_sig = None  # annealing point of the previous step() (speculate only on a flat schedule)
+        self._next_anneal = None  # the NEXT step's annealing point as predicted in step() (_predict_anneal), or None
         self._flat_schedule = False
         self.spec_hits = 0
         self.speculate_estep = os.environ.get('PM_SPECULATE_ESTEP', '1') == '1'
         # plain attributes (the tests flip them to compare code paths; no environment switches):
         self.fuse_mstats = True      # M-step row statistics inside the fused E-step pass
+        self.defer_stats = True      # data-truncation steps: the E-step pass leaves per-datapoint records, added after the cut
+                                     # is known (pm_bsc_defer_apply_f64) -- no second pass over the log-joints
         self.sparse_wp = True        # Wp = E[s]^T Y from the non-zero lists of E[s] (pm_bsc_wp_sparse_f64); the dense product
                                      # still runs -- decided on the device -- when a list overflowed
         self.use_fused = True        # scores GEMM + select + E-step as ONE kernel (bsc_fused8.hip / bsc_fused.hip)
@@ -223,9 +225,10 @@ class BSC_ET(DeviceCAModel):
         main = N // rnd * rnd
         return N if (N - main) * 10 >= rnd * 7 else main
 
-    def _fused_estep(self, res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats=None):
+    def _fused_estep(self, res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats=None, defer=False):
         """``mstats`` = (expect (N,H), stats): also produce the per-datapoint M-step statistics of the rows the fused
-        kernel takes (E_step inside ``step`` with no data truncation ahead)."""
+        kernel takes (E_step inside ``step``).  ``defer`` (a data-truncation step ahead): as per-datapoint records that
+        ``M_step`` adds once the cut is known, instead of accumulating them."""
         tab = self._state_tables()
         Y8, W8 = self._k8(res, "Y8", res["Y"]), self._k8(par, "Wt8", par["Wt"])
         N, H, Hp, S = Y8.shape[0], self.H, self.Hprime, self.no_states
@@ -261,6 +264,11 @@ class BSC_ET(DeviceCAModel):
                 entry = "pm_bsc_estep_fused8_nz_f64"
                 # ("listed": the pass stores the dense E[s] row of a datapoint only when its list overflowed)
                 self._nz = {"idx": nz[0], "val": nz[1], "stats": mstats[1], "rows": N, "dense_rows": "overflowed"}
+                if defer:
+                    rec = self._buf("defer_rec", (N, 40))              # PM_BSC_DEFER_LD
+                    args = args + (_ptr(rec),)
+                    entry = "pm_bsc_estep_fused8_defer_f64"
+                    self._nz["defer"] = rec
             if main_rows > 0:
                 self._call("estep_fused", entry, *(args + (1, self._stream())))
             if main_rows < main:
@@ -309,7 +317,8 @@ class BSC_ET(DeviceCAModel):
         """Datapoints one ``scores_gemm`` launch covers (bench.py's roofline accounting)."""
         return N if self._whole_shard(N) else min(N, self._chunk_rows(N))
 
-    def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None, mstats=None):
+    def _run_select_estep(self, res, par, mode, cand, P=None, wmu=None, ymu=None, logpj=None, lse=None, mstats=None,
+                          defer=False):
         """Scores GEMM + fused select/E-step kernel.  Whole-shard mode: the scores of all rows, then ONE pass of
         the row kernel.  Chunked mode (``chunk_rounds`` / shards beyond ``max_chunk_rows``): a chunk is a whole
         number of rounds of resident GEMM tiles; its (chunk, H) score block is consumed by the row kernel
@@ -317,7 +326,7 @@ class BSC_ET(DeviceCAModel):
         matters (one round per chunk 2.27 ms, whole shard 2.15 ms per pass at config 2).
         ``overlap``: GEMM of chunk c+1 on a side stream while the row kernel of chunk c runs."""
         if self._fused():
-            return self._fused_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats)
+            return self._fused_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats, defer)
         Y = res["Y"]
         N, H, Hp, S = Y.shape[0], self.H, self.Hprime, self.no_states
         tab = self._state_tables()
@@ -422,9 +431,7 @@ class BSC_ET(DeviceCAModel):
         """CAModel.step (camodels/__init__.py:163-193); E_step knows that M_step follows with the same arguments."""
         self._in_step = True
         self._par.pop("checked", None)        # the first look at W in every step is a full comparison (_same_W)
-        sig = (anneal['T'], bool(anneal['anneal_prior']), anneal['Ncut_factor'], anneal['partial'])
-        self._flat_schedule = (sig == self._anneal_sig)      # same annealing point as the previous step
-        self._anneal_sig = sig
+        self._next_anneal = self._predict_anneal(anneal)
         try:
             return DeviceCAModel.step(self, anneal, model_params, my_data)
         finally:
@@ -490,6 +497,10 @@ class BSC_ET(DeviceCAModel):
         if cand is None:      # selection + log-joints in one pass
             cand = torch.empty((N, Hp), dtype=torch.int32, device=self.device)
             mode = 3
+        defer = (want_ms == "defer")
+        if defer and not (self.defer_stats and self.sparse_wp and N and self._fused() and self._tile8_whole_shard()
+                          and self._fused_rows(N) == N):
+            want_ms = False           # (no deferred form on this path: the M-step runs its own pass behind the cut)
         mstats, rows = None, 0
         # (deterministic mode: the quanta of the statistics derive from W's column norms -- a pass whose W^T exists only on the
         # device so far, the M-step's speculative launch, carries no statistics; the M-step's own pass forms them then)
@@ -508,7 +519,7 @@ class BSC_ET(DeviceCAModel):
         self._nz = None
         self._qd_done = False
         if N:
-            rows = self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats)
+            rows = self._run_select_estep(res, par, mode, cand, P, wmu, ymu, logpj, lse, mstats, defer and mstats is not None)
         out = DeviceArray(logpj)
         out.lse = lse
         out.cand = cand
@@ -517,6 +528,14 @@ class BSC_ET(DeviceCAModel):
                           "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm), "nz": self._nz, "qd_done": self._qd_done}
         self._nz = None
         return out
+
+    def _want_ms(self, anneal):
+        """Which M-step statistics the E-step pass inside ``step`` carries: True -- accumulated in the pass (no data
+        truncation ahead); "defer" -- left as per-datapoint records that M_step adds once the cut is known
+        (``Ncut_factor > 0``: 49 of the 50 steps of the reference's schedules, bars-learning.py:77-80); False -- none."""
+        if anneal['Ncut_factor'] <= 0.0:
+            return True
+        return "defer" if self.defer_stats else False
 
     def _speculate_estep(self, res, par, anneal, pies, sigma):
         """Called by the M-step as soon as its scalar statistics are on the host, while the device still solves for
@@ -527,7 +546,7 @@ class BSC_ET(DeviceCAModel):
         if not (np.isfinite(pies) and np.isfinite(sigma) and 0.0 < pies < 1.0 and sigma > 0.0):
             return
         P = self._estep_params(anneal, pies, sigma, np.zeros(1))
-        want_ms = anneal['Ncut_factor'] <= 0.0
+        want_ms = self._want_ms(anneal)
         out = self._launch_estep(res, par, P, None, None, None, want_ms)
         self._spec_estep = {"par": par, "res": res, "want_ms": want_ms, "out": out,
                             "P": (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm)}
@@ -557,7 +576,7 @@ class BSC_ET(DeviceCAModel):
             # inside CAModel.step with no data truncation ahead the M-step's per-datapoint statistics are produced by
             # the same pass (fused kernel): posterior weights from the exponentials the log-sum-exp evaluates anyway, no
             # second pass over the 665 MB of log-joints
-            want_ms = self._in_step and anneal['Ncut_factor'] <= 0.0
+            want_ms = self._in_step and self._want_ms(anneal)
             sp, self._spec_estep = self._spec_estep, None
             if (sp is not None and fuse and sp["par"] is par and sp["res"] is res and sp["want_ms"] == want_ms
                     and sp["P"] == (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm) and not np.any(mu64)):
@@ -629,13 +648,8 @@ class BSC_ET(DeviceCAModel):
         E_pi_gamma = pies * H * A_pi_gamma / B_pi_gamma
 
         # data truncation (bsc_et.py:247-258): keep the N_use datapoints with the largest evidence
-        lse_cut = float("-inf")
-        if anneal['Ncut_factor'] > 0.0:
-            tracing.tracepoint("M_step:truncating")
-            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
-            lse_cut = self._kth_largest_global(lse, N_use)
-            if lse_cut < -745.1332191019412:     # log(2^-1075): the reference's un-stabilised evidence sums are exactly
-                lse_cut = float("-inf")          # 0 there, and `all_denoms >= 0` keeps every datapoint (bsc_et.py:253)
+        ncut = anneal['Ncut_factor'] > 0.0
+        N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor'])) if ncut else N
 
         # per-datapoint statistics + Wp GEMM into the packed buffer
         tracing.tracepoint("M_step:iterating")
@@ -656,9 +670,32 @@ class BSC_ET(DeviceCAModel):
             stats = self._buf("stats%d" % self._stats_flip, (n_stats + (D if 'mu' in self.to_learn else 0),))[:n_stats]
         self._ws["stats"] = stats                     # (the workspace of THIS M-step, for tools and tests)
         done, nz = 0, None
-        if (ms is not None and ms["res"] is res and ms["stats"] is stats and ms["expect"] is expect and ms["cand"] is cand
-                and ms["P"] == (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm) and lse_cut == float("-inf")
-                and tab["fast"]):
+        mine = (ms is not None and ms["res"] is res and ms["stats"] is stats and ms["expect"] is expect and ms["cand"] is cand
+                and ms["P"] == (P.pil_bar, P.ecoef, P.prior_scale, P.mu_sqnorm) and tab["fast"])
+        rec = ms["nz"].get("defer") if (mine and ms.get("nz")) else None
+        lse_cut = float("-inf")
+        if ncut and rec is None:
+            tracing.tracepoint("M_step:truncating")
+            lse_cut = self._kth_largest_global(lse, N_use)
+            if lse_cut < -745.1332191019412:     # log(2^-1075): the reference's un-stabilised evidence sums are exactly
+                lse_cut = float("-inf")          # 0 there, and `all_denoms >= 0` keeps every datapoint (bsc_et.py:253)
+        if mine and rec is not None:
+            # The E-step pass has left every datapoint's statistics as a record beside its non-zero list (a data-truncation
+            # step: _want_ms): the cut is selected ON THE DEVICE and stays there, pm_bsc_defer_apply_f64 adds the records of
+            # the datapoints above it and empties the lists of the others -- no host round trip, no second pass over the
+            # 665 MB of log-joints (round 6; pm_bsc_mstep_rows16_nz_f64 before: 0.42 ms + a device idle for the cut)
+            tracing.tracepoint("M_step:truncating")
+            if ncut:
+                cut_dev = self._kth_select_dev(lse, N_use)
+            else:
+                cut_dev = torch.full((1,), float("-inf"), dtype=torch.float64, device=lse.device)
+            done = ms["rows"]
+            nz = ms["nz"]
+            logpj.mstats = None
+            assert done == my_N and ms.get("qd_done")
+            self._call("defer_apply", "pm_bsc_defer_apply_f64", _ptr(lse), _ptr(cut_dev), _ptr(cand), _ptr(rec),
+                       _ptr(nz["idx"]), _ptr(nz["val"]), _ptr(expect), H, _ptr(stats), ctypes.byref(P), my_N, H, D, Hp, st)
+        elif mine and lse_cut == float("-inf"):
             done = ms["rows"]
             nz = ms.get("nz")
             logpj.mstats = None
@@ -728,6 +765,7 @@ class BSC_ET(DeviceCAModel):
         else:
             packed = stats
 
+        self._warm_force_long = ncut      # (the kept set of a truncation step can jump: the inverse's scaled warm start)
         # the exchange of the step (replaces bsc_et.py:225,258,266,373,374,387,417,426,427)
         comm.allreduce_device(packed)
         return self._finalize(packed, model_params, A_pi_gamma, E_pi_gamma, res, None, anneal)
@@ -781,12 +819,14 @@ class BSC_ET(DeviceCAModel):
 
         head = packed[o_mus:o_sc + 4]             # [mus (H) | 4 scalars], contiguous in the packed buffer; summed on the host
         Wq = rhs = seed = None
-        # A plain EM loop on a flat annealing schedule: the scalar statistics travel to the host AHEAD of the W solve, so
-        # pi_new / sigma_new are known while the device still inverts Wq, and the next step's E-step is enqueued right
-        # behind the solve (_speculate_estep) -- the device never waits for the host between two EM steps.
+        # A plain EM loop whose next annealing point is known (_predict_anneal: a flat schedule, or a LinearAnnealing that
+        # moved as predicted last step): the scalar statistics travel to the host AHEAD of the W solve, so pi_new / sigma_new
+        # are known while the device still inverts Wq, and the next step's E-step is enqueued right behind the solve
+        # (_speculate_estep) -- the device never waits for the host between two EM steps.
         early = None
         if (packed.is_cuda and res is not None and anneal is not None and learn_W and not learn_mu and not np.any(mu)
-                and self._in_step and self._flat_schedule and self._spec_ok and self.speculate and self.speculate_estep
+                and self._in_step and self._next_anneal is not None and self._spec_ok and self.speculate
+                and self.speculate_estep
                 and self._state_tables()["fast"] and self._fused()):
             early = self._download_async(head, slot="mstep_early")
         # The download buffer [mus | scalars | status (3) + pad | X (H,D) | data sums (D)]: the inverse writes its status and
@@ -830,7 +870,7 @@ class BSC_ET(DeviceCAModel):
                 if early is not None:
                     early[1].synchronize()
                     _, _, _, _, pi_e, sigma_e = self._scalar_updates(early[0], pies, sigma, E_pi_gamma)
-                    self._speculate_estep(res, spec[0], anneal, pi_e, sigma_e)
+                    self._speculate_estep(res, spec[0], self._next_anneal, pi_e, sigma_e)
             # (under speculation the head has already travelled: `body` then starts behind it)
             body = self._download(flat if early is None else flat[n_head:], slot="mstep", then=then if seed is not None else None)
             base = 0 if early is None else n_head

@@ -135,7 +135,7 @@ class GSC(DeviceCAModel):
         self.spec_hits = 0
         self.inverse_fallbacks = 0    # EM steps whose device inverses were rejected (host LAPACK took over, speculation void)
         self._in_step = False
-        self._anneal_sig = None
+        self._next_anneal = None     # the next step's annealing point (_predict_anneal), or None
         self._flat_schedule = False
         # True: E_step returns its statistics and leaves my_data['y'] / ['candidates'] in the reference's cluster order
         # (gsc_et.py:572-573) instead of datapoint order -- for callers that walk my_data['data_clusters'] alongside them
@@ -440,9 +440,7 @@ class GSC(DeviceCAModel):
     def step(self, anneal, model_params, my_data):
         """CAModel.step; M_step knows that an E_step of the next EM step is likely to follow."""
         self._in_step = True
-        sig = (anneal['T'], anneal['partial'])
-        self._flat_schedule = (sig == self._anneal_sig)      # same annealing point as the previous step
-        self._anneal_sig = sig
+        self._next_anneal = self._predict_anneal(anneal)     # (round 6: across a temperature ramp too, not only a flat schedule)
         try:
             return DeviceCAModel.step(self, anneal, model_params, my_data)
         finally:
@@ -842,9 +840,9 @@ class GSC(DeviceCAModel):
             else:
                 A = self._gemm_nt(Y, Wt_next, self._buf("scores_spec", (my_N, H)), "scores_gemm")
             self._seed = {"ykey": res["key"], "Wt": Wt_next, "G": fin["G"], "A": A, "W_host": None}
-            if self._in_step and self._flat_schedule:
+            if self._in_step and self._next_anneal is not None:
                 fin["out"] = self._launch_estep(res, A, fin["G"], fin["psi"], res["ynorm2"], fin["tdev"], 0.0,
-                                                anneal['T'], None, lists=True, zeros=zeros)
+                                                self._next_anneal['T'], None, lists=True, zeros=zeros)
 
         if packed.is_cuda:
             n_down = o_par + n_par if fin is not None else (o_par if Wt_next is not None else
@@ -869,7 +867,7 @@ class GSC(DeviceCAModel):
             piv, acc = tail[2 * nHH:2 * nHH + 4], tail[2 * nHH + 4:]
             # (a rejected start of the general matrix leaves only the inverse of its upper-mirrored stand-in: host then)
             good = np.isfinite(tail).all() and piv[0] > 0 and piv[2] > 0 and piv[0] / piv[1] > 1e-12 \
-                and piv[2] / piv[3] > 1e-12 and acc[1] == 1.0
+                and piv[2] / piv[3] > 1e-12 and acc[1] != 0.0
             if good:        # well-conditioned: use the device inverses; else LAPACK on the host as upstream
                 inverses = (tail[nHH:2 * nHH].reshape(H, H).T, tail[:nHH].reshape(H, H))    # (zz^-1, (ss + eps I)^-1)
         if inverses is None:
@@ -903,7 +901,7 @@ class GSC(DeviceCAModel):
             # snapshots serve the speculative E-step's check)
             self._dev_params = (whole[o_par:o_par + n_par], snap)
             if fin["out"] is not None:
-                self._spec = {"res": res, "T": anneal['T'], "out": fin["out"], "params": snap}
+                self._spec = {"res": res, "T": self._next_anneal['T'], "out": fin["out"], "params": snap}
             return model_params
         sum_xpt_ss = host[o:o + nHH].reshape(H, H).copy()
         sum_xpt_szsz = host[o + nHH:o + 2 * nHH].reshape(H, H).copy()

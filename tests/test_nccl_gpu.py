@@ -122,3 +122,52 @@ def test_kth_largest_kernels_match_sort(dev, n):
         got, want = float(out.item()), float(np.sort(x)[-k])
         assert got == want and np.signbit(got) == np.signbit(want), (k, got, want)
         assert int(hist.abs().sum()) == 0          # cleared for the next use
+
+
+@pytest.mark.parametrize("n", [1, 5, 1000, 70001, 200000])
+def test_kth_select_with_folded_scans_matches_sort(dev, n):
+    """pm_kth_round_f64 / pm_kth_final_f64 (round 6: every round's kernel repeats the previous round's scan in each
+    workgroup -- 1 + 6 + 1 launches, the value stays on the device): two 'ranks' histogram into the same per-round table
+    (what the all-reduce amounts to; the second shard's call repeats the scan of a table that is complete by then only for
+    the FIRST shard's round -- so the shards take turns round by round through two state/histogram sets, summed by hand),
+    incl. duplicates, +-0, -inf and denormals; and the host-level entry ``_kth_select_dev`` on one shard."""
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels._device import DeviceCAModel
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    rng = np.random.RandomState(n)
+    x = np.concatenate([rng.normal(size=n) * 50 - 600.0, [-np.inf, 0.0, -0.0, 1e-310, -1e-310, 3.5, 3.5]])
+    rng.shuffle(x)
+    cut = len(x) // 3
+    shards = [torch.from_numpy(x[:cut].copy()).to(dev), torch.from_numpy(x[cut:].copy()).to(dev)]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    R = DeviceCAModel.KTH_ROUNDS
+    m = BSC_ET(8, 4, 2, 2)
+    whole = torch.from_numpy(x).to(dev)
+    for k in sorted({1, 2, len(x) // 2, len(x) - 1, len(x)}):
+        want = float(np.sort(x)[-k])
+        # two ranks: each has its own buffer; the "all-reduce" adds the round's histograms before the next round reads them
+        bufs = [torch.zeros(16 + 6 * 4096, dtype=torch.int64, device=dev) for _ in shards]
+        for b in bufs:
+            b[1] = k
+        prev = (0, 1)
+        for r, (shift, bits) in enumerate(R):
+            if r:
+                tot = bufs[0][16:].view(6, 4096)[r - 1] + bufs[1][16:].view(6, 4096)[r - 1]
+                for b in bufs:
+                    b[16:].view(6, 4096)[r - 1] = tot
+            for sh, b in zip(shards, bufs):
+                _lib.call("pm_kth_round_f64", _p(sh) if sh.numel() else None, sh.numel(), _p(b[:14]), _p(b[16:]), r, prev[0],
+                          prev[1], shift, bits, st)
+            prev = (shift, bits)
+        tot = bufs[0][16:].view(6, 4096)[5] + bufs[1][16:].view(6, 4096)[5]
+        outs = []
+        for b in bufs:
+            b[16:].view(6, 4096)[5] = tot
+            out = torch.empty(1, dtype=torch.float64, device=dev)
+            _lib.call("pm_kth_final_f64", _p(b[:14]), _p(b[16:]), 6, prev[0], prev[1], _p(out), st)
+            outs.append(float(out.item()))
+        # (np.sort leaves +0.0 and -0.0, which compare equal, in either order: the sign is checked away from zero only)
+        assert outs[0] == outs[1] == want and (want == 0 or np.signbit(outs[0]) == np.signbit(want)), (k, outs, want)
+        got = float(m._kth_select_dev(whole, k).item())
+        assert got == want and (want == 0 or np.signbit(got) == np.signbit(want)), (k, got, want)
+        assert m._kth_largest_global(whole, k) == want
