@@ -498,6 +498,25 @@ int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const double *wno
                             const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
                             int64_t Hprime, double *logpj, int64_t ldl, double *lse1, double *lseb,
                             double *q1, int64_t ldq, double *stats, void *stream);
+/* DEFERRED statistics for a data-truncation step (mca_et.py:248-262 keeps the N_use datapoints with the largest
+ * log-denominator of the annealed weights; which ones is known only after every rank's E-step).
+ * pm_mca_estep_mstats_defer_f64 is pm_mca_estep_mstats_f64 that, given `defer_rec` (N x Hprime x D doubles) and
+ * `defer_sc` (N x 4), accumulates NOTHING into `stats`: per datapoint it leaves the Aid block of mca_et.py:309 (row j = its
+ * j-th candidate: what it would have added to Wq, and times y to Wp) in defer_rec, [sum q |s|, sum q e, log sum exp(logpj), -]
+ * in defer_sc, and the singleton posteriors in q1 as always.  Both NULL: exactly pm_mca_estep_mstats_f64.
+ * pm_mca_defer_apply_f64 then adds the records of the datapoints with lseb[n] >= *cut (a DEVICE double: the radix
+ * select's result never visits the host) into `stats` -- what the in-pass statistics of the kept datapoints would have been
+ * (mca_et.py:274-327) -- and zeroes the q1 rows of the others, so that the G1 = q1^T Y product behind it
+ * (pm_gemm_tn_acc_f64) sees kept datapoints only.  H, D <= 512, Hprime <= 12. */
+int pm_mca_estep_mstats_defer_f64(const double *scores, int64_t lds, const double *wnorm2, const double *ynorm2,
+                                  const double *Y, int64_t ldy, const double *Wrho, const double *Wrm1,
+                                  const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                                  const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
+                                  double *logpj, int64_t ldl, double *lse1, double *lseb, double *q1, int64_t ldq,
+                                  double *stats, double *defer_rec, double *defer_sc, void *stream);
+int pm_mca_defer_apply_f64(const double *lseb, const double *cut, const double *Y, int64_t ldy, const int32_t *cand,
+                           const double *records, const double *scalars, double *q1, int64_t ldq, double *stats,
+                           int64_t N, int64_t H, int64_t D, int64_t Hprime, void *stream);
 /* The per-step tables of the MCA / MMCA kernels from W^T (H x D, already clamped by check_params): tabs = [ W^T | sign(W) |W|^rho |
  * |W|^(rho-1) ] (three H x D planes; mca_et.py:218-227, mmca_et.py:250-260 compute them with NumPy on the host) and
  * wnorm2[h] = |W_h|^2.  The caller keeps the reference's assertions (finite logarithms, W^rho > 1e-86) on its host copy. */

@@ -42,6 +42,9 @@ __host__ __device__ static inline int64_t mca_stats_base(int64_t H, int64_t D) {
 #define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates, 4 T sums from candidate 0 only, 5 no wave reduction, 6 no exponential, 7 no states at all (S = 0)
 #endif
 
+// the fused pass's root / power table area: pm_load_root21 / pm_load_root6 (A/B builds) or pm_load_upow (any rho)
+#define PM_FUSED_RT_LEN (PM_ROOT21_LEN + 1)      // (>= PM_UPOW_AB_LEN; NOT larger: four workgroups of two wavefronts fill a CU's LDS to within 1.6 KB at config 5)
+
 namespace {
 
 __device__ __forceinline__ void wave_sync_lds() {
@@ -332,17 +335,24 @@ __global__ __launch_bounds__(256) void mca_estep_kernel(const double *__restrict
 
 // ROOT = 21: rho = 21 (every temperature T <= 1.05, unsigned W): the states' power through pm_pow_m20_21 (no log / exp);
 // ROOT = 6: rho = 6 (MMCA at every T <= 1.2): pm_pow_m5_6; ROOT = 0: any rho, the table power
-template <int DPL, int HP, bool SIGNED, int ROOT>      // ROOT: 21 / 6 = the log / exp-free powers of those rho, 0 = the table power
-__global__ __launch_bounds__(256, (HP <= 8 && DPL <= 4 && ROOT == 0 && !(SIGNED && HP * DPL >= 24) ? 2 : 1))     // (the table power at H' <= 8, D <= 256 would take 258 registers: keep two wavefronts per SIMD; the others fit uncapped, and schedule better so; signed W with >= 24 KB of rows per wavefront runs one per SIMD anyway)
-void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
+// (The body is a device function shared by two kernels: mca_estep_fused_kernel keeps the argument list it had before the
+// deferred form existed -- two more pointer arguments alone moved the rho = 21 instantiation from 202 to 235 registers and
+// from 6.6 to 7.7 ms --, mca_estep_fused_defer_kernel adds the record pointers.)
+template <int DPL, int HP, bool SIGNED, int ROOT, bool DEFER>      // ROOT: 21 / 6 = the log / exp-free powers of those rho, 0 = the uniform-exponent power; DEFER: statistics as per-datapoint records
+__device__ __forceinline__ void mca_estep_fused_body(const double *__restrict__ scores, int64_t lds,
                                        const double *__restrict__ wnorm2, const double *__restrict__ ynorm2,
                                        const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
                                        const double *__restrict__ Wrm1, const int32_t *__restrict__ cand,
                                        const uint16_t *__restrict__ masks, int S, pm_mca_params P, int64_t N, int H,
                                        int D, int Hp, double *__restrict__ logpj, int64_t ldl,
                                        double *__restrict__ lse1, double *__restrict__ lseb,
-                                       double *__restrict__ q1, int64_t ldq, double *__restrict__ stats) {
+                                       double *__restrict__ q1, int64_t ldq, double *__restrict__ stats,
+                                       double *__restrict__ defer_rec, double *__restrict__ defer_sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // DEFERRED statistics (defer_rec given; round 6): a data-truncation step (mca_et.py:248-262) keeps the N_use datapoints
+    // with the largest log-denominator, known only once every rank's E-step is through -- the pass then ACCUMULATES NOTHING:
+    // it leaves each datapoint's Aid block (Hp x D, what it would have scattered into Wq; times y into Wp) in defer_rec, its
+    // three scalars in defer_sc, its singleton posteriors in q1 as always, and mca_defer_apply_kernel adds the kept ones.
     // [ power tables (PM_POWTAB_LEN) | root table (PM_ROOT21_LEN) | q1sum (H) | red (4 * waves) | per wave: wr (HP*DS)
     //   [wm (HP*DS)] e (S) ]
     constexpr int DS = 64 * DPL;
@@ -350,8 +360,15 @@ void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *s_tab = reinterpret_cast<double *>(smem);
     double *s_rt = s_tab + PM_POWTAB_LEN;
-    double *s_q1sum = s_rt + PM_ROOT21_LEN + 1;          // (+ 1: 16-byte alignment of what follows stays as it was)
-    pm_load_powtab(s_tab, tid, blockDim.x);
+    double *s_q1sum = s_rt + PM_FUSED_RT_LEN;            // (an even number of doubles: 16-byte alignment of what follows)
+    if (ROOT == 0) {
+        // any other rho (every step of an annealing ramp): the tables of THIS launch's exponent 1 / rho - 1 (pm_pow_uni) --
+        // its (r_i, r_i^-c) pairs take the place of pm_pow_tab's (r_i, L_i) in the power table, pm_exp_tab's E_j stay
+        for (int i = 256 + tid; i < PM_POWTAB_LEN; i += blockDim.x) s_tab[i] = pm_powtab_dev[i];
+        pm_load_upow(s_tab, s_rt, pm_powtab_dev, P.inv_rho - 1.0, tid, blockDim.x);
+    } else {
+        pm_load_powtab(s_tab, tid, blockDim.x);
+    }
     if (!PM_POW_HWSEED && ROOT == 21) pm_load_root21(s_rt, pm_powtab_dev, tid, blockDim.x);  // (the table seed's tables: A/B builds)
     if (!PM_POW_HWSEED && ROOT == 6) pm_load_root6(s_rt, pm_powtab_dev, tid, blockDim.x);
     double *s_red = s_q1sum + H;
@@ -477,7 +494,7 @@ void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
                 const double aT = SIGNED ? fabs(T[i]) : T[i];      // (unsigned W: T is a sum of W^rho >= 0)
                 const double r = (PM_MCA_ABL == 2) ? aT * 0.37
                                  : (ROOT == 21 ? pm_pow_m20_21(aT, s_rt) : ROOT == 6 ? pm_pow_m5_6(aT, s_rt)
-                                                                                 : pm_pow_tab(aT, P.inv_rho - 1.0, s_tab));
+                                                                                 : pm_pow_uni(aT, s_tab, s_rt));
                 const double wb = (aT > 0.0) ? aT * r : 0.0;
                 const double df = (SIGNED ? copysign(wb, T[i]) : wb) - y[i];
                 part = fma(df, df, part);
@@ -746,6 +763,7 @@ void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
 
         // ---- M-step statistics of this datapoint (mca_et.py:274-327) ----
         double *qrow = q1 + n * ldq;
+        if constexpr (!DEFER) {
         if (lane == 0) {
             st_sigma += exp(P.beta * f0 - lb) * yn;
             st_ld += l1;
@@ -768,8 +786,51 @@ void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
             st_pi += q * ns;
             st_sigma += q * ((fs - P.pil_bar * ns) / P.pre1);
         }
+        }
         const double g = exp(M - lb);                   // <= 1: every multi-cause beta*f_s is <= lb
-        if (S > 0 && g != 0.0) {
+        if constexpr (DEFER) {
+            // this datapoint's share of sum q |s| and sum q e (lane partials -> one record), its Aid block as it stands
+            double r_pi = 0.0, r_sigma = 0.0;
+            if (lane == 0) r_sigma += exp(P.beta * f0 - lb) * yn;
+            for (int h = lane; h < H; h += 64) {
+                const double e = wnorm2[h] - 2.0 * arow[h] + yn;
+                const double q = exp(P.beta * (P.pil_bar + P.pre1 * e) - lb);
+                if (q != 0.0) {
+                    r_sigma += q * e;
+                    r_pi += q;
+                }
+                qrow[h] = q;
+            }
+            for (int s = lane; s < S; s += 64) {
+                const double fs = s_e[s];
+                const double q = exp(P.beta * fs - lb);
+                const double ns = (double)__builtin_popcount((unsigned)masks[s]);
+                r_pi += q * ns;
+                r_sigma += q * ((fs - P.pil_bar * ns) / P.pre1);
+            }
+            r_pi = pm_wave_sum(r_pi);
+            r_sigma = pm_wave_sum(r_sigma);
+            if (lane == 0) {
+                double *sc_n = defer_sc + 4 * n;
+                sc_n[0] = r_pi;
+                sc_n[1] = r_sigma;
+                sc_n[2] = l1;
+                sc_n[3] = 0.0;
+            }
+            double *rn = defer_rec + n * (int64_t)Hp * D;
+#pragma unroll
+            for (int j = 0; j < HP; ++j) {
+                if (j < Hp) {
+                    const int64_t base = (int64_t)cn[j] * D;
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) {
+                        const int d = lane + 64 * i;
+                        if (d < D) rn[j * D + d] = (S > 0 && g != 0.0) ? (SIGNED ? V[j][i] * g : V[j][i] * g * Wrm1[base + d]) : 0.0;
+                    }
+                }
+            }
+        }
+        if (!DEFER && S > 0 && g != 0.0) {
 #pragma unroll
             for (int j = 0; j < HP; ++j) {
                 if (j < Hp) {
@@ -813,6 +874,33 @@ void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
         const double v = s_q1sum[h];
         if (v != 0.0) pm_atomic_add(g_q1sum + h, v);
     }
+}
+
+#define PM_MCA_FUSED_BOUNDS __launch_bounds__(256, (HP <= 8 && DPL <= 4 && ROOT == 0 && !(SIGNED && HP * DPL >= 24) ? 2 : 1))     // (the table power at H' <= 8, D <= 256 would take 258 registers: keep two wavefronts per SIMD; the others fit uncapped, and schedule better so; signed W with >= 24 KB of rows per wavefront runs one per SIMD anyway)
+template <int DPL, int HP, bool SIGNED, int ROOT>
+__global__ PM_MCA_FUSED_BOUNDS void mca_estep_fused_kernel(const double *__restrict__ scores, int64_t lds,
+                                       const double *__restrict__ wnorm2, const double *__restrict__ ynorm2,
+                                       const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
+                                       const double *__restrict__ Wrm1, const int32_t *__restrict__ cand,
+                                       const uint16_t *__restrict__ masks, int S, pm_mca_params P, int64_t N, int H,
+                                       int D, int Hp, double *__restrict__ logpj, int64_t ldl,
+                                       double *__restrict__ lse1, double *__restrict__ lseb,
+                                       double *__restrict__ q1, int64_t ldq, double *__restrict__ stats) {
+    mca_estep_fused_body<DPL, HP, SIGNED, ROOT, false>(scores, lds, wnorm2, ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H,
+                                                       D, Hp, logpj, ldl, lse1, lseb, q1, ldq, stats, nullptr, nullptr);
+}
+template <int DPL, int HP, bool SIGNED, int ROOT>
+__global__ PM_MCA_FUSED_BOUNDS void mca_estep_fused_defer_kernel(const double *__restrict__ scores, int64_t lds,
+                                       const double *__restrict__ wnorm2, const double *__restrict__ ynorm2,
+                                       const double *__restrict__ Y, int64_t ldy, const double *__restrict__ Wrho,
+                                       const double *__restrict__ Wrm1, const int32_t *__restrict__ cand,
+                                       const uint16_t *__restrict__ masks, int S, pm_mca_params P, int64_t N, int H,
+                                       int D, int Hp, double *__restrict__ logpj, int64_t ldl,
+                                       double *__restrict__ lse1, double *__restrict__ lseb,
+                                       double *__restrict__ q1, int64_t ldq, double *__restrict__ stats,
+                                       double *__restrict__ defer_rec, double *__restrict__ defer_sc) {
+    mca_estep_fused_body<DPL, HP, SIGNED, ROOT, true>(scores, lds, wnorm2, ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H,
+                                                      D, Hp, logpj, ldl, lse1, lseb, q1, ldq, stats, defer_rec, defer_sc);
 }
 
 // (A variant with TWO wavefronts per datapoint -- the observed dimensions split between them, four wavefronts per SIMD --
@@ -1217,50 +1305,73 @@ int launch_fused_hp(int Hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, 
                     const double *wnorm2, const double *ynorm2, const double *Y, int64_t ldy, const double *Wrho,
                     const double *Wrm1, const int32_t *cand, const uint16_t *masks, int S, pm_mca_params P, int64_t N,
                     int H, int D, double *logpj, int64_t ldl, double *lse1, double *lseb, double *q1, int64_t ldq,
-                    double *stats) {
+                    double *stats, double *defer_rec, double *defer_sc) {
     const int hp = Hp <= 4 ? 4 : Hp <= 8 ? 8 : 12;
-    // rho = 21 (T <= 1.05: mca_et.py:142 clamps the temperature there), unsigned W: the log / exp-free power
-#ifdef PM_MCA_NO_ROOT21
-    const bool rho21 = false;
-#else
+    // Round 6: EVERY rho takes the uniform-exponent power (pm_pow_uni, ROOT = 0) -- 6.45 ms against 6.74 for the log / exp-free
+    // rho = 21 power at config 5 (scratch/mca_T_sweep.py), MMCA's rho = 6 likewise; -DPM_MCA_ROOT21 / -DPM_MCA_ROOT6 bring the
+    // special powers back (A/B builds).
+#ifdef PM_MCA_ROOT21
     const bool rho21 = !SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
-#endif
-    // rho = 6 (MMCA at T <= 1.2, mmca_et.py:37): pm_pow_m5_6
-#ifdef PM_MCA_NO_ROOT6          // (A/B builds: scratch/mca_ab.sh)
-    const bool rho6 = false;
 #else
-    const bool rho6 = SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 6.0) < 1e-9;
+    const bool rho21 = false;
 #endif
-#define PM_CASE(HPV)                                                                                                  \
-    case HPV: {                                                                                                       \
-        if (rho21) {                                                                                                  \
-            if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, false, 21>), shmem)) \
+#ifdef PM_MCA_ROOT6
+    const bool rho6 = SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 6.0) < 1e-9;
+#else
+    const bool rho6 = false;
+#endif
+#define PM_LAUNCH_F(HPV, SG, RT, DF)                                                                                  \
+    do {                                                                                                              \
+        if (DF) {                                                                                                     \
+            if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_defer_kernel<DPL, HPV, SG, RT>), shmem)) \
                 return e;                                                                                             \
-            hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, false, 21>), grid, block, shmem, s, scores, lds, wnorm2, \
-                               ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, \
-                               ldq, stats);                                                                           \
-            return (int)hipGetLastError();                                                                            \
-        }                                                                                                             \
-        if (rho6) {                                                                                                   \
-            if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, true, 6>), shmem)) \
+            hipLaunchKernelGGL((mca_estep_fused_defer_kernel<DPL, HPV, SG, RT>), grid, block, shmem, s, scores, lds, wnorm2, \
+                               ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, ldq, \
+                               stats, defer_rec, defer_sc);                                                           \
+        } else {                                                                                                      \
+            if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, SG, RT>), shmem)) \
                 return e;                                                                                             \
-            hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, true, 6>), grid, block, shmem, s, scores, lds, wnorm2, \
-                               ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, \
-                               ldq, stats);                                                                           \
-            return (int)hipGetLastError();                                                                            \
+            hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, SG, RT>), grid, block, shmem, s, scores, lds, wnorm2, \
+                               ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, ldq, \
+                               stats);                                                                                \
         }                                                                                                             \
-        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_estep_fused_kernel<DPL, HPV, SIGNED, 0>), shmem)) \
-            return e;                                                                                                 \
-        hipLaunchKernelGGL((mca_estep_fused_kernel<DPL, HPV, SIGNED, 0>), grid, block, shmem, s, scores, lds, wnorm2, \
-                           ynorm2, Y, ldy, Wrho, Wrm1, cand, masks, S, P, N, H, D, Hp, logpj, ldl, lse1, lseb, q1, ldq, \
-                           stats);                                                                                    \
         return (int)hipGetLastError();                                                                                \
+    } while (0)
+#ifdef PM_MCA_ROOT21
+#define PM_CASE21(HPV)                                                \
+    if (rho21) {                                                      \
+        if (defer_rec) PM_LAUNCH_F(HPV, false, 21, true);             \
+        PM_LAUNCH_F(HPV, false, 21, false);                           \
+    }
+#else
+#define PM_CASE21(HPV)
+#endif
+#ifdef PM_MCA_ROOT6
+#define PM_CASE6(HPV)                                                 \
+    if (rho6) {                                                       \
+        if (defer_rec) PM_LAUNCH_F(HPV, true, 6, true);               \
+        PM_LAUNCH_F(HPV, true, 6, false);                             \
+    }
+#else
+#define PM_CASE6(HPV)
+#endif
+#define PM_CASE(HPV)                                                  \
+    case HPV: {                                                       \
+        PM_CASE21(HPV)                                                \
+        PM_CASE6(HPV)                                                 \
+        if (defer_rec) PM_LAUNCH_F(HPV, SIGNED, 0, true);             \
+        PM_LAUNCH_F(HPV, SIGNED, 0, false);                           \
     }
     switch (hp) {
         PM_CASE(4) PM_CASE(8) PM_CASE(12)
         default: return PM_ERANGE;
     }
 #undef PM_CASE
+#undef PM_CASE21
+#undef PM_CASE6
+#undef PM_LAUNCH_F
+    (void)rho21;
+    (void)rho6;
 }
 }  // namespace
 
@@ -1270,6 +1381,186 @@ extern "C" int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const 
                                        const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
                                        int64_t Hprime, double *logpj, int64_t ldl, double *lse1, double *lseb,
                                        double *q1, int64_t ldq, double *stats, void *stream) {
+    return pm_mca_estep_mstats_defer_f64(scores, lds, wnorm2, ynorm2, Y, ldy, Wrho, Wrm1, cand, state_masks, S, params_host, N,
+                                         H, D, Hprime, logpj, ldl, lse1, lseb, q1, ldq, stats, nullptr, nullptr, stream);
+}
+
+namespace {
+// The deferred statistics of a data-truncation step (mca_estep_fused_kernel<.., DEFER = true>), added once the cut is known
+// (mca_et.py:250-258: the stabilised log-denominators of the annealed weights; the cut is a DEVICE double, the radix
+// select's result never visits the host).  Two kernels:
+//  * mca_defer_q1_kernel, one wavefront per datapoint: the q1 row of a dropped datapoint is zeroed (the G1 = q1^T Y product
+//    behind sees kept datapoints only), a kept one's goes into q1sum (register accumulators: a lane owns latents lane,
+//    lane + 64, ...) and its three scalars into the sums;
+//  * mca_defer_scatter_kernel: Wq[c_j, d] += Aid[j, d], Wp[c_j, d] += Aid[j, d] y_d over the kept datapoints.  Global f64
+//    atomics sustain ~0.1 T/s on this chip -- 2 H' D of them per datapoint took 2.7 ms at config 5 (the first form of this
+//    kernel) -- so a workgroup of sixteen wavefronts owns a slice of SW observed dimensions for 1/G of the datapoints,
+//    accumulates the H x SW slices of Wp and Wq in LDS (ds_add_f64; 128 KB) and flushes them once: 2 H D atomics per
+//    workgroup instead of per datapoint.  Bound by reading the records once (N_use H' D doubles).
+__global__ __launch_bounds__(256) void mca_defer_q1_kernel(const double *__restrict__ lseb, const double *__restrict__ cut_dev,
+                                                            const double *__restrict__ sc_in, double *__restrict__ q1,
+                                                            int64_t ldq, double *__restrict__ stats, int64_t N, int H, int D) {
+    __shared__ double s_q1sum[512];
+    __shared__ double s_red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int h = tid; h < 512; h += 256) s_q1sum[h] = 0.0;
+    __syncthreads();
+    const double cut = cut_dev[0];
+    double st_pi = 0.0, st_sigma = 0.0, st_ld = 0.0, st_cnt = 0.0;
+    double qs[8];                                  // H <= 512: latents lane + 64 i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qs[i] = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        double *qrow = q1 + n * ldq;
+        if (!(lseb[n] >= cut)) {
+            for (int h = lane; h < H; h += 64) qrow[h] = 0.0;
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int h = lane + 64 * i;
+            if (h < H) qs[i] += PM_Q(qrow[h], 2);
+        }
+        if (lane == 0) {
+            const double *sc_n = sc_in + 4 * n;
+            st_pi += sc_n[0];
+            st_sigma += sc_n[1];
+            st_ld += sc_n[2];
+            st_cnt += 1.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int h = lane + 64 * i;
+        if (h < H && qs[i] != 0.0) atomicAdd(&s_q1sum[h], qs[i]);
+    }
+    if (lane == 0) {
+        s_red[wave][0] = st_pi;
+        s_red[wave][1] = st_sigma;
+        s_red[wave][2] = st_ld;
+        s_red[wave][3] = st_cnt;
+    }
+    __syncthreads();
+    double *g_q1sum = stats + 3 * (int64_t)H * D;
+    double *sc = g_q1sum + H;
+    if (tid < 4) {
+        const double v = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        if (v != 0.0) pm_atomic_add(sc + tid, PM_Q(v, tid == 1 ? 3 : tid == 2 ? 4 : 2));    // pi | sum q e | sum lse | count
+    }
+    for (int h = tid; h < H; h += 256) {
+        const double v = s_q1sum[h];
+        if (v != 0.0) pm_atomic_add(g_q1sum + h, v);
+    }
+}
+
+template <int SW>      // observed dimensions per workgroup slice: 64 (H <= 128), 32 (H <= 256), 16 (H <= 512)
+__global__ __launch_bounds__(1024) void mca_defer_scatter_kernel(const double *__restrict__ lseb, const double *__restrict__ cut_dev,
+                                                                  const double *__restrict__ Y, int64_t ldy,
+                                                                  const int32_t *__restrict__ cand,
+                                                                  const double *__restrict__ rec, double *__restrict__ stats,
+                                                                  int64_t N, int H, int D, int Hp, int nslices) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *s_wp = reinterpret_cast<double *>(smem_raw), *s_wq = s_wp + (size_t)H * SW;
+    constexpr int NSUB = 64 / SW;                  // datapoints a wavefront takes at once
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * H * SW; i += 1024) s_wp[i] = 0.0;
+    __syncthreads();
+    const double cut = cut_dev[0];
+    const int slice = (int)(blockIdx.x % (unsigned)nslices);
+    const int64_t group = blockIdx.x / (unsigned)nslices, G = gridDim.x / (unsigned)nslices;
+    const int64_t per = (N + G - 1) / G, n_lo = group * per, n_hi = (n_lo + per < N) ? n_lo + per : N;
+    const int sub = lane / SW, col = lane % SW, d = slice * SW + col;
+    // two datapoints per trip, every load of both requested before the first LDS atomic (the loop is a chain of global
+    // round trips otherwise: log-denominator -> record rows -> atomics, ~100 trips per wavefront)
+    constexpr int HPM = 12;
+    const int64_t step = 16 * NSUB;
+    for (int64_t n = n_lo + wave * NSUB + sub; n < n_hi; n += 2 * step) {
+        const int64_t nn[2] = {n, n + step};
+        bool keep[2];
+        double y[2], aid[2][HPM];
+        int hh[2][HPM];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t m = nn[u] < n_hi ? nn[u] : n;
+            keep[u] = nn[u] < n_hi && d < D && lseb[m] >= cut;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t m = nn[u] < n_hi ? nn[u] : n;
+            const double *rn = rec + m * (int64_t)Hp * D + (d < D ? d : 0);
+            const int32_t *cn = cand + m * Hp;
+            y[u] = keep[u] ? Y[m * ldy + d] : 0.0;
+#pragma unroll
+            for (int j = 0; j < HPM; ++j) {
+                aid[u][j] = (keep[u] && j < Hp) ? rn[(int64_t)j * D] : 0.0;
+                hh[u][j] = j < Hp ? cn[j] : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < HPM; ++j)
+                if (aid[u][j] != 0.0) {
+                    atomicAdd(&s_wq[hh[u][j] * SW + col], PM_Q(aid[u][j], 0));
+                    atomicAdd(&s_wp[hh[u][j] * SW + col], PM_Q(aid[u][j] * y[u], 1));
+                }
+    }
+    __syncthreads();
+    // multi-cause numerator / denominator: this XCD's copy (pm_common.h), folded by the launcher
+    double *Wp = pm_xcd_copy(stats + (int64_t)H * D, stats + mca_stats_base(H, D), 2 * (int64_t)H * D);
+    double *Wq = Wp + (int64_t)H * D;
+    for (int i = tid; i < H * SW; i += 1024) {
+        const int h = i / SW, c = i % SW, dd = slice * SW + c;
+        if (dd < D) {
+            const double vp = s_wp[i], vq = s_wq[i];
+            if (vp != 0.0) pm_atomic_add(Wp + (int64_t)h * D + dd, vp);
+            if (vq != 0.0) pm_atomic_add(Wq + (int64_t)h * D + dd, vq);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int pm_mca_defer_apply_f64(const double *lseb, const double *cut, const double *Y, int64_t ldy, const int32_t *cand,
+                                      const double *records, const double *scalars, double *q1, int64_t ldq, double *stats,
+                                      int64_t N, int64_t H, int64_t D, int64_t Hprime, void *stream) {
+    if (N == 0) return PM_OK;
+    if (!lseb || !cut || !Y || !cand || !records || !scalars || !q1 || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 ||
+        ldy < D || ldq < H)
+        return PM_EINVAL;
+    if (H > 512 || D > 512 || Hprime > 12) return PM_ERANGE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t blocks = (N + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mca_defer_q1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lseb, cut, scalars, q1, ldq, stats, N,
+                       (int)H, (int)D);
+    const int sw = H <= 128 ? 64 : H <= 256 ? 32 : 16;
+    const int nslices = (int)((D + sw - 1) / sw);
+    int64_t groups = 256 / nslices;                       // one workgroup per CU
+    if (groups < 1) groups = 1;
+    if (groups > (N + 63) / 64) groups = (N + 63) / 64;
+    const size_t shmem = (size_t)2 * H * sw * sizeof(double);
+#define PM_SCATTER(SWV)                                                                                                   \
+    do {                                                                                                                  \
+        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_defer_scatter_kernel<SWV>), shmem)) return e;        \
+        hipLaunchKernelGGL((mca_defer_scatter_kernel<SWV>), dim3((unsigned)(groups * nslices)), dim3(1024), shmem, s, lseb, cut, \
+                           Y, ldy, cand, records, stats, N, (int)H, (int)D, (int)Hprime, nslices);                        \
+    } while (0)
+    if (sw == 64) PM_SCATTER(64);
+    else if (sw == 32) PM_SCATTER(32);
+    else PM_SCATTER(16);
+#undef PM_SCATTER
+    mca_fold(stats, H, D, s);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pm_mca_estep_mstats_defer_f64(const double *scores, int64_t lds, const double *wnorm2, const double *ynorm2,
+                                             const double *Y, int64_t ldy, const double *Wrho, const double *Wrm1,
+                                             const int32_t *cand, const uint16_t *state_masks, int64_t S,
+                                             const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D,
+                                             int64_t Hprime, double *logpj, int64_t ldl, double *lse1, double *lseb,
+                                             double *q1, int64_t ldq, double *stats, double *defer_rec, double *defer_sc,
+                                             void *stream) {
+    if ((defer_rec == nullptr) != (defer_sc == nullptr)) return PM_EINVAL;
     if (N == 0) return PM_OK;
     if (!scores || !wnorm2 || !ynorm2 || !Y || !Wrho || !Wrm1 || !cand || !params_host || !logpj || !lse1 || !lseb ||
         !q1 || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 || lds < H || ldy < D ||
@@ -1282,13 +1573,13 @@ extern "C" int pm_mca_estep_mstats_f64(const double *scores, int64_t lds, const 
     const bool sgn = params_host->signed_w != 0.0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_wave = sizeof(double) * ((size_t)hp_tile * 64 * dpl * (sgn ? 2 : 1) + S);
-    const size_t shared = sizeof(double) * (PM_POWTAB_LEN + PM_ROOT21_LEN + 1 + H + 16);
+    const size_t shared = sizeof(double) * (PM_POWTAB_LEN + PM_FUSED_RT_LEN + H + 16);
     const int waves = pick_waves(per_wave, shared);
     const size_t shmem = shared + per_wave * waves;
     if (shmem > 150 * 1024) return PM_ERANGE;
     dim3 grid((unsigned)grid_waves(N, waves)), block(64 * waves);
 #define PM_ARGS (int)Hprime, grid, block, shmem, s, scores, lds, wnorm2, ynorm2, Y, ldy, Wrho, Wrm1, cand, state_masks, \
-                (int)S, *params_host, N, (int)H, (int)D, logpj, ldl, lse1, lseb, q1, ldq, stats
+                (int)S, *params_host, N, (int)H, (int)D, logpj, ldl, lse1, lseb, q1, ldq, stats, defer_rec, defer_sc
     int rc;
     switch (dpl) {
         case 1: rc = sgn ? launch_fused_hp<1, true>(PM_ARGS) : launch_fused_hp<1, false>(PM_ARGS); break;

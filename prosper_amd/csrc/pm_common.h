@@ -335,6 +335,57 @@ __device__ __forceinline__ double pm_pow_m5_6(double x, const double *rt) {
 #endif
 }
 
+// x^c for NORMAL x > 0 and an exponent c that is UNIFORM over the launch (round 6: MCA / MMCA's state power at any
+// temperature, c = 1 / rho - 1 with rho = 1 / (1 - 1 / T) -- every step of an annealing ramp; pm_pow_tab's 36 slots + two
+// dependent lookups made those passes 18 % slower than the rho = 21 ones).  With c fixed nothing needs a logarithm:
+//   x = 2^(E - 1023) m,  m = (1 + d) / r_i  (i = top 7 mantissa bits, r_i ~ 1 / m_i: pm_pow_tab's table, |d| < 2^-8)
+//   x^c = 2^(c (64 E1 - 1023)) * 2^(c E0) * r_i^(-c) * (1 + d)^c,   E = 64 E1 + E0
+// -- three factors from tables of 32 + 64 + 128 entries that the workgroup builds for ITS c when it starts (pm_load_upow:
+// libm powers, once), and the binomial series of (1 + d)^c to degree 6 (the seventh term is below 2^-56) with coefficients
+// held beside the tables.  ~15 VALU slots and three independent LDS reads; relative error <= 5e-16 against an 80-bit
+// reference (scratch/pow_uni_check.hip): four correctly rounded factors and the series' rounding.
+// |c| <= 1 (the factor tables must not overflow).
+// Layout: `pairs` = 128 x (r_i, r_i^-c) -- the place of pm_pow_tab's (r_i, L_i) pairs in the workgroup's copy of the power
+// table, whose E_j part pm_exp_tab keeps using --, `ab` = [A (32) | B (64) | b1 .. b6 | pad]: PM_UPOW_AB_LEN doubles.
+#define PM_UPOW_AB_LEN (32 + 64 + 8)
+__device__ __forceinline__ void pm_load_upow(double *pairs, double *ab, const double *powtab, double c, int tid, int nthreads) {
+    for (int i = tid; i < 128; i += nthreads) {
+        const double ri = powtab[2 * i];
+        pairs[2 * i] = ri;
+        pairs[2 * i + 1] = pow(ri, -c);
+    }
+    // (2^(c n) with the product c n carried exactly: hi + lo, 2^hi (1 + lo ln 2) -- the rounding of c n alone would cost
+    // |c n| 2^-53 ~ 1e-13)
+    for (int i = tid; i < 96; i += nthreads) {
+        const double n = i < 32 ? (double)(64 * i - 1023) : (double)(i - 32);
+        const double eh = c * n, el = fma(c, n, -eh);
+        ab[i] = exp2(eh) * fma(el, 0.6931471805599453, 1.0);
+    }
+    if (tid < 8) {
+        double b = 1.0;      // b_k = c (c - 1) ... (c - k + 1) / k!
+        for (int k = 1; k <= tid + 1; ++k) b *= (c - (double)(k - 1)) / (double)k;
+        ab[96 + tid] = tid < 6 ? b : 0.0;
+    }
+}
+__device__ __forceinline__ double pm_pow_uni(double x, const double *pairs, const double *ab) {
+    typedef double pm_d2 __attribute__((ext_vector_type(2)));
+    const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
+    const unsigned idx = (hi >> 13) & 127u;
+    const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), (int)lo);       // [1, 2)
+    const pm_d2 rl = reinterpret_cast<const pm_d2 *>(pairs)[idx];
+    const double a = ab[hi >> 26];
+    const double b = ab[32 + ((hi >> 20) & 63u)];
+    const double d = fma(m, rl.x, -1.0);
+    double p = ab[101];
+    p = fma(p, d, ab[100]);
+    p = fma(p, d, ab[99]);
+    p = fma(p, d, ab[98]);
+    p = fma(p, d, ab[97]);
+    p = fma(p, d, ab[96]);
+    const double t = rl.y * (a * b);
+    return fma(t * d, p, t);
+}
+
 // e^x for x <= ~700 from the same tables: x = k ln2/128 + r (two-part ln2/128, |r| <= ln2/256), e^r by a degree-5
 // polynomial, 2^(k/128) = 2^N E_j.  Arguments below -708 return ~1e-308 (callers only scale by it).  14 VALU slots and one
 // LDS lookup; relative error <= 2.3e-16.

@@ -46,6 +46,8 @@ class MCA_ET(DeviceCAModel):
         self._masks_dev = None
         self.signed_w = 0.0           # 1.0 in MMCA_ET: signed W, see pm_mca_params
         self.fuse_em = True           # E_step also produces the M-step's per-datapoint statistics when it can
+        self.defer_stats = True       # ... on data-truncation steps as per-datapoint records, added once the cut is known
+        self.defer_max_bytes = 32 << 30     # (N x H' x D doubles of records: beyond this the M-step runs its own pass)
 
     @tracing.traced
     def check_params(self, model_params):
@@ -132,6 +134,11 @@ class MCA_ET(DeviceCAModel):
                               beta=float(1. / anneal['T']), inv_rho=float(1. / rho), signed_w=self.signed_w)
 
     # ------------------------------------------------------------------ hot path
+    def step(self, anneal, model_params, my_data):
+        """CAModel.step; the M-step builds the next step's power tables for the NEXT annealing point's rho."""
+        self._next_anneal = self._predict_anneal(anneal)
+        return DeviceCAModel.step(self, anneal, model_params, my_data)
+
     @tracing.traced
     def select_Hprimes(self, model_params, data):
         """``data['candidates']`` (N, Hprime): the latents with the smallest
@@ -201,17 +208,23 @@ class MCA_ET(DeviceCAModel):
             A = self._gemm_nt(Y, par["Wt"], self._buf("scores", (N, H)), "scores_gemm")
             hp_tile = 4 if Hp <= 4 else 8 if Hp <= 8 else 12
             dpl = 1 if D <= 64 else 2 if D <= 128 else 4 if D <= 256 else 8
-            if self.fuse_em and anneal['Ncut_factor'] == 0.0 and D <= 512 and Hp <= 12 and dpl * hp_tile <= 48:
-                # no data truncation ahead: the M-step's per-datapoint statistics come out of the same pass
-                # (every multi-cause power is evaluated once instead of twice)
+            ncut = anneal['Ncut_factor'] > 0.0
+            defer = (ncut and self.defer_stats and getattr(self, "_in_step", False) and H <= 512
+                     and 8 * N * Hp * D <= self.defer_max_bytes)
+            if self.fuse_em and (not ncut or defer) and D <= 512 and Hp <= 12 and dpl * hp_tile <= 48:
+                # the M-step's per-datapoint statistics come out of the same pass (every multi-cause power is evaluated once
+                # instead of twice): accumulated in the pass when no data truncation is ahead; with one ahead (49 of the 50
+                # steps of the reference's schedules) left as per-datapoint records that M_step adds once the cut is known
                 stats = torch.zeros(_lib.load().pm_mca_stats_len(H, D), dtype=torch.float64, device=self.device)
                 q1 = torch.empty((N, H), dtype=torch.float64, device=self.device)
-                self._call("estep_mstats", "pm_mca_estep_mstats_f64", _ptr(A), H, _ptr(par["wnorm2"]),
+                rec = (self._buf("mca_defer_rec", (N, Hp, D)), self._buf("mca_defer_sc", (N, 4))) if defer else None
+                self._call("estep_mstats", "pm_mca_estep_mstats_defer_f64", _ptr(A), H, _ptr(par["wnorm2"]),
                            _ptr(res["ynorm2"]), _ptr(Y), D, _ptr(par["Wrho"]), _ptr(par["Wrm1"]), _ptr(cand),
                            _ptr(masks), S, ctypes.byref(P), N, H, D, Hp, _ptr(logpj), K, _ptr(lse1), _ptr(lseb),
-                           _ptr(q1), H, _ptr(stats), self._stream())
+                           _ptr(q1), H, _ptr(stats), _ptr(rec[0]) if rec else None, _ptr(rec[1]) if rec else None,
+                           self._stream())
                 fused = {"stats": stats, "q1": q1, "par": par, "res": res, "cand": my_data['candidates'],
-                         "pi": model_params['pi'], "sigma": model_params['sigma']}
+                         "pi": model_params['pi'], "sigma": model_params['sigma'], "defer": rec}
             else:
                 self._call("estep", "pm_mca_estep_f64", _ptr(A), H, _ptr(par["wnorm2"]), _ptr(res["ynorm2"]), _ptr(Y),
                            D, _ptr(par["Wrho"]), _ptr(cand), _ptr(masks), S, ctypes.byref(P), N, H, D, Hp,
@@ -258,19 +271,36 @@ class MCA_ET(DeviceCAModel):
             A_pi_gamma += a
             B_pi_gamma += gp * a
 
-        lse_cut = float("-inf")
-        if anneal['Ncut_factor'] > 0.0:
-            tracing.tracepoint("M_step:truncating")
-            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
-            lse_cut = self._kth_largest_global(lseb, N_use)
-
-        tracing.tracepoint("M_step:iterating")
+        ncut = anneal['Ncut_factor'] > 0.0
+        N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor'])) if ncut else N
         lib = _lib.load()
         n_stats = lib.pm_mca_stats_len(H, D)
         fz = getattr(logpj, "fused", None) if isinstance(logpj, DeviceArray) else None
-        if fz is not None and lse_cut == float("-inf") and fz["par"] is par and fz["res"] is res \
-                and fz["cand"] is my_data['candidates'] and fz["pi"] == pies and fz["sigma"] == sigma \
-                and logpj.T == T:
+        mine = (fz is not None and fz["par"] is par and fz["res"] is res and fz["cand"] is my_data['candidates']
+                and fz["pi"] == pies and fz["sigma"] == sigma and logpj.T == T)
+        rec = fz.get("defer") if mine else None
+        lse_cut = float("-inf")
+        if ncut and rec is None:
+            tracing.tracepoint("M_step:truncating")
+            lse_cut = self._kth_largest_global(lseb, N_use)
+
+        tracing.tracepoint("M_step:iterating")
+        if mine and rec is not None:
+            # the pass left every datapoint's statistics as a record (a data-truncation step): the cut is selected on the
+            # device and stays there; pm_mca_defer_apply_f64 adds the records of the datapoints above it (round 6: no second
+            # evaluation of the S x D powers -- pm_mca_mstep_rows_f64, 5 ms at config 5 -- and no host round trip)
+            stats, q1 = fz["stats"], fz["q1"]
+            logpj.fused = None
+            if ncut:
+                cut_dev = self._kth_select_dev(lseb, N_use)
+            else:
+                cut_dev = torch.full((1,), float("-inf"), dtype=torch.float64, device=self.device)
+            if my_N and self.deterministic:
+                self._det_quanta(res, model_params, self._params(anneal, pies, sigma, par["rho"]), K)
+            if my_N:
+                self._call("defer_apply", "pm_mca_defer_apply_f64", _ptr(lseb), _ptr(cut_dev), _ptr(Y), D, _ptr(cand),
+                           _ptr(rec[0]), _ptr(rec[1]), _ptr(q1), H, _ptr(stats), my_N, H, D, Hp, self._stream())
+        elif mine and lse_cut == float("-inf") and not ncut:
             # E_step already accumulated the per-datapoint statistics for exactly these inputs
             stats, q1 = fz["stats"], fz["q1"]
             logpj.fused = None            # consumed: the buffer is all-reduced in place below
@@ -334,10 +364,14 @@ class MCA_ET(DeviceCAModel):
         if seedable:
             # behind the download: the next step's candidates AND its power tables from the clamped W^T on the device
             # (valid if the caller hands this W back at the same temperature: checked by value in _tables_for)
+            # (the NEXT step's rho where the schedule's next point is known -- _predict_anneal --, else this step's)
+            nxt = getattr(self, "_next_anneal", None)
+            rho_next = self._rho(nxt['T']) if nxt is not None else par["rho"]
+
             def ahead():
                 self._seed_select(res, Wt_cl)
-                tabs, wnorm2 = self._tables_on_device(Wt_cl, par["rho"])
-                self._next_tabs = {"ykey": res["key"], "rho": par["rho"], "tabs": tabs, "wnorm2": wnorm2, "W": None}
+                tabs, wnorm2 = self._tables_on_device(Wt_cl, rho_next)
+                self._next_tabs = {"ykey": res["key"], "rho": rho_next, "tabs": tabs, "wnorm2": wnorm2, "W": None}
             host = self._download(flat, then=ahead)
         else:
             host = self._download(flat) if flat.is_cuda else flat.numpy()

@@ -207,3 +207,91 @@ def test_a_schedule_that_is_not_advanced_falls_back_to_the_flat_predictor(dev):
         p = m.step(an, p, {"y": y})
     assert m.spec_hits >= 3, m.spec_hits
     assert np.isfinite(p["W"]).all()
+
+
+# ------------------------------------------------------------------------- MCA / MMCA
+@pytest.mark.parametrize("cls,D,H,Hp,gamma,N,T,ncut", [
+    ("MCA", 256, 128, 8, 3, 3000, 1.0, 0.6),       # config-5 dimensions: 64-column slices of the scatter kernel
+    ("MCA", 256, 128, 8, 3, 3000, 1.37, 1.0),      # a temperature of the ramp: rho = 3.70..., the uniform-exponent power
+    ("MCA", 100, 200, 5, 4, 700, 1.6, 0.3),        # H > 128: 32-column slices; D not a multiple of 64
+    ("MCA", 40, 300, 3, 2, 400, 2.0, 0.5),         # H > 256: 16-column slices
+    ("MMCA", 256, 128, 8, 3, 2000, 1.0, 0.6),      # signed W
+    ("MMCA", 64, 40, 6, 3, 900, 1.5, 1.0),
+])
+def test_mca_deferred_statistics_match_two_pass_and_oracle(dev, cls, D, H, Hp, gamma, N, T, ncut):
+    """MCA_ET / MMCA_ET.step on a data-truncation step: the fused pass leaves the Aid blocks as records
+    (pm_mca_estep_mstats_defer_f64), pm_mca_defer_apply_f64 adds the ones above the device-resident cut -- same statistics
+    and parameters as the M-step's own pass (pm_mca_mstep_rows_f64 behind a host-side cut), and as the oracle."""
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    from prosper_amd.em.camodels.mmca_et import MMCA_ET
+    rng = np.random.RandomState(D + H + N)
+    if cls == "MCA":
+        from oracle import mca_oracle as M
+        W_gt = np.abs(rng.normal(size=(D, H))) * 2.0 + 0.1
+        y, _ = M.generate_mca_data(W_gt, 2.0 / H, 1.0, N, rng)
+        params = {"W": W_gt * (1 + 0.2 * rng.uniform(-1, 1, size=(D, H))), "pi": 2.4 / H, "sigma": 1.1}
+        make = lambda: MCA_ET(D, H, Hp, gamma)
+    else:
+        W_gt = rng.normal(size=(D, H)) * 2.0
+        s = rng.random_sample((N, H)) < 2.0 / H
+        amax = np.abs(np.where(s[:, None, :], W_gt[None], 0.0))
+        idx = amax.argmax(axis=2)
+        y = np.take_along_axis(np.where(s[:, None, :], W_gt[None], 0.0), idx[:, :, None], axis=2)[:, :, 0] + rng.normal(size=(N, D))
+        params = {"W": W_gt + 0.1 * rng.normal(size=(D, H)), "pi": 2.4 / H, "sigma": 1.1}
+        make = lambda: MMCA_ET(D, H, Hp, gamma)
+    out = {}
+    for defer in (True, False):
+        m = make()
+        m.defer_stats = defer
+        names = _recorded(m)
+        new = m.step(_An(T=T, Ncut_factor=ncut), dict(params), {"y": y})
+        out[defer] = (new, names)
+    a, b = out[True], out[False]
+    assert "pm_mca_defer_apply_f64" in a[1] and "pm_mca_estep_mstats_defer_f64" in a[1] and "pm_mca_mstep_rows_f64" not in a[1]
+    assert "pm_mca_defer_apply_f64" not in b[1] and "pm_mca_mstep_rows_f64" in b[1]
+    for k in ("W", "pi", "sigma", "Q"):
+        np.testing.assert_allclose(a[0][k], b[0][k], rtol=1e-9, atol=1e-11)
+    if cls == "MCA":
+        ref, log = M.em_step(M.Anneal(T=T, Ncut_factor=ncut), M.make_model(D, H, Hp, gamma), dict(params), y, vec=True)
+        np.testing.assert_allclose(a[0]["W"], ref["W"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(a[0]["pi"], ref["pi"], rtol=1e-9)
+        np.testing.assert_allclose(a[0]["sigma"], ref["sigma"], rtol=1e-9)
+        if np.isfinite(ref["Q"]):
+            np.testing.assert_allclose(a[0]["Q"], ref["Q"], rtol=1e-10)
+
+
+def test_mca_em_run_on_the_reference_schedule(dev):
+    """EM.run over the reference's schedule at config-5 dimensions: the default path (deferred statistics, power tables built
+    for the NEXT step's rho behind the download) against the two-pass path."""
+    from oracle import mca_oracle as M
+    from prosper_amd.em import EM
+    from prosper_amd.em.annealing import LinearAnnealing
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    D, H, Hp, gamma, N, steps = 256, 128, 8, 3, 2500, 12
+    rng = np.random.RandomState(17)
+    W_gt = np.abs(rng.normal(size=(D, H))) * 2.0 + 0.1
+    y, _ = M.generate_mca_data(W_gt, 2.0 / H, 1.0, N, rng)
+    params = {"W": W_gt * (1 + 0.2 * rng.uniform(-1, 1, size=(D, H))), "pi": 2.4 / H, "sigma": 1.1}
+    out = {}
+    for fast in (True, False):
+        m = MCA_ET(D, H, Hp, gamma)
+        m.defer_stats = fast
+        names = _recorded(m)
+        an = LinearAnnealing(steps)
+        an['T'] = [(0, 2.), (.7, 1.)]
+        an['Ncut_factor'] = [(0, 0.), (2. / 3, 1.)]
+        h = dlog.set_handler(("N_use", "Q", "sigma"), StoreInMemory)
+        try:
+            em = EM(model=m, anneal=an, data={"y": y}, lparams=dict(params))
+            em.run()
+        finally:
+            dlog.remove_handler(h)
+        out[fast] = (em.lparams, np.array(h.tables["N_use"]), np.array(h.tables["Q"]), np.array(h.tables["sigma"]), names)
+    a, b = out[True], out[False]
+    # the tables of steps 2 .. come from the M-step before them (pm_mca_tables_f64 once per step, no second build)
+    assert a[4].count("pm_mca_tables_f64") <= steps + 2, a[4].count("pm_mca_tables_f64")
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-9)
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+    np.testing.assert_allclose(a[0]["W"], b[0]["W"], rtol=1e-6, atol=1e-8)
