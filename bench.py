@@ -292,6 +292,7 @@ def other_models(dev, Anneal, steps=20):
                            ("tsc", TSC_ET(Dm, Hm, 6, 3), {"W": W0, "pi": 2.0 / Hm, "sigma": 1.0}),
                            # MMCA (signed max-superposition) on the same signed data at config-5 dimensions: H' = 8
                            ("mmca", MMCA_ET(Dm, Hm, 8, 3), {"W": W0, "pi": 2.0 / Hm, "sigma": 1.0})):
+            p0 = dict(p)
             t_warm = time.perf_counter()
             while time.perf_counter() - t_warm < 0.3:
                 p = m.step(Anneal(T=1.0), p, {"y": Y})
@@ -302,6 +303,7 @@ def other_models(dev, Anneal, steps=20):
             torch.cuda.synchronize()
             out["%s_em_iter_ms" % name] = (time.perf_counter() - t) / steps * 1e3
             out[name] = "%s D=256 H=128 H'=%d gamma=3, N=%d" % (type(m).__name__, m.Hprime, N)
+            out["%s_annealed" % name] = annealed_em(m, p0, {"y": Y})
             m.timer = kt = KernelTimer()
             for _ in range(3):
                 p = m.step(Anneal(T=1.0), p, {"y": Y})

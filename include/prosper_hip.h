@@ -514,9 +514,10 @@ int pm_mca_estep_mstats_defer_f64(const double *scores, int64_t lds, const doubl
                                   const pm_mca_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
                                   double *logpj, int64_t ldl, double *lse1, double *lseb, double *q1, int64_t ldq,
                                   double *stats, double *defer_rec, double *defer_sc, void *stream);
+int64_t pm_mca_defer_apply_work_len(int64_t H, int64_t D);      /* doubles of `work` (per-group partial sums, no atomics) */
 int pm_mca_defer_apply_f64(const double *lseb, const double *cut, const double *Y, int64_t ldy, const int32_t *cand,
                            const double *records, const double *scalars, double *q1, int64_t ldq, double *stats,
-                           int64_t N, int64_t H, int64_t D, int64_t Hprime, void *stream);
+                           double *work, int64_t N, int64_t H, int64_t D, int64_t Hprime, void *stream);
 /* The per-step tables of the MCA / MMCA kernels from W^T (H x D, already clamped by check_params): tabs = [ W^T | sign(W) |W|^rho |
  * |W|^(rho-1) ] (three H x D planes; mca_et.py:218-227, mmca_et.py:250-260 compute them with NumPy on the host) and
  * wnorm2[h] = |W_h|^2.  The caller keeps the reference's assertions (finite logarithms, W^rho > 1e-86) on its host copy. */

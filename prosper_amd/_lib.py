@@ -116,7 +116,9 @@ SIGNATURES = {
     "pm_mca_estep_mstats_defer_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64,
                                                 C.POINTER(McaParams), i64, i64, i64, i64, c_dp, i64, c_dp, c_dp,
                                                 c_dp, i64, c_dp, c_dp, c_dp, c_dp]),
-    "pm_mca_defer_apply_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp, i64, i64, i64, i64, c_dp]),
+    "pm_mca_defer_apply_work_len": (i64, [i64, i64]),
+    "pm_mca_defer_apply_f64": (C.c_int, [c_dp, c_dp, c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp, c_dp, i64, i64, i64, i64,
+                                         c_dp]),
     "pm_xsc_select_supported": (C.c_int, [i64, i64, C.c_int]),
     "pm_xsc_select_f64": (C.c_int, [c_dp, i64, c_dp, C.POINTER(DscParams), i64, i64, i64, c_dp, c_dp]),
     "pm_dsc_select_scores_f64": (C.c_int, [c_dp, i64, c_dp, C.POINTER(DscParams), i64, i64, c_dp, i64, c_dp]),

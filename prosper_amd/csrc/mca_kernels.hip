@@ -42,6 +42,12 @@ __host__ __device__ static inline int64_t mca_stats_base(int64_t H, int64_t D) {
 #define PM_MCA_ABL 0   // timing ablations (scratch/mca_abl.sh): 1 no global atomics, 2 no powers, 3 no V updates, 4 T sums from candidate 0 only, 5 no wave reduction, 6 no exponential, 7 no states at all (S = 0)
 #endif
 
+#ifndef PM_SCATTER_LDS_DOUBLES
+#define PM_SCATTER_LDS_DOUBLES 16384  // LDS of a mca_defer_scatter_kernel workgroup, in doubles: 128 KB, one workgroup per CU (8192 = two per CU: 0.68 against 0.46 ms -- twice the latent ranges, every datapoint scanned and its y row read by twice as many workgroups)
+#endif
+#ifndef PM_SCATTER_ABL
+#define PM_SCATTER_ABL 0          // timing-only ablations of mca_defer_scatter_kernel (wrong results): 1 no LDS atomics, 2 no record loads
+#endif
 // the fused pass's root / power table area: pm_load_root21 / pm_load_root6 (A/B builds) or pm_load_upow (any rho)
 #define PM_FUSED_RT_LEN (PM_ROOT21_LEN + 1)      // (>= PM_UPOW_AB_LEN; NOT larger: four workgroups of two wavefronts fill a CU's LDS to within 1.6 KB at config 5)
 
@@ -1307,15 +1313,17 @@ int launch_fused_hp(int Hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, 
                     int H, int D, double *logpj, int64_t ldl, double *lse1, double *lseb, double *q1, int64_t ldq,
                     double *stats, double *defer_rec, double *defer_sc) {
     const int hp = Hp <= 4 ? 4 : Hp <= 8 ? 8 : 12;
-    // Round 6: EVERY rho takes the uniform-exponent power (pm_pow_uni, ROOT = 0) -- 6.45 ms against 6.74 for the log / exp-free
-    // rho = 21 power at config 5 (scratch/mca_T_sweep.py), MMCA's rho = 6 likewise; -DPM_MCA_ROOT21 / -DPM_MCA_ROOT6 bring the
-    // special powers back (A/B builds).
+    // Round 6: unsigned W takes the uniform-exponent power (pm_pow_uni, ROOT = 0) at EVERY rho -- 6.45 ms against 6.74 for the
+    // log / exp-free rho = 21 power at config 5 (scratch/mca_T_sweep.py; -DPM_MCA_ROOT21 brings that one back for A/B builds).
+    // Signed W (MMCA) keeps its rho = 6 power (pm_pow_m5_6: 9.65 against 10.48 ms, scratch/mmca_time.py -- that pass runs one
+    // wavefront per SIMD, where the uniform power's three LDS lookups are not hidden; -DPM_MCA_NO_ROOT6: A/B) and takes the
+    // uniform power at every other rho.
 #ifdef PM_MCA_ROOT21
     const bool rho21 = !SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 21.0) < 1e-9;
 #else
     const bool rho21 = false;
 #endif
-#ifdef PM_MCA_ROOT6
+#ifndef PM_MCA_NO_ROOT6
     const bool rho6 = SIGNED && P.inv_rho > 0.0 && fabs(1.0 / P.inv_rho - 6.0) < 1e-9;
 #else
     const bool rho6 = false;
@@ -1346,7 +1354,7 @@ int launch_fused_hp(int Hp, dim3 grid, dim3 block, size_t shmem, hipStream_t s, 
 #else
 #define PM_CASE21(HPV)
 #endif
-#ifdef PM_MCA_ROOT6
+#ifndef PM_MCA_NO_ROOT6
 #define PM_CASE6(HPV)                                                 \
     if (rho6) {                                                       \
         if (defer_rec) PM_LAUNCH_F(HPV, true, 6, true);               \
@@ -1453,79 +1461,125 @@ __global__ __launch_bounds__(256) void mca_defer_q1_kernel(const double *__restr
     }
 }
 
-template <int SW>      // observed dimensions per workgroup slice: 64 (H <= 128), 32 (H <= 256), 16 (H <= 512)
+constexpr int DEFER_GROUPS = 64;      // datapoint groups of the scatter kernel (workspace: one [Wp | Wq] partial per group)
+
+// A workgroup of sixteen wavefronts owns HR rows (latents) of Wp and Wq -- all D observed dimensions of them, in LDS -- for
+// 1/G of the datapoints.  [First form: slices of 64 observed dimensions of ALL latents per workgroup -- every 2 KB record row
+// was then read in four 512-byte pieces by four workgroups at four different times, and the kernel ran at 2 TB/s; a
+// workgroup that reads the whole rows whose latent it owns streams them.]  A wavefront takes the log-denominators and the
+// candidates of 64 of its datapoints at once (lane = datapoint: an 8-bit mask of the candidate positions whose latent is in
+// the workgroup's range, 0 for a dropped datapoint), then walks the non-empty ones: the datapoint's y row once, each owned
+// record row in full (DPL doubles per lane), two ds_add_f64 per element.
+template <int DPL>      // doubles per lane and row: D <= 64 DPL
 __global__ __launch_bounds__(1024) void mca_defer_scatter_kernel(const double *__restrict__ lseb, const double *__restrict__ cut_dev,
                                                                   const double *__restrict__ Y, int64_t ldy,
                                                                   const int32_t *__restrict__ cand,
-                                                                  const double *__restrict__ rec, double *__restrict__ stats,
-                                                                  int64_t N, int H, int D, int Hp, int nslices) {
+                                                                  const double *__restrict__ rec, double *__restrict__ part,
+                                                                  int64_t N, int H, int D, int Hp, int HR, int nranges) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double *s_wp = reinterpret_cast<double *>(smem_raw), *s_wq = s_wp + (size_t)H * SW;
-    constexpr int NSUB = 64 / SW;                  // datapoints a wavefront takes at once
+    constexpr int DS = 64 * DPL;
+    double *s_wp = reinterpret_cast<double *>(smem_raw), *s_wq = s_wp + (size_t)HR * DS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 2 * H * SW; i += 1024) s_wp[i] = 0.0;
+    for (int i = tid; i < 2 * HR * DS; i += 1024) s_wp[i] = 0.0;
     __syncthreads();
     const double cut = cut_dev[0];
-    const int slice = (int)(blockIdx.x % (unsigned)nslices);
-    const int64_t group = blockIdx.x / (unsigned)nslices, G = gridDim.x / (unsigned)nslices;
+    const int range = (int)(blockIdx.x % (unsigned)nranges), h0 = range * HR;
+    const int64_t group = blockIdx.x / (unsigned)nranges, G = gridDim.x / (unsigned)nranges;
     const int64_t per = (N + G - 1) / G, n_lo = group * per, n_hi = (n_lo + per < N) ? n_lo + per : N;
-    const int sub = lane / SW, col = lane % SW, d = slice * SW + col;
-    // two datapoints per trip, every load of both requested before the first LDS atomic (the loop is a chain of global
-    // round trips otherwise: log-denominator -> record rows -> atomics, ~100 trips per wavefront)
-    constexpr int HPM = 12;
-    const int64_t step = 16 * NSUB;
-    for (int64_t n = n_lo + wave * NSUB + sub; n < n_hi; n += 2 * step) {
-        const int64_t nn[2] = {n, n + step};
-        bool keep[2];
-        double y[2], aid[2][HPM];
-        int hh[2][HPM];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int64_t m = nn[u] < n_hi ? nn[u] : n;
-            keep[u] = nn[u] < n_hi && d < D && lseb[m] >= cut;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int64_t m = nn[u] < n_hi ? nn[u] : n;
-            const double *rn = rec + m * (int64_t)Hp * D + (d < D ? d : 0);
-            const int32_t *cn = cand + m * Hp;
-            y[u] = keep[u] ? Y[m * ldy + d] : 0.0;
-#pragma unroll
-            for (int j = 0; j < HPM; ++j) {
-                aid[u][j] = (keep[u] && j < Hp) ? rn[(int64_t)j * D] : 0.0;
-                hh[u][j] = j < Hp ? cn[j] : 0;
+    const int64_t first = n_lo + wave;
+    const int64_t cnt = first < n_hi ? (n_hi - first + 15) / 16 : 0;          // this wavefront's datapoints: first + 16 p
+    for (int64_t p0 = 0; p0 < cnt; p0 += 64) {
+        const int64_t p = p0 + lane;
+        unsigned mine = 0u;
+        if (p < cnt) {
+            const int64_t n = first + 16 * p;
+            if (lseb[n] >= cut) {
+                const int32_t *cn = cand + n * Hp;
+                for (int j = 0; j < Hp; ++j) mine |= ((unsigned)(cn[j] - h0) < (unsigned)HR) ? (1u << j) : 0u;
             }
         }
+        unsigned long long todo = __ballot(mine != 0u);
+        while (todo) {
+            const int b = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mine, b);
+            const int64_t n = first + 16 * (p0 + b);
+            const int32_t *cn = cand + n * Hp;
+            double y[DPL];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                y[i] = d < D ? Y[n * ldy + d] : 0.0;
+            }
+            while (m) {          // up to two owned rows per trip: their loads leave together
+                const int j0 = __builtin_ctz(m);
+                m &= m - 1u;
+                const bool two = m != 0u;
+                const int j1 = two ? __builtin_ctz(m) : j0;
+                m &= m - 1u;      // (m == 0 stays 0)
+                const int r0 = __builtin_amdgcn_readfirstlane(cn[j0]) - h0, r1 = __builtin_amdgcn_readfirstlane(cn[j1]) - h0;
+                const double *a0 = rec + (n * Hp + j0) * (int64_t)D, *a1 = rec + (n * Hp + j1) * (int64_t)D;
+                double v0[DPL], v1[DPL];
 #pragma unroll
-            for (int j = 0; j < HPM; ++j)
-                if (aid[u][j] != 0.0) {
-                    atomicAdd(&s_wq[hh[u][j] * SW + col], PM_Q(aid[u][j], 0));
-                    atomicAdd(&s_wp[hh[u][j] * SW + col], PM_Q(aid[u][j] * y[u], 1));
+                for (int i = 0; i < DPL; ++i) {
+                    const int d = lane + 64 * i;
+                    v0[i] = d < D ? a0[d] : 0.0;
+                    v1[i] = (two && d < D) ? a1[d] : 0.0;
                 }
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    if (v0[i] != 0.0 && (PM_SCATTER_ABL != 1 || v0[i] == 1.2345e-300)) {
+                        atomicAdd(&s_wq[r0 * DS + lane + 64 * i], PM_Q(v0[i], 0));
+                        atomicAdd(&s_wp[r0 * DS + lane + 64 * i], PM_Q(v0[i] * y[i], 1));
+                    }
+                    if (v1[i] != 0.0 && (PM_SCATTER_ABL != 1 || v1[i] == 1.2345e-300)) {
+                        atomicAdd(&s_wq[r1 * DS + lane + 64 * i], PM_Q(v1[i], 0));
+                        atomicAdd(&s_wp[r1 * DS + lane + 64 * i], PM_Q(v1[i] * y[i], 1));
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
-    // multi-cause numerator / denominator: this XCD's copy (pm_common.h), folded by the launcher
-    double *Wp = pm_xcd_copy(stats + (int64_t)H * D, stats + mca_stats_base(H, D), 2 * (int64_t)H * D);
-    double *Wq = Wp + (int64_t)H * D;
-    for (int i = tid; i < H * SW; i += 1024) {
-        const int h = i / SW, c = i % SW, dd = slice * SW + c;
-        if (dd < D) {
-            const double vp = s_wp[i], vq = s_wq[i];
-            if (vp != 0.0) pm_atomic_add(Wp + (int64_t)h * D + dd, vp);
-            if (vq != 0.0) pm_atomic_add(Wq + (int64_t)h * D + dd, vq);
+    // this group's partial [Wp | Wq] (H x D each): plain stores -- mca_defer_reduce_kernel sums the groups in a fixed order
+    double *pw = part + group * 2 * (int64_t)H * D;
+    for (int i = tid; i < HR * DS; i += 1024) {
+        const int r = i / DS, d = i % DS, h = h0 + r;
+        if (h < H && d < D) {
+            pw[(int64_t)h * D + d] = s_wp[i];
+            pw[(int64_t)(H + h) * D + d] = s_wq[i];
         }
     }
 }
+
+// out[i] += sum_g part[g][i], g in a fixed order (out = the [Wp_m | Wq_m] block of the statistics: 2 H D doubles)
+__global__ __launch_bounds__(256) void mca_defer_reduce_kernel(const double *__restrict__ part, int G, double *__restrict__ out,
+                                                                int64_t len) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+        a0 += part[(int64_t)g * len + i];
+        a1 += part[(int64_t)(g + 1) * len + i];
+        a2 += part[(int64_t)(g + 2) * len + i];
+        a3 += part[(int64_t)(g + 3) * len + i];
+    }
+    for (; g < G; ++g) a0 += part[(int64_t)g * len + i];
+    out[i] += (a0 + a1) + (a2 + a3);
+}
 }  // namespace
+
+extern "C" int64_t pm_mca_defer_apply_work_len(int64_t H, int64_t D) {
+    return (H > 0 && D > 0) ? (int64_t)DEFER_GROUPS * 2 * H * D : 0;
+}
 
 extern "C" int pm_mca_defer_apply_f64(const double *lseb, const double *cut, const double *Y, int64_t ldy, const int32_t *cand,
                                       const double *records, const double *scalars, double *q1, int64_t ldq, double *stats,
-                                      int64_t N, int64_t H, int64_t D, int64_t Hprime, void *stream) {
+                                      double *work, int64_t N, int64_t H, int64_t D, int64_t Hprime, void *stream) {
     if (N == 0) return PM_OK;
-    if (!lseb || !cut || !Y || !cand || !records || !scalars || !q1 || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 ||
-        ldy < D || ldq < H)
+    if (!lseb || !cut || !Y || !cand || !records || !scalars || !q1 || !stats || !work || N < 0 || H <= 0 || D <= 0 ||
+        Hprime <= 0 || ldy < D || ldq < H)
         return PM_EINVAL;
     if (H > 512 || D > 512 || Hprime > 12) return PM_ERANGE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1533,23 +1587,27 @@ extern "C" int pm_mca_defer_apply_f64(const double *lseb, const double *cut, con
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(mca_defer_q1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lseb, cut, scalars, q1, ldq, stats, N,
                        (int)H, (int)D);
-    const int sw = H <= 128 ? 64 : H <= 256 ? 32 : 16;
-    const int nslices = (int)((D + sw - 1) / sw);
-    int64_t groups = 256 / nslices;                       // one workgroup per CU
-    if (groups < 1) groups = 1;
-    if (groups > (N + 63) / 64) groups = (N + 63) / 64;
-    const size_t shmem = (size_t)2 * H * sw * sizeof(double);
-#define PM_SCATTER(SWV)                                                                                                   \
+    const int dpl = D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : 8;
+    int hr = PM_SCATTER_LDS_DOUBLES / (2 * 64 * dpl);          // rows of Wp and Wq per workgroup: 32 at D <= 256
+    if (hr > H) hr = (int)H;
+    const int nranges = (int)((H + hr - 1) / hr);
+    int64_t groups = DEFER_GROUPS;
+    if (groups > (N + 255) / 256) groups = (N + 255) / 256;
+    const size_t shmem = (size_t)2 * hr * 64 * dpl * sizeof(double);
+#define PM_SCATTER(DPLV)                                                                                                  \
     do {                                                                                                                  \
-        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_defer_scatter_kernel<SWV>), shmem)) return e;        \
-        hipLaunchKernelGGL((mca_defer_scatter_kernel<SWV>), dim3((unsigned)(groups * nslices)), dim3(1024), shmem, s, lseb, cut, \
-                           Y, ldy, cand, records, stats, N, (int)H, (int)D, (int)Hprime, nslices);                        \
+        if (int e = allow_lds_mca(reinterpret_cast<const void *>(mca_defer_scatter_kernel<DPLV>), shmem)) return e;       \
+        hipLaunchKernelGGL((mca_defer_scatter_kernel<DPLV>), dim3((unsigned)(groups * nranges)), dim3(1024), shmem, s, lseb, cut, \
+                           Y, ldy, cand, records, work, N, (int)H, (int)D, (int)Hprime, hr, nranges);                     \
     } while (0)
-    if (sw == 64) PM_SCATTER(64);
-    else if (sw == 32) PM_SCATTER(32);
-    else PM_SCATTER(16);
+    if (dpl == 1) PM_SCATTER(1);
+    else if (dpl == 2) PM_SCATTER(2);
+    else if (dpl == 4) PM_SCATTER(4);
+    else PM_SCATTER(8);
 #undef PM_SCATTER
-    mca_fold(stats, H, D, s);
+    const int64_t len = 2 * H * D;
+    hipLaunchKernelGGL(mca_defer_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, (const double *)work,
+                       (int)groups, stats + H * D, len);
     return (int)hipGetLastError();
 }
 

@@ -298,8 +298,9 @@ class MCA_ET(DeviceCAModel):
             if my_N and self.deterministic:
                 self._det_quanta(res, model_params, self._params(anneal, pies, sigma, par["rho"]), K)
             if my_N:
+                work = self._buf("mca_defer_work", (int(lib.pm_mca_defer_apply_work_len(H, D)),))
                 self._call("defer_apply", "pm_mca_defer_apply_f64", _ptr(lseb), _ptr(cut_dev), _ptr(Y), D, _ptr(cand),
-                           _ptr(rec[0]), _ptr(rec[1]), _ptr(q1), H, _ptr(stats), my_N, H, D, Hp, self._stream())
+                           _ptr(rec[0]), _ptr(rec[1]), _ptr(q1), H, _ptr(stats), _ptr(work), my_N, H, D, Hp, self._stream())
         elif mine and lse_cut == float("-inf") and not ncut:
             # E_step already accumulated the per-datapoint statistics for exactly these inputs
             stats, q1 = fz["stats"], fz["q1"]
