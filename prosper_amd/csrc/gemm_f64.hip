@@ -844,6 +844,15 @@ extern "C" int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int
             // (3392 x 256 x 1024: 9 slices 67 us, 4 slices 56 us, 2 slices 77 us)
             if (nsplit > 4 && rest_tiles >= 32) nsplit = nsplit / 2 > 4 ? nsplit / 2 : 4;
         }
+#ifdef PM_DETERMINISTIC
+        // The K-slices of a split remainder meet in f64 atomics, whose order is not fixed -- and this product (scores, selection
+        // distances, ragged remainders) has no bound of its own from which a quantum could be derived: the deterministic build
+        // never splits K here (every element of C is then written once, by one workgroup, in a fixed summation order).  The
+        // remainder of a shard runs a fraction of a round at full K instead: a few per cent of one launch.  [round-5 advisor
+        // finding: the slices used to be quantised with the `gemm` unit's category 0, i.e. with whatever M-step bound the
+        // previous step -- or another model of the process -- had installed, or with none at all in a fresh process.]
+        nsplit = 1;
+#endif
         if (main_panels > 0 && rest_rows > 0 && nsplit > 1 && fuse_remainder()) {
             launch_nt_dma_fused(A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)main_panels, (int)nsplit, s);
             return (int)hipGetLastError();

@@ -71,6 +71,10 @@ def _gsc(shape):
 _CASES = {
     "bsc_small": (_bsc, (20, 12, 5, 3, 700)), "bsc_fast": (_bsc, (64, 160, 8, 3, 1500)),      # fast: the 16-wavefront kernel's shapes
     "mca": (_mca, (64, 128, 8, 3, 900)), "dsc": (_dsc, (32, 24, 5, 3, 900)), "gsc": (_gsc, (128, 128, 6, 3, 1200)),
+    # shapes whose scores GEMM (pm_gemm_nt_f64) would split K in the default build -- a ragged remainder behind whole rounds
+    # of the 4-wavefront fused kernel; a shard smaller than one round at a large D (round-5 advisor finding: the slices'
+    # atomics were quantised with another kernel family's bounds, or none: the deterministic build does not split there)
+    "bsc_splitk": (_bsc, (256, 64, 6, 3, 40000)), "dsc_splitk": (_dsc, (512, 24, 5, 3, 900)),
 }
 
 
