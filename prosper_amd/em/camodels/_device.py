@@ -149,6 +149,9 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_DET_QUANTA_SET = {}      # unit -> the quanta last installed in libprosper_hip_det.so's symbols (process-global, like them)
+
+
 class _AnnealAt(object):
     """Read-only view of a schedule at another position (``LinearAnnealing.__getitem__`` reads ``cur_pos``,
     annealing.py:90-107); ``pos`` None: the schedule as it stands (objects without a position, e.g. a plain mapping)."""
@@ -264,7 +267,15 @@ class DeviceCAModel(CAModel):
     def _det_set(self, unit, bounds):
         """Install the quanta of one kernel family (include/prosper_hip.h: pm_det_set_quanta) ahead of its next launches:
         ``bounds[c]`` = what no partial sum of category c can exceed on this shard with these parameters."""
-        M = (ctypes.c_double * 8)(*([self._magic(b) for b in bounds] + [0.0] * (8 - len(bounds))))
+        vals = tuple([self._magic(b) for b in bounds] + [0.0] * (8 - len(bounds)))
+        # (a quantum is a power of two: it moves only when its bound crosses one -- the six uploads per step of a steady EM loop
+        # were six small copies on the stream's critical path for values already there.  The cache is per PROCESS, like the
+        # symbols: another model's different bounds invalidate it.)
+        cache = _DET_QUANTA_SET
+        if cache.get(unit) == vals:
+            return
+        cache[unit] = vals
+        M = (ctypes.c_double * 8)(*vals)
         keep = self.__dict__.setdefault("_det_keep", [])
         keep.append(M)
         del keep[:-16]

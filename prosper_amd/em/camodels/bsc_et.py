@@ -506,8 +506,8 @@ class BSC_ET(DeviceCAModel):
         # device so far, the M-step's speculative launch, carries no statistics; the M-step's own pass forms them then)
         Wh = par.get("Whost")
         if N and want_ms and self.fuse_mstats and self._fused() and Hp <= 8 and 'mu' not in self.to_learn \
-                and (not self.deterministic or Wh is not None):
-            if self.deterministic:
+                and (not self.deterministic or Wh is not None or defer):
+            if self.deterministic and not defer:
                 self._det_quanta(res, Wh.T if par["Whost_T"] else Wh, np.full(1, np.sqrt(max(P.mu_sqnorm, 0.0))), P, N)
             n_stats = _lib.load().pm_bsc_stats_len(H, D)
             # two statistics workspaces alternate: the M-step that launches the NEXT E-step (speculation) still reads its
@@ -533,8 +533,13 @@ class BSC_ET(DeviceCAModel):
         """Which M-step statistics the E-step pass inside ``step`` carries: True -- accumulated in the pass (no data
         truncation ahead); "defer" -- left as per-datapoint records that M_step adds once the cut is known
         (``Ncut_factor > 0``: 49 of the 50 steps of the reference's schedules, bars-learning.py:77-80); False -- none."""
-        if anneal['Ncut_factor'] <= 0.0:
+        if anneal['Ncut_factor'] <= 0.0 and not (self.deterministic and self.defer_stats and self.sparse_wp
+                                                 and self._fused() and self._tile8_whole_shard()):
             return True
+        # (deterministic mode takes the deferred form on EVERY step: the records need no quanta while the pass runs -- the
+        # M-step's speculative launch of the next pass knows W^T on the device only, not the bounds the quanta derive from --
+        # and the apply kernel runs when M_step has them; until round 6 every deterministic step paid the M-step's own
+        # pass over the log-joints instead: + 0.4 ms at config 2)
         return "defer" if self.defer_stats else False
 
     def _speculate_estep(self, res, par, anneal, pies, sigma):
