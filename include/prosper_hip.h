@@ -608,6 +608,14 @@ int pm_dsc_mstep_rows_nz_f64(const double *logpj, int64_t ldl, const double *lse
                           const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
                           double *expect, int64_t lde, double *stats, uint16_t *nz_idx, double *nz_val,
                              void *stream);
+/* The same pass with the data-truncation cut read on the DEVICE (round 6): `cut_dev` (one double, e.g. what pm_kth_final_f64
+ * left, adjusted as dsc_et.py:832 / tsc_et.py:433-440 ask) replaces `lse_cut` when it is not NULL -- the M-step of a
+ * truncation step then has no host round trip between the radix select and its row pass.  nz_idx / nz_val may be NULL
+ * (then exactly pm_dsc_mstep_rows_f64). */
+int pm_dsc_mstep_rows_cutp_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut, const double *cut_dev,
+                               const int32_t *cand, const uint8_t *state_idx, int64_t S, const double *prior,
+                               const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D, int64_t Hprime,
+                               double *expect, int64_t lde, double *stats, uint16_t *nz_idx, double *nz_val, void *stream);
 
 /* pm_dsc_estep_f64 that ALSO produces the M-step's row statistics -- what pm_dsc_mstep_rows_nz_f64 computes from the stored
  * log-joints (dsc_et.py:587-774: E[s] rows, their non-zero lists, the candidates' second moments -> Wq, qdiag, the value

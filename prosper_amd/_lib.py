@@ -130,6 +130,8 @@ SIGNATURES = {
                                         i64, i64, i64, i64, c_dp, i64, c_dp, c_dp]),
     "pm_dsc_mstep_rows_nz_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, i64, c_dp, C.POINTER(DscParams),
                                            i64, i64, i64, i64, c_dp, i64, c_dp, c_dp, c_dp, c_dp]),
+    "pm_dsc_mstep_rows_cutp_f64": (C.c_int, [c_dp, i64, c_dp, C.c_double, c_dp, c_dp, c_dp, i64, c_dp, C.POINTER(DscParams),
+                                             i64, i64, i64, i64, c_dp, i64, c_dp, c_dp, c_dp, c_dp]),
     "pm_dsc_rows16_supported": (C.c_int, [i64, i64, i64, i64, C.c_int]),
     "pm_dsc_estep_mstats_supported": (C.c_int, [i64, i64, i64, i64, C.c_int]),
     "pm_dsc_estep_mstats_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, i64, c_dp, C.POINTER(DscParams), i64, i64, i64,

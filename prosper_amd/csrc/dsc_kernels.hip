@@ -776,8 +776,9 @@ __global__ __launch_bounds__(64 * WAVES, MAXHP <= 8 ? 4 : 3) void dsc_mstep_rows
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior_g,
     pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ expect, int64_t lde,
-    double *__restrict__ stats, int stage) {
+    double *__restrict__ stats, int stage, const double *__restrict__ cut_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (cut_dev) lse_cut = cut_dev[0];       // (round 6: the radix select's result read where it was left, no host round trip)
     // [ qdiag (H) | cnt (8) | scal (4) | per wave: row (H) m (Hp) B (Hp*Hp) | state table ]
     double *s_qdiag = reinterpret_cast<double *>(smem);
     double *s_cnt = s_qdiag + H;
@@ -941,8 +942,10 @@ __global__ __launch_bounds__(256, (MAXHP <= 8 && VPL <= 8) ? PM_DSC_M16_WPE : 2)
     const double *__restrict__ logpj, int64_t ldl, const double *__restrict__ lse, double lse_cut,
     const int32_t *__restrict__ cand, const uint8_t *__restrict__ state_idx, int S, const double *__restrict__ prior_g,
     pm_dsc_params P, int64_t N, int H, int D, int Hp, double *__restrict__ expect, int64_t lde,
-    double *__restrict__ stats, int stage, uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val) {
+    double *__restrict__ stats, int stage, uint16_t *__restrict__ nz_idx, double *__restrict__ nz_val,
+    const double *__restrict__ cut_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (cut_dev) lse_cut = cut_dev[0];       // (round 6: the radix select's result read where it was left, no host round trip)
     double *s_qdiag = reinterpret_cast<double *>(smem);
     double *s_cnt = s_qdiag + H;
     double *s_scal = s_cnt + PM_DSC_MAX_K;
@@ -1363,6 +1366,15 @@ extern "C" int pm_dsc_mstep_rows_nz_f64(const double *logpj, int64_t ldl, const 
                                         const pm_dsc_params *params_host, int64_t N, int64_t H, int64_t D,
                                         int64_t Hprime, double *expect, int64_t lde, double *stats, uint16_t *nz_idx,
                                         double *nz_val, void *stream) {
+    return pm_dsc_mstep_rows_cutp_f64(logpj, ldl, lse, lse_cut, nullptr, cand, state_idx, S, prior, params_host, N, H, D, Hprime,
+                                      expect, lde, stats, nz_idx, nz_val, stream);
+}
+
+extern "C" int pm_dsc_mstep_rows_cutp_f64(const double *logpj, int64_t ldl, const double *lse, double lse_cut,
+                                          const double *cut_dev, const int32_t *cand, const uint8_t *state_idx, int64_t S,
+                                          const double *prior, const pm_dsc_params *params_host, int64_t N, int64_t H,
+                                          int64_t D, int64_t Hprime, double *expect, int64_t lde, double *stats,
+                                          uint16_t *nz_idx, double *nz_val, void *stream) {
     if ((nz_idx == nullptr) != (nz_val == nullptr)) return PM_EINVAL;
     if (N == 0) return PM_OK;
     if (!logpj || !lse || !cand || !prior || !expect || !stats || N < 0 || H <= 0 || D <= 0 || Hprime <= 0 || S < 0 ||
@@ -1385,7 +1397,8 @@ extern "C" int pm_dsc_mstep_rows_nz_f64(const double *logpj, int64_t ldl, const 
         if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows16_kernel<M, V>), sh16)) return e;      \
         hipLaunchKernelGGL((dsc_mstep_rows16_kernel<M, V>), dim3(grid16), dim3(256), sh16,                             \
                            static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior, \
-                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, stage16, nz_idx, nz_val); \
+                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, stage16, nz_idx, nz_val,  \
+                           cut_dev);                                                                                   \
     } while (0)
             if (Hprime <= 8 && H <= 128) PM_LAUNCH16(8, 8);
             else if (Hprime <= 8) PM_LAUNCH16(8, 16);
@@ -1406,7 +1419,7 @@ extern "C" int pm_dsc_mstep_rows_nz_f64(const double *logpj, int64_t ldl, const 
         if (int e = allow_lds_dsc(reinterpret_cast<const void *>(dsc_mstep_rows_kernel<M>), shmem)) return e;        \
         hipLaunchKernelGGL(dsc_mstep_rows_kernel<M>, dim3(row_grid(N, M <= 8 ? 4 : 3)), dim3(64 * WAVES), shmem,       \
                            static_cast<hipStream_t>(stream), logpj, ldl, lse, lse_cut, cand, state_idx, (int)S, prior, \
-                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, stage);                 \
+                           *params_host, N, (int)H, (int)D, (int)Hprime, expect, lde, stats, stage, cut_dev);        \
     } while (0)
     if (Hprime <= 8) PM_LAUNCH(8);
     else PM_LAUNCH(PM_MAX_HPRIME);

@@ -399,7 +399,7 @@ class DeviceCAModel(CAModel):
             return ms
         return None
 
-    def _rows_and_wp(self, rows_args, lp_ld, expect, Y, stats, my_N, K, flags, Hp, S, fused=None):
+    def _rows_and_wp(self, rows_args, lp_ld, expect, Y, stats, my_N, K, flags, Hp, S, fused=None, cut_dev=None):
         """DSC / TSC M-step: the per-datapoint pass (pm_dsc_mstep_rows[_nz]_f64) and Wp = E[s]^T Y.  Where the
         sixteen-lane kernel applies the pass also leaves the non-zero lists of E[s] and Wp is accumulated from them
         (pm_wp_sparse_f64); the dense product follows behind the device-side gate (last scalar of `stats`: rows whose
@@ -421,6 +421,20 @@ class DeviceCAModel(CAModel):
             return
         sparse = (getattr(self, "sparse_wp", True) and Y.is_cuda and H <= 256
                   and bool(lib.pm_dsc_rows16_supported(H, Hp, S, K, flags)))
+        if cut_dev is not None:
+            # ``cut_dev``: the data-truncation cut as the radix select left it on the device (round 6: no host round trip
+            # between the select and this pass -- on a slow host the device idled a quarter of the step there)
+            rows_args = rows_args[:4] + (_ptr(cut_dev),) + rows_args[4:]
+            nzb = (self._buf("nz_idx", (my_N, 16), torch.int16), self._buf("nz_val", (my_N, 16))) if sparse else (None, None)
+            self._call("mstep_rows", "pm_dsc_mstep_rows_cutp_f64", *(rows_args + (_ptr(nzb[0]), _ptr(nzb[1]), st)))
+            if sparse:
+                self._call("stats_sparse", "pm_wp_sparse_f64", _ptr(nzb[0]), _ptr(nzb[1]), _ptr(Y), Y.stride(0), _ptr(stats),
+                           D, gate, my_N, H, D, st)
+                self._call("stats_gemm", "pm_gemm_tn_acc_gated_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D,
+                           my_N, gate, st)
+            else:
+                self._call("stats_gemm", "pm_gemm_tn_acc_f64", _ptr(expect), H, _ptr(Y), D, _ptr(stats), D, H, D, my_N, st)
+            return
         if sparse:
             nz_idx, nz_val = self._buf("nz_idx", (my_N, 16), torch.int16), self._buf("nz_val", (my_N, 16))
             self._call("mstep_rows", "pm_dsc_mstep_rows_nz_f64", *(rows_args + (_ptr(nz_idx), _ptr(nz_val), st)))

@@ -331,13 +331,17 @@ class DSC_ET(DeviceCAModel):
         dlog.append("prior_mass", A_pi_gamma)
 
         # data truncation (dsc_et.py:825-843): keep the datapoints STRICTLY above the N_use-th largest evidence
-        lse_cut = float("-inf")
+        lse_cut, cut_dev = float("-inf"), None
         if anneal['Ncut_factor'] > 0.0:
             tracing.tracepoint("M_step:truncating")
             N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
             # the reference cuts on un-stabilised sums of exp(logpj), which are exactly 0 below the
             # underflow boundary: with the cut among those only strictly positive sums survive
-            lse_cut = max(self._kth_largest_global(lse, N_use), _LOG_UNDERFLOW)
+            if lse.is_cuda and my_N:      # (the cut stays on the device: the row pass reads it there)
+                cut_dev = torch.clamp_min(self._kth_select_dev(lse, N_use), _LOG_UNDERFLOW)
+                lse_cut = float("nan")    # (not -inf: statistics a fused E-step pass may have left do not apply)
+            else:
+                lse_cut = max(self._kth_largest_global(lse, N_use), _LOG_UNDERFLOW)
 
         tracing.tracepoint("M_step:iterating")
         lib = _lib.load()
@@ -354,7 +358,7 @@ class DSC_ET(DeviceCAModel):
             self._rows_and_wp((_ptr(lp), Kt, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S,
                                _ptr(prior) if prior is not None else None,
                                ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats)),
-                              Kt, expect, Y, stats, my_N, self.K, int(P.flags), Hp, S, fused=fused)
+                              Kt, expect, Y, stats, my_N, self.K, int(P.flags), Hp, S, fused=fused, cut_dev=cut_dev)
         comm.allreduce_device(stats)      # replaces dsc_et.py:648,738,739,747,769 and the allreduce in get_likelihood
         self._mstep_res = res
         return self._finalize(stats, model_params)

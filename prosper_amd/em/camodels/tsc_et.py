@@ -293,14 +293,20 @@ class TSC_ET(DeviceCAModel):
         E_pi_gamma = pi * H * A_pi_gamma / B_pi_gamma
 
         # data truncation (tsc_et.py:435-446): evidence >= the N_use-th largest
-        lse_cut = float("-inf")
+        lse_cut, cut_dev = float("-inf"), None
         if anneal['Ncut_factor'] > 0.0:
             tracing.tracepoint("M_step:truncating")
             N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
-            cut = self._kth_largest_global(lse, N_use)
             # the kernel keeps lse > cut; the un-stabilised sums upstream cuts on are exactly 0 below the
             # underflow boundary, where `>= 0` keeps every datapoint
-            lse_cut = float("-inf") if cut < _LOG_UNDERFLOW else float(np.nextafter(cut, -np.inf))
+            if lse.is_cuda and my_N:      # (the cut stays on the device: the row pass reads it there)
+                c = self._kth_select_dev(lse, N_use)
+                ninf = torch.full_like(c, float("-inf"))
+                cut_dev = torch.where(c < _LOG_UNDERFLOW, ninf, torch.nextafter(c, ninf))
+                lse_cut = float("nan")    # (not -inf: statistics a fused E-step pass may have left do not apply)
+            else:
+                cut = self._kth_largest_global(lse, N_use)
+                lse_cut = float("-inf") if cut < _LOG_UNDERFLOW else float(np.nextafter(cut, -np.inf))
 
         tracing.tracepoint("M_step:iterating")
         lib = _lib.load()
@@ -315,7 +321,7 @@ class TSC_ET(DeviceCAModel):
             self._rows_and_wp((_ptr(lp), S, _ptr(lse), ctypes.c_double(lse_cut), _ptr(cand), _ptr(tab), S,
                                _ptr(prior) if prior is not None else None,
                                ctypes.byref(P), my_N, H, D, Hp, _ptr(expect), H, _ptr(stats)),
-                              S, expect, Y, stats, my_N, int(P.K), int(P.flags), Hp, S, fused=fused)
+                              S, expect, Y, stats, my_N, int(P.K), int(P.flags), Hp, S, fused=fused, cut_dev=cut_dev)
         comm.allreduce_device(stats)      # replaces tsc_et.py:412,446,453,486,487,497,527
         self._mstep_res = res
         return self._finalize(stats, model_params, A_pi_gamma, E_pi_gamma)
