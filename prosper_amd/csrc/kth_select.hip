@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void kth_scan_kernel(unsigned long long *__res
 // data-truncation step once that step had no other host round trip left.  Every workgroup of round r now first repeats the
 // scan of round r - 1 for itself (the all-reduced histogram of 4096 bins and the state it started from: ~2 us, the same
 // answer in every workgroup), workgroup 0 records the result for the round after, and the histograms of the six rounds are
-// six separate buffers zeroed by ONE fill: 1 + 6 + 1 launches.
+// six separate buffers zeroed by ONE fill: 1 + 6 + 1 launches.  (One cooperative launch for the single-rank case -- the rounds
+// separated by grid barriers on a global counter -- was built and measured: 0.14 ms against 0.09, seven barriers across eight
+// XCDs cost more than seven launch gaps; not kept.)
 __device__ __forceinline__ void kth_scan_block(const unsigned long long *__restrict__ hist,
                                                const unsigned long long *__restrict__ state_in, int shift, int bits,
                                                unsigned long long *s_chunk, int *s_pick, unsigned long long *s_out) {
