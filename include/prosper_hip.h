@@ -337,7 +337,7 @@ int pm_bsc_estep_fused_f64(const double *Y, int64_t ldy, const double *Wt, int64
  * owns 128 datapoints x all latents, one per CU; a wavefront accumulates 16 datapoints x 128 latents (<= 128 registers:
  * four wavefronts per SIMD), the row passes run one half-wavefront per datapoint.  Same arguments, outputs and reference
  * lines (bsc_et.py:98-115, :119-192) as pm_bsc_estep_fused_f64.  Needs pm_bsc_fused8_supported(H, D, Hprime, S) --
- * 128 < H <= 256, Hprime = 8, S = 84 or 154, D a multiple of 8 -- and pm_bsc_fused8_whole_shard(H, Hprime, gamma, S): the
+ * 128 < H <= 256, Hprime = 5 .. 8 (round 6; 8 until then), S that of gamma = 3 or 4 (84 / 154 at Hprime = 8), D a multiple of 8 -- and pm_bsc_fused8_whole_shard(H, Hprime, gamma, S): the
  * complete state set of sizes 2 .. gamma, gamma 3 or 4.  The call takes a WHOLE shard: whole rounds of resident
  * workgroups run 128-row tiles, a ragged remainder of up to two rounds of 16-row workgroups that split K four ways runs in
  * a second launch (no scores buffer, no separate row kernel), and `stats` / `expect` (the M-step statistics of
@@ -384,7 +384,7 @@ int pm_bsc_estep_fused8_nz_f64(const double *Y, int64_t ldy, const double *Wt, i
  * result never visits the host; values below log(2^-1075) mean "keep all", bsc_et.py:253) into `stats` -- Wq pair block,
  * mus = qdiag, sum q e, sum lse, kept count, i.e. what the in-pass statistics of the kept datapoints would have been
  * (bsc_et.py:334-366, 395-415) -- and empties the lists (zeroes the dense rows) of the others, so that
- * pm_bsc_wp_sparse_expand_f64 / pm_gemm_tn_acc_gated_f64 behind it see kept datapoints only.  H <= 256, Hprime = 8. */
+ * pm_bsc_wp_sparse_expand_f64 / pm_gemm_tn_acc_gated_f64 behind it see kept datapoints only.  H <= 256, Hprime = 5 .. 8. */
 #define PM_BSC_DEFER_LD 40
 int pm_bsc_estep_fused8_defer_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
                                   const double *ynorm2, const double *wmu, const double *ymu,

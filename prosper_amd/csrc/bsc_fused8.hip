@@ -1,5 +1,5 @@
 // Binary Sparse Coding: scores GEMM + select_Hprimes + E_step (+ the M-step's row statistics) in ONE kernel
-// (bsc_et.py:98-192, 334-366, 395-415), config 2's shape class: H in (128, 256], H' = 8, gamma in {3, 4}.
+// (bsc_et.py:98-192, 334-366, 395-415), config 2's shape class: H in (128, 256], H' in 5 .. 8 (round 6; H' = 8 until then), gamma in {3, 4}.
 //
 // A workgroup of SIXTEEN wavefronts owns 128 datapoints x 256 latents (one workgroup per CU): wavefront (rg, half) =
 // (wave & 7, wave >> 3) accumulates datapoints 16 rg .. 16 rg + 15 against latents 128 half .. 128 half + 127 -- 64
@@ -397,9 +397,13 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
     constexpr int TILE_ROWS = TAIL ? TAIL_ROWS : 128, NPASS = TAIL ? 1 : 4;
     constexpr int NWAVES = W16 ? 16 : 8, RGMASK = W16 ? 7 : 3, HSHIFT = W16 ? 3 : 2;
     constexpr int S = SS::S;
-    constexpr int O_D = 8, O_G = 8 * 9, O_E = 8 * (9 + HP * HP);          // byte offsets inside P = [zero | d | G | e]
-    static_assert(9 + HP * HP + S <= 256 && S <= S_MAX8, "P = [zero | d (8) | G | e] must fit the 2 KB list area");
-    static_assert(HP == 8, "lane <-> Gram entry mapping below assumes H' = 8");
+    // (round 6: H' = 5 .. 8.  The LAYOUT stays that of eight candidate positions -- the lane <-> Gram entry mapping, the 8 x 8
+    // block in P, the 36-entry pair block --, positions H' .. 7 hold latent 0 and no state refers to them; the selection pops
+    // H' winners and the state set is that of H' positions.)
+    constexpr int PH = 8;
+    constexpr int O_D = 8, O_G = 8 * 9, O_E = 8 * (9 + PH * PH);          // byte offsets inside P = [zero | d | G | e]
+    static_assert(9 + PH * PH + S <= 256 && S <= S_MAX8, "P = [zero | d (8) | G | e] must fit the 2 KB list area");
+    static_assert(HP >= 4 && HP <= PH && GAMMA <= HP, "H' between 4 and the eight positions of the layout");
     extern __shared__ __attribute__((aligned(1024))) double sm[];
 
     const int tid = threadIdx.x;
@@ -488,14 +492,14 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
         const int b0 = __builtin_ctz(rest);
         const unsigned e0 = (g == 2) ? (unsigned)(O_D + 8 * b0) : (unsigned)(O_E + 8 * par);
         const unsigned e1 = O_D + 8 * k;
-        const unsigned e2 = O_G + 8 * (b0 * HP + k);
+        const unsigned e2 = O_G + 8 * (b0 * PH + k);
         unsigned e3 = 0, e4 = 0;
         rest &= rest - 1;
         if (rest) {
-            e3 = O_G + 8 * (__builtin_ctz(rest) * HP + k);
+            e3 = O_G + 8 * (__builtin_ctz(rest) * PH + k);
             rest &= rest - 1;
         }
-        if (rest) e4 = O_G + 8 * (__builtin_ctz(rest) * HP + k);
+        if (rest) e4 = O_G + 8 * (__builtin_ctz(rest) * PH + k);
         uint32_t *dst = reinterpret_cast<uint32_t *>(smem + T_ST + 16 * s);
         dst[0] = e0 | (e1 << 16);
         dst[1] = e2 | (e3 << 16);
@@ -660,6 +664,8 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
         if (j32 < HP) {
             ac = reinterpret_cast<const double *>(area + A_ROW)[myc];
             cl[j32] = myc;
+        } else if (HP < PH && j32 < PH) {
+            cl[j32] = 0;             // (an unused position: a valid latent for the Gram fetch below, never part of a state)
         }
         // Gram block of the candidates, requested NOW (an L2 round trip that the barrier, the next pass's score rows and the
         // singleton log-joints below cover): lane j32 fetches G[c_i, c_k] and G[c_(i+4), c_k], i = j32 >> 3, k = j32 & 7
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
         Pm[9 + j32] = G0;
         Pm[9 + 32 + j32] = G1;
         wave_lds_sync16();
-        if (j32 < HP) Pm[1 + j32] = Pm[9 + (HP + 1) * j32] - 2.0 * (ac - wmuc);     // d_k = G_kk - 2 a_k
+        if (j32 < HP) Pm[1 + j32] = Pm[9 + (PH + 1) * j32] - 2.0 * (ac - wmuc);     // d_k = G_kk - 2 a_k
         if (j32 == 0) Pm[0] = 0.0;
         wave_lds_sync16();
         F8_ESTAMP(r * 8 + 4);
@@ -998,7 +1004,8 @@ __global__ __launch_bounds__(TAIL ? THREADS : 1024, TAIL ? 2 : 4) void bsc_estep
 __global__ __launch_bounds__(256) void bsc_defer_apply_kernel(
     const double *__restrict__ lse, const double *__restrict__ cut_dev, const int32_t *__restrict__ cand,
     const double *__restrict__ rec, uint16_t *__restrict__ nz_idx, const double *__restrict__ nz_val,
-    double *__restrict__ expect, int64_t lde, double *__restrict__ stats, int64_t N, int H, int Dstats, double ecoef) {
+    double *__restrict__ expect, int64_t lde, double *__restrict__ stats, int64_t N, int H, int Dstats, double ecoef,
+    int Hp) {
     __shared__ double s_mus[256];
     __shared__ double s_red[3][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1018,13 +1025,15 @@ __global__ __launch_bounds__(256) void bsc_defer_apply_kernel(
         const int64_t n = t / PM_BSC_DEFER_LD;
         const int e = (int)(t - n * PM_BSC_DEFER_LD);
         const int ec = e < PAIR_ENTRIES ? e : 0;
-        const int pk = (ec >= 1) + (ec >= 3) + (ec >= 6) + (ec >= 10) + (ec >= 15) + (ec >= 21) + (ec >= 28);
-        const int pi = ec - pk * (pk + 1) / 2;
+        int pk = (ec >= 1) + (ec >= 3) + (ec >= 6) + (ec >= 10) + (ec >= 15) + (ec >= 21) + (ec >= 28);
+        int pi = ec - pk * (pk + 1) / 2;
+        pk = pk < Hp ? pk : 0;             // (positions H' .. 7 of the layout carry zeros: any valid candidate will do for the load)
+        pi = pi < Hp ? pi : 0;
         // (all four loads leave before any of them is looked at: a dropped datapoint's record is read for nothing, but no
         // load waits for another)
         const double l = lse[n];
         const double v = rec[t];
-        const int ci = cand[n * 8 + pi], ck = cand[n * 8 + pk];
+        const int ci = cand[n * Hp + pi], ck = cand[n * Hp + pk];
         if (e > PAIR_ENTRIES + 1 || !(l >= cut)) continue;
         if (e < PAIR_ENTRIES) {
             if (v != 0.0) {
@@ -1099,12 +1108,23 @@ extern "C" int pm_f8_read_estamps(unsigned long long *host) {
 }
 #endif
 
-// The kernel covers config 2's shape class: 128 < H <= 256 latents, H' = 8 candidates, the complete state set of sizes
+// The kernel covers config 2's shape class: 128 < H <= 256 latents, H' = 5 .. 8 candidates, the complete state set of sizes
 // 2 .. gamma for gamma in {3, 4} (what generate_state_matrix builds: S = 84 / 154), D a multiple of 8.  Everything else
 // takes the 4-wavefront kernel of bsc_fused.hip or the two-kernel path.
+// number of multi-cause states of the complete state set of sizes 2 .. gamma over hp candidate positions (0: not an instance)
+static int fused8_states(int64_t hp, int64_t gamma) {
+    if (hp < 5 || hp > 8 || gamma < 3 || gamma > 4) return 0;
+    int s = 0, c = (int)hp;
+    for (int g = 2; g <= (int)gamma; ++g) {
+        c = c * ((int)hp - g + 1) / g;              // C(hp, g) from C(hp, g - 1)
+        s += c;
+    }
+    return s;
+}
+
 extern "C" int pm_bsc_fused8_supported(int64_t H, int64_t D, int64_t Hprime, int64_t S) {
-    if (H <= 128 || H > 256 || D < DK || D % DK != 0 || Hprime != 8) return 0;
-    return (S == StateSet<8, 4>::S || S == StateSet<8, 3>::S) ? 1 : 0;
+    if (H <= 128 || H > 256 || D < DK || D % DK != 0 || Hprime < 5 || Hprime > 8) return 0;
+    return (S > 0 && (S == fused8_states(Hprime, 3) || S == fused8_states(Hprime, 4))) ? 1 : 0;
 }
 
 // pm_bsc_estep_fused8_f64 takes a WHOLE shard in one call -- whole rounds of 128-row tiles plus the TAIL kernel for a
@@ -1125,8 +1145,8 @@ extern "C" int64_t pm_bsc_fused8_main_rows(int64_t N, int64_t D) {
 }
 
 extern "C" int pm_bsc_fused8_whole_shard(int64_t H, int64_t Hprime, int64_t gamma, int64_t S) {
-    if (H <= 128 || H > 256 || Hprime != 8) return 0;
-    return ((gamma == 4 && S == StateSet<8, 4>::S) || (gamma == 3 && S == StateSet<8, 3>::S)) ? 1 : 0;
+    if (H <= 128 || H > 256) return 0;
+    return (S > 0 && S == fused8_states(Hprime, gamma)) ? 1 : 0;
 }
 
 extern "C" int pm_bsc_estep_fused8_f64(const double *Y, int64_t ldy, const double *Wt, int64_t ldw, const double *gram,
@@ -1161,12 +1181,12 @@ extern "C" int pm_bsc_defer_apply_f64(const double *lse, const double *cut, cons
                                       int64_t Hprime, void *stream) {
     if (!lse || !cut || !cand || !records || !nz_idx || !nz_val || !expect || !stats || !params_host || N < 0 || lde < H)
         return PM_EINVAL;
-    if (H <= 0 || H > 256 || Hprime != 8 || D <= 0 || params_host->ecoef == 0.0) return PM_ERANGE;
+    if (H <= 0 || H > 256 || Hprime < 5 || Hprime > 8 || D <= 0 || params_host->ecoef == 0.0) return PM_ERANGE;
     if (N == 0) return PM_OK;
     int64_t blocks = (N * PM_BSC_DEFER_LD + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(bsc_defer_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), lse,
-                       cut, cand, records, nz_idx, nz_val, expect, lde, stats, N, (int)H, (int)D, params_host->ecoef);
+                       cut, cand, records, nz_idx, nz_val, expect, lde, stats, N, (int)H, (int)D, params_host->ecoef, (int)Hprime);
     return (int)hipGetLastError();
 }
 
@@ -1193,22 +1213,34 @@ extern "C" int pm_bsc_estep_fused8_defer_f64(const double *Y, int64_t ldy, const
     if (N == 0) return PM_OK;
     pm_bsc_estep_params P = params_host ? *params_host : pm_bsc_estep_params{0, 0, 0, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // H' = 8 and the complete state set of sizes 2 .. gamma (what generate_state_matrix builds), in its order
+    // H' = 5 .. 8 and the complete state set of sizes 2 .. gamma (what generate_state_matrix builds), in its order
     if (!pm_bsc_fused8_whole_shard(H, Hprime, gamma, S)) return PM_ERANGE;
-    if ((mode & 2) && S > 0)
-        for (int g = 2; g <= gamma; ++g)
-            if (size_offsets_host[g - 2] != (gamma == 4 ? StateSet<8, 4>::off(g) : StateSet<8, 3>::off(g))) return PM_EINVAL;
+    if ((mode & 2) && S > 0) {
+        int off = 0, c = (int)Hprime;
+        for (int g = 2; g <= gamma; ++g) {
+            if (size_offsets_host[g - 2] != off) return PM_EINVAL;
+            c = c * ((int)Hprime - g + 1) / g;
+            off += c;
+        }
+    }
     const size_t shmem_s = (size_t)LEAN16_LDS_BYTES;      // (>= the ring: 4 stages x 24 KB)
-#define PM_LAUNCH8SMT(G, F, M, T, GRID, SH, NN, R0)                                                                    \
+#define PM_LAUNCH8SMTH(HPV, G, F, M, T, GRID, SH, NN, R0)                                                              \
     do {                                                                                                               \
-        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), \
+        if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(bsc_estep_fused8s_kernel<4, HPV, G, F, M, T>), \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SH)))                   \
             return e;                                                                                                  \
-        hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, 8, G, F, M, T>), dim3((unsigned)(GRID)),                       \
+        hipLaunchKernelGGL((bsc_estep_fused8s_kernel<4, HPV, G, F, M, T>), dim3((unsigned)(GRID)),                     \
                            dim3((T) ? THREADS : 1024), (SH), s, Y, ldy,                                                \
                            Wt, ldw, (int)D, gram, ynorm2, wmu, ymu, state_masks, state_parents, P, (int64_t)(NN),    \
                            (int)H, mode, cand, logpj, ldl, lse, expect, lde, stats, (int)D_stats, (int64_t)(R0),      \
                            nz_idx, nz_val, records);                                                                   \
+    } while (0)
+#define PM_LAUNCH8SMT(G, F, M, T, GRID, SH, NN, R0)                                  \
+    do {                                                                             \
+        if (Hprime == 8) PM_LAUNCH8SMTH(8, G, F, M, T, GRID, SH, NN, R0);            \
+        else if (Hprime == 7) PM_LAUNCH8SMTH(7, G, F, M, T, GRID, SH, NN, R0);       \
+        else if (Hprime == 6) PM_LAUNCH8SMTH(6, G, F, M, T, GRID, SH, NN, R0);       \
+        else PM_LAUNCH8SMTH(5, G, F, M, T, GRID, SH, NN, R0);                        \
     } while (0)
 #define PM_LAUNCH8ST(G, F, T, GRID, SH, NN, R0)            \
     do {                                                    \
@@ -1241,6 +1273,7 @@ extern "C" int pm_bsc_estep_fused8_defer_f64(const double *Y, int64_t ldy, const
 #undef PM_LAUNCH8SGF
 #undef PM_LAUNCH8ST
 #undef PM_LAUNCH8SMT
+#undef PM_LAUNCH8SMTH
     return (int)hipGetLastError();
 }
 

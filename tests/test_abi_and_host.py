@@ -446,7 +446,8 @@ def test_shipped_hot_kernels_do_not_spill(tmp_path):
     assert not bad, bad
     # <STAGES, H', gamma, FULL, MSTATS, TAIL = false>: the 16-wavefront main launch, <= 128 registers (4 wavefronts per SIMD)
     main = {n: md for n, md in seen.items() if "bsc_estep_fused8s_kernel" in n and n.split("EEEv")[0].endswith("ELb0")}
-    assert len(main) == 8 and all(md[".vgpr_count"] <= 128 for md in main.values()), main
+    # (round 6: H' = 5 .. 8 -> four times the eight instantiations of <gamma, FULL, MSTATS>)
+    assert len(main) == 32 and all(md[".vgpr_count"] <= 128 for md in main.values()), main
     gsc = [md for n, md in seen.items() if "gsc_estep_kernel" in n]
     assert gsc and all(md[".vgpr_count"] <= 168 for md in gsc), gsc          # three wavefronts per SIMD
 

@@ -44,6 +44,9 @@ def _recorded(m):
     (512, 256, 8, 4, 6000, 50.0, 0.9, 1.05),      # hot: lists overflow, the dense product runs behind its gate
     (1024, 256, 8, 4, 3000, 1.0, 0.5, 0.3),       # every log-evidence below log(2^-1075): the reference keeps ALL (bsc_et.py:253)
     (256, 256, 8, 4, 33000, 1.0, 1.0, 1.05),      # Ncut_factor = 1: the plateau of the reference's schedule
+    (128, 256, 6, 3, 40000, 1.0, 0.6, 1.05),      # H' = 6, 5, 7 on the 16-wavefront kernel (round 6: the layout of eight
+    (64, 192, 5, 4, 36000, 1.3, 0.4, 1.05),       # candidate positions, the state set of H')
+    (96, 200, 7, 4, 5000, 1.0, 0.8, 1.05),
 ])
 def test_deferred_statistics_match_two_pass_and_oracle(dev, D, H, Hp, gamma, N, T, ncut, sigma0):
     from oracle import bsc_oracle as O

@@ -745,7 +745,9 @@ def _expect_of(m):
     return E
 
 
-@pytest.mark.parametrize("D,H,Hp,gamma,N", [(1024, 256, 8, 4, 40000), (64, 200, 7, 3, 3000), (25, 10, 5, 3, 333)])
+@pytest.mark.parametrize("D,H,Hp,gamma,N", [(1024, 256, 8, 4, 40000), (64, 200, 7, 3, 3000), (25, 10, 5, 3, 333),
+                                            # round 6: H' = 5 .. 7 on the 16-wavefront kernel (main launch + TAIL)
+                                            (128, 256, 6, 3, 40000), (64, 192, 5, 4, 36000), (64, 200, 7, 4, 34000)])
 def test_step_with_fused_mstep_statistics(dev, D, H, Hp, gamma, N):
     """Inside ``step`` with no data truncation ahead the fused E-step kernel also produces the M-step's per-datapoint
     statistics (E[s] rows, Wq block, mus, scalars; the ragged last round of a large shard still goes through
