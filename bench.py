@@ -349,7 +349,10 @@ def other_shapes(dev, Anneal, budget_s=40.0):
                 rec["skipped"] = "time budget"
                 out.append(rec)
                 continue
-            N = int(min(200_000, (1.2e9 / (8 * D)) // 1024 * 1024))
+            # whole rounds of 128-row tiles on 256 CUs (32768 datapoints): what a large shard amounts to -- a ragged last
+            # round costs every tiled kernel a whole tile time (config 2's own N = 200 000 is 6.1 rounds; rounds 4-5 used
+            # multiples of 1024 here and timed 4.47 rounds as 5 on the one-kernel paths)
+            N = int(min(200_000, 1.2e9 / (8 * D)) // 32768 * 32768)
             g = torch.Generator(device=dev).manual_seed(0)
             W_gt = torch.randn(D, H, generator=g, device=dev, dtype=torch.float64)
             Y = torch.empty(N, D, dtype=torch.float64, device=dev)
