@@ -686,7 +686,7 @@ int pm_gsc_estep_f64(const double *scores, int64_t lds, const double *gram, cons
  * format of pm_bsc_estep_fused8_nz_f64; for pm_wp_sparse_t_f64), any other row an empty list and its index in
  * dense_rows[0 .. *dense_count) (for pm_gemm_tn_acc_rows_f64; *dense_count = 0 at launch; order as the workgroups finish).
  * nz_val holds TWO planes of N x PM_BSC_NZ_MAX doubles: xpt_sz at the listed entries, then xpt_s at them (pm_gsc_list_pairs_f64).
- * The threshold is written by pm_gsc_mstep_finish_f64 (2^-75 of the smallest |column sum| of xpt_sz over all ranks: what
+ * The threshold is written by pm_gsc_mstep_finish_f64 (2^-57 / N of the smallest |column sum| of xpt_sz over all ranks: what
  * the lists drop is below the rounding of the sums); 0 keeps every row dense.  Where pm_gsc_lists_supported(H, Hprime,
  * gamma, D), else PM_ERANGE. */
 int pm_gsc_lists_supported(int64_t H, int64_t Hprime, int64_t gamma, int64_t D);

@@ -171,9 +171,9 @@ __device__ unsigned long long pm_gsc_stamps[32][12][10];
 // A row of xpt_sz whose entries above `thr` number at most PM_BSC_NZ_MAX leaves them as a list (format of the BSC / DSC
 // statistics passes: nz_idx uint16 x 16 with 0xFFFF behind the last, nz_val f64 x 16) for pm_wp_sparse_t_f64; any other row
 // gets an empty list and its index appended to `dense_rows` (gathered by the workgroup in LDS, ONE global atomic on
-// *dense_count per workgroup) for pm_gemm_tn_acc_rows_f64.  thr = tables[8 H + 1]: 2^-75 of the smallest |column sum| of
+// *dense_count per workgroup) for pm_gemm_tn_acc_rows_f64.  thr = tables[8 H + 1]: 2^-57 / N of the smallest |column sum| of
 // xpt_sz of the previous EM step (pm_gsc_mstep_finish_f64) -- what a list drops from a column of the product is below
-// N thr max|left operand| <= 2^-57 of that column's own scale for N <= 2^18 (2^-52: N = 8 M), under the rounding of the sums
+// N thr max|left operand| <= 2^-57 of that column's own scale for ANY N (round 6: N is the all-ranks count the finish kernel gets), under the rounding of the sums
 // themselves; thr = 0 (first step, a dead latent's column) keeps everything: every row is dense then, correct and slow.
 constexpr int GSC_DENSE_CAP = 512;          // datapoints per workgroup in LIST mode at most (the launcher sizes the grid)
 template <int VPL, int GMAX, bool LPJ, bool LACC, bool LIST = false>
@@ -256,9 +256,9 @@ __global__ __launch_bounds__(256, (VPL <= 8 && GMAX <= 3) ? PM_GSC_WPE : 1) void
     // Entries of a datapoint's blocks below thr_p are not sent.  The pass is bound by its vector-memory traffic, and the sixty
     // f64 atomics per datapoint are the largest single item of it (a build without them runs 0.09 ms of 0.63 faster at config
     // 4); most datapoints put all their weight on one or two states, so that all but a few entries of their blocks are
-    // ~1e-20 of the others.  thr_p = 2^-75 of the smallest diagonal entry of the PREVIOUS EM step's all-reduced sums (tables[8 H
+    // ~1e-20 of the others.  thr_p = 2^-57 / N of the smallest diagonal entry of the PREVIOUS EM step's all-reduced sums (tables[8 H
     // + 2], pm_gsc_mstep_finish_f64; 0 -- everything is sent -- when the tables come from the host): what is dropped from any
-    // entry of sum xpt_ss / sum xpt_szsz stays below N thr_p <= 2^-57 of the smallest diagonal entry for N <= 2^18, under the
+    // entry of sum xpt_ss / sum xpt_szsz stays below N thr_p = 2^-57 of the smallest diagonal entry whatever N is, under the
     // rounding of the diagonal sums themselves -- nothing the inverses, the element-wise psi_sq update or sigma_sq can see.
     const double thr_p = (inv_s2_host != 0.0 || H <= 2) ? 0.0 : T.c0[8 * (int64_t)H + 2];
 
@@ -849,8 +849,11 @@ __global__ __launch_bounds__(1024) void gsc_mstep_finish_kernel(
         if (tid < w) s_red[tid] = fmin(s_red[tid], s_red[tid + w]);
         __syncthreads();
     }
-    if (tid == 0 && H > 1) tables[8 * H + 1] = ldexp(s_red[0], -75);
-    // tables[8 H + 2]: below this an entry of a datapoint's pair blocks is not sent (gsc_estep_kernel, thr_p): 2^-75 of the smallest
+    // (2^-57 / N of it: whatever the lists drop from a column over all N datapoints of all ranks stays below 2^-57 of that
+    // column's scale -- round-5 advisor finding: the fixed 2^-75 assumed N <= 2^18)
+    const double n_all = N > 1.0 ? N : 1.0;
+    if (tid == 0 && H > 1) tables[8 * H + 1] = ldexp(s_red[0], -57) / n_all;
+    // tables[8 H + 2]: below this an entry of a datapoint's pair blocks is not sent (gsc_estep_kernel, thr_p): 2^-57 / N of the smallest
     // diagonal entry of sum xpt_ss (= sum xpt_s) and sum xpt_szsz
     __syncthreads();
     s_red[tid] = tid < H ? fmin(fabs(sum_s[tid]), fabs(sum_zz[(int64_t)tid * H + tid])) : INFINITY;
@@ -859,7 +862,7 @@ __global__ __launch_bounds__(1024) void gsc_mstep_finish_kernel(
         if (tid < w) s_red[tid] = fmin(s_red[tid], s_red[tid + w]);
         __syncthreads();
     }
-    if (tid == 0 && H > 2) tables[8 * H + 2] = ldexp(s_red[0], -75);
+    if (tid == 0 && H > 2) tables[8 * H + 2] = ldexp(s_red[0], -57) / n_all;
 }
 }  // namespace
 

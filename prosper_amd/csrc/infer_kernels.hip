@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void infer_topk_signed_kernel(const double *__
                     }
                 }
                 pm_wave_argmax(bv, bi);
-                if (r > 0 && bi >= 0 && bv == pv) tied = 1;
+                // (a tie in what upstream RANKS -- the normalised lpc = logpj - lse, tsc_et.py:620-626: two distinct log-joints can
+                // round to the same lpc, and argsort's order among equals is not a function of (value, index): those rows go to
+                // NumPy as the exactly tied ones do; round-5 advisor finding)
+                if (r > 0 && bi >= 0 && (bv == pv || (bv - lse) == (pv - lse))) tied = 1;
                 if (r < topK && lane == 0) top_idx[n * topK + r] = bi;
                 pv = bv;
                 pi = bi;

@@ -377,11 +377,13 @@ def test_gsc_mstep_finish_kernel(H, D, learn):
     lam = Gd / s2 + 1. / psid
     want = np.stack([-(np.log(psid) + np.log(lam)) - mu * mu * Gd / s2, 2. * mu / s2, Gd * mu, 1. / (lam * s2 * s2),
                      1. / (lam * s2), 1. / lam, mu, np.log(pi) - np.log(1 - pi), np.full(H, 1. / s2)])
-    want[8, 1] = float(np.abs(sum_sz).min()) * 2.0 ** -75     # the list threshold of the next E-step (pm_gsc_estep_lists_f64)
+    # the list threshold of the next E-step (pm_gsc_estep_lists_f64): 2^-57 / N of the smallest column sum (round 6: the
+    # all-ranks N the kernel is given, not a fixed 2^-75 that assumed N <= 2^18)
+    want[8, 1] = float(np.abs(sum_sz).min()) * 2.0 ** -57 / max(float(N), 1.0)
     thr_got, tab[8, 1] = tab[8, 1], want[8, 1]
     np.testing.assert_allclose(thr_got, want[8, 1], rtol=1e-14)
     # ... and the threshold below which an entry of a datapoint's pair blocks is not sent (gsc_estep_kernel, thr_p)
-    want[8, 2] = min(float(np.abs(sum_s).min()), float(np.abs(np.diag(sum_zz)).min())) * 2.0 ** -75
+    want[8, 2] = min(float(np.abs(sum_s).min()), float(np.abs(np.diag(sum_zz)).min())) * 2.0 ** -57 / max(float(N), 1.0)
     thr_got, tab[8, 2] = tab[8, 2], want[8, 2]
     np.testing.assert_allclose(thr_got, want[8, 2], rtol=1e-14)
     np.testing.assert_allclose(tab, want, rtol=1e-10, atol=1e-12)
