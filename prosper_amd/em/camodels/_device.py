@@ -739,10 +739,10 @@ class DeviceCAModel(CAModel):
             # The LONG form (scaled start, eight + one steps, ~60 us) where the start is likely to be far: the step after
             # one whose start was (``_warm_long``: _solve_accurate), and data-truncation steps, whose kept set can jump
             # (``_warm_force_long``, set by the model's M_step) -- the short form would hand those to the 0.3 ms sweep.
-            # (truncation steps take it only while a far start is recent -- within sixteen steps: on data whose kept set does
-            # not jump the short form is accepted on every step of the ramp and is 0.04 ms cheaper)
-            long = getattr(self, "_warm_long", False) or (getattr(self, "_warm_force_long", False)
-                                                            and getattr(self, "_warm_reject_age", 1000) < 16)
+            # (Measured and dropped: the long form on truncation steps only while a far start is recent.  On the ramp the start
+            # residual has norm ~0.08 in every direction: R_0^8 lands at 2-3e-8 in the Frobenius norm, just above the short
+            # form's guard, and the step pays the sweep -- the schedule's mean went 2.43 -> 2.49 ms.)
+            long = getattr(self, "_warm_long", False) or getattr(self, "_warm_force_long", False)
             self._call("spd_inverse", "pm_spd_inverse_warm_long_f64" if long else "pm_spd_inverse_warm_f64", _ptr(Wq_u), H,
                        _ptr(qdiag), H, _ptr(prev), H, _ptr(work), _ptr(Wq), _ptr(Winv), H, _ptr(piv), self._stream())
         else:
@@ -841,8 +841,6 @@ class DeviceCAModel(CAModel):
         last, self._last_solve = getattr(self, "_last_solve", None), None
         self._refine_next = (flag == 0.0)
         self._warm_long = (flag != 1.0)       # (a far start this time: the scaled long form next time)
-        # (steps since the last start that was far -- rejected, or accepted from a start residual above 1)
-        self._warm_reject_age = 0 if flag != 1.0 else getattr(self, "_warm_reject_age", 1000) + 1
         if flag != 0.0 or last is None:
             return None
         Wq, Winv, rhs = last
