@@ -688,7 +688,9 @@ class BSC_ET(DeviceCAModel):
             # The E-step pass has left every datapoint's statistics as a record beside its non-zero list (a data-truncation
             # step: _want_ms): the cut is selected ON THE DEVICE and stays there, pm_bsc_defer_apply_f64 adds the records of
             # the datapoints above it and empties the lists of the others -- no host round trip, no second pass over the
-            # 665 MB of log-joints (round 6; pm_bsc_mstep_rows16_nz_f64 before: 0.42 ms + a device idle for the cut)
+            # 665 MB of log-joints (round 6; pm_bsc_mstep_rows16_nz_f64 before: 0.42 ms + a device idle for the cut).
+            # (Measured and dropped: the kept datapoints' half of the apply kernel on a second stream beside the sparse
+            # product -- 2.36-2.41 ms per step either way, scratch/em_ncut_wall.py: what one gains the other loses.)
             tracing.tracepoint("M_step:truncating")
             if ncut:
                 cut_dev = self._kth_select_dev(lse, N_use)
