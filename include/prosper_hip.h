@@ -214,6 +214,13 @@ int pm_kth_round_f64(const double *x, int64_t n, uint64_t *states, uint64_t *his
                      int shift, int bits, void *stream);
 int pm_kth_final_f64(uint64_t *states, const uint64_t *hists, int rounds, int shift_prev, int bits_prev, double *out,
                      void *stream);
+/* ... without the fill in front: pm_kth_round_k_f64 (round 0 only) takes the rank k0 as an argument instead of from states[1],
+ * pm_kth_final_z_f64 with rezero != 0 leaves the `rounds` histograms zeroed for the next select on the same buffer (which the
+ * caller zeroes once, when it allocates it). */
+int pm_kth_round_k_f64(const double *x, int64_t n, uint64_t *states, uint64_t *hists, int round, int shift_prev, int bits_prev,
+                       int shift, int bits, int64_t k0, void *stream);
+int pm_kth_final_z_f64(uint64_t *states, uint64_t *hists, int rounds, int shift_prev, int bits_prev, double *out, int rezero,
+                       void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Binary Sparse Coding (prosper/em/camodels/bsc_et.py)

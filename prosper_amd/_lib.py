@@ -56,6 +56,8 @@ SIGNATURES = {
     "pm_kth_value_f64": (C.c_int, [c_dp, c_dp, c_dp]),
     "pm_kth_round_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_dp]),
     "pm_kth_final_f64": (C.c_int, [c_dp, c_dp, C.c_int, C.c_int, C.c_int, c_dp, c_dp]),
+    "pm_kth_round_k_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i64, c_dp]),
+    "pm_kth_final_z_f64": (C.c_int, [c_dp, c_dp, C.c_int, C.c_int, C.c_int, c_dp, C.c_int, c_dp]),
     "pm_bsc_select_f64": (C.c_int, [c_dp, i64, c_dp, i64, c_dp, i64, i64, i64, c_dp, c_dp]),
     "pm_bsc_estep_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, i64,
                                    C.POINTER(EStepParams), i64, i64, i64, c_dp, i64, c_dp, c_dp]),

@@ -173,7 +173,7 @@ __device__ __forceinline__ void kth_scan_block(const unsigned long long *__restr
 __global__ __launch_bounds__(256) void kth_round_kernel(const double *__restrict__ x, int64_t n,
                                                          unsigned long long *__restrict__ states,
                                                          unsigned long long *__restrict__ hists, int round,
-                                                         int shift_prev, int bits_prev, int shift, int bits) {
+                                                         int shift_prev, int bits_prev, int shift, int bits, long long k0) {
     __shared__ unsigned int s_h[BINS];
     __shared__ unsigned long long s_chunk[256];
     __shared__ int s_pick;
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256) void kth_round_kernel(const double *__restrict
             states[2 * round + 1] = s_state[1];
         }
     } else {
-        if (threadIdx.x < 2) s_state[threadIdx.x] = states[threadIdx.x];
+        // (k0 >= 0: the rank comes as an argument -- nothing has to be written into the buffer in front of a select, whose
+        // histograms the previous select's final kernel has left zeroed; workgroup 0 records it for the scan of round 1)
+        if (threadIdx.x < 2) s_state[threadIdx.x] = k0 >= 0 ? (threadIdx.x ? (unsigned long long)k0 : 0ull) : states[threadIdx.x];
+        if (k0 >= 0 && blockIdx.x == 0 && threadIdx.x < 2) states[threadIdx.x] = threadIdx.x ? (unsigned long long)k0 : 0ull;
         __syncthreads();
     }
     const int top = shift + bits;                     // bits [top, 64) are decided
@@ -209,8 +212,8 @@ __global__ __launch_bounds__(256) void kth_round_kernel(const double *__restrict
 
 // the last round's scan and the conversion back to a double
 __global__ __launch_bounds__(256) void kth_final_kernel(unsigned long long *__restrict__ states,
-                                                         const unsigned long long *__restrict__ hists, int rounds,
-                                                         int shift_prev, int bits_prev, double *__restrict__ out) {
+                                                         unsigned long long *__restrict__ hists, int rounds,
+                                                         int shift_prev, int bits_prev, double *__restrict__ out, int rezero) {
     __shared__ unsigned long long s_chunk[256];
     __shared__ int s_pick;
     __shared__ unsigned long long s_state[2];
@@ -221,6 +224,11 @@ __global__ __launch_bounds__(256) void kth_final_kernel(unsigned long long *__re
         states[2 * rounds] = s_state[0];
         states[2 * rounds + 1] = s_state[1];
         out[0] = value_of(s_state[0]);
+    }
+    // (rezero: the histograms are left zeroed for the next select on this buffer -- no fill launch in front of it)
+    if (rezero) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < rounds * BINS; i += 256) hists[i] = 0ull;
     }
 }
 
@@ -260,6 +268,12 @@ extern "C" int pm_kth_value_f64(const uint64_t *state, double *out, void *stream
 
 extern "C" int pm_kth_round_f64(const double *x, int64_t n, uint64_t *states, uint64_t *hists, int round, int shift_prev,
                                 int bits_prev, int shift, int bits, void *stream) {
+    return pm_kth_round_k_f64(x, n, states, hists, round, shift_prev, bits_prev, shift, bits, -1, stream);
+}
+
+extern "C" int pm_kth_round_k_f64(const double *x, int64_t n, uint64_t *states, uint64_t *hists, int round, int shift_prev,
+                                  int bits_prev, int shift, int bits, int64_t k0, void *stream) {
+    if (k0 >= 0 && round != 0) return PM_EINVAL;
     if (n < 0 || !states || !hists || round < 0 || round > 5 || shift < 0 || bits < 1 || bits > 12 || shift + bits > 64 ||
         (n > 0 && !x) || (round > 0 && (shift_prev < 0 || bits_prev < 1 || bits_prev > 12 || shift_prev + bits_prev > 64)))
         return PM_EINVAL;
@@ -269,17 +283,22 @@ extern "C" int pm_kth_round_f64(const double *x, int64_t n, uint64_t *states, ui
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kth_round_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n,
                        reinterpret_cast<unsigned long long *>(states), reinterpret_cast<unsigned long long *>(hists), round,
-                       shift_prev, bits_prev, shift, bits);
+                       shift_prev, bits_prev, shift, bits, (long long)k0);
     return (int)hipGetLastError();
 }
 
 extern "C" int pm_kth_final_f64(uint64_t *states, const uint64_t *hists, int rounds, int shift_prev, int bits_prev, double *out,
                                 void *stream) {
+    return pm_kth_final_z_f64(states, const_cast<uint64_t *>(hists), rounds, shift_prev, bits_prev, out, 0, stream);
+}
+
+extern "C" int pm_kth_final_z_f64(uint64_t *states, uint64_t *hists, int rounds, int shift_prev, int bits_prev, double *out,
+                                  int rezero, void *stream) {
     if (!states || !hists || !out || rounds < 1 || rounds > 6 || shift_prev < 0 || bits_prev < 1 || bits_prev > 12 ||
         shift_prev + bits_prev > 64)
         return PM_EINVAL;
     hipLaunchKernelGGL(kth_final_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<unsigned long long *>(states), reinterpret_cast<const unsigned long long *>(hists),
-                       rounds, shift_prev, bits_prev, out);
+                       reinterpret_cast<unsigned long long *>(states), reinterpret_cast<unsigned long long *>(hists),
+                       rounds, shift_prev, bits_prev, out, rezero);
     return (int)hipGetLastError();
 }

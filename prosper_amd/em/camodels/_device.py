@@ -948,23 +948,28 @@ class DeviceCAModel(CAModel):
         lse = lse.contiguous()
         dev = lse.device
         n = int(lse.shape[0])
-        # one buffer, one fill: [states: 7 x (prefix, k) | pad | 6 histograms of 4096 bins]; slot 0 <- (0, N_use)
-        buf = torch.zeros(16 + 6 * 4096, dtype=torch.int64, device=dev)
-        buf[1:2].fill_(int(N_use))
+        # one persistent buffer [states: 7 x (prefix, k) | pad | 6 histograms of 4096 bins], zeroed when it is allocated and
+        # left zeroed by every select's final kernel; the rank travels as an argument of round 0: 6 + 1 launches, no fills
+        ws = self.__dict__.get("_kth_buf")
+        if ws is None or ws[0].device != dev or ws[1]:
+            ws = self._kth_buf = [torch.zeros(16 + 6 * 4096, dtype=torch.int64, device=dev), False]
+        ws[1] = True                   # (dirty until the final kernel is enqueued: an exception in between re-zeroes)
+        buf = ws[0]
         states, hists = buf[:14], buf[16:].view(6, 4096)
         st = self._stream()
         prev = (0, 1)
         for r, (shift, bits) in enumerate(self.KTH_ROUNDS):
             if r and comm.size > 1:
                 comm.allreduce_device(hists[r - 1])
-            self._call("kth_round", "pm_kth_round_f64", _ptr(lse) if n else None, n, _ptr(states), _ptr(hists), r, prev[0],
-                       prev[1], shift, bits, st)
+            self._call("kth_round", "pm_kth_round_k_f64", _ptr(lse) if n else None, n, _ptr(states), _ptr(hists), r, prev[0],
+                       prev[1], shift, bits, int(N_use) if r == 0 else -1, st)
             prev = (shift, bits)
         if comm.size > 1:
             comm.allreduce_device(hists[len(self.KTH_ROUNDS) - 1])
         out = torch.empty(1, dtype=torch.float64, device=dev)
-        self._call("kth_final", "pm_kth_final_f64", _ptr(states), _ptr(hists), len(self.KTH_ROUNDS), prev[0], prev[1],
-                   _ptr(out), st)
+        self._call("kth_final", "pm_kth_final_z_f64", _ptr(states), _ptr(hists), len(self.KTH_ROUNDS), prev[0], prev[1],
+                   _ptr(out), 1, st)
+        ws[1] = False
         return out
 
     # ------------------------------------------------------------------ inference ("next" row)

@@ -475,3 +475,13 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0.9 * 2.2e9
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # round 6: the EM-iteration wall-clock -- flat schedule and the reference's own (T and Ncut_factor ramps: the regime 49 of
+    # a canonical run's 50 steps are in) -- also inside `roofline`, the sub-dict a driver record keeps
+    if "em_iter_annealed_ms" in d:
+        for k in ("em_iter_ms", "em_iter_steady_ms", "em_iter_annealed_ms", "em_iter_annealed_ramp_ms", "em_iter_annealed_plateau_ms"):
+            assert r[k] > 0, k
+        assert abs(r["em_iter_annealed_ms"] - d["em_iter_annealed_ms"]) < 1e-12
+        a = d["em_iter_annealed"]
+        assert a["steps"] == 50 and "Ncut_factor" in a["schedule"] and a["spec_hits"] >= 40
+        # the schedule's mean stays within 1.15 of the flat steady-state figure (round 5: 1.49)
+        assert d["em_iter_annealed_ms"] < 1.15 * d["em_iter_steady_ms"], (d["em_iter_annealed_ms"], d["em_iter_steady_ms"])
