@@ -1470,7 +1470,8 @@ constexpr int DEFER_GROUPS = 64;      // datapoint groups of the scatter kernel 
 // candidates of 64 of its datapoints at once (lane = datapoint: an 8-bit mask of the candidate positions whose latent is in
 // the workgroup's range, 0 for a dropped datapoint), then walks the non-empty ones: the datapoint's y row once, each owned
 // record row in full (DPL doubles per lane), two ds_add_f64 per element.  [Measured on top of this form and not kept, all
-// within 0.46-0.51 ms: two datapoints per trip, two trips in flight (a software pipeline over the walk), and the ablations -- no
+// within 0.46-0.51 ms: two datapoints per trip, two trips in flight (a software pipeline over the walk; with the candidates kept
+// in registers and read by v_readlane it spills at 128 VGPRs: 0.58), the candidates in registers alone (0.46), and the ablations -- no
 // atomics: the same time; no record loads: half.  The kernel moves 1.5 GB (1.03 GB of kept records + the y rows once per latent
 // range) at 3 TB/s with one sixteen-wavefront workgroup per CU; a plain torch.sum streams the same buffer at 5.7
 // (scratch/bw_probe.py).]
