@@ -45,7 +45,7 @@ int pm_version(void);
  * build every addend is rounded to a multiple of a quantum q_c = 2^-52 M_c before it is added, M_c a power of two no partial
  * sum of its category can exceed: all additions are then exact and the result is independent of their order -- the same
  * bits in every run.  pm_det_build(): 1 in that build, 0 in the default one (whose kernels contain none of this).
- * pm_det_set_quanta(unit, M8, stream): the eight magic constants 1.5 M_c of one kernel family (host memory; copied before the
+ * pm_det_set_quanta(unit, M8, stream): the eight magic constants 1.5 M_c of one kernel family (host OR device memory; copied before the
  * family's next launch on `stream`; PM_ERANGE-like -2 in the default build).  Categories per family:
  *   PM_DET_BSC_FUSED8 / PM_DET_DSC   0 Wq, mus, counts (sums of probabilities)   1 sum of q e   2 sum of log-evidences
  *   PM_DET_WP_SPARSE                 0 Wp (sums of E[s] y)
@@ -63,6 +63,18 @@ int pm_version(void);
 #define PM_DET_BSC_KERNELS 8
 int pm_det_build(void);
 int pm_det_set_quanta(int unit, const double *M8, void *stream);
+/* GSC, deterministic build, inside an EM loop: the quanta of the next E-step (PM_DET_GSC) and of its M-step's contraction
+ * (PM_DET_GEMM and PM_DET_WP_SPARSE), derived AND installed by one kernel from parameters that are on the device only -- gram
+ * (H,H: its diagonal = |W_h|^2), psi_sq (H,H), tables as pm_gsc_mstep_finish_f64 leaves them (mu in row 6, 1/sigma_sq in
+ * tables[8 H]); ymax = max |y_nd|, ynmax = max |y_n|, n = datapoints of the shard.  quanta16 (device): a copy of what was
+ * installed, [8 of PM_DET_GSC | 8 of the contraction].  The bounds are those of GSC._det_quanta (gsc_et.py here; the
+ * reference has no such mode).  -2 in the default build. */
+int pm_gsc_det_quanta_f64(const double *gram, int64_t ldg, const double *psi_sq, const double *tables, int64_t H,
+                          int64_t gamma, double ymax, double ynmax, double n, double *quanta16, void *stream);
+/* A device-side row list that was built with an atomic counter (`rows[0 .. *count)`, distinct values in [0, N)) sorted
+ * ascending, in place, by one workgroup (N <= 2^20, else PM_ERANGE): what makes a gathered contraction over it
+ * (pm_gemm_tn_acc_rows_f64) independent of the order its producers finished in. */
+int pm_sort_row_list_i32(int32_t *rows, const int32_t *count, int64_t N, void *stream);
 const char *pm_error_string(int code);
 
 /* ---------------------------------------------------------------------------------------

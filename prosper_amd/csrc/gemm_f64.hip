@@ -852,6 +852,12 @@ extern "C" int pm_gemm_nt_f64(const double *A, int64_t lda, const double *B, int
         // finding: the slices used to be quantised with the `gemm` unit's category 0, i.e. with whatever M-step bound the
         // previous step -- or another model of the process -- had installed, or with none at all in a fresh process.]
         nsplit = 1;
+        // ... and as ONE launch: the remainder's tiles take the slots the last whole round frees (as a launch of its own it ran
+        // alone behind the rounds: 37 us for 27 tiles at GSC's config 4, on the EM loop's critical path)
+        if (main_panels > 0 && rest_rows > 0) {
+            launch_nt_dma(A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, 1, s);
+            return (int)hipGetLastError();
+        }
 #endif
         if (main_panels > 0 && rest_rows > 0 && nsplit > 1 && fuse_remainder()) {
             launch_nt_dma_fused(A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, (int)main_panels, (int)nsplit, s);

@@ -1209,4 +1209,164 @@ extern "C" int pm_gsc_component_scores_f64(const double *scores, int64_t lds, co
     return (int)hipGetLastError();
 }
 
+namespace {
+// Deterministic mode inside an EM loop: the quanta of the NEXT E-step and of its M-step's contraction from parameters that exist
+// on the device only (the M-step's own solution; the host sets the quanta of an E-step it launches from host-side parameters
+// -- gsc_et.py GSC._det_quanta, whose bounds these are).  Posterior means |kappa| <= zb = |mu|_max + min(|y|_max / min_h |W_h|,
+// |Psi|_inf |W_a| (|y|_max + |W_a| sqrt(gamma) |mu|_max) / sigma^2), |W_a| <= sqrt(gamma) max_h |W_h|; second moments
+// kappa^2 + Lambda^-1 <= zb^2 + max_h psi_hh.  One workgroup; writes this unit's own quanta and leaves them, with the
+// contraction's (PM_DET_GEMM, PM_DET_WP_SPARSE: their symbols' addresses come in as arguments), and a copy of all in `out`.
+__device__ double det_magic(double bound) {          // 1.5 * 2^(e + 1), 2^e >= bound (DeviceCAModel._magic)
+    if (!(bound > 0.0) || !(bound < INFINITY)) return 0.0;
+    int e;
+    const double m = frexp(bound, &e);                // bound = m 2^e, m in [0.5, 1)
+    if (m == 0.5) --e;
+    return ldexp(1.5, e + 1);
+}
+
+__global__ __launch_bounds__(256) void gsc_det_quanta_kernel(const double *__restrict__ gram, int64_t ldg,
+                                                               const double *__restrict__ psi, const double *__restrict__ tables,
+                                                               int H, double sqrt_gamma, double ymax, double ynmax, double n,
+                                                               double *__restrict__ out, double *__restrict__ gsc_M,
+                                                               double *__restrict__ gemm_M, double *__restrict__ sparse_M) {
+    __shared__ double s_red[5][4];      // (four wavefronts: the kernel runs beside the scores GEMM and must find room on a CU)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double w2max = 0.0, w2min = INFINITY, mumax = 0.0, prow = 0.0, pdiag = 0.0;
+    for (int h = tid; h < H; h += 256) {
+        const double g = gram[(int64_t)h * ldg + h];
+        w2max = fmax(w2max, g);
+        w2min = fmin(w2min, g);
+        mumax = fmax(mumax, fabs(tables[6 * (int64_t)H + h]));
+        pdiag = fmax(pdiag, fabs(psi[(int64_t)h * H + h]));
+    }
+    // |Psi|_inf: a wavefront per row, lanes along it (coalesced), eight rows' loads in flight -- a thread per row read its row
+    // element by element: 140 us for a 128 x 128 matrix, on the critical path of the EM loop
+    for (int h0 = wave; h0 < H; h0 += 4 * 8) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int h = h0 + 4 * j;
+            r[j] = 0.0;
+            if (h < H)
+                for (int k = lane; k < H; k += 64) r[j] += fabs(psi[(int64_t)h * H + k]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            for (int o = 32; o > 0; o >>= 1) r[j] += __shfl_xor(r[j], o);
+            prow = fmax(prow, r[j]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        w2max = fmax(w2max, __shfl_xor(w2max, o));
+        w2min = fmin(w2min, __shfl_xor(w2min, o));
+        mumax = fmax(mumax, __shfl_xor(mumax, o));
+        pdiag = fmax(pdiag, __shfl_xor(pdiag, o));
+    }
+    if (lane == 0) {
+        s_red[0][wave] = w2max;
+        s_red[1][wave] = -w2min;
+        s_red[2][wave] = mumax;
+        s_red[3][wave] = prow;
+        s_red[4][wave] = pdiag;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            for (int q = 0; q < 5; ++q) s_red[q][0] = fmax(s_red[q][0], s_red[q][w]);
+        const double wmax = sqrt(s_red[0][0]), wmin = sqrt(fmax(-s_red[1][0], 0.0));
+        const double inv_s2 = tables[8 * (int64_t)H];
+        mumax = s_red[2][0];
+        const double wa = sqrt_gamma * wmax;
+        const double zb = mumax + fmin(ynmax / fmax(wmin, 1e-300), s_red[3][0] * wa * (ynmax + wa * sqrt_gamma * mumax) * inv_s2);
+        const double M0 = det_magic(n), M1 = det_magic(n * zb), M2 = det_magic(n * (zb * zb + s_red[4][0]));
+        const double Mg = det_magic(n * fmax(fmax(ymax, 1.0), zb) * zb);
+        for (int i = 0; i < 16; ++i) out[i] = 0.0;
+        out[0] = M0;
+        out[1] = M1;
+        out[2] = M2;
+        out[8] = Mg;
+        for (int i = 0; i < 8; ++i) {      // (the contraction's two kernels add into the same accumulators: one quantum)
+            if (gsc_M) gsc_M[i] = i == 0 ? M0 : i == 1 ? M1 : i == 2 ? M2 : 0.0;
+            if (gemm_M) gemm_M[i] = i == 0 ? Mg : 0.0;
+            if (sparse_M) sparse_M[i] = i == 0 ? Mg : 0.0;
+        }
+    }
+}
+
+// A row list built with an atomic counter (the dense rows of gsc_estep_kernel<LIST>: in the order the workgroups finished) put
+// into ASCENDING order, in place: the gathered GEMM behind it then sums its K-slices in an order that does not depend on the
+// schedule.  One workgroup: the rows as bits of an LDS bitmap (N <= 2^20), a prefix sum over its words, the bits written back.
+__global__ __launch_bounds__(1024) void sort_row_list_kernel(int32_t *__restrict__ rows, const int32_t *__restrict__ count, int N) {
+    extern __shared__ unsigned long long s_bits[];
+    __shared__ int s_cnt[1024];
+    const int tid = threadIdx.x, words = (N + 63) >> 6;
+    for (int w = tid; w < words; w += 1024) s_bits[w] = 0ull;
+    __syncthreads();
+    const int cnt = *count;
+    for (int i0 = tid; i0 < cnt; i0 += 8 * 1024) {       // eight loads in flight per thread (one at a time: 200 us for 40 000 rows)
+        int r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (i0 + 1024 * j < cnt) ? rows[i0 + 1024 * j] : -1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (r[j] >= 0 && r[j] < N) atomicOr(&s_bits[r[j] >> 6], 1ull << (r[j] & 63));
+    }
+    __syncthreads();
+    const int per = (words + 1023) / 1024, w0 = tid * per, w1 = (w0 + per < words) ? w0 + per : words;
+    int mine = 0;
+    for (int w = w0; w < w1; ++w) mine += __popcll(s_bits[w]);
+    s_cnt[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {              // inclusive scan (Hillis-Steele)
+        const int v = tid >= d ? s_cnt[tid - d] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    int o = s_cnt[tid] - mine;
+    for (int w = w0; w < w1; ++w) {
+        unsigned long long b = s_bits[w];
+        while (b) {
+            rows[o++] = (w << 6) + __builtin_ctzll(b);
+            b &= b - 1ull;
+        }
+    }
+}
+}  // namespace
+
+extern "C" double *prosper_det_addr_gsc(void);
+extern "C" double *prosper_det_addr_gemm(void);
+extern "C" double *prosper_det_addr_bsc_wp_sparse(void);
+
+extern "C" int pm_gsc_det_quanta_f64(const double *gram, int64_t ldg, const double *psi_sq, const double *tables, int64_t H,
+                                     int64_t gamma, double ymax, double ynmax, double n, double *quanta16, void *stream) {
+    if (!gram || !psi_sq || !tables || !quanta16 || H <= 0 || ldg < H || gamma <= 0) return PM_EINVAL;
+    if (H > INT32_MAX) return PM_ERANGE;
+#ifndef PM_DETERMINISTIC
+    return -2;
+#else
+    static double *gsc_M = prosper_det_addr_gsc(), *gemm_M = prosper_det_addr_gemm(), *sparse_M = prosper_det_addr_bsc_wp_sparse();
+    if (!gsc_M || !gemm_M || !sparse_M) return PM_EINVAL;
+    hipLaunchKernelGGL(gsc_det_quanta_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), gram, ldg, psi_sq, tables,
+                       (int)H, sqrt((double)gamma), ymax, ynmax, n, quanta16, gsc_M, gemm_M, sparse_M);
+    return (int)hipGetLastError();
+#endif
+}
+
+extern "C" int pm_sort_row_list_i32(int32_t *rows, const int32_t *count, int64_t N, void *stream) {
+    if (!rows || !count || N < 0) return PM_EINVAL;
+    if (N > (1 << 20)) return PM_ERANGE;
+    if (N == 0) return PM_OK;
+    const size_t lds = (size_t)((N + 63) / 64) * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sort_row_list_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 20) / 8);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sort_row_list_kernel, dim3(1), dim3(1024), lds, static_cast<hipStream_t>(stream), rows, count, (int)N);
+    return (int)hipGetLastError();
+}
+
 PM_DET_SETTER(gsc)

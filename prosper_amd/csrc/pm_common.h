@@ -24,19 +24,30 @@ __device__ __forceinline__ void pm_atomic_add(double *p, double v) {
 // rounding error the plain sum makes on its LARGEST entries, spread over all of them).  The default build compiles PM_Q to
 // nothing: its kernels are bit-for-bit the ones that were tuned.
 //   PM_Q(v, c)   v rounded to category c's quantum (pm_det_M[c] = 1.5 * 2^e: the add / subtract trick)
-//   each translation unit with accumulators has its own pm_det_M and a setter the host calls before its launches
+//   each translation unit with accumulators has its own pm_det_M and a setter the host calls before its launches (from host or
+//   device memory -- pm_gsc_det_quanta_f64 leaves quanta on the device)
 #ifdef PM_DETERMINISTIC
-static __device__ double pm_det_M[8];
+// (__constant__: loads from the constant address space are invariant for the compiler -- it keeps a quantum in a scalar register
+// across the atomics of a loop instead of re-reading a global that, for all it knows, the atomic has just changed: the sparse
+// product ran 20 % slower in this build for that alone.  Written between launches only: by the setter, or by
+// gsc_det_quanta_kernel through the address prosper_det_addr_<unit> returns.)
+static __constant__ double pm_det_M[8];
 #define PM_Q(v, c) (((v) + pm_det_M[c]) - pm_det_M[c])
 #define PM_DET_SETTER(unit)                                                                                      \
     extern "C" int prosper_det_set_##unit(const double *M8, void *stream) {                                     \
-        return (int)hipMemcpyToSymbolAsync(HIP_SYMBOL(pm_det_M), M8, 8 * sizeof(double), 0, hipMemcpyHostToDevice, \
-                                           static_cast<hipStream_t>(stream));                                    \
+        void *sym = nullptr;                                                                                     \
+        if (hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(pm_det_M)); e != hipSuccess) return (int)e;      \
+        return (int)hipMemcpyAsync(sym, M8, 8 * sizeof(double), hipMemcpyDefault, static_cast<hipStream_t>(stream)); \
+    }                                                                                                            \
+    extern "C" double *prosper_det_addr_##unit(void) {     /* the unit's eight quanta, for a kernel that derives them */ \
+        void *sym = nullptr;                                                                                     \
+        return hipGetSymbolAddress(&sym, HIP_SYMBOL(pm_det_M)) == hipSuccess ? static_cast<double *>(sym) : nullptr; \
     }
 #else
 #define PM_Q(v, c) (v)
 #define PM_DET_SETTER(unit) \
-    extern "C" int prosper_det_set_##unit(const double *, void *) { return -2; }
+    extern "C" int prosper_det_set_##unit(const double *, void *) { return -2; } \
+    extern "C" double *prosper_det_addr_##unit(void) { return nullptr; }
 #endif
 
 // MI355X has 8 XCDs with one L2 each.  f64 atomics from all of them on the same few thousand lines bounce those

@@ -415,8 +415,8 @@ class GSC(DeviceCAModel):
                        _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
                        ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
                        _ptr(stats), _ptr(logpj), logpj.stride(0), self._stream())
-        elif N and lists and self.fuse_moment_gemm and self.sparse_moments and cand_in is None and not self.deterministic \
-                and _lib.load().pm_gsc_lists_supported(H, Hp, self.gamma, D):
+        elif N and lists and self.fuse_moment_gemm and self.sparse_moments and cand_in is None \
+                and (not self.deterministic or N <= (1 << 20)) and _lib.load().pm_gsc_lists_supported(H, Hp, self.gamma, D):
             # (`tables` comes from pm_gsc_mstep_finish_f64 here: its slot 8 H + 1 holds the list threshold)
             lb = res.setdefault("gsc_lists", [None, None])
             if lb[k] is None:
@@ -429,6 +429,11 @@ class GSC(DeviceCAModel):
                        _ptr(tables), _ptr(masks), S, self.gamma, ctypes.c_double(1. / anneal_T),
                        ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
                        _ptr(stats), _ptr(nz_idx), _ptr(nz_val), _ptr(dense_rows), _ptr(dense_count), self._stream())
+            if self.deterministic:
+                # the dense rows were listed in the order the workgroups finished: ascending, so that the gathered GEMM's
+                # K-slices hold the same rows in the same order in every run.  (Right behind the pass, on an idle device: beside
+                # the sparse product the one-workgroup kernel waited 0.2 ms for room on a CU, and the GEMM for it.)
+                self._call("estep", "pm_sort_row_list_i32", _ptr(dense_rows), _ptr(dense_count), N, self._stream())
             stats._pm_lists = (nz_idx, nz_val, dense_rows, dense_count, bufs[k])
         elif N:
             self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(G), _ptr(psi_d), _ptr(yn),
@@ -619,9 +624,14 @@ class GSC(DeviceCAModel):
 
         old_dev = None
         if self.deterministic and my_N:
-            self._det_quanta(res, model_params)
-        if self.speculate and self.speculate_estep and self.sigma_sq_type == 'scalar' and my_N and 'W' in self.to_learn \
-                and not self.deterministic:
+            # (the quanta of a pass the previous M-step launched were derived on the device, for these very parameters:
+            # _det_dev_quanta; they are installed again only if another model's launches came in between)
+            made = getattr(suff_stats.get('_stats', (None,))[0], "_pm_det", None)
+            if made is not None:
+                self._det_dev_install(made)
+            else:
+                self._det_quanta(res, model_params)
+        if self.speculate and self.speculate_estep and self.sigma_sq_type == 'scalar' and my_N and 'W' in self.to_learn:
             # the old parameters for pm_gsc_mstep_finish_f64, uploaded NOW: enqueued in front of the contraction they are on
             # the device long before the finish kernel wants them (uploaded next to it, the copy and its latency sat in the
             # middle of the M-step's chain of small launches: ~30 us of idle device per step)
@@ -703,8 +713,7 @@ class GSC(DeviceCAModel):
         # a mostly idle device) runs on a stream of its own BESIDE the contraction over the datapoints instead of behind it.
         inv_early = None
         if (raw is not None and my_N and whole.is_cuda and H <= 256 and getattr(comm, "size", 1) == 1 and self.overlap_moments
-                and self.early_inverse
-                and self.timer is None and not self.deterministic):
+                and self.early_inverse and self.timer is None):
             s3 = getattr(self, "_inv_stream", None)
             if s3 is None:
                 s3 = self._inv_stream = torch.cuda.Stream(device=self.device)
@@ -802,8 +811,7 @@ class GSC(DeviceCAModel):
         # with exactly the parameters this M-step returns).  The host still receives everything with the one download.
         fin = None
         scores_side = None
-        # (deterministic mode: the next E-step is launched by E_step itself, from host-side parameters whose norms bound its sums)
-        if Wt_next is not None and self.speculate_estep and my_N and old_dev is not None and not self.deterministic:
+        if Wt_next is not None and self.speculate_estep and my_N and old_dev is not None:
             if self.overlap_scores and self.timer is None:
                 # the scores GEMM needs W_new^T only: it starts here on the second stream while the main one still runs the
                 # Gram product, the one-workgroup finish kernel and the download (0.04 ms of a mostly idle device at config 4)
@@ -825,6 +833,10 @@ class GSC(DeviceCAModel):
                        at(o2), at(o2 + H), at(o2 + 2 * H), _ptr(G_next), _ptr(old_dev),
                        ctypes.c_double(float(N)), D, H, learn, at(o_par), _ptr(tdev), st)
             fin = {"G": G_next, "psi": whole[o_par + 2 * H:o_par + 2 * H + nHH].view(H, H), "tdev": tdev, "out": None}
+            if self.deterministic:
+                # the next pass's quanta (and its M-step's) from the parameters as the device holds them: bounds as in
+                # _det_quanta, evaluated by one small kernel behind the finish kernel
+                fin["det"] = self._det_dev_quanta(res, G_next, fin["psi"], tdev)
 
         def after_copy():
             if fin is None:
@@ -843,6 +855,8 @@ class GSC(DeviceCAModel):
             if self._in_step and self._next_anneal is not None:
                 fin["out"] = self._launch_estep(res, A, fin["G"], fin["psi"], res["ynorm2"], fin["tdev"], 0.0,
                                                 self._next_anneal['T'], None, lists=True, zeros=zeros)
+                if fin.get("det") is not None:
+                    fin["out"][3]._pm_det = fin["det"]
 
         if packed.is_cuda:
             n_down = o_par + n_par if fin is not None else (o_par if Wt_next is not None else
@@ -929,6 +943,27 @@ class GSC(DeviceCAModel):
         n = float(res["Y"].shape[0])
         self._det_set("gsc", [n, n * zb, n * (zb * zb + float(np.abs(np.diag(psi)).max()))])
         self._det_set("gemm", [n * max(ymax, 1.0, zb) * zb])
+
+    def _det_dev_quanta(self, res, G, psi, tables):
+        """Deterministic mode inside an EM loop: the same bounds from parameters that are on the device only (the M-step's
+        solution: ``G`` = W^T W, ``psi``, ``tables`` of pm_gsc_mstep_finish_f64), by pm_gsc_det_quanta_f64 -- installed for the
+        E-step kernel, the contraction GEMM and the sparse product.  Returns the record ``_det_dev_install`` re-installs from."""
+        made = {"res": res, "G": G, "psi": psi, "tables": tables,
+                "q": torch.empty(16, dtype=torch.float64, device=self.device)}
+        self._det_dev_install(made)
+        return made
+
+    def _det_dev_install(self, made):
+        from ._device import _DET_QUANTA_SET as cache
+        if all(cache.get(u) is made for u in ("gsc", "gemm", "wp_sparse")):
+            return
+        ymax, ynmax = self._det_data_bounds(made["res"])
+        st = self._stream()
+        _lib.call("pm_gsc_det_quanta_f64", _ptr(made["G"]), made["G"].stride(0), _ptr(made["psi"]), _ptr(made["tables"]), self.H,
+                  self.gamma, ctypes.c_double(ymax), ctypes.c_double(ynmax), ctypes.c_double(float(made["res"]["Y"].shape[0])),
+                  _ptr(made["q"]), st, det=True)
+        for u in ("gsc", "gemm", "wp_sparse"):
+            cache[u] = made
 
     def _eps_diag(self, H, eps):
         """[eps ... eps | 0 ... 0]: the diagonal terms of the batched inverse of (sum_ss + eps I, sum_zz)."""

@@ -7,7 +7,7 @@ class An(dict):
     def __missing__(s, k): return 0.0
     def as_dict(s): return dict(s)
 dev = torch.device("cuda", 0)
-def loop(m, p, Y, secs=0.4, steps=15):
+def loop(m, p, Y, secs=0.4, steps=40):
     t = time.perf_counter()
     while time.perf_counter() - t < secs:
         p = m.step(An(T=1.0), p, {"y": Y})
@@ -60,6 +60,6 @@ for lo in range(0, N, 25_000):
 p0 = {"W": (W_gt * 1.05).cpu().numpy(), "pi": 2.0 / H, "sigma": 1.0}
 for det in (False, True):
     m = MCA_ET(D, H, 8, 3); m.deterministic = det
-    out["mca_c5_%s" % ("det" if det else "default")] = round(loop(m, dict(p0), Y, secs=0.6, steps=8), 3)
+    out["mca_c5_%s" % ("det" if det else "default")] = round(loop(m, dict(p0), Y, secs=0.6, steps=16), 3)
     del m
 print(out)

@@ -152,3 +152,82 @@ def test_default_build_is_not_bitwise_reproducible_where_the_deterministic_one_i
     for a, b in zip(runs[False][0], runs[True][0]):          # ... and the two builds stay within rounding of each other
         for k in keys:
             np.testing.assert_allclose(b[k], a[k], rtol=1e-7, atol=1e-9 * max(1.0, float(np.abs(a[k]).max())))
+
+
+def _gsc_big(N=30000, D=256, H=128):
+    """Config-4 dimensions at a size where the list pass has dense rows for the gathered GEMM (vectorised generator)."""
+    from prosper_amd.em.camodels.gsc_et import GSC
+    rng = np.random.RandomState(15)
+    W = rng.normal(size=(D, H))
+    s = rng.uniform(size=(N, H)) < 2.0 / H
+    z = s * (1.5 + rng.normal(size=(N, H)))
+    y = z @ W.T + rng.normal(size=(N, D))
+    p = {"W": W + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, 2.2 / H), "mu": np.full(H, 1.4),
+         "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+    return (lambda: GSC(D, H, 6, 3, "scalar")), p, y, ("W", "pi", "mu", "psi_sq", "sigma_sq")
+
+
+def test_gsc_deterministic_mode_keeps_the_speculated_list_pass():
+    """Round 6: the deterministic mode no longer switches off what makes GSC's EM loop fast -- the M-step launches the next
+    E-step (quanta derived on the device from the parameters it has just solved: pm_gsc_det_quanta_f64), that pass writes
+    lists, and its dense rows go through the gathered GEMM in ascending order (pm_sort_row_list_i32).  Two runs: identical
+    bits at every step; the passes are adopted; and the loop stays within rounding of the default build's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    make, p0, y, keys = _gsc_big()
+    yd = torch.from_numpy(y).cuda()
+    hits = []
+
+    def loop(det, steps=14):
+        m = make()
+        m.deterministic = det
+        p, traj = _copy(p0), []
+        for it in range(steps):
+            p = m.step(_An(T=1.2 if it < 4 else 1.0), p, {"y": yd})
+            traj.append({k: np.array(p[k], copy=True) for k in keys})
+        hits.append(m.spec_hits)
+        return traj
+
+    a, b, c = loop(True), loop(True), loop(False)
+    assert hits[0] >= 10 and hits[0] == hits[1], hits            # (the temperature moves once: one dropped pass)
+    for it, (pa, pb) in enumerate(zip(a, b)):
+        for k in keys:
+            assert np.array_equal(pa[k], pb[k]), "step %d, %s differs between two deterministic runs" % (it, k)
+    for k in keys:       # same trajectory as the default build up to the quanta (14 steps of error growth: loose)
+        np.testing.assert_allclose(a[-1][k], c[-1][k], rtol=1e-6, atol=1e-8 * max(1.0, float(np.abs(c[-1][k]).max())))
+
+
+def test_sort_row_list_and_device_quanta():
+    """pm_sort_row_list_i32 against np.sort on a shuffled list; pm_gsc_det_quanta_f64 against GSC._det_quanta's host bounds."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    import ctypes
+    from prosper_amd import _lib
+    rng = np.random.RandomState(5)
+    for N, cnt in ((1000, 0), (1000, 1), (1000, 1000), (200_000, 41_237), (1 << 20, 77_777)):
+        rows = rng.permutation(N)[:cnt].astype(np.int32)
+        buf = torch.full((max(cnt, 1) + 8,), -7, dtype=torch.int32, device="cuda")
+        buf[:cnt] = torch.from_numpy(rows).cuda()
+        count = torch.tensor([cnt], dtype=torch.int32, device="cuda")
+        _lib.call("pm_sort_row_list_i32", ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(count.data_ptr()), N, None)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[:cnt], np.sort(rows)) and (got[cnt:] == -7).all(), (N, cnt)
+    make, p, y, _ = _gsc((128, 128, 6, 3, 600))
+    m = make()
+    m.deterministic = True
+    res = m._resident(y)
+    par = m._tables_for(p, res)
+    from prosper_amd.em.camodels import _device
+    _device._DET_QUANTA_SET.clear()
+    m._det_quanta(res, p)
+    host = _device._DET_QUANTA_SET["gsc"][:3] + _device._DET_QUANTA_SET["gemm"][:1]
+    H = m.H
+    tab = torch.zeros(9 * H, dtype=torch.float64, device="cuda")
+    tab[:8 * H] = par["tables"].reshape(-1)[:8 * H]
+    tab[8 * H] = 1.0 / par["s2"]
+    made = m._det_dev_quanta(res, par["G"], par["psi_d"], tab)
+    torch.cuda.synchronize()
+    q = made["q"].cpu().numpy()
+    assert tuple(q[:3]) + (q[8],) == host, (q, host)
+    assert all(_device._DET_QUANTA_SET[u] is made for u in ("gsc", "gemm", "wp_sparse"))
