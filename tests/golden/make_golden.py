@@ -578,6 +578,48 @@ def anneal_tracks():
     print("anneal_tracks ok", names)
 
 
+def schedule_trajectory(name, kind, D, H, Hp, gamma, N, seed, steps=50):
+    """The reference's own annealing schedule (bars-learning.py:77-80) for ``steps`` EM steps at a BASELINE configuration's
+    DIMENSIONS: per-step free energy, N_use and scalar / vector parameters, the matrices after two of the steps.  Inputs: schedule_inputs.py."""
+    import time
+    from schedule_inputs import schedule_inputs
+    y, p0 = schedule_inputs(kind, D, H, N, seed)
+    if kind == "gsc":
+        model = GSC(D, H, Hp, gamma, sigma_sq_type="scalar")
+    else:
+        model = {"bsc": BSC_ET, "mca": MCA_ET}[kind](D, H, Hp, gamma)
+    anneal = LinearAnnealing(steps)
+    anneal["T"] = [(0, 2.), (.7, 1.)]
+    anneal["Ncut_factor"] = [(0, 0.), (2. / 3, 1.)]
+    anneal["anneal_prior"] = False
+    Capture.rows.clear()
+    data = {"y": y.copy()}
+    lparams = {k: np.array(v, copy=True) for k, v in p0.items()}
+    keep = (steps // 5, steps - 1)          # (W, and GSC's psi_sq, after these steps only: megabytes each)
+    Ws, scal = [], {k: [] for k in p0 if k != "W"}
+    t0 = time.time()
+    it = 0
+    while not anneal.finished:                      # EM.run body (em/__init__.py:163-178)
+        new = model.step(anneal, lparams, data)
+        anneal.next(model.gain(lparams, new))
+        lparams = new
+        if it in keep:
+            Ws.append(np.array(new["W"], copy=True))
+        for k in scal:
+            if np.ndim(new[k]) < 2 or it in keep:
+                scal[k].append(np.array(new[k], copy=True))
+        it += 1
+    out = {"kind": kind, "D": D, "H": H, "Hprime": Hp, "gamma": gamma, "N": N, "seed": seed, "steps": steps,
+           "keep": np.array(keep), "W": np.stack(Ws), "L": np.array(Capture.rows.get("L", [])),
+           "N_use": np.array(Capture.rows.get("N_use", [N] * steps))}
+    for k, v in scal.items():
+        out[k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, "schedule_%s.npz" % name), **out)
+    print("schedule_%s: %d steps in %.0f s, L[0]=%.6f L[-1]=%.6f N_use[-1]=%d" % (
+        name, steps, time.time() - t0, out["L"][0] if len(out["L"]) else np.nan, out["L"][-1] if len(out["L"]) else np.nan,
+        out["N_use"][-1]))
+
+
 def main(only=None, cases=None):
     """``only``: regenerate just the fixtures whose maker's name starts with this prefix (e.g. ``mmca``);
     ``cases``: of those, just the named step cases (e.g. ``c2_plain,c2_cut``)."""
@@ -585,11 +627,12 @@ def main(only=None, cases=None):
     g = globals()
     for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
                "mca_inference_case", "mmca_inference_case", "gsc_inference_case", "gsc_posterior_hprime_case", "bsc_trajectory",
-               "bsc_init", "anneal_tracks"):
+               "bsc_init", "anneal_tracks", "schedule_trajectory"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
     if cases:
-        for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "tsc_step_case"):
+        for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "tsc_step_case",
+                   "schedule_trajectory"):
             g[_n] = (lambda fn: (lambda name, *a, **k: fn(name, *a, **k) if name in cases else None))(g[_n])
     # BASELINE config-1 dims (D=25 H=10 H'=5 gamma=3)
     bsc_step_case("c1_plain", 25, 10, 5, 3, 400, seed=1, T=1.0, Ncut=0.0, anneal_prior=False, bars=True)
@@ -644,6 +687,10 @@ def main(only=None, cases=None):
     gsc_inference_case()
     gsc_posterior_hprime_case()
     bsc_trajectory()
+    # the reference's 50-step schedule at the dimensions of BASELINE configs 2, 4 and 5 (round 6)
+    schedule_trajectory("bsc_c2", "bsc", 1024, 256, 8, 4, 4000, seed=201)
+    schedule_trajectory("gsc_c4", "gsc", 256, 128, 6, 3, 200, seed=202)
+    schedule_trajectory("mca_c5", "mca", 256, 128, 8, 3, 200, seed=203)
     bsc_init()
     anneal_tracks()
     mmca_step_case("small", 16, 8, 4, 3, 300, seed=51, T=1.0, Ncut=0.0)
