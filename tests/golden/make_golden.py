@@ -586,8 +586,13 @@ def schedule_trajectory(name, kind, D, H, Hp, gamma, N, seed, steps=50):
     y, p0 = schedule_inputs(kind, D, H, N, seed)
     if kind == "gsc":
         model = GSC(D, H, Hp, gamma, sigma_sq_type="scalar")
+    elif kind == "dsc":
+        from schedule_inputs import DSC_STATES
+        model = DSC_ET(D, H, Hp, gamma, states=DSC_STATES.copy())
+    elif kind == "tsc":
+        model = _make_tsc(D, H, Hp, gamma)
     else:
-        model = {"bsc": BSC_ET, "mca": MCA_ET}[kind](D, H, Hp, gamma)
+        model = {"bsc": BSC_ET, "mca": MCA_ET, "mmca": MMCA_ET}[kind](D, H, Hp, gamma)
     anneal = LinearAnnealing(steps)
     anneal["T"] = [(0, 2.), (.7, 1.)]
     anneal["Ncut_factor"] = [(0, 0.), (2. / 3, 1.)]
@@ -691,6 +696,9 @@ def main(only=None, cases=None):
     schedule_trajectory("bsc_c2", "bsc", 1024, 256, 8, 4, 4000, seed=201)
     schedule_trajectory("gsc_c4", "gsc", 256, 128, 6, 3, 200, seed=202)
     schedule_trajectory("mca_c5", "mca", 256, 128, 8, 3, 200, seed=203)
+    schedule_trajectory("mmca", "mmca", 256, 128, 8, 3, 200, seed=204)
+    schedule_trajectory("dsc", "dsc", 128, 64, 6, 3, 800, seed=205)
+    schedule_trajectory("tsc", "tsc", 128, 64, 6, 3, 800, seed=206)
     bsc_init()
     anneal_tracks()
     mmca_step_case("small", 16, 8, 4, 3, 300, seed=51, T=1.0, Ncut=0.0)

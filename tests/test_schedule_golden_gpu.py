@@ -1,5 +1,5 @@
 """The reference's OWN annealing schedule (examples/barstests/bars-learning.py:77-80: T = [(0, 2.), (.7, 1.)], Ncut_factor =
-[(0, 0.), (2/3, 1.)], 50 steps) at the dimensions of BASELINE configs 2, 4 and 5, against trajectories the reference itself
+[(0, 0.), (2/3, 1.)], 50 steps) at the dimensions of BASELINE configs 2, 4 and 5 (and MMCA at config 5's, DSC / TSC at D = 128, H = 64), against trajectories the reference itself
 produced here (tests/golden/make_golden.py::schedule_trajectory; inputs re-created from seeds, tests/golden/schedule_inputs.py).
 The drop-in loop ``EM(model, anneal).run()`` runs on the fast path -- next E-step launched by the M-step across the ramp,
 deferred statistics on the truncation steps -- and has to follow the reference step by step: the same N_use at every step,
@@ -31,6 +31,16 @@ def _run(kind, z, fast):
     elif kind == "mca":
         from prosper_amd.em.camodels.mca_et import MCA_ET as cls
         m = cls(D, H, Hp, gamma)
+    elif kind == "mmca":
+        from prosper_amd.em.camodels.mmca_et import MMCA_ET as cls
+        m = cls(D, H, Hp, gamma)
+    elif kind == "dsc":
+        from schedule_inputs import DSC_STATES
+        from prosper_amd.em.camodels.dsc_et import DSC_ET
+        m = DSC_ET(D, H, Hp, gamma, states=DSC_STATES.copy())
+    elif kind == "tsc":
+        from prosper_amd.em.camodels.tsc_et import TSC_ET
+        m = TSC_ET(D, H, Hp, gamma)
     else:
         from prosper_amd.em.camodels.gsc_et import GSC
         m = GSC(D, H, Hp, gamma, sigma_sq_type="scalar")
@@ -53,7 +63,8 @@ def _run(kind, z, fast):
 
 
 @pytest.mark.parametrize("name,kind,fast", [("bsc_c2", "bsc", True), ("bsc_c2", "bsc", False), ("gsc_c4", "gsc", True),
-                                            ("mca_c5", "mca", True), ("mca_c5", "mca", False)])
+                                            ("mca_c5", "mca", True), ("mca_c5", "mca", False), ("mmca", "mmca", True),
+                                            ("dsc", "dsc", True), ("tsc", "tsc", True)])
 def test_em_run_follows_the_reference_on_its_own_schedule(name, kind, fast):
     if not torch.cuda.is_available():
         pytest.skip("needs the GPU box (MI355X)")
@@ -67,7 +78,8 @@ def test_em_run_follows_the_reference_on_its_own_schedule(name, kind, fast):
         ok = np.isfinite(z["L"])
         assert ok.sum() >= steps - 2, "the fixture is meant to stay in the reference's representable range"
         np.testing.assert_allclose(got["L"][ok], z["L"][ok], rtol=1e-10)
-    tol = {"bsc": 1e-11, "gsc": 1e-9, "mca": 1e-7}[kind]     # (measured: 4e-15, 7e-13, 3e-11 of the largest entry after 50 steps)
+    # (measured for BSC / GSC / MCA: 4e-15, 7e-13, 3e-11 of the largest entry after 50 steps)
+    tol = {"bsc": 1e-11, "gsc": 1e-9, "mca": 1e-7, "mmca": 1e-7, "dsc": 1e-9, "tsc": 1e-9}[kind]
     for k in ("pi", "sigma", "mu", "sigma_sq"):
         if k in z.files:
             np.testing.assert_allclose(got[k], z[k], rtol=tol, atol=tol * float(np.abs(z[k]).max()), err_msg=k)

@@ -21,20 +21,25 @@ def _schedule(steps):
     return an
 
 
-@pytest.mark.parametrize("name,kind,upto", [("bsc_c2", "bsc", 11), ("gsc_c4", "gsc", 11), ("mca_c5", "mca", 50)])
+@pytest.mark.parametrize("name,kind,upto", [("bsc_c2", "bsc", 11), ("gsc_c4", "gsc", 11), ("mca_c5", "mca", 50),
+                                            ("mmca", "mmca", 11), ("dsc", "dsc", 50), ("tsc", "tsc", 50)])
 def test_oracle_follows_the_reference_schedule(name, kind, upto):
     from schedule_inputs import schedule_inputs
-    from oracle import bsc_oracle as B, gsc_oracle as G, mca_oracle as M
+    from oracle import bsc_oracle as B, gsc_oracle as G, mca_oracle as M, mmca_oracle as MM, dsc_oracle as DS, tsc_oracle as TS
+    from schedule_inputs import DSC_STATES
     z = np.load(os.path.join(HERE, "golden", "schedule_%s.npz" % name))
     D, H, Hp, gamma, N, steps = (int(z[k]) for k in ("D", "H", "Hprime", "gamma", "N", "steps"))
     y, p = schedule_inputs(kind, D, H, N, int(z["seed"]))
-    O = {"bsc": B, "gsc": G, "mca": M}[kind]
-    model = (G if kind == "gsc" else B).make_model(D, H, Hp, gamma)
+    O = {"bsc": B, "gsc": G, "mca": M, "mmca": MM, "dsc": DS, "tsc": TS}[kind]
+    if kind == "dsc":
+        model = DS.make_model(D, H, Hp, gamma, DSC_STATES.copy())
+    else:
+        model = {"gsc": G, "tsc": TS}.get(kind, B).make_model(D, H, Hp, gamma)
     if kind == "bsc":
         p = dict(p, mu=np.zeros(D))
     an = _schedule(steps)
     keep = [int(k) for k in z["keep"]]
-    tol = {"bsc": 1e-11, "gsc": 1e-9, "mca": 1e-7}[kind]
+    tol = {"bsc": 1e-11, "gsc": 1e-9, "mca": 1e-7, "mmca": 1e-7, "dsc": 1e-9, "tsc": 1e-9}[kind]
     for it in range(upto):
         A = B.Anneal(T=an["T"], Ncut_factor=an["Ncut_factor"], anneal_prior=False)
         out = O.em_step(A, model, p, y, stats_fn=B.m_step_stats_vec, vec=True) if kind == "bsc" else O.em_step(A, model, p, y)
