@@ -38,7 +38,8 @@ def _stream():
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (200, 256, 1024), (333, 10, 25), (1, 1, 1), (130, 129, 18),
                                    (5000, 256, 1024), (64, 100, 48), (257, 12, 30),
                                    (35768, 256, 256),    # one whole round of tiles + a ragged one: the fused launch
-                                   (33000, 200, 512)])   # ... with edge tiles in both directions
+                                   (33000, 200, 512),    # ... with edge tiles in both directions
+                                   (9000, 400, 784), (700, 136, 64), (300, 72, 40)])   # column tiles with 1, 8 or 9 of their 16-column blocks inside N
 def test_gemm_nt_matches_numpy(dev, M, N, K):
     from prosper_amd import _lib
     rng = np.random.RandomState(M + 7 * N + K)
