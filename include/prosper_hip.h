@@ -72,9 +72,10 @@ int pm_det_set_quanta(int unit, const double *M8, void *stream);
 int pm_gsc_det_quanta_f64(const double *gram, int64_t ldg, const double *psi_sq, const double *tables, int64_t H,
                           int64_t gamma, double ymax, double ynmax, double n, double *quanta16, void *stream);
 /* A device-side row list that was built with an atomic counter (`rows[0 .. *count)`, distinct values in [0, N)) sorted
- * ascending, in place, by one workgroup (N <= 2^20, else PM_ERANGE): what makes a gathered contraction over it
- * (pm_gemm_tn_acc_rows_f64) independent of the order its producers finished in. */
-int pm_sort_row_list_i32(int32_t *rows, const int32_t *count, int64_t N, void *stream);
+ * ascending, in place: what makes a gathered contraction over it (pm_gemm_tn_acc_rows_f64) independent of the order its
+ * producers finished in.  `flags`: 8-byte aligned, 8 * ceil(N / 8) bytes that are ZERO on entry and zero again on return
+ * (every listed row sets its byte; a workgroup per 8192 rows compacts them) + 4 * ceil(N / 8192) bytes of scratch behind them. */
+int pm_sort_row_list_i32(int32_t *rows, const int32_t *count, int64_t N, unsigned char *flags, void *stream);
 const char *pm_error_string(int code);
 
 /* ---------------------------------------------------------------------------------------

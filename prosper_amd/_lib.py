@@ -164,7 +164,7 @@ SIGNATURES = {
     "pm_det_set_quanta": (C.c_int, [C.c_int, c_dp, c_dp]),
     "pm_gsc_det_quanta_f64": (C.c_int, [c_dp, C.c_int64, c_dp, c_dp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                         c_dp, c_dp]),
-    "pm_sort_row_list_i32": (C.c_int, [c_dp, c_dp, C.c_int64, c_dp]),
+    "pm_sort_row_list_i32": (C.c_int, [c_dp, c_dp, C.c_int64, c_dp, c_dp]),
     "pm_gsc_component_scores_f64": (C.c_int, [c_dp, i64, c_dp, c_dp, C.c_double, i64, i64, c_dp, i64, c_dp]),
 }
 
@@ -173,7 +173,7 @@ class HipError(RuntimeError):
     pass
 
 
-MIN_VERSION = 1013
+MIN_VERSION = 1014
 _lib = None
 _lib_det = None
 LIB_PATH_DET = os.path.join(os.path.dirname(LIB_PATH), "libprosper_hip_det.so")

@@ -3,7 +3,7 @@
 
 #include "prosper_hip.h"
 
-extern "C" int pm_version(void) { return 1013; }  // 1013 GSC's deterministic quanta from device-side parameters (pm_gsc_det_quanta_f64), pm_sort_row_list_i32; 1012 deferred statistics of data-truncation steps (pm_bsc_estep_fused8_defer_f64, pm_bsc_defer_apply_f64); 1011 the list-writing BSC pass keeps only overflowed datapoints' dense rows (pm_bsc_wp_sparse_expand_f64); 1007 fused scores GEMM + E-step (pm_bsc_estep_fused_f64); 1001 spd inverse, 1002 MMCA (pm_mca_params.signed_w), 1003 DSC, 1004 fused MCA pass + column moments, 1005 TSC flags in pm_dsc_params, weighted row norms, 1006 batched spd inverse, per-XCD scratch in the MCA / GSC statistics
+extern "C" int pm_version(void) { return 1014; }  // 1014 pm_sort_row_list_i32 takes a flag array (two launches, no LDS atomics); 1013 GSC's deterministic quanta from device-side parameters (pm_gsc_det_quanta_f64), pm_sort_row_list_i32; 1012 deferred statistics of data-truncation steps (pm_bsc_estep_fused8_defer_f64, pm_bsc_defer_apply_f64); 1011 the list-writing BSC pass keeps only overflowed datapoints' dense rows (pm_bsc_wp_sparse_expand_f64); 1007 fused scores GEMM + E-step (pm_bsc_estep_fused_f64); 1001 spd inverse, 1002 MMCA (pm_mca_params.signed_w), 1003 DSC, 1004 fused MCA pass + column moments, 1005 TSC flags in pm_dsc_params, weighted row norms, 1006 batched spd inverse, per-XCD scratch in the MCA / GSC statistics
 
 extern "C" const char *pm_error_string(int code) {
     if (code == PM_OK) return "ok";

@@ -1229,7 +1229,9 @@ __global__ __launch_bounds__(256) void gsc_det_quanta_kernel(const double *__res
                                                                int H, double sqrt_gamma, double ymax, double ynmax, double n,
                                                                double *__restrict__ out, double *__restrict__ gsc_M,
                                                                double *__restrict__ gemm_M, double *__restrict__ sparse_M) {
-    __shared__ double s_red[5][4];      // (four wavefronts: the kernel runs beside the scores GEMM and must find room on a CU)
+    // (four wavefronts: the kernel runs beside the scores GEMM and must find room on a CU.  15 us on an idle device, ~130 us
+    // beside that GEMM -- s_setprio changes nothing -- and still done before it: the next pass waits for the GEMM, not for this)
+    __shared__ double s_red[5][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double w2max = 0.0, w2min = INFINITY, mumax = 0.0, prow = 0.0, pdiag = 0.0;
     for (int h = tid; h < H; h += 256) {
@@ -1295,41 +1297,69 @@ __global__ __launch_bounds__(256) void gsc_det_quanta_kernel(const double *__res
 
 // A row list built with an atomic counter (the dense rows of gsc_estep_kernel<LIST>: in the order the workgroups finished) put
 // into ASCENDING order, in place: the gathered GEMM behind it then sums its K-slices in an order that does not depend on the
-// schedule.  One workgroup: the rows as bits of an LDS bitmap (N <= 2^20), a prefix sum over its words, the bits written back.
-__global__ __launch_bounds__(1024) void sort_row_list_kernel(int32_t *__restrict__ rows, const int32_t *__restrict__ count, int N) {
-    extern __shared__ unsigned long long s_bits[];
-    __shared__ int s_cnt[1024];
-    const int tid = threadIdx.x, words = (N + 63) >> 6;
-    for (int w = tid; w < words; w += 1024) s_bits[w] = 0ull;
+// schedule.  Three small launches: every listed row sets its byte in a flag array of N bytes (plain stores; zero on entry);
+// a workgroup per chunk of 8192 rows counts the chunk's set bytes; the same grid again adds the counts in front of its chunk,
+// scans its own and writes the rows back in order, clearing the flags as it goes.  [Measured before: ONE workgroup with the
+// rows as bits of an LDS bitmap set by ds_or_b64 -- 50 us for 40 000 rows; one workgroup compacting the byte flags -- 61 us:
+// a single CU is slow at anything 200 KB wide.]
+__global__ __launch_bounds__(256) void row_list_flag_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ count,
+                                                             unsigned char *__restrict__ flags, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < *count) {
+        const int r = rows[i];
+        if (r >= 0 && r < N) flags[r] = 1;
+    }
+}
+
+// (a chunk = 1024 flag words = 8192 rows, one workgroup: lane-contiguous 8-byte loads)
+__global__ __launch_bounds__(1024) void row_list_count_kernel(const unsigned long long *__restrict__ flags8, int words,
+                                                               int *__restrict__ counts) {
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, w = blockIdx.x * 1024 + tid;
+    int c = w < words ? __popcll(flags8[w] & 0x0101010101010101ull) : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((tid & 63) == 0) s_wave[tid >> 6] = c;
     __syncthreads();
-    const int cnt = *count;
-    for (int i0 = tid; i0 < cnt; i0 += 8 * 1024) {       // eight loads in flight per thread (one at a time: 200 us for 40 000 rows)
-        int r[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (i0 + 1024 * j < cnt) ? rows[i0 + 1024 * j] : -1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (r[j] >= 0 && r[j] < N) atomicOr(&s_bits[r[j] >> 6], 1ull << (r[j] & 63));
+    if (tid == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += s_wave[k];
+        counts[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void row_list_write_kernel(int32_t *__restrict__ rows, unsigned long long *__restrict__ flags8,
+                                                               int words, const int *__restrict__ counts) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x * 1024 + tid;
+    int before = 0;                                          // rows of the chunks in front of this one
+    for (int k = tid; k < (int)blockIdx.x; k += 1024) before += counts[k];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if (lane == 0) s_wave[wave] = before;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += s_wave[k];
+        s_base = t;
     }
     __syncthreads();
-    const int per = (words + 1023) / 1024, w0 = tid * per, w1 = (w0 + per < words) ? w0 + per : words;
-    int mine = 0;
-    for (int w = w0; w < w1; ++w) mine += __popcll(s_bits[w]);
-    s_cnt[tid] = mine;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {              // inclusive scan (Hillis-Steele)
-        const int v = tid >= d ? s_cnt[tid - d] : 0;
-        __syncthreads();
-        s_cnt[tid] += v;
-        __syncthreads();
+    unsigned long long b = w < words ? flags8[w] & 0x0101010101010101ull : 0ull;
+    const int mine = __popcll(b);
+    int incl = mine;                                         // inclusive scan over the wavefront, then over the 16 wavefronts
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
     }
-    int o = s_cnt[tid] - mine;
-    for (int w = w0; w < w1; ++w) {
-        unsigned long long b = s_bits[w];
-        while (b) {
-            rows[o++] = (w << 6) + __builtin_ctzll(b);
-            b &= b - 1ull;
-        }
+    const int base = s_base;
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int o = base + incl - mine;
+    for (int k = 0; k < wave; ++k) o += s_wave[k];
+    if (b) flags8[w] = 0ull;
+    while (b) {
+        rows[o++] = (w << 3) + (__builtin_ctzll(b) >> 3);
+        b &= b - 1ull;
     }
 }
 }  // namespace
@@ -1353,19 +1383,17 @@ extern "C" int pm_gsc_det_quanta_f64(const double *gram, int64_t ldg, const doub
 #endif
 }
 
-extern "C" int pm_sort_row_list_i32(int32_t *rows, const int32_t *count, int64_t N, void *stream) {
-    if (!rows || !count || N < 0) return PM_EINVAL;
-    if (N > (1 << 20)) return PM_ERANGE;
+extern "C" int pm_sort_row_list_i32(int32_t *rows, const int32_t *count, int64_t N, unsigned char *flags, void *stream) {
+    if (!rows || !count || !flags || N < 0 || (reinterpret_cast<uintptr_t>(flags) & 7)) return PM_EINVAL;
+    if (N > INT32_MAX - 1024) return PM_ERANGE;
     if (N == 0) return PM_OK;
-    const size_t lds = (size_t)((N + 63) / 64) * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sort_row_list_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 20) / 8);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(sort_row_list_kernel, dim3(1), dim3(1024), lds, static_cast<hipStream_t>(stream), rows, count, (int)N);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(row_list_flag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, rows, count, flags, (int)N);
+    const int words = (int)((N + 7) / 8), chunks = (words + 1023) / 1024;
+    unsigned long long *f8 = reinterpret_cast<unsigned long long *>(flags);
+    int *counts = reinterpret_cast<int *>(flags + (size_t)words * 8);
+    hipLaunchKernelGGL(row_list_count_kernel, dim3((unsigned)chunks), dim3(1024), 0, s, f8, words, counts);
+    hipLaunchKernelGGL(row_list_write_kernel, dim3((unsigned)chunks), dim3(1024), 0, s, rows, f8, words, counts);
     return (int)hipGetLastError();
 }
 

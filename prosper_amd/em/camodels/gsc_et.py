@@ -416,7 +416,7 @@ class GSC(DeviceCAModel):
                        ctypes.c_double(s2), N, H, Hp, do_select, _ptr(cand), _ptr(xs), _ptr(xsz), both.stride(0),
                        _ptr(stats), _ptr(logpj), logpj.stride(0), self._stream())
         elif N and lists and self.fuse_moment_gemm and self.sparse_moments and cand_in is None \
-                and (not self.deterministic or N <= (1 << 20)) and _lib.load().pm_gsc_lists_supported(H, Hp, self.gamma, D):
+                and _lib.load().pm_gsc_lists_supported(H, Hp, self.gamma, D):
             # (`tables` comes from pm_gsc_mstep_finish_f64 here: its slot 8 H + 1 holds the list threshold)
             lb = res.setdefault("gsc_lists", [None, None])
             if lb[k] is None:
@@ -433,7 +433,11 @@ class GSC(DeviceCAModel):
                 # the dense rows were listed in the order the workgroups finished: ascending, so that the gathered GEMM's
                 # K-slices hold the same rows in the same order in every run.  (Right behind the pass, on an idle device: beside
                 # the sparse product the one-workgroup kernel waited 0.2 ms for room on a CU, and the GEMM for it.)
-                self._call("estep", "pm_sort_row_list_i32", _ptr(dense_rows), _ptr(dense_count), N, self._stream())
+                flags = res.get("gsc_row_flags")
+                if flags is None:      # (zero between calls: the compaction clears what it reads)
+                    flags = res["gsc_row_flags"] = torch.zeros((N + 7) // 8 * 8 + 4 * ((N + 8191) // 8192), dtype=torch.uint8,
+                                                               device=self.device)
+                self._call("estep", "pm_sort_row_list_i32", _ptr(dense_rows), _ptr(dense_count), N, _ptr(flags), self._stream())
             stats._pm_lists = (nz_idx, nz_val, dense_rows, dense_count, bufs[k])
         elif N:
             self._call("estep", "pm_gsc_estep_f64", _ptr(A), H, _ptr(G), _ptr(psi_d), _ptr(yn),

@@ -204,15 +204,19 @@ def test_sort_row_list_and_device_quanta():
     import ctypes
     from prosper_amd import _lib
     rng = np.random.RandomState(5)
-    for N, cnt in ((1000, 0), (1000, 1), (1000, 1000), (200_000, 41_237), (1 << 20, 77_777)):
+    for N, cnt in ((1000, 0), (1000, 1), (1000, 1000), (1003, 1003), (200_000, 41_237), (1 << 20, 77_777), (3_000_001, 500_000)):
         rows = rng.permutation(N)[:cnt].astype(np.int32)
         buf = torch.full((max(cnt, 1) + 8,), -7, dtype=torch.int32, device="cuda")
         buf[:cnt] = torch.from_numpy(rows).cuda()
         count = torch.tensor([cnt], dtype=torch.int32, device="cuda")
-        _lib.call("pm_sort_row_list_i32", ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(count.data_ptr()), N, None)
+        nflag = (N + 7) // 8 * 8
+        flags = torch.zeros(nflag + 4 * ((N + 8191) // 8192), dtype=torch.uint8, device="cuda")
+        _lib.call("pm_sort_row_list_i32", ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(count.data_ptr()), N,
+                  ctypes.c_void_p(flags.data_ptr()), None)
         torch.cuda.synchronize()
         got = buf.cpu().numpy()
         assert np.array_equal(got[:cnt], np.sort(rows)) and (got[cnt:] == -7).all(), (N, cnt)
+        assert int(flags[:nflag].sum()) == 0, "the flag array is handed back cleared"
     make, p, y, _ = _gsc((128, 128, 6, 3, 600))
     m = make()
     m.deterministic = True
