@@ -15,6 +15,10 @@ Fixtures (all float64, bit-for-bit what the reference returned):
                         20 EM.run steps, parameters after every step
   bsc_init_c1.npz       generate_data + standard_init for fixed seeds (RNG stream order)
   anneal_tracks.npz     LinearAnnealing values per step for the bars-learning schedule
+  schedule_<name>.npz   the reference's own 50-step schedule at config-2 / 4 / 5 dimensions (+ MMCA, DSC, TSC): per-step
+                        L, N_use, parameters (tests/golden/schedule_inputs.py holds the seeded inputs).  Slow: the
+                        reference needs 9 minutes each for bsc_c2 and gsc_c4 -- `make_golden.py schedule` mints only
+                        these, `make_golden.py schedule mca_c5,dsc` a subset
 """
 import os
 import sys
@@ -693,7 +697,7 @@ def main(only=None, cases=None):
     gsc_posterior_hprime_case()
     bsc_trajectory()
     # the reference's 50-step schedule at the dimensions of BASELINE configs 2, 4 and 5 (round 6)
-    schedule_trajectory("bsc_c2", "bsc", 1024, 256, 8, 4, 4000, seed=201)
+    schedule_trajectory("bsc_c2", "bsc", 1024, 256, 8, 4, 2500, seed=201)
     schedule_trajectory("gsc_c4", "gsc", 256, 128, 6, 3, 200, seed=202)
     schedule_trajectory("mca_c5", "mca", 256, 128, 8, 3, 200, seed=203)
     schedule_trajectory("mmca", "mmca", 256, 128, 8, 3, 200, seed=204)
