@@ -121,9 +121,15 @@ __device__ __forceinline__ void sym_inverse(double (&M)[G][G], LogDet &ld) {
 // normal double become `tiny`) from the 2^(j/128) table (pm_exp_tab: 14 instructions, relative error 2.3e-16; libm's exp
 // is ~45, and a datapoint evaluates 11-12 of them per lane: a tenth of the kernel's instructions).  exp(x) < tiny exactly
 // when x < log(tiny): decided on the argument; arguments above 700 (never seen: a log-joint) take libm.
+// (round 6: the table form saturates at exp(-708.0); an argument in [log(tiny), -708.0) -- a weight within a factor 1.5 of the
+// clamp, i.e. a datapoint ALL of whose states have underflowed: 8 of config 4's 200 000 -- used to get exp(-708.0), up to 48 %
+// too much; found by comparing every row of the shard with the oracle, test_config4_full_shard_against_oracle.  libm there.)
 __device__ __forceinline__ double gsc_weight(double x, const double *etab) {
     const double tiny = 2.2250738585072014e-308;
-    if (__builtin_expect(x > 700.0, 0)) return exp(x);
+    if (__builtin_expect(x > 700.0 || (x < -708.0 && x >= -708.3964185322641), 0)) {
+        const double e = exp(x);
+        return e < tiny ? tiny : e;
+    }
     double p = pm_exp_tab(x, etab);
     if (!(x >= -708.3964185322641)) p = tiny;            // (NaN included)
     return p;

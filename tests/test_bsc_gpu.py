@@ -1196,6 +1196,58 @@ def test_config2_full_shard_against_oracle(dev):
     assert int(round(sc[2])) == len(rows)
 
 
+def test_config2_full_shard_every_row_against_oracle(dev):
+    """The same shard, EVERY row (round 6; the sampled test above was the answer to a slow host -- the GPU boxes' hosts run the
+    vectorised oracle at ~20 k datapoints/s): candidates of all 200 000 datapoints equal to the oracle's, all 82 M log-joints
+    to 1e-10, and the full shard's M-step statistics (Wp, Wq, the sigma sum, the kept count) against the oracle's summed over
+    chunks -- through the shipped launches (1536 sixteen-wavefront workgroups + the TAIL launch), statistics from the pass."""
+    from oracle import bsc_oracle as O
+    from prosper_amd import _lib
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    D, H, Hp, gamma, N = 1024, 256, 8, 4, 200_000
+    rs0 = np.random.RandomState(0)
+    W_gt_h = rs0.randn(D, H)
+    W0 = np.ascontiguousarray((W_gt_h + 0.1 * rs0.randn(D, H)).T).T
+    W_gt = torch.from_numpy(W_gt_h).to(dev)
+    rs = np.random.RandomState(0)
+    Y = torch.empty(N, D, dtype=torch.float64, device=dev)
+    for lo in range(0, N, 25_000):
+        S = torch.from_numpy((rs.random_sample((25_000, H)) < 4.0 / H).astype(np.float64)).to(dev)
+        noise = torch.from_numpy(rs.normal(size=(25_000, D))).to(dev)
+        Y[lo:lo + 25_000] = torch.addmm(noise, S, W_gt.t())
+    del S, noise
+    params = {"W": W0, "pi": 4.0 / H, "sigma": 1.0, "mu": np.zeros(D)}
+    an = _An(T=1.0)
+    m = BSC_ET(D, H, Hp, gamma)
+    p = m.step(an, dict(params), {"y": Y})                  # (the statistics-carrying pass + M-step, as an EM loop runs them)
+    Wp, Wq = _device_stats(m)
+    sc = m._ws["stats"].cpu().numpy()[_lib.load().pm_bsc_stats_offset_scalars(H, D):][:3]
+    d = m.select_Hprimes(dict(params), {"y": Y})
+    ss = m.E_step(an, dict(params), d)
+    cand, lp = d["candidates"].tensor, ss["logpj"].tensor
+    om = O.make_model(D, H, Hp, gamma)
+    Wp_ref, Wq_ref, sig_ref, worst, bad = np.zeros((H, D)), np.zeros((H, H)), 0.0, 0.0, 0
+    CH = 8192
+    for lo in range(0, N, CH):
+        y_c = Y[lo:lo + CH].cpu().numpy()
+        c_ref = O.select_hprimes_vec(W0, y_c, Hp)
+        bad += int((cand[lo:lo + CH].cpu().numpy() != c_ref).any(axis=1).sum())
+        lp_ref = O.e_step_vec(O.Anneal(T=1.0), W0, params["pi"], params["sigma"], params["mu"], y_c, c_ref, om["SM"],
+                              om["state_abs"])
+        got = lp[lo:lo + CH].cpu().numpy()
+        worst = max(worst, float(np.max(np.abs(got - lp_ref) / (1e-9 + 1e-10 * np.abs(lp_ref)))))
+        st = O.m_step_stats_vec(W0, params["mu"], y_c, c_ref, lp_ref, om["SM"])
+        Wp_ref += st["Wp"]
+        Wq_ref += st["Wq"]
+        sig_ref += st["sigma"]
+    assert bad == 0, "%d of %d datapoints with other candidates than the oracle's" % (bad, N)
+    assert worst <= 1.0, "log-joints: %.2f times the tolerance (rtol 1e-10, atol 1e-9)" % worst
+    np.testing.assert_allclose(Wp, Wp_ref, rtol=1e-9, atol=1e-11 * np.abs(Wp_ref).max())
+    np.testing.assert_allclose(Wq, Wq_ref, rtol=1e-9, atol=1e-12 * np.abs(Wq_ref).max())
+    np.testing.assert_allclose(sc[0], sig_ref, rtol=1e-10)
+    assert int(round(sc[2])) == N and np.isfinite(p["W"]).all()
+
+
 def test_empty_and_tiny_shards(dev):
     """N = 0 rows on a rank must not launch anything; N = 1 works."""
     from prosper_amd.em.camodels.bsc_et import BSC_ET

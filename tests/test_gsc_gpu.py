@@ -626,7 +626,7 @@ def test_gsc_pair_block_threshold_drops_nothing_visible():
 
 def test_config4_full_shard_against_oracle():
     """BASELINE config 4 at its real size -- D=256 H=128 H'=6 gamma=3, N = 200 000 -- through the shipped launches.
-    The oracle runs on ~400 sampled rows: candidates identical, posterior moments xpt_s / xpt_sz to 1e-9; the sampled rows
+    The oracle runs on ~400 sampled rows -- and, round 6, on every row -- : candidates identical, posterior moments xpt_s / xpt_sz to 1e-9; the sampled rows
     as a shard of their own reproduce the oracle's whole EM step (device M-step tail included)."""
     from oracle import gsc_oracle as G
     from prosper_amd.em.camodels.gsc_et import GSC
@@ -656,6 +656,22 @@ def test_config4_full_shard_against_oracle():
     suff = G.e_step(G.Anneal(T=1.0), model, p, y_s, cand_ref)
     np.testing.assert_allclose(ss["xpt_s"].tensor[idx].cpu().numpy(), suff["xpt_s"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(ss["xpt_sz"].tensor[idx].cpu().numpy(), suff["xpt_sz"], rtol=1e-9, atol=1e-12)
+    # round 6: the candidates of EVERY datapoint, and the moments of every datapoint too (the oracle's E-step walks the data
+    # clusters in Python: ~0.25 ms per row on the GPU boxes' hosts)
+    bad = 0
+    for lo in range(0, N, 20_000):
+        c_ref = G.select_hprimes(p, Y[lo:lo + 20_000].cpu().numpy(), Hp)
+        bad += int((data["candidates"].tensor[lo:lo + 20_000].cpu().numpy().astype(np.int64) != c_ref).any(axis=1).sum())
+    assert bad == 0, "%d of %d datapoints with other candidates than the oracle's" % (bad, N)
+    worst = 0.0
+    for lo in range(0, N, 2000):          # (2000 rows at a time: the oracle materialises the (n, H, H) second moments)
+        y_m = Y[lo:lo + 2000].cpu().numpy()
+        c_m = data["candidates"].tensor[lo:lo + 2000].cpu().numpy().astype(np.int64)
+        suff_m = G.e_step(G.Anneal(T=1.0), model, p, y_m, c_m)
+        for k in ("xpt_s", "xpt_sz"):
+            got_m = ss[k].tensor[lo:lo + 2000].cpu().numpy()
+            worst = max(worst, float(np.max(np.abs(got_m - suff_m[k]) / (1e-12 + 1e-9 * np.abs(suff_m[k])))))
+    assert worst <= 1.0, "posterior moments: %.2f times the tolerance (rtol 1e-9, atol 1e-12)" % worst
     new = m.M_step(an, cp(p), ss, data)
     assert np.isfinite(new["W"]).all() and (new["pi"] > 0).all() and new["sigma_sq"] > 0
     ref, log = G.em_step(G.Anneal(T=1.0), model, cp(p), y_s)

@@ -269,6 +269,22 @@ def test_config5_full_shard_against_oracle():
     got = MCA_ET(D, H, Hp, gamma).step(an, dict(params), {"y": y_s})
     np.testing.assert_allclose(got["W"], ref["W"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose([got["pi"], got["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-9)
+    # ... and EVERY row of the shard (round 6; 500 sampled rows before: the GPU boxes' hosts run the vectorised oracle at
+    # ~3 k datapoints/s)
+    worst, bad = 0.0, 0
+    every = np.arange(0, N)
+    for lo in range(0, len(every), 2048):
+        r = every[lo:lo + 2048]
+        ix = torch.from_numpy(r).to(dev)
+        y_c = Y[ix].cpu().numpy()
+        c_ref = M.select_hprimes_vec(W0, y_c, Hp)
+        c_got = data["candidates"].tensor[ix].cpu().numpy()
+        bad += int((np.sort(c_got, 1) != np.sort(c_ref, 1)).any(axis=1).sum())
+        lp_c = M.e_step_vec(M.Anneal(T=1.0), W0, params["pi"], params["sigma"], y_c, c_got, model["SM"], model["state_abs"])
+        got_c = ss["logpj"].tensor[ix].cpu().numpy()
+        worst = max(worst, float(np.max(np.abs(got_c - lp_c) / (1e-9 + 1e-10 * np.abs(lp_c)))))
+    assert bad == 0, "%d of %d datapoints with another candidate set than the oracle's" % (bad, len(every))
+    assert worst <= 1.0, "log-joints: %.2f times the tolerance (rtol 1e-10, atol 1e-9)" % worst
 
 
 @pytest.mark.parametrize("tag,kw", [("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
