@@ -359,6 +359,23 @@ def test_full_shard_against_oracle_rows(model):
     logpj = M.e_step_vec(oan, om, W0, pi, 1.0, y[idx], cand)
     got = np.asarray(ss["logpj"][idx])
     np.testing.assert_allclose(got, logpj, rtol=1e-10, atol=1e-9)
+    # round 6: EVERY row of the shard -- candidates (equal up to ties of the ranked scores) and all log-joints
+    worst, moved = 0.0, 0
+    cand_all, lp_all = np.asarray(data["candidates"]), ss["logpj"]
+    for lo in range(0, N, 4096):
+        y_c, c_c = y[lo:lo + 4096], cand_all[lo:lo + 4096]
+        ref_c = M.select_hprimes_vec(om, W0, pi, 1.0, y_c)
+        if model == "dsc":
+            moved += _check_candidates(c_c, ref_c, M.select_scores_vec(om, W0, pi, 1.0, y_c))
+        else:
+            best_c = M.select_scores_vec(om, W0, y_c)
+            np.testing.assert_allclose(np.sort(np.take_along_axis(best_c, c_c, 1), axis=1),
+                                       np.sort(np.take_along_axis(best_c, ref_c, 1), axis=1), rtol=1e-9)
+        lp_c = M.e_step_vec(oan, om, W0, pi, 1.0, y_c, c_c)
+        got_c = np.asarray(lp_all[lo:lo + 4096])
+        worst = max(worst, float(np.max(np.abs(got_c - lp_c) / (1e-9 + 1e-10 * np.abs(lp_c)))))
+    assert worst <= 1.0, "log-joints: %.2f times the tolerance (rtol 1e-10, atol 1e-9)" % worst
+    assert moved <= N // 1000, moved
     new = m.M_step(an, params, ss, data)
     E = m._ws["expect"].cpu().numpy()
     q = np.exp(logpj - np.logaddexp.reduce(logpj, axis=1, keepdims=True))

@@ -117,6 +117,41 @@ def test_mmca_step_matches_oracle(D, H, Hp, gamma, N, T, ncut):
         np.testing.assert_allclose(new["Q"], lAi * log["N_use"] + logsumexp(logpj[keep], axis=1).sum(), rtol=1e-10)
 
 
+def test_mmca_full_shard_every_row_against_oracle():
+    """MMCA at config 5's dimensions on one GPU's share (N = 100 000; the bench's `mmca` shape) through the shipped launches --
+    distance-mode selection, the fused E-step + M-statistics pass with signed W: the log-joints of EVERY row against the
+    vectorised oracle on the device's candidates (1e-10), the candidates against the oracle's on every 25th row (its
+    selection is a per-datapoint loop), and one EM step on a sample as its own shard."""
+    from oracle import mmca_oracle as M
+    from prosper_amd.em.camodels.mmca_et import MMCA_ET
+    D, H, Hp, gamma, N = 256, 128, 8, 3, 100_000
+    rng = np.random.RandomState(77)
+    W_gt = rng.normal(size=(D, H)) * 3.0
+    y = np.empty((N, D))
+    for lo in range(0, N, 10_000):
+        s = rng.random_sample((10_000, H)) < 2.0 / H
+        y[lo:lo + 10_000] = M.generate_from_hidden(W_gt, s) + rng.normal(size=(10_000, D))
+    params = {"W": W_gt * (1 + 0.02 * rng.uniform(-1, 1, size=(D, H))), "pi": 2.4 / H, "sigma": 1.1}
+    model = M.make_model(D, H, Hp, gamma)
+    m = MMCA_ET(D, H, Hp, gamma)
+    p = m.check_params({k: (v.copy() if hasattr(v, "copy") else v) for k, v in params.items()})
+    an = _An(T=1.0)
+    data = m.select_Hprimes(p, {"y": y})
+    ss = m.E_step(an, p, data)
+    cand, lp = np.asarray(data["candidates"]), ss["logpj"]
+    worst = 0.0
+    for lo in range(0, N, 2048):
+        ref = M.e_step_vec(M.Anneal(T=1.0), p["W"], p["pi"], p["sigma"], y[lo:lo + 2048], cand[lo:lo + 2048], model["SM"],
+                           model["state_abs"])
+        got = np.asarray(lp[lo:lo + 2048])
+        worst = max(worst, float(np.max(np.abs(got - ref) / (1e-9 + 1e-10 * np.abs(ref)))))
+    assert worst <= 1.0, "log-joints: %.2f times the tolerance (rtol 1e-10, atol 1e-9)" % worst
+    rows = np.arange(0, N, 25)
+    _same_candidates(cand[rows], M.select_hprimes_loop(p["W"], y[rows], Hp), p["W"], y[rows])
+    new = m.M_step(an, p, ss, data)
+    assert np.isfinite(new["W"]).all() and 0 < new["pi"] < 1 and new["sigma"] > 0
+
+
 def test_mmca_em_improves_likelihood():
     """A few EM steps through the reference-shaped driver loop raise Q on MMCA data."""
     from oracle import mmca_oracle as M
