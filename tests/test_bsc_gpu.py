@@ -1248,6 +1248,55 @@ def test_config2_full_shard_every_row_against_oracle(dev):
     assert int(round(sc[2])) == N and np.isfinite(p["W"]).all()
 
 
+def test_config2_full_shard_truncation_step_against_oracle(dev):
+    """A whole EM step of config 2 at its real size on an ANNEALED, DATA-TRUNCATING point of the reference's schedule (T = 1.6,
+    Ncut_factor = 0.5: what 49 of its 50 steps look like) against the oracle on all 200 000 rows: ``CAModel.step`` -- the pass
+    that leaves per-datapoint records, the cut selected on the device, the apply kernel, the sparse product, the solve --
+    returns the oracle's W, pi, sigma; the same N_use and free energy are logged (round 6)."""
+    from oracle import bsc_oracle as O
+    from prosper_amd.em.camodels.bsc_et import BSC_ET
+    from prosper_amd.utils.datalog import dlog, StoreInMemory
+    D, H, Hp, gamma, N = 1024, 256, 8, 4, 200_000
+    # (bench.py's own data -- causes of norm 32 in unit noise, four per datapoint -- sits in the regime where the reference's
+    # un-stabilised exp(logpj) sums underflow for every datapoint with a cause outside its state set: its cut is 0 and it
+    # keeps ALL datapoints, which the device mirrors (N_use = N in both: measured with this test's first version).  Causes of
+    # norm ~10, two per datapoint: a genuine cut.)
+    rs0 = np.random.RandomState(0)
+    W_gt_h = 0.3 * rs0.randn(D, H)
+    W0 = np.ascontiguousarray((W_gt_h + 0.03 * rs0.randn(D, H)).T).T
+    rs = np.random.RandomState(0)
+    y = np.empty((N, D))
+    for lo in range(0, N, 25_000):
+        S = (rs.random_sample((25_000, H)) < 2.0 / H).astype(np.float64)
+        y[lo:lo + 25_000] = rs.normal(size=(25_000, D)) + S @ W_gt_h.T
+    Y = torch.from_numpy(y).to(dev)
+    params = {"W": W0, "pi": 2.0 / H, "sigma": 1.0, "mu": np.zeros(D)}
+    an = _An(T=1.6, Ncut_factor=0.5)
+    m = BSC_ET(D, H, Hp, gamma)
+    h = dlog.set_handler(("N_use", "L"), StoreInMemory)
+    try:
+        new = m.step(an, dict(params), {"y": Y})
+    finally:
+        dlog.remove_handler(h)
+    assert m.defer_stats and m._fused()
+    om = O.make_model(D, H, Hp, gamma)
+    oan = O.Anneal(T=1.6, Ncut_factor=0.5, anneal_prior=False)
+    K = 1 + H + om["SM"].shape[0]
+    cand = np.empty((N, Hp), dtype=np.int64)
+    logpj = np.empty((N, K))
+    CH = 8192
+    for lo in range(0, N, CH):
+        cand[lo:lo + CH] = O.select_hprimes_vec(W0, y[lo:lo + CH], Hp)
+        logpj[lo:lo + CH] = O.e_step_vec(oan, W0, params["pi"], params["sigma"], params["mu"], y[lo:lo + CH], cand[lo:lo + CH],
+                                         om["SM"], om["state_abs"])
+    ref, log = O.m_step(oan, om, W0, params["pi"], params["sigma"], params["mu"], y, cand, logpj,
+                        stats_fn=O.m_step_stats_vec, shards=[np.arange(lo, min(lo + CH, N)) for lo in range(0, N, CH)])
+    assert int(h.tables["N_use"][0]) == log["N_use"] and 0.5 * N < log["N_use"] < N
+    np.testing.assert_allclose(h.tables["L"][0], log["L"], rtol=1e-10)
+    np.testing.assert_allclose([new["pi"], new["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-9)
+    np.testing.assert_allclose(new["W"], ref["W"], rtol=0, atol=1e-8 * np.abs(ref["W"]).max())
+
+
 def test_empty_and_tiny_shards(dev):
     """N = 0 rows on a rank must not launch anything; N = 1 works."""
     from prosper_amd.em.camodels.bsc_et import BSC_ET
