@@ -664,16 +664,49 @@ def test_config4_full_shard_against_oracle():
         bad += int((data["candidates"].tensor[lo:lo + 20_000].cpu().numpy().astype(np.int64) != c_ref).any(axis=1).sum())
     assert bad == 0, "%d of %d datapoints with other candidates than the oracle's" % (bad, N)
     worst = 0.0
+    full = {"xpt_s": np.empty((N, H)), "xpt_sz": np.empty((N, H)), "xpt_ss": np.zeros((1, H, H)), "xpt_szsz": np.zeros((1, H, H))}
+    y_host = np.empty((N, D))
     for lo in range(0, N, 2000):          # (2000 rows at a time: the oracle materialises the (n, H, H) second moments)
-        y_m = Y[lo:lo + 2000].cpu().numpy()
+        y_m = y_host[lo:lo + 2000] = Y[lo:lo + 2000].cpu().numpy()
         c_m = data["candidates"].tensor[lo:lo + 2000].cpu().numpy().astype(np.int64)
         suff_m = G.e_step(G.Anneal(T=1.0), model, p, y_m, c_m)
         for k in ("xpt_s", "xpt_sz"):
             got_m = ss[k].tensor[lo:lo + 2000].cpu().numpy()
             worst = max(worst, float(np.max(np.abs(got_m - suff_m[k]) / (1e-12 + 1e-9 * np.abs(suff_m[k])))))
+            full[k][lo:lo + 2000] = suff_m[k]
+        full["xpt_ss"][0] += suff_m["xpt_ss"].sum(axis=0)
+        full["xpt_szsz"][0] += suff_m["xpt_szsz"].sum(axis=0)
     assert worst <= 1.0, "posterior moments: %.2f times the tolerance (rtol 1e-9, atol 1e-12)" % worst
     new = m.M_step(an, cp(p), ss, data)
     assert np.isfinite(new["W"]).all() and (new["pi"] > 0).all() and new["sigma_sq"] > 0
+    # ... and the M-step of the WHOLE shard -- list pass, sparse product + gathered GEMM, pair atomics under their threshold,
+    # device-side inverses and finish kernel -- against the oracle's update from its own moments of all 200 000 rows (the
+    # (N, H, H) moments enter the update only as sums: accumulated chunk by chunk)
+    ref_full = G.m_step(model, cp(p), full, y_host)
+    tol_f = max(1e-8, 50 * np.linalg.cond(full["xpt_szsz"][0]) * np.finfo(float).eps)
+    for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
+        np.testing.assert_allclose(new[k], ref_full[k], rtol=10 * tol_f, atol=tol_f * max(1.0, np.abs(ref_full[k]).max()),
+                                   err_msg="full shard: " + k)
+    # ... and the SECOND step of an EM loop on the whole shard -- the pass the first M-step launched itself: lists, the sparse
+    # product + the gathered GEMM over the dense rows -- against the oracle's second step from the oracle's first
+    m2 = GSC(D, H, Hp, gamma, 'scalar')
+    m2._predict_anneal(an)                 # (as if a step at this annealing point had gone before: the look-ahead is trusted)
+    p1 = m2.step(an, cp(p), {"y": Y})
+    p2 = m2.step(an, p1, {"y": Y})
+    assert m2.spec_hits == 1
+    full2 = {"xpt_s": np.empty((N, H)), "xpt_sz": np.empty((N, H)), "xpt_ss": np.zeros((1, H, H)), "xpt_szsz": np.zeros((1, H, H))}
+    for lo in range(0, N, 2000):
+        y_m = y_host[lo:lo + 2000]
+        suff_m = G.e_step(G.Anneal(T=1.0), model, ref_full, y_m, G.select_hprimes(ref_full, y_m, Hp))
+        for k in ("xpt_s", "xpt_sz"):
+            full2[k][lo:lo + 2000] = suff_m[k]
+        full2["xpt_ss"][0] += suff_m["xpt_ss"].sum(axis=0)
+        full2["xpt_szsz"][0] += suff_m["xpt_szsz"].sum(axis=0)
+    ref2 = G.m_step(model, cp(ref_full), full2, y_host)
+    tol_2 = 10 * max(1e-8, 50 * np.linalg.cond(full2["xpt_szsz"][0]) * np.finfo(float).eps)       # (two steps of error growth)
+    for k in ("W", "pi", "mu", "psi_sq", "sigma_sq"):
+        np.testing.assert_allclose(p2[k], ref2[k], rtol=10 * tol_2, atol=tol_2 * max(1.0, np.abs(ref2[k]).max()),
+                                   err_msg="full shard, second step: " + k)
     ref, log = G.em_step(G.Anneal(T=1.0), model, cp(p), y_s)
     got = GSC(D, H, Hp, gamma, 'scalar').step(an, cp(p), {"y": y_s})
     tol = max(1e-8, 50 * np.linalg.cond(log["suff"]["xpt_szsz"].sum(0)) * np.finfo(float).eps)
