@@ -287,6 +287,65 @@ def test_config5_full_shard_against_oracle():
     assert worst <= 1.0, "log-joints: %.2f times the tolerance (rtol 1e-10, atol 1e-9)" % worst
 
 
+def test_config5_full_shard_truncation_step_against_oracle():
+    """A whole EM step of config 5 at one GPU's share (N = 100 000) on an annealed, data-truncating point of the reference's
+    schedule (T = 1.4 -> rho = 3.5, Ncut_factor = 0.5) against the oracle on ALL rows (round 6): ``CAModel.step`` -- the pass
+    with the uniform-exponent power that leaves per-datapoint records, the cut selected on the device, the LDS-privatised
+    scatter -- returns the oracle's W, pi, sigma and Q.  The oracle's statistics are sums over the kept datapoints: its
+    m_step runs on them chunk by chunk (the cut itself from the log-denominators of all rows, mca_et.py:237-262)."""
+    from oracle import mca_oracle as M
+    from prosper_amd.em.camodels.mca_et import MCA_ET
+    dev = torch.device("cuda", 0)
+    D, H, Hp, gamma, N = 256, 128, 8, 3, 100_000
+    rng = np.random.RandomState(56)
+    W_gt = np.abs(rng.normal(size=(D, H))) * 2 + 0.1
+    y = np.empty((N, D))
+    for lo in range(0, N, 10_000):
+        s = rng.random_sample((10_000, H)) < 2.0 / H
+        y[lo:lo + 10_000] = np.where(s[:, None, :], W_gt[None, :, :], 0.0).max(axis=2) + rng.normal(size=(10_000, D))
+    params = M.check_params({"W": W_gt * (1 + 0.1 * rng.uniform(-1, 1, size=(D, H))), "pi": 2.0 / H, "sigma": 1.0})
+    T, ncut = 1.4, 0.5
+    an = _An(T=T, Ncut_factor=ncut)
+    m = MCA_ET(D, H, Hp, gamma)
+    got = m.step(an, {k: (v.copy() if hasattr(v, "copy") else v) for k, v in params.items()}, {"y": torch.from_numpy(y).to(dev)})
+    assert m.defer_stats
+    model = M.make_model(D, H, Hp, gamma)
+    oan = M.Anneal(T=T, Ncut_factor=ncut)
+    K = 1 + H + model["SM"].shape[0]
+    cand = np.empty((N, Hp), dtype=np.int64)
+    logpj = np.empty((N, K))
+    for lo in range(0, N, 2048):
+        cand[lo:lo + 2048] = M.select_hprimes_vec(params["W"], y[lo:lo + 2048], Hp)
+        logpj[lo:lo + 2048] = M.e_step_vec(oan, params["W"], params["pi"], params["sigma"], y[lo:lo + 2048], cand[lo:lo + 2048],
+                                           model["SM"], model["state_abs"])
+    beta = 1.0 / T
+    corr = beta * logpj.max(axis=1)
+    denoms = np.log(np.exp(beta * logpj - corr[:, None]).sum(axis=1)) + corr
+    A_pg, B_pg = M.pi_gamma_factors(params["pi"], H, gamma)
+    N_use = int(N * (1 - (1 - A_pg) * ncut))
+    keep = np.nonzero(denoms >= np.sort(denoms, kind="mergesort")[-N_use])[0]
+    N_use = len(keep)
+    assert 0.5 * N < N_use < N
+    tot, ld = None, 0.0
+    flat = M.Anneal(T=T, Ncut_factor=0.0)                       # (the kept rows' statistics; the cut is applied above)
+    for lo in range(0, N_use, 2048):
+        r = keep[lo:lo + 2048]
+        _, log = M.m_step(flat, model, params["W"], params["pi"], params["sigma"], y[r], cand[r], logpj[r], vec=True)
+        tot = log["stats"] if tot is None else {k: tot[k] + log["stats"][k] for k in tot}
+        ld += np.log(np.exp(logpj[r]).sum(axis=1)).sum()
+    Wp, Wq = tot["Wp"].copy(), tot["Wq"].copy()                 # (the update: mca_et.py:333-377)
+    tiny = np.finfo(np.float64).tiny
+    Wp[Wq < tiny] = 0.0
+    Wq[Wq < tiny] = tiny
+    W_ref = (Wp / Wq).T
+    pi_ref = A_pg / B_pg * params["pi"] * tot["pi"] / N_use
+    sigma_ref = np.sqrt(tot["sigma"] / D / N_use)
+    Q_ref = ((H * np.log(1. - pi_ref)) - ((D / 2) * np.log(2 * np.pi)) - (D * np.log(sigma_ref))) * N_use + ld
+    np.testing.assert_allclose(got["W"], W_ref, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose([got["pi"], got["sigma"]], [pi_ref, sigma_ref], rtol=1e-9)
+    np.testing.assert_allclose(got["Q"], Q_ref, rtol=1e-10)
+
+
 @pytest.mark.parametrize("tag,kw", [("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(topK=4, adaptive=True)),
                                     ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True))])
 def test_mca_inference_matches_reference(tag, kw, capsys):
