@@ -155,6 +155,25 @@ _INFERENCE_RUNS = (("plain", dict(topK=5, adaptive=False)), ("adaptive", dict(to
                    ("capped", dict(topK=3, adaptive=True, Hprime_max=5, gamma_max=3, logprob=True)))
 
 
+def inference_big_case(kind, D, H, Hp, gamma, N, seed):
+    """CAModel.inference on thousands of datapoints (inputs: schedule_inputs.py): plain top-K and the adaptive H' / gamma
+    growth with caps -- ties, repeated growth rounds and every exit of the loop get exercised, which 60 datapoints do not."""
+    from schedule_inputs import schedule_inputs
+    y, p0 = schedule_inputs(kind, D, H, N, seed)
+    if kind == "gsc":
+        model = GSC(D, H, Hp, gamma, sigma_sq_type="scalar")
+    else:
+        model = {"bsc": BSC_ET, "mca": MCA_ET}[kind](D, H, Hp, gamma)
+    anneal = LinearAnnealing(1)
+    anneal["T"] = [(0, 1.)]
+    anneal["anneal_prior"] = False
+    out = _inference_runs(model, anneal, p0, y, (("plain", dict(topK=4, adaptive=False)),
+                                                   ("capped", dict(topK=3, adaptive=True, Hprime_max=Hp + 1, gamma_max=gamma + 1))))
+    np.savez_compressed(os.path.join(HERE, "%s_inference_big.npz" % kind), D=D, H=H, Hprime=Hp, gamma=gamma, N=N, seed=seed, **out)
+    print("%s_inference_big: N=%d, capped gamma max %d, Hprime max %d, %d datapoints grown" % (
+        kind, N, out["capped_gamma"].max(), out["capped_Hprime"].max(), int((out["capped_Hprime"] > Hp).sum())))
+
+
 def mca_inference_case():
     """CAModel.inference (camodels/__init__.py:256-375) of MCA_ET: compute_lpj = select_Hprimes + E_step
     (mca_et.py:88-179), top-K states, marginals, adaptive H'/gamma."""
@@ -636,7 +655,7 @@ def main(only=None, cases=None):
     g = globals()
     for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
                "mca_inference_case", "mmca_inference_case", "gsc_inference_case", "gsc_posterior_hprime_case", "bsc_trajectory",
-               "bsc_init", "anneal_tracks", "schedule_trajectory"):
+               "bsc_init", "anneal_tracks", "schedule_trajectory", "inference_big_case"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
     if cases:
@@ -695,6 +714,9 @@ def main(only=None, cases=None):
     mmca_inference_case()
     gsc_inference_case()
     gsc_posterior_hprime_case()
+    inference_big_case("bsc", 64, 40, 6, 3, 3000, seed=301)
+    inference_big_case("mca", 64, 40, 6, 3, 2000, seed=302)
+    inference_big_case("gsc", 48, 24, 5, 3, 1500, seed=303)
     bsc_trajectory()
     # the reference's 50-step schedule at the dimensions of BASELINE configs 2, 4 and 5 (round 6)
     schedule_trajectory("bsc_c2", "bsc", 1024, 256, 8, 4, 2500, seed=201)
