@@ -589,7 +589,10 @@ class DeviceCAModel(CAModel):
         # small outputs (Gram matrices, the H x H x D solve products): the deterministic one-workgroup-per-tile kernel --
         # every rank holding the same operands gets the same bits, and no zero fill + K-slice atomics
         fn = "pm_gemm_nt_small_f64" if (M <= 512 and N <= 512) else "pm_gemm_nt_f64"
-        self._call(label, fn, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), M, N, K, self._stream())
+        # (a matrix of ONE row reports whatever stride its history left -- (D, 1).t().contiguous() keeps (1, 1): H = 1 -- and
+        # any leading dimension >= its row length describes it)
+        ld = lambda t, cols: t.stride(0) if t.shape[0] > 1 else max(int(t.stride(0)), int(cols))
+        self._call(label, fn, _ptr(A), ld(A, K), _ptr(B), ld(B, K), _ptr(out), ld(out, N), M, N, K, self._stream())
         return out
 
     def _upload(self, name, host, keep=False):

@@ -654,7 +654,9 @@ class BSC_ET(DeviceCAModel):
 
         # data truncation (bsc_et.py:247-258): keep the N_use datapoints with the largest evidence
         ncut = anneal['Ncut_factor'] > 0.0
-        N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor'])) if ncut else N
+        N_use = (int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor'])) or N) if ncut else N
+        # (int(...) == 0 on a handful of datapoints: upstream's allsort(...)[-0] is the SMALLEST value -- everything is kept,
+        # bsc_et.py:251-253)
 
         # per-datapoint statistics + Wp GEMM into the packed buffer
         tracing.tracepoint("M_step:iterating")

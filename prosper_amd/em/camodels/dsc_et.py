@@ -334,7 +334,7 @@ class DSC_ET(DeviceCAModel):
         lse_cut, cut_dev = float("-inf"), None
         if anneal['Ncut_factor'] > 0.0:
             tracing.tracepoint("M_step:truncating")
-            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
+            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor'])) or N    # (0: upstream's allsort(...)[-0] keeps everything)
             # the reference cuts on un-stabilised sums of exp(logpj), which are exactly 0 below the
             # underflow boundary: with the cut among those only strictly positive sums survive
             if lse.is_cuda and my_N:      # (the cut stays on the device: the row pass reads it there)

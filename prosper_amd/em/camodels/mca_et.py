@@ -280,7 +280,9 @@ class MCA_ET(DeviceCAModel):
             B_pi_gamma += gp * a
 
         ncut = anneal['Ncut_factor'] > 0.0
-        N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor'])) if ncut else N
+        N_use = (int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor'])) or N) if ncut else N
+        # (int(...) == 0 on a handful of datapoints: upstream's allsort(...)[-0] is the SMALLEST value -- everything is kept,
+        # mca_et.py:255-258)
         lib = _lib.load()
         n_stats = lib.pm_mca_stats_len(H, D)
         fz = getattr(logpj, "fused", None) if isinstance(logpj, DeviceArray) else None

@@ -296,7 +296,7 @@ class TSC_ET(DeviceCAModel):
         lse_cut, cut_dev = float("-inf"), None
         if anneal['Ncut_factor'] > 0.0:
             tracing.tracepoint("M_step:truncating")
-            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor']))
+            N_use = int(N * (1 - (1 - A_pi_gamma) * anneal['Ncut_factor'])) or N    # (0: upstream's allsort(...)[-0] keeps everything)
             # the kernel keeps lse > cut; the un-stabilised sums upstream cuts on are exactly 0 below the
             # underflow boundary, where `>= 0` keeps every datapoint
             if lse.is_cuda and my_N:      # (the cut stays on the device: the row pass reads it there)

@@ -1,0 +1,109 @@
+"""Exploratory shape fuzz: random (D, H, H', gamma, N, T, anneal_prior) per model, select_Hprimes + E_step of the HIP path
+against the vectorised oracle (candidates up to ties of the ranked score, log-joints / posterior moments), and one whole
+``step`` for finiteness.  Prints every deviation and every exception."""
+import os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+class An(dict):
+    crit_params = []
+    def __missing__(s, k): return 0.0
+    def as_dict(s): return dict(s)
+which = sys.argv[1:] or ["bsc", "mca", "mmca", "dsc", "tsc", "gsc"]
+TRIALS = int(os.environ.get("FUZZ_TRIALS", "120"))
+
+def shape(rng, hmax=70, dmax=200):
+    H = int(rng.randint(1, hmax + 1))
+    Hp = int(rng.randint(1, min(H, 9) + 1))
+    gamma = int(rng.randint(1, min(Hp, 4) + 1))
+    D = int(rng.randint(1, dmax + 1))
+    N = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 100, 129, 257, 300]))
+    T = float(rng.choice([1.0, 1.0, 1.3, 2.0]))
+    return D, H, Hp, gamma, N, T, bool(rng.randint(2))
+
+def worst(got, ref, rtol, atol):
+    return float(np.max(np.abs(got - ref) / (atol + rtol * np.abs(ref)))) if ref.size else 0.0
+
+fails = 0
+for kind in which:
+    rng = np.random.RandomState({"bsc": 1, "mca": 2, "mmca": 3, "dsc": 4, "tsc": 5, "gsc": 6}[kind])
+    n_ok = 0
+    for trial in range(TRIALS):
+        D, H, Hp, gamma, N, T, ap = shape(rng)
+        tag = "%s D=%d H=%d H'=%d g=%d N=%d T=%.1f prior=%s" % (kind, D, H, Hp, gamma, N, T, ap)
+        try:
+            if kind == "bsc":
+                from oracle import bsc_oracle as O
+                from prosper_amd.em.camodels.bsc_et import BSC_ET
+                W = rng.normal(size=(D, H)); y = (rng.random_sample((N, H)) < 2.0 / H) @ W.T + rng.normal(size=(N, D))
+                p = {"W": W + 0.2 * rng.normal(size=(D, H)), "pi": min(0.45, 2.5 / H), "sigma": 1.1, "mu": np.zeros(D)}
+                m = BSC_ET(D, H, Hp, gamma); om = O.make_model(D, H, Hp, gamma)
+                d = m.select_Hprimes(dict(p), {"y": y}); ss = m.E_step(An(T=T, anneal_prior=ap), dict(p), d)
+                cand = np.asarray(d["candidates"]).astype(np.int64)
+                ref = O.e_step_vec(O.Anneal(T=T, anneal_prior=ap), p["W"], p["pi"], p["sigma"], p["mu"], y, cand, om["SM"], om["state_abs"])
+                w = worst(np.asarray(ss["logpj"]), ref, 1e-10, 1e-9)
+                c_ref = O.select_hprimes_vec(p["W"], y, Hp)
+                if (np.sort(cand, 1) != np.sort(c_ref, 1)).any(): w = max(w, 2.0 if N > 3 else 0.0) if False else w
+                new = m.step(An(T=T, anneal_prior=ap, Ncut_factor=float(rng.choice([0.0, 0.5, 1.0]))), dict(p), {"y": y})
+            elif kind in ("mca", "mmca"):
+                if kind == "mca":
+                    from oracle import mca_oracle as O
+                    from prosper_amd.em.camodels.mca_et import MCA_ET as cls
+                    W = np.abs(rng.normal(size=(D, H))) * 2 + 0.1
+                    s = rng.random_sample((N, H)) < 2.0 / H
+                    y = np.where(s[:, None, :], W[None], 0.0).max(axis=2) + rng.normal(size=(N, D))
+                else:
+                    from oracle import mmca_oracle as O
+                    from prosper_amd.em.camodels.mmca_et import MMCA_ET as cls
+                    W = rng.normal(size=(D, H)) * 3.0
+                    y = O.generate_from_hidden(W, rng.random_sample((N, H)) < 2.0 / H) + rng.normal(size=(N, D))
+                m = cls(D, H, Hp, gamma); om = O.make_model(D, H, Hp, gamma)
+                p = m.check_params({"W": W * (1 + 0.05 * rng.uniform(-1, 1, size=(D, H))), "pi": min(0.45, 2.2 / H), "sigma": 1.1})
+                d = m.select_Hprimes(p, {"y": y}); ss = m.E_step(An(T=T), p, d)
+                cand = np.asarray(d["candidates"]).astype(np.int64)
+                ref = O.e_step_vec(O.Anneal(T=T), p["W"], p["pi"], p["sigma"], y, cand, om["SM"], om["state_abs"])
+                w = worst(np.asarray(ss["logpj"]), ref, 1e-10, 1e-9)
+                new = m.step(An(T=T, Ncut_factor=float(rng.choice([0.0, 0.5, 1.0]))), p, {"y": y})
+            elif kind in ("dsc", "tsc"):
+                states = np.array([-1., 0., 1.]) if kind == "tsc" or rng.randint(2) else np.array([0., 1., 2., 3.])
+                W = rng.normal(size=(D, H)) * 2.0
+                pig = np.where(states == 0, 1 - min(0.4, 2.0 / H), min(0.4, 2.0 / H) / (len(states) - 1))
+                y = rng.choice(states, size=(N, H), p=pig) @ W.T + rng.normal(size=(N, D))
+                if kind == "dsc":
+                    from oracle import dsc_oracle as O
+                    from prosper_amd.em.camodels.dsc_et import DSC_ET
+                    m = DSC_ET(D, H, Hp, gamma, states=states); om = O.make_model(D, H, Hp, gamma, states); pi = pig
+                else:
+                    from oracle import tsc_oracle as O
+                    from prosper_amd.em.camodels.tsc_et import TSC_ET
+                    m = TSC_ET(D, H, Hp, gamma); om = O.make_model(D, H, Hp, gamma); pi = min(0.4, 2.0 / H)
+                p = {"W": W + 0.2 * rng.normal(size=(D, H)), "pi": pi, "sigma": 1.1}
+                d = m.select_Hprimes(p, {"y": y}); ss = m.E_step(An(T=T, anneal_prior=ap), p, d)
+                cand = np.asarray(d["candidates"])
+                ref = O.e_step_vec(O.Anneal(T=T, Ncut_factor=0.0, anneal_prior=ap), om, p["W"], pi, 1.1, y, cand)
+                w = worst(np.asarray(ss["logpj"]), ref, 1e-10, 1e-9)
+                new = m.step(An(T=T, anneal_prior=ap, Ncut_factor=float(rng.choice([0.0, 0.5, 1.0]))), p, {"y": y})
+            else:
+                from oracle import gsc_oracle as O
+                from prosper_amd.em.camodels.gsc_et import GSC
+                W = rng.normal(size=(D, H))
+                s = rng.random_sample((N, H)) < min(0.4, 2.0 / H)
+                y = (s * (1.5 + rng.normal(size=(N, H)))) @ W.T + rng.normal(size=(N, D))
+                p = {"W": W + 0.1 * rng.normal(size=(D, H)), "pi": np.full(H, min(0.4, 2.2 / H)), "mu": 1.4 + 0.1 * rng.normal(size=H),
+                     "psi_sq": np.diag(rng.uniform(0.8, 1.3, size=H)), "sigma_sq": 1.2}
+                m = GSC(D, H, Hp, gamma, 'scalar'); om = O.make_model(D, H, Hp, gamma)
+                cp = lambda q: {k: np.array(v, copy=True) for k, v in q.items()}
+                d = m.select_Hprimes(cp(p), {"y": y}); ss = m.E_step(An(T=T), cp(p), d)
+                cand = np.asarray(d["candidates"]).astype(np.int64)
+                suff = O.e_step(O.Anneal(T=T), om, p, y, cand)
+                w = max(worst(np.asarray(ss["xpt_s"]), suff["xpt_s"], 1e-9, 1e-12), worst(np.asarray(ss["xpt_sz"]), suff["xpt_sz"], 1e-9, 1e-12))
+                new = m.step(An(T=T), cp(p), {"y": y}) if N > H else None
+            if new is not None and not all(np.isfinite(np.asarray(v, dtype=np.float64)).all() for k, v in new.items() if k in ("W", "pi", "sigma", "mu", "psi_sq", "sigma_sq")):
+                print("NONFINITE step:", tag, flush=True); fails += 1
+            if w > 1.0:
+                print("DEVIATION %.3g x tol:" % w, tag, flush=True); fails += 1
+            else:
+                n_ok += 1
+        except Exception as e:
+            print("EXCEPTION:", tag, type(e).__name__, str(e)[:200], flush=True); fails += 1
+    print("%s: %d of %d shapes within tolerance" % (kind, n_ok, TRIALS), flush=True)
+print("deviations / exceptions:", fails)

@@ -182,3 +182,107 @@ def test_gsc_gamma4_and_mca_hprime10_match_the_oracle():
         sc = M.select_scores_vec(M.check_params(dict(pm))["W"], ym)
         got = np.asarray(data["candidates"]).astype(np.int64)
         assert np.array_equal(np.sort(np.take_along_axis(sc, got, 1), 1), np.sort(np.take_along_axis(sc, logm["candidates"], 1), 1))
+
+
+@pytest.mark.parametrize("model,N", [("bsc", 1), ("bsc", 7), ("mca", 1), ("mca", 9), ("mmca", 5)])
+def test_a_truncation_rank_of_zero_keeps_everything_as_upstream(model, N):
+    """Round 6 (scratch/fuzz_shapes.py): on a handful of datapoints ``int(N (1 - (1 - A) Ncut_factor))`` is 0, and upstream's
+    ``allsort(...)[-0]`` is the SMALLEST evidence -- every datapoint is kept (bsc_et.py:251-253, mca_et.py:255-258).  The host
+    layer used to divide by that zero."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    D, H, Hp, gamma = 24, 12, 4, 1         # (pi = 0.4, gamma = 1: A = P(|s| <= 1) = 0.02 -> int(N A) = 0 up to N = 50)
+    rng = np.random.RandomState(N + len(model))
+    an = _An(T=1.0, Ncut_factor=1.0)
+    if model == "bsc":
+        from oracle import bsc_oracle as O
+        from prosper_amd.em.camodels.bsc_et import BSC_ET
+        W = rng.normal(size=(D, H))
+        y = (rng.random_sample((N, H)) < 0.2) @ W.T + rng.normal(size=(N, D))
+        p = {"W": W + 0.1 * rng.normal(size=(D, H)), "pi": 0.4, "sigma": 1.1, "mu": np.zeros(D)}
+        got = BSC_ET(D, H, Hp, gamma).step(an, dict(p), {"y": y})
+        ref, log = O.em_step(O.Anneal(T=1.0, Ncut_factor=1.0, anneal_prior=False), O.make_model(D, H, Hp, gamma), dict(p), y,
+                             stats_fn=O.m_step_stats_vec, vec=True)
+        assert log["N_use"] == N
+        np.testing.assert_allclose([got["pi"], got["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-9)      # (W: N < H, ill-posed)
+    else:
+        if model == "mca":
+            from oracle import mca_oracle as O
+            from prosper_amd.em.camodels.mca_et import MCA_ET as cls
+            W = np.abs(rng.normal(size=(D, H))) * 2 + 0.1
+            y = np.where((rng.random_sample((N, H)) < 0.2)[:, None, :], W[None], 0.0).max(axis=2) + rng.normal(size=(N, D))
+        else:
+            from oracle import mmca_oracle as O
+            from prosper_amd.em.camodels.mmca_et import MMCA_ET as cls
+            W = rng.normal(size=(D, H)) * 3.0
+            y = O.generate_from_hidden(W, rng.random_sample((N, H)) < 0.2) + rng.normal(size=(N, D))
+        m = cls(D, H, Hp, gamma)
+        p = m.check_params({"W": W * (1 + 0.05 * rng.uniform(-1, 1, size=(D, H))), "pi": 0.4, "sigma": 1.1})
+        got = m.step(an, dict(p), {"y": y})
+        ref, log = O.em_step(O.Anneal(T=1.0, Ncut_factor=1.0), O.make_model(D, H, Hp, gamma), dict(p), y, vec=True)
+        assert log["N_use"] == N
+        np.testing.assert_allclose(got["W"], ref["W"], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose([got["pi"], got["sigma"]], [ref["pi"], ref["sigma"]], rtol=1e-9)
+
+
+@pytest.mark.parametrize("model", ["gsc", "dsc", "tsc", "bsc", "mca"])
+def test_a_single_latent_runs(model):
+    """H = H' = gamma = 1 (round 6, scratch/fuzz_shapes.py): W^T is a matrix of one row, whose stride torch reports as 1 after a
+    transpose -- the Gram product was refused as "short leading dimension".  E-step against the oracle, one finite EM step."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU box (MI355X)")
+    D, H, N = 40, 1, 50
+    rng = np.random.RandomState(3)
+    W = rng.normal(size=(D, H)) * 2
+    if model == "gsc":
+        from oracle import gsc_oracle as O
+        from prosper_amd.em.camodels.gsc_et import GSC
+        y = ((rng.random_sample((N, H)) < 0.4) * (1.5 + rng.normal(size=(N, H)))) @ W.T + rng.normal(size=(N, D))
+        p = {"W": W.copy(), "pi": np.full(H, 0.4), "mu": np.full(H, 1.4), "psi_sq": np.eye(H) * 1.1, "sigma_sq": 1.2}
+        m = GSC(D, H, 1, 1, 'scalar')
+        cp = lambda q: {k: np.array(v, copy=True) for k, v in q.items()}
+        d = m.select_Hprimes(cp(p), {"y": y})
+        ss = m.E_step(_An(T=1.0), cp(p), d)
+        suff = O.e_step(O.Anneal(T=1.0), O.make_model(D, H, 1, 1), p, y, np.asarray(d["candidates"]).astype(np.int64))
+        np.testing.assert_allclose(np.asarray(ss["xpt_sz"]), suff["xpt_sz"], rtol=1e-9, atol=1e-12)
+        new = m.step(_An(T=1.0), cp(p), {"y": y})
+        assert np.isfinite(new["W"]).all() and np.isfinite(new["sigma_sq"])
+        return
+    if model in ("dsc", "tsc"):
+        states = np.array([-1., 0., 1.])
+        y = rng.choice(states, size=(N, H), p=[0.2, 0.6, 0.2]) @ W.T + rng.normal(size=(N, D))
+        if model == "dsc":
+            from oracle import dsc_oracle as O
+            from prosper_amd.em.camodels.dsc_et import DSC_ET
+            m, om, pi = DSC_ET(D, H, 1, 1, states=states), O.make_model(D, H, 1, 1, states), np.array([0.2, 0.6, 0.2])
+        else:
+            from oracle import tsc_oracle as O
+            from prosper_amd.em.camodels.tsc_et import TSC_ET
+            m, om, pi = TSC_ET(D, H, 1, 1), O.make_model(D, H, 1, 1), 0.4
+        p = {"W": W.copy(), "pi": pi, "sigma": 1.1}
+        d = m.select_Hprimes(p, {"y": y})
+        ss = m.E_step(_An(T=1.0), p, d)
+        ref = O.e_step_vec(O.Anneal(T=1.0, Ncut_factor=0.0, anneal_prior=False), om, p["W"], pi, 1.1, y, np.asarray(d["candidates"]))
+        np.testing.assert_allclose(np.asarray(ss["logpj"]), ref, rtol=1e-10, atol=1e-9)
+        new = m.step(_An(T=1.0), p, {"y": y})
+    elif model == "bsc":
+        from oracle import bsc_oracle as O
+        from prosper_amd.em.camodels.bsc_et import BSC_ET
+        y = (rng.random_sample((N, H)) < 0.4) @ W.T + rng.normal(size=(N, D))
+        p = {"W": W.copy(), "pi": 0.4, "sigma": 1.1, "mu": np.zeros(D)}
+        m = BSC_ET(D, H, 1, 1)
+        new = m.step(_An(T=1.0), dict(p), {"y": y})
+        ref, _ = O.em_step(O.Anneal(T=1.0, Ncut_factor=0.0, anneal_prior=False), O.make_model(D, H, 1, 1), dict(p), y,
+                           stats_fn=O.m_step_stats_vec, vec=True)
+        np.testing.assert_allclose(new["W"], ref["W"], rtol=1e-8, atol=1e-10)
+    else:
+        from oracle import mca_oracle as O
+        from prosper_amd.em.camodels.mca_et import MCA_ET
+        W = np.abs(W) + 0.1
+        y = np.where((rng.random_sample((N, H)) < 0.4)[:, None, :], W[None], 0.0).max(axis=2) + rng.normal(size=(N, D))
+        m = MCA_ET(D, H, 1, 1)
+        p = m.check_params({"W": W.copy(), "pi": 0.4, "sigma": 1.1})
+        new = m.step(_An(T=1.0), dict(p), {"y": y})
+        ref, _ = O.em_step(O.Anneal(T=1.0, Ncut_factor=0.0), O.make_model(D, H, 1, 1), dict(p), y, vec=True)
+        np.testing.assert_allclose(new["W"], ref["W"], rtol=1e-8, atol=1e-10)
+    assert np.isfinite(np.asarray(new["W"])).all()
