@@ -648,6 +648,43 @@ def schedule_trajectory(name, kind, D, H, Hp, gamma, N, seed, steps=50):
         out["N_use"][-1]))
 
 
+def noise_trajectory(kind, D, H, Hp, gamma, N, seed, steps=12):
+    """EM.run with parameter noise and partial data (noisify_params em/__init__.py:63-107, select_partial_data
+    camodels/__init__.py:124-152): both draw from NumPy's global stream, seeded here -- a drop-in that consumes the stream in the
+    same order reproduces the trajectory."""
+    from schedule_inputs import schedule_inputs
+    y, p0 = schedule_inputs(kind, D, H, N, seed)
+    if kind == "gsc":
+        model = GSC(D, H, Hp, gamma, sigma_sq_type="scalar")
+    else:
+        model = {"bsc": BSC_ET, "mca": MCA_ET}[kind](D, H, Hp, gamma)
+    anneal = LinearAnnealing(steps)
+    anneal["T"] = [(0, 1.6), (.7, 1.)]
+    anneal["Ncut_factor"] = [(0, 0.), (2. / 3, 1.)]
+    anneal["anneal_prior"] = False
+    anneal["partial"] = [(0, .6), (.5, 1.)]
+    anneal["W_noise"] = [(0, .08), (.6, 0.)]
+    anneal["pi_noise"] = [(0, .002), (.6, 0.)]
+    anneal["sigma_noise" if kind != "gsc" else "sigma_sq_noise"] = [(0, .03), (.6, 0.)]
+    Capture.rows.clear()
+    np.random.seed(1000 + seed)
+    data = {"y": y.copy()}
+    lparams = {k: np.array(v, copy=True) for k, v in p0.items()}
+    hist = {k: [] for k in p0}
+    while not anneal.finished:
+        new = model.step(anneal, lparams, data)
+        anneal.next(model.gain(lparams, new))
+        lparams = new
+        for k in hist:
+            hist[k].append(np.array(new[k], copy=True))
+    out = {"kind": kind, "D": D, "H": H, "Hprime": Hp, "gamma": gamma, "N": N, "seed": seed, "steps": steps,
+           "N_use": np.array(Capture.rows.get("N_use", [])), "L": np.array(Capture.rows.get("L", []))}
+    for k, v in hist.items():
+        out[k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, "noise_traj_%s.npz" % kind), **out)
+    print("noise_traj_%s: %d steps, N_use %s" % (kind, steps, out["N_use"][:6]))
+
+
 def main(only=None, cases=None):
     """``only``: regenerate just the fixtures whose maker's name starts with this prefix (e.g. ``mmca``);
     ``cases``: of those, just the named step cases (e.g. ``c2_plain,c2_cut``)."""
@@ -655,7 +692,7 @@ def main(only=None, cases=None):
     g = globals()
     for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
                "mca_inference_case", "mmca_inference_case", "gsc_inference_case", "gsc_posterior_hprime_case", "bsc_trajectory",
-               "bsc_init", "anneal_tracks", "schedule_trajectory", "inference_big_case"):
+               "bsc_init", "anneal_tracks", "schedule_trajectory", "inference_big_case", "noise_trajectory"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
     if cases:
@@ -725,6 +762,9 @@ def main(only=None, cases=None):
     schedule_trajectory("mmca", "mmca", 256, 128, 8, 3, 200, seed=204)
     schedule_trajectory("dsc", "dsc", 128, 64, 6, 3, 800, seed=205)
     schedule_trajectory("tsc", "tsc", 128, 64, 6, 3, 800, seed=206)
+    noise_trajectory("bsc", 40, 16, 5, 3, 600, seed=401)
+    noise_trajectory("mca", 40, 16, 5, 3, 500, seed=402)
+    noise_trajectory("gsc", 30, 12, 4, 3, 400, seed=403)
     bsc_init()
     anneal_tracks()
     mmca_step_case("small", 16, 8, 4, 3, 300, seed=51, T=1.0, Ncut=0.0)
