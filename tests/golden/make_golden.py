@@ -656,8 +656,13 @@ def noise_trajectory(kind, D, H, Hp, gamma, N, seed, steps=12):
     y, p0 = schedule_inputs(kind, D, H, N, seed)
     if kind == "gsc":
         model = GSC(D, H, Hp, gamma, sigma_sq_type="scalar")
+    elif kind == "dsc":
+        from schedule_inputs import DSC_STATES
+        model = DSC_ET(D, H, Hp, gamma, states=DSC_STATES.copy())
+    elif kind == "tsc":
+        model = _make_tsc(D, H, Hp, gamma)
     else:
-        model = {"bsc": BSC_ET, "mca": MCA_ET}[kind](D, H, Hp, gamma)
+        model = {"bsc": BSC_ET, "mca": MCA_ET, "mmca": MMCA_ET}[kind](D, H, Hp, gamma)
     anneal = LinearAnnealing(steps)
     anneal["T"] = [(0, 1.6), (.7, 1.)]
     anneal["Ncut_factor"] = [(0, 0.), (2. / 3, 1.)]
@@ -697,7 +702,7 @@ def main(only=None, cases=None):
             g[_n] = (lambda *a, **k: None)
     if cases:
         for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "tsc_step_case",
-                   "schedule_trajectory"):
+                   "schedule_trajectory", "noise_trajectory"):
             g[_n] = (lambda fn: (lambda name, *a, **k: fn(name, *a, **k) if name in cases else None))(g[_n])
     # BASELINE config-1 dims (D=25 H=10 H'=5 gamma=3)
     bsc_step_case("c1_plain", 25, 10, 5, 3, 400, seed=1, T=1.0, Ncut=0.0, anneal_prior=False, bars=True)
@@ -765,6 +770,9 @@ def main(only=None, cases=None):
     noise_trajectory("bsc", 40, 16, 5, 3, 600, seed=401)
     noise_trajectory("mca", 40, 16, 5, 3, 500, seed=402)
     noise_trajectory("gsc", 30, 12, 4, 3, 400, seed=403)
+    noise_trajectory("mmca", 40, 16, 5, 3, 500, seed=404)
+    noise_trajectory("dsc", 40, 16, 5, 3, 600, seed=405)
+    noise_trajectory("tsc", 40, 16, 5, 3, 600, seed=406)
     bsc_init()
     anneal_tracks()
     mmca_step_case("small", 16, 8, 4, 3, 300, seed=51, T=1.0, Ncut=0.0)

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 
-@pytest.mark.parametrize("kind", ["bsc", "mca", "gsc"])
+@pytest.mark.parametrize("kind", ["bsc", "mca", "gsc", "mmca", "dsc", "tsc"])
 def test_noise_and_partial_data_follow_the_reference_stream(kind):
     if not torch.cuda.is_available():
         pytest.skip("needs the GPU box (MI355X)")
@@ -31,6 +31,16 @@ def test_noise_and_partial_data_follow_the_reference_stream(kind):
     elif kind == "mca":
         from prosper_amd.em.camodels.mca_et import MCA_ET
         m = MCA_ET(D, H, Hp, gamma)
+    elif kind == "mmca":
+        from prosper_amd.em.camodels.mmca_et import MMCA_ET
+        m = MMCA_ET(D, H, Hp, gamma)
+    elif kind == "dsc":
+        from schedule_inputs import DSC_STATES
+        from prosper_amd.em.camodels.dsc_et import DSC_ET
+        m = DSC_ET(D, H, Hp, gamma, states=DSC_STATES.copy())
+    elif kind == "tsc":
+        from prosper_amd.em.camodels.tsc_et import TSC_ET
+        m = TSC_ET(D, H, Hp, gamma)
     else:
         from prosper_amd.em.camodels.gsc_et import GSC
         m = GSC(D, H, Hp, gamma, sigma_sq_type="scalar")
@@ -56,7 +66,7 @@ def test_noise_and_partial_data_follow_the_reference_stream(kind):
         dlog.remove_handler(h)
     if len(g["N_use"]):
         assert np.array_equal(np.array(h.tables["N_use"]).astype(np.int64), g["N_use"].astype(np.int64))
-    tol = {"bsc": 1e-9, "mca": 1e-7, "gsc": 1e-7}[kind]
+    tol = {"bsc": 1e-9, "mca": 1e-7, "gsc": 1e-7, "mmca": 1e-7, "dsc": 1e-9, "tsc": 1e-9}[kind]
     for k in hist:
         ref = g[k]
         got = np.stack(hist[k])
