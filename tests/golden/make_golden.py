@@ -690,6 +690,26 @@ def noise_trajectory(kind, D, H, Hp, gamma, N, seed, steps=12):
     print("noise_traj_%s: %d steps, N_use %s" % (kind, steps, out["N_use"][:6]))
 
 
+def standard_init_cases():
+    """``standard_init`` of every model (camodels/__init__.py:196-235; gsc_et.py:59-114, dsc_et.py's own) from a seeded NumPy
+    stream, inputs from schedule_inputs.py: a drop-in that draws in the same order returns the same parameters."""
+    from schedule_inputs import schedule_inputs, DSC_STATES
+    out = {}
+    for tag, kind, mk in (("mca", "mca", lambda: MCA_ET(40, 16, 5, 3)), ("mmca", "mmca", lambda: MMCA_ET(40, 16, 5, 3)),
+                          ("dsc", "dsc", lambda: DSC_ET(40, 16, 5, 3, states=DSC_STATES.copy())),
+                          ("tsc", "tsc", lambda: _make_tsc(40, 16, 5, 3)),
+                          ("gsc_scalar", "gsc", lambda: GSC(40, 16, 5, 3, sigma_sq_type="scalar")),
+                          ("gsc_diagonal", "gsc", lambda: GSC(40, 16, 5, 3, sigma_sq_type="diagonal")),
+                          ("gsc_full", "gsc", lambda: GSC(40, 16, 5, 3, sigma_sq_type="full"))):
+        y, _ = schedule_inputs(kind, 40, 16, 300, 500)
+        np.random.seed(77)
+        init = mk().standard_init({"y": y.copy()})
+        for k, v in init.items():
+            out["%s_%s" % (tag, k)] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "standard_init_all.npz"), **out)
+    print("standard_init_all:", sorted(out))
+
+
 def main(only=None, cases=None):
     """``only``: regenerate just the fixtures whose maker's name starts with this prefix (e.g. ``mmca``);
     ``cases``: of those, just the named step cases (e.g. ``c2_plain,c2_cut``)."""
@@ -697,7 +717,7 @@ def main(only=None, cases=None):
     g = globals()
     for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
                "mca_inference_case", "mmca_inference_case", "gsc_inference_case", "gsc_posterior_hprime_case", "bsc_trajectory",
-               "bsc_init", "anneal_tracks", "schedule_trajectory", "inference_big_case", "noise_trajectory"):
+               "bsc_init", "anneal_tracks", "schedule_trajectory", "inference_big_case", "noise_trajectory", "standard_init_cases"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
     if cases:
@@ -773,6 +793,7 @@ def main(only=None, cases=None):
     noise_trajectory("mmca", 40, 16, 5, 3, 500, seed=404)
     noise_trajectory("dsc", 40, 16, 5, 3, 600, seed=405)
     noise_trajectory("tsc", 40, 16, 5, 3, 600, seed=406)
+    standard_init_cases()
     bsc_init()
     anneal_tracks()
     mmca_step_case("small", 16, 8, 4, 3, 300, seed=51, T=1.0, Ncut=0.0)
