@@ -710,6 +710,23 @@ def standard_init_cases():
     print("standard_init_all:", sorted(out))
 
 
+def generate_data_cases():
+    """``generate_data`` of every model from a seeded NumPy stream (the reference draws latents and noise per datapoint)."""
+    from schedule_inputs import schedule_inputs, DSC_STATES
+    out = {}
+    for tag, kind, mk in (("bsc", "bsc", lambda: BSC_ET(24, 10, 4, 3)), ("mca", "mca", lambda: MCA_ET(24, 10, 4, 3)),
+                          ("mmca", "mmca", lambda: MMCA_ET(24, 10, 4, 3)),
+                          ("dsc", "dsc", lambda: DSC_ET(24, 10, 4, 3, states=DSC_STATES.copy())),
+                          ("gsc", "gsc", lambda: GSC(24, 10, 4, 3, sigma_sq_type="scalar"))):
+        _, p0 = schedule_inputs(kind, 24, 10, 8, 600)
+        np.random.seed(91)
+        data = mk().generate_data({k: np.array(v, copy=True) for k, v in p0.items()}, 40)
+        for k, v in data.items():
+            out["%s_%s" % (tag, k)] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "generate_data_all.npz"), **out)
+    print("generate_data_all:", sorted(out))
+
+
 def main(only=None, cases=None):
     """``only``: regenerate just the fixtures whose maker's name starts with this prefix (e.g. ``mmca``);
     ``cases``: of those, just the named step cases (e.g. ``c2_plain,c2_cut``)."""
@@ -717,7 +734,7 @@ def main(only=None, cases=None):
     g = globals()
     for _n in ("bsc_step_case", "gsc_step_case", "mca_step_case", "mmca_step_case", "dsc_step_case", "dsc_inference_case", "tsc_step_case", "tsc_inference_case", "bsc_inference_case",
                "mca_inference_case", "mmca_inference_case", "gsc_inference_case", "gsc_posterior_hprime_case", "bsc_trajectory",
-               "bsc_init", "anneal_tracks", "schedule_trajectory", "inference_big_case", "noise_trajectory", "standard_init_cases"):
+               "bsc_init", "anneal_tracks", "schedule_trajectory", "inference_big_case", "noise_trajectory", "standard_init_cases", "generate_data_cases"):
         if not want(g[_n]):
             g[_n] = (lambda *a, **k: None)
     if cases:
@@ -794,6 +811,7 @@ def main(only=None, cases=None):
     noise_trajectory("dsc", 40, 16, 5, 3, 600, seed=405)
     noise_trajectory("tsc", 40, 16, 5, 3, 600, seed=406)
     standard_init_cases()
+    generate_data_cases()
     bsc_init()
     anneal_tracks()
     mmca_step_case("small", 16, 8, 4, 3, 300, seed=51, T=1.0, Ncut=0.0)
