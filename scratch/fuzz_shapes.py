@@ -9,6 +9,13 @@ class An(dict):
     def __missing__(s, k): return 0.0
     def as_dict(s): return dict(s)
 which = sys.argv[1:] or ["bsc", "mca", "mmca", "dsc", "tsc", "gsc"]
+if os.environ.get("FUZZ_DET") == "1":          # every model in deterministic mode (libprosper_hip_det.so)
+    from prosper_amd.em.camodels import _device
+    _orig_init = _device.DeviceCAModel.__init__
+    def _init(self, *a, **k):
+        _orig_init(self, *a, **k)
+        self.deterministic = True
+    _device.DeviceCAModel.__init__ = _init
 TRIALS = int(os.environ.get("FUZZ_TRIALS", "120"))
 SEED = int(os.environ.get("FUZZ_SEED", "0"))
 HMAX, DMAX = int(os.environ.get("FUZZ_HMAX", "70")), int(os.environ.get("FUZZ_DMAX", "200"))

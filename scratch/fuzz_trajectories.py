@@ -9,6 +9,13 @@ class _OA(dict):
 def sched(steps):
     an = LinearAnnealing(steps); an["T"] = [(0, 1.6), (.7, 1.)]; an["Ncut_factor"] = [(0, 0.), (2. / 3, 1.)]; an["anneal_prior"] = False
     return an
+if os.environ.get("FUZZ_DET") == "1":          # every model in deterministic mode (libprosper_hip_det.so)
+    from prosper_amd.em.camodels import _device
+    _orig_init = _device.DeviceCAModel.__init__
+    def _init(self, *a, **k):
+        _orig_init(self, *a, **k)
+        self.deterministic = True
+    _device.DeviceCAModel.__init__ = _init
 rng = np.random.RandomState(21)
 fails = 0
 STEPS = 6
