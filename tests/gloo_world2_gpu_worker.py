@@ -205,6 +205,32 @@ def main():
         for step, (a, b) in enumerate(zip(*runs)):
             for k in ("W", "pi", "sigma"):
                 assert np.array_equal(a[k], b[k]), "deterministic mode, rank %d: step %d %s differs between two runs" % (rank, step, k)
+        # ---- ... and GSC (round 6: the mode keeps the speculative list pass -- quanta derived on the device, dense rows sorted):
+        # a sharded 6-step loop at config-4 dimensions twice, bit for bit the same parameters in both runs, on both ranks
+        D, H, Hp, gamma, N = 256, 128, 6, 3, 9001
+        rng = np.random.RandomState(33)
+        gt = {"W": rng.normal(size=(D, H)), "pi": np.full(H, 2.0 / H), "mu": np.full(H, 1.5), "psi_sq": np.eye(H), "sigma_sq": 1.0}
+        yg, _, _ = GO.generate_gsc_data(gt, N, rng)
+        pg0 = {"W": gt["W"] + 0.1 * rng.normal(size=(D, H)), "pi": gt["pi"] * 1.1, "mu": gt["mu"] + 0.1 * rng.normal(size=H),
+               "psi_sq": np.diag(rng.uniform(0.7, 1.4, size=H)), "sigma_sq": 1.2}
+        lo, hi = parallel.stride_data(N, comm=comm)
+        runs, hits = [], []
+        for rep in range(2):
+            mg = GSC(D, H, Hp, gamma, "scalar", comm=comm)
+            mg.deterministic = True
+            p, traj = {k: np.array(v, copy=True) for k, v in pg0.items()}, []
+            shard = {"y": yg[lo:hi].copy()}
+            for step in range(6):
+                p = mg.step(An(T=1.2 if step < 2 else 1.0), p, shard)
+                same_on_all_ranks(p, "deterministic GSC run %d step %d" % (rep, step), keys=("W", "pi", "mu", "psi_sq", "sigma_sq"))
+                traj.append({k: np.array(p[k], copy=True) for k in ("W", "pi", "mu", "psi_sq", "sigma_sq")})
+            runs.append(traj)
+            hits.append(mg.spec_hits)
+            del mg
+        assert hits[0] == hits[1] and hits[0] >= 2, hits
+        for step, (a, b) in enumerate(zip(*runs)):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), "deterministic GSC, rank %d: step %d %s differs between two runs" % (rank, step, k)
         comm.Barrier()
         print("ok %d" % rank)
     finally:
