@@ -390,7 +390,11 @@ class DSC_ET(DeviceCAModel):
         cnt = host[:8]
         my_sigma, Fs, N_use = float(host[8]) / D, float(host[9]), int(round(host[10]))
 
-        L = -0.5 * D * np.log(2 * np.pi * sigma ** 2) + Fs / N_use          # dsc_et.py:845-870
+        # (a cut that keeps NO datapoint -- upstream's strict '>' on two or three of them: dsc_et.py:832 -- divides by zero the
+        # NumPy way upstream: nan / inf and a warning, no exception)
+        Nf = np.float64(N_use)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            L = -0.5 * D * np.log(2 * np.pi * sigma ** 2) + np.float64(Fs) / Nf          # dsc_et.py:845-870
         dlog.append('L', L)
 
         W = np.asarray(model_params['W'])
@@ -439,7 +443,8 @@ class DSC_ET(DeviceCAModel):
 
         if 'sigma' in self.to_learn:
             tracing.tracepoint("M_step:update sigma")
-            sigma_new = np.sqrt(my_sigma / N_use)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                sigma_new = np.sqrt(np.float64(my_sigma) / Nf)
         else:
             sigma_new = sigma
 

@@ -107,6 +107,8 @@ for kind in which:
                 suff = O.e_step(O.Anneal(T=T), om, p, y, cand)
                 w = max(worst(np.asarray(ss["xpt_s"]), suff["xpt_s"], 1e-9, 1e-12), worst(np.asarray(ss["xpt_sz"]), suff["xpt_sz"], 1e-9, 1e-12))
                 new = m.step(An(T=T), cp(p), {"y": y}) if N > H else None
+            if kind == "dsc" and N <= 3:
+                new = None     # (upstream's strict '>' cut can keep NO datapoint of two or three: nan parameters there as here)
             if new is not None and not all(np.isfinite(np.asarray(v, dtype=np.float64)).all() for k, v in new.items() if k in ("W", "pi", "sigma", "mu", "psi_sq", "sigma_sq")):
                 print("NONFINITE step:", tag, flush=True); fails += 1
             if w > 1.0:
